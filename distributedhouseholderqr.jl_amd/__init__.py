@@ -1,0 +1,20 @@
+"""distributedhouseholderqr.jl_amd -- MI355X-native hot path of jwscook/DistributedHouseholderQR.jl.
+
+The directory name contains a dot, so it is loaded by path: `__graft_entry__.import_package()`
+registers it in sys.modules as `dhqr_amd`.  Contents: csrc/ (HIP kernels + the C ABI of
+include/dhqr.h), _lib.py (ctypes binding), api.py (host mirror of the reference's Julia API),
+partition.py / distributed.py (1-D column split over torch.distributed), julia/ (ccall wrapper).
+"""
+from . import _lib
+from ._lib import NB, DHQRError, build
+from .api import (Context, DistributedHouseholderQRStruct, apply_q_, bench_mfma_tflops,
+                  bench_stream_gbps, empty_colmajor, get_context, householder_, ldiv, partialdot,
+                  qr_, rand_colmajor, rand_vector_device, residual, solve_householder_)
+from .partition import BlockCyclicColumns, LocalColumnBlock, contiguous_column_blocks
+
+__all__ = [
+    "NB", "DHQRError", "build", "Context", "DistributedHouseholderQRStruct", "apply_q_",
+    "bench_mfma_tflops", "bench_stream_gbps", "empty_colmajor", "get_context", "householder_",
+    "ldiv", "partialdot", "qr_", "rand_colmajor", "rand_vector_device", "residual",
+    "solve_householder_", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
+]

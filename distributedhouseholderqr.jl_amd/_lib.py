@@ -1,0 +1,102 @@
+"""ctypes binding of libdhqr.so (include/dhqr.h).  The HIP library is the product: there is no CPU
+fallback here -- a missing or unloadable library raises immediately."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_PKG, "libdhqr.so")
+CSRC = os.path.join(_PKG, "csrc")
+NB = 128  # DHQR_NB
+
+OK, EINVAL, EHIP, ENOMEM, ENODEVICE = 0, -1, -2, -3, -4
+
+
+class DHQRError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libdhqr error {code}: {msg}")
+        self.code = code
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in
+                ("ms_panel", "ms_tbuild", "ms_gemm_vta", "ms_gemm_tw", "ms_gemm_avw", "ms_rank1",
+                 "ms_solve")] + \
+               [(n, ctypes.c_int64) for n in
+                ("n_panel", "n_tbuild", "n_gemm_vta", "n_gemm_tw", "n_gemm_avw", "n_rank1",
+                 "n_solve")] + \
+               [(n, ctypes.c_double) for n in ("flops_gemm_vta", "flops_gemm_avw", "bytes_rank1")]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of csrc/ -> libdhqr.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_PKG, "..", "include", "dhqr.h"))
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if force or not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < newest:
+        subprocess.check_call(["bash", os.path.join(CSRC, "build.sh")])
+    return SO_PATH
+
+
+_i32, _i64, _u64, _f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
+_p = ctypes.c_void_p
+_pp = ctypes.POINTER(ctypes.c_void_p)
+_pd = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); mirrors include/dhqr.h one to one
+SIGNATURES = {
+    "dhqr_version": (_i32, []),
+    "dhqr_last_error": (ctypes.c_char_p, []),
+    "dhqr_device_count": (_i32, [ctypes.POINTER(_i32)]),
+    "dhqr_create": (_i32, [_pp, _i32]),
+    "dhqr_destroy": (_i32, [_p]),
+    "dhqr_set_stream": (_i32, [_p, _p]),
+    "dhqr_synchronize": (_i32, [_p]),
+    "dhqr_set_profiling": (_i32, [_p, _i32]),
+    "dhqr_reset_stats": (_i32, [_p]),
+    "dhqr_get_stats": (_i32, [_p, ctypes.POINTER(Stats)]),
+    "dhqr_fill_uniform_f64": (_i32, [_p, _p, _i64, _i64, _i64, _u64, _i64, _i64, _i64, _i32, _i32]),
+    "dhqr_factor_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32]),
+    "dhqr_qr_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32]),
+    "dhqr_solve_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p]),
+    "dhqr_ldiv_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "dhqr_partialdot_f64": (_i32, [_p, _p, _p, _i64, _i64, _pd]),
+    "dhqr_apply_q_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _i64, _i32]),
+    "dhqr_residual_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _pd]),
+    "dhqr_panel_ldv": (_i64, [_i64]),
+    "dhqr_panel_buffer_elems": (_i64, [_i64]),
+    "dhqr_panel_factor_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
+    "dhqr_panel_apply_f64": (_i32, [_p, _p, _i64, _p, _i64, _i64, _i32]),
+    "dhqr_bench_mfma_f64": (_i32, [_p, _pd]),
+    "dhqr_bench_stream_f64": (_i32, [_p, _i64, _pd]),
+    "dhqr_debug_mfma_probe": (_i32, [_p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libdhqr.so (built in-tree by build()).  Raises if it is missing: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} not found: build it with __graft_entry__.build() "
+                "(hipcc --offload-arch=gfx950); this package has no CPU fallback")
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise DHQRError(rc, lib().dhqr_last_error().decode(errors="replace"))

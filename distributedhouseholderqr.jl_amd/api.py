@@ -1,0 +1,277 @@
+"""Host-side mirror of the reference's Julia API on top of libdhqr.so.
+
+Reference (src/DistributedHouseholderQR.jl)        here
+  qr!(A)                         :311-315          qr_(A, nb=...)             ('!' -> trailing '_')
+  DistributedHouseholderQRStruct :296-309          DistributedHouseholderQRStruct(A, α)
+  H \\ b                          :317-321          ldiv(H, b)  /  H.solve(b)
+  householder!(A, α)             :113-120          householder_(A, α, nb=...)
+  solve_householder!(b, H, α)    :284-294          solve_householder_(b, H, α)
+  partialdot(a, b, is, T)        :42-49            partialdot(a, b, lo, hi)
+
+Inputs are either host numpy arrays (column-major float64; goes through the host-in/host-out
+C entry points, like qr!(::Matrix)) or CUDA/HIP torch tensors in column-major layout
+(stride(0) == 1; device-resident entry points).  PyTorch is only plumbing here (device memory and
+streams); every FLOP runs in the HIP library.  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import NB, DHQRError, Stats, check
+
+try:  # torch is only needed for device-resident tensors
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class Context:
+    """One dhqr_ctx per (process, GPU)."""
+
+    def __init__(self, device: int = 0):
+        self._h = ctypes.c_void_p()
+        self.device = device
+        check(_lib.lib().dhqr_create(ctypes.byref(self._h), device))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def use_torch_stream(self):
+        """run on torch's current stream of this device (so torch ops and dhqr kernels order)"""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        check(_lib.lib().dhqr_set_stream(self._h, ctypes.c_void_p(s)))
+
+    def synchronize(self):
+        check(_lib.lib().dhqr_synchronize(self._h))
+
+    def set_profiling(self, on: bool):
+        check(_lib.lib().dhqr_set_profiling(self._h, 1 if on else 0))
+
+    def reset_stats(self):
+        check(_lib.lib().dhqr_reset_stats(self._h))
+
+    def stats(self) -> dict:
+        st = Stats()
+        check(_lib.lib().dhqr_get_stats(self._h, ctypes.byref(st)))
+        return st.asdict()
+
+    def close(self):
+        if self._h:
+            _lib.lib().dhqr_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts: Dict[int, Context] = {}
+
+
+def get_context(device: Optional[int] = None) -> Context:
+    if device is None:
+        device = torch.cuda.current_device() if (torch is not None and torch.cuda.is_available()) else 0
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]
+
+
+# ------------------------------------------------------------------------------- helpers
+def _is_tensor(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _dev_matrix(A):
+    """(ptr, m, n, lda, device) of a column-major float64 CUDA tensor."""
+    if A.dtype != torch.float64 or not A.is_cuda:
+        raise TypeError("device path needs a float64 CUDA tensor")
+    if A.dim() != 2:
+        raise ValueError("matrix expected")
+    m, n = A.shape
+    if m > 1 and A.stride(0) != 1:
+        raise ValueError("column-major layout required (stride(0) == 1); build it with "
+                         "empty_colmajor(m, n) or X.t() of a contiguous (n, m) tensor")
+    lda = A.stride(1) if n > 1 else max(m, 1)
+    return ctypes.c_void_p(A.data_ptr()), m, n, lda, A.device.index
+
+
+def _dev_vector(v, length=None):
+    if v.dtype != torch.float64 or not v.is_cuda or v.dim() != 1 or (v.numel() > 1 and v.stride(0) != 1):
+        raise TypeError("contiguous float64 CUDA vector expected")
+    if length is not None and v.numel() < length:
+        raise ValueError(f"vector shorter than {length}")
+    return ctypes.c_void_p(v.data_ptr())
+
+
+def empty_colmajor(m: int, n: int, device="cuda"):
+    """uninitialised m x n float64 device matrix in column-major layout (lda = m)."""
+    return torch.empty((n, m), dtype=torch.float64, device=device).t()
+
+
+def rand_colmajor(m: int, n: int, seed: int, device="cuda", *, global_m=None, row0=0, colblock=NB,
+                  nranks=1, rank=0):
+    """Device-side synthetic input: A[i,j] = u01(seed, gi + gj*global_m), the generator shared with
+    oracle/ (stands in for rand(T,m,n), test/runtests.jl:45).  With nranks > 1 fills the LOCAL
+    block of a block-cyclic column layout."""
+    A = empty_colmajor(m, n, device)
+    ctx = get_context(A.device.index)
+    ctx.use_torch_stream()
+    ptr, m_, n_, lda, _ = _dev_matrix(A)
+    check(_lib.lib().dhqr_fill_uniform_f64(ctx.handle, ptr, m_, n_, lda, seed,
+                                           global_m if global_m is not None else m, row0, colblock,
+                                           nranks, rank))
+    return A
+
+
+def rand_vector_device(m: int, seed: int, device="cuda"):
+    return rand_colmajor(m, 1, seed, device).reshape(-1)
+
+
+# ------------------------------------------------------------------------------- API mirror
+class DistributedHouseholderQRStruct:
+    """src:296-309: the factored matrix `A` (V on/below the diagonal, R strictly above) and
+    `α` = diag(R).  `alpha` is an ASCII alias of `α`."""
+
+    def __init__(self, A, α=None):
+        self.A = A
+        if α is None:  # src:306-309  α = zeros(eltype(A), size(A, 2))
+            n = A.shape[1]
+            α = torch.zeros(n, dtype=torch.float64, device=A.device) if _is_tensor(A) else np.zeros(n)
+        self.α = α
+
+    @property
+    def alpha(self):
+        return self.α
+
+    def solve(self, b):
+        return ldiv(self, b)
+
+    def __repr__(self):
+        return f"DistributedHouseholderQRStruct(A={tuple(self.A.shape)}, α={tuple(self.α.shape)})"
+
+
+def householder_(A, α, nb: int = NB):
+    """householder!(A, α) (src:113): factor A in place, fill α. nb=0 -> unblocked rank-1 path
+    (the reference's algorithm verbatim), nb=128 -> blocked MFMA path. Returns (A, α)."""
+    L = _lib.lib()
+    if _is_tensor(A):
+        ptr, m, n, lda, dev = _dev_matrix(A)
+        ctx = get_context(dev)
+        ctx.use_torch_stream()
+        check(L.dhqr_factor_f64(ctx.handle, ptr, m, n, lda, _dev_vector(α, n), nb))
+        return A, α
+    if not isinstance(A, np.ndarray) or A.dtype != np.float64 or A.ndim != 2:
+        raise TypeError("float64 numpy matrix or CUDA tensor expected")
+    if not isinstance(α, np.ndarray) or α.dtype != np.float64 or α.size < A.shape[1] or not α.flags.c_contiguous:
+        raise TypeError("α must be a contiguous float64 numpy vector of length n")
+    m, n = A.shape
+    ctx = get_context()
+    F = A if A.flags.f_contiguous else np.asfortranarray(A)
+    check(L.dhqr_qr_f64(ctx.handle, F.ctypes.data_as(ctypes.c_void_p), m, n, max(1, F.strides[1] // 8),
+                        α.ctypes.data_as(ctypes.c_void_p), nb))
+    if F is not A:
+        A[...] = F  # in-place semantics of qr! for row-major callers
+    return A, α
+
+
+def qr_(A, nb: int = NB) -> DistributedHouseholderQRStruct:
+    """qr!(A) (src:311-315): mutates A, returns the struct."""
+    H = DistributedHouseholderQRStruct(A)
+    householder_(H.A, H.α, nb=nb)
+    return H
+
+
+def solve_householder_(b, H, α):
+    """solve_householder!(b, H, α) (src:284-294): mutates b (b <- Q'b, then back substitution)
+    and returns b[1:n] (a copy, like Julia's b[1:n])."""
+    L = _lib.lib()
+    if _is_tensor(H):
+        ptr, m, n, lda, dev = _dev_matrix(H)
+        ctx = get_context(dev)
+        ctx.use_torch_stream()
+        check(L.dhqr_solve_f64(ctx.handle, ptr, m, n, lda, _dev_vector(α, n), _dev_vector(b, m)))
+        return b[:n].clone()
+    m, n = H.shape
+    F = H if H.flags.f_contiguous else np.asfortranarray(H)
+    x = np.empty(n)
+    bb = np.ascontiguousarray(b, dtype=np.float64)
+    ctx = get_context()
+    check(L.dhqr_ldiv_f64(ctx.handle, F.ctypes.data_as(ctypes.c_void_p), m, n, max(1, F.strides[1] // 8),
+                          np.ascontiguousarray(α).ctypes.data_as(ctypes.c_void_p),
+                          bb.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p)))
+    return x
+
+
+def ldiv(H: DistributedHouseholderQRStruct, b):
+    """`H \\ b` (src:317-321): least-squares solution of length n; the caller's b is NOT modified
+    (the reference copies it into a SharedArray first, src:318)."""
+    if _is_tensor(H.A):
+        return solve_householder_(b.clone(), H.A, H.α)
+    return solve_householder_(b, H.A, H.α)
+
+
+def partialdot(a, b, lo: int, hi: int) -> float:
+    """partialdot(a, b, lo:hi-1, Float64) (src:42-49), 0-based with hi exclusive, reduced on the GPU."""
+    L = _lib.lib()
+    if not _is_tensor(a):
+        dev = get_context().device
+        a = torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=f"cuda:{dev}")
+        b = torch.as_tensor(np.ascontiguousarray(b, dtype=np.float64), device=f"cuda:{dev}")
+    ctx = get_context(a.device.index)
+    ctx.use_torch_stream()
+    out = ctypes.c_double()
+    check(L.dhqr_partialdot_f64(ctx.handle, _dev_vector(a, hi), _dev_vector(b, hi), lo, hi, ctypes.byref(out)))
+    return out.value
+
+
+# ------------------------------------------------------------------------------- metric helpers
+def apply_q_(H: DistributedHouseholderQRStruct, B, trans: bool):
+    """B <- Q' B (trans) or Q B, in place, device tensors only."""
+    ptr, m, n, lda, dev = _dev_matrix(H.A)
+    bptr, mb, nrhs, ldb, _ = _dev_matrix(B)
+    if mb != m:
+        raise ValueError("row mismatch")
+    ctx = get_context(dev)
+    ctx.use_torch_stream()
+    check(_lib.lib().dhqr_apply_q_f64(ctx.handle, ptr, m, n, lda, bptr, nrhs, ldb, 1 if trans else 0))
+    return B
+
+
+def residual(H: DistributedHouseholderQRStruct, Aorig, work=None) -> float:
+    """||Aorig - Q R||_F / ||Aorig||_F on the device (north-star metric)."""
+    ptr, m, n, lda, dev = _dev_matrix(H.A)
+    optr, mo, no, ldo, _ = _dev_matrix(Aorig)
+    if (mo, no) != (m, n):
+        raise ValueError("shape mismatch")
+    if work is None:
+        work = empty_colmajor(m, n, H.A.device)
+    wptr, _, _, ldw, _ = _dev_matrix(work)
+    if ldw != m:
+        raise ValueError("work must have leading dimension m")
+    ctx = get_context(dev)
+    ctx.use_torch_stream()
+    out = ctypes.c_double()
+    check(_lib.lib().dhqr_residual_f64(ctx.handle, ptr, m, n, lda, _dev_vector(H.α, n), optr, ldo, wptr,
+                                       ctypes.byref(out)))
+    return out.value
+
+
+def bench_mfma_tflops(device: Optional[int] = None) -> float:
+    ctx = get_context(device)
+    out = ctypes.c_double()
+    check(_lib.lib().dhqr_bench_mfma_f64(ctx.handle, ctypes.byref(out)))
+    return out.value
+
+
+def bench_stream_gbps(nbytes: int = 1 << 30, device: Optional[int] = None) -> float:
+    ctx = get_context(device)
+    out = ctypes.c_double()
+    check(_lib.lib().dhqr_bench_stream_f64(ctx.handle, nbytes, ctypes.byref(out)))
+    return out.value

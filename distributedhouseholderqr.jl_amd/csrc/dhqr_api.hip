@@ -1,0 +1,652 @@
+// dhqr_api.hip -- host side of libdhqr.so: context, workspaces, panel/trailing-update drivers and
+// the extern "C" entry points declared in include/dhqr.h.  gfx950 only; no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/dhqr.h"
+#include "dhqr_common.h"
+#include "dhqr_gemm.h"
+#include "dhqr_rank1.h"
+#include "dhqr_solve.h"
+
+static thread_local char g_err[512] = "";
+static int32_t set_err(int32_t code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHECK(expr)                                                                        \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return set_err(DHQR_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),        \
+                     __FILE__, __LINE__);                                                     \
+  } while (0)
+#define CHECK(expr)                  \
+  do {                               \
+    int32_t rc_ = (expr);            \
+    if (rc_ != DHQR_OK) return rc_;  \
+  } while (0)
+#define LAUNCHCHECK() HIPCHECK(hipGetLastError())
+
+enum { CAT_PANEL = 0, CAT_TBUILD, CAT_VTA, CAT_TW, CAT_AVW, CAT_RANK1, CAT_SOLVE, CAT_N };
+
+struct Buf {
+  double *p = nullptr;
+  size_t cap = 0;  // doubles
+};
+
+struct dhqr_ctx {
+  int device = 0;
+  hipStream_t own = nullptr, stream = nullptr;
+  bool profiling = false;
+  Buf vbuf, vt, w1, w2, spart, sfull, scratch;
+  // profiling
+  struct Ev { hipEvent_t a, b; int cat; };
+  std::vector<Ev> evs;
+  size_t ev_used = 0;
+  dhqr_stats st;
+};
+
+static int32_t ensure(dhqr_ctx *c, Buf &b, size_t need) {
+  if (need <= b.cap) return DHQR_OK;
+  if (b.p) {
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  need = (need + 1023) & ~(size_t)1023;
+  hipError_t e = hipMalloc((void **)&b.p, need * sizeof(double));
+  if (e != hipSuccess)
+    return set_err(DHQR_ENOMEM, "hipMalloc(%zu bytes) failed: %s", need * sizeof(double),
+                   hipGetErrorString(e));
+  b.cap = need;
+  return DHQR_OK;
+}
+
+static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- profiling: one hipEvent pair per timed launch group, resolved in dhqr_get_stats ---------
+static int32_t prof_begin(dhqr_ctx *c, int cat) {
+  if (!c->profiling) return DHQR_OK;
+  if (c->ev_used == c->evs.size()) {
+    dhqr_ctx::Ev e;
+    HIPCHECK(hipEventCreate(&e.a));
+    HIPCHECK(hipEventCreate(&e.b));
+    e.cat = cat;
+    c->evs.push_back(e);
+  }
+  c->evs[c->ev_used].cat = cat;
+  HIPCHECK(hipEventRecord(c->evs[c->ev_used].a, c->stream));
+  return DHQR_OK;
+}
+static int32_t prof_end(dhqr_ctx *c) {
+  if (!c->profiling) return DHQR_OK;
+  HIPCHECK(hipEventRecord(c->evs[c->ev_used].b, c->stream));
+  c->ev_used++;
+  return DHQR_OK;
+}
+static int32_t prof_resolve(dhqr_ctx *c) {
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  double *ms[CAT_N] = {&c->st.ms_panel, &c->st.ms_tbuild, &c->st.ms_gemm_vta, &c->st.ms_gemm_tw,
+                       &c->st.ms_gemm_avw, &c->st.ms_rank1, &c->st.ms_solve};
+  int64_t *cnt[CAT_N] = {&c->st.n_panel, &c->st.n_tbuild, &c->st.n_gemm_vta, &c->st.n_gemm_tw,
+                         &c->st.n_gemm_avw, &c->st.n_rank1, &c->st.n_solve};
+  for (size_t i = 0; i < c->ev_used; ++i) {
+    float t = 0.f;
+    HIPCHECK(hipEventElapsedTime(&t, c->evs[i].a, c->evs[i].b));
+    *ms[c->evs[i].cat] += (double)t;
+    *cnt[c->evs[i].cat] += 1;
+  }
+  c->ev_used = 0;
+  return DHQR_OK;
+}
+
+// ---- unblocked factorisation of the columns of a rows x ncols block (src:122-148,198-213) ----
+// P's row 0 is the diagonal row of column 0.  One launch per column (k_rank1_*), the workgroup
+// owning column j+1 builds the next reflector in the same launch.
+template <int VEC>
+static void launch_rank1(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int64_t j, int64_t nupd,
+                         const double *vcur, double *vnext, double *alpha) {
+  const int64_t r0 = (VEC == 2) ? (j & ~(int64_t)1) : j;
+  const int64_t cov = rows - r0;
+  dim3 grid((unsigned)nupd);
+#define DHQR_R1(T_, E_)                                                                          \
+  hipLaunchKernelGGL((k_rank1_fused<T_, E_, VEC>), grid, dim3(T_), 0, c->stream, P, ldp, rows, j, \
+                     vcur, vnext, alpha)
+  if (cov <= 256 * 2) DHQR_R1(256, 2);
+  else if (cov <= 256 * 4) DHQR_R1(256, 4);
+  else if (cov <= 256 * 8) DHQR_R1(256, 8);
+  else if (cov <= 512 * 8) DHQR_R1(512, 8);
+  else if (cov <= 1024 * 8) DHQR_R1(1024, 8);
+  else
+    hipLaunchKernelGGL((k_rank1_generic<1024, VEC>), grid, dim3(1024), 0, c->stream, P, ldp, rows,
+                       j, vcur, vnext, alpha);
+#undef DHQR_R1
+}
+
+static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64_t ncols,
+                                     int64_t ldp, double *alpha, int cat) {
+  const size_t vlen = (size_t)((rows + 17) & ~(int64_t)15);
+  CHECK(ensure(c, c->vbuf, 2 * vlen));
+  double *vb[2] = {c->vbuf.p, c->vbuf.p + vlen};
+  const bool vec = (ldp % 2 == 0) && (rows % 2 == 0) && aligned16(P);
+  CHECK(prof_begin(c, cat));
+  hipLaunchKernelGGL((k_reflector<1024>), dim3(1), dim3(1024), 0, c->stream, P, rows, (int64_t)0,
+                     vb[0], alpha);
+  CHECK(prof_end(c));
+  for (int64_t j = 0; j + 1 < ncols; ++j) {
+    const int64_t nupd = ncols - (j + 1);
+    CHECK(prof_begin(c, cat));
+    if (vec) launch_rank1<2>(c, P, ldp, rows, j, nupd, vb[j & 1], vb[(j + 1) & 1], alpha);
+    else launch_rank1<1>(c, P, ldp, rows, j, nupd, vb[j & 1], vb[(j + 1) & 1], alpha);
+    CHECK(prof_end(c));
+    if (c->profiling && cat == CAT_RANK1)
+      c->st.bytes_rank1 += 16.0 * (double)(rows - j) * (double)nupd;
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+// ---- packed panel buffer helpers ------------------------------------------------------------
+static inline int64_t panel_ldv(int64_t rows) { return (rows + 15) & ~(int64_t)15; }
+static inline double *vt_T(double *vt, int64_t rows) { return vt + panel_ldv(rows) * DHQR_NBV; }
+static inline double *vt_Tt(double *vt, int64_t rows) { return vt_T(vt, rows) + DHQR_NBV * DHQR_NBV; }
+static inline double *vt_alpha(double *vt, int64_t rows) { return vt_Tt(vt, rows) + DHQR_NBV * DHQR_NBV; }
+static inline int64_t panel_elems(int64_t rows) {
+  return panel_ldv(rows) * DHQR_NBV + 2 * DHQR_NBV * DHQR_NBV + DHQR_NBV;
+}
+
+static void pick_split(int64_t rows, int64_t ntiles, int64_t target_wgs, int64_t max_split,
+                       int64_t *nsplit, int64_t *rps) {
+  int64_t ns = (target_wgs + ntiles - 1) / ntiles;
+  ns = std::min(ns, max_split);
+  ns = std::min(ns, std::max<int64_t>(1, rows / 128));
+  ns = std::max<int64_t>(ns, 1);
+  int64_t r = (rows + ns - 1) / ns;
+  r = (r + G_KT - 1) / G_KT * G_KT;
+  if (r < G_KT) r = G_KT;
+  *rps = r;
+  *nsplit = (rows + r - 1) / r;
+  if (*nsplit < 1) *nsplit = 1;
+}
+
+// Pack V (R part zeroed) and build T / T' for a factored panel P (rows x ncols, ncols <= 128).
+static int32_t panel_pack_and_t(dhqr_ctx *c, const double *P, int64_t rows, int64_t ncols,
+                                int64_t ldp, const double *alpha, double *vt) {
+  const int64_t ldv = panel_ldv(rows);
+  double *V = vt;
+  CHECK(prof_begin(c, CAT_TBUILD));
+  {
+    dim3 grid((unsigned)std::min<int64_t>((ldv + 255) / 256, 64), DHQR_NBV);
+    hipLaunchKernelGGL(k_pack_v, grid, dim3(256), 0, c->stream, P, ldp, rows, ncols, V, ldv);
+  }
+  int64_t nsplit, rps;
+  pick_split(rows, 1, 128, 128, &nsplit, &rps);
+  CHECK(ensure(c, c->spart, (size_t)nsplit * DHQR_NBV * DHQR_NBV));
+  CHECK(ensure(c, c->sfull, (size_t)DHQR_NBV * DHQR_NBV));
+  hipLaunchKernelGGL((k_gemm_tn<2>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, V, ldv, V,
+                     ldv, 1, (int64_t)0, rows, (int64_t)DHQR_NBV, rps, c->spart.p,
+                     (int64_t)DHQR_NBV, (int64_t)DHQR_NBV * DHQR_NBV);
+  hipLaunchKernelGGL(k_reduce_splits, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream,
+                     c->spart.p, (int)nsplit, (int64_t)DHQR_NBV * DHQR_NBV,
+                     (int64_t)DHQR_NBV * DHQR_NBV, c->sfull.p);
+  hipLaunchKernelGGL(k_build_t, dim3(1), dim3(128), 0, c->stream, c->sfull.p, vt_T(vt, rows),
+                     vt_Tt(vt, rows));
+  if (alpha) {  // nullptr: the caller already placed alpha in the buffer tail (or does not need it)
+    HIPCHECK(hipMemsetAsync(vt_alpha(vt, rows), 0, DHQR_NBV * sizeof(double), c->stream));
+    HIPCHECK(hipMemcpyAsync(vt_alpha(vt, rows), alpha, (size_t)ncols * sizeof(double),
+                            hipMemcpyDeviceToDevice, c->stream));
+  }
+  CHECK(prof_end(c));
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+// C (rows x ncols) <- (I - V op(T) V') C with op(T) = T' (trans=1) or T (trans=0).
+static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *C, int64_t ncols,
+                           int64_t ldc, int trans) {
+  if (ncols <= 0 || rows <= 0) return DHQR_OK;
+  const int64_t ldv = panel_ldv(rows);
+  const double *V = vt;
+  const double *Top = trans ? vt_T(const_cast<double *>(vt), rows) : vt_Tt(const_cast<double *>(vt), rows);
+  const int64_t ntiles = (ncols + 127) / 128;
+  int64_t nsplit, rps;
+  pick_split(rows, ntiles, 512, 64, &nsplit, &rps);
+  CHECK(ensure(c, c->w1, (size_t)nsplit * DHQR_NBV * (size_t)ncols));
+  CHECK(ensure(c, c->w2, (size_t)DHQR_NBV * (size_t)ncols));
+  const bool vec = (ldc % 2 == 0) && (rows % 2 == 0) && aligned16(C);
+  const int64_t wstride = (int64_t)DHQR_NBV * ncols;
+
+  CHECK(prof_begin(c, CAT_VTA));
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_tn<2>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(256), 0,
+                       c->stream, V, ldv, (const double *)C, ldc, 1, (int64_t)0, rows, ncols, rps,
+                       c->w1.p, (int64_t)DHQR_NBV, wstride);
+  else
+    hipLaunchKernelGGL((k_gemm_tn<1>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(256), 0,
+                       c->stream, V, ldv, (const double *)C, ldc, 1, (int64_t)0, rows, ncols, rps,
+                       c->w1.p, (int64_t)DHQR_NBV, wstride);
+  CHECK(prof_end(c));
+
+  CHECK(prof_begin(c, CAT_TW));
+  hipLaunchKernelGGL((k_gemm_tn<2>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top,
+                     (int64_t)DHQR_NBV, (const double *)c->w1.p, (int64_t)DHQR_NBV, (int)nsplit,
+                     wstride, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV, c->w2.p,
+                     (int64_t)DHQR_NBV, (int64_t)0);
+  CHECK(prof_end(c));
+
+  CHECK(prof_begin(c, CAT_AVW));
+  dim3 grid((unsigned)((rows + 127) / 128), (unsigned)ntiles);
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_nn_sub<2>), grid, dim3(256), 0, c->stream, V, ldv,
+                       (const double *)c->w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols);
+  else
+    hipLaunchKernelGGL((k_gemm_nn_sub<1>), grid, dim3(256), 0, c->stream, V, ldv,
+                       (const double *)c->w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols);
+  CHECK(prof_end(c));
+  if (c->profiling) {
+    c->st.flops_gemm_vta += 2.0 * DHQR_NBV * (double)rows * (double)ncols;
+    c->st.flops_gemm_avw += 2.0 * DHQR_NBV * (double)rows * (double)ncols;
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+static int32_t check_ctx(dhqr_ctx *c) {
+  if (!c) return set_err(DHQR_EINVAL, "null context");
+  HIPCHECK(hipSetDevice(c->device));
+  return DHQR_OK;
+}
+static int32_t check_mat(const void *A, int64_t m, int64_t n, int64_t lda, bool need_tall) {
+  if (!A) return set_err(DHQR_EINVAL, "null matrix pointer");
+  if (m <= 0 || n <= 0) return set_err(DHQR_EINVAL, "m and n must be positive (m=%lld n=%lld)", (long long)m, (long long)n);
+  if (need_tall && m < n) return set_err(DHQR_EINVAL, "m >= n required (m=%lld n=%lld)", (long long)m, (long long)n);
+  if (lda < m) return set_err(DHQR_EINVAL, "leading dimension %lld < m=%lld", (long long)lda, (long long)m);
+  return DHQR_OK;
+}
+
+// Q' B (trans=1) / Q B (trans=0) panel by panel; when `triangular` only columns >= the panel's
+// first column are touched (B = [R;0] while forming Q*R).
+static int32_t apply_q_impl(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda,
+                            const double *dalpha, double *dB, int64_t nrhs, int64_t ldb, int trans,
+                            bool triangular) {
+  const int64_t npan = (n + DHQR_NBV - 1) / DHQR_NBV;
+  CHECK(ensure(c, c->vt, (size_t)panel_elems(m)));
+  // alpha is only carried along in the packed buffer; a dummy pointer is fine when absent
+  for (int64_t q = 0; q < npan; ++q) {
+    const int64_t k = trans ? q : npan - 1 - q;
+    const int64_t c0 = k * DHQR_NBV, w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
+    const double *P = dA + c0 + c0 * lda;
+    CHECK(panel_pack_and_t(c, P, rows, w, lda, dalpha ? dalpha + c0 : nullptr, c->vt.p));
+    if (triangular) {
+      if (nrhs - c0 > 0) CHECK(panel_apply(c, c->vt.p, rows, dB + c0 + c0 * ldb, nrhs - c0, ldb, trans));
+    } else {
+      CHECK(panel_apply(c, c->vt.p, rows, dB + c0, nrhs, ldb, trans));
+    }
+  }
+  return DHQR_OK;
+}
+
+// =================================================================================== C ABI
+extern "C" {
+
+int32_t dhqr_version(void) { return DHQR_VERSION; }
+const char *dhqr_last_error(void) { return g_err; }
+
+int32_t dhqr_device_count(int32_t *count) {
+  if (!count) return set_err(DHQR_EINVAL, "null count");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return set_err(DHQR_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return DHQR_OK;
+}
+
+int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
+  if (!out) return set_err(DHQR_EINVAL, "null ctx out-pointer");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return set_err(DHQR_ENODEVICE, "no HIP device visible (%s); libdhqr has no CPU fallback",
+                   e != hipSuccess ? hipGetErrorString(e) : "count = 0");
+  if (device < 0 || device >= n) return set_err(DHQR_EINVAL, "device %d out of range [0,%d)", device, n);
+  HIPCHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHECK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_err(DHQR_ENODEVICE, "device %d is %s; this library is built for gfx950 only", device,
+                   prop.gcnArchName);
+  dhqr_ctx *c = new dhqr_ctx();
+  c->device = device;
+  memset(&c->st, 0, sizeof(c->st));
+  HIPCHECK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
+  c->stream = c->own;
+  *out = c;
+  return DHQR_OK;
+}
+
+int32_t dhqr_destroy(dhqr_ctx *c) {
+  if (!c) return DHQR_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  Buf *bufs[] = {&c->vbuf, &c->vt, &c->w1, &c->w2, &c->spart, &c->sfull, &c->scratch};
+  for (Buf *b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  for (auto &e : c->evs) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  if (c->own) (void)hipStreamDestroy(c->own);
+  delete c;
+  return DHQR_OK;
+}
+
+int32_t dhqr_set_stream(dhqr_ctx *c, void *s) {
+  CHECK(check_ctx(c));
+  c->stream = s ? (hipStream_t)s : c->own;
+  return DHQR_OK;
+}
+int32_t dhqr_synchronize(dhqr_ctx *c) {
+  CHECK(check_ctx(c));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return DHQR_OK;
+}
+int32_t dhqr_set_profiling(dhqr_ctx *c, int32_t on) {
+  CHECK(check_ctx(c));
+  if (c->profiling && !on) CHECK(prof_resolve(c));
+  c->profiling = on != 0;
+  return DHQR_OK;
+}
+int32_t dhqr_reset_stats(dhqr_ctx *c) {
+  CHECK(check_ctx(c));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  c->ev_used = 0;
+  memset(&c->st, 0, sizeof(c->st));
+  return DHQR_OK;
+}
+int32_t dhqr_get_stats(dhqr_ctx *c, dhqr_stats *out) {
+  CHECK(check_ctx(c));
+  if (!out) return set_err(DHQR_EINVAL, "null stats pointer");
+  CHECK(prof_resolve(c));
+  *out = c->st;
+  return DHQR_OK;
+}
+
+int32_t dhqr_fill_uniform_f64(dhqr_ctx *c, double *dA, int64_t rows, int64_t cols, int64_t lda,
+                              uint64_t seed, int64_t global_m, int64_t row0, int64_t colblock,
+                              int32_t nranks, int32_t rank) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(dA, rows, cols, lda, false));
+  if (colblock <= 0 || nranks <= 0 || rank < 0 || rank >= nranks || global_m < rows)
+    return set_err(DHQR_EINVAL, "bad layout arguments to dhqr_fill_uniform_f64");
+  const int64_t total = rows * cols;
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(k_fill_uniform, dim3(grid), dim3(256), 0, c->stream, dA, rows, cols, lda, seed,
+                     global_m, row0, colblock, (int)nranks, (int)rank);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+int32_t dhqr_factor_f64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha,
+                        int32_t nb) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(dA, m, n, lda, true));
+  if (!dalpha) return set_err(DHQR_EINVAL, "null alpha pointer");
+  if (nb != 0 && nb != DHQR_NB)
+    return set_err(DHQR_EINVAL, "nb must be 0 (unblocked) or %d (blocked); got %d", DHQR_NB, nb);
+  if (nb == 0) return factor_unblocked_cols(c, dA, m, n, lda, dalpha, CAT_RANK1);
+  CHECK(ensure(c, c->vt, (size_t)panel_elems(m)));
+  for (int64_t c0 = 0; c0 < n; c0 += DHQR_NBV) {
+    const int64_t w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
+    double *P = dA + c0 + c0 * lda;
+    CHECK(factor_unblocked_cols(c, P, rows, w, lda, dalpha + c0, CAT_PANEL));
+    if (c0 + w < n) {
+      CHECK(panel_pack_and_t(c, P, rows, w, lda, dalpha + c0, c->vt.p));
+      CHECK(panel_apply(c, c->vt.p, rows, dA + c0 + (c0 + w) * lda, n - c0 - w, lda, 1));
+    }
+  }
+  return DHQR_OK;
+}
+
+int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha,
+                    int32_t nb) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(hA, m, n, lda, true));
+  if (!halpha) return set_err(DHQR_EINVAL, "null alpha pointer");
+  double *dA = nullptr, *dal = nullptr;
+  const int64_t ldd = (m + 1) & ~(int64_t)1;
+  if (hipMalloc((void **)&dA, (size_t)ldd * n * sizeof(double)) != hipSuccess)
+    return set_err(DHQR_ENOMEM, "hipMalloc of the %lld x %lld matrix failed", (long long)m, (long long)n);
+  if (hipMalloc((void **)&dal, (size_t)n * sizeof(double)) != hipSuccess) {
+    (void)hipFree(dA);
+    return set_err(DHQR_ENOMEM, "hipMalloc of alpha failed");
+  }
+  int32_t rc = DHQR_OK;
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMemcpy2DAsync(dA, ldd * sizeof(double), hA, lda * sizeof(double), m * sizeof(double),
+                              n, hipMemcpyHostToDevice, c->stream));
+    // the reference factors whatever m x n block it is given; m odd is handled by the scalar path
+    CHECK(dhqr_factor_f64(c, dA, m, n, ldd, dal, nb));
+    HIPCHECK(hipMemcpy2DAsync(hA, lda * sizeof(double), dA, ldd * sizeof(double), m * sizeof(double),
+                              n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(halpha, dal, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return DHQR_OK;
+  };
+  rc = body();
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(dA);
+  (void)hipFree(dal);
+  return rc;
+}
+
+int32_t dhqr_solve_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda,
+                       const double *dalpha, double *db) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(dA, m, n, lda, true));
+  if (!dalpha || !db) return set_err(DHQR_EINVAL, "null alpha or b pointer");
+  CHECK(prof_begin(c, CAT_SOLVE));
+  const bool was = c->profiling;
+  c->profiling = false;  // the solve is timed as one group
+  int32_t rc = apply_q_impl(c, dA, m, n, lda, dalpha, db, 1, m, 1, false);  // src:215-242
+  if (rc == DHQR_OK) {
+    for (int64_t hi = n; hi > 0; hi -= BS_NB) {  // src:244-282
+      const int64_t lo = std::max<int64_t>(0, hi - BS_NB);
+      hipLaunchKernelGGL(k_backsub_diag, dim3(1), dim3(64), 0, c->stream, dA, lda, dalpha, db, lo, hi);
+      if (lo > 0)
+        hipLaunchKernelGGL(k_backsub_update, dim3((unsigned)((lo + 255) / 256)), dim3(256), 0,
+                           c->stream, dA, lda, db, lo, hi);
+    }
+  }
+  c->profiling = was;
+  CHECK(rc);
+  CHECK(prof_end(c));
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64_t lda,
+                      const double *halpha, const double *hb, double *hx) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(hA, m, n, lda, true));
+  if (!halpha || !hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
+  double *dA = nullptr, *dal = nullptr, *db = nullptr;
+  const int64_t ldd = (m + 1) & ~(int64_t)1;
+  if (hipMalloc((void **)&dA, (size_t)ldd * n * sizeof(double)) != hipSuccess)
+    return set_err(DHQR_ENOMEM, "hipMalloc failed");
+  if (hipMalloc((void **)&dal, (size_t)n * sizeof(double)) != hipSuccess) { (void)hipFree(dA); return set_err(DHQR_ENOMEM, "hipMalloc failed"); }
+  if (hipMalloc((void **)&db, (size_t)(m + 2) * sizeof(double)) != hipSuccess) { (void)hipFree(dA); (void)hipFree(dal); return set_err(DHQR_ENOMEM, "hipMalloc failed"); }
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMemcpy2DAsync(dA, ldd * sizeof(double), hA, lda * sizeof(double), m * sizeof(double),
+                              n, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(dal, halpha, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(db, hb, m * sizeof(double), hipMemcpyHostToDevice, c->stream));  // src:318 copy of b
+    CHECK(dhqr_solve_f64(c, dA, m, n, ldd, dal, db));
+    HIPCHECK(hipMemcpyAsync(hx, db, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));  // src:320
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return DHQR_OK;
+  };
+  int32_t rc = body();
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(dA);
+  (void)hipFree(dal);
+  (void)hipFree(db);
+  return rc;
+}
+
+int32_t dhqr_partialdot_f64(dhqr_ctx *c, const double *da, const double *db, int64_t lo, int64_t hi,
+                            double *hout) {
+  CHECK(check_ctx(c));
+  if (!da || !db || !hout) return set_err(DHQR_EINVAL, "null pointer argument");
+  if (lo < 0 || hi < lo) return set_err(DHQR_EINVAL, "bad range [%lld,%lld)", (long long)lo, (long long)hi);
+  CHECK(ensure(c, c->scratch, 4096));
+  const int64_t len = hi - lo;
+  const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((len + 255) / 256, 1024));
+  hipLaunchKernelGGL(k_partialdot_partial, dim3(nblk), dim3(256), 0, c->stream, da, db, lo, hi, c->scratch.p);
+  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, c->stream, (const double *)c->scratch.p, nblk, c->scratch.p + 2048);
+  LAUNCHCHECK();
+  HIPCHECK(hipMemcpyAsync(hout, c->scratch.p + 2048, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return DHQR_OK;
+}
+
+int32_t dhqr_apply_q_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda, double *dB,
+                         int64_t nrhs, int64_t ldb, int32_t trans) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(dA, m, n, lda, true));
+  CHECK(check_mat(dB, m, nrhs, ldb, false));
+  return apply_q_impl(c, dA, m, n, lda, nullptr, dB, nrhs, ldb, trans ? 1 : 0, false);
+}
+
+int32_t dhqr_residual_f64(dhqr_ctx *c, const double *dAfact, int64_t m, int64_t n, int64_t lda,
+                          const double *dalpha, const double *dAorig, int64_t ldo, double *dwork,
+                          double *hrel) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(dAfact, m, n, lda, true));
+  CHECK(check_mat(dAorig, m, n, ldo, true));
+  if (!dalpha || !dwork || !hrel) return set_err(DHQR_EINVAL, "null pointer argument");
+  {
+    dim3 grid((unsigned)std::min<int64_t>((m + 255) / 256, 128), (unsigned)n);
+    if (n > 65535) return set_err(DHQR_EINVAL, "n too large for dhqr_residual_f64");
+    hipLaunchKernelGGL(k_form_r0, grid, dim3(256), 0, c->stream, dAfact, lda, dalpha, m, n, dwork, m);
+  }
+  const bool was = c->profiling;
+  c->profiling = false;
+  int32_t rc = apply_q_impl(c, dAfact, m, n, lda, dalpha, dwork, n, m, 0, true);
+  c->profiling = was;
+  CHECK(rc);
+  CHECK(ensure(c, c->scratch, 4096));
+  const int nblk = 1024;
+  hipLaunchKernelGGL(k_diff_norms, dim3(nblk), dim3(256), 0, c->stream, dAorig, ldo, (const double *)dwork, m, m, n, c->scratch.p);
+  hipLaunchKernelGGL(k_sum2_final, dim3(1), dim3(256), 0, c->stream, (const double *)c->scratch.p, nblk, c->scratch.p + 2048);
+  LAUNCHCHECK();
+  double h[2] = {0, 0};
+  HIPCHECK(hipMemcpyAsync(h, c->scratch.p + 2048, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  *hrel = std::sqrt(h[0] / h[1]);
+  return DHQR_OK;
+}
+
+int64_t dhqr_panel_ldv(int64_t rows) { return panel_ldv(rows); }
+int64_t dhqr_panel_buffer_elems(int64_t rows) { return panel_elems(rows); }
+
+int32_t dhqr_panel_factor_f64(dhqr_ctx *c, double *dP, int64_t rows, int64_t ncols, int64_t ldp,
+                              double *dVT) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(dP, rows, ncols, ldp, true));
+  if (ncols > DHQR_NB) return set_err(DHQR_EINVAL, "panel wider than %d", DHQR_NB);
+  if (!dVT || !aligned16(dVT)) return set_err(DHQR_EINVAL, "dVT must be a 16-byte aligned device buffer");
+  // alpha of the panel lives in the tail of dVT; factor writes it there directly
+  double *al = vt_alpha(dVT, rows);
+  HIPCHECK(hipMemsetAsync(al, 0, DHQR_NBV * sizeof(double), c->stream));
+  CHECK(factor_unblocked_cols(c, dP, rows, ncols, ldp, al, CAT_PANEL));
+  return panel_pack_and_t(c, dP, rows, ncols, ldp, nullptr, dVT);
+}
+
+int32_t dhqr_panel_apply_f64(dhqr_ctx *c, const double *dVT, int64_t rows, double *dC, int64_t ncols,
+                             int64_t ldc, int32_t trans) {
+  CHECK(check_ctx(c));
+  if (!dVT || !aligned16(dVT)) return set_err(DHQR_EINVAL, "dVT must be a 16-byte aligned device buffer");
+  if (ncols == 0) return DHQR_OK;
+  CHECK(check_mat(dC, rows, ncols, ldc, false));
+  return panel_apply(c, dVT, rows, dC, ncols, ldc, trans ? 1 : 0);
+}
+
+int32_t dhqr_bench_mfma_f64(dhqr_ctx *c, double *tflops) {
+  CHECK(check_ctx(c));
+  if (!tflops) return set_err(DHQR_EINVAL, "null output");
+  const int nblk = 256 * 8, iters = 4000;
+  CHECK(ensure(c, c->scratch, (size_t)nblk * 256 + 4096));
+  hipEvent_t a, b;
+  HIPCHECK(hipEventCreate(&a));
+  HIPCHECK(hipEventCreate(&b));
+  hipLaunchKernelGGL(k_mfma_bench, dim3(nblk), dim3(256), 0, c->stream, c->scratch.p, 100);
+  HIPCHECK(hipEventRecord(a, c->stream));
+  hipLaunchKernelGGL(k_mfma_bench, dim3(nblk), dim3(256), 0, c->stream, c->scratch.p, iters);
+  HIPCHECK(hipEventRecord(b, c->stream));
+  HIPCHECK(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIPCHECK(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  const double flops = (double)nblk * 4.0 * (double)iters * 16.0 * 2048.0;
+  *tflops = flops / ((double)ms * 1e-3) / 1e12;
+  return DHQR_OK;
+}
+
+int32_t dhqr_bench_stream_f64(dhqr_ctx *c, int64_t bytes, double *gbps) {
+  CHECK(check_ctx(c));
+  if (!gbps || bytes < 4096) return set_err(DHQR_EINVAL, "bad arguments");
+  const int64_t n2 = bytes / 16;
+  double *x = nullptr, *y = nullptr;
+  if (hipMalloc((void **)&x, (size_t)n2 * 16) != hipSuccess || hipMalloc((void **)&y, (size_t)n2 * 16) != hipSuccess) {
+    if (x) (void)hipFree(x);
+    return set_err(DHQR_ENOMEM, "hipMalloc failed in dhqr_bench_stream_f64");
+  }
+  (void)hipMemsetAsync(x, 0, (size_t)n2 * 16, c->stream);
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  const unsigned grid = 256 * 16;
+  hipLaunchKernelGGL(k_stream_bench, dim3(grid), dim3(256), 0, c->stream, (const double2 *)x, (double2 *)y, n2);
+  (void)hipEventRecord(a, c->stream);
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(k_stream_bench, dim3(grid), dim3(256), 0, c->stream, (const double2 *)x, (double2 *)y, n2);
+  (void)hipEventRecord(b, c->stream);
+  (void)hipEventSynchronize(b);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  (void)hipFree(x);
+  (void)hipFree(y);
+  *gbps = 2.0 * (double)n2 * 16.0 * reps / ((double)ms * 1e-3) / 1e9;
+  return DHQR_OK;
+}
+
+// test hook (not in dhqr.h's stable surface, declared in the test binding only):
+// raw MFMA D registers for the documented operand maps
+int32_t dhqr_debug_mfma_probe(dhqr_ctx *c, const double *da, const double *db, double *dout) {
+  CHECK(check_ctx(c));
+  hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, c->stream, da, db, dout);
+  LAUNCHCHECK();
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return DHQR_OK;
+}
+
+}  // extern "C"

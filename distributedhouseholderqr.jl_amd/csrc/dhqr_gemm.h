@@ -1,0 +1,382 @@
+// dhqr_gemm.h -- FP64 MFMA kernels of the blocked (compact-WY) trailing update
+//     C <- C - V * (op(T) * (V' * C))                         (BASELINE config 3/4)
+// which is the blocked form of the reference's per-column partialdot + hotloop!
+// (src/DistributedHouseholderQR.jl:198-213): k_gemm_tn is `s = partialdot(Hj, H[:,jj])` for 128
+// reflectors at once, k_gemm_nn_sub is `H[:,jj] -= Hj*s`.
+//
+// Both kernels use v_mfma_f64_16x16x4_f64 (2048 flop / instruction, 64 cycles on a gfx950 SIMD):
+//   D[i][j] += sum_k A[i][k] * B[k][j],  i,j in 0..15, k in 0..3
+//   A operand: lane l holds A[i = l&15][k = l>>4];  B operand: lane l holds B[k = l>>4][j = l&15]
+//   C/D: lane l, register g holds D[i = (l>>4) + 4*g][j = l&15]
+// (f64 C/D map differs from the f32 family: cdna_hip_programming.md section 3; verified on the
+// device by tests/test_gpu_kernels.py::test_mfma_layout_probe.)
+// The MFMA "j" index is always mapped to the memory-contiguous direction of the output so every
+// 16-lane group stores/loads one contiguous 128-byte segment.
+//
+// Tiles: 256 threads = 4 waves, output tile 128 x 128, each wave 64 x 64 = 4 x 4 MFMA tiles
+// (16 accumulators x 4 doubles = 128 VGPRs), K-tile 16, operands staged global -> registers ->
+// LDS (double buffered, one barrier per K-tile, next tile's global loads in flight during the
+// 64 MFMAs of the current one).  LDS strides are chosen so the fragment reads (ds_read_b64,
+// 64-bank) are conflict free: 18 doubles (36 dwords) for k-contiguous tiles, 144 doubles for the
+// row-contiguous V tile.
+#pragma once
+#include "dhqr_common.h"
+
+#define G_KT 16          // K-tile depth
+#define G_LDK 18         // LDS stride (doubles) of a k-contiguous tile column
+#define G_LDR 144        // LDS stride (doubles) of a row-contiguous 128-row tile column
+
+__device__ __forceinline__ dhqr_d4 mfma_f64(double a, double b, dhqr_d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// -------------------------------------------------------------------------------------------
+// k_gemm_tn:  out[y][p + c*ldo] = sum_{r in slab y} V[r + p*ldv] * Ceff[r + c*ldc]
+//   p in [0,128), c in [0,ncols); slab y = rows [y*rps, min(rows,(y+1)*rps)), rps % 16 == 0.
+//   Ceff = sum_{q < ncsplit} C[q*csplit_stride + ...]  (folds a previous split-K reduction into
+//   the operand load; ncsplit = 1 for the big trailing GEMM).
+// grid = (ceil(ncols/128), nsplit).  Used for W = V'C (K = panel height), S = V'V, W = op(T)'W.
+// VEC = 2: 16-byte global loads (host guarantees rows, ldv, ldc even and 16-byte aligned bases).
+// All global loads are unconditional (clamped offset + select): no branch sits between a load
+// and its use, so the whole next K-tile is in flight behind the current tile's 64 MFMAs.
+template <int VEC>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V, int64_t ldv,
+                                                    const double *__restrict__ C, int64_t ldc,
+                                                    int ncsplit, int64_t csplit_stride,
+                                                    int64_t rows, int64_t ncols, int64_t rps,
+                                                    double *__restrict__ out, int64_t ldo,
+                                                    int64_t osplit_stride) {
+  __shared__ __attribute__((aligned(16))) double Vs[2][128 * G_LDK];
+  __shared__ __attribute__((aligned(16))) double Cs[2][128 * G_LDK];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int i16 = lane & 15, k4 = lane >> 4;
+  const int wc = w >> 1, wp = w & 1;
+  const int64_t c0 = (int64_t)blockIdx.x * 128;
+  const int64_t rbeg = (int64_t)blockIdx.y * rps;
+  const int64_t rend = (rbeg + rps < rows) ? rbeg + rps : rows;
+  const int nkt = (int)((rend - rbeg + G_KT - 1) / G_KT);
+  const int ncv = (int)((ncols - c0 < 128) ? ncols - c0 : 128);  // valid columns in this tile
+
+  dhqr_d4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+
+  // staging: tile = 128 columns x 16 rows; chunk q = t + i*256 -> column q/8, row pair q%8.
+  // 32-bit element offsets from the (uniform) tile base.
+  const double *Vb = V + rbeg;
+  const double *Cb = C + rbeg + c0 * ldc;
+  uint32_t offv[4], offc[4];
+  bool okc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = t + i * 256;
+    const int col = q >> 3;
+    okc[i] = col < ncv;
+    offv[i] = (uint32_t)(col * ldv);
+    offc[i] = (uint32_t)((okc[i] ? col : 0) * ldc);
+  }
+  double2 sv[4], sc[4];
+  auto load_tile = [&](int kt) {
+    const int left = (int)(rend - rbeg) - kt * G_KT;  // valid rows in this K-tile (>0)
+    const double *Vt = Vb + kt * G_KT;
+    const double *Ct = Cb + kt * G_KT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rp = (t + i * 256) & 7;
+      double2 x, y = make_double2(0.0, 0.0);
+      if constexpr (VEC == 2) {
+        const bool ok = 2 * rp < left;  // rows even => the pair is all-or-nothing
+        const uint32_t ro = ok ? 2 * rp : 0;
+        x = *reinterpret_cast<const double2 *>(Vt + (offv[i] + ro));
+        for (int qs = 0; qs < ncsplit; ++qs) {
+          const double2 z = *reinterpret_cast<const double2 *>(Ct + (int64_t)qs * csplit_stride + (offc[i] + ro));
+          y.x += z.x; y.y += z.y;
+        }
+        if (!ok) x = make_double2(0.0, 0.0);
+        if (!ok || !okc[i]) y = make_double2(0.0, 0.0);
+      } else {
+        const bool ok0 = 2 * rp < left, ok1 = 2 * rp + 1 < left;
+        const uint32_t r0o = ok0 ? 2 * rp : 0, r1o = ok1 ? 2 * rp + 1 : 0;
+        x.x = Vt[offv[i] + r0o];
+        x.y = Vt[offv[i] + r1o];
+        for (int qs = 0; qs < ncsplit; ++qs) {
+          const double *Cq = Ct + (int64_t)qs * csplit_stride;
+          y.x += Cq[offc[i] + r0o];
+          y.y += Cq[offc[i] + r1o];
+        }
+        if (!ok0) x.x = 0.0;
+        if (!ok1) x.y = 0.0;
+        if (!ok0 || !okc[i]) y.x = 0.0;
+        if (!ok1 || !okc[i]) y.y = 0.0;
+      }
+      sv[i] = x;
+      sc[i] = y;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = t + i * 256;
+      const int col = q >> 3, rp = q & 7;
+      *reinterpret_cast<double2 *>(&Vs[buf][col * G_LDK + 2 * rp]) = sv[i];
+      *reinterpret_cast<double2 *>(&Cs[buf][col * G_LDK + 2 * rp]) = sc[i];
+    }
+  };
+
+  if (nkt > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    const double *cs = &Cs[buf][(wc * 64 + i16) * G_LDK + k4];
+    const double *vs = &Vs[buf][(wp * 64 + i16) * G_LDK + k4];
+#pragma unroll
+    for (int kk = 0; kk < G_KT / 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        a[x] = cs[x * 16 * G_LDK + kk * 4];
+        b[x] = vs[x * 16 * G_LDK + kk * 4];
+      }
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) acc[ci][pi] = mfma_f64(a[ci], b[pi], acc[ci][pi]);
+    }
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  double *o = out + (int64_t)blockIdx.y * osplit_stride + c0 * ldo;
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
+      if (cl < ncv) {
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi)
+          o[(uint32_t)(wp * 64 + pi * 16 + i16) + (uint32_t)(cl * ldo)] = acc[ci][pi][g];
+      }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// k_gemm_nn_sub:  C[r + c*ldc] -= sum_{p<128} V[r + p*ldv] * W[p + c*ldw]
+//   r in [0,rows), c in [0,ncols).  grid = (ceil(rows/128), ceil(ncols/128)).
+// The accumulators are initialised with the C tile and the W operand is negated while staging,
+// so the MFMA chain itself performs the subtraction.
+template <int VEC>
+__global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict__ V, int64_t ldv,
+                                                        const double *__restrict__ W, int64_t ldw,
+                                                        double *__restrict__ C, int64_t ldc,
+                                                        int64_t rows, int64_t ncols) {
+  __shared__ __attribute__((aligned(16))) double Vs[2][G_KT * G_LDR];
+  __shared__ __attribute__((aligned(16))) double Ws[2][128 * G_LDK];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int i16 = lane & 15, k4 = lane >> 4;
+  const int wr = w & 1, wc = w >> 1;
+  const int64_t r0 = (int64_t)blockIdx.x * 128;
+  const int64_t c0 = (int64_t)blockIdx.y * 128;
+  const int nrv = (int)((rows - r0 < 128) ? rows - r0 : 128);    // valid rows in this tile
+  const int ncv = (int)((ncols - c0 < 128) ? ncols - c0 : 128);  // valid columns
+
+  const double *Vb = V + r0;
+  const double *Wb = W + c0 * ldw;
+  double *Cb = C + r0 + c0 * ldc;
+
+  // staging offsets (32-bit, from uniform bases); invalid rows/columns are clamped to element 0
+  uint32_t offv[4], offw[4];
+  bool okv0[4], okv1[4], okw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = t + i * 256;
+    const int p = q >> 6, rp = q & 63;  // V tile: 16 p-columns x 128 rows (one wave = 1 KiB run)
+    okv0[i] = 2 * rp < nrv;
+    okv1[i] = 2 * rp + 1 < nrv;
+    offv[i] = (uint32_t)(p * ldv) + (okv0[i] ? 2 * rp : 0);
+    const int col = q >> 3, pp = q & 7;  // W tile: 128 columns x 16 p (128 B per column)
+    okw[i] = col < ncv;
+    offw[i] = (uint32_t)((okw[i] ? col : 0) * ldw) + 2 * pp;
+  }
+  double2 sv[4], sw[4];
+  auto load_tile = [&](int kt) {
+    const double *Vt = Vb + (int64_t)kt * G_KT * ldv;
+    const double *Wt = Wb + kt * G_KT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double2 x, y;
+      if constexpr (VEC == 2) {
+        x = *reinterpret_cast<const double2 *>(Vt + offv[i]);  // rows even: pair all-or-nothing
+        y = *reinterpret_cast<const double2 *>(Wt + offw[i]);
+        if (!okv0[i]) x = make_double2(0.0, 0.0);
+      } else {
+        x.x = Vt[offv[i]];
+        x.y = Vt[offv[i] + (okv1[i] ? 1 : 0)];
+        y.x = Wt[offw[i]];
+        y.y = Wt[offw[i] + 1];
+        if (!okv0[i]) x.x = 0.0;
+        if (!okv1[i]) x.y = 0.0;
+      }
+      if (!okw[i]) y = make_double2(0.0, 0.0);
+      sv[i] = x;
+      sw[i] = make_double2(-y.x, -y.y);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = t + i * 256;
+      *reinterpret_cast<double2 *>(&Vs[buf][(q >> 6) * G_LDR + 2 * (q & 63)]) = sv[i];
+      *reinterpret_cast<double2 *>(&Ws[buf][(q >> 3) * G_LDK + 2 * (q & 7)]) = sw[i];
+    }
+  };
+
+  load_tile(0);
+
+  // accumulators <- C tile.  lane (i16,k4), register g of tile (ci,ri) holds
+  // C[r0 + wr*64 + ri*16 + i16][c0 + wc*64 + ci*16 + k4 + 4g]
+  dhqr_d4 acc[4][4];
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
+      const bool cok = cl < ncv;
+      const uint32_t co = (uint32_t)((cok ? cl : 0) * ldc);
+#pragma unroll
+      for (int ri = 0; ri < 4; ++ri) {
+        const int rl = wr * 64 + ri * 16 + i16;
+        const bool ok = cok && rl < nrv;
+        const double x = Cb[co + (uint32_t)(rl < nrv ? rl : 0)];
+        acc[ci][ri][g] = ok ? x : 0.0;
+      }
+    }
+
+  store_tile(0);
+  __syncthreads();
+  constexpr int NKT = DHQR_NBV / G_KT;
+#pragma unroll 1
+  for (int kt = 0; kt < NKT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < NKT) load_tile(kt + 1);
+    const double *ws = &Ws[buf][(wc * 64 + i16) * G_LDK + k4];
+    const double *vs = &Vs[buf][k4 * G_LDR + wr * 64 + i16];
+#pragma unroll
+    for (int kk = 0; kk < G_KT / 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        a[x] = ws[x * 16 * G_LDK + kk * 4];
+        b[x] = vs[kk * 4 * G_LDR + x * 16];
+      }
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = mfma_f64(a[ci], b[ri], acc[ci][ri]);
+    }
+    if (kt + 1 < NKT) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
+      if (cl < ncv) {
+        const uint32_t co = (uint32_t)(cl * ldc);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+          const int rl = wr * 64 + ri * 16 + i16;
+          if (rl < nrv) Cb[co + (uint32_t)rl] = acc[ci][ri][g];
+        }
+      }
+    }
+}
+
+// out[e] = sum_{s<nsplit} in[s*stride + e], e < count  (split-K reduction, deterministic order)
+__global__ __launch_bounds__(256) void k_reduce_splits(const double *__restrict__ in, int nsplit,
+                                                       int64_t stride, int64_t count,
+                                                       double *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  double s = 0.0;
+  for (int q = 0; q < nsplit; ++q) s += in[(int64_t)q * stride + e];
+  out[e] = s;
+}
+
+// Compact-WY T from S = V'V (128 x 128, ld 128; only the strict upper triangle is used):
+//   T[0:j, j] = -T[0:j,0:j] * S[0:j, j],  T[j][j] = 1       (tau_j == 1: H_j = I - v_j v_j')
+// which is T^{-1} = I + striu(V'V); valid for ANY v_j, so the reference's zero-pivot reflectors
+// (||v||^2 != 2) are reproduced exactly.  One workgroup of 128 threads, T kept in LDS
+// (column l contiguous over rows i). Writes T and T' (both 128 x 128, ld 128, dense).
+__global__ __launch_bounds__(128) void k_build_t(const double *__restrict__ S,
+                                                 double *__restrict__ Tout,
+                                                 double *__restrict__ Ttout) {
+  __shared__ double Tl[128 * 128];
+  __shared__ double Scol[128];
+  const int i = threadIdx.x;
+  for (int l = 0; l < 128; ++l) Tl[l * 128 + i] = 0.0;
+  __syncthreads();
+  for (int j = 0; j < 128; ++j) {
+    if (i < j) Scol[i] = S[i + j * 128];
+    __syncthreads();
+    double z = 0.0;
+    if (i < j) {
+      for (int l = i; l < j; ++l) z = fma(Tl[l * 128 + i], Scol[l], z);
+    }
+    if (i < j) Tl[j * 128 + i] = -z;
+    if (i == j) Tl[j * 128 + j] = 1.0;
+    __syncthreads();
+  }
+  for (int l = 0; l < 128; ++l) {
+    const double x = Tl[l * 128 + i];  // T[i][l]
+    Tout[i + l * 128] = x;
+    Ttout[l + i * 128] = x;
+  }
+}
+
+// Raw MFMA layout probe (test hook): out[lane*4 + g] = D register g of lane, with
+// A[i][k] = a[i*4+k], B[k][j] = b[k*16+j] loaded per the operand maps documented above, C = 0.
+__global__ void k_mfma_probe(const double *__restrict__ a, const double *__restrict__ b,
+                             double *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int i16 = lane & 15, k4 = lane >> 4;
+  dhqr_d4 acc = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+  acc = mfma_f64(a[i16 * 4 + k4], b[k4 * 16 + i16], acc);
+  for (int g = 0; g < 4; ++g) out[lane * 4 + g] = acc[g];
+}
+
+// FP64 MFMA issue-rate micro-benchmark: every wave runs `iters` x 16 independent accumulators.
+__global__ __launch_bounds__(256) void k_mfma_bench(double *__restrict__ out, int iters) {
+  dhqr_d4 acc[16];
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+#pragma unroll
+  for (int x = 0; x < 16; ++x) acc[x] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acc[x] = mfma_f64(a, b, acc[x]);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int x = 0; x < 16; ++x) s += acc[x][0] + acc[x][1] + acc[x][2] + acc[x][3];
+  out[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// streaming read+write micro-benchmark (y = x + 1 on double2)
+__global__ __launch_bounds__(256) void k_stream_bench(const double2 *__restrict__ x,
+                                                      double2 *__restrict__ y, int64_t n2) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += stride) {
+    double2 v = x[e];
+    v.x += 1.0;
+    v.y += 1.0;
+    y[e] = v;
+  }
+}

@@ -1,0 +1,237 @@
+// dhqr_rank1.h -- HBM-bound streaming kernels of the unblocked path (BASELINE config 2) and of
+// the in-panel factorisation: synthetic fill, reflector construction, fused rank-1 update.
+//
+// Reference mapping (src/DistributedHouseholderQR.jl):
+//   k_reflector        src:129-140  (norm, alpha, f, scale, copy column into Hj)
+//   k_rank1_fused/_generic
+//                      src:198-213 + src:42-49 + src:156-160 for every trailing column of step j,
+//                      PLUS src:129-140 for column j+1 done by the workgroup that owns it, so one
+//                      launch per column replaces the reference's norm / scale / copy / @spawnat
+//                      sequence.  The trailing column stays in registers between the dot and the
+//                      update: HBM sees one read and one write per element (16 B / element /
+//                      reflector, the algorithmic traffic of SURVEY.md section 8d).
+//   `vcur`/`vnext`     the reference's dense `Hj` staging vector (src:125,138-140), double
+//                      buffered; entries above the diagonal are kept at 0.
+#pragma once
+#include "dhqr_common.h"
+
+__global__ __launch_bounds__(256) void k_fill_uniform(double *__restrict__ A, int64_t rows,
+                                                      int64_t cols, int64_t lda, uint64_t seed,
+                                                      int64_t gm, int64_t row0, int64_t cb,
+                                                      int nranks, int rank) {
+  const int64_t total = rows * cols;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t jl = e / rows, il = e - jl * rows;
+    const int64_t gj = ((jl / cb) * nranks + rank) * cb + jl % cb;
+    A[il + jl * lda] = dhqr_u01(seed, (uint64_t)(row0 + il + gj * gm));
+  }
+}
+
+// One workgroup builds the reflector of column j from scratch (first column of a matrix/panel).
+// col = &A[0 + j*lda].  Writes the scaled v in place, vnext[0:m] (zeros above the diagonal), alpha.
+template <int T>
+__global__ __launch_bounds__(T) void k_reflector(double *__restrict__ col, int64_t m, int64_t j,
+                                                 double *__restrict__ vnext,
+                                                 double *__restrict__ alpha_j) {
+  __shared__ double red[T / 64 + 1];
+  const int t = threadIdx.x;
+  const double h = col[j];
+  double s2 = 0.0;
+  for (int64_t i = j + t; i < m; i += T) {
+    const double x = col[i];
+    s2 = fma(x, x, s2);
+  }
+  s2 = block_sum<T>(s2, red);
+  const double s = sqrt(s2);                       // src:129
+  const double al = s * dhqr_alphafactor(h);       // src:130
+  const double f = 1.0 / sqrt(s * (s + fabs(h)));  // src:131
+  for (int64_t i = t; i < m; i += T) {
+    double val = 0.0;
+    if (i >= j) {
+      val = (i == j ? h - al : col[i]) * f;  // src:132-135
+      col[i] = val;
+    }
+    vnext[i] = val;  // src:138-140
+  }
+  if (t == 0) *alpha_j = al;
+}
+
+// Fused step j, register-resident variant: workgroup b owns trailing column c = j+1+b.
+// T threads x EPT doubles cover rows [r0, r0 + T*EPT) with r0 = j (VEC=1) or j rounded down to
+// even (VEC=2, 16-byte loads; needs lda, m even and 16-byte aligned bases).  Loads are
+// unconditional (clamped address + select) so all EPT/VEC loads of a thread are in flight at once.
+template <int T, int EPT, int VEC>
+__global__ __launch_bounds__(T) void k_rank1_fused(double *__restrict__ A, int64_t lda, int64_t m,
+                                                   int64_t j, const double *__restrict__ vcur,
+                                                   double *__restrict__ vnext,
+                                                   double *__restrict__ alpha) {
+  __shared__ double red[T / 64 + 2];
+  const int t = threadIdx.x;
+  const int64_t c = j + 1 + blockIdx.x;
+  double *__restrict__ col = A + c * lda;
+  const int64_t r0 = (VEC == 2) ? (j & ~(int64_t)1) : j;
+  const int64_t mlast = m - VEC;  // last valid (pair) start
+  double a[EPT], v[EPT];
+
+  if constexpr (VEC == 2) {
+#pragma unroll
+    for (int i = 0; i < EPT / 2; ++i) {
+      const int64_t row = r0 + 2 * ((int64_t)t + (int64_t)i * T);
+      const bool ok = row < m;
+      const int64_t rc = ok ? row : mlast;
+      const double2 x = *reinterpret_cast<const double2 *>(col + rc);
+      const double2 y = *reinterpret_cast<const double2 *>(vcur + rc);
+      a[2 * i] = ok ? x.x : 0.0; a[2 * i + 1] = ok ? x.y : 0.0;
+      v[2 * i] = ok ? y.x : 0.0; v[2 * i + 1] = ok ? y.y : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t row = r0 + t + (int64_t)e * T;
+      const bool ok = row < m;
+      const int64_t rc = ok ? row : mlast;
+      const double x = col[rc], y = vcur[rc];
+      a[e] = ok ? x : 0.0;
+      v[e] = ok ? y : 0.0;
+    }
+  }
+
+  double dot = 0.0;  // src:208 partialdot(Hj, view(Hl,:,jj), j:m)
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) dot = fma(a[e], v[e], dot);
+  const double s = block_sum<T>(dot, red);
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) a[e] = fma(-v[e], s, a[e]);  // src:209 hotloop!
+
+  const bool pivot = (blockIdx.x == 0);  // this workgroup owns column j+1: build its reflector
+  if (pivot) {
+    const int64_t jp = j + 1;
+    double s2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t row = (VEC == 2) ? r0 + 2 * ((int64_t)t + (int64_t)(e >> 1) * T) + (e & 1)
+                                     : r0 + t + (int64_t)e * T;
+      if (row == jp) red[T / 64] = a[e];
+      if (row >= jp && row < m) s2 = fma(a[e], a[e], s2);
+    }
+    s2 = block_sum<T>(s2, red);  // barriers inside also publish red[T/64]
+    const double h = red[T / 64];
+    const double sn = sqrt(s2);                        // src:129
+    const double al = sn * dhqr_alphafactor(h);        // src:130
+    const double f = 1.0 / sqrt(sn * (sn + fabs(h)));  // src:131
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t row = (VEC == 2) ? r0 + 2 * ((int64_t)t + (int64_t)(e >> 1) * T) + (e & 1)
+                                     : r0 + t + (int64_t)e * T;
+      if (row == jp) a[e] = (h - al) * f;  // src:132-135
+      else if (row > jp) a[e] *= f;
+      v[e] = (row >= jp) ? a[e] : 0.0;  // reuse v[] as the outgoing Hj (src:138-140)
+    }
+    if (t == 0) alpha[jp] = al;
+  }
+
+  if constexpr (VEC == 2) {
+#pragma unroll
+    for (int i = 0; i < EPT / 2; ++i) {
+      const int64_t row = r0 + 2 * ((int64_t)t + (int64_t)i * T);
+      if (row < m) {
+        *reinterpret_cast<double2 *>(col + row) = make_double2(a[2 * i], a[2 * i + 1]);
+        if (pivot) *reinterpret_cast<double2 *>(vnext + row) = make_double2(v[2 * i], v[2 * i + 1]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t row = r0 + t + (int64_t)e * T;
+      if (row < m) {
+        col[row] = a[e];
+        if (pivot) vnext[row] = v[e];
+      }
+    }
+  }
+}
+
+// Fused step j for columns taller than 1024*8 rows: same contract, the column is streamed twice
+// (the second pass hits L2: a 32768-row column is 256 KiB).
+template <int T, int VEC>
+__global__ __launch_bounds__(T) void k_rank1_generic(double *__restrict__ A, int64_t lda,
+                                                     int64_t m, int64_t j,
+                                                     const double *__restrict__ vcur,
+                                                     double *__restrict__ vnext,
+                                                     double *__restrict__ alpha) {
+  __shared__ double red[T / 64 + 2];
+  const int t = threadIdx.x;
+  const int64_t c = j + 1 + blockIdx.x;
+  double *col = A + c * lda;
+  const int64_t r0 = (VEC == 2) ? (j & ~(int64_t)1) : j;
+
+  double dot = 0.0;
+  if constexpr (VEC == 2) {
+    for (int64_t row = r0 + 2 * (int64_t)t; row < m; row += 2 * T) {
+      const double2 x = *reinterpret_cast<const double2 *>(col + row);
+      const double2 y = *reinterpret_cast<const double2 *>(vcur + row);
+      dot = fma(x.x, y.x, dot);
+      dot = fma(x.y, y.y, dot);
+    }
+  } else {
+    for (int64_t row = r0 + t; row < m; row += T) dot = fma(col[row], vcur[row], dot);
+  }
+  const double s = block_sum<T>(dot, red);
+  if constexpr (VEC == 2) {
+    for (int64_t row = r0 + 2 * (int64_t)t; row < m; row += 2 * T) {
+      double2 x = *reinterpret_cast<const double2 *>(col + row);
+      const double2 y = *reinterpret_cast<const double2 *>(vcur + row);
+      x.x = fma(-y.x, s, x.x);
+      x.y = fma(-y.y, s, x.y);
+      *reinterpret_cast<double2 *>(col + row) = x;
+    }
+  } else {
+    for (int64_t row = r0 + t; row < m; row += T) col[row] = fma(-vcur[row], s, col[row]);
+  }
+  if (blockIdx.x != 0) return;
+
+  const int64_t jp = j + 1;
+  __syncthreads();  // column j+1 fully updated and visible inside this workgroup
+  const double h = col[jp];
+  double s2 = 0.0;
+  if constexpr (VEC == 2) {
+    for (int64_t row = r0 + 2 * (int64_t)t; row < m; row += 2 * T) {
+      const double2 x = *reinterpret_cast<const double2 *>(col + row);
+      if (row >= jp) s2 = fma(x.x, x.x, s2);
+      if (row + 1 >= jp) s2 = fma(x.y, x.y, s2);
+    }
+  } else {
+    for (int64_t row = r0 + t; row < m; row += T)
+      if (row >= jp) s2 = fma(col[row], col[row], s2);
+  }
+  s2 = block_sum<T>(s2, red);
+  const double sn = sqrt(s2);
+  const double al = sn * dhqr_alphafactor(h);
+  const double f = 1.0 / sqrt(sn * (sn + fabs(h)));
+  // every thread read h before block_sum's barriers; the owner of row jp overwrites it below.
+  for (int64_t row = r0 + t; row < m; row += T) {
+    double val = 0.0;
+    if (row >= jp) {
+      val = (row == jp ? h - al : col[row]) * f;
+      col[row] = val;
+    }
+    vnext[row] = val;
+  }
+  if (t == 0) alpha[jp] = al;
+}
+
+// Pack a factored panel into the clean V operand of the MFMA GEMMs / the broadcast buffer:
+// Vw[r + p*ldv] = P[r + p*ldp] for r >= p, p < ncols; 0 above the diagonal (that is R), in the
+// zero-padded columns p >= ncols and in the pad rows [rows, ldv).
+__global__ __launch_bounds__(256) void k_pack_v(const double *__restrict__ P, int64_t ldp,
+                                                int64_t rows, int64_t ncols,
+                                                double *__restrict__ Vw, int64_t ldv) {
+  const int64_t p = blockIdx.y;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ldv; r += stride) {
+    double x = 0.0;
+    if (p < ncols && r >= p && r < rows) x = P[r + p * ldp];
+    Vw[r + p * ldv] = x;
+  }
+}

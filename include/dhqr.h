@@ -1,0 +1,173 @@
+/*
+ * dhqr.h -- C ABI of libdhqr.so: MI355X (gfx950) Householder QR hot path, drop-in for the
+ * Julia functions of jwscook/DistributedHouseholderQR.jl (src/DistributedHouseholderQR.jl).
+ *
+ * The reference has no FFI layer; its boundary is the Julia function API.  Each entry point
+ * below names the reference function (file:line) it replaces.  A Julia `ccall` wrapper with the
+ * reference's names (`qr!`, `\`, `householder!`, `solve_householder!`, `partialdot`) is in
+ * distributedhouseholderqr.jl_amd/julia/DistributedHouseholderQR.jl; the same ABI is bound from
+ * Python (ctypes) by distributedhouseholderqr.jl_amd/_lib.py.  INTEGRATION.md shows both stubs.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns int32 status (0 = DHQR_OK, <0 error),
+ *     message via dhqr_last_error() (thread-local); nothing throws across the boundary.
+ *   - sizes are int64 (Julia Int); matrices are column-major Float64 with leading dimension ld*.
+ *   - "d"-prefixed pointers are DEVICE pointers owned by the caller (hipMalloc, torch tensor
+ *     .data_ptr(), AMDGPU.jl ROCArray pointer ...); "h"-prefixed pointers are HOST pointers,
+ *     borrowed for the duration of the call.
+ *   - device-resident entry points enqueue work on the context's stream and return without
+ *     synchronising unless they hand a host scalar back (documented per function).
+ *   - one dhqr_ctx per (host thread, GPU); a ctx is not re-entrant.
+ *   - factor format (identical to the reference, src:296-309): after factorisation
+ *       A[j:m, j] = v_j  (diagonal INCLUDED, ||v_j||^2 = 2, H_j = I - v_j v_j'),
+ *       A[i, j]  = R[i,j] for i < j,   alpha[j] = R[j,j].
+ */
+#ifndef DHQR_H
+#define DHQR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DHQR_VERSION 100 /* 0.1.0 */
+
+#define DHQR_OK 0
+#define DHQR_EINVAL (-1)   /* bad argument (null pointer, m < n, ld < m, unsupported nb ...) */
+#define DHQR_EHIP (-2)     /* a HIP runtime call failed; text in dhqr_last_error() */
+#define DHQR_ENOMEM (-3)   /* workspace allocation failed */
+#define DHQR_ENODEVICE (-4) /* no gfx950 device visible */
+
+/* Panel (block-reflector) width of the blocked path.  BASELINE.json configs 3/4 fix it at 128. */
+#define DHQR_NB 128
+
+typedef struct dhqr_ctx dhqr_ctx; /* opaque: device id, stream, workspaces, event pools */
+
+/* Per-phase device timings (ms, hipEvent on the ctx stream) and launch counts accumulated since
+ * the last dhqr_reset_stats(); only filled while profiling is enabled (dhqr_set_profiling).
+ * Replaces the reference's inline @elapsed accumulators t1a/t1b/t2 (src:126-146, src:291). */
+typedef struct dhqr_stats {
+  double ms_panel;      /* reflector construction + in-panel rank-1 updates   (src:122-148)  */
+  double ms_tbuild;     /* pack V, V'V, T recurrence                           (new)          */
+  double ms_gemm_vta;   /* W = V' * A     trailing GEMM 1 (MFMA)               (src:208)      */
+  double ms_gemm_tw;    /* W = T' * W     small GEMM (MFMA)                    (new)          */
+  double ms_gemm_avw;   /* A -= V * W     trailing GEMM 2 (MFMA)               (src:209)      */
+  double ms_rank1;      /* unblocked fused reflector-apply kernel (nb = 0)     (src:198-213)  */
+  double ms_solve;      /* Q'b + back substitution                             (src:215-294)  */
+  int64_t n_panel, n_tbuild, n_gemm_vta, n_gemm_tw, n_gemm_avw, n_rank1, n_solve; /* launches */
+  double flops_gemm_vta, flops_gemm_avw; /* algorithmic flops issued by the two trailing GEMMs */
+  double bytes_rank1;                    /* algorithmic bytes (16 B / trailing element / reflector) */
+} dhqr_stats;
+
+/* ------------------------------------------------------------------ library / context */
+int32_t dhqr_version(void);
+const char *dhqr_last_error(void);
+int32_t dhqr_device_count(int32_t *count);
+
+/* Create a context on HIP device `device` (fails with DHQR_ENODEVICE when no GPU is visible:
+ * there is NO CPU fallback).  Owns a stream and lazily grown workspaces. */
+int32_t dhqr_create(dhqr_ctx **ctx, int32_t device);
+int32_t dhqr_destroy(dhqr_ctx *ctx);
+/* Borrow the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores
+ * the ctx-owned stream. */
+int32_t dhqr_set_stream(dhqr_ctx *ctx, void *hip_stream);
+int32_t dhqr_synchronize(dhqr_ctx *ctx);
+int32_t dhqr_set_profiling(dhqr_ctx *ctx, int32_t on);
+int32_t dhqr_reset_stats(dhqr_ctx *ctx);
+int32_t dhqr_get_stats(dhqr_ctx *ctx, dhqr_stats *out); /* synchronises the ctx stream */
+
+/* ------------------------------------------------------------------ synthetic inputs
+ * Replaces rand(T,m,n) / rand(T,m) of test/runtests.jl:45-46 with the portable counter-based
+ * generator shared with oracle/ :  value(gi, gj) = u01(seed, gi + gj*global_m).
+ * The local block holds `rows` x `cols`; local row il is global row row0+il; local column jl is
+ * global column ((jl / colblock) * nranks + rank) * colblock + jl % colblock  (block-cyclic 1-D
+ * column layout; nranks = 1, rank = 0 gives the identity map). Async. */
+int32_t dhqr_fill_uniform_f64(dhqr_ctx *ctx, double *dA, int64_t rows, int64_t cols, int64_t lda,
+                              uint64_t seed, int64_t global_m, int64_t row0, int64_t colblock,
+                              int32_t nranks, int32_t rank);
+
+/* ------------------------------------------------------------------ factorisation
+ * dhqr_factor_f64: device-resident replacement of householder!(A, alpha) (src:113, src:122-148,
+ * src:198-213) for one GPU.  In place on dA (m x n, m >= n), writes dalpha[0:n].
+ *   nb == 0      : unblocked path -- per column one fused kernel (reflector build + rank-1
+ *                  trailing update), the reference's algorithm verbatim (BASELINE config 2).
+ *   nb == DHQR_NB: blocked path -- panel factorisation + compact-WY trailing update
+ *                  A -= V * (T' * (V' * A)) on FP64 MFMA (BASELINE config 3).
+ * Async on the ctx stream. */
+int32_t dhqr_factor_f64(dhqr_ctx *ctx, double *dA, int64_t m, int64_t n, int64_t lda,
+                        double *dalpha, int32_t nb);
+
+/* dhqr_qr_f64: host-in / host-out drop-in for qr!(A::Matrix{Float64}) (src:311-315): uploads hA,
+ * factors, downloads hA and halpha.  Synchronous. */
+int32_t dhqr_qr_f64(dhqr_ctx *ctx, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha,
+                    int32_t nb);
+
+/* ------------------------------------------------------------------ solve
+ * dhqr_solve_f64: device-resident replacement of solve_householder!(b, H, alpha) (src:284-294):
+ * db (length m) <- Q' db (src:215-242), then back substitution with strict-upper dA and the
+ * diagonal dalpha (src:244-282); the solution is db[0:n].  Mutates db like the reference. Async. */
+int32_t dhqr_solve_f64(dhqr_ctx *ctx, const double *dA, int64_t m, int64_t n, int64_t lda,
+                       const double *dalpha, double *db);
+
+/* dhqr_ldiv_f64: host-in / host-out drop-in for `H \ b` (src:317-321): does NOT modify hb (the
+ * reference copies b into a SharedArray first); writes hx[0:n].  Synchronous. */
+int32_t dhqr_ldiv_f64(dhqr_ctx *ctx, const double *hA, int64_t m, int64_t n, int64_t lda,
+                      const double *halpha, const double *hb, double *hx);
+
+/* KAT hook mirroring partialdot(a, b, lo:hi, Float64) (src:42-49; test/partialdot.jl:18):
+ * sum_{i=lo}^{hi-1} da[i]*db[i] (0-based, hi exclusive) reduced on the device with the same
+ * wavefront-shuffle + LDS tree the factor kernels use.  Synchronous (returns a host scalar). */
+int32_t dhqr_partialdot_f64(dhqr_ctx *ctx, const double *da, const double *db, int64_t lo,
+                            int64_t hi, double *hout);
+
+/* ------------------------------------------------------------------ Q application / metric
+ * dB (m x nrhs) <- Q' dB (trans = 1) or Q dB (trans = 0), Q = H_1 ... H_n from a factored dA.
+ * Blocked compact-WY on MFMA (T is rebuilt per panel from V). No reference analogue beyond
+ * src:215-242 (single vector); needed for the north-star metric ||A - QR|| / ||A||. Async. */
+int32_t dhqr_apply_q_f64(dhqr_ctx *ctx, const double *dA, int64_t m, int64_t n, int64_t lda,
+                         double *dB, int64_t nrhs, int64_t ldb, int32_t trans);
+
+/* rel = ||dAorig - Q R||_F / ||dAorig||_F with Q,R taken from (dAfact, dalpha). dwork is an
+ * m x n scratch matrix (leading dimension m) that receives Q*R.  Synchronous (host scalar). */
+int32_t dhqr_residual_f64(dhqr_ctx *ctx, const double *dAfact, int64_t m, int64_t n, int64_t lda,
+                          const double *dalpha, const double *dAorig, int64_t ldo, double *dwork,
+                          double *hrel);
+
+/* ------------------------------------------------------------------ panel level (multi-GPU)
+ * The 1-D column-split driver (one process per GPU, torch.distributed/RCCL broadcast of the panel,
+ * replacing the per-column @spawnat fan-out of src:141-143) is built from these two calls.
+ *
+ * Packed panel buffer ("VT"), doubles:  [ V : ldv x DHQR_NB | T : NB x NB | alpha : NB ]
+ *   ldv = dhqr_panel_ldv(rows); V is the panel's reflectors with the R part above the diagonal
+ *   zeroed and columns >= ncols zero; T is the upper-triangular compact-WY factor
+ *   (H_1...H_nb = I - V T V').  dhqr_panel_buffer_elems gives the total length. */
+int64_t dhqr_panel_ldv(int64_t rows);
+int64_t dhqr_panel_buffer_elems(int64_t rows);
+
+/* Factor the rows x ncols panel dP in place (ncols <= DHQR_NB, rows >= ncols; row 0 of dP is the
+ * panel's diagonal row) exactly like src:122-148 restricted to these columns, and emit dVT. Async. */
+int32_t dhqr_panel_factor_f64(dhqr_ctx *ctx, double *dP, int64_t rows, int64_t ncols, int64_t ldp,
+                              double *dVT);
+/* dC (rows x ncols) <- (I - V T' V') dC  (trans = 1, the factorisation's trailing update,
+ * src:198-213 blocked) or (I - V T V') dC (trans = 0). Async. */
+int32_t dhqr_panel_apply_f64(dhqr_ctx *ctx, const double *dVT, int64_t rows, double *dC,
+                             int64_t ncols, int64_t ldc, int32_t trans);
+
+/* ------------------------------------------------------------------ micro-benchmarks
+ * Device ceilings measured on the box itself (bench.py reports them next to the spec peaks):
+ * FP64 MFMA issue-bound TFLOP/s (v_mfma_f64_16x16x4_f64 only) and a read+write streaming
+ * copy in GB/s over `bytes` bytes. Synchronous. */
+int32_t dhqr_bench_mfma_f64(dhqr_ctx *ctx, double *tflops);
+int32_t dhqr_bench_stream_f64(dhqr_ctx *ctx, int64_t bytes, double *gbps);
+
+/* ------------------------------------------------------------------ test hook
+ * One v_mfma_f64_16x16x4_f64 with A[i][k] = da[i*4+k], B[k][j] = db[k*16+j], C = 0, operands
+ * loaded with the lane maps documented in csrc/dhqr_gemm.h; dout[lane*4+g] = raw D register g.
+ * tests/test_gpu_kernels.py uses it to pin the f64 C/D fragment layout on the device. Synchronous. */
+int32_t dhqr_debug_mfma_probe(dhqr_ctx *ctx, const double *da, const double *db, double *dout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DHQR_H */

@@ -1,0 +1,58 @@
+"""The C-ABI library loads and exports every symbol include/dhqr.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "dhqr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dhqr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(pkg):
+    pkg.build()
+    L = ctypes.CDLL(pkg._lib.SO_PATH)
+    names = _declared()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(L, n), f"libdhqr.so does not export {n}"
+    # the Python binding covers the whole header and nothing else
+    assert sorted(pkg._lib.SIGNATURES) == names
+
+
+def test_version_and_error_string(pkg):
+    L = pkg._lib.lib()
+    assert L.dhqr_version() == 100
+    assert isinstance(L.dhqr_last_error(), bytes)
+    assert L.dhqr_panel_ldv(100) == 112 and L.dhqr_panel_ldv(128) == 128
+    assert L.dhqr_panel_buffer_elems(256) == 256 * 128 + 2 * 128 * 128 + 128
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a GPU the product path must fail loudly (DHQR_ENODEVICE), never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.DHQRError) as e:
+        pkg.Context(0)
+    assert e.value.code == pkg._lib.ENODEVICE
+    import numpy as np
+    with pytest.raises(pkg.DHQRError):
+        pkg.qr_(np.asfortranarray(np.random.rand(8, 4)))
+
+
+def test_product_package_does_not_import_oracle():
+    pkgdir = os.path.join(ROOT, "distributedhouseholderqr.jl_amd")
+    for dirpath, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+                assert not re.search(r"#\s*include[^\n]*oracle", txt), f
+                assert "libdhqr_oracle" not in txt and "dhqr_oracle_" not in txt.replace(
+                    "dhqr_oracle_u01", ""), f  # (a comment names the generator twin)
