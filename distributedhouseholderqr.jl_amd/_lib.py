@@ -27,7 +27,7 @@ class Stats(ctypes.Structure):
                [(n, ctypes.c_int64) for n in
                 ("n_panel", "n_tbuild", "n_gemm_vta", "n_gemm_tw", "n_gemm_avw", "n_rank1",
                  "n_solve")] + \
-               [(n, ctypes.c_double) for n in ("flops_gemm_vta", "flops_gemm_avw", "bytes_rank1")]
+               [(n, ctypes.c_double) for n in ("flops_gemm_vta", "flops_gemm_avw", "bytes_rank1", "bytes_panel")]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -56,6 +56,7 @@ SIGNATURES = {
     "dhqr_create": (_i32, [_pp, _i32]),
     "dhqr_destroy": (_i32, [_p]),
     "dhqr_set_stream": (_i32, [_p, _p]),
+    "dhqr_use_own_stream": (_i32, [_p]),
     "dhqr_synchronize": (_i32, [_p]),
     "dhqr_set_profiling": (_i32, [_p, _i32]),
     "dhqr_reset_stats": (_i32, [_p]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     "dhqr_factor_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32]),
     "dhqr_qr_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32]),
     "dhqr_solve_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p]),
+    "dhqr_backsub_block_f64": (_i32, [_p, _p, _i64, _p, _p, _i64, _i64, _i32, _i32]),
     "dhqr_ldiv_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "dhqr_partialdot_f64": (_i32, [_p, _p, _p, _i64, _i64, _pd]),
     "dhqr_apply_q_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _i64, _i32]),
@@ -71,8 +73,12 @@ SIGNATURES = {
     "dhqr_panel_ldv": (_i64, [_i64]),
     "dhqr_panel_buffer_elems": (_i64, [_i64]),
     "dhqr_panel_factor_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
+    "dhqr_panel_pack_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
+    "dhqr_form_r0_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i32, _i32]),
+    "dhqr_diff_norms_f64": (_i32, [_p, _p, _i64, _p, _i64, _i64, _i64, _pd]),
     "dhqr_panel_apply_f64": (_i32, [_p, _p, _i64, _p, _i64, _i64, _i32]),
     "dhqr_bench_mfma_f64": (_i32, [_p, _pd]),
+    "dhqr_bench_issue_f64": (_i32, [_p, _i32, _i32, _pd, _pd]),
     "dhqr_bench_stream_f64": (_i32, [_p, _i64, _pd]),
     "dhqr_debug_mfma_probe": (_i32, [_p, _p, _p, _p]),
 }

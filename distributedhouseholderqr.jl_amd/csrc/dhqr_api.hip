@@ -150,8 +150,11 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
     if (vec) launch_rank1<2>(c, P, ldp, rows, j, nupd, vb[j & 1], vb[(j + 1) & 1], alpha);
     else launch_rank1<1>(c, P, ldp, rows, j, nupd, vb[j & 1], vb[(j + 1) & 1], alpha);
     CHECK(prof_end(c));
-    if (c->profiling && cat == CAT_RANK1)
-      c->st.bytes_rank1 += 16.0 * (double)(rows - j) * (double)nupd;
+    if (c->profiling) {
+      const double by = 16.0 * (double)(rows - j) * (double)nupd;
+      if (cat == CAT_RANK1) c->st.bytes_rank1 += by;
+      else c->st.bytes_panel += by;
+    }
   }
   LAUNCHCHECK();
   return DHQR_OK;
@@ -357,7 +360,12 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
 
 int32_t dhqr_set_stream(dhqr_ctx *c, void *s) {
   CHECK(check_ctx(c));
-  c->stream = s ? (hipStream_t)s : c->own;
+  c->stream = (hipStream_t)s;  // NULL is the device's default (null) stream, as torch uses it
+  return DHQR_OK;
+}
+int32_t dhqr_use_own_stream(dhqr_ctx *c) {
+  CHECK(check_ctx(c));
+  c->stream = c->own;
   return DHQR_OK;
 }
 int32_t dhqr_synchronize(dhqr_ctx *c) {
@@ -479,6 +487,27 @@ int32_t dhqr_solve_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int6
   return DHQR_OK;
 }
 
+int32_t dhqr_backsub_block_f64(dhqr_ctx *c, const double *dAcols, int64_t lda, const double *dalpha,
+                               double *db, int64_t lo, int64_t hi, int32_t do_diag, int32_t do_update) {
+  CHECK(check_ctx(c));
+  if (!dAcols || !dalpha || !db) return set_err(DHQR_EINVAL, "null pointer argument");
+  if (lo < 0 || hi <= lo) return set_err(DHQR_EINVAL, "bad block [%lld,%lld)", (long long)lo, (long long)hi);
+  for (int64_t h = hi; h > lo; h -= BS_NB) {  // blocks wider than 64 are walked in 64-row steps
+    const int64_t l = std::max<int64_t>(lo, h - BS_NB);
+    if (do_diag) {
+      hipLaunchKernelGGL(k_backsub_diag, dim3(1), dim3(64), 0, c->stream, dAcols, lda, dalpha, db, l, h);
+      if (l > lo)  // rows of this block above the 64-row step just solved
+        hipLaunchKernelGGL(k_backsub_update_range, dim3((unsigned)((l - lo + 255) / 256)), dim3(256), 0,
+                           c->stream, dAcols, lda, db, lo, l, l, h);
+    }
+    if (do_update && lo > 0)  // rows above the block
+      hipLaunchKernelGGL(k_backsub_update_range, dim3((unsigned)((lo + 255) / 256)), dim3(256), 0,
+                         c->stream, dAcols, lda, db, (int64_t)0, lo, l, h);
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
 int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64_t lda,
                       const double *halpha, const double *hb, double *hx) {
   CHECK(check_ctx(c));
@@ -542,7 +571,8 @@ int32_t dhqr_residual_f64(dhqr_ctx *c, const double *dAfact, int64_t m, int64_t 
   {
     dim3 grid((unsigned)std::min<int64_t>((m + 255) / 256, 128), (unsigned)n);
     if (n > 65535) return set_err(DHQR_EINVAL, "n too large for dhqr_residual_f64");
-    hipLaunchKernelGGL(k_form_r0, grid, dim3(256), 0, c->stream, dAfact, lda, dalpha, m, n, dwork, m);
+    hipLaunchKernelGGL(k_form_r0, grid, dim3(256), 0, c->stream, dAfact, lda, dalpha, m, n, dwork, m,
+                       (int64_t)DHQR_NBV, 1, 0);
   }
   const bool was = c->profiling;
   c->profiling = false;
@@ -577,6 +607,50 @@ int32_t dhqr_panel_factor_f64(dhqr_ctx *c, double *dP, int64_t rows, int64_t nco
   return panel_pack_and_t(c, dP, rows, ncols, ldp, nullptr, dVT);
 }
 
+int32_t dhqr_panel_pack_f64(dhqr_ctx *c, const double *dP, int64_t rows, int64_t ncols, int64_t ldp,
+                            double *dVT) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(dP, rows, ncols, ldp, true));
+  if (ncols > DHQR_NB) return set_err(DHQR_EINVAL, "panel wider than %d", DHQR_NB);
+  if (!dVT || !aligned16(dVT)) return set_err(DHQR_EINVAL, "dVT must be a 16-byte aligned device buffer");
+  HIPCHECK(hipMemsetAsync(vt_alpha(dVT, rows), 0, DHQR_NBV * sizeof(double), c->stream));
+  return panel_pack_and_t(c, dP, rows, ncols, ldp, nullptr, dVT);
+}
+
+int32_t dhqr_form_r0_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t cols, int64_t lda,
+                         const double *dalpha, double *dW, int64_t ldw, int64_t colblock,
+                         int32_t nranks, int32_t rank) {
+  CHECK(check_ctx(c));
+  if (cols == 0) return DHQR_OK;
+  CHECK(check_mat(dA, m, cols, lda, false));
+  CHECK(check_mat(dW, m, cols, ldw, false));
+  if (!dalpha || colblock <= 0 || nranks <= 0 || rank < 0 || rank >= nranks || cols > 65535)
+    return set_err(DHQR_EINVAL, "bad arguments to dhqr_form_r0_f64");
+  dim3 grid((unsigned)std::min<int64_t>((m + 255) / 256, 128), (unsigned)cols);
+  hipLaunchKernelGGL(k_form_r0, grid, dim3(256), 0, c->stream, dA, lda, dalpha, m, cols, dW, ldw, colblock,
+                     (int)nranks, (int)rank);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+int32_t dhqr_diff_norms_f64(dhqr_ctx *c, const double *dX, int64_t ldx, const double *dY, int64_t ldy,
+                            int64_t m, int64_t n, double *hout2) {
+  CHECK(check_ctx(c));
+  if (!hout2) return set_err(DHQR_EINVAL, "null output");
+  hout2[0] = hout2[1] = 0.0;
+  if (m == 0 || n == 0) return DHQR_OK;
+  CHECK(check_mat(dX, m, n, ldx, false));
+  CHECK(check_mat(dY, m, n, ldy, false));
+  CHECK(ensure(c, c->scratch, 4096));
+  const int nblk = 1024;
+  hipLaunchKernelGGL(k_diff_norms, dim3(nblk), dim3(256), 0, c->stream, dX, ldx, dY, ldy, m, n, c->scratch.p);
+  hipLaunchKernelGGL(k_sum2_final, dim3(1), dim3(256), 0, c->stream, (const double *)c->scratch.p, nblk, c->scratch.p + 2048);
+  LAUNCHCHECK();
+  HIPCHECK(hipMemcpyAsync(hout2, c->scratch.p + 2048, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return DHQR_OK;
+}
+
 int32_t dhqr_panel_apply_f64(dhqr_ctx *c, const double *dVT, int64_t rows, double *dC, int64_t ncols,
                              int64_t ldc, int32_t trans) {
   CHECK(check_ctx(c));
@@ -605,6 +679,39 @@ int32_t dhqr_bench_mfma_f64(dhqr_ctx *c, double *tflops) {
   (void)hipEventDestroy(b);
   const double flops = (double)nblk * 4.0 * (double)iters * 16.0 * 2048.0;
   *tflops = flops / ((double)ms * 1e-3) / 1e12;
+  return DHQR_OK;
+}
+
+int32_t dhqr_bench_issue_f64(dhqr_ctx *c, int32_t kind, int32_t nblocks, double *cycles_per_instr,
+                             double *tflops) {
+  CHECK(check_ctx(c));
+  if (!cycles_per_instr || !tflops || nblocks <= 0 || nblocks > 4096 || (kind != 0 && kind != 1))
+    return set_err(DHQR_EINVAL, "bad arguments");
+  const int iters = 2000;
+  CHECK(ensure(c, c->scratch, (size_t)nblocks * 256 + 4096 + (size_t)nblocks * 4 + 16));
+  double *sink = c->scratch.p;
+  long long *cyc = (long long *)(c->scratch.p + (size_t)nblocks * 256 + 4096);
+  hipEvent_t a, b;
+  HIPCHECK(hipEventCreate(&a));
+  HIPCHECK(hipEventCreate(&b));
+  for (int rep = 0; rep < 2; ++rep) {  // first pass warms clocks / code
+    HIPCHECK(hipEventRecord(a, c->stream));
+    if (kind == 0) hipLaunchKernelGGL((k_issue_probe<0>), dim3(nblocks), dim3(256), 0, c->stream, sink, cyc, iters);
+    else hipLaunchKernelGGL((k_issue_probe<1>), dim3(nblocks), dim3(256), 0, c->stream, sink, cyc, iters);
+    HIPCHECK(hipEventRecord(b, c->stream));
+    HIPCHECK(hipEventSynchronize(b));
+  }
+  float ms = 0.f;
+  HIPCHECK(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  std::vector<long long> h((size_t)nblocks * 4);
+  HIPCHECK(hipMemcpy(h.data(), cyc, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+  double sum = 0;
+  for (long long v : h) sum += (double)v;
+  *cycles_per_instr = sum / (double)h.size() / ((double)iters * 16.0);
+  const double flop_per_instr = kind == 0 ? 2048.0 : 128.0;
+  *tflops = (double)nblocks * 4.0 * iters * 16.0 * flop_per_instr / ((double)ms * 1e-3) / 1e12;
   return DHQR_OK;
 }
 

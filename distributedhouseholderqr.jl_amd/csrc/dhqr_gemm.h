@@ -369,6 +369,43 @@ __global__ __launch_bounds__(256) void k_mfma_bench(double *__restrict__ out, in
   out[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// Issue-rate probes in SHADER cycles (s_memtime), independent of DVFS: per wave, `iters` x 16
+// independent v_mfma_f64_16x16x4_f64 (kind 0) or v_fma_f64 (kind 1) chains; cyc[wave] = cycles.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_issue_probe(double *__restrict__ sink,
+                                                     long long *__restrict__ cyc, int iters) {
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  long long t0, t1;
+  double s = 0.0;
+  if constexpr (KIND == 0) {
+    dhqr_d4 acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acc[x] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+    t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[x] = mfma_f64(a, b, acc[x]);
+    }
+    t1 = clock64();
+#pragma unroll
+    for (int x = 0; x < 16; ++x) s += acc[x][0] + acc[x][1] + acc[x][2] + acc[x][3];
+  } else {
+    double acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acc[x] = threadIdx.x * 1e-3 + x;
+    t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[x] = fma(acc[x], a, b);
+    }
+    t1 = clock64();
+#pragma unroll
+    for (int x = 0; x < 16; ++x) s += acc[x];
+  }
+  sink[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 // streaming read+write micro-benchmark (y = x + 1 on double2)
 __global__ __launch_bounds__(256) void k_stream_bench(const double2 *__restrict__ x,
                                                       double2 *__restrict__ y, int64_t n2) {

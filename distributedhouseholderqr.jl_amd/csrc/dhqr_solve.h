@@ -53,6 +53,24 @@ __global__ __launch_bounds__(256) void k_backsub_update(const double *__restrict
   b[r] -= acc;
 }
 
+// b[top:rend] -= R[top:rend, xlo:xhi] * b[xlo:xhi]  (row-range variant used by the block-level
+// entry point; rend <= xlo so the x entries are never modified)
+__global__ __launch_bounds__(256) void k_backsub_update_range(const double *__restrict__ A,
+                                                              int64_t lda, double *__restrict__ b,
+                                                              int64_t top, int64_t rend, int64_t xlo,
+                                                              int64_t xhi) {
+  __shared__ double xs[BS_NB];
+  const int t = threadIdx.x;
+  const int nb = (int)(xhi - xlo);
+  if (t < nb) xs[t] = b[xlo + t];
+  __syncthreads();
+  const int64_t r = top + (int64_t)blockIdx.x * blockDim.x + t;
+  if (r >= rend) return;
+  double acc = 0.0;
+  for (int c = 0; c < nb; ++c) acc = fma(A[r + (xlo + c) * lda], xs[c], acc);
+  b[r] -= acc;
+}
+
 // partialdot hook: partial sums per workgroup, then one workgroup finishes.
 __global__ __launch_bounds__(256) void k_partialdot_partial(const double *__restrict__ a,
                                                             const double *__restrict__ b,
@@ -75,17 +93,20 @@ __global__ __launch_bounds__(256) void k_sum_final(const double *__restrict__ pa
   if (threadIdx.x == 0) *out = s;
 }
 
-// W = [R; 0] from the factor format: W[i,j] = A[i,j] (i<j), alpha[j] (i==j), 0 (i>j)
+// W = [R; 0] from the factor format: W[i,jl] = A[i,jl] (i<gj), alpha[gj] (i==gj), 0 (i>gj), with
+// gj the GLOBAL index of local column jl in a block-cyclic column layout (identity for 1 rank).
 __global__ __launch_bounds__(256) void k_form_r0(const double *__restrict__ A, int64_t lda,
                                                  const double *__restrict__ alpha, int64_t m,
-                                                 int64_t n, double *__restrict__ W, int64_t ldw) {
-  const int64_t j = blockIdx.y;
+                                                 int64_t ncols, double *__restrict__ W, int64_t ldw,
+                                                 int64_t cb, int nranks, int rank) {
+  const int64_t jl = blockIdx.y;
+  const int64_t j = ((jl / cb) * nranks + rank) * cb + jl % cb;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
     double x = 0.0;
-    if (i < j) x = A[i + j * lda];
+    if (i < j) x = A[i + jl * lda];
     else if (i == j) x = alpha[j];
-    W[i + j * ldw] = x;
+    W[i + jl * ldw] = x;
   }
 }
 

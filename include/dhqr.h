@@ -58,6 +58,7 @@ typedef struct dhqr_stats {
   int64_t n_panel, n_tbuild, n_gemm_vta, n_gemm_tw, n_gemm_avw, n_rank1, n_solve; /* launches */
   double flops_gemm_vta, flops_gemm_avw; /* algorithmic flops issued by the two trailing GEMMs */
   double bytes_rank1;                    /* algorithmic bytes (16 B / trailing element / reflector) */
+  double bytes_panel;                    /* same accounting for the in-panel rank-1 updates */
 } dhqr_stats;
 
 /* ------------------------------------------------------------------ library / context */
@@ -69,9 +70,11 @@ int32_t dhqr_device_count(int32_t *count);
  * there is NO CPU fallback).  Owns a stream and lazily grown workspaces. */
 int32_t dhqr_create(dhqr_ctx **ctx, int32_t device);
 int32_t dhqr_destroy(dhqr_ctx *ctx);
-/* Borrow the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores
- * the ctx-owned stream. */
+/* Run on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  NULL means the
+ * device's default (null) stream -- that IS torch's default stream.  dhqr_use_own_stream switches
+ * back to the ctx-owned non-blocking stream (the state after dhqr_create). */
 int32_t dhqr_set_stream(dhqr_ctx *ctx, void *hip_stream);
+int32_t dhqr_use_own_stream(dhqr_ctx *ctx);
 int32_t dhqr_synchronize(dhqr_ctx *ctx);
 int32_t dhqr_set_profiling(dhqr_ctx *ctx, int32_t on);
 int32_t dhqr_reset_stats(dhqr_ctx *ctx);
@@ -110,6 +113,16 @@ int32_t dhqr_qr_f64(dhqr_ctx *ctx, double *hA, int64_t m, int64_t n, int64_t lda
 int32_t dhqr_solve_f64(dhqr_ctx *ctx, const double *dA, int64_t m, int64_t n, int64_t lda,
                        const double *dalpha, double *db);
 
+/* One block step of the back substitution (src:244-282) for rows/columns [lo, hi):
+ *   do_diag  : solve the diagonal block in place in db[lo:hi] (divide by dalpha[lo:hi]);
+ *   do_update: db[0:lo] -= R[0:lo, lo:hi] * db[lo:hi].
+ * dAcols is addressed by GLOBAL column index: column j of R is read at dAcols + j*lda (a
+ * column-split caller passes its local block shifted accordingly).  dhqr_solve_f64 is this call
+ * looped over blocks; the distributed solve interleaves it with the all-reduce of the partial
+ * dots (replacing sum(fetch.(futures)), src:262-266).  Async. */
+int32_t dhqr_backsub_block_f64(dhqr_ctx *ctx, const double *dAcols, int64_t lda, const double *dalpha,
+                               double *db, int64_t lo, int64_t hi, int32_t do_diag, int32_t do_update);
+
 /* dhqr_ldiv_f64: host-in / host-out drop-in for `H \ b` (src:317-321): does NOT modify hb (the
  * reference copies b into a SharedArray first); writes hx[0:n].  Synchronous. */
 int32_t dhqr_ldiv_f64(dhqr_ctx *ctx, const double *hA, int64_t m, int64_t n, int64_t lda,
@@ -134,6 +147,16 @@ int32_t dhqr_residual_f64(dhqr_ctx *ctx, const double *dAfact, int64_t m, int64_
                           const double *dalpha, const double *dAorig, int64_t ldo, double *dwork,
                           double *hrel);
 
+/* Building blocks of the residual for a column-split matrix (same maps as dhqr_fill_uniform_f64):
+ * dW[:, jl] = [R; 0] column of local column jl (global index via the block-cyclic map; dalpha is
+ * the GLOBAL alpha vector).  Async. */
+int32_t dhqr_form_r0_f64(dhqr_ctx *ctx, const double *dA, int64_t m, int64_t cols, int64_t lda,
+                         const double *dalpha, double *dW, int64_t ldw, int64_t colblock,
+                         int32_t nranks, int32_t rank);
+/* hout2[0] = sum (X-Y)^2, hout2[1] = sum X^2 over an m x n block. Synchronous (host scalars). */
+int32_t dhqr_diff_norms_f64(dhqr_ctx *ctx, const double *dX, int64_t ldx, const double *dY, int64_t ldy,
+                            int64_t m, int64_t n, double *hout2);
+
 /* ------------------------------------------------------------------ panel level (multi-GPU)
  * The 1-D column-split driver (one process per GPU, torch.distributed/RCCL broadcast of the panel,
  * replacing the per-column @spawnat fan-out of src:141-143) is built from these two calls.
@@ -149,6 +172,10 @@ int64_t dhqr_panel_buffer_elems(int64_t rows);
  * panel's diagonal row) exactly like src:122-148 restricted to these columns, and emit dVT. Async. */
 int32_t dhqr_panel_factor_f64(dhqr_ctx *ctx, double *dP, int64_t rows, int64_t ncols, int64_t ldp,
                               double *dVT);
+/* Pack + T only, for a panel that is ALREADY factored (used when Q is re-applied, e.g. to form
+ * Q*R for the residual on a column-split matrix). Async. */
+int32_t dhqr_panel_pack_f64(dhqr_ctx *ctx, const double *dP, int64_t rows, int64_t ncols, int64_t ldp,
+                            double *dVT);
 /* dC (rows x ncols) <- (I - V T' V') dC  (trans = 1, the factorisation's trailing update,
  * src:198-213 blocked) or (I - V T V') dC (trans = 0). Async. */
 int32_t dhqr_panel_apply_f64(dhqr_ctx *ctx, const double *dVT, int64_t rows, double *dC,
@@ -160,6 +187,11 @@ int32_t dhqr_panel_apply_f64(dhqr_ctx *ctx, const double *dVT, int64_t rows, dou
  * copy in GB/s over `bytes` bytes. Synchronous. */
 int32_t dhqr_bench_mfma_f64(dhqr_ctx *ctx, double *tflops);
 int32_t dhqr_bench_stream_f64(dhqr_ctx *ctx, int64_t bytes, double *gbps);
+/* Issue-rate probe in shader cycles (s_memtime, DVFS independent): kind 0 = v_mfma_f64_16x16x4_f64,
+ * kind 1 = v_fma_f64; nblocks workgroups of 4 waves (one per SIMD), 16 independent chains per wave.
+ * Returns mean cycles per instruction per wave and the wall-clock TFLOP/s of the launch. */
+int32_t dhqr_bench_issue_f64(dhqr_ctx *ctx, int32_t kind, int32_t nblocks, double *cycles_per_instr,
+                             double *tflops);
 
 /* ------------------------------------------------------------------ test hook
  * One v_mfma_f64_16x16x4_f64 with A[i][k] = da[i*4+k], B[k][j] = db[k*16+j], C = 0, operands

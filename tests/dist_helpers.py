@@ -1,0 +1,157 @@
+"""Test-only helpers for the world_size-2 gloo tests: an oracle-backed CPU backend with the same
+interface as the product's HipBackend, so ColumnCyclicQR's orchestration (ownership, local
+offsets, broadcast order, look-ahead, α gathering, residual and solve pipelines) runs on CPU.
+The product never imports this file."""
+import math
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NB = 128
+
+
+def _ldv(rows):
+    return (rows + 15) // 16 * 16
+
+
+class OracleBackend:
+    def __init__(self):
+        from oracle import dhqr_oracle
+        self.orc = dhqr_oracle
+
+    def empty(self, m, n):
+        return torch.zeros((max(n, 1), m), dtype=torch.float64).t()
+
+    def zeros_vec(self, n):
+        return torch.zeros(n, dtype=torch.float64)
+
+    def panel_elems(self, rows):
+        return _ldv(rows) * NB + 2 * NB * NB + NB
+
+    def panel_buffer(self, rows):
+        return torch.zeros(self.panel_elems(rows), dtype=torch.float64)
+
+    def alpha_of(self, vt, rows):
+        off = _ldv(rows) * NB + 2 * NB * NB
+        return vt[off: off + NB]
+
+    def _views(self, vt, rows):
+        ldv = _ldv(rows)
+        v = vt.numpy()
+        V = v[: ldv * NB].reshape((ldv, NB), order="F")
+        T = v[ldv * NB: ldv * NB + NB * NB].reshape((NB, NB), order="F")
+        Tt = v[ldv * NB + NB * NB: ldv * NB + 2 * NB * NB].reshape((NB, NB), order="F")
+        al = v[ldv * NB + 2 * NB * NB: ldv * NB + 2 * NB * NB + NB]
+        return V, T, Tt, al
+
+    def fill(self, A, ncols, seed, gm, nb, nranks, rank):
+        a = A.numpy()
+        for jl in range(ncols):
+            gj = ((jl // nb) * nranks + rank) * nb + jl % nb
+            a[:, jl] = self.orc.u01(seed, np.arange(gm, dtype=np.uint64) + np.uint64(gj * gm))
+
+    def _pack(self, P, w, vt, rows, alpha=None):
+        V, T, Tt, al = self._views(vt, rows)
+        V[:] = 0.0
+        V[:rows, :w] = np.tril(P)
+        S = V.T @ V
+        T[:] = 0.0
+        for j in range(NB):
+            T[:j, j] = -T[:j, :j] @ S[:j, j]
+            T[j, j] = 1.0
+        Tt[:] = T.T
+        al[:] = 0.0
+        if alpha is not None:
+            al[:w] = alpha
+
+    def panel_factor(self, A, c0, lc0, w, vt):
+        a = A.numpy()
+        rows = a.shape[0] - c0
+        H, alpha = self.orc.householder(np.asfortranarray(a[c0:, lc0: lc0 + w]))
+        a[c0:, lc0: lc0 + w] = H
+        self._pack(H, w, vt, rows, alpha)
+
+    def panel_pack(self, A, c0, lc0, w, vt):
+        a = A.numpy()
+        self._pack(a[c0:, lc0: lc0 + w], w, vt, a.shape[0] - c0)
+
+    def panel_apply(self, vt, C, c0, lo, cnt, trans):
+        if cnt <= 0:
+            return
+        c = C.numpy()
+        rows = c.shape[0] - c0
+        V, T, Tt, _ = self._views(vt, rows)
+        V = V[:rows]
+        Top = T.T if trans else T
+        if c.ndim == 1:
+            blk = c[c0:]
+            blk -= V @ (Top @ (V.T @ blk))
+        else:
+            blk = c[c0:, lo: lo + cnt]
+            blk -= V @ (Top @ (V.T @ blk))
+
+    def form_r0(self, A, ncols, alpha, W, nb, nranks, rank):
+        a, w, al = A.numpy(), W.numpy(), alpha.numpy()
+        m = a.shape[0]
+        for jl in range(ncols):
+            gj = ((jl // nb) * nranks + rank) * nb + jl % nb
+            w[:, jl] = 0.0
+            w[:gj, jl] = a[:gj, jl]
+            if gj < m:
+                w[gj, jl] = al[gj]
+
+    def diff_norms(self, X, Y, ncols):
+        x, y = X.numpy()[:, :ncols], Y.numpy()[:, :ncols]
+        return float(((x - y) ** 2).sum()), float((x ** 2).sum())
+
+    def backsub_block(self, A, lc0, alpha, b, lo, hi, diag, update):
+        a, al, bb = A.numpy(), alpha.numpy(), b.numpy()
+        w = hi - lo
+        R = a[:, lc0: lc0 + w]
+        if diag:
+            for i in range(hi - 1, lo - 1, -1):
+                bb[i] = (bb[i] - R[i, i - lo + 1: w] @ bb[i + 1: hi]) / al[i]
+        if update and lo > 0:
+            bb[:lo] -= R[:lo, :] @ bb[lo:hi]
+
+    def synchronize(self):
+        pass
+
+
+def run_ranks(fn, world_size, *args):
+    """spawn `world_size` gloo ranks running fn(rank, world_size, *args); re-raise failures"""
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world_size, port, q, args)) for r in range(world_size)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    errs = [r for r in results if r[1] is not None]
+    if errs:
+        raise AssertionError("rank failures:\n" + "\n".join(f"[rank {r[0]}] {r[1]}" for r in errs))
+    return {r[0]: r[2] for r in results}
+
+
+def _entry(fn, rank, world_size, port, q, args):
+    try:
+        if ROOT not in sys.path:
+            sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["OMP_NUM_THREADS"] = "2"
+        dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        out = fn(rank, world_size, *args)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, None, out))
+    except BaseException:
+        q.put((rank, traceback.format_exc(), None))

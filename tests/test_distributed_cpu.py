@@ -1,0 +1,77 @@
+"""world_size-2 gloo tests (CPU):
+ 1. the reference's DArray structure restated (oracle/dist_oracle.py, BASELINE config 1:
+    512 x 512, nprocs = 2) equals the single-process oracle;
+ 2. the product's ColumnCyclicQR orchestration (block-cyclic split, one panel broadcast per
+    block, look-ahead, α replication, residual and solve pipelines) with an oracle-backed CPU
+    backend injected by the test equals the single-process oracle."""
+import numpy as np
+import pytest
+
+from dist_helpers import OracleBackend, run_ranks
+
+
+def _ref_darray(rank, P, m, n):
+    import torch.distributed as dist
+    from oracle import dhqr_oracle as orc
+    from oracle import dist_oracle as do
+    A = orc.rand_matrix(m, n, 0)
+    b = orc.rand_vector(m, 1)
+    lo, hi = do.column_blocks(n, P)[rank]
+    Al = np.array(A[:, lo:hi], order="F", copy=True)
+    alpha = np.zeros(n)
+    do.householder_darray(Al, m, n, alpha)
+    x = do.solve_darray(Al, m, n, alpha, b)
+    Ho, ao = orc.householder(A)
+    xo = orc.solve(Ho, ao, b)
+    scale = np.abs(Ho).max()
+    assert np.abs(Al - Ho[:, lo:hi]).max() <= 1e-12 * scale
+    assert np.abs(alpha - ao).max() <= 1e-12 * scale
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    return float(np.abs(Al - Ho[:, lo:hi]).max())
+
+
+@pytest.mark.parametrize("m,n,P", [(512, 512, 2), (110, 100, 2), (67, 33, 3)])
+def test_reference_darray_structure(m, n, P):
+    run_ranks(_ref_darray, P, m, n)
+
+
+def _cyclic(rank, P, m, n, lookahead):
+    import torch
+    import __graft_entry__ as g
+    from oracle import dhqr_oracle as orc
+    pkg = g.import_package()
+    q = pkg.ColumnCyclicQR(m, n, backend=OracleBackend(), lookahead=lookahead)
+    q.fill(5)
+    q.factor()
+    H, alpha = q.gather_full()
+    A = orc.rand_matrix(m, n, 5)
+    Ho, ao = orc.householder(A)
+    scale = np.abs(Ho).max()
+    assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
+    assert np.abs(alpha - ao).max() <= 1e-11 * scale
+    res = q.residual(5)
+    assert res < 1e-13, res
+    b = orc.rand_vector(m, 6)
+    x = q.solve(torch.from_numpy(b.copy())).numpy()
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    return res
+
+
+@pytest.mark.parametrize("lookahead", [True, False])
+@pytest.mark.parametrize("m,n,P", [(300, 260, 2), (700, 520, 2), (400, 385, 3), (200, 100, 2), (640, 640, 2)])
+def test_column_cyclic_orchestration(m, n, P, lookahead):
+    run_ranks(_cyclic, P, m, n, lookahead)
+
+
+def test_single_rank_without_process_group():
+    import __graft_entry__ as g
+    from oracle import dhqr_oracle as orc
+    pkg = g.import_package()
+    q = pkg.ColumnCyclicQR(300, 200, backend=OracleBackend())
+    q.fill(2)
+    q.factor()
+    H, alpha = q.gather_full()
+    Ho, ao = orc.householder(orc.rand_matrix(300, 200, 2))
+    assert np.abs(H - Ho).max() <= 1e-11 * np.abs(Ho).max()
+    assert q.residual(2) < 1e-13

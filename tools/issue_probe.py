@@ -1,0 +1,11 @@
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+pkg = g.import_package()
+ctx = pkg.get_context(0)
+L = pkg._lib.lib()
+for kind, name in ((0, "v_mfma_f64_16x16x4_f64"), (1, "v_fma_f64")):
+    for nb in (1, 8, 256, 1024, 2048):
+        c, t = ctypes.c_double(), ctypes.c_double()
+        pkg._lib.check(L.dhqr_bench_issue_f64(ctx.handle, kind, nb, ctypes.byref(c), ctypes.byref(t)))
+        print(f"{name}: blocks={nb:5d} cycles/instr/wave={c.value:8.2f} wall TFLOP/s={t.value:8.2f}", flush=True)
