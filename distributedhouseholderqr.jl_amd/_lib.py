@@ -79,6 +79,7 @@ SIGNATURES = {
     "dhqr_panel_apply_f64": (_i32, [_p, _p, _i64, _p, _i64, _i64, _i32]),
     "dhqr_bench_mfma_f64": (_i32, [_p, _pd]),
     "dhqr_bench_issue_f64": (_i32, [_p, _i32, _i32, _pd, _pd]),
+    "dhqr_bench_issue2_f64": (_i32, [_p, _i32, _i32, _i32, _pd]),
     "dhqr_bench_stream_f64": (_i32, [_p, _i64, _pd]),
     "dhqr_debug_mfma_probe": (_i32, [_p, _p, _p, _p]),
 }

@@ -12,6 +12,7 @@
 #include "../../include/dhqr.h"
 #include "dhqr_common.h"
 #include "dhqr_gemm.h"
+#include "dhqr_panel.h"
 #include "dhqr_rank1.h"
 #include "dhqr_solve.h"
 
@@ -48,7 +49,9 @@ struct dhqr_ctx {
   int device = 0;
   hipStream_t own = nullptr, stream = nullptr;
   bool profiling = false;
-  Buf vbuf, vt, w1, w2, spart, sfull, scratch;
+  Buf vbuf, vt, vts, w1, w2, spart, sfull, scratch, pbuf;
+  int panel_impl = 2;  // 2: row-split sub-panel kernels (dhqr_panel.h); 1: one workgroup per column
+  int ib = DHQR_IB;
   // profiling
   struct Ev { hipEvent_t a, b; int cat; };
   std::vector<Ev> evs;
@@ -169,19 +172,33 @@ static inline int64_t panel_elems(int64_t rows) {
   return panel_ldv(rows) * DHQR_NBV + 2 * DHQR_NBV * DHQR_NBV + DHQR_NBV;
 }
 
+// Split-K factor for k_gemm_tn: `ntiles` column tiles x ns row slabs should fill the 512 resident
+// workgroup slots (256 CUs x 2) in whole waves -- 765 workgroups on 512 slots run at 75 %.
 static void pick_split(int64_t rows, int64_t ntiles, int64_t target_wgs, int64_t max_split,
                        int64_t *nsplit, int64_t *rps) {
-  int64_t ns = (target_wgs + ntiles - 1) / ntiles;
-  ns = std::min(ns, max_split);
-  ns = std::min(ns, std::max<int64_t>(1, rows / 128));
-  ns = std::max<int64_t>(ns, 1);
-  int64_t r = (rows + ns - 1) / ns;
+  const int64_t slots = 512;
+  int64_t cap = std::min<int64_t>(max_split, std::max<int64_t>(1, rows / 128));
+  int64_t best = 1;
+  double best_score = -1.0;
+  for (int64_t ns = 1; ns <= cap; ++ns) {
+    const int64_t wgs = ntiles * ns;
+    const int64_t waves = (wgs + slots - 1) / slots;
+    double eff = (double)wgs / (double)(waves * slots);
+    if (wgs < target_wgs && wgs < slots) eff *= 0.999;  // fine, just not full
+    // prefer fewer splits at equal efficiency (less partial traffic); stop growing past 4 waves
+    const double score = eff - 1e-4 * (double)ns - (waves > 4 ? 0.05 : 0.0);
+    if (score > best_score) { best_score = score; best = ns; }
+    if (wgs >= 4 * slots) break;
+  }
+  int64_t r = (rows + best - 1) / best;
   r = (r + G_KT - 1) / G_KT * G_KT;
   if (r < G_KT) r = G_KT;
   *rps = r;
-  *nsplit = (rows + r - 1) / r;
-  if (*nsplit < 1) *nsplit = 1;
+  *nsplit = std::max<int64_t>(1, (rows + r - 1) / r);
 }
+
+// T / T' of a packed panel buffer whose V part is already in place (ncols real columns).
+static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *vt);
 
 // Pack V (R part zeroed) and build T / T' for a factored panel P (rows x ncols, ncols <= 128).
 static int32_t panel_pack_and_t(dhqr_ctx *c, const double *P, int64_t rows, int64_t ncols,
@@ -193,24 +210,32 @@ static int32_t panel_pack_and_t(dhqr_ctx *c, const double *P, int64_t rows, int6
     dim3 grid((unsigned)std::min<int64_t>((ldv + 255) / 256, 64), DHQR_NBV);
     hipLaunchKernelGGL(k_pack_v, grid, dim3(256), 0, c->stream, P, ldp, rows, ncols, V, ldv);
   }
-  int64_t nsplit, rps;
-  pick_split(rows, 1, 128, 128, &nsplit, &rps);
-  CHECK(ensure(c, c->spart, (size_t)nsplit * DHQR_NBV * DHQR_NBV));
-  CHECK(ensure(c, c->sfull, (size_t)DHQR_NBV * DHQR_NBV));
-  hipLaunchKernelGGL((k_gemm_tn<2>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, V, ldv, V,
-                     ldv, 1, (int64_t)0, rows, (int64_t)DHQR_NBV, rps, c->spart.p,
-                     (int64_t)DHQR_NBV, (int64_t)DHQR_NBV * DHQR_NBV);
-  hipLaunchKernelGGL(k_reduce_splits, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream,
-                     c->spart.p, (int)nsplit, (int64_t)DHQR_NBV * DHQR_NBV,
-                     (int64_t)DHQR_NBV * DHQR_NBV, c->sfull.p);
-  hipLaunchKernelGGL(k_build_t, dim3(1), dim3(128), 0, c->stream, c->sfull.p, vt_T(vt, rows),
-                     vt_Tt(vt, rows));
+  CHECK(panel_build_t(c, rows, ncols, vt));
   if (alpha) {  // nullptr: the caller already placed alpha in the buffer tail (or does not need it)
     HIPCHECK(hipMemsetAsync(vt_alpha(vt, rows), 0, DHQR_NBV * sizeof(double), c->stream));
     HIPCHECK(hipMemcpyAsync(vt_alpha(vt, rows), alpha, (size_t)ncols * sizeof(double),
                             hipMemcpyDeviceToDevice, c->stream));
   }
   CHECK(prof_end(c));
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *vt) {
+  const int64_t ldv = panel_ldv(rows);
+  double *V = vt;
+  int64_t nsplit, rps;
+  pick_split(rows, 1, 128, 128, &nsplit, &rps);
+  CHECK(ensure(c, c->spart, (size_t)nsplit * DHQR_NBV * DHQR_NBV));
+  CHECK(ensure(c, c->sfull, (size_t)DHQR_NBV * DHQR_NBV));
+  hipLaunchKernelGGL((k_gemm_tn<2, 1>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, V, ldv, V,
+                     ldv, 1, (int64_t)0, rows, (int64_t)DHQR_NBV, rps, c->spart.p,
+                     (int64_t)DHQR_NBV, (int64_t)DHQR_NBV * DHQR_NBV);
+  hipLaunchKernelGGL(k_reduce_splits, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream,
+                     c->spart.p, (int)nsplit, (int64_t)DHQR_NBV * DHQR_NBV,
+                     (int64_t)DHQR_NBV * DHQR_NBV, c->sfull.p);
+  hipLaunchKernelGGL(k_build_t2, dim3(1), dim3(128), 0, c->stream, (const double *)c->sfull.p,
+                     (int)ncols, vt_T(vt, rows), vt_Tt(vt, rows));
   LAUNCHCHECK();
   return DHQR_OK;
 }
@@ -232,17 +257,17 @@ static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *
 
   CHECK(prof_begin(c, CAT_VTA));
   if (vec)
-    hipLaunchKernelGGL((k_gemm_tn<2>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(256), 0,
+    hipLaunchKernelGGL((k_gemm_tn<2, 1>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(256), 0,
                        c->stream, V, ldv, (const double *)C, ldc, 1, (int64_t)0, rows, ncols, rps,
                        c->w1.p, (int64_t)DHQR_NBV, wstride);
   else
-    hipLaunchKernelGGL((k_gemm_tn<1>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(256), 0,
+    hipLaunchKernelGGL((k_gemm_tn<1, 1>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(256), 0,
                        c->stream, V, ldv, (const double *)C, ldc, 1, (int64_t)0, rows, ncols, rps,
                        c->w1.p, (int64_t)DHQR_NBV, wstride);
   CHECK(prof_end(c));
 
   CHECK(prof_begin(c, CAT_TW));
-  hipLaunchKernelGGL((k_gemm_tn<2>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top,
+  hipLaunchKernelGGL((k_gemm_tn<2, 0>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top,
                      (int64_t)DHQR_NBV, (const double *)c->w1.p, (int64_t)DHQR_NBV, (int)nsplit,
                      wstride, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV, c->w2.p,
                      (int64_t)DHQR_NBV, (int64_t)0);
@@ -251,10 +276,10 @@ static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *
   CHECK(prof_begin(c, CAT_AVW));
   dim3 grid((unsigned)((rows + 127) / 128), (unsigned)ntiles);
   if (vec)
-    hipLaunchKernelGGL((k_gemm_nn_sub<2>), grid, dim3(256), 0, c->stream, V, ldv,
+    hipLaunchKernelGGL((k_gemm_nn_sub<2, 128>), grid, dim3(256), 0, c->stream, V, ldv,
                        (const double *)c->w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols);
   else
-    hipLaunchKernelGGL((k_gemm_nn_sub<1>), grid, dim3(256), 0, c->stream, V, ldv,
+    hipLaunchKernelGGL((k_gemm_nn_sub<1, 128>), grid, dim3(256), 0, c->stream, V, ldv,
                        (const double *)c->w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols);
   CHECK(prof_end(c));
   if (c->profiling) {
@@ -263,6 +288,87 @@ static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *
   }
   LAUNCHCHECK();
   return DHQR_OK;
+}
+
+// ---- panel factorisation, row-split sub-panel version (dhqr_panel.h) --------------------------
+// Factors the rows x w panel P in place, writes alpha[0:w], and leaves the packed V, T, T', alpha in
+// `vt` (the operand of the trailing update / the broadcast buffer).
+static int32_t factor_panel_v2(dhqr_ctx *c, double *P, int64_t rows, int64_t w, int64_t ldp,
+                               double *alpha, double *vt) {
+  const int64_t ldvw = panel_ldv(rows);
+  const int ib = c->ib;
+  const int64_t nchmax = (rows + PS_RC - 1) / PS_RC;
+  const int64_t rpad = (rows + 31) & ~(int64_t)15;
+  CHECK(ensure(c, c->pbuf, (size_t)(2 * rpad + 2 * DHQR_NBV + 2 * (int64_t)ib * nchmax + 64)));
+  CHECK(ensure(c, c->vts, (size_t)panel_elems(rows)));
+  double *piv[2] = {c->pbuf.p, c->pbuf.p + rpad};
+  double *prow[2] = {c->pbuf.p + 2 * rpad, c->pbuf.p + 2 * rpad + DHQR_NBV};
+  double *part[2] = {c->pbuf.p + 2 * rpad + 2 * DHQR_NBV, c->pbuf.p + 2 * rpad + 2 * DHQR_NBV + (int64_t)ib * nchmax};
+  const bool vec = (ldp % 2 == 0) && (rows % 2 == 0) && aligned16(P);
+  CHECK(prof_begin(c, CAT_PANEL));
+  const bool was = c->profiling;
+  c->profiling = false;  // the nested T builds / GEMMs are accounted to the panel
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMemsetAsync(vt, 0, (size_t)ldvw * DHQR_NBV * sizeof(double), c->stream));
+    for (int64_t j0 = 0; j0 < w; j0 += ib) {
+      const int ncs = (int)std::min<int64_t>(ib, w - j0);
+      const int64_t rows_s = rows - j0;
+      double *Ps = P + j0 + j0 * ldp;
+      const int nch = (int)((rows_s + PS_RC - 1) / PS_RC);
+      const int64_t ldvs = panel_ldv(rows_s);
+      HIPCHECK(hipMemsetAsync(c->vts.p, 0, (size_t)ldvs * DHQR_NBV * sizeof(double), c->stream));
+      if (vec)
+        hipLaunchKernelGGL((k_panel_init<2>), dim3(nch, ncs), dim3(256), 0, c->stream, (const double *)Ps, ldp,
+                           rows_s, piv[0], prow[0], part[0], nch);
+      else
+        hipLaunchKernelGGL((k_panel_init<1>), dim3(nch, ncs), dim3(256), 0, c->stream, (const double *)Ps, ldp,
+                           rows_s, piv[0], prow[0], part[0], nch);
+      for (int q = 0; q < ncs; ++q) {
+        dim3 grid(nch - q / PS_RC, ncs - q);
+        double *vwq = vt + j0 + (j0 + q) * ldvw;
+        if (vec)
+          hipLaunchKernelGGL((k_panel_step<2>), grid, dim3(256), 0, c->stream, Ps, ldp, rows_s, q, ncs,
+                             (const double *)piv[q & 1], piv[(q + 1) & 1], (const double *)prow[q & 1],
+                             prow[(q + 1) & 1], (const double *)part[q & 1], part[(q + 1) & 1], nch, c->vts.p,
+                             ldvs, vwq, ldvw, alpha + j0 + q);
+        else
+          hipLaunchKernelGGL((k_panel_step<1>), grid, dim3(256), 0, c->stream, Ps, ldp, rows_s, q, ncs,
+                             (const double *)piv[q & 1], piv[(q + 1) & 1], (const double *)prow[q & 1],
+                             prow[(q + 1) & 1], (const double *)part[q & 1], part[(q + 1) & 1], nch, c->vts.p,
+                             ldvs, vwq, ldvw, alpha + j0 + q);
+      }
+      if (j0 + ncs < w) {  // block reflector of this sub-panel onto the rest of the panel (MFMA)
+        CHECK(panel_build_t(c, rows_s, ncs, c->vts.p));
+        CHECK(panel_apply(c, c->vts.p, rows_s, P + j0 + (j0 + ncs) * ldp, w - j0 - ncs, ldp, 1));
+      }
+    }
+    {
+      dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), (unsigned)w);
+      hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, P, ldp, rows, w, (const double *)vt, ldvw);
+    }
+    CHECK(panel_build_t(c, rows, w, vt));
+    HIPCHECK(hipMemsetAsync(vt_alpha(vt, rows), 0, DHQR_NBV * sizeof(double), c->stream));
+    HIPCHECK(hipMemcpyAsync(vt_alpha(vt, rows), alpha, (size_t)w * sizeof(double), hipMemcpyDeviceToDevice,
+                            c->stream));
+    LAUNCHCHECK();
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  c->profiling = was;
+  CHECK(rc);
+  if (c->profiling) {
+    for (int64_t j = 0; j + 1 < w; ++j) c->st.bytes_panel += 16.0 * (double)(rows - j) * (double)(w - j - 1);
+  }
+  CHECK(prof_end(c));
+  return DHQR_OK;
+}
+
+// Factor one panel and leave (V, T, T', alpha) packed in vt.
+static int32_t factor_panel(dhqr_ctx *c, double *P, int64_t rows, int64_t w, int64_t ldp, double *alpha,
+                            double *vt) {
+  if (c->panel_impl == 2) return factor_panel_v2(c, P, rows, w, ldp, alpha, vt);
+  CHECK(factor_unblocked_cols(c, P, rows, w, ldp, alpha, CAT_PANEL));
+  return panel_pack_and_t(c, P, rows, w, ldp, alpha, vt);
 }
 
 static int32_t check_ctx(dhqr_ctx *c) {
@@ -338,6 +444,11 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
   memset(&c->st, 0, sizeof(c->st));
   HIPCHECK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
   c->stream = c->own;
+  if (const char *e = getenv("DHQR_PANEL")) c->panel_impl = atoi(e) == 1 ? 1 : 2;
+  if (const char *e = getenv("DHQR_IB")) {
+    const int v = atoi(e);
+    if (v == 16 || v == 32 || v == 64 || v == 128) c->ib = v;
+  }
   *out = c;
   return DHQR_OK;
 }
@@ -346,7 +457,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   if (!c) return DHQR_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  Buf *bufs[] = {&c->vbuf, &c->vt, &c->w1, &c->w2, &c->spart, &c->sfull, &c->scratch};
+  Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->w1, &c->w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {
@@ -421,11 +532,8 @@ int32_t dhqr_factor_f64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t l
   for (int64_t c0 = 0; c0 < n; c0 += DHQR_NBV) {
     const int64_t w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
     double *P = dA + c0 + c0 * lda;
-    CHECK(factor_unblocked_cols(c, P, rows, w, lda, dalpha + c0, CAT_PANEL));
-    if (c0 + w < n) {
-      CHECK(panel_pack_and_t(c, P, rows, w, lda, dalpha + c0, c->vt.p));
-      CHECK(panel_apply(c, c->vt.p, rows, dA + c0 + (c0 + w) * lda, n - c0 - w, lda, 1));
-    }
+    CHECK(factor_panel(c, P, rows, w, lda, dalpha + c0, c->vt.p));
+    if (c0 + w < n) CHECK(panel_apply(c, c->vt.p, rows, dA + c0 + (c0 + w) * lda, n - c0 - w, lda, 1));
   }
   return DHQR_OK;
 }
@@ -600,11 +708,10 @@ int32_t dhqr_panel_factor_f64(dhqr_ctx *c, double *dP, int64_t rows, int64_t nco
   CHECK(check_mat(dP, rows, ncols, ldp, true));
   if (ncols > DHQR_NB) return set_err(DHQR_EINVAL, "panel wider than %d", DHQR_NB);
   if (!dVT || !aligned16(dVT)) return set_err(DHQR_EINVAL, "dVT must be a 16-byte aligned device buffer");
-  // alpha of the panel lives in the tail of dVT; factor writes it there directly
-  double *al = vt_alpha(dVT, rows);
-  HIPCHECK(hipMemsetAsync(al, 0, DHQR_NBV * sizeof(double), c->stream));
-  CHECK(factor_unblocked_cols(c, dP, rows, ncols, ldp, al, CAT_PANEL));
-  return panel_pack_and_t(c, dP, rows, ncols, ldp, nullptr, dVT);
+  // alpha is produced in a small scratch vector and packed into the tail of dVT by factor_panel
+  CHECK(ensure(c, c->scratch, 4096));
+  double *al = c->scratch.p + 3072;
+  return factor_panel(c, dP, rows, ncols, ldp, al, dVT);
 }
 
 int32_t dhqr_panel_pack_f64(dhqr_ctx *c, const double *dP, int64_t rows, int64_t ncols, int64_t ldp,
@@ -712,6 +819,43 @@ int32_t dhqr_bench_issue_f64(dhqr_ctx *c, int32_t kind, int32_t nblocks, double 
   *cycles_per_instr = sum / (double)h.size() / ((double)iters * 16.0);
   const double flop_per_instr = kind == 0 ? 2048.0 : 128.0;
   *tflops = (double)nblocks * 4.0 * iters * 16.0 * flop_per_instr / ((double)ms * 1e-3) / 1e12;
+  return DHQR_OK;
+}
+
+int32_t dhqr_bench_issue2_f64(dhqr_ctx *c, int32_t mode, int32_t threads, int32_t nblocks, double *out4) {
+  CHECK(check_ctx(c));
+  if (!out4 || nblocks <= 0 || nblocks > 4096 || mode < 0 || mode > 2 || threads % 256 || threads > 1024)
+    return set_err(DHQR_EINVAL, "bad arguments");
+  const int iters = 1000, wpb = threads / 64;
+  CHECK(ensure(c, c->scratch, (size_t)nblocks * threads + 4096 + (size_t)nblocks * wpb + 16));
+  double *sink = c->scratch.p;
+  long long *cyc = (long long *)(c->scratch.p + (size_t)nblocks * threads + 4096);
+  hipEvent_t a, b;
+  HIPCHECK(hipEventCreate(&a));
+  HIPCHECK(hipEventCreate(&b));
+  for (int rep = 0; rep < 2; ++rep) {
+    HIPCHECK(hipEventRecord(a, c->stream));
+    hipLaunchKernelGGL(k_issue_probe2, dim3(nblocks), dim3(threads), 0, c->stream, sink, cyc, iters, (int)mode);
+    HIPCHECK(hipEventRecord(b, c->stream));
+    HIPCHECK(hipEventSynchronize(b));
+  }
+  float ms = 0.f;
+  HIPCHECK(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  std::vector<long long> h((size_t)nblocks * wpb);
+  HIPCHECK(hipMemcpy(h.data(), cyc, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+  double sm = 0, sv = 0;
+  int64_t nm = 0, nv = 0;
+  for (size_t i = 0; i < h.size(); ++i) {
+    const int wave = (int)(i % wpb);
+    const bool mf = (mode == 0) || (mode == 2 && wave < 4);
+    if (mf) { sm += (double)h[i]; nm++; } else { sv += (double)h[i]; nv++; }
+  }
+  out4[0] = nm ? sm / nm / (iters * 8.0) : 0.0;          // cycles per MFMA per wave
+  out4[1] = nv ? sv / nv / (iters * 8.0 * 16.0) : 0.0;   // cycles per v_fma_f64 per wave
+  out4[2] = (double)nm * iters * 8.0 * 2048.0 / (ms * 1e-3) / 1e12;
+  out4[3] = (double)nv * iters * 8.0 * 16.0 * 128.0 / (ms * 1e-3) / 1e12;
   return DHQR_OK;
 }
 

@@ -39,7 +39,7 @@ __device__ __forceinline__ dhqr_d4 mfma_f64(double a, double b, dhqr_d4 c) {
 // VEC = 2: 16-byte global loads (host guarantees rows, ldv, ldc even and 16-byte aligned bases).
 // All global loads are unconditional (clamped offset + select): no branch sits between a load
 // and its use, so the whole next K-tile is in flight behind the current tile's 64 MFMAs.
-template <int VEC>
+template <int VEC, int NCS>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V, int64_t ldv,
                                                     const double *__restrict__ C, int64_t ldc,
                                                     int ncsplit, int64_t csplit_stride,
@@ -77,6 +77,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
     offv[i] = (uint32_t)(col * ldv);
     offc[i] = (uint32_t)((okc[i] ? col : 0) * ldc);
   }
+  // Software pipeline: load_tile only ISSUES the global loads of the next K-tile (raw values stay
+  // in registers, nothing consumes them), the 64 MFMAs of the current tile run, and only then
+  // store_tile masks the out-of-range lanes and writes LDS.  (Masking right after the load made
+  // the compiler wait for vmcnt(0) BEFORE the MFMA block -- no overlap at all.)
   double2 sv[4], sc[4];
   auto load_tile = [&](int kt) {
     const int left = (int)(rend - rbeg) - kt * G_KT;  // valid rows in this K-tile (>0)
@@ -85,54 +89,63 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rp = (t + i * 256) & 7;
-      double2 x, y = make_double2(0.0, 0.0);
       if constexpr (VEC == 2) {
-        const bool ok = 2 * rp < left;  // rows even => the pair is all-or-nothing
-        const uint32_t ro = ok ? 2 * rp : 0;
-        x = *reinterpret_cast<const double2 *>(Vt + (offv[i] + ro));
-        for (int qs = 0; qs < ncsplit; ++qs) {
-          const double2 z = *reinterpret_cast<const double2 *>(Ct + (int64_t)qs * csplit_stride + (offc[i] + ro));
-          y.x += z.x; y.y += z.y;
+        const uint32_t ro = (2 * rp < left) ? 2 * rp : 0;  // rows even => pair all-or-nothing
+        sv[i] = *reinterpret_cast<const double2 *>(Vt + (offv[i] + ro));
+        if constexpr (NCS == 1) {
+          sc[i] = *reinterpret_cast<const double2 *>(Ct + (offc[i] + ro));
+        } else {
+          double2 y = make_double2(0.0, 0.0);
+          for (int qs = 0; qs < ncsplit; ++qs) {
+            const double2 z = *reinterpret_cast<const double2 *>(Ct + (int64_t)qs * csplit_stride + (offc[i] + ro));
+            y.x += z.x; y.y += z.y;
+          }
+          sc[i] = y;
         }
-        if (!ok) x = make_double2(0.0, 0.0);
-        if (!ok || !okc[i]) y = make_double2(0.0, 0.0);
       } else {
-        const bool ok0 = 2 * rp < left, ok1 = 2 * rp + 1 < left;
-        const uint32_t r0o = ok0 ? 2 * rp : 0, r1o = ok1 ? 2 * rp + 1 : 0;
-        x.x = Vt[offv[i] + r0o];
-        x.y = Vt[offv[i] + r1o];
-        for (int qs = 0; qs < ncsplit; ++qs) {
-          const double *Cq = Ct + (int64_t)qs * csplit_stride;
-          y.x += Cq[offc[i] + r0o];
-          y.y += Cq[offc[i] + r1o];
+        const uint32_t r0o = (2 * rp < left) ? 2 * rp : 0, r1o = (2 * rp + 1 < left) ? 2 * rp + 1 : 0;
+        sv[i].x = Vt[offv[i] + r0o];
+        sv[i].y = Vt[offv[i] + r1o];
+        if constexpr (NCS == 1) {
+          sc[i].x = Ct[offc[i] + r0o];
+          sc[i].y = Ct[offc[i] + r1o];
+        } else {
+          double2 y = make_double2(0.0, 0.0);
+          for (int qs = 0; qs < ncsplit; ++qs) {
+            const double *Cq = Ct + (int64_t)qs * csplit_stride;
+            y.x += Cq[offc[i] + r0o];
+            y.y += Cq[offc[i] + r1o];
+          }
+          sc[i] = y;
         }
-        if (!ok0) x.x = 0.0;
-        if (!ok1) x.y = 0.0;
-        if (!ok0 || !okc[i]) y.x = 0.0;
-        if (!ok1 || !okc[i]) y.y = 0.0;
       }
-      sv[i] = x;
-      sc[i] = y;
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, int kt) {
+    const int left = (int)(rend - rbeg) - kt * G_KT;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = t + i * 256;
       const int col = q >> 3, rp = q & 7;
-      *reinterpret_cast<double2 *>(&Vs[buf][col * G_LDK + 2 * rp]) = sv[i];
-      *reinterpret_cast<double2 *>(&Cs[buf][col * G_LDK + 2 * rp]) = sc[i];
+      const bool ok0 = 2 * rp < left, ok1 = 2 * rp + 1 < left;
+      double2 x = sv[i], y = sc[i];
+      if (!ok0) { x.x = 0.0; y.x = 0.0; }
+      if (!ok1) { x.y = 0.0; y.y = 0.0; }
+      if (!okc[i]) y = make_double2(0.0, 0.0);
+      *reinterpret_cast<double2 *>(&Vs[buf][col * G_LDK + 2 * rp]) = x;
+      *reinterpret_cast<double2 *>(&Cs[buf][col * G_LDK + 2 * rp]) = y;
     }
   };
 
   if (nkt > 0) {
     load_tile(0);
-    store_tile(0);
+    store_tile(0, 0);
   }
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) load_tile(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the load issue above, their consumers below the MFMAs
     const double *cs = &Cs[buf][(wc * 64 + i16) * G_LDK + k4];
     const double *vs = &Vs[buf][(wp * 64 + i16) * G_LDK + k4];
 #pragma unroll
@@ -148,7 +161,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) acc[ci][pi] = mfma_f64(a[ci], b[pi], acc[ci][pi]);
     }
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nkt) store_tile(buf ^ 1, kt + 1);
     __syncthreads();
   }
 
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
 //   r in [0,rows), c in [0,ncols).  grid = (ceil(rows/128), ceil(ncols/128)).
 // The accumulators are initialised with the C tile and the W operand is negated while staging,
 // so the MFMA chain itself performs the subtraction.
-template <int VEC>
+template <int VEC, int KW>
 __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict__ V, int64_t ldv,
                                                         const double *__restrict__ W, int64_t ldw,
                                                         double *__restrict__ C, int64_t ldc,
@@ -205,35 +219,32 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
     offw[i] = (uint32_t)((okw[i] ? col : 0) * ldw) + 2 * pp;
   }
   double2 sv[4], sw[4];
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt) {  // issue only; masking / negation happen in store_tile
     const double *Vt = Vb + (int64_t)kt * G_KT * ldv;
     const double *Wt = Wb + kt * G_KT;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      double2 x, y;
       if constexpr (VEC == 2) {
-        x = *reinterpret_cast<const double2 *>(Vt + offv[i]);  // rows even: pair all-or-nothing
-        y = *reinterpret_cast<const double2 *>(Wt + offw[i]);
-        if (!okv0[i]) x = make_double2(0.0, 0.0);
+        sv[i] = *reinterpret_cast<const double2 *>(Vt + offv[i]);  // rows even: pair all-or-nothing
+        sw[i] = *reinterpret_cast<const double2 *>(Wt + offw[i]);
       } else {
-        x.x = Vt[offv[i]];
-        x.y = Vt[offv[i] + (okv1[i] ? 1 : 0)];
-        y.x = Wt[offw[i]];
-        y.y = Wt[offw[i] + 1];
-        if (!okv0[i]) x.x = 0.0;
-        if (!okv1[i]) x.y = 0.0;
+        sv[i].x = Vt[offv[i]];
+        sv[i].y = Vt[offv[i] + (okv1[i] ? 1 : 0)];
+        sw[i].x = Wt[offw[i]];
+        sw[i].y = Wt[offw[i] + 1];
       }
-      if (!okw[i]) y = make_double2(0.0, 0.0);
-      sv[i] = x;
-      sw[i] = make_double2(-y.x, -y.y);
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = t + i * 256;
-      *reinterpret_cast<double2 *>(&Vs[buf][(q >> 6) * G_LDR + 2 * (q & 63)]) = sv[i];
-      *reinterpret_cast<double2 *>(&Ws[buf][(q >> 3) * G_LDK + 2 * (q & 7)]) = sw[i];
+      double2 x = sv[i], y = sw[i];
+      if (!okv0[i]) x.x = 0.0;
+      if (!okv1[i]) x.y = 0.0;
+      if (!okw[i]) y = make_double2(0.0, 0.0);
+      *reinterpret_cast<double2 *>(&Vs[buf][(q >> 6) * G_LDR + 2 * (q & 63)]) = x;
+      *reinterpret_cast<double2 *>(&Ws[buf][(q >> 3) * G_LDK + 2 * (q & 7)]) = make_double2(-y.x, -y.y);
     }
   };
 
@@ -260,11 +271,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
 
   store_tile(0);
   __syncthreads();
-  constexpr int NKT = DHQR_NBV / G_KT;
+  constexpr int NKT = KW / G_KT;
 #pragma unroll 1
   for (int kt = 0; kt < NKT; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < NKT) load_tile(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
     const double *ws = &Ws[buf][(wc * 64 + i16) * G_LDK + k4];
     const double *vs = &Vs[buf][k4 * G_LDR + wr * 64 + i16];
 #pragma unroll
@@ -280,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = mfma_f64(a[ci], b[ri], acc[ci][ri]);
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < NKT) store_tile(buf ^ 1);
     __syncthreads();
   }
@@ -404,6 +417,47 @@ __global__ __launch_bounds__(256) void k_issue_probe(double *__restrict__ sink,
   }
   sink[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+// Second probe: several waves per SIMD and MFMA/VALU co-issue.  mode 0: every wave MFMA; mode 1:
+// every wave v_fma_f64; mode 2: waves 0-3 of the workgroup MFMA, the others VALU (blockDim 512:
+// one MFMA wave + one VALU wave per SIMD).  8 independent chains per wave (low register use, so
+// blockDim up to 1024 = 4 waves per SIMD fits).
+__global__ __launch_bounds__(1024) void k_issue_probe2(double *__restrict__ sink,
+                                                       long long *__restrict__ cyc, int iters,
+                                                       int mode) {
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  const int wave = threadIdx.x >> 6;
+  const bool do_mfma = (mode == 0) || (mode == 2 && wave < 4);
+  long long t0, t1;
+  double s = 0.0;
+  if (do_mfma) {
+    dhqr_d4 acc[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) acc[x] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+    t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) acc[x] = mfma_f64(a, b, acc[x]);
+    }
+    t1 = clock64();
+#pragma unroll
+    for (int x = 0; x < 8; ++x) s += acc[x][0] + acc[x][1] + acc[x][2] + acc[x][3];
+  } else {
+    double acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acc[x] = threadIdx.x * 1e-3 + x;
+    t0 = clock64();
+    for (int it = 0; it < iters * 8; ++it) {  // 16 FMA per trip: ~same duration as the MFMA waves
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[x] = fma(acc[x], a, b);
+    }
+    t1 = clock64();
+#pragma unroll
+    for (int x = 0; x < 16; ++x) s += acc[x];
+  }
+  sink[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + wave] = t1 - t0;
 }
 
 // streaming read+write micro-benchmark (y = x + 1 on double2)

@@ -199,6 +199,10 @@ int32_t dhqr_bench_issue_f64(dhqr_ctx *ctx, int32_t kind, int32_t nblocks, doubl
  * tests/test_gpu_kernels.py uses it to pin the f64 C/D fragment layout on the device. Synchronous. */
 int32_t dhqr_debug_mfma_probe(dhqr_ctx *ctx, const double *da, const double *db, double *dout);
 
+/* Probe 2: `threads`/256 waves per SIMD; mode 0 all-MFMA, 1 all-v_fma_f64, 2 mixed (waves 0-3 MFMA,
+ * rest VALU).  out4 = {cycles/MFMA/wave, cycles/v_fma_f64/wave, MFMA TFLOP/s, VALU TFLOP/s}. */
+int32_t dhqr_bench_issue2_f64(dhqr_ctx *ctx, int32_t mode, int32_t threads, int32_t nblocks, double *out4);
+
 #ifdef __cplusplus
 }
 #endif
