@@ -49,7 +49,12 @@ struct dhqr_ctx {
   int device = 0;
   hipStream_t own = nullptr, stream = nullptr;
   bool profiling = false;
-  Buf vbuf, vt, vts, w1, w2, spart, sfull, scratch, pbuf;
+  hipStream_t hi = nullptr;      // high-priority stream: panel factorisation under look-ahead
+  struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
+  int cur_ws = 0;
+  bool lookahead = true;
+  hipEvent_t ev_panel[4] = {}, ev_wide[4] = {};
+  Buf vbuf, vt, vt2, vts, spart, sfull, scratch, pbuf;
   int panel_impl = 2;  // 2: row-split sub-panel kernels (dhqr_panel.h); 1: one workgroup per column
   int ib = DHQR_IB;
   // profiling
@@ -62,7 +67,7 @@ struct dhqr_ctx {
 static int32_t ensure(dhqr_ctx *c, Buf &b, size_t need) {
   if (need <= b.cap) return DHQR_OK;
   if (b.p) {
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipDeviceSynchronize());  // another stream of this ctx may still use the old buffer
     HIPCHECK(hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -198,7 +203,7 @@ static void pick_split(int64_t rows, int64_t ntiles, int64_t target_wgs, int64_t
 }
 
 // T / T' of a packed panel buffer whose V part is already in place (ncols real columns).
-static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *vt);
+static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *vt, int kw = DHQR_NBV);
 
 // Pack V (R part zeroed) and build T / T' for a factored panel P (rows x ncols, ncols <= 128).
 static int32_t panel_pack_and_t(dhqr_ctx *c, const double *P, int64_t rows, int64_t ncols,
@@ -221,20 +226,25 @@ static int32_t panel_pack_and_t(dhqr_ctx *c, const double *P, int64_t rows, int6
   return DHQR_OK;
 }
 
-static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *vt) {
+static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *vt, int kw) {
   const int64_t ldv = panel_ldv(rows);
   double *V = vt;
   int64_t nsplit, rps;
   pick_split(rows, 1, 128, 128, &nsplit, &rps);
   CHECK(ensure(c, c->spart, (size_t)nsplit * DHQR_NBV * DHQR_NBV));
   CHECK(ensure(c, c->sfull, (size_t)DHQR_NBV * DHQR_NBV));
-  hipLaunchKernelGGL((k_gemm_tn<2, 1>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, V, ldv, V,
-                     ldv, 1, (int64_t)0, rows, (int64_t)DHQR_NBV, rps, c->spart.p,
-                     (int64_t)DHQR_NBV, (int64_t)DHQR_NBV * DHQR_NBV);
-  hipLaunchKernelGGL(k_reduce_splits, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream,
-                     c->spart.p, (int)nsplit, (int64_t)DHQR_NBV * DHQR_NBV,
-                     (int64_t)DHQR_NBV * DHQR_NBV, c->sfull.p);
-  hipLaunchKernelGGL(k_build_t2, dim3(1), dim3(128), 0, c->stream, (const double *)c->sfull.p,
+#define DHQR_SGEMM(KW_)                                                                           \
+  hipLaunchKernelGGL((k_gemm_tn<2, 1, KW_>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, V, ldv, \
+                     V, ldv, 1, (int64_t)0, rows, (int64_t)KW_, rps, c->spart.p, (int64_t)DHQR_NBV,      \
+                     (int64_t)DHQR_NBV * DHQR_NBV)
+  if (kw == 32) DHQR_SGEMM(32);
+  else if (kw == 64) DHQR_SGEMM(64);
+  else DHQR_SGEMM(128);
+#undef DHQR_SGEMM
+  hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(DHQR_NBV * kw / 256)), dim3(256), 0, c->stream,
+                     (const double *)c->spart.p, (int)nsplit, (int64_t)DHQR_NBV * DHQR_NBV,
+                     (int64_t)DHQR_NBV * kw, c->sfull.p);
+  hipLaunchKernelGGL(k_build_t2, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sfull.p,
                      (int)ncols, vt_T(vt, rows), vt_Tt(vt, rows));
   LAUNCHCHECK();
   return DHQR_OK;
@@ -242,7 +252,7 @@ static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *v
 
 // C (rows x ncols) <- (I - V op(T) V') C with op(T) = T' (trans=1) or T (trans=0).
 static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *C, int64_t ncols,
-                           int64_t ldc, int trans) {
+                           int64_t ldc, int trans, int kw = DHQR_NBV) {
   if (ncols <= 0 || rows <= 0) return DHQR_OK;
   const int64_t ldv = panel_ldv(rows);
   const double *V = vt;
@@ -250,38 +260,51 @@ static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *
   const int64_t ntiles = (ncols + 127) / 128;
   int64_t nsplit, rps;
   pick_split(rows, ntiles, 512, 64, &nsplit, &rps);
-  CHECK(ensure(c, c->w1, (size_t)nsplit * DHQR_NBV * (size_t)ncols));
-  CHECK(ensure(c, c->w2, (size_t)DHQR_NBV * (size_t)ncols));
+  dhqr_ctx::WS &ws = c->ws[c->cur_ws];
+  CHECK(ensure(c, ws.w1, (size_t)nsplit * DHQR_NBV * (size_t)ncols));
+  CHECK(ensure(c, ws.w2, (size_t)DHQR_NBV * (size_t)ncols));
+  if (nsplit > 1) CHECK(ensure(c, ws.w1r, (size_t)DHQR_NBV * (size_t)ncols));
   const bool vec = (ldc % 2 == 0) && (rows % 2 == 0) && aligned16(C);
   const int64_t wstride = (int64_t)DHQR_NBV * ncols;
 
-  CHECK(prof_begin(c, CAT_VTA));
-  if (vec)
-    hipLaunchKernelGGL((k_gemm_tn<2, 1>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(256), 0,
-                       c->stream, V, ldv, (const double *)C, ldc, 1, (int64_t)0, rows, ncols, rps,
-                       c->w1.p, (int64_t)DHQR_NBV, wstride);
-  else
-    hipLaunchKernelGGL((k_gemm_tn<1, 1>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(256), 0,
-                       c->stream, V, ldv, (const double *)C, ldc, 1, (int64_t)0, rows, ncols, rps,
-                       c->w1.p, (int64_t)DHQR_NBV, wstride);
-  CHECK(prof_end(c));
-
-  CHECK(prof_begin(c, CAT_TW));
-  hipLaunchKernelGGL((k_gemm_tn<2, 0>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top,
-                     (int64_t)DHQR_NBV, (const double *)c->w1.p, (int64_t)DHQR_NBV, (int)nsplit,
-                     wstride, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV, c->w2.p,
-                     (int64_t)DHQR_NBV, (int64_t)0);
-  CHECK(prof_end(c));
-
-  CHECK(prof_begin(c, CAT_AVW));
-  dim3 grid((unsigned)((rows + 127) / 128), (unsigned)ntiles);
-  if (vec)
-    hipLaunchKernelGGL((k_gemm_nn_sub<2, 128>), grid, dim3(256), 0, c->stream, V, ldv,
-                       (const double *)c->w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols);
-  else
-    hipLaunchKernelGGL((k_gemm_nn_sub<1, 128>), grid, dim3(256), 0, c->stream, V, ldv,
-                       (const double *)c->w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols);
-  CHECK(prof_end(c));
+  // one instantiation per reflector-block width (32 / 64 inside a panel, 128 for the trailing update)
+#define DHQR_APPLY(KW_)                                                                              \
+  do {                                                                                               \
+    CHECK(prof_begin(c, CAT_VTA));                                                                   \
+    if (vec)                                                                                         \
+      hipLaunchKernelGGL((k_gemm_tn<2, 1, KW_>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(256), 0, \
+                         c->stream, V, ldv, (const double *)C, ldc, 1, (int64_t)0, rows, ncols, rps,    \
+                         ws.w1.p, (int64_t)DHQR_NBV, wstride);                                           \
+    else                                                                                             \
+      hipLaunchKernelGGL((k_gemm_tn<1, 1, KW_>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(256), 0, \
+                         c->stream, V, ldv, (const double *)C, ldc, 1, (int64_t)0, rows, ncols, rps,    \
+                         ws.w1.p, (int64_t)DHQR_NBV, wstride);                                           \
+    CHECK(prof_end(c));                                                                              \
+    CHECK(prof_begin(c, CAT_TW));                                                                    \
+    const double *w1sum = ws.w1.p;                                                                   \
+    if (nsplit > 1) { /* bandwidth-friendly, deterministic split-K reduction */                      \
+      hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)((wstride + 255) / 256)), dim3(256), 0,     \
+                         c->stream, (const double *)ws.w1.p, (int)nsplit, wstride, wstride, ws.w1r.p); \
+      w1sum = ws.w1r.p;                                                                              \
+    }                                                                                                \
+    hipLaunchKernelGGL((k_gemm_tn<2, 1, KW_>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top, \
+                       (int64_t)DHQR_NBV, w1sum, (int64_t)DHQR_NBV, 1, (int64_t)0, (int64_t)KW_, ncols,  \
+                       (int64_t)KW_, ws.w2.p, (int64_t)DHQR_NBV, (int64_t)0);                            \
+    CHECK(prof_end(c));                                                                              \
+    CHECK(prof_begin(c, CAT_AVW));                                                                   \
+    dim3 grid((unsigned)((rows + 127) / 128), (unsigned)ntiles);                                     \
+    if (vec)                                                                                         \
+      hipLaunchKernelGGL((k_gemm_nn_sub<2, KW_>), grid, dim3(256), 0, c->stream, V, ldv,             \
+                         (const double *)ws.w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols);           \
+    else                                                                                             \
+      hipLaunchKernelGGL((k_gemm_nn_sub<1, KW_>), grid, dim3(256), 0, c->stream, V, ldv,             \
+                         (const double *)ws.w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols);           \
+    CHECK(prof_end(c));                                                                              \
+  } while (0)
+  if (kw == 32) DHQR_APPLY(32);
+  else if (kw == 64) DHQR_APPLY(64);
+  else DHQR_APPLY(128);
+#undef DHQR_APPLY
   if (c->profiling) {
     c->st.flops_gemm_vta += 2.0 * DHQR_NBV * (double)rows * (double)ncols;
     c->st.flops_gemm_avw += 2.0 * DHQR_NBV * (double)rows * (double)ncols;
@@ -316,7 +339,7 @@ static int32_t factor_panel_v2(dhqr_ctx *c, double *P, int64_t rows, int64_t w, 
       double *Ps = P + j0 + j0 * ldp;
       const int nch = (int)((rows_s + PS_RC - 1) / PS_RC);
       const int64_t ldvs = panel_ldv(rows_s);
-      HIPCHECK(hipMemsetAsync(c->vts.p, 0, (size_t)ldvs * DHQR_NBV * sizeof(double), c->stream));
+      HIPCHECK(hipMemsetAsync(c->vts.p, 0, (size_t)ldvs * (ncs <= 32 ? 32 : (ncs <= 64 ? 64 : 128)) * sizeof(double), c->stream));
       if (vec)
         hipLaunchKernelGGL((k_panel_init<2>), dim3(nch, ncs), dim3(256), 0, c->stream, (const double *)Ps, ldp,
                            rows_s, piv[0], prow[0], part[0], nch);
@@ -324,22 +347,23 @@ static int32_t factor_panel_v2(dhqr_ctx *c, double *P, int64_t rows, int64_t w, 
         hipLaunchKernelGGL((k_panel_init<1>), dim3(nch, ncs), dim3(256), 0, c->stream, (const double *)Ps, ldp,
                            rows_s, piv[0], prow[0], part[0], nch);
       for (int q = 0; q < ncs; ++q) {
-        dim3 grid(nch - q / PS_RC, ncs - q);
+        dim3 grid(nch - q / PS_RC, 1 + (ncs - q - 1 + PS_CPW - 1) / PS_CPW);
         double *vwq = vt + j0 + (j0 + q) * ldvw;
         if (vec)
-          hipLaunchKernelGGL((k_panel_step<2>), grid, dim3(256), 0, c->stream, Ps, ldp, rows_s, q, ncs,
+          hipLaunchKernelGGL((k_panel_step<2, PS_CPW>), grid, dim3(256), 0, c->stream, Ps, ldp, rows_s, q, ncs,
                              (const double *)piv[q & 1], piv[(q + 1) & 1], (const double *)prow[q & 1],
                              prow[(q + 1) & 1], (const double *)part[q & 1], part[(q + 1) & 1], nch, c->vts.p,
                              ldvs, vwq, ldvw, alpha + j0 + q);
         else
-          hipLaunchKernelGGL((k_panel_step<1>), grid, dim3(256), 0, c->stream, Ps, ldp, rows_s, q, ncs,
+          hipLaunchKernelGGL((k_panel_step<1, PS_CPW>), grid, dim3(256), 0, c->stream, Ps, ldp, rows_s, q, ncs,
                              (const double *)piv[q & 1], piv[(q + 1) & 1], (const double *)prow[q & 1],
                              prow[(q + 1) & 1], (const double *)part[q & 1], part[(q + 1) & 1], nch, c->vts.p,
                              ldvs, vwq, ldvw, alpha + j0 + q);
       }
       if (j0 + ncs < w) {  // block reflector of this sub-panel onto the rest of the panel (MFMA)
-        CHECK(panel_build_t(c, rows_s, ncs, c->vts.p));
-        CHECK(panel_apply(c, c->vts.p, rows_s, P + j0 + (j0 + ncs) * ldp, w - j0 - ncs, ldp, 1));
+        const int kw = ncs <= 32 ? 32 : (ncs <= 64 ? 64 : 128);
+        CHECK(panel_build_t(c, rows_s, ncs, c->vts.p, kw));
+        CHECK(panel_apply(c, c->vts.p, rows_s, P + j0 + (j0 + ncs) * ldp, w - j0 - ncs, ldp, 1, kw));
       }
     }
     {
@@ -369,6 +393,74 @@ static int32_t factor_panel(dhqr_ctx *c, double *P, int64_t rows, int64_t w, int
   if (c->panel_impl == 2) return factor_panel_v2(c, P, rows, w, ldp, alpha, vt);
   CHECK(factor_unblocked_cols(c, P, rows, w, ldp, alpha, CAT_PANEL));
   return panel_pack_and_t(c, P, rows, w, ldp, alpha, vt);
+}
+
+// ---- blocked driver (BASELINE config 3) ------------------------------------------------------
+// Right-looking with look-ahead depth 1 on two streams of the same GPU:
+//   stream B (high priority): narrow update of block k+1 by panel k, then factorisation of
+//                             panel k+1  (latency-bound, needs few CUs)
+//   stream A (caller's)     : wide update of blocks >= k+2 by panel k  (MFMA-bound)
+// so the panel factorisation the reference serialises in front of every trailing update
+// (src:127-143) runs underneath the previous trailing update.
+static int32_t factor_blocked(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
+  const int64_t K = (n + DHQR_NBV - 1) / DHQR_NBV;
+  CHECK(ensure(c, c->vt, (size_t)panel_elems(m)));
+  if (!c->lookahead || K < 3) {
+    for (int64_t c0 = 0; c0 < n; c0 += DHQR_NBV) {
+      const int64_t w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
+      double *P = dA + c0 + c0 * lda;
+      CHECK(factor_panel(c, P, rows, w, lda, dalpha + c0, c->vt.p));
+      if (c0 + w < n) CHECK(panel_apply(c, c->vt.p, rows, dA + c0 + (c0 + w) * lda, n - c0 - w, lda, 1));
+    }
+    return DHQR_OK;
+  }
+  // size every workspace up front: no (re)allocation while two streams are in flight
+  CHECK(ensure(c, c->vt2, (size_t)panel_elems(m)));
+  CHECK(ensure(c, c->vts, (size_t)panel_elems(m)));
+  {
+    const size_t ntmax = (size_t)((n + 127) / 128);
+    const size_t w1cap = (size_t)DHQR_NBV * DHQR_NBV * (2048 + ntmax + 64);
+    for (int s = 0; s < 2; ++s) {
+      CHECK(ensure(c, c->ws[s].w1, s == 0 ? w1cap : (size_t)DHQR_NBV * DHQR_NBV * 1100));
+      CHECK(ensure(c, c->ws[s].w1r, (size_t)DHQR_NBV * (size_t)n));
+      CHECK(ensure(c, c->ws[s].w2, (size_t)DHQR_NBV * (size_t)n));
+    }
+    CHECK(ensure(c, c->spart, (size_t)128 * DHQR_NBV * DHQR_NBV));
+    CHECK(ensure(c, c->sfull, (size_t)DHQR_NBV * DHQR_NBV));
+  }
+  double *vt[2] = {c->vt.p, c->vt2.p};
+  hipStream_t sA = c->stream, sB = c->hi;
+  auto on = [&](hipStream_t s, int wsi) { c->stream = s; c->cur_ws = wsi; };
+  auto body = [&]() -> int32_t {
+    // order stream B after whatever the caller queued on A (e.g. the fill)
+    HIPCHECK(hipEventRecord(c->ev_wide[3], sA));
+    HIPCHECK(hipStreamWaitEvent(sB, c->ev_wide[3], 0));
+    on(sB, 1);
+    CHECK(factor_panel(c, dA, m, std::min<int64_t>(DHQR_NBV, n), lda, dalpha, vt[0]));
+    HIPCHECK(hipEventRecord(c->ev_panel[0], sB));
+    for (int64_t k = 0; k < K; ++k) {
+      const int64_t c0 = k * DHQR_NBV, w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
+      if (k + 1 < K) {
+        const int64_t c1 = c0 + w, w1 = std::min<int64_t>(DHQR_NBV, n - c1);
+        on(sB, 1);
+        if (k >= 1) HIPCHECK(hipStreamWaitEvent(sB, c->ev_wide[(k - 1) & 3], 0));  // block k+1 is current, vt[(k+1)&1] free
+        CHECK(panel_apply(c, vt[k & 1], rows, dA + c0 + c1 * lda, w1, lda, 1));
+        CHECK(factor_panel(c, dA + c1 + c1 * lda, m - c1, w1, lda, dalpha + c1, vt[(k + 1) & 1]));
+        HIPCHECK(hipEventRecord(c->ev_panel[(k + 1) & 3], sB));
+        const int64_t c2 = c1 + w1;
+        on(sA, 0);
+        HIPCHECK(hipStreamWaitEvent(sA, c->ev_panel[k & 3], 0));
+        if (c2 < n) CHECK(panel_apply(c, vt[k & 1], rows, dA + c0 + c2 * lda, n - c2, lda, 1));
+        HIPCHECK(hipEventRecord(c->ev_wide[k & 3], sA));
+      }
+    }
+    // the caller's stream owns the result: wait for the last panel
+    HIPCHECK(hipStreamWaitEvent(sA, c->ev_panel[(K - 1) & 3], 0));
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  on(sA, 0);
+  return rc;
 }
 
 static int32_t check_ctx(dhqr_ctx *c) {
@@ -444,6 +536,16 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
   memset(&c->st, 0, sizeof(c->st));
   HIPCHECK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
   c->stream = c->own;
+  {
+    int lo = 0, hi = 0;
+    HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
+    HIPCHECK(hipStreamCreateWithPriority(&c->hi, hipStreamNonBlocking, hi));
+    for (int i = 0; i < 4; ++i) {
+      HIPCHECK(hipEventCreateWithFlags(&c->ev_panel[i], hipEventDisableTiming));
+      HIPCHECK(hipEventCreateWithFlags(&c->ev_wide[i], hipEventDisableTiming));
+    }
+  }
+  if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
   if (const char *e = getenv("DHQR_PANEL")) c->panel_impl = atoi(e) == 1 ? 1 : 2;
   if (const char *e = getenv("DHQR_IB")) {
     const int v = atoi(e);
@@ -457,13 +559,19 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   if (!c) return DHQR_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->w1, &c->w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf};
+  Buf *bufs[] = {&c->vbuf, &c->vt, &c->vt2, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
+                 &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
+  for (int i = 0; i < 4; ++i) {
+    if (c->ev_panel[i]) (void)hipEventDestroy(c->ev_panel[i]);
+    if (c->ev_wide[i]) (void)hipEventDestroy(c->ev_wide[i]);
+  }
+  if (c->hi) (void)hipStreamDestroy(c->hi);
   if (c->own) (void)hipStreamDestroy(c->own);
   delete c;
   return DHQR_OK;
@@ -528,14 +636,7 @@ int32_t dhqr_factor_f64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t l
   if (nb != 0 && nb != DHQR_NB)
     return set_err(DHQR_EINVAL, "nb must be 0 (unblocked) or %d (blocked); got %d", DHQR_NB, nb);
   if (nb == 0) return factor_unblocked_cols(c, dA, m, n, lda, dalpha, CAT_RANK1);
-  CHECK(ensure(c, c->vt, (size_t)panel_elems(m)));
-  for (int64_t c0 = 0; c0 < n; c0 += DHQR_NBV) {
-    const int64_t w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
-    double *P = dA + c0 + c0 * lda;
-    CHECK(factor_panel(c, P, rows, w, lda, dalpha + c0, c->vt.p));
-    if (c0 + w < n) CHECK(panel_apply(c, c->vt.p, rows, dA + c0 + (c0 + w) * lda, n - c0 - w, lda, 1));
-  }
-  return DHQR_OK;
+  return factor_blocked(c, dA, m, n, lda, dalpha);
 }
 
 int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha,

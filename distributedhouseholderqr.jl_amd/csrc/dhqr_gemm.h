@@ -39,29 +39,37 @@ __device__ __forceinline__ dhqr_d4 mfma_f64(double a, double b, dhqr_d4 c) {
 // VEC = 2: 16-byte global loads (host guarantees rows, ldv, ldc even and 16-byte aligned bases).
 // All global loads are unconditional (clamped offset + select): no branch sits between a load
 // and its use, so the whole next K-tile is in flight behind the current tile's 64 MFMAs.
-template <int VEC, int NCS>
+// NBV = number of V columns (reflectors) = output rows: 128 for the trailing update, 32 / 64 for
+// the narrow block reflectors inside a panel.  Wave layout: NBV=128 -> 2 (cols) x 2 (p) waves of
+// 64 x 64; NBV=64 -> 4 x 1 waves of 32 cols x 64 p; NBV=32 -> 4 x 1 waves of 32 cols x 32 p.
+template <int VEC, int NCS, int NBV>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V, int64_t ldv,
                                                     const double *__restrict__ C, int64_t ldc,
                                                     int ncsplit, int64_t csplit_stride,
                                                     int64_t rows, int64_t ncols, int64_t rps,
                                                     double *__restrict__ out, int64_t ldo,
                                                     int64_t osplit_stride) {
-  __shared__ __attribute__((aligned(16))) double Vs[2][128 * G_LDK];
+  constexpr int NPI = (NBV >= 64) ? 4 : NBV / 16;  // p tiles per wave
+  constexpr int WP = NBV / (16 * NPI);              // waves along p (1 or 2)
+  constexpr int WC = 4 / WP;                        // waves along the columns
+  constexpr int NCI = 128 / (16 * WC);              // column tiles per wave
+  constexpr int NVL = NBV / 32;                     // V staging loads per thread (NBV*8 chunks / 256)
+  __shared__ __attribute__((aligned(16))) double Vs[2][NBV * G_LDK];
   __shared__ __attribute__((aligned(16))) double Cs[2][128 * G_LDK];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int i16 = lane & 15, k4 = lane >> 4;
-  const int wc = w >> 1, wp = w & 1;
+  const int wc = (WP == 2) ? (w >> 1) : w, wp = (WP == 2) ? (w & 1) : 0;
   const int64_t c0 = (int64_t)blockIdx.x * 128;
   const int64_t rbeg = (int64_t)blockIdx.y * rps;
   const int64_t rend = (rbeg + rps < rows) ? rbeg + rps : rows;
   const int nkt = (int)((rend - rbeg + G_KT - 1) / G_KT);
   const int ncv = (int)((ncols - c0 < 128) ? ncols - c0 : 128);  // valid columns in this tile
 
-  dhqr_d4 acc[4][4];
+  dhqr_d4 acc[NCI][NPI];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NCI; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < NPI; ++b) acc[a][b] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
 
   // staging: tile = 128 columns x 16 rows; chunk q = t + i*256 -> column q/8, row pair q%8.
   // 32-bit element offsets from the (uniform) tile base.
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
       const int rp = (t + i * 256) & 7;
       if constexpr (VEC == 2) {
         const uint32_t ro = (2 * rp < left) ? 2 * rp : 0;  // rows even => pair all-or-nothing
-        sv[i] = *reinterpret_cast<const double2 *>(Vt + (offv[i] + ro));
+        if (i < NVL) sv[i] = *reinterpret_cast<const double2 *>(Vt + (offv[i] + ro));
         if constexpr (NCS == 1) {
           sc[i] = *reinterpret_cast<const double2 *>(Ct + (offc[i] + ro));
         } else {
@@ -104,8 +112,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
         }
       } else {
         const uint32_t r0o = (2 * rp < left) ? 2 * rp : 0, r1o = (2 * rp + 1 < left) ? 2 * rp + 1 : 0;
-        sv[i].x = Vt[offv[i] + r0o];
-        sv[i].y = Vt[offv[i] + r1o];
+        if (i < NVL) {
+          sv[i].x = Vt[offv[i] + r0o];
+          sv[i].y = Vt[offv[i] + r1o];
+        }
         if constexpr (NCS == 1) {
           sc[i].x = Ct[offc[i] + r0o];
           sc[i].y = Ct[offc[i] + r1o];
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
       if (!ok0) { x.x = 0.0; y.x = 0.0; }
       if (!ok1) { x.y = 0.0; y.y = 0.0; }
       if (!okc[i]) y = make_double2(0.0, 0.0);
-      *reinterpret_cast<double2 *>(&Vs[buf][col * G_LDK + 2 * rp]) = x;
+      if (i < NVL) *reinterpret_cast<double2 *>(&Vs[buf][col * G_LDK + 2 * rp]) = x;
       *reinterpret_cast<double2 *>(&Cs[buf][col * G_LDK + 2 * rp]) = y;
     }
   };
@@ -146,20 +156,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
     const int buf = kt & 1;
     if (kt + 1 < nkt) load_tile(kt + 1);
     __builtin_amdgcn_sched_barrier(0);  // keep the load issue above, their consumers below the MFMAs
-    const double *cs = &Cs[buf][(wc * 64 + i16) * G_LDK + k4];
+    const double *cs = &Cs[buf][(wc * (NCI * 16) + i16) * G_LDK + k4];
     const double *vs = &Vs[buf][(wp * 64 + i16) * G_LDK + k4];
 #pragma unroll
     for (int kk = 0; kk < G_KT / 4; ++kk) {
-      double a[4], b[4];
+      double a[NCI], b[NPI];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        a[x] = cs[x * 16 * G_LDK + kk * 4];
-        b[x] = vs[x * 16 * G_LDK + kk * 4];
-      }
+      for (int x = 0; x < NCI; ++x) a[x] = cs[x * 16 * G_LDK + kk * 4];
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
+      for (int x = 0; x < NPI; ++x) b[x] = vs[x * 16 * G_LDK + kk * 4];
 #pragma unroll
-        for (int pi = 0; pi < 4; ++pi) acc[ci][pi] = mfma_f64(a[ci], b[pi], acc[ci][pi]);
+      for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < NPI; ++pi) acc[ci][pi] = mfma_f64(a[ci], b[pi], acc[ci][pi]);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nkt) store_tile(buf ^ 1, kt + 1);
@@ -168,13 +177,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
 
   double *o = out + (int64_t)blockIdx.y * osplit_stride + c0 * ldo;
 #pragma unroll
-  for (int ci = 0; ci < 4; ++ci)
+  for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
+      const int cl = wc * (NCI * 16) + ci * 16 + k4 + 4 * g;
       if (cl < ncv) {
 #pragma unroll
-        for (int pi = 0; pi < 4; ++pi)
+        for (int pi = 0; pi < NPI; ++pi)
           o[(uint32_t)(wp * 64 + pi * 16 + i16) + (uint32_t)(cl * ldo)] = acc[ci][pi][g];
       }
     }

@@ -22,7 +22,8 @@
 #pragma once
 #include "dhqr_common.h"
 
-#define DHQR_IB 64   // sub-panel width (measured: 64 beats 32 and 16 while the inter-sub-panel GEMMs are 128-wide)
+#define DHQR_IB 64   // sub-panel width (measured on MI355X at 32768^2: 64 > 32 > 16; DHQR_IB env overrides)
+#define PS_CPW 4     // columns per workgroup in k_panel_step
 #define PS_RC 1024   // rows per workgroup chunk (256 threads x 4 rows)
 
 // chunk-local rows of thread t: VEC=2: pairs at 2*(t + i*256), i=0,1 ; VEC=1: t + i*256, i=0..3
@@ -93,33 +94,55 @@ __global__ __launch_bounds__(256) void k_panel_init(const double *__restrict__ P
 }
 
 // One reflector step of a sub-panel.  q = local column of the reflector (its diagonal is local
-// row q); grid = (nch - q/PS_RC, ncs - q) with ncs = columns in this sub-panel; blockIdx.y = 0 is
-// the pivot column itself (emits v), blockIdx.y = k' >= 1 updates column q + k'.
-template <int VEC>
+// row q); ncs = columns in this sub-panel.  grid = (nch - q/PS_RC, 1 + ceil((ncs-q-1)/CPW)):
+// blockIdx.y = 0 is the pivot column itself (emits v and alpha); blockIdx.y = y >= 1 updates the
+// CPW columns starting at q + 1 + (y-1)*CPW on row chunk blockIdx.x.  The pivot chunk v and the
+// updated next-pivot chunk are formed once per workgroup and reused for its CPW columns.
+template <int VEC, int CPW>
 __global__ __launch_bounds__(256) void k_panel_step(
     double *__restrict__ Ps, int64_t ldp, int64_t rows, int q, int ncs,
     const double *__restrict__ piv, double *__restrict__ pivnext, const double *__restrict__ prow,
     double *__restrict__ prownext, const double *__restrict__ part, double *__restrict__ partnext,
     int nch, double *__restrict__ Vs, int64_t ldvs, double *__restrict__ Vw, int64_t ldvw,
     double *__restrict__ alpha_q) {
-  __shared__ double red[6];
-  const int t = threadIdx.x, lane = t & 63;
+  __shared__ double red[4 * CPW];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int c0 = q / PS_RC;
   const int c = c0 + blockIdx.x;
-  const int kk = blockIdx.y, kq = q + kk;
+  const int y = blockIdx.y;
+  const int first = q + 1 + (y - 1) * CPW;              // first column of this group (y >= 1)
+  const int ncol = (y == 0) ? 0 : ((ncs - first < CPW) ? ncs - first : CPW);
   const int64_t cbase = (int64_t)c * PS_RC;
   const bool havenext = (q + 1 < ncs);
 
+  // (0) issue every chunk load of this workgroup first: pivot chunk, old next-pivot chunk and
+  // the CPW columns -- they do not depend on the reductions below and overlap their latency.
+  double v[4], an[4], a[CPW][4];
+  ps_load<VEC>(piv, cbase, t, rows, v);
+  if (y > 0) {
+    ps_load<VEC>(Ps + (int64_t)(q + 1) * ldp, cbase, t, rows, an);
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int kq = (i < ncol) ? first + i : first;  // clamp: load something valid, ignore it
+      ps_load<VEC>(Ps + (int64_t)kq * ldp, cbase, t, rows, a[i]);
+    }
+  }
+
   // (1) finish this step's reductions (every wave redundantly; fixed order => deterministic)
-  double dj = 0.0, dk = 0.0, dn = 0.0;
+  double dj = 0.0, dn = 0.0, dk[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) dk[i] = 0.0;
   for (int cc = c0 + lane; cc < nch; cc += 64) {
     dj += part[(int64_t)q * nch + cc];
-    dk += part[(int64_t)kq * nch + cc];
     if (havenext) dn += part[(int64_t)(q + 1) * nch + cc];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i)
+      if (i < ncol) dk[i] += part[(int64_t)(first + i) * nch + cc];
   }
   dj = wave_sum(dj);
-  dk = wave_sum(dk);
   dn = wave_sum(dn);
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) dk[i] = wave_sum(dk[i]);
 
   // (2) reflector scalars (src:129-131), identical in every workgroup
   const double h = prow[q];
@@ -128,61 +151,64 @@ __global__ __launch_bounds__(256) void k_panel_step(
   const double f = 1.0 / sqrt(s * (s + fabs(h)));
 
   // (3) v on this chunk from the unscaled pivot column
-  double v[4];
-  ps_load<VEC>(piv, cbase, t, rows, v);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int64_t r = ps_row<VEC>(cbase, t, e);
     v[e] = (r == q) ? (h - al) * f : (r > q ? v[e] * f : 0.0);  // src:132-135
   }
 
-  if (kk == 0) {  // (4) pivot column: publish v (packed buffers) and alpha
+  if (y == 0) {  // (4) pivot column: publish v (packed buffers) and alpha
     ps_store<VEC>(Vs + (int64_t)q * ldvs, cbase, t, rows, v);
     ps_store<VEC>(Vw, cbase, t, rows, v);  // Vw already points at (row j0, column of this reflector)
     if (blockIdx.x == 0 && t == 0) *alpha_q = al;
     return;
   }
 
-  // (5) rank-1 update of column kq on this chunk
-  const double wk = f * (dk - al * prow[kq]);  // v' a_k
-  double a[4];
-  double *colk = Ps + (int64_t)kq * ldp;
-  ps_load<VEC>(colk, cbase, t, rows, a);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) a[e] = fma(-v[e], wk, a[e]);  // src:209
-  if (kk == 1) {
-    // next pivot column: staged in pivnext (other workgroups still read the old values from A);
-    // only its final R entry (row q) goes in place
-    ps_store<VEC>(pivnext, cbase, t, rows, a);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (ps_row<VEC>(cbase, t, e) == q) colk[q] = a[e];
-  } else {
-    ps_store<VEC>(colk, cbase, t, rows, a);
-  }
-  if (!havenext) return;
-
-  // (6) partial dot of the next step on the updated registers: a_{q+1}' a_k over rows >= q+1
-  double d = 0.0;
-  if (kk == 1) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (ps_row<VEC>(cbase, t, e) > q) d = fma(a[e], a[e], d);
-  } else {
+  // updated next-pivot chunk a_{q+1} - v (v'a_{q+1}), from the OLD column q+1 still in A
+  {
     const double wn = f * (dn - al * prow[q + 1]);
-    double an[4];
-    ps_load<VEC>(Ps + (int64_t)(q + 1) * ldp, cbase, t, rows, an);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      an[e] = fma(-v[e], wn, an[e]);
-      if (ps_row<VEC>(cbase, t, e) > q) d = fma(an[e], a[e], d);
+    for (int e = 0; e < 4; ++e) an[e] = fma(-v[e], wn, an[e]);
+  }
+
+  // (5)+(6) rank-1 update of each column of the group, then its partial dot for the next step
+  double d[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    d[i] = 0.0;
+    if (i < ncol) {
+      const int kq = first + i;
+      const double wk = f * (dk[i] - al * prow[kq]);  // v' a_k = f (a_j'a_k - alpha a_jk)
+      double *colk = Ps + (int64_t)kq * ldp;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[i][e] = fma(-v[e], wk, a[i][e]);  // src:209
+      if (kq == q + 1) {
+        // next pivot column: staged in pivnext (other workgroups still read the old values from
+        // A); only its final R entry (row q) goes in place
+        ps_store<VEC>(pivnext, cbase, t, rows, a[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (ps_row<VEC>(cbase, t, e) == q) colk[q] = a[i][e];
+      } else {
+        ps_store<VEC>(colk, cbase, t, rows, a[i]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t r = ps_row<VEC>(cbase, t, e);
+        if (r > q) d[i] = fma(an[e], a[i][e], d[i]);   // a_{q+1}' a_k over rows >= q+1
+        if (r == q + 1) prownext[kq] = a[i][e];        // row q+1 after this step
+      }
     }
   }
+  // block reduction of the CPW partial dots
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (ps_row<VEC>(cbase, t, e) == q + 1) prownext[kq] = a[e];  // row q+1 after this step
-  d = block_sum<256>(d, red);
-  if (t == 0) partnext[(int64_t)kq * nch + c] = d;
+  for (int i = 0; i < CPW; ++i) d[i] = wave_sum(d[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) red[wv * CPW + i] = d[i];
+  }
+  __syncthreads();
+  if (t < ncol) partnext[(int64_t)(first + t) * nch + c] = red[t] + red[CPW + t] + red[2 * CPW + t] + red[3 * CPW + t];
 }
 
 // A[r, p] <- Vw[r, p] for r >= p (the reflectors, produced out of place by k_panel_step)
@@ -196,44 +222,50 @@ __global__ __launch_bounds__(256) void k_unpack_v(double *__restrict__ P, int64_
     P[r + p * ldp] = Vw[r + p * ldv];
 }
 
-// Compact-WY T from S = V'V (see dhqr_gemm.h for the algebra): T = (I + striu(S))^{-1}, one thread
-// per column j solving U x = e_j by back substitution; N = striu(S) and X = T live packed
-// (row i holds entries i..127) in LDS, no barriers and no global loads inside the solve.
-// Columns >= ncols of V are zero padding: T[j][j] = 1, rest of the column 0.
-__global__ __launch_bounds__(128) void k_build_t2(const double *__restrict__ S, int ncols,
-                                                  double *__restrict__ Tout,
-                                                  double *__restrict__ Ttout) {
+// Compact-WY T from S = V'V (see dhqr_gemm.h for the algebra): T = (I + striu(S))^{-1}, i.e. for
+// every column j solve U x = e_j by back substitution.  1024 threads: 8 lanes per column split the
+// inner sum, rows are walked in lockstep (one barrier per row), N = striu(S) and X = T live packed
+// (row i holds entries i..127) in LDS.  Columns >= ncols of V are zero padding: T[j][j] = 1, rest 0.
+__global__ __launch_bounds__(1024) void k_build_t2(const double *__restrict__ S, int ncols,
+                                                   double *__restrict__ Tout,
+                                                   double *__restrict__ Ttout) {
   constexpr int N = 128, PK = N * (N + 1) / 2;
   __shared__ double Nl[PK];
   __shared__ double Xl[PK];
   const int t = threadIdx.x;
   auto pidx = [](int i, int l) { return i * N - (i * (i - 1)) / 2 + (l - i); };  // i <= l
-  for (int idx = t; idx < N * N; idx += N) {
-    const int i = idx & (N - 1), l = idx >> 7;
-    if (i <= l) Nl[pidx(i, l)] = (i < l && l < ncols) ? S[i + l * N] : 0.0;
-  }
-  __syncthreads();
-  const int j = t;
-  Xl[pidx(j, j)] = 1.0;
-  // rows walked in lockstep by the whole wave (i uniform): the N[i][l] reads are LDS broadcasts
-  for (int i = N - 2; i >= 0; --i) {
-    if (i < j) {
-      double acc0 = 0.0, acc1 = 0.0;
-      if (j < ncols) {
-        acc0 = Nl[pidx(i, j)];  // l = j term: N[i][j] * X[j][j]
-        int l = i + 1;
-        for (; l + 1 < j; l += 2) {
-          acc0 = fma(Nl[pidx(i, l)], Xl[pidx(l, j)], acc0);
-          acc1 = fma(Nl[pidx(i, l + 1)], Xl[pidx(l + 1, j)], acc1);
-        }
-        if (l < j) acc0 = fma(Nl[pidx(i, l)], Xl[pidx(l, j)], acc0);
+  {  // fill: all 16 global loads of a thread are issued before the first LDS store
+    double sv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = t + u * 1024, i = idx & (N - 1), l = idx >> 7;
+      sv[u] = (i < l && l < ncols) ? S[idx] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = t + u * 1024, i = idx & (N - 1), l = idx >> 7;
+      if (i <= l) {
+        Nl[pidx(i, l)] = sv[u];
+        Xl[pidx(i, l)] = (i == l) ? 1.0 : 0.0;
       }
-      Xl[pidx(i, j)] = -(acc0 + acc1);
     }
   }
   __syncthreads();
-  for (int idx = t; idx < N * N; idx += N) {
-    const int i = idx & (N - 1), l = idx >> 7;  // Tout[i + l*N] = T[i][l]
+  const int j = t >> 3, sub = t & 7;
+  for (int i = ncols - 2; i >= 0; --i) {  // uniform loop; rows >= ncols-1 stay identity / zero
+    if (i < j && j < ncols) {
+      double acc = 0.0;
+      for (int l = i + 1 + sub; l < j; l += 8) acc = fma(Nl[pidx(i, l)], Xl[pidx(l, j)], acc);
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      if (sub == 0) Xl[pidx(i, j)] = -(acc + Nl[pidx(i, j)]);  // l = j term: N[i][j] * X[j][j]
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int idx = t + u * 1024, i = idx & (N - 1), l = idx >> 7;  // Tout[i + l*N] = T[i][l]
     Tout[idx] = (i <= l) ? Xl[pidx(i, l)] : 0.0;
     Ttout[idx] = (l <= i) ? Xl[pidx(l, i)] : 0.0;  // Tt[i + l*N] = T[l][i]
   }
