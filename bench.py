@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-residual", action="store_true")
     ap.add_argument("--no-lookahead", action="store_true")
+    ap.add_argument("--driver", choices=["auto", "c", "python"], default="auto",
+                    help="N=1: 'c' = dhqr_factor_f64 (default), 'python' = the multi-GPU ColumnCyclicQR driver at world size 1")
     args = ap.parse_args()
 
     import torch
@@ -113,7 +115,8 @@ def main():
     seed = 0
     ctx = pkg.get_context(local_rank)
 
-    if world == 1:
+    use_c = (world == 1 and args.driver != "python")
+    if use_c:
         A = pkg.empty_colmajor(m, n, dev)
         alpha = torch.zeros(n, dtype=torch.float64, device=dev)
         L = pkg._lib.lib()
@@ -144,6 +147,9 @@ def main():
     barrier()
     ctx.reset_stats()
     ctx.set_profiling(True)
+    if not use_c and hasattr(q.be, "ctx_hi"):
+        q.be.ctx_hi.reset_stats()
+        q.be.ctx_hi.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -151,6 +157,10 @@ def main():
     dt = time.perf_counter() - t0
     st = ctx.stats()
     ctx.set_profiling(False)
+    if not use_c and hasattr(q.be, "ctx_hi"):  # add the look-ahead lane's share (panels, narrow updates)
+        st2 = q.be.ctx_hi.stats()
+        q.be.ctx_hi.set_profiling(False)
+        st = {k: st[k] + st2[k] for k in st}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -158,7 +168,7 @@ def main():
 
     resid = None
     if not args.no_residual:
-        if world == 1:
+        if use_c:
             H = pkg.DistributedHouseholderQRStruct(A, alpha)
             A0 = pkg.rand_colmajor(m, n, seed, dev)
             resid = pkg.residual(H, A0)
@@ -204,7 +214,7 @@ def main():
                                (f"blocked nb=128 (BASELINE configs[{2 if world == 1 else 3}])" if nb else
                                 "unblocked rank-1 (BASELINE configs[1])"),
                    "m": m, "n": n, "nb": nb,
-                   "parallelism": "single GPU" if world == 1 else f"1-D block-cyclic column split x{world}, RCCL panel broadcast"},
+                   "parallelism": ("single GPU" if use_c else "single GPU, python column-cyclic driver") if world == 1 else f"1-D block-cyclic column split x{world}, RCCL panel broadcast"},
         "residual": resid,
         "roofline": {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
                                          "launches", "avg_launch_ms")},
@@ -218,7 +228,8 @@ def main():
         except Exception as e:  # diagnostics only
             out["ubench_error"] = repr(e)
         if not args.no_cpu_baseline:
-            del A
+            if use_c:
+                del A
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(m, n)
             out["host_cores"] = os.cpu_count()

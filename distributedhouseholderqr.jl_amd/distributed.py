@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 from . import _lib
 from ._lib import NB, check
-from .api import empty_colmajor, get_context
+from .api import Context, empty_colmajor, get_context
 from .partition import BlockCyclicColumns
 
 
@@ -40,6 +40,53 @@ class HipBackend:
         self.ctx = get_context(device)
         self.L = _lib.lib()
         self.torch_device = torch.device("cuda", device)
+        # look-ahead lane: its own high-priority torch stream AND its own dhqr context (= its own
+        # workspaces), so narrow update + panel factorisation + broadcast of panel k+1 run
+        # underneath the wide trailing update of panel k on the main stream
+        self.hi_stream = torch.cuda.Stream(device=self.torch_device, priority=-1)
+        self.ctx_hi = Context(device)
+        self._lane = self.ctx
+
+    def lane(self, hi: bool):
+        """context manager: run the enclosed backend calls on the look-ahead lane (hi) or main"""
+        be = self
+
+        class _Lane:
+            def __enter__(self_inner):
+                self_inner.prev = be._lane
+                be._lane = be.ctx_hi if hi else be.ctx
+                self_inner.cm = torch.cuda.stream(be.hi_stream) if hi else None
+                if self_inner.cm is not None:
+                    self_inner.cm.__enter__()
+
+            def __exit__(self_inner, *exc):
+                if self_inner.cm is not None:
+                    self_inner.cm.__exit__(*exc)
+                be._lane = self_inner.prev
+                return False
+
+        return _Lane()
+
+    def record_main(self):
+        """event on the current (main) stream the look-ahead lane can wait on"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def hi_wait(self, ev):
+        if ev is not None:
+            self.hi_stream.wait_event(ev)
+
+    def main_wait_hi(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.hi_stream)
+
+    def record_current(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def wait_event(self, ev):
+        torch.cuda.current_stream(self.device).wait_event(ev)
 
     # -- memory
     def empty(self, m, n):
@@ -65,53 +112,53 @@ class HipBackend:
     def fill(self, A, ncols, seed, gm, nb, nranks, rank):
         if ncols == 0:
             return
-        self.ctx.use_torch_stream()
-        check(self.L.dhqr_fill_uniform_f64(self.ctx.handle, self._p(A, 0, 0), A.shape[0], ncols, A.stride(1),
+        self._lane.use_torch_stream()
+        check(self.L.dhqr_fill_uniform_f64(self._lane.handle, self._p(A, 0, 0), A.shape[0], ncols, A.stride(1),
                                            seed, gm, 0, nb, nranks, rank))
 
     def panel_factor(self, A, c0, lc0, w, vt):
-        self.ctx.use_torch_stream()
+        self._lane.use_torch_stream()
         rows = A.shape[0] - c0
-        check(self.L.dhqr_panel_factor_f64(self.ctx.handle, self._p(A, c0, lc0), rows, w, A.stride(1),
+        check(self.L.dhqr_panel_factor_f64(self._lane.handle, self._p(A, c0, lc0), rows, w, A.stride(1),
                                            ctypes.c_void_p(vt.data_ptr())))
 
     def panel_pack(self, A, c0, lc0, w, vt):
-        self.ctx.use_torch_stream()
+        self._lane.use_torch_stream()
         rows = A.shape[0] - c0
-        check(self.L.dhqr_panel_pack_f64(self.ctx.handle, self._p(A, c0, lc0), rows, w, A.stride(1),
+        check(self.L.dhqr_panel_pack_f64(self._lane.handle, self._p(A, c0, lc0), rows, w, A.stride(1),
                                          ctypes.c_void_p(vt.data_ptr())))
 
     def panel_apply(self, vt, C, c0, lo, cnt, trans):
         if cnt <= 0:
             return
-        self.ctx.use_torch_stream()
+        self._lane.use_torch_stream()
         rows = C.shape[0] - c0
         ldc = C.stride(1) if C.dim() == 2 and C.shape[1] > 1 else C.shape[0]
         ptr = ctypes.c_void_p(C.data_ptr() + 8 * (c0 + lo * ldc))
-        check(self.L.dhqr_panel_apply_f64(self.ctx.handle, ctypes.c_void_p(vt.data_ptr()), rows, ptr, cnt, ldc,
+        check(self.L.dhqr_panel_apply_f64(self._lane.handle, ctypes.c_void_p(vt.data_ptr()), rows, ptr, cnt, ldc,
                                           1 if trans else 0))
 
     def form_r0(self, A, ncols, alpha, W, nb, nranks, rank):
         if ncols == 0:
             return
-        self.ctx.use_torch_stream()
-        check(self.L.dhqr_form_r0_f64(self.ctx.handle, self._p(A, 0, 0), A.shape[0], ncols, A.stride(1),
+        self._lane.use_torch_stream()
+        check(self.L.dhqr_form_r0_f64(self._lane.handle, self._p(A, 0, 0), A.shape[0], ncols, A.stride(1),
                                       ctypes.c_void_p(alpha.data_ptr()), self._p(W, 0, 0), W.stride(1), nb,
                                       nranks, rank))
 
     def diff_norms(self, X, Y, ncols):
         out = (ctypes.c_double * 2)()
         if ncols > 0:
-            self.ctx.use_torch_stream()
-            check(self.L.dhqr_diff_norms_f64(self.ctx.handle, self._p(X, 0, 0), X.stride(1), self._p(Y, 0, 0),
+            self._lane.use_torch_stream()
+            check(self.L.dhqr_diff_norms_f64(self._lane.handle, self._p(X, 0, 0), X.stride(1), self._p(Y, 0, 0),
                                              Y.stride(1), X.shape[0], ncols, out))
         return out[0], out[1]
 
     def backsub_block(self, A, lc0, alpha, b, lo, hi, diag, update):
         """one block step of the back substitution with this rank's columns [lc0, lc0+hi-lo)"""
-        self.ctx.use_torch_stream()
+        self._lane.use_torch_stream()
         base = A.data_ptr() + 8 * (lc0 - lo) * A.stride(1)  # so that global column j sits at base + j*lda
-        check(self.L.dhqr_backsub_block_f64(self.ctx.handle, ctypes.c_void_p(base), A.stride(1),
+        check(self.L.dhqr_backsub_block_f64(self._lane.handle, ctypes.c_void_p(base), A.stride(1),
                                             ctypes.c_void_p(alpha.data_ptr()), ctypes.c_void_p(b.data_ptr()),
                                             lo, hi, 1 if diag else 0, 1 if update else 0))
 
@@ -142,6 +189,7 @@ class ColumnCyclicQR:
         self.alpha = self.be.zeros_vec(n)
         self.vt = [self.be.panel_buffer(m), self.be.panel_buffer(m)]
         self._work = {}
+        self._ev_panel = {}
 
     # ------------------------------------------------------------------ helpers
     def _src(self, k):  # global rank of the owner of block k
@@ -162,30 +210,42 @@ class ColumnCyclicQR:
         self.be.fill(self.A, self.ncl, seed, self.m, self.nb, self.P, self.rank)
 
     # ------------------------------------------------------------------ factorisation
-    def _factor_and_post(self, k):
-        """owner factors block k into vt[k%2]; every rank posts the (async) broadcast."""
+    def _factor_and_post(self, k, pre=None):
+        """owner factors block k into vt[k%2] (after `pre()`, e.g. the narrow update that brings
+        the block up to date); every rank posts the (async) broadcast."""
         lay = self.layout
         buf = self.vt[k % 2]
         if lay.owner(k) == self.rank:
+            if pre is not None:
+                pre()
             self.be.panel_factor(self.A, k * self.nb, lay.local_col_start(k), len(lay.block_cols(k)), buf)
+            if hasattr(self.be, "record_current"):
+                # the panel may have been produced on the look-ahead lane: consumers on the main
+                # stream wait for this event (the broadcast alone orders them only when P > 1)
+                self._ev_panel[k] = self.be.record_current()
         self._work[k] = self._bcast(k, buf, async_op=True)
 
     def _wait(self, k):
+        ev = self._ev_panel.pop(k, None)
+        if ev is not None:
+            self.be.wait_event(ev)
         w = self._work.pop(k, None)
         if w is not None:
             w.wait()
 
     def factor(self):
         """householder!(A::DArray, α) (src:115-148) on the block-cyclic column split."""
-        lay, r, nb = self.layout, self.rank, self.nb
+        lay, r, nb, be = self.layout, self.rank, self.nb, self.be
         K = lay.nblocks
+        two_lanes = self.lookahead and hasattr(be, "lane")
         self._factor_and_post(0)
+        ev_wide = None  # main-stream event after the previous wide update
         for k in range(K):
             buf = self.vt[k % 2]
             rows, c0 = self._rows(k), k * nb
             w = len(lay.block_cols(k))
             self._wait(k)
-            self.alpha[c0: c0 + w].copy_(self.be.alpha_of(buf, rows)[:w])
+            self.alpha[c0: c0 + w].copy_(be.alpha_of(buf, rows)[:w])
             lo, cnt = lay.trailing_local_cols(r, k)
             if k + 1 >= K:
                 break
@@ -193,15 +253,22 @@ class ColumnCyclicQR:
                 # look-ahead: bring block k+1 up to date, factor it and ship it while the rest of
                 # trailing update k is still running
                 w1 = len(lay.block_cols(k + 1))
-                self.be.panel_apply(buf, self.A, c0, lo, w1, True)
-                self._factor_and_post(k + 1)
-                self.be.panel_apply(buf, self.A, c0, lo + w1, cnt - w1, True)
+                if two_lanes:
+                    ev_now = be.record_main()      # alpha copy / receipt of panel k are on main
+                    be.hi_wait(ev_now)
+                    with be.lane(True):
+                        self._factor_and_post(k + 1, pre=lambda: be.panel_apply(buf, self.A, c0, lo, w1, True))
+                else:
+                    self._factor_and_post(k + 1, pre=lambda: be.panel_apply(buf, self.A, c0, lo, w1, True))
+                be.panel_apply(buf, self.A, c0, lo + w1, cnt - w1, True)
             elif self.lookahead:
                 self._factor_and_post(k + 1)  # non-owner: only posts the receive
-                self.be.panel_apply(buf, self.A, c0, lo, cnt, True)
+                be.panel_apply(buf, self.A, c0, lo, cnt, True)
             else:
-                self.be.panel_apply(buf, self.A, c0, lo, cnt, True)
+                be.panel_apply(buf, self.A, c0, lo, cnt, True)
                 self._factor_and_post(k + 1)
+        if two_lanes:
+            be.main_wait_hi()
         return self
 
     # ------------------------------------------------------------------ metric
