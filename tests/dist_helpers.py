@@ -148,6 +148,7 @@ def _entry(fn, rank, world_size, port, q, args):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         os.environ["OMP_NUM_THREADS"] = "2"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("gloo", rank=rank, world_size=world_size)
         out = fn(rank, world_size, *args)
         dist.barrier()

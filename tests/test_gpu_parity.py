@@ -162,3 +162,47 @@ def test_column_cyclic_driver_single_rank(pkg, orc, m, n):
     x = q.solve(torch.tensor(b, device="cuda:0")).cpu().numpy()
     xo = orc.solve(Ho, ao, b)
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+
+
+def _two_rank_gpu(rank, P, m, n):
+    """both ranks share cuda:0; gloo moves the device tensors -- exercises the product HipBackend
+    (two lanes, panel events, async broadcast ordering) at world size 2 on a 1-GPU box"""
+    import torch
+    import __graft_entry__ as g
+    from oracle import dhqr_oracle as orc
+    torch.cuda.set_device(0)
+    pkg = g.import_package()
+    q = pkg.ColumnCyclicQR(m, n)
+    q.fill(11)
+    q.factor()
+    torch.cuda.synchronize()
+    H, alpha = q.gather_full()
+    Ho, ao = orc.householder(orc.rand_matrix(m, n, 11))
+    scale = np.abs(Ho).max()
+    assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
+    assert np.abs(alpha - ao).max() <= 1e-11 * scale
+    res = q.residual(11)
+    assert res < 1e-12, res
+    b = orc.rand_vector(m, 12)
+    x = q.solve(torch.tensor(b, device="cuda:0")).cpu().numpy()
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    return res
+
+
+@pytest.mark.parametrize("m,n", [(1500, 1300), (2304, 2304)])
+def test_column_cyclic_driver_two_ranks_one_gpu(m, n):
+    from dist_helpers import run_ranks
+    run_ranks(_two_rank_gpu, 2, m, n)
+
+
+def test_tall_skinny_single_gpu(pkg, orc):
+    """tall panel shapes (many row chunks per panel step): 70000 x 200, blocked and unblocked"""
+    m, n = 70000, 200
+    Ho, ao = orc.householder(orc.rand_matrix(m, n, 13))
+    for nb in (0, 128):
+        H, A0 = _factor_dev(pkg, m, n, 13, nb)
+        scale = np.abs(Ho).max()
+        assert np.abs(H.A.cpu().numpy() - Ho).max() <= 1e-11 * scale
+        assert np.abs(H.α.cpu().numpy() - ao).max() <= 1e-11 * scale
+        assert pkg.residual(H, A0) < 1e-12
