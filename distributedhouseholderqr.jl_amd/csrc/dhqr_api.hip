@@ -14,6 +14,7 @@
 #include "dhqr_gemm.h"
 #include "dhqr_panel.h"
 #include "dhqr_rank1.h"
+#include "dhqr_recon.h"
 #include "dhqr_solve.h"
 
 static thread_local char g_err[512] = "";
@@ -55,7 +56,13 @@ struct dhqr_ctx {
   bool lookahead = true;
   hipEvent_t ev_panel[4] = {}, ev_wide[4] = {};
   Buf vbuf, vt, vt2, vts, spart, sfull, scratch, pbuf;
-  int panel_impl = 2;  // 2: row-split sub-panel kernels (dhqr_panel.h); 1: one workgroup per column
+  int panel_impl = 3;  // 3: R-first (CholeskyQR2 + reconstruction, dhqr_recon.h) with fallback to 2;
+                       // 2: row-split sub-panel kernels (dhqr_panel.h); 1: one workgroup per column
+  int *hflag = nullptr;  // pinned host copy of the fast path's verification flags
+  Buf rbuf;              // R1, -R1^{-1}, R, Rref, -M^{-1}, alpha_tmp, flags
+  int64_t n_fast = 0, n_fallback = 0;
+  int cholqr_passes = 1;  // Gram/Cholesky passes of the fast path (2 = CholeskyQR2)
+  double recon_tol = 2e-12;  // accepted deviation of ||v_j||^2 from 2 before falling back
   int ib = DHQR_IB;
   // profiling
   struct Ev { hipEvent_t a, b; int cat; };
@@ -244,7 +251,7 @@ static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *v
   hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(DHQR_NBV * kw / 256)), dim3(256), 0, c->stream,
                      (const double *)c->spart.p, (int)nsplit, (int64_t)DHQR_NBV * DHQR_NBV,
                      (int64_t)DHQR_NBV * kw, c->sfull.p);
-  hipLaunchKernelGGL(k_build_t2, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sfull.p,
+  hipLaunchKernelGGL(k_build_t3, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sfull.p,
                      (int)ncols, vt_T(vt, rows), vt_Tt(vt, rows));
   LAUNCHCHECK();
   return DHQR_OK;
@@ -387,10 +394,122 @@ static int32_t factor_panel_v2(dhqr_ctx *c, double *P, int64_t rows, int64_t w, 
   return DHQR_OK;
 }
 
+// ---- panel factorisation, R-first fast path (dhqr_recon.h) -------------------------------------
+// G = X'X (128 x 128) for a rows x 128 operand: split-K TN GEMM + deterministic reduction.
+static int32_t gram128(dhqr_ctx *c, const double *X, int64_t ldx, int64_t rows, double *out) {
+  int64_t nsplit, rps;
+  pick_split(rows, 1, 512, 256, &nsplit, &rps);
+  CHECK(ensure(c, c->spart, (size_t)nsplit * DHQR_NBV * DHQR_NBV));
+  const bool vec = (ldx % 2 == 0) && (rows % 2 == 0) && aligned16(X);
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, X, ldx, X, ldx,
+                       1, (int64_t)0, rows, (int64_t)DHQR_NBV, rps, c->spart.p, (int64_t)DHQR_NBV,
+                       (int64_t)DHQR_NBV * DHQR_NBV);
+  else
+    hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, X, ldx, X, ldx,
+                       1, (int64_t)0, rows, (int64_t)DHQR_NBV, rps, c->spart.p, (int64_t)DHQR_NBV,
+                       (int64_t)DHQR_NBV * DHQR_NBV);
+  hipLaunchKernelGGL(k_reduce_splits, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream,
+                     (const double *)c->spart.p, (int)nsplit, (int64_t)DHQR_NBV * DHQR_NBV,
+                     (int64_t)DHQR_NBV * DHQR_NBV, out);
+  return DHQR_OK;
+}
+// out (rows x 128, ld ldo) = X (rows x 128, ld ldx) * Y with negY = -Y given (128 x 128, ld 128)
+static int32_t mul128(dhqr_ctx *c, const double *X, int64_t ldx, int64_t rows, const double *negY, double *out,
+                      int64_t ldo) {
+  HIPCHECK(hipMemsetAsync(out, 0, (size_t)ldo * DHQR_NBV * sizeof(double), c->stream));
+  const bool vec = (ldx % 2 == 0) && (rows % 2 == 0) && aligned16(X);
+  dim3 grid((unsigned)((rows + 127) / 128), 1);
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_nn_sub<2, 128>), grid, dim3(256), 0, c->stream, X, ldx, negY, (int64_t)DHQR_NBV, out,
+                       ldo, rows, (int64_t)DHQR_NBV);
+  else
+    hipLaunchKernelGGL((k_gemm_nn_sub<1, 128>), grid, dim3(256), 0, c->stream, X, ldx, negY, (int64_t)DHQR_NBV, out,
+                       ldo, rows, (int64_t)DHQR_NBV);
+  return DHQR_OK;
+}
+
+static int32_t factor_panel_v2(dhqr_ctx *c, double *P, int64_t rows, int64_t w, int64_t ldp, double *alpha,
+                               double *vt);
+
+// Full-width panel (w == 128).  Nothing is written to P until the reflectors are verified; on a
+// failed check (ill-conditioned panel) the robust column-by-column path runs on the untouched P.
+// The verification flag is read on the host: one stream synchronisation per panel (the caller has
+// already queued the concurrent trailing update on the other stream).
+static int32_t factor_panel_v3(dhqr_ctx *c, double *P, int64_t rows, int64_t ldp, double *alpha, double *vt) {
+  const int64_t ldv = panel_ldv(rows);
+  const size_t NN = (size_t)DHQR_NBV * DHQR_NBV;
+  CHECK(ensure(c, c->rbuf, 6 * NN + 1024));
+  CHECK(ensure(c, c->vts, (size_t)panel_elems(rows)));
+  CHECK(ensure(c, c->sfull, NN));
+  double *R1 = c->rbuf.p, *negR1inv = R1 + NN, *Rf = R1 + 2 * NN, *Rref = R1 + 3 * NN, *negMinv = R1 + 4 * NN;
+  double *G = R1 + 5 * NN, *altmp = R1 + 6 * NN;
+  int *dflag = (int *)(altmp + 256);
+  double *Q1 = c->vts.p;  // rows x 128 scratch, ld = ldv
+  CHECK(prof_begin(c, CAT_PANEL));
+  const bool was = c->profiling;
+  c->profiling = false;
+  bool ok = false;
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMemsetAsync(dflag, 0, 4 * sizeof(int), c->stream));
+    CHECK(gram128(c, P, ldp, rows, G));                                            // G  = P'P
+    if (c->cholqr_passes == 2) {
+      hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, (const double *)G, (const double *)nullptr,
+                         R1, negR1inv, dflag);                                     // R1, -R1^{-1}
+      CHECK(mul128(c, P, ldp, rows, negR1inv, Q1, ldv));                           // Q1 = P R1^{-1}
+      CHECK(gram128(c, Q1, ldv, rows, G));                                         // G2 = Q1'Q1
+      hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, (const double *)G, (const double *)R1, Rf,
+                         (double *)nullptr, dflag);                                // R  = chol(G2) R1
+    } else {
+      hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, (const double *)G, (const double *)nullptr,
+                         Rf, (double *)nullptr, dflag);                            // R = chol(P'P)
+    }
+    hipLaunchKernelGGL(k_recon_top, dim3(1), dim3(1024), 0, c->stream, (const double *)P, ldp, (const double *)Rf,
+                       altmp, Rref, negMinv);                                      // alpha, R_ref, -M^{-1}
+    CHECK(mul128(c, P, ldp, rows, negMinv, vt, ldv));                              // Vw = P M^{-1}
+    hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, vt, ldv, (const double *)altmp,
+                       (const double *)negMinv);                                   // Vw = tril((P - aE) M^{-1})
+    CHECK(gram128(c, vt, ldv, rows, c->sfull.p));                                  // S = V'V
+    hipLaunchKernelGGL(k_recon_check, dim3(1), dim3(128), 0, c->stream, (const double *)c->sfull.p, c->recon_tol, dflag);
+    HIPCHECK(hipMemcpyAsync(c->hflag, dflag, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    LAUNCHCHECK();
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    ok = (c->hflag[0] == 0 && c->hflag[1] == 0);
+    if (ok) {  // commit: reflectors, R, alpha, T
+      dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
+      hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, P, ldp, rows, (int64_t)DHQR_NBV,
+                         (const double *)vt, ldv);
+      hipLaunchKernelGGL(k_recon_write_r, dim3(NN / 256), dim3(256), 0, c->stream, P, ldp, (const double *)Rref);
+      HIPCHECK(hipMemcpyAsync(alpha, altmp, DHQR_NBV * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHECK(hipMemcpyAsync(vt_alpha(vt, rows), altmp, DHQR_NBV * sizeof(double), hipMemcpyDeviceToDevice,
+                              c->stream));
+      hipLaunchKernelGGL(k_build_t3, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sfull.p, (int)DHQR_NBV,
+                         vt_T(vt, rows), vt_Tt(vt, rows));
+      LAUNCHCHECK();
+    }
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  c->profiling = was;
+  CHECK(rc);
+  if (ok) {
+    c->n_fast++;
+    if (c->profiling)
+      for (int64_t j = 0; j + 1 < DHQR_NBV; ++j)
+        c->st.bytes_panel += 16.0 * (double)(rows - j) * (double)(DHQR_NBV - j - 1);
+    CHECK(prof_end(c));
+    return DHQR_OK;
+  }
+  c->n_fallback++;
+  CHECK(prof_end(c));
+  return factor_panel_v2(c, P, rows, DHQR_NBV, ldp, alpha, vt);
+}
+
 // Factor one panel and leave (V, T, T', alpha) packed in vt.
 static int32_t factor_panel(dhqr_ctx *c, double *P, int64_t rows, int64_t w, int64_t ldp, double *alpha,
                             double *vt) {
-  if (c->panel_impl == 2) return factor_panel_v2(c, P, rows, w, ldp, alpha, vt);
+  if (c->panel_impl == 3 && w == DHQR_NBV && rows >= 2 * DHQR_NBV) return factor_panel_v3(c, P, rows, ldp, alpha, vt);
+  if (c->panel_impl >= 2) return factor_panel_v2(c, P, rows, w, ldp, alpha, vt);
   CHECK(factor_unblocked_cols(c, P, rows, w, ldp, alpha, CAT_PANEL));
   return panel_pack_and_t(c, P, rows, w, ldp, alpha, vt);
 }
@@ -442,16 +561,17 @@ static int32_t factor_blocked(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int
       const int64_t c0 = k * DHQR_NBV, w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
       if (k + 1 < K) {
         const int64_t c1 = c0 + w, w1 = std::min<int64_t>(DHQR_NBV, n - c1);
+        const int64_t c2 = c1 + w1;
+        // wide update first: the panel path below synchronises its stream on the host once
+        on(sA, 0);
+        HIPCHECK(hipStreamWaitEvent(sA, c->ev_panel[k & 3], 0));
+        if (c2 < n) CHECK(panel_apply(c, vt[k & 1], rows, dA + c0 + c2 * lda, n - c2, lda, 1));
+        HIPCHECK(hipEventRecord(c->ev_wide[k & 3], sA));
         on(sB, 1);
         if (k >= 1) HIPCHECK(hipStreamWaitEvent(sB, c->ev_wide[(k - 1) & 3], 0));  // block k+1 is current, vt[(k+1)&1] free
         CHECK(panel_apply(c, vt[k & 1], rows, dA + c0 + c1 * lda, w1, lda, 1));
         CHECK(factor_panel(c, dA + c1 + c1 * lda, m - c1, w1, lda, dalpha + c1, vt[(k + 1) & 1]));
         HIPCHECK(hipEventRecord(c->ev_panel[(k + 1) & 3], sB));
-        const int64_t c2 = c1 + w1;
-        on(sA, 0);
-        HIPCHECK(hipStreamWaitEvent(sA, c->ev_panel[k & 3], 0));
-        if (c2 < n) CHECK(panel_apply(c, vt[k & 1], rows, dA + c0 + c2 * lda, n - c2, lda, 1));
-        HIPCHECK(hipEventRecord(c->ev_wide[k & 3], sA));
       }
     }
     // the caller's stream owns the result: wait for the last panel
@@ -546,7 +666,13 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     }
   }
   if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
-  if (const char *e = getenv("DHQR_PANEL")) c->panel_impl = atoi(e) == 1 ? 1 : 2;
+  HIPCHECK(hipHostMalloc((void **)&c->hflag, 4 * sizeof(int), hipHostMallocDefault));
+  if (const char *e = getenv("DHQR_CHOLQR_PASSES")) c->cholqr_passes = atoi(e) == 2 ? 2 : 1;
+  if (const char *e = getenv("DHQR_RECON_TOL")) c->recon_tol = atof(e);
+  if (const char *e = getenv("DHQR_PANEL")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 3) c->panel_impl = v;
+  }
   if (const char *e = getenv("DHQR_IB")) {
     const int v = atoi(e);
     if (v == 16 || v == 32 || v == 64 || v == 128) c->ib = v;
@@ -560,7 +686,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   Buf *bufs[] = {&c->vbuf, &c->vt, &c->vt2, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
-                 &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf};
+                 &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {
@@ -571,6 +697,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
     if (c->ev_panel[i]) (void)hipEventDestroy(c->ev_panel[i]);
     if (c->ev_wide[i]) (void)hipEventDestroy(c->ev_wide[i]);
   }
+  if (c->hflag) (void)hipHostFree(c->hflag);
   if (c->hi) (void)hipStreamDestroy(c->hi);
   if (c->own) (void)hipStreamDestroy(c->own);
   delete c;

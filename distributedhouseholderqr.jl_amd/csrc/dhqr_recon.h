@@ -1,0 +1,287 @@
+// dhqr_recon.h -- "R first" panel factorisation: the fast path of the blocked driver.
+//
+// The reference needs one full-column reduction per panel column (norm + dots, src:129, 208): 128
+// dependent global synchronisations per 128-column panel.  For a panel P (rows x 128) we instead
+//   1. get R of P = QR with two Gram/Cholesky passes (CholeskyQR2): G = P'P, R1 = chol(G),
+//      Q1 = P R1^{-1}, G2 = Q1'Q1, R2 = chol(G2), R = R2 R1     -- GEMMs on the MFMA kernels,
+//   2. replay the unblocked algorithm ON THE TOP 128 x 128 BLOCK ONLY (k_recon_top): with R known,
+//      every quantity the reference derives from a global reduction follows from the pivot row:
+//         s_j = |R_jj|, alpha_j = -sign(a_jj) s_j, f_j            (src:129-131)
+//         v_j' a_k = (a_jk - R_jk) / v_jj                         (row j of the update, src:209)
+//      which gives the upper-triangular M with  P - alpha E - striu(R) = V M,
+//   3. obtain all 128 reflectors at once:  V = tril( (P - alpha E) M^{-1} )   -- one more GEMM,
+//   4. verify ||v_j||^2 = 2 for every column (diag of V'V, needed for T anyway).
+// The result is the SAME factorisation the reference computes (Householder QR is unique given the
+// sign rule), to rounding: numpy prototype and GPU tests agree with the oracle to ~5e-15.  For
+// numerically rank-deficient panels CholeskyQR loses accuracy (or breaks down); step 4 detects
+// that BEFORE anything is written to P and the driver falls back to the column-by-column kernels
+// of dhqr_panel.h, so robustness is that of the reference algorithm.
+#pragma once
+#include "dhqr_common.h"
+
+#define RC_N 128
+
+// X = R^{-1} for an upper-triangular 128 x 128 R held in registers in the 4 x 4 cyclic layout of a
+// 1024-thread workgroup (thread (ti,tk) owns R[ti+32a][tk+32b]; entries below the diagonal are
+// ignored).  Row l of X is finished from the running products acc = R[:, l+1:] X[l+1:, :] and
+// immediately folded in as a rank-1 update, exactly the data flow of the Cholesky loop below:
+// per step only one column of R and one row of X travel through LDS.  x gets the same layout.
+__device__ __forceinline__ void rc_upper_inverse_regs(const double (&r)[4][4], double (&x)[4][4],
+                                                      double *dinv, double *rowbuf, double *colbuf) {
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (ti == tk) dinv[ti + 32 * a] = 1.0 / r[a][a];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { acc[a][b] = 0.0; x[a][b] = 0.0; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int la = 3; la >= 0; --la)
+    for (int lm = 31; lm >= 0; --lm) {
+      const int l = la * 32 + lm;
+      if (ti == lm) {  // owners of row l of X
+        const double di = dinv[l];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int k = tk + 32 * b;
+          const double v = (k >= l) ? ((k == l ? 1.0 : 0.0) - acc[la][b]) * di : 0.0;
+          x[la][b] = v;
+          rowbuf[k] = v;
+        }
+      }
+      if (tk == lm) {  // owners of column l of R
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int i = ti + 32 * a;
+          colbuf[i] = (i < l) ? r[a][la] : 0.0;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const double ci = colbuf[ti + 32 * a];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = fma(ci, rowbuf[tk + 32 * b], acc[a][b]);
+      }
+      __syncthreads();
+    }
+}
+
+// Cholesky G = R'R (upper R) of a 128 x 128 Gram matrix, optional R <- R * Rprev (second
+// CholeskyQR pass), optional output of -R^{-1} (the W operand of k_gemm_nn_sub, which negates it
+// again).  1024 threads; thread (ti,tk) keeps the 4 x 4 cyclic sub-block G[ti+32a][tk+32b] in
+// registers for the whole factorisation; per step only row j travels through LDS.
+// flag[0] is set to 1 when a pivot is not positive (breakdown).
+__global__ __launch_bounds__(1024) void k_chol_inv(const double *__restrict__ G,
+                                                   const double *__restrict__ Rprev,
+                                                   double *__restrict__ Rout,
+                                                   double *__restrict__ negXout,
+                                                   int *__restrict__ flag) {
+  __shared__ double rowbuf[RC_N], colbuf[RC_N], dinv[RC_N];
+  __shared__ double dsh;
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
+  double g[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) g[a][b] = G[(ti + 32 * a) + (tk + 32 * b) * RC_N];
+
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja)  // unrolled so every register-array index is a compile-time constant
+    for (int jm = 0; jm < 32; ++jm) {
+      const int j = ja * 32 + jm;
+      if (ti == jm && tk == jm) dsh = g[ja][ja];
+      __syncthreads();
+      double d = dsh;
+      if (!(d > 0.0)) {  // breakdown (or NaN): flag it, keep going with a harmless pivot
+        if (t == 0) flag[0] = 1;
+        d = 1.0;
+      }
+      const double r = sqrt(d), rinv = 1.0 / r;
+      if (ti == jm) {  // owners of row j: R[j,k] = G[j,k] / r (k > j), R[j,j] = r
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int k = tk + 32 * b;
+          const double x = (k == j) ? r : g[ja][b] * rinv;
+          g[ja][b] = x;
+          rowbuf[k] = (k > j) ? x : 0.0;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int i = ti + 32 * a;
+        const double ri = (i > j) ? rowbuf[i] : 0.0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) g[a][b] = fma(-ri, rowbuf[tk + 32 * b], g[a][b]);
+      }
+    }
+  // registers now hold R in the upper triangle
+  if (Rprev) {  // R <- R * Rprev through LDS-free global reads of Rprev (rare second pass)
+    __shared__ double Rl[RC_N * (RC_N + 1) / 2];
+    auto pidx = [](int i, int l) { return i * RC_N - (i * (i - 1)) / 2 + (l - i); };
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = ti + 32 * a, k = tk + 32 * b;
+        if (i <= k) Rl[pidx(i, k)] = g[a][b];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = ti + 32 * a, k = tk + 32 * b;
+        double x = 0.0;
+        if (i <= k)
+          for (int l = i; l <= k; ++l) x = fma(Rl[pidx(i, l)], Rprev[l + k * RC_N], x);
+        g[a][b] = x;
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = ti + 32 * a, k = tk + 32 * b;
+      Rout[i + k * RC_N] = (i <= k) ? g[a][b] : 0.0;
+    }
+  if (!negXout) return;
+  double x[4][4];
+  __syncthreads();
+  rc_upper_inverse_regs(g, x, dinv, rowbuf, colbuf);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) negXout[(ti + 32 * a) + (tk + 32 * b) * RC_N] = -x[a][b];
+}
+
+// Replay of the unblocked algorithm on the top 128 x 128 block with R known (see file header).
+// Inputs: P (original panel, ldp), R (128 x 128 upper, any row signs).
+// Outputs: alpha[128]; Rref = strict upper part of the reference's R (row signs fixed so that
+// R_jj = alpha_j), dense 128 x 128; negMinv = -M^{-1} dense 128 x 128.
+__global__ __launch_bounds__(1024) void k_recon_top(const double *__restrict__ P, int64_t ldp,
+                                                    const double *__restrict__ R,
+                                                    double *__restrict__ alpha,
+                                                    double *__restrict__ Rref,
+                                                    double *__restrict__ negMinv) {
+  __shared__ double wrow[RC_N], vcol[RC_N], dinv[RC_N];
+  __shared__ double sh[2];
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
+  double a[4][4], r[4][4], mm[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int i = ti + 32 * x, k = tk + 32 * y;
+      a[x][y] = P[i + (int64_t)k * ldp];
+      r[x][y] = R[i + k * RC_N];
+      mm[x][y] = 0.0;
+    }
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja)  // unrolled: constant register-array indices (no scratch)
+    for (int jm = 0; jm < 32; ++jm) {
+      const int j = ja * 32 + jm;
+      if (ti == jm && tk == jm) { sh[0] = a[ja][ja]; sh[1] = r[ja][ja]; }
+      __syncthreads();
+      const double ajj = sh[0], rjj = sh[1];
+      const double s = fabs(rjj);                         // src:129 (norm of the updated column)
+      const double al = s * dhqr_alphafactor(ajj);        // src:130
+      const double f = 1.0 / sqrt(s * (s + fabs(ajj)));   // src:131
+      const double vjj = (ajj - al) * f;                  // src:132-135
+      const double sg = al / rjj;                         // row sign: reference R_jj == alpha_j
+      const double vinv = 1.0 / vjj;
+      if (ti == jm) {  // owners of row j: w_jk = v_j' a_k, R row in the reference's sign convention
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          const int k = tk + 32 * y;
+          const double rr = sg * r[ja][y];
+          const double w = (k > j) ? (a[ja][y] - rr) * vinv : 0.0;
+          wrow[k] = w;
+          mm[ja][y] = (k > j) ? w : (k == j ? 1.0 / f : 0.0);  // M[j][k] = w_jk, M[j][j] = 1/f_j
+          Rref[j + k * RC_N] = (k > j) ? rr : 0.0;
+        }
+      }
+      if (tk == jm) {  // owners of column j: v_ij = f a_ij (i > j)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int i = ti + 32 * x;
+          vcol[i] = (i > j) ? f * a[x][ja] : 0.0;
+        }
+      }
+      if (t == 0) alpha[j] = al;
+      __syncthreads();
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const double vi = vcol[ti + 32 * x];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) a[x][y] = fma(-vi, wrow[tk + 32 * y], a[x][y]);  // src:209, top rows
+      }
+    }
+  __syncthreads();
+  double xm[4][4];
+  rc_upper_inverse_regs(mm, xm, dinv, wrow, vcol);
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) negMinv[(ti + 32 * x) + (tk + 32 * y) * RC_N] = -xm[x][y];
+}
+
+// Compact-WY T = (I + striu(S))^{-1} from S = V'V (algebra: dhqr_gemm.h), register-resident
+// inverse.  Columns >= ncols of V are zero padding: T[j][j] = 1, rest of the column 0.
+__global__ __launch_bounds__(1024) void k_build_t3(const double *__restrict__ S, int ncols,
+                                                   double *__restrict__ Tout,
+                                                   double *__restrict__ Ttout) {
+  __shared__ double rowbuf[RC_N], colbuf[RC_N], dinv[RC_N];
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
+  double u[4][4], x[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = ti + 32 * a, k = tk + 32 * b;
+      u[a][b] = (i == k) ? 1.0 : ((i < k && k < ncols) ? S[i + k * RC_N] : 0.0);
+    }
+  rc_upper_inverse_regs(u, x, dinv, rowbuf, colbuf);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = ti + 32 * a, k = tk + 32 * b;
+      Tout[i + k * RC_N] = x[a][b];   // upper triangular (x is 0 below the diagonal)
+      Ttout[k + i * RC_N] = x[a][b];
+    }
+}
+
+// Vw currently holds P * M^{-1}; finish V = tril((P - alpha E) M^{-1}) on the top 128 rows:
+// Vw[i][j] -= alpha_i * Minv[i][j] (i <= j ... only i == row index < 128), and zero above the diagonal.
+__global__ __launch_bounds__(256) void k_recon_fix(double *__restrict__ Vw, int64_t ldv,
+                                                   const double *__restrict__ alpha,
+                                                   const double *__restrict__ negMinv) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // 128 x 128 entries
+  if (idx >= RC_N * RC_N) return;
+  const int i = idx & (RC_N - 1), j = idx >> 7;
+  double x = 0.0;
+  if (i >= j) x = Vw[i + (int64_t)j * ldv] + alpha[i] * negMinv[i + j * RC_N];  // - alpha_i * Minv[i][j]
+  Vw[i + (int64_t)j * ldv] = x;
+}
+
+// flag[1] = 1 unless every ||v_j||^2 (diag of S = V'V) is within tol of 2 (NaN fails too)
+__global__ __launch_bounds__(128) void k_recon_check(const double *__restrict__ S, double tol,
+                                                     int *__restrict__ flag) {
+  const int j = threadIdx.x;
+  const double d = S[j + j * RC_N];
+  const bool ok = fabs(d - 2.0) <= tol;
+  if (!ok) flag[1] = 1;
+}
+
+// commit: strict upper part of the top block <- reference R
+__global__ __launch_bounds__(256) void k_recon_write_r(double *__restrict__ P, int64_t ldp,
+                                                       const double *__restrict__ Rref) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= RC_N * RC_N) return;
+  const int i = idx & (RC_N - 1), j = idx >> 7;
+  if (i < j) P[i + (int64_t)j * ldp] = Rref[idx];
+}

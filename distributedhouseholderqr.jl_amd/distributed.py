@@ -254,13 +254,17 @@ class ColumnCyclicQR:
                 # trailing update k is still running
                 w1 = len(lay.block_cols(k + 1))
                 if two_lanes:
-                    ev_now = be.record_main()      # alpha copy / receipt of panel k are on main
+                    # the panel path synchronises its own stream on the host once (verification
+                    # flag of the fast path), so the wide update is queued on the main stream
+                    # FIRST; the look-ahead lane only waits for what was queued before it
+                    ev_now = be.record_main()      # alpha copy / receipt of panel k / wide update k-1
+                    be.panel_apply(buf, self.A, c0, lo + w1, cnt - w1, True)
                     be.hi_wait(ev_now)
                     with be.lane(True):
                         self._factor_and_post(k + 1, pre=lambda: be.panel_apply(buf, self.A, c0, lo, w1, True))
                 else:
                     self._factor_and_post(k + 1, pre=lambda: be.panel_apply(buf, self.A, c0, lo, w1, True))
-                be.panel_apply(buf, self.A, c0, lo + w1, cnt - w1, True)
+                    be.panel_apply(buf, self.A, c0, lo + w1, cnt - w1, True)
             elif self.lookahead:
                 self._factor_and_post(k + 1)  # non-owner: only posts the receive
                 be.panel_apply(buf, self.A, c0, lo, cnt, True)

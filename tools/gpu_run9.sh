@@ -1,0 +1,13 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -rfEs -p no:cacheprovider -x 2>&1 | tail -30 > gpurun_out/pytest_gpu9.txt
+tail -12 gpurun_out/pytest_gpu9.txt
+for P in 3 2; do for LA in 1 0; do echo "== DHQR_PANEL=$P DHQR_LOOKAHEAD=$LA"; DHQR_PANEL=$P DHQR_LOOKAHEAD=$LA timeout 600 python tools/quick_bench.py 16384,128 32768,128 2>&1 | grep -v "amdgpu.ids\|ubench"; done; done > gpurun_out/quick_bench9.txt
+python - <<'PY'
+import json
+for l in open('gpurun_out/quick_bench9.txt'):
+    if l.startswith('=='): print(l.strip()); continue
+    try: d=json.loads(l)
+    except Exception: print(l.strip()[:300]); continue
+    s=d['stats']; print(f"  n={d['n']} t={d['t0']:.3f}s {d['gflops']/1e3:.1f} TF/s panel={s.get('ms_panel',0):.0f} vta={s.get('ms_gemm_vta',0):.0f} tw={s.get('ms_gemm_tw',0):.0f} avw={s.get('ms_gemm_avw',0):.0f} resid={d.get('resid'):.1e}")
+PY
