@@ -166,6 +166,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
+    panel_counts = list(ctx.panel_counters())
+    if not use_c and hasattr(q.be, "ctx_hi"):
+        pc2 = q.be.ctx_hi.panel_counters()
+        panel_counts = [panel_counts[0] + pc2[0], panel_counts[1] + pc2[1]]
     resid = None
     if not args.no_residual:
         if use_c:
@@ -220,10 +224,17 @@ def main():
                                          "launches", "avg_launch_ms")},
         "roofline_all": rl_all,
         "phase_ms_per_step": {k: st[k] / args.steps for k in st if k.startswith("ms_") and st[k] > 0},
+        "panels_fast_fallback": panel_counts,
     }
     if rank == 0 and world == 1:
         try:
-            out["fp64_mfma_ubench_tflops"] = pkg.bench_mfma_tflops(local_rank)
+            import ctypes as _ct
+            o4 = (_ct.c_double * 4)()   # 4 waves/SIMD, accumulators in VGPRs: the achievable issue rate
+            pkg._lib.check(pkg._lib.lib().dhqr_bench_issue2_f64(ctx.handle, 0, 1024, 256, o4))
+            out["fp64_mfma_ubench_tflops"] = o4[2]
+            out["fp64_mfma_ubench_note"] = ("v_mfma_f64_16x16x4_f64 only, 4 waves/SIMD, VGPR accumulators "
+                                            "(16 AGPR accumulators per wave issue at half rate: %.1f TFLOP/s)"
+                                            % pkg.bench_mfma_tflops(local_rank))
             out["stream_ubench_gbps"] = pkg.bench_stream_gbps(1 << 30, local_rank)
         except Exception as e:  # diagnostics only
             out["ubench_error"] = repr(e)

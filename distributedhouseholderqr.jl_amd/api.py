@@ -60,6 +60,12 @@ class Context:
         check(_lib.lib().dhqr_get_stats(self._h, ctypes.byref(st)))
         return st.asdict()
 
+    def panel_counters(self):
+        """(panels done by the R-first fast path, panels that fell back to the step kernels)"""
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        check(_lib.lib().dhqr_get_panel_counters(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def close(self):
         if self._h:
             _lib.lib().dhqr_destroy(self._h)

@@ -730,6 +730,7 @@ int32_t dhqr_reset_stats(dhqr_ctx *c) {
   HIPCHECK(hipStreamSynchronize(c->stream));
   c->ev_used = 0;
   memset(&c->st, 0, sizeof(c->st));
+  c->n_fast = c->n_fallback = 0;
   return DHQR_OK;
 }
 int32_t dhqr_get_stats(dhqr_ctx *c, dhqr_stats *out) {
@@ -737,6 +738,13 @@ int32_t dhqr_get_stats(dhqr_ctx *c, dhqr_stats *out) {
   if (!out) return set_err(DHQR_EINVAL, "null stats pointer");
   CHECK(prof_resolve(c));
   *out = c->st;
+  return DHQR_OK;
+}
+
+int32_t dhqr_get_panel_counters(dhqr_ctx *c, int64_t *n_fast, int64_t *n_fallback) {
+  CHECK(check_ctx(c));
+  if (n_fast) *n_fast = c->n_fast;
+  if (n_fallback) *n_fallback = c->n_fallback;
   return DHQR_OK;
 }
 

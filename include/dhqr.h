@@ -80,6 +80,10 @@ int32_t dhqr_set_profiling(dhqr_ctx *ctx, int32_t on);
 int32_t dhqr_reset_stats(dhqr_ctx *ctx);
 int32_t dhqr_get_stats(dhqr_ctx *ctx, dhqr_stats *out); /* synchronises the ctx stream */
 
+/* Panels factored since the last dhqr_reset_stats() by the R-first fast path (csrc/dhqr_recon.h)
+ * and panels whose verification failed and were redone by the column-by-column path. */
+int32_t dhqr_get_panel_counters(dhqr_ctx *ctx, int64_t *n_fast, int64_t *n_fallback);
+
 /* ------------------------------------------------------------------ synthetic inputs
  * Replaces rand(T,m,n) / rand(T,m) of test/runtests.jl:45-46 with the portable counter-based
  * generator shared with oracle/ :  value(gi, gj) = u01(seed, gi + gj*global_m).

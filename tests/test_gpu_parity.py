@@ -206,3 +206,33 @@ def test_tall_skinny_single_gpu(pkg, orc):
         assert np.abs(H.A.cpu().numpy() - Ho).max() <= 1e-11 * scale
         assert np.abs(H.α.cpu().numpy() - ao).max() <= 1e-11 * scale
         assert pkg.residual(H, A0) < 1e-12
+
+
+def test_fast_panel_path_is_used_and_falls_back(pkg, orc):
+    """The R-first panel path must (a) actually run on well-conditioned input and (b) detect an
+    ill-conditioned panel (two nearly dependent columns), redo it with the column-by-column kernels
+    and still deliver a backward-stable factorisation."""
+    import torch
+    ctx = pkg.get_context(0)
+    m, n = 1500, 640
+    ctx.reset_stats()
+    H, A0 = _factor_dev(pkg, m, n, 21, 128)
+    fast, fb = ctx.panel_counters()
+    assert fast >= 4 and fb == 0, (fast, fb)
+    assert pkg.residual(H, A0) < 1e-12
+    # near-dependent columns inside the second panel
+    A = pkg.rand_colmajor(m, n, 22, "cuda:0")
+    A[:, 200] = A[:, 199] * (1.0 + 1e-9)
+    A0 = A.clone()
+    Ah = A0.cpu().numpy()
+    ctx.reset_stats()
+    H = pkg.qr_(A, nb=128)
+    torch.cuda.synchronize()
+    fast, fb = ctx.panel_counters()
+    assert fb >= 1, (fast, fb)
+    assert pkg.residual(H, A0) < 1e-12
+    Ho, ao = orc.householder(np.asfortranarray(Ah))
+    # R agrees with the oracle where it is well determined (|R| not tiny)
+    Rg = np.triu(H.A.cpu().numpy()[:n], 1) + np.diag(H.α.cpu().numpy())
+    Ro = np.triu(Ho[:n], 1) + np.diag(ao)
+    assert np.abs(np.abs(Rg[:199, :199]) - np.abs(Ro[:199, :199])).max() <= 1e-10 * np.abs(Ro).max()
