@@ -51,6 +51,7 @@ struct dhqr_ctx {
   hipStream_t own = nullptr, stream = nullptr;
   bool profiling = false;
   hipStream_t hi = nullptr;      // high-priority stream: panel factorisation under look-ahead
+  int swizzle = 1;               // XCD-aware tile order in k_gemm_nn_sub (+1.5 % at 32768^2; DHQR_SWIZZLE=0 disables)
   struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
   int cur_ws = 0;
   bool lookahead = true;
@@ -299,13 +300,16 @@ static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *
                        (int64_t)KW_, ws.w2.p, (int64_t)DHQR_NBV, (int64_t)0);                            \
     CHECK(prof_end(c));                                                                              \
     CHECK(prof_begin(c, CAT_AVW));                                                                   \
-    dim3 grid((unsigned)((rows + 127) / 128), (unsigned)ntiles);                                     \
+    const int64_t gx_ = (rows + 127) / 128;                                                          \
+    const int swz_ = (c->swizzle && gx_ >= 16 && ntiles >= 16) ? 1 : 0;                              \
+    dim3 grid((unsigned)gx_, (unsigned)ntiles);                                                      \
+    if (swz_) grid = dim3((unsigned)((((gx_ + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);      \
     if (vec)                                                                                         \
       hipLaunchKernelGGL((k_gemm_nn_sub<2, KW_>), grid, dim3(256), 0, c->stream, V, ldv,             \
-                         (const double *)ws.w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols);           \
+                         (const double *)ws.w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols, swz_);     \
     else                                                                                             \
       hipLaunchKernelGGL((k_gemm_nn_sub<1, KW_>), grid, dim3(256), 0, c->stream, V, ldv,             \
-                         (const double *)ws.w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols);           \
+                         (const double *)ws.w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols, swz_);     \
     CHECK(prof_end(c));                                                                              \
   } while (0)
   if (kw == 32) DHQR_APPLY(32);
@@ -422,10 +426,10 @@ static int32_t mul128(dhqr_ctx *c, const double *X, int64_t ldx, int64_t rows, c
   dim3 grid((unsigned)((rows + 127) / 128), 1);
   if (vec)
     hipLaunchKernelGGL((k_gemm_nn_sub<2, 128>), grid, dim3(256), 0, c->stream, X, ldx, negY, (int64_t)DHQR_NBV, out,
-                       ldo, rows, (int64_t)DHQR_NBV);
+                       ldo, rows, (int64_t)DHQR_NBV, 0);
   else
     hipLaunchKernelGGL((k_gemm_nn_sub<1, 128>), grid, dim3(256), 0, c->stream, X, ldx, negY, (int64_t)DHQR_NBV, out,
-                       ldo, rows, (int64_t)DHQR_NBV);
+                       ldo, rows, (int64_t)DHQR_NBV, 0);
   return DHQR_OK;
 }
 
@@ -450,10 +454,11 @@ static int32_t factor_panel_v3(dhqr_ctx *c, double *P, int64_t rows, int64_t ldp
   const bool was = c->profiling;
   c->profiling = false;
   bool ok = false;
+  int passes = c->cholqr_passes;
   auto body = [&]() -> int32_t {
     HIPCHECK(hipMemsetAsync(dflag, 0, 4 * sizeof(int), c->stream));
     CHECK(gram128(c, P, ldp, rows, G));                                            // G  = P'P
-    if (c->cholqr_passes == 2) {
+    if (passes == 2) {
       hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, (const double *)G, (const double *)nullptr,
                          R1, negR1inv, dflag);                                     // R1, -R1^{-1}
       CHECK(mul128(c, P, ldp, rows, negR1inv, Q1, ldv));                           // Q1 = P R1^{-1}
@@ -489,7 +494,11 @@ static int32_t factor_panel_v3(dhqr_ctx *c, double *P, int64_t rows, int64_t ldp
     }
     return DHQR_OK;
   };
-  const int32_t rc = body();
+  int32_t rc = body();
+  if (rc == DHQR_OK && !ok && passes == 1) {  // moderately ill-conditioned panel: CholeskyQR2 before giving up
+    passes = 2;
+    rc = body();
+  }
   c->profiling = was;
   CHECK(rc);
   if (ok) {
@@ -548,12 +557,14 @@ static int32_t factor_blocked(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int
     CHECK(ensure(c, c->sfull, (size_t)DHQR_NBV * DHQR_NBV));
   }
   double *vt[2] = {c->vt.p, c->vt2.p};
-  hipStream_t sA = c->stream, sB = c->hi;
+  hipStream_t sU = c->stream, sB = c->hi;          // sU: the caller's stream
+  hipStream_t sA = sU;                             // stream of the wide updates
   auto on = [&](hipStream_t s, int wsi) { c->stream = s; c->cur_ws = wsi; };
   auto body = [&]() -> int32_t {
     // order stream B after whatever the caller queued on A (e.g. the fill)
-    HIPCHECK(hipEventRecord(c->ev_wide[3], sA));
+    HIPCHECK(hipEventRecord(c->ev_wide[3], sU));
     HIPCHECK(hipStreamWaitEvent(sB, c->ev_wide[3], 0));
+    if (sA != sU) HIPCHECK(hipStreamWaitEvent(sA, c->ev_wide[3], 0));
     on(sB, 1);
     CHECK(factor_panel(c, dA, m, std::min<int64_t>(DHQR_NBV, n), lda, dalpha, vt[0]));
     HIPCHECK(hipEventRecord(c->ev_panel[0], sB));
@@ -574,12 +585,16 @@ static int32_t factor_blocked(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int
         HIPCHECK(hipEventRecord(c->ev_panel[(k + 1) & 3], sB));
       }
     }
-    // the caller's stream owns the result: wait for the last panel
-    HIPCHECK(hipStreamWaitEvent(sA, c->ev_panel[(K - 1) & 3], 0));
+    // the caller's stream owns the result: wait for the last panel (and the last wide update)
+    HIPCHECK(hipStreamWaitEvent(sU, c->ev_panel[(K - 1) & 3], 0));
+    if (sA != sU) {
+      HIPCHECK(hipEventRecord(c->ev_wide[2], sA));
+      HIPCHECK(hipStreamWaitEvent(sU, c->ev_wide[2], 0));
+    }
     return DHQR_OK;
   };
   const int32_t rc = body();
-  on(sA, 0);
+  on(sU, 0);
   return rc;
 }
 
@@ -666,6 +681,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     }
   }
   if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
+  if (const char *e = getenv("DHQR_SWIZZLE")) c->swizzle = atoi(e) != 0;
   HIPCHECK(hipHostMalloc((void **)&c->hflag, 4 * sizeof(int), hipHostMallocDefault));
   if (const char *e = getenv("DHQR_CHOLQR_PASSES")) c->cholqr_passes = atoi(e) == 2 ? 2 : 1;
   if (const char *e = getenv("DHQR_RECON_TOL")) c->recon_tol = atof(e);

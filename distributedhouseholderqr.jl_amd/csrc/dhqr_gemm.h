@@ -198,14 +198,28 @@ template <int VEC, int KW>
 __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict__ V, int64_t ldv,
                                                         const double *__restrict__ W, int64_t ldw,
                                                         double *__restrict__ C, int64_t ldc,
-                                                        int64_t rows, int64_t ncols) {
+                                                        int64_t rows, int64_t ncols, int swz) {
   __shared__ __attribute__((aligned(16))) double Vs[2][G_KT * G_LDR];
   __shared__ __attribute__((aligned(16))) double Ws[2][128 * G_LDK];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int i16 = lane & 15, k4 = lane >> 4;
   const int wr = w & 1, wc = w >> 1;
-  const int64_t r0 = (int64_t)blockIdx.x * 128;
-  const int64_t c0 = (int64_t)blockIdx.y * 128;
+  int64_t tr = blockIdx.x, tc = blockIdx.y;
+  if (swz) {
+    // XCD-aware order (1-D launch): workgroup L runs on XCD L % 8 (observed dispatch rule, speed
+    // only).  Each XCD walks its own 8 x 8 blocks of tiles so the V row-tiles and W column-tiles it
+    // re-reads (8 + 8 tiles x 128 KiB = 2 MiB) stay in its private 4 MiB L2.
+    const int64_t gx = (rows + 127) / 128, gy = (ncols + 127) / 128;
+    const int64_t bx = (gx + 7) / 8;
+    const int64_t L = blockIdx.x;
+    const int64_t xcd = L & 7, sq = L >> 3;
+    const int64_t blk = (sq >> 6) * 8 + xcd, idx = sq & 63;
+    tr = (blk % bx) * 8 + (idx & 7);
+    tc = (blk / bx) * 8 + (idx >> 3);
+    if (tr >= gx || tc >= gy) return;
+  }
+  const int64_t r0 = tr * 128;
+  const int64_t c0 = tc * 128;
   const int nrv = (int)((rows - r0 < 128) ? rows - r0 : 128);    // valid rows in this tile
   const int ncv = (int)((ncols - c0 < 128) ? ncols - c0 : 128);  // valid columns
 

@@ -237,7 +237,12 @@ class ColumnCyclicQR:
         """householder!(A::DArray, α) (src:115-148) on the block-cyclic column split."""
         lay, r, nb, be = self.layout, self.rank, self.nb, self.be
         K = lay.nblocks
-        two_lanes = self.lookahead and hasattr(be, "lane")
+        # Two lanes (panel k+1 on a second stream underneath the wide update k) only pay at world
+        # size 1.  With P > 1 the block owner's own wide update is off the critical path (the next
+        # P-1 panels belong to other ranks) while its panel IS the critical path, and the panel's
+        # single-workgroup kernels run 4-20x slower when they share the GPU with the GEMMs
+        # (profiles/r01c_*), so the owner factors first and updates afterwards.
+        two_lanes = self.lookahead and hasattr(be, "lane") and self.P == 1
         self._factor_and_post(0)
         ev_wide = None  # main-stream event after the previous wide update
         for k in range(K):
