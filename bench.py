@@ -191,7 +191,7 @@ def main():
         groups.append(dict(kernel="k_gemm_tn (W = V'*A, FP64 MFMA)", bound="mfma", ms=st["ms_gemm_vta"],
                            launches=st["n_gemm_vta"], work=st["flops_gemm_vta"]))
     if st["ms_panel"] > 0:
-        groups.append(dict(kernel="k_rank1_fused/generic (panel factorisation)", bound="hbm", ms=st["ms_panel"],
+        groups.append(dict(kernel="panel lane: Gram/Cholesky/replay/narrow-update kernels (dhqr_recon.h)", bound="hbm", ms=st["ms_panel"],
                            launches=st["n_panel"], work=st["bytes_panel"]))
     if st["ms_rank1"] > 0:
         groups.append(dict(kernel="k_rank1_fused (reflector apply)", bound="hbm", ms=st["ms_rank1"],

@@ -580,7 +580,15 @@ static int32_t factor_blocked(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int
         HIPCHECK(hipEventRecord(c->ev_wide[k & 3], sA));
         on(sB, 1);
         if (k >= 1) HIPCHECK(hipStreamWaitEvent(sB, c->ev_wide[(k - 1) & 3], 0));  // block k+1 is current, vt[(k+1)&1] free
-        CHECK(panel_apply(c, vt[k & 1], rows, dA + c0 + c1 * lda, w1, lda, 1));
+        {  // narrow (one block column) update of the look-ahead lane: accounted to the panel group
+          CHECK(prof_begin(c, CAT_PANEL));
+          const bool was = c->profiling;
+          c->profiling = false;
+          const int32_t rcn = panel_apply(c, vt[k & 1], rows, dA + c0 + c1 * lda, w1, lda, 1);
+          c->profiling = was;
+          CHECK(rcn);
+          CHECK(prof_end(c));
+        }
         CHECK(factor_panel(c, dA + c1 + c1 * lda, m - c1, w1, lda, dalpha + c1, vt[(k + 1) & 1]));
         HIPCHECK(hipEventRecord(c->ev_panel[(k + 1) & 3], sB));
       }

@@ -347,36 +347,11 @@ __global__ __launch_bounds__(256) void k_reduce_splits(const double *__restrict_
   out[e] = s;
 }
 
-// Compact-WY T from S = V'V (128 x 128, ld 128; only the strict upper triangle is used):
-//   T[0:j, j] = -T[0:j,0:j] * S[0:j, j],  T[j][j] = 1       (tau_j == 1: H_j = I - v_j v_j')
-// which is T^{-1} = I + striu(V'V); valid for ANY v_j, so the reference's zero-pivot reflectors
-// (||v||^2 != 2) are reproduced exactly.  One workgroup of 128 threads, T kept in LDS
-// (column l contiguous over rows i). Writes T and T' (both 128 x 128, ld 128, dense).
-__global__ __launch_bounds__(128) void k_build_t(const double *__restrict__ S,
-                                                 double *__restrict__ Tout,
-                                                 double *__restrict__ Ttout) {
-  __shared__ double Tl[128 * 128];
-  __shared__ double Scol[128];
-  const int i = threadIdx.x;
-  for (int l = 0; l < 128; ++l) Tl[l * 128 + i] = 0.0;
-  __syncthreads();
-  for (int j = 0; j < 128; ++j) {
-    if (i < j) Scol[i] = S[i + j * 128];
-    __syncthreads();
-    double z = 0.0;
-    if (i < j) {
-      for (int l = i; l < j; ++l) z = fma(Tl[l * 128 + i], Scol[l], z);
-    }
-    if (i < j) Tl[j * 128 + i] = -z;
-    if (i == j) Tl[j * 128 + j] = 1.0;
-    __syncthreads();
-  }
-  for (int l = 0; l < 128; ++l) {
-    const double x = Tl[l * 128 + i];  // T[i][l]
-    Tout[i + l * 128] = x;
-    Ttout[l + i * 128] = x;
-  }
-}
+// Compact-WY algebra used by the T kernel (k_build_t3, dhqr_recon.h): for reflectors
+// H_j = I - v_j v_j' (tau_j == 1 because ||v_j||^2 = 2), H_1...H_nb = I - V T V' with
+//   T^{-1} = I + striu(V'V),  equivalently  T[0:j, j] = -T[0:j,0:j] (V'V)[0:j, j], T[j][j] = 1.
+// This holds for ANY vectors v_j, so the reference's zero-pivot reflectors (||v||^2 != 2, src:8)
+// are reproduced exactly.  The trailing update is A <- A - V (T' (V' A)).
 
 // Raw MFMA layout probe (test hook): out[lane*4 + g] = D register g of lane, with
 // A[i][k] = a[i*4+k], B[k][j] = b[k*16+j] loaded per the operand maps documented above, C = 0.

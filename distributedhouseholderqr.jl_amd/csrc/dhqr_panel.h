@@ -221,52 +221,3 @@ __global__ __launch_bounds__(256) void k_unpack_v(double *__restrict__ P, int64_
   for (int64_t r = p + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride)
     P[r + p * ldp] = Vw[r + p * ldv];
 }
-
-// Compact-WY T from S = V'V (see dhqr_gemm.h for the algebra): T = (I + striu(S))^{-1}, i.e. for
-// every column j solve U x = e_j by back substitution.  1024 threads: 8 lanes per column split the
-// inner sum, rows are walked in lockstep (one barrier per row), N = striu(S) and X = T live packed
-// (row i holds entries i..127) in LDS.  Columns >= ncols of V are zero padding: T[j][j] = 1, rest 0.
-__global__ __launch_bounds__(1024) void k_build_t2(const double *__restrict__ S, int ncols,
-                                                   double *__restrict__ Tout,
-                                                   double *__restrict__ Ttout) {
-  constexpr int N = 128, PK = N * (N + 1) / 2;
-  __shared__ double Nl[PK];
-  __shared__ double Xl[PK];
-  const int t = threadIdx.x;
-  auto pidx = [](int i, int l) { return i * N - (i * (i - 1)) / 2 + (l - i); };  // i <= l
-  {  // fill: all 16 global loads of a thread are issued before the first LDS store
-    double sv[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = t + u * 1024, i = idx & (N - 1), l = idx >> 7;
-      sv[u] = (i < l && l < ncols) ? S[idx] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = t + u * 1024, i = idx & (N - 1), l = idx >> 7;
-      if (i <= l) {
-        Nl[pidx(i, l)] = sv[u];
-        Xl[pidx(i, l)] = (i == l) ? 1.0 : 0.0;
-      }
-    }
-  }
-  __syncthreads();
-  const int j = t >> 3, sub = t & 7;
-  for (int i = ncols - 2; i >= 0; --i) {  // uniform loop; rows >= ncols-1 stay identity / zero
-    if (i < j && j < ncols) {
-      double acc = 0.0;
-      for (int l = i + 1 + sub; l < j; l += 8) acc = fma(Nl[pidx(i, l)], Xl[pidx(l, j)], acc);
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      acc += __shfl_xor(acc, 4, 64);
-      if (sub == 0) Xl[pidx(i, j)] = -(acc + Nl[pidx(i, j)]);  // l = j term: N[i][j] * X[j][j]
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int idx = t + u * 1024, i = idx & (N - 1), l = idx >> 7;  // Tout[i + l*N] = T[i][l]
-    Tout[idx] = (i <= l) ? Xl[pidx(i, l)] : 0.0;
-    Ttout[idx] = (l <= i) ? Xl[pidx(l, i)] : 0.0;  // Tt[i + l*N] = T[l][i]
-  }
-}
