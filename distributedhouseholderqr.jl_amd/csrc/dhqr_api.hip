@@ -249,7 +249,7 @@ static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *v
   else if (kw == 64) DHQR_SGEMM(64);
   else DHQR_SGEMM(128);
 #undef DHQR_SGEMM
-  hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(DHQR_NBV * kw / 256)), dim3(256), 0, c->stream,
+  hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(DHQR_NBV * kw / 64)), dim3(256), 0, c->stream,
                      (const double *)c->spart.p, (int)nsplit, (int64_t)DHQR_NBV * DHQR_NBV,
                      (int64_t)DHQR_NBV * kw, c->sfull.p);
   hipLaunchKernelGGL(k_build_t3, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sfull.p,
@@ -291,7 +291,7 @@ static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *
     CHECK(prof_begin(c, CAT_TW));                                                                    \
     const double *w1sum = ws.w1.p;                                                                   \
     if (nsplit > 1) { /* bandwidth-friendly, deterministic split-K reduction */                      \
-      hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)((wstride + 255) / 256)), dim3(256), 0,     \
+      hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)((wstride + 63) / 64)), dim3(256), 0,       \
                          c->stream, (const double *)ws.w1.p, (int)nsplit, wstride, wstride, ws.w1r.p); \
       w1sum = ws.w1r.p;                                                                              \
     }                                                                                                \
@@ -413,7 +413,7 @@ static int32_t gram128(dhqr_ctx *c, const double *X, int64_t ldx, int64_t rows, 
     hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, X, ldx, X, ldx,
                        1, (int64_t)0, rows, (int64_t)DHQR_NBV, rps, c->spart.p, (int64_t)DHQR_NBV,
                        (int64_t)DHQR_NBV * DHQR_NBV);
-  hipLaunchKernelGGL(k_reduce_splits, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream,
+  hipLaunchKernelGGL(k_reduce_splits, dim3(DHQR_NBV * DHQR_NBV / 64), dim3(256), 0, c->stream,
                      (const double *)c->spart.p, (int)nsplit, (int64_t)DHQR_NBV * DHQR_NBV,
                      (int64_t)DHQR_NBV * DHQR_NBV, out);
   return DHQR_OK;

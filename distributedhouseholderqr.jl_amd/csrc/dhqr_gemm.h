@@ -336,15 +336,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
     }
 }
 
-// out[e] = sum_{s<nsplit} in[s*stride + e], e < count  (split-K reduction, deterministic order)
+// out[e] = sum_{s<nsplit} in[s*stride + e], e < count  (split-K reduction, deterministic order).
+// A block of 256 threads owns 64 consecutive elements; its four 64-thread groups each sum a quarter
+// of the splits (interleaved) and the quarters are combined through LDS in a fixed order, so a
+// 128 x 128 Gram matrix with 256 partials is reduced by 256 blocks instead of 64.
 __global__ __launch_bounds__(256) void k_reduce_splits(const double *__restrict__ in, int nsplit,
                                                        int64_t stride, int64_t count,
                                                        double *__restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= count) return;
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
   double s = 0.0;
-  for (int q = 0; q < nsplit; ++q) s += in[(int64_t)q * stride + e];
-  out[e] = s;
+  if (e < count)
+    for (int q = grp; q < nsplit; q += 4) s += in[(int64_t)q * stride + e];
+  part[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0 && e < count) out[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 // Compact-WY algebra used by the T kernel (k_build_t3, dhqr_recon.h): for reflectors

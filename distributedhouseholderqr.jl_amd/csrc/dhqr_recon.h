@@ -189,10 +189,13 @@ __global__ __launch_bounds__(1024) void k_recon_top(const double *__restrict__ P
       const double ajj = sh[0], rjj = sh[1];
       const double s = fabs(rjj);                         // src:129 (norm of the updated column)
       const double al = s * dhqr_alphafactor(ajj);        // src:130
-      const double f = 1.0 / sqrt(s * (s + fabs(ajj)));   // src:131
-      const double vjj = (ajj - al) * f;                  // src:132-135
-      const double sg = al / rjj;                         // row sign: reference R_jj == alpha_j
-      const double vinv = 1.0 / vjj;
+      // src:131-135 with no division depending on another one: f = 1/sqrt(q), 1/v_jj = sqrt(q)/(a_jj - alpha)
+      const double q = s * (s + fabs(ajj));
+      const double sq = sqrt(q);
+      const double f = 1.0 / sq;
+      const double vinv = sq / (ajj - al);
+      // row sign so that the reference's R_jj equals alpha_j: al / rjj = -sign(a_jj) * sign(r_jj)
+      const double sg = (al == 0.0) ? 0.0 : ((al < 0.0) == (rjj < 0.0) ? 1.0 : -1.0);
       if (ti == jm) {  // owners of row j: w_jk = v_j' a_k, R row in the reference's sign convention
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_recon_top(const double *__restrict__ P
           const double rr = sg * r[ja][y];
           const double w = (k > j) ? (a[ja][y] - rr) * vinv : 0.0;
           wrow[k] = w;
-          mm[ja][y] = (k > j) ? w : (k == j ? 1.0 / f : 0.0);  // M[j][k] = w_jk, M[j][j] = 1/f_j
+          mm[ja][y] = (k > j) ? w : (k == j ? sq : 0.0);  // M[j][k] = w_jk, M[j][j] = 1/f_j = sqrt(q)
           Rref[j + k * RC_N] = (k > j) ? rr : 0.0;
         }
       }
