@@ -267,7 +267,9 @@ static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *
   const double *Top = trans ? vt_T(const_cast<double *>(vt), rows) : vt_Tt(const_cast<double *>(vt), rows);
   const int64_t ntiles = (ncols + 127) / 128;
   int64_t nsplit, rps;
-  pick_split(rows, ntiles, 512, 64, &nsplit, &rps);
+  // narrow updates (one or two column tiles: the look-ahead lane / a rank's single block) are split
+  // over up to 256 row slabs so the latency-critical chain uses the whole chip
+  pick_split(rows, ntiles, 512, ntiles <= 2 ? 256 : 64, &nsplit, &rps);
   dhqr_ctx::WS &ws = c->ws[c->cur_ws];
   CHECK(ensure(c, ws.w1, (size_t)nsplit * DHQR_NBV * (size_t)ncols));
   CHECK(ensure(c, ws.w2, (size_t)DHQR_NBV * (size_t)ncols));
