@@ -52,11 +52,14 @@ struct dhqr_ctx {
   bool profiling = false;
   hipStream_t hi = nullptr;      // high-priority stream: panel factorisation under look-ahead
   int swizzle = 1;               // XCD-aware tile order in k_gemm_nn_sub (+1.5 % at 32768^2; DHQR_SWIZZLE=0 disables)
-  struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
+  struct WS { Buf w1, w1r, w1r2, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
   int cur_ws = 0;
   bool lookahead = true;
   hipEvent_t ev_panel[4] = {}, ev_wide[4] = {};
   Buf vbuf, vt, vt2, vts, spart, sfull, scratch, pbuf;
+  Buf pairv[2], pairt;           // two-panel (K = 256) update: [V_a V_b] buffers, T_a/T_b/S_ba side storage
+  int pair = 1;                  // 1: wide updates apply two panels per pass (DHQR_PAIR=0 disables)
+  int64_t pair_min_n = 20480;    // below this the longer look-ahead lane of the pair driver costs more than it saves
   int panel_impl = 3;  // 3: R-first (CholeskyQR2 + reconstruction, dhqr_recon.h) with fallback to 2;
                        // 2: row-split sub-panel kernels (dhqr_panel.h); 1: one workgroup per column
   int *hflag = nullptr;  // pinned host copy of the fast path's verification flags
@@ -532,9 +535,12 @@ static int32_t factor_panel(dhqr_ctx *c, double *P, int64_t rows, int64_t w, int
 //   stream A (caller's)     : wide update of blocks >= k+2 by panel k  (MFMA-bound)
 // so the panel factorisation the reference serialises in front of every trailing update
 // (src:127-143) runs underneath the previous trailing update.
+static int32_t factor_blocked_pair(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha);
 static int32_t factor_blocked(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
   const int64_t K = (n + DHQR_NBV - 1) / DHQR_NBV;
   CHECK(ensure(c, c->vt, (size_t)panel_elems(m)));
+  if (c->lookahead && c->pair && K >= 4 && n % DHQR_NBV == 0 && n >= c->pair_min_n)
+    return factor_blocked_pair(c, dA, m, n, lda, dalpha);
   if (!c->lookahead || K < 3) {
     for (int64_t c0 = 0; c0 < n; c0 += DHQR_NBV) {
       const int64_t w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
@@ -601,6 +607,233 @@ static int32_t factor_blocked(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int
       HIPCHECK(hipEventRecord(c->ev_wide[2], sA));
       HIPCHECK(hipStreamWaitEvent(sU, c->ev_wide[2], 0));
     }
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  on(sU, 0);
+  return rc;
+}
+
+// ---- two-panel trailing update (K = 256) ------------------------------------------------------
+// C <- (I - V_b T_b' V_b')(I - V_a T_a' V_a') C in ONE pass over C for the subtraction:
+//   W_a = T_a' (V_a' C),  W_b = T_b' (V_b' C - (V_b' V_a) W_a),  C -= [V_a V_b] [W_a; W_b].
+// Vp = [V_a | V_b] (ldv x 256; V_b shifted down by 128 rows, zeros above), rows = rows of panel a.
+// Halves the C read+write traffic of the NN GEMM per flop (0.125 -> 0.094 B/flop through the CU
+// memory pipe), which is what bounds k_gemm_nn_sub.
+__global__ __launch_bounds__(256) void k_copy_vb(const double *__restrict__ Vb, int64_t ldvb, int64_t rows_b,
+                                                 double *__restrict__ Vp, int64_t ldv, int64_t rows_a) {
+  const int64_t p = blockIdx.y;  // column of V_b
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ldv; r += stride) {
+    double x = 0.0;
+    if (r >= DHQR_NBV && r < rows_a && r - DHQR_NBV < rows_b) x = Vb[(r - DHQR_NBV) + p * ldvb];
+    Vp[r + (DHQR_NBV + p) * ldv] = x;
+  }
+}
+
+static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows, const double *Ta,
+                          const double *Tb, const double *Sba, double *C, int64_t ncols, int64_t ldc) {
+  if (ncols <= 0) return DHQR_OK;
+  const int64_t rows_b = rows - DHQR_NBV;
+  const int64_t ntiles = (ncols + 127) / 128;
+  int64_t nsplit, rps;
+  pick_split(rows, ntiles, 512, ntiles <= 2 ? 256 : 64, &nsplit, &rps);
+  dhqr_ctx::WS &ws = c->ws[c->cur_ws];
+  CHECK(ensure(c, ws.w1, (size_t)nsplit * DHQR_NBV * (size_t)ncols));
+  CHECK(ensure(c, ws.w1r, (size_t)DHQR_NBV * (size_t)ncols));
+  CHECK(ensure(c, ws.w1r2, (size_t)DHQR_NBV * (size_t)ncols));
+  CHECK(ensure(c, ws.w2, (size_t)2 * DHQR_NBV * (size_t)ncols));
+  const bool vec = (ldc % 2 == 0) && (rows % 2 == 0) && aligned16(C);
+  const int64_t wstride = (int64_t)DHQR_NBV * ncols;
+  const double *Vb = Vp + DHQR_NBV + (int64_t)DHQR_NBV * ldv;  // first non-zero row of V_b
+  const dim3 gtn((unsigned)ntiles, (unsigned)nsplit), gred((unsigned)((wstride + 63) / 64));
+
+  CHECK(prof_begin(c, CAT_VTA));
+  if (vec) {
+    hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), gtn, dim3(256), 0, c->stream, Vp, ldv, (const double *)C, ldc, 1,
+                       (int64_t)0, rows, ncols, rps, ws.w1.p, (int64_t)DHQR_NBV, wstride);
+    hipLaunchKernelGGL(k_reduce_splits, gred, dim3(256), 0, c->stream, (const double *)ws.w1.p, (int)nsplit, wstride,
+                       wstride, ws.w1r.p);
+    hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), gtn, dim3(256), 0, c->stream, Vb, ldv, (const double *)(C + DHQR_NBV),
+                       ldc, 1, (int64_t)0, rows_b, ncols, rps, ws.w1.p, (int64_t)DHQR_NBV, wstride);
+  } else {
+    hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), gtn, dim3(256), 0, c->stream, Vp, ldv, (const double *)C, ldc, 1,
+                       (int64_t)0, rows, ncols, rps, ws.w1.p, (int64_t)DHQR_NBV, wstride);
+    hipLaunchKernelGGL(k_reduce_splits, gred, dim3(256), 0, c->stream, (const double *)ws.w1.p, (int)nsplit, wstride,
+                       wstride, ws.w1r.p);
+    hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), gtn, dim3(256), 0, c->stream, Vb, ldv, (const double *)(C + DHQR_NBV),
+                       ldc, 1, (int64_t)0, rows_b, ncols, rps, ws.w1.p, (int64_t)DHQR_NBV, wstride);
+  }
+  hipLaunchKernelGGL(k_reduce_splits, gred, dim3(256), 0, c->stream, (const double *)ws.w1.p, (int)nsplit, wstride,
+                     wstride, ws.w1r2.p);
+  CHECK(prof_end(c));
+
+  CHECK(prof_begin(c, CAT_TW));
+  const int64_t ld2 = 2 * DHQR_NBV;
+  // W_a = T_a' Y_a  -> rows 0..127 of W2 (ld 256)
+  hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Ta, (int64_t)DHQR_NBV,
+                     (const double *)ws.w1r.p, (int64_t)DHQR_NBV, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols,
+                     (int64_t)DHQR_NBV, ws.w2.p, ld2, (int64_t)0);
+  // Y_b -= (V_b' V_a) W_a
+  hipLaunchKernelGGL((k_gemm_nn_sub<2, 128>), dim3(1, (unsigned)ntiles), dim3(256), 0, c->stream, Sba, (int64_t)DHQR_NBV,
+                     (const double *)ws.w2.p, ld2, ws.w1r2.p, (int64_t)DHQR_NBV, (int64_t)DHQR_NBV, ncols, 0);
+  // W_b = T_b' Y_b  -> rows 128..255 of W2
+  hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Tb, (int64_t)DHQR_NBV,
+                     (const double *)ws.w1r2.p, (int64_t)DHQR_NBV, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols,
+                     (int64_t)DHQR_NBV, ws.w2.p + DHQR_NBV, ld2, (int64_t)0);
+  CHECK(prof_end(c));
+
+  CHECK(prof_begin(c, CAT_AVW));
+  const int64_t gx = (rows + 127) / 128;
+  const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
+  dim3 grid((unsigned)gx, (unsigned)ntiles);
+  if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_nn_sub<2, 256>), grid, dim3(256), 0, c->stream, Vp, ldv, (const double *)ws.w2.p, ld2, C,
+                       ldc, rows, ncols, swz);
+  else
+    hipLaunchKernelGGL((k_gemm_nn_sub<1, 256>), grid, dim3(256), 0, c->stream, Vp, ldv, (const double *)ws.w2.p, ld2, C,
+                       ldc, rows, ncols, swz);
+  CHECK(prof_end(c));
+  if (c->profiling) {
+    c->st.flops_gemm_vta += 2.0 * DHQR_NBV * ((double)rows + (double)rows_b) * (double)ncols;
+    c->st.flops_gemm_avw += 2.0 * DHQR_NBV * ((double)rows + (double)rows_b) * (double)ncols;
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+// Blocked driver, two panels per wide update.  Panels are paired (0,1), (2,3), ...; while the wide
+// stream applies pair q to blocks >= 2q+4, the look-ahead lane brings blocks 2q+2 and 2q+3 up to
+// date, factors them and assembles pair q+1.
+static int32_t factor_blocked_pair(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
+  const int64_t K = (n + DHQR_NBV - 1) / DHQR_NBV, NB = DHQR_NBV;
+  const int64_t ldvmax = panel_ldv(m);
+  const size_t NN = (size_t)NB * NB;
+  // size everything up front
+  for (int s = 0; s < 2; ++s) CHECK(ensure(c, c->pairv[s], (size_t)ldvmax * 2 * NB + 2 * NN + NB + 1024));
+  CHECK(ensure(c, c->pairt, 2 * 3 * NN));  // per pair buffer: T_a, T_b, S_ba
+  CHECK(ensure(c, c->vt2, (size_t)panel_elems(m)));
+  CHECK(ensure(c, c->vts, (size_t)panel_elems(m)));
+  {
+    const size_t ntmax = (size_t)((n + 127) / 128);
+    const size_t w1cap = (size_t)NB * NB * (2048 + ntmax + 64);
+    for (int s = 0; s < 2; ++s) {
+      CHECK(ensure(c, c->ws[s].w1, s == 0 ? w1cap : (size_t)NB * NB * 1100));
+      CHECK(ensure(c, c->ws[s].w1r, (size_t)NB * (size_t)n));
+      CHECK(ensure(c, c->ws[s].w1r2, (size_t)NB * (size_t)n));
+      CHECK(ensure(c, c->ws[s].w2, (size_t)2 * NB * (size_t)n));
+    }
+    CHECK(ensure(c, c->spart, (size_t)256 * NN));
+    CHECK(ensure(c, c->sfull, NN));
+    CHECK(ensure(c, c->rbuf, 6 * NN + 1024));
+    CHECK(ensure(c, c->scratch, 4096));
+  }
+  hipStream_t sU = c->stream, sB = c->hi, sA = sU;
+  auto on = [&](hipStream_t s, int wsi) { c->stream = s; c->cur_ws = wsi; };
+  auto Ta = [&](int q) { return c->pairt.p + (size_t)(q & 1) * 3 * NN; };
+  auto Tb = [&](int q) { return Ta(q) + NN; };
+  auto Sba = [&](int q) { return Ta(q) + 2 * NN; };
+  auto colptr = [&](int64_t rowblk, int64_t colblk) { return dA + rowblk * NB + colblk * NB * lda; };
+  auto wcols = [&](int64_t k) { return std::min<int64_t>(NB, n - k * NB); };
+
+  // lane helpers (stream sB, workspace set 1), all accounted to the panel group
+  auto lane_single_apply = [&](const double *vt, int64_t k, int64_t blk) -> int32_t {
+    return panel_apply(c, vt, m - k * NB, colptr(k, blk), wcols(blk), lda, 1);
+  };
+  // assemble pair q from panel a (already in pairv[q&1] as a standard VT) and panel b (in vt2)
+  auto build_pair = [&](int q) -> int32_t {
+    const int64_t a = 2 * (int64_t)q, rows_a = m - a * NB, rows_b = rows_a - NB;
+    const int64_t ldva = panel_ldv(rows_a), ldvb = panel_ldv(rows_b);
+    double *pv = c->pairv[q & 1].p;
+    HIPCHECK(hipMemcpyAsync(Ta(q), vt_T(pv, rows_a), NN * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(Tb(q), vt_T(c->vt2.p, rows_b), NN * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    dim3 grid((unsigned)std::min<int64_t>((ldva + 255) / 256, 64), (unsigned)NB);
+    hipLaunchKernelGGL(k_copy_vb, grid, dim3(256), 0, c->stream, (const double *)c->vt2.p, ldvb, rows_b, pv, ldva, rows_a);
+    // S_ba = V_b' V_a over the rows of panel b
+    int64_t nsplit, rps;
+    pick_split(rows_b, 1, 512, 256, &nsplit, &rps);
+    const double *Vb = pv + NB + NB * ldva;
+    hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, Vb, ldva,
+                       (const double *)(pv + NB), ldva, 1, (int64_t)0, rows_b, (int64_t)NB, rps, c->spart.p, (int64_t)NB,
+                       (int64_t)NN);
+    hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(NN / 64)), dim3(256), 0, c->stream, (const double *)c->spart.p,
+                       (int)nsplit, (int64_t)NN, (int64_t)NN, Sba(q));
+    LAUNCHCHECK();
+    return DHQR_OK;
+  };
+
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipEventRecord(c->ev_wide[3], sU));
+    HIPCHECK(hipStreamWaitEvent(sB, c->ev_wide[3], 0));
+    on(sB, 1);
+    const bool was0 = c->profiling;
+    // ---- pair 0
+    CHECK(factor_panel(c, dA, m, wcols(0), lda, dalpha, c->pairv[0].p));
+    if (K >= 2) {
+      CHECK(prof_begin(c, CAT_PANEL));
+      c->profiling = false;
+      int32_t r1 = lane_single_apply(c->pairv[0].p, 0, 1);
+      c->profiling = was0;
+      CHECK(r1);
+      CHECK(prof_end(c));
+      CHECK(factor_panel(c, colptr(1, 1), m - NB, wcols(1), lda, dalpha + NB, c->vt2.p));
+      if (K >= 3) {
+        CHECK(prof_begin(c, CAT_PANEL));
+        c->profiling = false;
+        r1 = build_pair(0);
+        c->profiling = was0;
+        CHECK(r1);
+        CHECK(prof_end(c));
+      }
+    }
+    HIPCHECK(hipEventRecord(c->ev_panel[0], sB));
+    for (int q = 0;; ++q) {
+      const int64_t a = 2 * (int64_t)q, b = a + 1;
+      if (b + 1 >= K) break;  // no block after panel b: nothing left to update
+      const int64_t A2 = b + 1, B2 = b + 2, W0 = b + 3;  // next pair's panels, first block of the wide update
+      // wide update first (the lane below synchronises its stream on the host)
+      on(sA, 0);
+      HIPCHECK(hipStreamWaitEvent(sA, c->ev_panel[q & 3], 0));
+      if (W0 < K)
+        CHECK(pair_apply(c, c->pairv[q & 1].p, panel_ldv(m - a * NB), m - a * NB, Ta(q), Tb(q), Sba(q), colptr(a, W0),
+                         n - W0 * NB, lda));
+      HIPCHECK(hipEventRecord(c->ev_wide[q & 3], sA));
+      // look-ahead lane: blocks A2, B2
+      on(sB, 1);
+      if (q >= 1) HIPCHECK(hipStreamWaitEvent(sB, c->ev_wide[(q - 1) & 3], 0));
+      const bool was = c->profiling;
+      CHECK(prof_begin(c, CAT_PANEL));
+      c->profiling = false;
+      // blocks A2 and B2 are adjacent: one 256-column pair update brings both up to date
+      int32_t rc2 = pair_apply(c, c->pairv[q & 1].p, panel_ldv(m - a * NB), m - a * NB, Ta(q), Tb(q), Sba(q),
+                               colptr(a, A2), wcols(A2) + (B2 < K ? wcols(B2) : 0), lda);
+      c->profiling = was;
+      CHECK(rc2);
+      CHECK(prof_end(c));
+      CHECK(factor_panel(c, colptr(A2, A2), m - A2 * NB, wcols(A2), lda, dalpha + A2 * NB, c->pairv[(q + 1) & 1].p));
+      if (B2 < K) {
+        CHECK(prof_begin(c, CAT_PANEL));
+        c->profiling = false;
+        rc2 = lane_single_apply(c->pairv[(q + 1) & 1].p, A2, B2);
+        c->profiling = was;
+        CHECK(rc2);
+        CHECK(prof_end(c));
+        CHECK(factor_panel(c, colptr(B2, B2), m - B2 * NB, wcols(B2), lda, dalpha + B2 * NB, c->vt2.p));
+        if (B2 + 1 < K) {
+          CHECK(prof_begin(c, CAT_PANEL));
+          c->profiling = false;
+          rc2 = build_pair(q + 1);
+          c->profiling = was;
+          CHECK(rc2);
+          CHECK(prof_end(c));
+        }
+      }
+      HIPCHECK(hipEventRecord(c->ev_panel[(q + 1) & 3], sB));
+    }
+    // join the lane back into the caller's stream
+    HIPCHECK(hipEventRecord(c->ev_panel[3], sB));
+    HIPCHECK(hipStreamWaitEvent(sU, c->ev_panel[3], 0));
     return DHQR_OK;
   };
   const int32_t rc = body();
@@ -692,6 +925,8 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
   }
   if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
   if (const char *e = getenv("DHQR_SWIZZLE")) c->swizzle = atoi(e) != 0;
+  if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;
+  if (const char *e = getenv("DHQR_PAIR_MIN_N")) c->pair_min_n = atoll(e);
   HIPCHECK(hipHostMalloc((void **)&c->hflag, 4 * sizeof(int), hipHostMallocDefault));
   if (const char *e = getenv("DHQR_CHOLQR_PASSES")) c->cholqr_passes = atoi(e) == 2 ? 2 : 1;
   if (const char *e = getenv("DHQR_RECON_TOL")) c->recon_tol = atof(e);
@@ -711,8 +946,8 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   if (!c) return DHQR_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  Buf *bufs[] = {&c->vbuf, &c->vt, &c->vt2, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
-                 &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf};
+  Buf *bufs[] = {&c->vbuf, &c->vt, &c->vt2, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w1r2, &c->ws[0].w2, &c->ws[1].w1,
+                 &c->ws[1].w1r, &c->ws[1].w1r2, &c->ws[1].w2, &c->pairv[0], &c->pairv[1], &c->pairt, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {

@@ -58,7 +58,10 @@ def test_unblocked_vs_oracle(pkg, orc, m, n):
 
 
 @pytest.mark.parametrize("m,n", [(128, 128), (129, 129), (300, 128), (300, 200), (1000, 999), (2050, 1030),
-                                 (1153, 600), (9000, 300)])
+                                 (1153, 600), (9000, 300),
+                                 # n % 128 == 0 with >= 4 panels: the two-panel (K = 256) wide-update driver,
+                                 # even / odd panel counts, square and tall
+                                 (512, 512), (640, 640), (1536, 1024), (2048, 2048), (3000, 1152), (1281, 896)])
 def test_blocked_vs_oracle(pkg, orc, m, n):
     H, A0 = _factor_dev(pkg, m, n, 4, 128)
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 4))
