@@ -69,6 +69,7 @@ SIGNATURES = {
     "dhqr_backsub_block_f64": (_i32, [_p, _p, _i64, _p, _p, _i64, _i64, _i32, _i32]),
     "dhqr_ldiv_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "dhqr_partialdot_f64": (_i32, [_p, _p, _p, _i64, _i64, _pd]),
+    "dhqr_partialdot_host_f64": (_i32, [_p, _p, _p, _i64, _i64, _pd]),
     "dhqr_apply_q_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _i64, _i32]),
     "dhqr_residual_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _pd]),
     "dhqr_panel_ldv": (_i64, [_i64]),

@@ -226,10 +226,13 @@ def ldiv(H: DistributedHouseholderQRStruct, b):
 def partialdot(a, b, lo: int, hi: int) -> float:
     """partialdot(a, b, lo:hi-1, Float64) (src:42-49), 0-based with hi exclusive, reduced on the GPU."""
     L = _lib.lib()
-    if not _is_tensor(a):
-        dev = get_context().device
-        a = torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=f"cuda:{dev}")
-        b = torch.as_tensor(np.ascontiguousarray(b, dtype=np.float64), device=f"cuda:{dev}")
+    if not _is_tensor(a):  # host vectors: the entry point the Julia module binds
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        out = ctypes.c_double()
+        check(L.dhqr_partialdot_host_f64(get_context().handle, a.ctypes.data_as(ctypes.c_void_p),
+                                         b.ctypes.data_as(ctypes.c_void_p), lo, hi, ctypes.byref(out)))
+        return out.value
     ctx = get_context(a.device.index)
     ctx.use_torch_stream()
     out = ctypes.c_double()

@@ -1158,6 +1158,26 @@ int32_t dhqr_partialdot_f64(dhqr_ctx *c, const double *da, const double *db, int
   return DHQR_OK;
 }
 
+int32_t dhqr_partialdot_host_f64(dhqr_ctx *c, const double *ha, const double *hb, int64_t lo, int64_t hi,
+                                 double *hout) {
+  CHECK(check_ctx(c));
+  if (!ha || !hb || !hout) return set_err(DHQR_EINVAL, "null pointer argument");
+  if (lo < 0 || hi < lo) return set_err(DHQR_EINVAL, "bad range [%lld,%lld)", (long long)lo, (long long)hi);
+  if (hi == lo) { *hout = 0.0; return DHQR_OK; }
+  double *d = nullptr;
+  const size_t len = (size_t)(hi - lo);
+  if (hipMalloc((void **)&d, 2 * len * sizeof(double)) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc failed");
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMemcpyAsync(d, ha + lo, len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(d + len, hb + lo, len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return dhqr_partialdot_f64(c, d, d + len, 0, (int64_t)len, hout);
+  };
+  const int32_t rc = body();
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  return rc;
+}
+
 int32_t dhqr_apply_q_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda, double *dB,
                          int64_t nrhs, int64_t ldb, int32_t trans) {
   CHECK(check_ctx(c));
@@ -1174,8 +1194,7 @@ int32_t dhqr_residual_f64(dhqr_ctx *c, const double *dAfact, int64_t m, int64_t 
   CHECK(check_mat(dAorig, m, n, ldo, true));
   if (!dalpha || !dwork || !hrel) return set_err(DHQR_EINVAL, "null pointer argument");
   {
-    dim3 grid((unsigned)std::min<int64_t>((m + 255) / 256, 128), (unsigned)n);
-    if (n > 65535) return set_err(DHQR_EINVAL, "n too large for dhqr_residual_f64");
+    dim3 grid((unsigned)std::min<int64_t>((m + 255) / 256, 128), (unsigned)std::min<int64_t>(n, 32768));
     hipLaunchKernelGGL(k_form_r0, grid, dim3(256), 0, c->stream, dAfact, lda, dalpha, m, n, dwork, m,
                        (int64_t)DHQR_NBV, 1, 0);
   }
@@ -1228,9 +1247,9 @@ int32_t dhqr_form_r0_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t cols,
   if (cols == 0) return DHQR_OK;
   CHECK(check_mat(dA, m, cols, lda, false));
   CHECK(check_mat(dW, m, cols, ldw, false));
-  if (!dalpha || colblock <= 0 || nranks <= 0 || rank < 0 || rank >= nranks || cols > 65535)
+  if (!dalpha || colblock <= 0 || nranks <= 0 || rank < 0 || rank >= nranks)
     return set_err(DHQR_EINVAL, "bad arguments to dhqr_form_r0_f64");
-  dim3 grid((unsigned)std::min<int64_t>((m + 255) / 256, 128), (unsigned)cols);
+  dim3 grid((unsigned)std::min<int64_t>((m + 255) / 256, 128), (unsigned)std::min<int64_t>(cols, 32768));
   hipLaunchKernelGGL(k_form_r0, grid, dim3(256), 0, c->stream, dA, lda, dalpha, m, cols, dW, ldw, colblock,
                      (int)nranks, (int)rank);
   LAUNCHCHECK();

@@ -99,14 +99,15 @@ __global__ __launch_bounds__(256) void k_form_r0(const double *__restrict__ A, i
                                                  const double *__restrict__ alpha, int64_t m,
                                                  int64_t ncols, double *__restrict__ W, int64_t ldw,
                                                  int64_t cb, int nranks, int rank) {
-  const int64_t jl = blockIdx.y;
-  const int64_t j = ((jl / cb) * nranks + rank) * cb + jl % cb;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-    double x = 0.0;
-    if (i < j) x = A[i + jl * lda];
-    else if (i == j) x = alpha[j];
-    W[i + jl * ldw] = x;
+  for (int64_t jl = blockIdx.y; jl < ncols; jl += gridDim.y) {  // grid.y is capped at 32768
+    const int64_t j = ((jl / cb) * nranks + rank) * cb + jl % cb;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+      double x = 0.0;
+      if (i < j) x = A[i + jl * lda];
+      else if (i == j) x = alpha[j];
+      W[i + jl * ldw] = x;
+    }
   }
 }
 

@@ -12,7 +12,7 @@
 #   H \ b                       src:317-321   \(H, b)                       -> dhqr_ldiv_f64
 #   householder!(A, α)          src:113       householder!(A, α; nb=128)    -> dhqr_qr_f64
 #   solve_householder!(b, H, α) src:284-294   solve_householder!(b, H, α)   -> dhqr_ldiv_f64
-#   partialdot(a, b, is, T)     src:42-49     partialdot(a, b, is, Float64) -> dhqr_partialdot_f64 (KAT hook)
+#   partialdot(a, b, is, T)     src:42-49     partialdot(a, b, is, Float64) -> dhqr_partialdot_host_f64 (KAT hook)
 #   DistributedHouseholderQRStruct src:296-309  same fields A, α
 #
 # `qr!(A::DArray)` (src:115-120): one Julia worker per GPU calls `dhqr_panel_factor_f64` /
@@ -90,11 +90,14 @@ function LinearAlgebra.:(\)(H::DistributedHouseholderQRStruct, b::AbstractVector
   return solve_householder!(s, H.A, H.α)
 end
 
-# partialdot(a, b, is, ::Type{<:Real}) -- src:42-49 (test/partialdot.jl:18).  Device reduction.
+# partialdot(a, b, is, ::Type{<:Real}) -- src:42-49 (test/partialdot.jl:18).  Reduced on the device with the
+# same wavefront-shuffle + LDS tree the factor kernels use (KAT hook).
 function partialdot(a::Vector{Float64}, b::Vector{Float64}, is::UnitRange{Int}, ::Type{Float64})
-  # the KAT hook takes DEVICE pointers; stage the two vectors through the fill-free upload path
-  error("partialdot on host vectors: use the Python harness (tests/test_gpu_kernels.py::test_partialdot_kat); " *
-        "a Julia caller with device arrays passes their pointers to :dhqr_partialdot_f64 directly")
+  out = Ref{Float64}(0.0)
+  check(ccall((:dhqr_partialdot_host_f64, libdhqr), Int32,
+              (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ref{Float64}),
+              context(), a, b, first(is) - 1, last(is), out))     # 1-based inclusive -> 0-based half-open
+  return out[]
 end
 
 alphafactor(x::Real) = -sign(x)   # src:8 (kept for API completeness; the device applies the same rule)

@@ -137,6 +137,9 @@ int32_t dhqr_ldiv_f64(dhqr_ctx *ctx, const double *hA, int64_t m, int64_t n, int
  * wavefront-shuffle + LDS tree the factor kernels use.  Synchronous (returns a host scalar). */
 int32_t dhqr_partialdot_f64(dhqr_ctx *ctx, const double *da, const double *db, int64_t lo,
                             int64_t hi, double *hout);
+/* Same with HOST vectors (uploads ha[lo:hi], hb[lo:hi]); what the Julia module's partialdot binds. */
+int32_t dhqr_partialdot_host_f64(dhqr_ctx *ctx, const double *ha, const double *hb, int64_t lo,
+                                 int64_t hi, double *hout);
 
 /* ------------------------------------------------------------------ Q application / metric
  * dB (m x nrhs) <- Q' dB (trans = 1) or Q dB (trans = 0), Q = H_1 ... H_n from a factored dA.
