@@ -77,12 +77,62 @@ def cpu_baseline(m, n, budget_s=20.0):
     }
 
 
+def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev):
+    """BASELINE configs[4]: 262144 x 4096 Float64, rows split over the ranks (RowSplitQR)."""
+    m = args.m or 262144
+    n = args.n or 4096
+    q = pkg.RowSplitQR(m, n)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        q.fill(0)
+        q.factor()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        q.fill(0)
+        q.factor()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    resid = None if args.no_residual else q.residual(0)
+    value = flops_qr(m, n) / (dt / args.steps) / 1e9
+    out = {
+        "metric": "QR GFLOP/s (F = 2mn^2 - 2/3 n^3), ||A-QR||/||A|| alongside",
+        "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{m}x{n} Float64 tall-skinny QR, row split (BASELINE configs[4])", "m": m, "n": n,
+                   "nb": 128, "parallelism": f"rows split x{world}, all-reduce of Gram matrices and V'C partial dots"},
+        "residual": resid,
+        "roofline": {"bound": "mfma", "achieved": value / 1e3 / world, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": value / 1e3 / world / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                     "kernel": "whole row-split factorisation per GPU (not a single kernel)"},
+        "rowsplit_stats": q.stats,
+    }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["blocked", "unblocked"], default="blocked")
+    ap.add_argument("--config", choices=["blocked", "unblocked", "tallskinny"], default="blocked",
+                    help="blocked = BASELINE configs[2]/[3] (default, the metric's configuration); unblocked = configs[1]; "
+                         "tallskinny = configs[4] (262144x4096, rows split over the ranks, all-reduce of partial dots)")
     ap.add_argument("--n", type=int, default=0, help="matrix order (default 32768 blocked / 8192 unblocked)")
     ap.add_argument("--m", type=int, default=0, help="rows (default = n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -109,6 +159,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.config == "tallskinny":
+        return tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev)
     nb = 128 if args.config == "blocked" else 0
     n = args.n or (32768 if nb else 8192)
     m = args.m or n

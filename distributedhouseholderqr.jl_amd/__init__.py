@@ -11,11 +11,12 @@ from .api import (Context, DistributedHouseholderQRStruct, apply_q_, bench_mfma_
                   bench_stream_gbps, empty_colmajor, get_context, householder_, ldiv, partialdot,
                   qr_, rand_colmajor, rand_vector_device, residual, solve_householder_)
 from .distributed import ColumnCyclicQR, HipBackend
+from .rowsplit import HipRowBackend, RowSplitQR
 from .partition import BlockCyclicColumns, LocalColumnBlock, contiguous_column_blocks
 
 __all__ = [
     "NB", "DHQRError", "build", "Context", "DistributedHouseholderQRStruct", "apply_q_",
     "bench_mfma_tflops", "bench_stream_gbps", "empty_colmajor", "get_context", "householder_",
     "ldiv", "partialdot", "qr_", "rand_colmajor", "rand_vector_device", "residual",
-    "solve_householder_", "ColumnCyclicQR", "HipBackend", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
+    "solve_householder_", "ColumnCyclicQR", "HipBackend", "RowSplitQR", "HipRowBackend", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
 ]

@@ -79,6 +79,18 @@ SIGNATURES = {
     "dhqr_form_r0_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i32, _i32]),
     "dhqr_diff_norms_f64": (_i32, [_p, _p, _i64, _p, _i64, _i64, _i64, _pd]),
     "dhqr_panel_apply_f64": (_i32, [_p, _p, _i64, _p, _i64, _i64, _i32]),
+    "dhqr_rs_gram_f64": (_i32, [_p, _p, _i64, _i64, _p]),
+    "dhqr_rs_chol_f64": (_i32, [_p, _p, _p, _p]),
+    "dhqr_rs_recon_top_f64": (_i32, [_p, _p, _i64, _p, _p, _p, _p]),
+    "dhqr_rs_mul_f64": (_i32, [_p, _p, _i64, _i64, _p, _p, _i64]),
+    "dhqr_rs_fix_top_f64": (_i32, [_p, _p, _i64, _p, _p]),
+    "dhqr_rs_write_r_f64": (_i32, [_p, _p, _i64, _p]),
+    "dhqr_rs_commit_f64": (_i32, [_p, _p, _i64, _i64, _p, _i64, _i32, _p]),
+    "dhqr_rs_pack_f64": (_i32, [_p, _p, _i64, _i64, _p, _i64, _i32]),
+    "dhqr_rs_build_t_f64": (_i32, [_p, _p, _i32, _p, _p]),
+    "dhqr_rs_vtc_f64": (_i32, [_p, _p, _i64, _p, _i64, _i64, _i64, _p]),
+    "dhqr_rs_tw_f64": (_i32, [_p, _p, _p, _i64, _p]),
+    "dhqr_rs_vw_f64": (_i32, [_p, _p, _i64, _p, _p, _i64, _i64, _i64]),
     "dhqr_bench_mfma_f64": (_i32, [_p, _pd]),
     "dhqr_bench_issue_f64": (_i32, [_p, _i32, _i32, _pd, _pd]),
     "dhqr_bench_issue2_f64": (_i32, [_p, _i32, _i32, _i32, _pd]),

@@ -1274,6 +1274,157 @@ int32_t dhqr_diff_norms_f64(dhqr_ctx *c, const double *dX, int64_t ldx, const do
   return DHQR_OK;
 }
 
+// ---- row-split building blocks (BASELINE configs[4]: tall-skinny, rows distributed over ranks) ----
+// Each call works on the caller's LOCAL row slab; the sums over ranks (Gram matrices, V'C partial
+// dots) are all-reduced by the host layer (rowsplit.py) between calls.
+int32_t dhqr_rs_gram_f64(dhqr_ctx *c, const double *dX, int64_t ldx, int64_t rows, double *dG) {
+  CHECK(check_ctx(c));
+  if (!dX || !dG) return set_err(DHQR_EINVAL, "null pointer argument");
+  if (rows <= 0) {  // a rank may own no active rows of this panel
+    HIPCHECK(hipMemsetAsync(dG, 0, (size_t)DHQR_NBV * DHQR_NBV * sizeof(double), c->stream));
+    return DHQR_OK;
+  }
+  CHECK(gram128(c, dX, ldx, rows, dG));
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// R = chol(G) (upper, dense 128 x 128).  flags are left on the device: dflag[0] != 0 on breakdown.
+int32_t dhqr_rs_chol_f64(dhqr_ctx *c, const double *dG, double *dR, int32_t *dflag) {
+  CHECK(check_ctx(c));
+  if (!dG || !dR || !dflag) return set_err(DHQR_EINVAL, "null pointer argument");
+  hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, dG, (const double *)nullptr, dR, (double *)nullptr,
+                     (int *)dflag);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// Top-block replay on the rank that owns the panel's diagonal rows: dPtop = &P[diag row, first col].
+int32_t dhqr_rs_recon_top_f64(dhqr_ctx *c, const double *dPtop, int64_t ldp, const double *dR, double *dalpha128,
+                              double *dRref, double *dnegMinv) {
+  CHECK(check_ctx(c));
+  if (!dPtop || !dR || !dalpha128 || !dRref || !dnegMinv) return set_err(DHQR_EINVAL, "null pointer argument");
+  hipLaunchKernelGGL(k_recon_top, dim3(1), dim3(1024), 0, c->stream, dPtop, ldp, dR, dalpha128, dRref, dnegMinv);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// dOut (rows x 128, ld ldo) = dX (rows x 128) * Y, given negY = -Y (128 x 128).
+int32_t dhqr_rs_mul_f64(dhqr_ctx *c, const double *dX, int64_t ldx, int64_t rows, const double *dnegY, double *dOut,
+                        int64_t ldo) {
+  CHECK(check_ctx(c));
+  if (rows <= 0) return DHQR_OK;
+  if (!dX || !dnegY || !dOut || ldo < rows) return set_err(DHQR_EINVAL, "bad arguments to dhqr_rs_mul_f64");
+  CHECK(mul128(c, dX, ldx, rows, dnegY, dOut, ldo));
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// finish V = tril((P - alpha E) M^{-1}) on the 128 diagonal rows (diagonal owner only)
+int32_t dhqr_rs_fix_top_f64(dhqr_ctx *c, double *dVw, int64_t ldv, const double *dalpha128, const double *dnegMinv) {
+  CHECK(check_ctx(c));
+  hipLaunchKernelGGL(k_recon_fix, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream, dVw, ldv, dalpha128,
+                     dnegMinv);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+int32_t dhqr_rs_write_r_f64(dhqr_ctx *c, double *dPtop, int64_t ldp, const double *dRref) {
+  CHECK(check_ctx(c));
+  hipLaunchKernelGGL(k_recon_write_r, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream, dPtop, ldp, dRref);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// commit one panel's reflectors into the local slab: the diagonal owner writes the lower trapezoid
+// (rows >= column) and the reference-format R above it, every other rank copies all of its rows.
+int32_t dhqr_rs_commit_f64(dhqr_ctx *c, double *dP, int64_t ldp, int64_t rows, const double *dVw, int64_t ldv,
+                           int32_t diag_owner, const double *dRref) {
+  CHECK(check_ctx(c));
+  if (rows <= 0) return DHQR_OK;
+  if (diag_owner) {
+    dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
+    hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, dP, ldp, rows, (int64_t)DHQR_NBV, dVw, ldv);
+    hipLaunchKernelGGL(k_recon_write_r, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream, dP, ldp, dRref);
+  } else {
+    HIPCHECK(hipMemcpy2DAsync(dP, ldp * sizeof(double), dVw, ldv * sizeof(double), rows * sizeof(double), DHQR_NBV,
+                              hipMemcpyDeviceToDevice, c->stream));
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// V operand of an ALREADY factored panel for re-applying Q: the diagonal owner gets its rows with
+// the R part zeroed, other ranks a plain copy of their rows.  dVw: ldv x 128.
+int32_t dhqr_rs_pack_f64(dhqr_ctx *c, const double *dP, int64_t ldp, int64_t rows, double *dVw, int64_t ldv,
+                         int32_t diag_owner) {
+  CHECK(check_ctx(c));
+  if (rows <= 0) return DHQR_OK;
+  if (diag_owner) {
+    dim3 grid((unsigned)std::min<int64_t>((ldv + 255) / 256, 64), DHQR_NBV);
+    hipLaunchKernelGGL(k_pack_v, grid, dim3(256), 0, c->stream, dP, ldp, rows, (int64_t)DHQR_NBV, dVw, ldv);
+  } else {
+    HIPCHECK(hipMemcpy2DAsync(dVw, ldv * sizeof(double), dP, ldp * sizeof(double), rows * sizeof(double), DHQR_NBV,
+                              hipMemcpyDeviceToDevice, c->stream));
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+int32_t dhqr_rs_build_t_f64(dhqr_ctx *c, const double *dS, int32_t ncols, double *dT, double *dTt) {
+  CHECK(check_ctx(c));
+  hipLaunchKernelGGL(k_build_t3, dim3(1), dim3(1024), 0, c->stream, dS, (int)ncols, dT, dTt);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// dW1 (128 x ncols, ld 128) = dV' dC over the local rows (split-K partials reduced on the device)
+int32_t dhqr_rs_vtc_f64(dhqr_ctx *c, const double *dV, int64_t ldv, const double *dC, int64_t ldc, int64_t rows,
+                        int64_t ncols, double *dW1) {
+  CHECK(check_ctx(c));
+  if (ncols <= 0) return DHQR_OK;
+  const int64_t wstride = (int64_t)DHQR_NBV * ncols;
+  if (rows <= 0) {
+    HIPCHECK(hipMemsetAsync(dW1, 0, (size_t)wstride * sizeof(double), c->stream));
+    return DHQR_OK;
+  }
+  const int64_t ntiles = (ncols + 127) / 128;
+  int64_t nsplit, rps;
+  pick_split(rows, ntiles, 512, ntiles <= 2 ? 256 : 64, &nsplit, &rps);
+  dhqr_ctx::WS &ws = c->ws[c->cur_ws];
+  CHECK(ensure(c, ws.w1, (size_t)nsplit * DHQR_NBV * (size_t)ncols));
+  const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(dC) && aligned16(dV);
+  const dim3 gtn((unsigned)ntiles, (unsigned)nsplit);
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), gtn, dim3(256), 0, c->stream, dV, ldv, dC, ldc, 1, (int64_t)0, rows, ncols,
+                       rps, ws.w1.p, (int64_t)DHQR_NBV, wstride);
+  else
+    hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), gtn, dim3(256), 0, c->stream, dV, ldv, dC, ldc, 1, (int64_t)0, rows, ncols,
+                       rps, ws.w1.p, (int64_t)DHQR_NBV, wstride);
+  hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)((wstride + 63) / 64)), dim3(256), 0, c->stream,
+                     (const double *)ws.w1.p, (int)nsplit, wstride, wstride, dW1);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// dW2 (128 x ncols) = op(T)' dW1 with dTop = T (update) or T' (apply Q)
+int32_t dhqr_rs_tw_f64(dhqr_ctx *c, const double *dTop, const double *dW1, int64_t ncols, double *dW2) {
+  CHECK(check_ctx(c));
+  if (ncols <= 0) return DHQR_OK;
+  const int64_t ntiles = (ncols + 127) / 128;
+  hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, dTop, (int64_t)DHQR_NBV,
+                     dW1, (int64_t)DHQR_NBV, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV, dW2,
+                     (int64_t)DHQR_NBV, (int64_t)0);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// dC (rows x ncols) -= dV (rows x 128) * dW2 (128 x ncols)
+int32_t dhqr_rs_vw_f64(dhqr_ctx *c, const double *dV, int64_t ldv, const double *dW2, double *dC, int64_t ldc,
+                       int64_t rows, int64_t ncols) {
+  CHECK(check_ctx(c));
+  if (rows <= 0 || ncols <= 0) return DHQR_OK;
+  const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(dC) && aligned16(dV);
+  dim3 grid((unsigned)((rows + 127) / 128), (unsigned)((ncols + 127) / 128));
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_nn_sub<2, 128>), grid, dim3(256), 0, c->stream, dV, ldv, dW2, (int64_t)DHQR_NBV, dC, ldc,
+                       rows, ncols, 0);
+  else
+    hipLaunchKernelGGL((k_gemm_nn_sub<1, 128>), grid, dim3(256), 0, c->stream, dV, ldv, dW2, (int64_t)DHQR_NBV, dC, ldc,
+                       rows, ncols, 0);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
 int32_t dhqr_panel_apply_f64(dhqr_ctx *c, const double *dVT, int64_t rows, double *dC, int64_t ncols,
                              int64_t ldc, int32_t trans) {
   CHECK(check_ctx(c));

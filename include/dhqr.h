@@ -188,6 +188,32 @@ int32_t dhqr_panel_pack_f64(dhqr_ctx *ctx, const double *dP, int64_t rows, int64
 int32_t dhqr_panel_apply_f64(dhqr_ctx *ctx, const double *dVT, int64_t rows, double *dC,
                              int64_t ncols, int64_t ldc, int32_t trans);
 
+/* ------------------------------------------------------------------ row-split building blocks
+ * BASELINE configs[4] (tall-skinny, ROWS distributed over the ranks; the reference cannot split rows,
+ * src:33).  One panel = the R-first algorithm of csrc/dhqr_recon.h with the sums over ranks done by
+ * the host layer (distributedhouseholderqr.jl_amd/rowsplit.py) through all-reduce: Gram matrices
+ * (128 x 128) and the V'C partial dots (128 x ncols) -- "RCCL all-reduce of the cross-partition
+ * partial dots".  All pointers are device pointers to the caller's LOCAL row slab; all calls async. */
+int32_t dhqr_rs_gram_f64(dhqr_ctx *ctx, const double *dX, int64_t ldx, int64_t rows, double *dG);
+int32_t dhqr_rs_chol_f64(dhqr_ctx *ctx, const double *dG, double *dR, int32_t *dflag);
+int32_t dhqr_rs_recon_top_f64(dhqr_ctx *ctx, const double *dPtop, int64_t ldp, const double *dR,
+                              double *dalpha128, double *dRref, double *dnegMinv);
+int32_t dhqr_rs_mul_f64(dhqr_ctx *ctx, const double *dX, int64_t ldx, int64_t rows, const double *dnegY,
+                        double *dOut, int64_t ldo);
+int32_t dhqr_rs_fix_top_f64(dhqr_ctx *ctx, double *dVw, int64_t ldv, const double *dalpha128,
+                            const double *dnegMinv);
+int32_t dhqr_rs_write_r_f64(dhqr_ctx *ctx, double *dPtop, int64_t ldp, const double *dRref);
+int32_t dhqr_rs_commit_f64(dhqr_ctx *ctx, double *dP, int64_t ldp, int64_t rows, const double *dVw, int64_t ldv,
+                           int32_t diag_owner, const double *dRref);
+int32_t dhqr_rs_pack_f64(dhqr_ctx *ctx, const double *dP, int64_t ldp, int64_t rows, double *dVw, int64_t ldv,
+                         int32_t diag_owner);
+int32_t dhqr_rs_build_t_f64(dhqr_ctx *ctx, const double *dS, int32_t ncols, double *dT, double *dTt);
+int32_t dhqr_rs_vtc_f64(dhqr_ctx *ctx, const double *dV, int64_t ldv, const double *dC, int64_t ldc,
+                        int64_t rows, int64_t ncols, double *dW1);
+int32_t dhqr_rs_tw_f64(dhqr_ctx *ctx, const double *dTop, const double *dW1, int64_t ncols, double *dW2);
+int32_t dhqr_rs_vw_f64(dhqr_ctx *ctx, const double *dV, int64_t ldv, const double *dW2, double *dC,
+                       int64_t ldc, int64_t rows, int64_t ncols);
+
 /* ------------------------------------------------------------------ micro-benchmarks
  * Device ceilings measured on the box itself (bench.py reports them next to the spec peaks):
  * FP64 MFMA issue-bound TFLOP/s (v_mfma_f64_16x16x4_f64 only) and a read+write streaming

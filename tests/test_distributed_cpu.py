@@ -75,3 +75,35 @@ def test_single_rank_without_process_group():
     Ho, ao = orc.householder(orc.rand_matrix(300, 200, 2))
     assert np.abs(H - Ho).max() <= 1e-11 * np.abs(Ho).max()
     assert q.residual(2) < 1e-13
+
+
+def _rowsplit(rank, P, m, n):
+    import importlib
+    import __graft_entry__ as g
+    from oracle import dhqr_oracle as orc
+    from dist_helpers import NumpyRowBackend
+    pkg = g.import_package()
+    rs = importlib.import_module("dhqr_amd.rowsplit")
+    q = rs.RowSplitQR(m, n, backend=NumpyRowBackend())
+    q.fill(31)
+    q.factor()
+    H, alpha = q.gather_full()
+    Ho, ao = orc.householder(orc.rand_matrix(m, n, 31))
+    scale = np.abs(Ho).max()
+    assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
+    assert np.abs(alpha - ao).max() <= 1e-11 * scale
+    res = q.residual(31)
+    assert res < 1e-13, res
+    return res
+
+
+@pytest.mark.parametrize("m,n,P", [(2048, 256, 2), (3000, 384, 3), (1024, 128, 2), (1536, 512, 1)])
+def test_row_split_orchestration(m, n, P):
+    """BASELINE configs[4] structure (rows split over ranks, all-reduce of Gram matrices and of the
+    V'C partial dots) with the numpy backend under gloo, against the single-process oracle."""
+    if P == 1:
+        import torch.distributed as dist
+        assert not dist.is_initialized()
+        _rowsplit(0, 1, m, n)
+    else:
+        run_ranks(_rowsplit, P, m, n)
