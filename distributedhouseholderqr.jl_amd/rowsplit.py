@@ -107,6 +107,13 @@ class HipRowBackend:
         check(self.L.dhqr_rs_vw_f64(self._go(), self._p(Vw, 0, 0), Vw.stride(1), self._v(W2), self._p(C, row, col),
                                     C.stride(1), rows, ncols))
 
+    def backsub(self, A, n, alpha, y):
+        """in place: y[0:n] <- R^{-1} y[0:n] with R = strict upper of A[0:n, 0:n] and diag alpha (src:244-254)"""
+        h = self._go()
+        for hi in range(n, 0, -NB):
+            lo = max(0, hi - NB)
+            check(self.L.dhqr_backsub_block_f64(h, self._p(A, 0, 0), A.stride(1), self._v(alpha), self._v(y), lo, hi, 1, 1))
+
     def form_r0(self, A, m, n, alpha, W):
         check(self.L.dhqr_form_r0_f64(self._go(), self._p(A, 0, 0), m, n, A.stride(1), self._v(alpha),
                                       self._p(W, 0, 0), W.stride(1), NB, 1, 0))
@@ -145,6 +152,7 @@ class RowSplitQR:
         self.W1, self.W2 = be.zeros(NB * n), be.zeros(NB * n)
         self.flag = be.izeros(4)
         self.stats = {"panels": 0, "cholqr2_retries": 0}
+        self.Ts = {}  # compact-WY T of every panel (128 x 128 each), kept for the solve
 
     # ------------------------------------------------------------------ helpers
     def _allreduce(self, t):
@@ -219,6 +227,7 @@ class RowSplitQR:
                     raise RuntimeError(f"row-split panel at column {c0} is numerically rank deficient "
                                        f"(| ||v||^2 - 2 | = {dev:.2e}); no column-by-column fallback in this path")
             be.build_t(self.S, self.T, self.Tt)
+            self.Ts[c0] = self.T.clone()
             be.commit(self.A, off, c0, rows, self.Vw, self.rank == 0, self.Rref)
             self.alpha[c0: c0 + NB].copy_(self.bc[_NN:])
             ncols = n - c0 - NB
@@ -261,6 +270,31 @@ class RowSplitQR:
             dist.all_reduce(t, group=self.group)
             d2, x2 = t.tolist()
         return math.sqrt(d2 / x2)
+
+    # ------------------------------------------------------------------ solve
+    def solve(self, b_loc):
+        """`H \\ b` (src:317-321) for the row split.  `b_loc` = this rank's rows of b (length mloc, not
+        modified).  Q'b (src:215-242): per panel the partial dots V_r' b_r are all-reduced (a 128-vector),
+        then b_r -= V_r (T' w) locally.  Back substitution (src:244-254) is local to rank 0, which owns R;
+        x (length n) is broadcast to every rank."""
+        be, n = self.be, self.n
+        y = be.empty(self.mloc, 1)
+        y[: self.mloc, 0].copy_(b_loc)
+        w1, w2 = self.W1[:NB], self.W2[:NB]
+        for c0 in range(0, n, NB):
+            off, rows = self._active(c0)
+            be.pack(self.A, off, c0, rows, self.Vw, self.rank == 0)
+            be.vtc(self.Vw, y, off, 0, rows, 1, w1)
+            self._allreduce(w1)
+            be.tw(self.Ts[c0], w1, 1, w2)
+            be.vw(self.Vw, w2, y, off, 0, rows, 1)
+        x = be.zeros(n)
+        if self.rank == 0:
+            yv = y[: self.mloc, 0]
+            be.backsub(self.A, n, self.alpha, yv)
+            x.copy_(yv[:n])
+        self._bcast0(x)
+        return x
 
     def gather_full(self):
         """(H, alpha) as host numpy arrays on every rank (small problems / tests)"""

@@ -272,6 +272,11 @@ class NumpyRowBackend:
             w2 = W2.numpy()[: NB * ncols].reshape((NB, ncols), order="F")
             C.numpy()[row: row + rows, col: col + ncols] -= Vw.numpy()[:rows, :NB] @ w2
 
+    def backsub(self, A, n, alpha, y):
+        a, al, yy = A.numpy(), alpha.numpy(), y.numpy()
+        for i in range(n - 1, -1, -1):
+            yy[i] = (yy[i] - a[i, i + 1:n] @ yy[i + 1:n]) / al[i]
+
     def form_r0(self, A, m, n, alpha, W):
         a, w, al = A.numpy(), W.numpy(), alpha.numpy()
         w[:] = 0.0

@@ -94,6 +94,11 @@ def _rowsplit(rank, P, m, n):
     assert np.abs(alpha - ao).max() <= 1e-11 * scale
     res = q.residual(31)
     assert res < 1e-13, res
+    import torch
+    b = orc.rand_vector(m, 32)
+    x = q.solve(torch.from_numpy(b[q.row0: q.row0 + q.mloc].copy())).numpy()
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     return res
 
 

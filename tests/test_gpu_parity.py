@@ -281,6 +281,11 @@ def test_row_split_driver_single_rank(pkg, orc, m, n):
     assert np.abs(alpha - ao).max() <= 1e-11 * scale
     assert q.residual(41) < 1e-12
     assert q.stats["panels"] == n // 128
+    import torch
+    b = orc.rand_vector(m, 42)
+    x = q.solve(torch.tensor(b, device="cuda:0")).cpu().numpy()
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
 
 
 def _two_rank_rowsplit(rank, P, m, n):
@@ -300,6 +305,10 @@ def _two_rank_rowsplit(rank, P, m, n):
     assert np.abs(alpha - ao).max() <= 1e-11 * scale
     res = q.residual(43)
     assert res < 1e-12, res
+    b = orc.rand_vector(m, 44)
+    x = q.solve(torch.tensor(b[q.row0: q.row0 + q.mloc], device="cuda:0")).cpu().numpy()
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     return res
 
 
