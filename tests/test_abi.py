@@ -56,3 +56,26 @@ def test_product_package_does_not_import_oracle():
                 assert not re.search(r"#\s*include[^\n]*oracle", txt), f
                 assert "libdhqr_oracle" not in txt and "dhqr_oracle_" not in txt.replace(
                     "dhqr_oracle_u01", ""), f  # (a comment names the generator twin)
+
+
+def test_julia_wrapper_binds_existing_symbols_with_matching_arity():
+    """The Julia `ccall` stubs (unexecutable here: no Julia) must at least name symbols the header
+    declares, with as many argument types as the C prototype has parameters."""
+    jl = open(os.path.join(ROOT, "distributedhouseholderqr.jl_amd", "julia", "DistributedHouseholderQR.jl")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dhqr.h")).read(), flags=re.S)
+    protos = {m.group(1): m.group(2) for m in re.finditer(r"\b(dhqr_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)}
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(dhqr_[a-z0-9_]+),\s*libdhqr\),\s*\w+,\s*\(", jl):
+        i, depth = m.end(), 1          # balanced scan of the argument-type tuple
+        while depth:
+            depth += {"(": 1, ")": -1}.get(jl[i], 0)
+            i += 1
+        calls.append((m.group(1), jl[m.end(): i - 1]))
+    assert len(calls) >= 5
+    for name, argtypes in calls:
+        assert name in protos, f"{name} is not declared in include/dhqr.h"
+        nparams = 0 if protos[name].strip() in ("", "void") else protos[name].count(",") + 1
+        flat = re.sub(r"\{[^{}]*\}", "", argtypes)   # Ptr{Cvoid}, Ref{Ptr{Cvoid}} -> no inner commas
+        flat = re.sub(r"\{[^{}]*\}", "", flat)
+        jl_args = [a for a in flat.replace("\n", " ").split(",") if a.strip()]
+        assert len(jl_args) == nparams, (name, len(jl_args), nparams)
