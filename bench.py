@@ -26,6 +26,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC; must be in the environment before the HSA runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_FP64_MFMA_TFLOPS = 78.6   # AMD MI355X datasheet FP64 matrix (== vector) peak; the local
                                # MI355X_MICROARCH.md guide lists no FP64 number
@@ -156,7 +158,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
     if args.config == "tallskinny":
