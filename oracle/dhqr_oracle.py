@@ -20,6 +20,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libdhqr_oracle.so")
 _SRC = os.path.join(_HERE, "dhqr_oracle.c")
+_SRC_C64 = os.path.join(_HERE, "dhqr_oracle_c64.c")
 
 _GOLDEN = np.uint64(0x9E3779B97F4A7C15)
 _M1 = np.uint64(0xBF58476D1CE4E5B9)
@@ -29,9 +30,10 @@ _M2 = np.uint64(0x94D049BB133111EB)
 def build(force: bool = False) -> str:
     """Compile oracle/dhqr_oracle.c -> oracle/libdhqr_oracle.so (gcc, OpenMP). Generic x86-64
     code generation: the .so travels to the GPU box whose host CPU may differ."""
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+    newest = max(os.path.getmtime(_SRC), os.path.getmtime(_SRC_C64))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         subprocess.check_call(
-            ["gcc", "-O3", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", _SO, _SRC, "-lm"]
+            ["gcc", "-O3", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", _SO, _SRC, _SRC_C64, "-lm"]
         )
     return _SO
 
@@ -65,6 +67,13 @@ def lib() -> ctypes.CDLL:
         L.dhqr_oracle_solve.argtypes = [p, p, i64, i64, i64, p]
         L.dhqr_oracle_form_qr.argtypes = [p, i64, i64, i64, p, p, i64]
         L.dhqr_oracle_num_threads.restype = ctypes.c_int
+        # ComplexF64 methods (oracle/dhqr_oracle_c64.c)
+        L.dhqr_oracle_alphafactor_c64.argtypes = [p, p]
+        L.dhqr_oracle_partialdot_c64.argtypes = [p, p, i64, i64, p]
+        L.dhqr_oracle_householder_inner_c64.argtypes = [p, i64, i64, i64, p, i64, i64, i64]
+        L.dhqr_oracle_householder_c64.argtypes = [p, i64, i64, i64, p]
+        L.dhqr_oracle_solve_c64.argtypes = [p, p, i64, i64, i64, p]
+        L.dhqr_oracle_form_qr_c64.argtypes = [p, i64, i64, i64, p, p, i64]
         _lib = L
     return _lib
 
@@ -178,6 +187,102 @@ def solve_np(H: np.ndarray, alpha: np.ndarray, b: np.ndarray) -> np.ndarray:
     b = np.array(b, dtype=np.float64, copy=True)
     for j in range(n):
         s = H[j:, j] @ b[j:]
+        b[j:] -= H[j:, j] * s
+    for i in range(n - 1, -1, -1):
+        b[i] = (b[i] - H[i, i + 1:n] @ b[i + 1:n]) / alpha[i]
+    return b[:n].copy()
+
+
+# ============================================================================= ComplexF64 methods
+def rand_matrix_c(m: int, n: int, seed: int) -> np.ndarray:
+    """rand(ComplexF64, m, n) stand-in (test/runtests.jl:45): re and im parts are consecutive
+    draws, A[i,j] = u01(seed, 2(i + j m)) + im*u01(seed, 2(i + j m) + 1) -- i.e. the REAL fill of
+    the interleaved 2m x n view, which is how the device generates it."""
+    r = u01(seed, np.arange(2 * m * n, dtype=np.uint64))
+    return np.asfortranarray((r[0::2] + 1j * r[1::2]).reshape((m, n), order="F"))
+
+
+def rand_vector_c(m: int, seed: int) -> np.ndarray:
+    r = u01(seed, np.arange(2 * m, dtype=np.uint64))
+    return r[0::2] + 1j * r[1::2]
+
+
+def _zcheck(a: np.ndarray) -> np.ndarray:
+    assert a.dtype == np.complex128 and a.flags["F_CONTIGUOUS"], "oracle wants column-major complex128"
+    return a
+
+
+def alphafactor_c(x: complex) -> complex:
+    """src:9"""
+    xin = np.array([x.real, x.imag])
+    out = np.zeros(2)
+    lib().dhqr_oracle_alphafactor_c64(_ptr(xin), _ptr(out))
+    return complex(out[0], out[1])
+
+
+def partialdot_c(a: np.ndarray, b: np.ndarray, lo: int, hi: int) -> complex:
+    """src:51-59 with is = lo:hi-1 (0-based, hi exclusive): sum conj(a[i]) * b[i]."""
+    a = np.ascontiguousarray(a, dtype=np.complex128)
+    b = np.ascontiguousarray(b, dtype=np.complex128)
+    out = np.zeros(2)
+    lib().dhqr_oracle_partialdot_c64(_ptr(a), _ptr(b), lo, hi, _ptr(out))
+    return complex(out[0], out[1])
+
+
+def householder_c(A: np.ndarray):
+    """qr!(A) for a ComplexF64 matrix; returns (H, alpha) with alpha complex (diag(R), not
+    phase-normalised: alpha_j = -exp(i arg a_jj) * ||a_j||)."""
+    H = np.array(A, dtype=np.complex128, order="F", copy=True)
+    m, n = H.shape
+    alpha = np.zeros(n, dtype=np.complex128)
+    lib().dhqr_oracle_householder_c64(_ptr(H), m, n, H.strides[1] // 16, _ptr(alpha))
+    return H, alpha
+
+
+def solve_c(H: np.ndarray, alpha: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """H \\ b for ComplexF64 (src:317-321)."""
+    _zcheck(H)
+    m, n = H.shape
+    bb = np.array(b, dtype=np.complex128, copy=True)
+    al = np.ascontiguousarray(alpha, dtype=np.complex128)
+    lib().dhqr_oracle_solve_c64(_ptr(bb), _ptr(H), m, n, H.strides[1] // 16, _ptr(al))
+    return bb[:n].copy()
+
+
+def form_qr_c(H: np.ndarray, alpha: np.ndarray) -> np.ndarray:
+    _zcheck(H)
+    m, n = H.shape
+    B = np.zeros((m, n), dtype=np.complex128, order="F")
+    al = np.ascontiguousarray(alpha, dtype=np.complex128)
+    lib().dhqr_oracle_form_qr_c64(_ptr(H), m, n, H.strides[1] // 16, _ptr(al), _ptr(B), m)
+    return B
+
+
+def householder_c_np(A: np.ndarray):
+    """Pure-numpy restatement of the ComplexF64 path (src:9, 51-59, 122-148, 171-213); small
+    cases only.  Independent of the C oracle: tests require the two to agree."""
+    H = np.array(A, dtype=np.complex128, order="F", copy=True)
+    m, n = H.shape
+    alpha = np.zeros(n, dtype=np.complex128)
+    for j in range(n):
+        col = H[j:, j]
+        s = float(np.sqrt(np.sum(col.real.astype(np.longdouble) ** 2 + col.imag.astype(np.longdouble) ** 2)))
+        alpha[j] = s * (-np.exp(1j * np.angle(H[j, j])))   # src:9, src:130
+        f = 1.0 / np.sqrt(s * (s + abs(H[j, j])))          # src:131
+        H[j, j] -= alpha[j]
+        H[j:, j] *= f
+        Hj = H[:, j].copy()
+        if j + 1 < n:
+            sdot = np.conj(Hj[j:]) @ H[j:, j + 1:]          # src:51-59
+            H[j:, j + 1:] -= np.outer(Hj[j:], sdot)         # src:150-154
+    return H, alpha
+
+
+def solve_c_np(H: np.ndarray, alpha: np.ndarray, b: np.ndarray) -> np.ndarray:
+    m, n = H.shape
+    b = np.array(b, dtype=np.complex128, copy=True)
+    for j in range(n):
+        s = np.conj(H[j:, j]) @ b[j:]
         b[j:] -= H[j:, j] * s
     for i in range(n - 1, -1, -1):
         b[i] = (b[i] - H[i, i + 1:n] @ b[i + 1:n]) / alpha[i]
