@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import NB, DHQRError, build
 from .api import (Context, DistributedHouseholderQRStruct, apply_q_, bench_mfma_tflops,
                   bench_stream_gbps, empty_colmajor, get_context, householder_, ldiv, partialdot,
-                  qr_, rand_colmajor, rand_vector_device, residual, solve_householder_)
+                  qr_, rand_colmajor, rand_colmajor_c, rand_vector_device, residual, solve_householder_)
 from .distributed import ColumnCyclicQR, HipBackend
 from .rowsplit import HipRowBackend, RowSplitQR
 from .partition import BlockCyclicColumns, LocalColumnBlock, contiguous_column_blocks
@@ -17,6 +17,6 @@ from .partition import BlockCyclicColumns, LocalColumnBlock, contiguous_column_b
 __all__ = [
     "NB", "DHQRError", "build", "Context", "DistributedHouseholderQRStruct", "apply_q_",
     "bench_mfma_tflops", "bench_stream_gbps", "empty_colmajor", "get_context", "householder_",
-    "ldiv", "partialdot", "qr_", "rand_colmajor", "rand_vector_device", "residual",
+    "ldiv", "partialdot", "qr_", "rand_colmajor", "rand_colmajor_c", "rand_vector_device", "residual",
     "solve_householder_", "ColumnCyclicQR", "HipBackend", "RowSplitQR", "HipRowBackend", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
 ]

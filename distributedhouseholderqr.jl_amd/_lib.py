@@ -70,6 +70,12 @@ SIGNATURES = {
     "dhqr_ldiv_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "dhqr_partialdot_f64": (_i32, [_p, _p, _p, _i64, _i64, _pd]),
     "dhqr_partialdot_host_f64": (_i32, [_p, _p, _p, _i64, _i64, _pd]),
+    "dhqr_factor_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
+    "dhqr_qr_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
+    "dhqr_solve_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p]),
+    "dhqr_ldiv_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "dhqr_partialdot_c64": (_i32, [_p, _p, _p, _i64, _i64, _pd]),
+    "dhqr_partialdot_host_c64": (_i32, [_p, _p, _p, _i64, _i64, _pd]),
     "dhqr_apply_q_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _i64, _i32]),
     "dhqr_residual_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _pd]),
     "dhqr_panel_ldv": (_i64, [_i64]),

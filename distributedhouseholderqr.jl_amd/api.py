@@ -6,7 +6,12 @@ Reference (src/DistributedHouseholderQR.jl)        here
   H \\ b                          :317-321          ldiv(H, b)  /  H.solve(b)
   householder!(A, α)             :113-120          householder_(A, α, nb=...)
   solve_householder!(b, H, α)    :284-294          solve_householder_(b, H, α)
-  partialdot(a, b, is, T)        :42-49            partialdot(a, b, lo, hi)
+  partialdot(a, b, is, T)        :42-49, :51-59    partialdot(a, b, lo, hi)
+
+The reference's functions are generic over the element type (its tests run Float64 and ComplexF64,
+test/runtests.jl:43); here the dtype of the argument selects the method the same way: float64 ->
+the *_f64 entry points (blocked MFMA path by default), complex128 -> the *_c64 entry points
+(unblocked path; nb must be None or 0).
 
 Inputs are either host numpy arrays (column-major float64; goes through the host-in/host-out
 C entry points, like qr!(::Matrix)) or CUDA/HIP torch tensors in column-major layout
@@ -94,10 +99,28 @@ def _is_tensor(x) -> bool:
     return torch is not None and isinstance(x, torch.Tensor)
 
 
-def _dev_matrix(A):
-    """(ptr, m, n, lda, device) of a column-major float64 CUDA tensor."""
-    if A.dtype != torch.float64 or not A.is_cuda:
-        raise TypeError("device path needs a float64 CUDA tensor")
+def _is_complex(x) -> bool:
+    if _is_tensor(x):
+        return x.dtype == torch.complex128
+    return isinstance(x, np.ndarray) and x.dtype == np.complex128
+
+
+def _resolve_nb(A, nb):
+    """nb=None: the default of the element type (128 blocked for Float64, 0 unblocked for ComplexF64)"""
+    if _is_complex(A):
+        if nb not in (None, 0):
+            raise ValueError("ComplexF64 runs the unblocked path only (nb=None or 0); a blocked complex "
+                             "MFMA path is not built yet")
+        return 0
+    return NB if nb is None else nb
+
+
+def _dev_matrix(A, dtype=None):
+    """(ptr, m, n, lda, device) of a column-major CUDA tensor (float64 unless `dtype` is given);
+    lda counts elements."""
+    dtype = torch.float64 if dtype is None else dtype
+    if A.dtype != dtype or not A.is_cuda:
+        raise TypeError(f"device path needs a {dtype} CUDA tensor")
     if A.dim() != 2:
         raise ValueError("matrix expected")
     m, n = A.shape
@@ -108,9 +131,10 @@ def _dev_matrix(A):
     return ctypes.c_void_p(A.data_ptr()), m, n, lda, A.device.index
 
 
-def _dev_vector(v, length=None):
-    if v.dtype != torch.float64 or not v.is_cuda or v.dim() != 1 or (v.numel() > 1 and v.stride(0) != 1):
-        raise TypeError("contiguous float64 CUDA vector expected")
+def _dev_vector(v, length=None, dtype=None):
+    dtype = torch.float64 if dtype is None else dtype
+    if v.dtype != dtype or not v.is_cuda or v.dim() != 1 or (v.numel() > 1 and v.stride(0) != 1):
+        raise TypeError(f"contiguous {dtype} CUDA vector expected")
     if length is not None and v.numel() < length:
         raise ValueError(f"vector shorter than {length}")
     return ctypes.c_void_p(v.data_ptr())
@@ -140,6 +164,18 @@ def rand_vector_device(m: int, seed: int, device="cuda"):
     return rand_colmajor(m, 1, seed, device).reshape(-1)
 
 
+def rand_colmajor_c(m: int, n: int, seed: int, device="cuda"):
+    """rand(ComplexF64, m, n) stand-in on the device: the Float64 generator run over the
+    interleaved 2m x n real view, A[i,j] = u01(seed, 2(i + j m)) + im*u01(seed, 2(i + j m) + 1)
+    (identical to oracle rand_matrix_c)."""
+    A = torch.empty((n, m), dtype=torch.complex128, device=device).t()
+    ctx = get_context(A.device.index)
+    ctx.use_torch_stream()
+    check(_lib.lib().dhqr_fill_uniform_f64(ctx.handle, ctypes.c_void_p(A.data_ptr()), 2 * m, n, 2 * m, seed,
+                                           2 * m, 0, NB, 1, 0))
+    return A
+
+
 # ------------------------------------------------------------------------------- API mirror
 class DistributedHouseholderQRStruct:
     """src:296-309: the factored matrix `A` (V on/below the diagonal, R strictly above) and
@@ -149,7 +185,7 @@ class DistributedHouseholderQRStruct:
         self.A = A
         if α is None:  # src:306-309  α = zeros(eltype(A), size(A, 2))
             n = A.shape[1]
-            α = torch.zeros(n, dtype=torch.float64, device=A.device) if _is_tensor(A) else np.zeros(n)
+            α = torch.zeros(n, dtype=A.dtype, device=A.device) if _is_tensor(A) else np.zeros(n, dtype=A.dtype)
         self.α = α
 
     @property
@@ -163,10 +199,34 @@ class DistributedHouseholderQRStruct:
         return f"DistributedHouseholderQRStruct(A={tuple(self.A.shape)}, α={tuple(self.α.shape)})"
 
 
-def householder_(A, α, nb: int = NB):
-    """householder!(A, α) (src:113): factor A in place, fill α. nb=0 -> unblocked rank-1 path
-    (the reference's algorithm verbatim), nb=128 -> blocked MFMA path. Returns (A, α)."""
+def _householder_c64(A, α):
+    """ComplexF64 method of householder! (src:9, 51-59, 122-148, 171-213): unblocked HIP path."""
     L = _lib.lib()
+    if _is_tensor(A):
+        ptr, m, n, lda, dev = _dev_matrix(A, torch.complex128)
+        ctx = get_context(dev)
+        ctx.use_torch_stream()
+        check(L.dhqr_factor_c64(ctx.handle, ptr, m, n, lda, _dev_vector(α, n, torch.complex128)))
+        return A, α
+    if not isinstance(α, np.ndarray) or α.dtype != np.complex128 or α.size < A.shape[1] or not α.flags.c_contiguous:
+        raise TypeError("α must be a contiguous complex128 numpy vector of length n")
+    m, n = A.shape
+    F = A if A.flags.f_contiguous else np.asfortranarray(A)
+    check(L.dhqr_qr_c64(get_context().handle, F.ctypes.data_as(ctypes.c_void_p), m, n,
+                        max(1, F.strides[1] // 16), α.ctypes.data_as(ctypes.c_void_p)))
+    if F is not A:
+        A[...] = F
+    return A, α
+
+
+def householder_(A, α, nb: Optional[int] = None):
+    """householder!(A, α) (src:113): factor A in place, fill α. nb=0 -> unblocked rank-1 path
+    (the reference's algorithm verbatim), nb=128 -> blocked MFMA path (the Float64 default).
+    complex128 input selects the ComplexF64 method (unblocked). Returns (A, α)."""
+    L = _lib.lib()
+    nb = _resolve_nb(A, nb)
+    if _is_complex(A):
+        return _householder_c64(A, α)
     if _is_tensor(A):
         ptr, m, n, lda, dev = _dev_matrix(A)
         ctx = get_context(dev)
@@ -187,7 +247,7 @@ def householder_(A, α, nb: int = NB):
     return A, α
 
 
-def qr_(A, nb: int = NB) -> DistributedHouseholderQRStruct:
+def qr_(A, nb: Optional[int] = None) -> DistributedHouseholderQRStruct:
     """qr!(A) (src:311-315): mutates A, returns the struct."""
     H = DistributedHouseholderQRStruct(A)
     householder_(H.A, H.α, nb=nb)
@@ -198,6 +258,23 @@ def solve_householder_(b, H, α):
     """solve_householder!(b, H, α) (src:284-294): mutates b (b <- Q'b, then back substitution)
     and returns b[1:n] (a copy, like Julia's b[1:n])."""
     L = _lib.lib()
+    if _is_complex(H):
+        if _is_tensor(H):
+            ptr, m, n, lda, dev = _dev_matrix(H, torch.complex128)
+            ctx = get_context(dev)
+            ctx.use_torch_stream()
+            check(L.dhqr_solve_c64(ctx.handle, ptr, m, n, lda, _dev_vector(α, n, torch.complex128),
+                                   _dev_vector(b, m, torch.complex128)))
+            return b[:n].clone()
+        m, n = H.shape
+        F = H if H.flags.f_contiguous else np.asfortranarray(H)
+        x = np.empty(n, dtype=np.complex128)
+        bb = np.ascontiguousarray(b, dtype=np.complex128)
+        check(L.dhqr_ldiv_c64(get_context().handle, F.ctypes.data_as(ctypes.c_void_p), m, n,
+                              max(1, F.strides[1] // 16),
+                              np.ascontiguousarray(α, dtype=np.complex128).ctypes.data_as(ctypes.c_void_p),
+                              bb.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p)))
+        return x
     if _is_tensor(H):
         ptr, m, n, lda, dev = _dev_matrix(H)
         ctx = get_context(dev)
@@ -223,9 +300,29 @@ def ldiv(H: DistributedHouseholderQRStruct, b):
     return solve_householder_(b, H.A, H.α)
 
 
-def partialdot(a, b, lo: int, hi: int) -> float:
-    """partialdot(a, b, lo:hi-1, Float64) (src:42-49), 0-based with hi exclusive, reduced on the GPU."""
+def _partialdot_c64(a, b, lo: int, hi: int) -> complex:
+    """partialdot(a, b, lo:hi-1, ComplexF64) (src:51-59): sum conj(a[i]) b[i]"""
     L = _lib.lib()
+    out = (ctypes.c_double * 2)()
+    if not _is_tensor(a):
+        a = np.ascontiguousarray(a, dtype=np.complex128)
+        b = np.ascontiguousarray(b, dtype=np.complex128)
+        check(L.dhqr_partialdot_host_c64(get_context().handle, a.ctypes.data_as(ctypes.c_void_p),
+                                         b.ctypes.data_as(ctypes.c_void_p), lo, hi, out))
+        return complex(out[0], out[1])
+    ctx = get_context(a.device.index)
+    ctx.use_torch_stream()
+    check(L.dhqr_partialdot_c64(ctx.handle, _dev_vector(a, hi, torch.complex128),
+                                _dev_vector(b, hi, torch.complex128), lo, hi, out))
+    return complex(out[0], out[1])
+
+
+def partialdot(a, b, lo: int, hi: int):
+    """partialdot(a, b, lo:hi-1, T) (src:42-49 Float64, src:51-59 ComplexF64 = conj(a).b), 0-based
+    with hi exclusive, reduced on the GPU."""
+    L = _lib.lib()
+    if _is_complex(a) or _is_complex(b):
+        return _partialdot_c64(a, b, lo, hi)
     if not _is_tensor(a):  # host vectors: the entry point the Julia module binds
         a = np.ascontiguousarray(a, dtype=np.float64)
         b = np.ascontiguousarray(b, dtype=np.float64)

@@ -11,6 +11,7 @@
 
 #include "../../include/dhqr.h"
 #include "dhqr_common.h"
+#include "dhqr_complex.h"
 #include "dhqr_gemm.h"
 #include "dhqr_panel.h"
 #include "dhqr_rank1.h"
@@ -1171,6 +1172,170 @@ int32_t dhqr_partialdot_host_f64(dhqr_ctx *c, const double *ha, const double *hb
     HIPCHECK(hipMemcpyAsync(d, ha + lo, len * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(d + len, hb + lo, len * sizeof(double), hipMemcpyHostToDevice, c->stream));
     return dhqr_partialdot_f64(c, d, d + len, 0, (int64_t)len, hout);
+  };
+  const int32_t rc = body();
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------- ComplexF64
+// (re, im) interleaved; device code sees double2 elements.
+static int32_t check_zptr(const void *p, const char *what) {
+  if (!p) return set_err(DHQR_EINVAL, "null %s pointer", what);
+  if (!aligned16(p)) return set_err(DHQR_EINVAL, "%s pointer must be 16-byte aligned (ComplexF64 elements)", what);
+  return DHQR_OK;
+}
+
+int32_t dhqr_factor_c64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(dA, m, n, lda, true));
+  CHECK(check_zptr(dA, "matrix"));
+  CHECK(check_zptr(dalpha, "alpha"));
+  const size_t vlen = (size_t)((m + 15) & ~(int64_t)15);  // complex elements per staging vector
+  CHECK(ensure(c, c->vbuf, 4 * vlen));
+  double2 *A = reinterpret_cast<double2 *>(dA), *al = reinterpret_cast<double2 *>(dalpha);
+  double2 *vb[2] = {reinterpret_cast<double2 *>(c->vbuf.p), reinterpret_cast<double2 *>(c->vbuf.p) + vlen};
+  CHECK(prof_begin(c, CAT_RANK1));
+  hipLaunchKernelGGL((k_zreflector<1024>), dim3(1), dim3(1024), 0, c->stream, A, m, (int64_t)0, vb[0], al);
+  CHECK(prof_end(c));
+  for (int64_t j = 0; j + 1 < n; ++j) {
+    const unsigned nupd = (unsigned)(n - (j + 1));
+    const int64_t cov = m - j;
+    CHECK(prof_begin(c, CAT_RANK1));
+    if (cov <= 1024)
+      hipLaunchKernelGGL((k_zrank1<256>), dim3(nupd), dim3(256), 0, c->stream, A, lda, m, j,
+                         (const double2 *)vb[j & 1], vb[(j + 1) & 1], al);
+    else if (cov <= 4096)
+      hipLaunchKernelGGL((k_zrank1<512>), dim3(nupd), dim3(512), 0, c->stream, A, lda, m, j,
+                         (const double2 *)vb[j & 1], vb[(j + 1) & 1], al);
+    else
+      hipLaunchKernelGGL((k_zrank1<1024>), dim3(nupd), dim3(1024), 0, c->stream, A, lda, m, j,
+                         (const double2 *)vb[j & 1], vb[(j + 1) & 1], al);
+    CHECK(prof_end(c));
+    if (c->profiling) c->st.bytes_rank1 += 32.0 * (double)cov * (double)nupd;
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+int32_t dhqr_qr_c64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(hA, m, n, lda, true));
+  if (!halpha) return set_err(DHQR_EINVAL, "null alpha pointer");
+  double *dA = nullptr, *dal = nullptr;
+  const size_t esz = 2 * sizeof(double);
+  if (hipMalloc((void **)&dA, (size_t)m * n * esz) != hipSuccess)
+    return set_err(DHQR_ENOMEM, "hipMalloc of the %lld x %lld complex matrix failed", (long long)m, (long long)n);
+  if (hipMalloc((void **)&dal, (size_t)n * esz) != hipSuccess) {
+    (void)hipFree(dA);
+    return set_err(DHQR_ENOMEM, "hipMalloc of alpha failed");
+  }
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMemcpy2DAsync(dA, m * esz, hA, lda * esz, m * esz, n, hipMemcpyHostToDevice, c->stream));
+    CHECK(dhqr_factor_c64(c, dA, m, n, m, dal));
+    HIPCHECK(hipMemcpy2DAsync(hA, lda * esz, dA, m * esz, m * esz, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(halpha, dal, n * esz, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(dA);
+  (void)hipFree(dal);
+  return rc;
+}
+
+int32_t dhqr_solve_c64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda,
+                       const double *dalpha, double *db) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(dA, m, n, lda, true));
+  CHECK(check_zptr(dA, "matrix"));
+  CHECK(check_zptr(dalpha, "alpha"));
+  CHECK(check_zptr(db, "b"));
+  const double2 *A = reinterpret_cast<const double2 *>(dA), *al = reinterpret_cast<const double2 *>(dalpha);
+  double2 *b = reinterpret_cast<double2 *>(db);
+  CHECK(prof_begin(c, CAT_SOLVE));
+  for (int64_t j = 0; j < n; ++j) {  // src:215-224: reflectors in column order
+    const int64_t cov = m - j;
+    if (cov <= 2048)
+      hipLaunchKernelGGL((k_zqtb_col<256>), dim3(1), dim3(256), 0, c->stream, A + j * lda, b, m, j);
+    else
+      hipLaunchKernelGGL((k_zqtb_col<1024>), dim3(1), dim3(1024), 0, c->stream, A + j * lda, b, m, j);
+  }
+  for (int64_t hi = n; hi > 0; hi -= ZBS_NB) {  // src:244-254
+    const int64_t lo = std::max<int64_t>(0, hi - ZBS_NB);
+    hipLaunchKernelGGL(k_zbacksub_diag, dim3(1), dim3(64), 0, c->stream, A, lda, al, b, lo, hi);
+    if (lo > 0)
+      hipLaunchKernelGGL(k_zbacksub_update, dim3((unsigned)((lo + 255) / 256)), dim3(256), 0, c->stream, A,
+                         lda, b, lo, hi);
+  }
+  CHECK(prof_end(c));
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+int32_t dhqr_ldiv_c64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64_t lda,
+                      const double *halpha, const double *hb, double *hx) {
+  CHECK(check_ctx(c));
+  CHECK(check_mat(hA, m, n, lda, true));
+  if (!halpha || !hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
+  double *dA = nullptr, *dal = nullptr, *db = nullptr;
+  const size_t esz = 2 * sizeof(double);
+  if (hipMalloc((void **)&dA, (size_t)m * n * esz) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc failed");
+  if (hipMalloc((void **)&dal, (size_t)n * esz) != hipSuccess) { (void)hipFree(dA); return set_err(DHQR_ENOMEM, "hipMalloc failed"); }
+  if (hipMalloc((void **)&db, (size_t)m * esz) != hipSuccess) { (void)hipFree(dA); (void)hipFree(dal); return set_err(DHQR_ENOMEM, "hipMalloc failed"); }
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMemcpy2DAsync(dA, m * esz, hA, lda * esz, m * esz, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(dal, halpha, n * esz, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(db, hb, m * esz, hipMemcpyHostToDevice, c->stream));  // src:318 copy of b
+    CHECK(dhqr_solve_c64(c, dA, m, n, m, dal, db));
+    HIPCHECK(hipMemcpyAsync(hx, db, n * esz, hipMemcpyDeviceToHost, c->stream));  // src:320
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(dA);
+  (void)hipFree(dal);
+  (void)hipFree(db);
+  return rc;
+}
+
+int32_t dhqr_partialdot_c64(dhqr_ctx *c, const double *da, const double *db, int64_t lo, int64_t hi,
+                            double *hout) {
+  CHECK(check_ctx(c));
+  CHECK(check_zptr(da, "a"));
+  CHECK(check_zptr(db, "b"));
+  if (!hout) return set_err(DHQR_EINVAL, "null output pointer");
+  if (lo < 0 || hi < lo) return set_err(DHQR_EINVAL, "bad range [%lld,%lld)", (long long)lo, (long long)hi);
+  CHECK(ensure(c, c->scratch, 4096));
+  const int64_t len = hi - lo;
+  const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((len + 255) / 256, 1024));
+  hipLaunchKernelGGL(k_zpartialdot_partial, dim3(nblk), dim3(256), 0, c->stream,
+                     reinterpret_cast<const double2 *>(da), reinterpret_cast<const double2 *>(db), lo, hi,
+                     c->scratch.p);
+  hipLaunchKernelGGL(k_sum2_final, dim3(1), dim3(256), 0, c->stream, (const double *)c->scratch.p, nblk,
+                     c->scratch.p + 2048);
+  LAUNCHCHECK();
+  HIPCHECK(hipMemcpyAsync(hout, c->scratch.p + 2048, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return DHQR_OK;
+}
+
+int32_t dhqr_partialdot_host_c64(dhqr_ctx *c, const double *ha, const double *hb, int64_t lo, int64_t hi,
+                                 double *hout) {
+  CHECK(check_ctx(c));
+  if (!ha || !hb || !hout) return set_err(DHQR_EINVAL, "null pointer argument");
+  if (lo < 0 || hi < lo) return set_err(DHQR_EINVAL, "bad range [%lld,%lld)", (long long)lo, (long long)hi);
+  if (hi == lo) { hout[0] = 0.0; hout[1] = 0.0; return DHQR_OK; }
+  double *d = nullptr;
+  const size_t len = (size_t)(hi - lo), esz = 2 * sizeof(double);
+  if (hipMalloc((void **)&d, 2 * len * esz) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc failed");
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMemcpyAsync(d, ha + 2 * lo, len * esz, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(d + 2 * len, hb + 2 * lo, len * esz, hipMemcpyHostToDevice, c->stream));
+    return dhqr_partialdot_c64(c, d, d + 2 * len, 0, (int64_t)len, hout);
   };
   const int32_t rc = body();
   (void)hipStreamSynchronize(c->stream);

@@ -1,0 +1,207 @@
+// dhqr_complex.h -- ComplexF64 methods of the hot path (unblocked): reflector, fused rank-1
+// update, Q^H b, back substitution, conj-dot KAT hook.  SURVEY.md section 8(f) rank 4.
+//
+// Reference mapping (src/DistributedHouseholderQR.jl):
+//   zalphafactor        src:9      alphafactor(x::Complex) = -exp(im*angle(x))  (angle(0) = 0 => -1)
+//   k_zreflector        src:129-140 (norm, alpha, f, scale, copy column into Hj)
+//   k_zrank1            src:198-213 + src:51-59 (conj-dot) + src:171-196 (complex hotloop!) for every
+//                       trailing column of step j, plus src:129-140 for column j+1 by the workgroup
+//                       that owns it -- the same launch structure as the Float64 k_rank1_generic.
+//   k_zqtb_col          src:215-224  b <- (I - v_j v_j^H) b, one launch per column
+//   k_zbacksub_*        src:244-254  blocked by 32 rows (dhqr_solve.h uses 64), complex division by alpha
+//   k_zpartialdot_*     src:51-59    sum conj(a[i]) b[i]   (test/partialdot.jl hook)
+//
+// A complex element is a double2 (x = re, y = im) == Julia's ComplexF64 == C `double _Complex`;
+// one 16-byte load/store per element, leading dimensions are in ELEMENTS.  HBM-bound like the
+// Float64 unblocked path: 32 algorithmic bytes and 16 real flops per trailing element per reflector.
+#pragma once
+#include "dhqr_common.h"
+
+__device__ __forceinline__ double2 zmake(double re, double im) { return make_double2(re, im); }
+// conj(a) * b   (src:51-59: Complex(ar*br + ai*bi, ar*bi - ai*br))
+__device__ __forceinline__ void zcdot_acc(const double2 a, const double2 b, double &sr, double &si) {
+  sr = fma(a.x, b.x, sr);
+  sr = fma(a.y, b.y, sr);
+  si = fma(a.x, b.y, si);
+  si = fma(-a.y, b.x, si);
+}
+// c - v * s   (src:171-196: re -= sr*vr; im -= si*vr; re += si*vi; im -= sr*vi)
+__device__ __forceinline__ double2 zsubmul(double2 c, const double2 v, const double sr, const double si) {
+  c.x = fma(-sr, v.x, c.x);
+  c.y = fma(-si, v.x, c.y);
+  c.x = fma(si, v.y, c.x);
+  c.y = fma(-sr, v.y, c.y);
+  return c;
+}
+// a * b
+__device__ __forceinline__ double2 zmul(const double2 a, const double2 b) {
+  return zmake(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
+}
+// a / b (Smith's algorithm: no overflow in |b|^2)
+__device__ __forceinline__ double2 zdiv(const double2 a, const double2 b) {
+  if (fabs(b.x) >= fabs(b.y)) {
+    const double r = b.y / b.x, d = b.x + b.y * r;
+    return zmake((a.x + a.y * r) / d, (a.y - a.x * r) / d);
+  }
+  const double r = b.x / b.y, d = b.x * r + b.y;
+  return zmake((a.x * r + a.y) / d, (a.y * r - a.x) / d);
+}
+// src:9; returns the unit factor, *absh = |h|
+__device__ __forceinline__ double2 zalphafactor(const double2 h, double *absh) {
+  const double ah = hypot(h.x, h.y);
+  *absh = ah;
+  if (ah == 0.0) return zmake(-1.0, 0.0);  // angle(0) == 0
+  return zmake(-h.x / ah, -h.y / ah);
+}
+template <int THREADS>
+__device__ __forceinline__ double2 zblock_sum(double sr, double si, double *red) {
+  const double a = block_sum<THREADS>(sr, red);
+  const double b = block_sum<THREADS>(si, red);
+  return zmake(a, b);
+}
+
+// One workgroup builds the reflector of column j from scratch.  col = &A[0 + j*lda].
+template <int T>
+__global__ __launch_bounds__(T) void k_zreflector(double2 *__restrict__ col, int64_t m, int64_t j,
+                                                  double2 *__restrict__ vnext,
+                                                  double2 *__restrict__ alpha_j) {
+  __shared__ double red[T / 64 + 1];
+  const int t = threadIdx.x;
+  const double2 h = col[j];
+  double s2 = 0.0;
+  for (int64_t i = j + t; i < m; i += T) {
+    const double2 x = col[i];
+    s2 = fma(x.x, x.x, s2);
+    s2 = fma(x.y, x.y, s2);
+  }
+  s2 = block_sum<T>(s2, red);  // every thread has read h before the barriers inside
+  const double s = sqrt(s2);   // src:129
+  double ah;
+  const double2 af = zalphafactor(h, &ah);
+  const double2 al = zmake(s * af.x, s * af.y);  // src:130
+  const double f = 1.0 / sqrt(s * (s + ah));     // src:131
+  for (int64_t i = t; i < m; i += T) {
+    double2 val = zmake(0.0, 0.0);
+    if (i >= j) {
+      const double2 x = (i == j) ? zmake(h.x - al.x, h.y - al.y) : col[i];  // src:132
+      val = zmake(x.x * f, x.y * f);                                        // src:133-135
+      col[i] = val;
+    }
+    vnext[i] = val;  // src:138-140
+  }
+  if (t == 0) *alpha_j = al;
+}
+
+// Fused step j: workgroup b owns trailing column c = j+1+b; the column is streamed twice (the
+// second pass hits L2: a 32768-row complex column is 512 KiB).  Workgroup 0 also builds the
+// reflector of column j+1 and writes it to vnext / alpha[j+1].
+template <int T>
+__global__ __launch_bounds__(T) void k_zrank1(double2 *__restrict__ A, int64_t lda, int64_t m,
+                                              int64_t j, const double2 *__restrict__ vcur,
+                                              double2 *__restrict__ vnext,
+                                              double2 *__restrict__ alpha) {
+  __shared__ double red[T / 64 + 1];
+  const int t = threadIdx.x;
+  const int64_t c = j + 1 + blockIdx.x;
+  double2 *col = A + c * lda;
+
+  double sr = 0.0, si = 0.0;  // src:208 partialdot(Hj, view(Hl,:,jj), j:m): conj(Hj) . col
+  for (int64_t row = j + t; row < m; row += T) zcdot_acc(vcur[row], col[row], sr, si);
+  const double2 s = zblock_sum<T>(sr, si, red);
+  for (int64_t row = j + t; row < m; row += T) col[row] = zsubmul(col[row], vcur[row], s.x, s.y);  // src:209
+  if (blockIdx.x != 0) return;
+
+  const int64_t jp = j + 1;
+  __syncthreads();  // column j+1 fully updated and visible inside this workgroup
+  const double2 h = col[jp];
+  double s2 = 0.0;
+  for (int64_t row = jp + t; row < m; row += T) {
+    const double2 x = col[row];
+    s2 = fma(x.x, x.x, s2);
+    s2 = fma(x.y, x.y, s2);
+  }
+  s2 = block_sum<T>(s2, red);  // barriers inside: every thread has read h before row jp is rewritten
+  const double sn = sqrt(s2);
+  double ah;
+  const double2 af = zalphafactor(h, &ah);
+  const double2 al = zmake(sn * af.x, sn * af.y);
+  const double f = 1.0 / sqrt(sn * (sn + ah));
+  for (int64_t row = j + t; row < m; row += T) {  // row j of vnext is above the new diagonal: 0
+    double2 val = zmake(0.0, 0.0);
+    if (row >= jp) {
+      const double2 x = (row == jp) ? zmake(h.x - al.x, h.y - al.y) : col[row];
+      val = zmake(x.x * f, x.y * f);
+      col[row] = val;
+    }
+    vnext[row] = val;
+  }
+  if (t == 0) alpha[jp] = al;
+}
+
+// b[j:m] <- (I - v v^H) b[j:m] for the reflector stored in column j (v = &A[0 + j*lda]); one workgroup.
+template <int T>
+__global__ __launch_bounds__(T) void k_zqtb_col(const double2 *__restrict__ v, double2 *__restrict__ b,
+                                                int64_t m, int64_t j) {
+  __shared__ double red[T / 64 + 1];
+  const int t = threadIdx.x;
+  double sr = 0.0, si = 0.0;
+  for (int64_t i = j + t; i < m; i += T) zcdot_acc(v[i], b[i], sr, si);  // src:217
+  const double2 s = zblock_sum<T>(sr, si, red);
+  for (int64_t i = j + t; i < m; i += T) b[i] = zsubmul(b[i], v[i], s.x, s.y);  // src:218-220
+}
+
+#define ZBS_NB 32  // 32 x 33 double2 of LDS (a 64-wide block would exceed the 64 KiB static limit)
+// diagonal block rows/cols [lo, hi) (hi - lo <= ZBS_NB; launched with one wavefront): x_i = (b_i - sum_{j>i} R_ij x_j) / alpha_i
+__global__ __launch_bounds__(64) void k_zbacksub_diag(const double2 *__restrict__ A, int64_t lda,
+                                                      const double2 *__restrict__ alpha,
+                                                      double2 *__restrict__ b, int64_t lo, int64_t hi) {
+  __shared__ double2 Rs[ZBS_NB * (ZBS_NB + 1)];
+  const int t = threadIdx.x;
+  const int nb = (int)(hi - lo);
+  for (int c = 0; c < nb; ++c)
+    if (t < c) Rs[c * (ZBS_NB + 1) + t] = A[(lo + t) + (lo + c) * lda];
+  __syncthreads();
+  double2 bi = (t < nb) ? b[lo + t] : zmake(0.0, 0.0);
+  const double2 ai = (t < nb) ? alpha[lo + t] : zmake(1.0, 0.0);
+  for (int c = nb - 1; c >= 0; --c) {
+    double2 xc = zmake(0.0, 0.0);
+    if (t == c) xc = zdiv(bi, ai);  // src:251
+    xc.x = __shfl(xc.x, c, 64);
+    xc.y = __shfl(xc.y, c, 64);
+    if (t == c) bi = xc;
+    if (t < c) bi = zsubmul(bi, Rs[c * (ZBS_NB + 1) + t], xc.x, xc.y);  // src:248-250
+  }
+  if (t < nb) b[lo + t] = bi;
+}
+
+// b[0:lo] -= R[0:lo, lo:hi] * x[lo:hi]   (x already stored in b[lo:hi])
+__global__ __launch_bounds__(256) void k_zbacksub_update(const double2 *__restrict__ A, int64_t lda,
+                                                         double2 *__restrict__ b, int64_t lo, int64_t hi) {
+  __shared__ double2 xs[ZBS_NB];
+  const int t = threadIdx.x;
+  const int nb = (int)(hi - lo);
+  if (t < nb) xs[t] = b[lo + t];
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + t;
+  if (r >= lo) return;
+  double2 acc = b[r];
+  for (int c = 0; c < nb; ++c) acc = zsubmul(acc, A[r + (lo + c) * lda], xs[c].x, xs[c].y);
+  b[r] = acc;
+}
+
+// conj-dot KAT hook: per-workgroup partial sums (re at part[2*b], im at part[2*b+1]); finished by
+// k_sum2_final (dhqr_solve.h)
+__global__ __launch_bounds__(256) void k_zpartialdot_partial(const double2 *__restrict__ a,
+                                                             const double2 *__restrict__ b, int64_t lo,
+                                                             int64_t hi, double *__restrict__ part) {
+  __shared__ double red[4];
+  double sr = 0.0, si = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride)
+    zcdot_acc(a[i], b[i], sr, si);
+  const double2 s = zblock_sum<256>(sr, si, red);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = s.x;
+    part[2 * blockIdx.x + 1] = s.y;
+  }
+}

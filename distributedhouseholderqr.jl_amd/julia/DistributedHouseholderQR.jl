@@ -14,6 +14,10 @@
 #   solve_householder!(b, H, α) src:284-294   solve_householder!(b, H, α)   -> dhqr_ldiv_f64
 #   partialdot(a, b, is, T)     src:42-49     partialdot(a, b, is, Float64) -> dhqr_partialdot_host_f64 (KAT hook)
 #   DistributedHouseholderQRStruct src:296-309  same fields A, α
+#   ComplexF64 methods (src:9, 51-59, 171-196; test/runtests.jl:43, test/partialdot.jl) dispatch on the
+#   element type exactly like the reference: qr!/householder! -> dhqr_qr_c64, \ / solve_householder!
+#   -> dhqr_ldiv_c64, partialdot(a, b, is, ComplexF64) -> dhqr_partialdot_host_c64.  A Ptr{ComplexF64}
+#   is the interleaved (re, im) `double *` of include/dhqr.h.
 #
 # `qr!(A::DArray)` (src:115-120): one Julia worker per GPU calls `dhqr_panel_factor_f64` /
 # `dhqr_panel_apply_f64` on its block-cyclic local part and broadcasts the packed (V, T, α) panel
@@ -86,8 +90,45 @@ function solve_householder!(b::Vector{Float64}, H::StridedMatrix{Float64}, α::V
 end
 
 function LinearAlgebra.:(\)(H::DistributedHouseholderQRStruct, b::AbstractVector)   # src:317-321
-  s = Vector{Float64}(b)            # the reference copies b into a SharedArray (src:318)
+  s = Vector{eltype(H.A)}(b)        # the reference copies b into a SharedArray (src:318)
   return solve_householder!(s, H.A, H.α)
+end
+
+# ---- ComplexF64 methods (unblocked device path) ------------------------------------------------
+function householder!(A::StridedMatrix{ComplexF64}, α::Vector{ComplexF64}; nb::Integer=0)
+  nb == 0 || throw(ArgumentError("ComplexF64 runs the unblocked path (nb = 0)"))
+  m, n = size(A)
+  stride(A, 1) == 1 || throw(ArgumentError("column-major storage required"))
+  check(ccall((:dhqr_qr_c64, libdhqr), Int32,
+              (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Int64, Int64, Ptr{ComplexF64}),
+              context(), A, m, n, stride(A, 2), α))
+  return (A, α)
+end
+
+function qr!(A::StridedMatrix{ComplexF64}; nb::Integer=0)   # src:311-315
+  H = DistributedHouseholderQRStruct(A)
+  householder!(H.A, H.α; nb=nb)
+  return H
+end
+
+function solve_householder!(b::Vector{ComplexF64}, H::StridedMatrix{ComplexF64}, α::Vector{ComplexF64})
+  m, n = size(H)
+  x = Vector{ComplexF64}(undef, n)
+  check(ccall((:dhqr_ldiv_c64, libdhqr), Int32,
+              (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Int64, Int64, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}),
+              context(), H, m, n, stride(H, 2), α, b, x))
+  b[1:n] .= x
+  return x
+end
+
+# partialdot(a, b, is, ::Type{<:Complex}) -- src:51-59: sum conj(a[i]) b[i]; the function
+# test/partialdot.jl:12-20 checks against dot(a[i:end], b[i:end]).
+function partialdot(a::Vector{ComplexF64}, b::Vector{ComplexF64}, is::UnitRange{Int}, ::Type{ComplexF64})
+  out = Ref{ComplexF64}(0.0 + 0.0im)
+  check(ccall((:dhqr_partialdot_host_c64, libdhqr), Int32,
+              (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{ComplexF64}, Int64, Int64, Ref{ComplexF64}),
+              context(), a, b, first(is) - 1, last(is), out))
+  return out[]
 end
 
 # partialdot(a, b, is, ::Type{<:Real}) -- src:42-49 (test/partialdot.jl:18).  Reduced on the device with the
@@ -101,5 +142,6 @@ function partialdot(a::Vector{Float64}, b::Vector{Float64}, is::UnitRange{Int}, 
 end
 
 alphafactor(x::Real) = -sign(x)   # src:8 (kept for API completeness; the device applies the same rule)
+alphafactor(x::Complex) = -exp(im * angle(x))   # src:9
 
 end # module

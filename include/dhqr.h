@@ -141,6 +141,35 @@ int32_t dhqr_partialdot_f64(dhqr_ctx *ctx, const double *da, const double *db, i
 int32_t dhqr_partialdot_host_f64(dhqr_ctx *ctx, const double *ha, const double *hb, int64_t lo,
                                  int64_t hi, double *hout);
 
+/* ------------------------------------------------------------------ ComplexF64 methods
+ * The reference's qr!/`\` are generic over the element type and its tests run every shape for
+ * ComplexF64 too (test/runtests.jl:43); these are the ComplexF64 counterparts of the Float64 entry
+ * points above (unblocked path).  A complex element is an interleaved
+ * (re, im) pair of doubles == Julia's ComplexF64, so a `Ptr{ComplexF64}` is passed as `double *`;
+ * m, n, lda and the lo/hi ranges count ELEMENTS.  Device pointers must be 16-byte aligned.
+ * Factor format as for Float64 with H_j = I - v_j v_j^H and complex alpha (the reference does not
+ * phase-normalise R: alpha_j = -exp(i arg a_jj) ||a_j||, src:9,130; a zero pivot gives -||a_j||).
+ *
+ * dhqr_factor_c64   householder!(A, alpha) for ComplexF64 (src:113, 122-148, 171-213). Async.
+ * dhqr_qr_c64       host-in / host-out qr!(A) (src:311-315). Synchronous.
+ * dhqr_solve_c64    solve_householder!(b, H, alpha) (src:284-294 with the conj-dot of src:51-59):
+ *                   db (m elements) is overwritten, x = db[0:n]. Async.
+ * dhqr_ldiv_c64     host-in / host-out `H \ b` (src:317-321); hb is not modified. Synchronous.
+ * dhqr_partialdot_c64 / _host_c64
+ *                   partialdot(a, b, lo:hi, ComplexF64) = sum conj(a[i]) b[i] (src:51-59) -- the
+ *                   function the reference's only known-answer test exercises
+ *                   (test/partialdot.jl:12-20); hout[0] = re, hout[1] = im. Synchronous. */
+int32_t dhqr_factor_c64(dhqr_ctx *ctx, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha);
+int32_t dhqr_qr_c64(dhqr_ctx *ctx, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha);
+int32_t dhqr_solve_c64(dhqr_ctx *ctx, const double *dA, int64_t m, int64_t n, int64_t lda,
+                       const double *dalpha, double *db);
+int32_t dhqr_ldiv_c64(dhqr_ctx *ctx, const double *hA, int64_t m, int64_t n, int64_t lda,
+                      const double *halpha, const double *hb, double *hx);
+int32_t dhqr_partialdot_c64(dhqr_ctx *ctx, const double *da, const double *db, int64_t lo, int64_t hi,
+                            double *hout);
+int32_t dhqr_partialdot_host_c64(dhqr_ctx *ctx, const double *ha, const double *hb, int64_t lo,
+                                 int64_t hi, double *hout);
+
 /* ------------------------------------------------------------------ Q application / metric
  * dB (m x nrhs) <- Q' dB (trans = 1) or Q dB (trans = 0), Q = H_1 ... H_n from a factored dA.
  * Blocked compact-WY on MFMA (T is rebuilt per panel from V). No reference analogue beyond

@@ -1,0 +1,125 @@
+"""ComplexF64 methods of the HIP path (dhqr_*_c64, through the C ABI) against the CPU oracle, the
+complex golden fixtures and the reference's own ComplexF64 assertions.
+
+Reference: the test suite runs every shape for T in (Float64, ComplexF64) (test/runtests.jl:43) and
+its only known-answer test is the ComplexF64 partialdot (test/partialdot.jl:12-20).
+Tolerances as in test_gpu_parity.py: |dH|, |dalpha| <= 1e-11 * max|H|, ||A-QR||_F/||A||_F < 1e-12,
+and ||A^H A x - A^H b|| < 8 * (same for LAPACK QR).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REF_SHAPES = [(110, 100), (220, 200), (440, 400), (880, 800), (1100, 1000), (2200, 2000), (4400, 4000)]
+
+
+def test_partialdot_kat_reference_host(pkg):
+    # test/partialdot.jl:12-20, through the entry point the Julia module binds (host vectors)
+    rng = np.random.default_rng(0)
+    for N in range(1, 21):
+        a = rng.random(N) + 1j * rng.random(N)
+        b = rng.random(N) + 1j * rng.random(N)
+        for i in range(N):
+            got = pkg.partialdot(a, b, i, N)
+            assert got == pytest.approx(np.vdot(a[i:], b[i:]), rel=np.sqrt(np.finfo(float).eps))
+    assert pkg.partialdot(a, b, 5, 5) == 0
+
+
+def test_partialdot_device_long(pkg, orc):
+    import torch
+    n = 1_000_003
+    a = orc.rand_vector_c(n, 5)
+    b = orc.rand_vector_c(n, 6) - (0.5 + 0.5j)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    for lo, hi in ((0, n), (17, n - 5), (n - 1, n)):
+        got = pkg.partialdot(ta, tb, lo, hi)
+        want = np.vdot(a[lo:hi], b[lo:hi])
+        assert abs(got - want) <= 1e-12 * np.sum(np.abs(a[lo:hi]) * np.abs(b[lo:hi]))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "zqr_*.npz"))))
+def test_golden_fixtures_complex_host_dropin(pkg, orc, path):
+    """qr!(A::Matrix{ComplexF64}) / `\\` with host arrays (dhqr_qr_c64 / dhqr_ldiv_c64)."""
+    g = np.load(path)
+    m, n, seed = int(g["m"]), int(g["n"]), int(g["seed"])
+    A = orc.rand_matrix_c(m, n, seed)
+    A0 = A.copy()
+    H = pkg.qr_(A)
+    assert H.A is A and H.α.dtype == np.complex128  # in place, complex alpha (src:306-309)
+    scale = np.abs(g["H"]).max()
+    assert np.abs(A - g["H"]).max() <= 1e-11 * scale
+    assert np.abs(H.α - g["alpha"]).max() <= 1e-11 * scale
+    b = orc.rand_vector_c(m, seed + 1)
+    b0 = b.copy()
+    x = pkg.ldiv(H, b)
+    assert np.array_equal(b, b0), "H \\ b must not modify b (src:318)"
+    assert np.abs(x - g["x"]).max() <= 1e-9 * np.abs(g["x"]).max()
+    QR = orc.form_qr_c(np.asfortranarray(A), H.α)
+    assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-12
+
+
+# every kernel variant: 256 / 512 / 1024 threads per column (<=1024, <=4096, >4096 rows), m == n, tiny
+@pytest.mark.parametrize("m,n", [(5, 3), (2, 2), (64, 64), (111, 100), (1500, 40), (5000, 24), (9001, 12)])
+def test_device_path_vs_oracle(pkg, orc, m, n):
+    import torch
+    A = pkg.rand_colmajor_c(m, n, 3, "cuda:0")
+    A0 = A.cpu().numpy().copy()
+    assert np.array_equal(A0, orc.rand_matrix_c(m, n, 3))  # same generator on device and host
+    H = pkg.qr_(A)
+    torch.cuda.synchronize()
+    Ho, ao = orc.householder_c(A0)
+    scale = np.abs(Ho).max()
+    Hd, ad = H.A.cpu().numpy(), H.α.cpu().numpy()
+    assert np.abs(Hd - Ho).max() <= 1e-11 * scale
+    assert np.abs(ad - ao).max() <= 1e-11 * scale
+    QR = orc.form_qr_c(np.asfortranarray(Hd), ad)
+    assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-12
+    # solve on the device, b untouched
+    b = torch.from_numpy(orc.rand_vector_c(m, 4)).cuda()
+    b0 = b.clone()
+    x = pkg.ldiv(H, b)
+    assert torch.equal(b, b0)
+    xo = orc.solve_c(Ho, ao, b0.cpu().numpy())
+    assert np.abs(x.cpu().numpy() - xo).max() <= 1e-11 * max(1.0, np.linalg.cond(A0)) * np.abs(xo).max()
+
+
+@pytest.mark.parametrize("m,n", REF_SHAPES)
+def test_reference_acceptance_inequality_complex(pkg, orc, m, n):
+    """test/runtests.jl:42-63 with T = ComplexF64 and x from the GPU path."""
+    A = orc.rand_matrix_c(m, n, 0)
+    b = orc.rand_vector_c(m, 1)
+    q, r = np.linalg.qr(A)
+    x1 = sl.solve_triangular(r, q.conj().T @ b)
+    Ah = A.conj().T
+    stdliberr = np.linalg.norm(Ah @ (A @ x1) - Ah @ b)
+    H = pkg.qr_(A.copy(order="F"))
+    x2 = pkg.ldiv(H, b)
+    assert np.linalg.norm(Ah @ (A @ x2) - Ah @ b) < 8 * stdliberr
+    if n == 4000:  # the oracle on the largest shape, deferred from the CPU suite (128+ host cores here)
+        Ho, ao = orc.householder_c(A)
+        scale = np.abs(Ho).max()
+        assert np.abs(H.A - Ho).max() <= 1e-10 * scale
+        assert np.abs(H.α - ao).max() <= 1e-10 * scale
+
+
+def test_zero_pivot_complex(pkg, orc):
+    # angle(0) == 0 => alpha = -||a|| and a proper reflection (src:9); the Real method gives alpha = 0
+    A = np.asfortranarray(np.array([[0.0, 1.0], [3.0j, 2.0], [4.0, 5.0j]], dtype=complex))
+    A0 = A.copy()
+    H = pkg.qr_(A)
+    assert H.α[0] == pytest.approx(-5.0)
+    Ho, ao = orc.householder_c(A0)
+    assert np.abs(A - Ho).max() < 1e-14 and np.abs(H.α - ao).max() < 1e-14
+
+
+def test_complex_argument_errors(pkg):
+    A = np.asfortranarray(np.ones((8, 4), dtype=complex))
+    with pytest.raises(ValueError):
+        pkg.qr_(A, nb=128)  # no blocked ComplexF64 path
+    with pytest.raises(pkg.DHQRError):
+        pkg.qr_(np.asfortranarray(np.ones((3, 5), dtype=complex)))  # m < n
