@@ -83,8 +83,9 @@ def test_factor_format_and_lapack_equivalence_complex(orc, m, n):
 
 @pytest.mark.parametrize("m,n", REF_SHAPES[:-1])
 def test_reference_acceptance_inequality_complex(orc, m, n):
-    # test/runtests.jl:42-63 with T = ComplexF64.  The 4400 x 4000 shape (70 s of unblocked CPU
-    # work on the 8 cores of the dev container) runs in the gpu-marked suite, next to the HIP path.
+    # test/runtests.jl:42-63 with T = ComplexF64.  The 4400 x 4000 shape is 70 s of unblocked CPU
+    # work on the 8 cores of the dev container: it is the opt-in test below (DHQR_SLOW=1); the HIP
+    # path runs that shape in tests/test_gpu_complex.py.
     A = orc.rand_matrix_c(m, n, 0)
     b = orc.rand_vector_c(m, 1)
     q, r = np.linalg.qr(A)
@@ -94,6 +95,11 @@ def test_reference_acceptance_inequality_complex(orc, m, n):
     H, alpha = orc.householder_c(A)
     x2 = orc.solve_c(H, alpha, b)
     assert np.linalg.norm(Ah @ (A @ x2) - Ah @ b) < 8 * stdliberr
+
+
+@pytest.mark.skipif(os.environ.get("DHQR_SLOW") != "1", reason="70 s on 8 cores; set DHQR_SLOW=1")
+def test_reference_acceptance_inequality_complex_largest(orc):
+    test_reference_acceptance_inequality_complex(orc, *REF_SHAPES[-1])
 
 
 def test_zero_pivot_complex_reflects(orc):
