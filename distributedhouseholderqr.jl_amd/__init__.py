@@ -8,7 +8,7 @@ partition.py / distributed.py (1-D column split over torch.distributed), julia/ 
 from . import _lib
 from ._lib import NB, DHQRError, build
 from .api import (Context, DistributedHouseholderQRStruct, apply_q_, bench_mfma_tflops,
-                  bench_stream_gbps, empty_colmajor, get_context, householder_, ldiv, partialdot,
+                  bench_stream_gbps, empty_colmajor, get_context, get_q, get_r, householder_, ldiv, partialdot,
                   qr_, rand_colmajor, rand_colmajor_c, rand_vector_device, residual, solve_householder_)
 from .distributed import ColumnCyclicQR, HipBackend
 from .rowsplit import HipRowBackend, RowSplitQR
@@ -16,7 +16,7 @@ from .partition import BlockCyclicColumns, LocalColumnBlock, contiguous_column_b
 
 __all__ = [
     "NB", "DHQRError", "build", "Context", "DistributedHouseholderQRStruct", "apply_q_",
-    "bench_mfma_tflops", "bench_stream_gbps", "empty_colmajor", "get_context", "householder_",
+    "bench_mfma_tflops", "bench_stream_gbps", "empty_colmajor", "get_context", "get_q", "get_r", "householder_",
     "ldiv", "partialdot", "qr_", "rand_colmajor", "rand_colmajor_c", "rand_vector_device", "residual",
     "solve_householder_", "ColumnCyclicQR", "HipBackend", "RowSplitQR", "HipRowBackend", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
 ]

@@ -350,6 +350,28 @@ def apply_q_(H: DistributedHouseholderQRStruct, B, trans: bool):
     return B
 
 
+def get_r(H: DistributedHouseholderQRStruct):
+    """n x n upper-triangular R of a Float64 device factorisation (strict upper part of H.A + α on the
+    diagonal, src:296-309), as a new column-major device tensor.  The reference exposes R only
+    implicitly through `\`; SURVEY.md section 8f rank 2 asks for the explicit extraction."""
+    ptr, m, n, lda, dev = _dev_matrix(H.A)
+    W = empty_colmajor(m, n, H.A.device)
+    wptr, _, _, ldw, _ = _dev_matrix(W)
+    ctx = get_context(dev)
+    ctx.use_torch_stream()
+    check(_lib.lib().dhqr_form_r0_f64(ctx.handle, ptr, m, n, lda, _dev_vector(H.α, n), wptr, ldw, NB, 1, 0))
+    return W[:n, :]
+
+
+def get_q(H: DistributedHouseholderQRStruct):
+    """explicit thin Q (m x n, column-major device tensor): Q = H_1 ... H_n applied to [I; 0]."""
+    m, n = H.A.shape
+    Q = empty_colmajor(m, n, H.A.device)
+    Q.zero_()
+    Q.diagonal().fill_(1.0)
+    return apply_q_(H, Q, trans=False)
+
+
 def residual(H: DistributedHouseholderQRStruct, Aorig, work=None) -> float:
     """||Aorig - Q R||_F / ||Aorig||_F on the device (north-star metric)."""
     ptr, m, n, lda, dev = _dev_matrix(H.A)

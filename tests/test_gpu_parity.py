@@ -317,3 +317,20 @@ def test_row_split_driver_two_ranks_one_gpu(m, n):
     """two processes share cuda:0; gloo all-reduces the Gram matrices and the V'C partial dots"""
     from dist_helpers import run_ranks
     run_ranks(_two_rank_rowsplit, 2, m, n)
+
+
+@pytest.mark.parametrize("m,n", [(300, 128), (1000, 333)])
+def test_explicit_q_and_r(pkg, m, n):
+    """get_r / get_q: R upper triangular with diag == alpha, Q'Q == I, Q R == A"""
+    import torch
+    A = pkg.rand_colmajor(m, n, 9, "cuda:0")
+    A0 = A.clone()
+    H = pkg.qr_(A)
+    R = pkg.get_r(H)
+    Q = pkg.get_q(H)
+    torch.cuda.synchronize()
+    assert R.shape == (n, n) and Q.shape == (m, n)
+    assert torch.equal(torch.triu(R), R) and torch.equal(R.diagonal(), H.α)
+    eye = torch.eye(n, dtype=torch.float64, device="cuda:0")
+    assert (Q.t() @ Q - eye).abs().max().item() < 1e-12
+    assert ((Q @ R - A0).norm() / A0.norm()).item() < 1e-12
