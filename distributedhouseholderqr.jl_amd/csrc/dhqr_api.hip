@@ -69,6 +69,7 @@ struct dhqr_ctx {
   int cholqr_passes = 1;  // Gram/Cholesky passes of the fast path (2 = CholeskyQR2)
   double recon_tol = 2e-12;  // accepted deviation of ||v_j||^2 from 2 before falling back
   int ib = DHQR_IB;
+  int smallk = 3;  // generation of the single-workgroup panel kernels: 3 (default), 4 = one barrier per step (DHQR_SMALLK)
   // profiling
   struct Ev { hipEvent_t a, b; int cat; };
   std::vector<Ev> evs;
@@ -180,6 +181,26 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
   return DHQR_OK;
 }
 
+// ---- the three single-workgroup dense 128 x 128 kernels of the panel chain (dhqr_recon.h), by generation
+static inline void launch_chol_inv(dhqr_ctx *c, const double *G, const double *Rprev, double *Rout, double *negX,
+                                   int *flag) {
+  if (c->smallk == 4)
+    hipLaunchKernelGGL(k_chol_inv4, dim3(1), dim3(1024), 0, c->stream, G, Rprev, Rout, negX, flag);
+  else
+    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, G, Rprev, Rout, negX, flag);
+}
+static inline void launch_recon_top(dhqr_ctx *c, const double *P, int64_t ldp, const double *R, double *alpha,
+                                    double *Rref, double *negMinv) {
+  if (c->smallk == 4)
+    hipLaunchKernelGGL(k_recon_top4, dim3(1), dim3(1024), 0, c->stream, P, ldp, R, alpha, Rref, negMinv);
+  else
+    hipLaunchKernelGGL(k_recon_top, dim3(1), dim3(1024), 0, c->stream, P, ldp, R, alpha, Rref, negMinv);
+}
+static inline void launch_build_t(dhqr_ctx *c, const double *S, int ncols, double *T, double *Tt) {
+  if (c->smallk == 4) hipLaunchKernelGGL(k_build_t4, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt);
+  else hipLaunchKernelGGL(k_build_t3, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt);
+}
+
 // ---- packed panel buffer helpers ------------------------------------------------------------
 static inline int64_t panel_ldv(int64_t rows) { return (rows + 15) & ~(int64_t)15; }
 static inline double *vt_T(double *vt, int64_t rows) { return vt + panel_ldv(rows) * DHQR_NBV; }
@@ -256,8 +277,7 @@ static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *v
   hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(DHQR_NBV * kw / 64)), dim3(256), 0, c->stream,
                      (const double *)c->spart.p, (int)nsplit, (int64_t)DHQR_NBV * DHQR_NBV,
                      (int64_t)DHQR_NBV * kw, c->sfull.p);
-  hipLaunchKernelGGL(k_build_t3, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sfull.p,
-                     (int)ncols, vt_T(vt, rows), vt_Tt(vt, rows));
+  launch_build_t(c, c->sfull.p, (int)ncols, vt_T(vt, rows), vt_Tt(vt, rows));
   LAUNCHCHECK();
   return DHQR_OK;
 }
@@ -465,18 +485,14 @@ static int32_t factor_panel_v3(dhqr_ctx *c, double *P, int64_t rows, int64_t ldp
     HIPCHECK(hipMemsetAsync(dflag, 0, 4 * sizeof(int), c->stream));
     CHECK(gram128(c, P, ldp, rows, G));                                            // G  = P'P
     if (passes == 2) {
-      hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, (const double *)G, (const double *)nullptr,
-                         R1, negR1inv, dflag);                                     // R1, -R1^{-1}
+      launch_chol_inv(c, G, nullptr, R1, negR1inv, dflag);                          // R1, -R1^{-1}
       CHECK(mul128(c, P, ldp, rows, negR1inv, Q1, ldv));                           // Q1 = P R1^{-1}
       CHECK(gram128(c, Q1, ldv, rows, G));                                         // G2 = Q1'Q1
-      hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, (const double *)G, (const double *)R1, Rf,
-                         (double *)nullptr, dflag);                                // R  = chol(G2) R1
+      launch_chol_inv(c, G, R1, Rf, nullptr, dflag);                                // R  = chol(G2) R1
     } else {
-      hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, (const double *)G, (const double *)nullptr,
-                         Rf, (double *)nullptr, dflag);                            // R = chol(P'P)
+      launch_chol_inv(c, G, nullptr, Rf, nullptr, dflag);                           // R = chol(P'P)
     }
-    hipLaunchKernelGGL(k_recon_top, dim3(1), dim3(1024), 0, c->stream, (const double *)P, ldp, (const double *)Rf,
-                       altmp, Rref, negMinv);                                      // alpha, R_ref, -M^{-1}
+    launch_recon_top(c, P, ldp, Rf, altmp, Rref, negMinv);                          // alpha, R_ref, -M^{-1}
     CHECK(mul128(c, P, ldp, rows, negMinv, vt, ldv));                              // Vw = P M^{-1}
     hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, vt, ldv, (const double *)altmp,
                        (const double *)negMinv);                                   // Vw = tril((P - aE) M^{-1})
@@ -494,8 +510,7 @@ static int32_t factor_panel_v3(dhqr_ctx *c, double *P, int64_t rows, int64_t ldp
       HIPCHECK(hipMemcpyAsync(alpha, altmp, DHQR_NBV * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
       HIPCHECK(hipMemcpyAsync(vt_alpha(vt, rows), altmp, DHQR_NBV * sizeof(double), hipMemcpyDeviceToDevice,
                               c->stream));
-      hipLaunchKernelGGL(k_build_t3, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sfull.p, (int)DHQR_NBV,
-                         vt_T(vt, rows), vt_Tt(vt, rows));
+      launch_build_t(c, c->sfull.p, (int)DHQR_NBV, vt_T(vt, rows), vt_Tt(vt, rows));
       LAUNCHCHECK();
     }
     return DHQR_OK;
@@ -931,6 +946,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
   HIPCHECK(hipHostMalloc((void **)&c->hflag, 4 * sizeof(int), hipHostMallocDefault));
   if (const char *e = getenv("DHQR_CHOLQR_PASSES")) c->cholqr_passes = atoi(e) == 2 ? 2 : 1;
   if (const char *e = getenv("DHQR_RECON_TOL")) c->recon_tol = atof(e);
+  if (const char *e = getenv("DHQR_SMALLK")) c->smallk = atoi(e) == 4 ? 4 : 3;
   if (const char *e = getenv("DHQR_PANEL")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 3) c->panel_impl = v;
@@ -1457,8 +1473,7 @@ int32_t dhqr_rs_gram_f64(dhqr_ctx *c, const double *dX, int64_t ldx, int64_t row
 int32_t dhqr_rs_chol_f64(dhqr_ctx *c, const double *dG, double *dR, int32_t *dflag) {
   CHECK(check_ctx(c));
   if (!dG || !dR || !dflag) return set_err(DHQR_EINVAL, "null pointer argument");
-  hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, dG, (const double *)nullptr, dR, (double *)nullptr,
-                     (int *)dflag);
+  launch_chol_inv(c, dG, nullptr, dR, nullptr, (int *)dflag);
   LAUNCHCHECK();
   return DHQR_OK;
 }
@@ -1467,7 +1482,7 @@ int32_t dhqr_rs_recon_top_f64(dhqr_ctx *c, const double *dPtop, int64_t ldp, con
                               double *dRref, double *dnegMinv) {
   CHECK(check_ctx(c));
   if (!dPtop || !dR || !dalpha128 || !dRref || !dnegMinv) return set_err(DHQR_EINVAL, "null pointer argument");
-  hipLaunchKernelGGL(k_recon_top, dim3(1), dim3(1024), 0, c->stream, dPtop, ldp, dR, dalpha128, dRref, dnegMinv);
+  launch_recon_top(c, dPtop, ldp, dR, dalpha128, dRref, dnegMinv);
   LAUNCHCHECK();
   return DHQR_OK;
 }
@@ -1530,7 +1545,7 @@ int32_t dhqr_rs_pack_f64(dhqr_ctx *c, const double *dP, int64_t ldp, int64_t row
 }
 int32_t dhqr_rs_build_t_f64(dhqr_ctx *c, const double *dS, int32_t ncols, double *dT, double *dTt) {
   CHECK(check_ctx(c));
-  hipLaunchKernelGGL(k_build_t3, dim3(1), dim3(1024), 0, c->stream, dS, (int)ncols, dT, dTt);
+  launch_build_t(c, dS, (int)ncols, dT, dTt);
   LAUNCHCHECK();
   return DHQR_OK;
 }

@@ -54,7 +54,7 @@ __device__ __forceinline__ double2 zalphafactor(const double2 h, double *absh) {
   return zmake(-h.x / ah, -h.y / ah);
 }
 // ---- extended-precision sum of squares for the column norm.  The reference's norm (src:129) is BLAS
-// dznrm2, which OpenBLAS accumulates in x87 extended precision on x86-64 (oracle/dhqr_oracle_c64.c
+// dznrm2, which OpenBLAS accumulates in x87 extended precision on x86-64 (the CPU test oracle
 // restates that with long double).  The reflector of the dominant direction is what the reference's
 // acceptance metric ||A^H (A x - b)|| is most sensitive to, so the device keeps the same accuracy:
 // a double-double (hi, lo) accumulator built from error-free transforms (TwoSum, FMA TwoProd), carried

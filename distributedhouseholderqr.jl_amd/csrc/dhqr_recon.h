@@ -258,6 +258,235 @@ __global__ __launch_bounds__(1024) void k_build_t3(const double *__restrict__ S,
     }
 }
 
+// =================================================================================================
+// "v4" variants of the three single-workgroup kernels: ONE workgroup barrier per elimination step
+// instead of two or three.  They sit on the critical path of every panel (and of the multi-GPU panel
+// chain), where a step costs ~1250 cycles in the kernels above, most of it barrier + LDS round trips.
+//   * the pivot scalars are broadcast with a wavefront shuffle inside the half-wave that owns the pivot
+//     row (thread (ti,tk) = lane (ti&1)*32 + tk of wave ti>>1), not through LDS + barrier;
+//   * the row / column staging buffers are double buffered by step parity, so the only barrier of a
+//     step is the one between "owners wrote the buffers" and "everybody reads them": a writer of step
+//     s+2 has passed barrier s+1, which every thread reaches only after its reads of step s;
+//   * the replay folds f into the broadcast row (a -= a_ij * ((a_jk - R_jk)/(a_jj - alpha))), so the
+//     column owners need no scalar at all.
+// Same data layout and the same arithmetic up to the order of two multiplications.  Selected with
+// DHQR_SMALLK=4; tests/test_simt_emulation.py runs both generations on the CPU SIMT emulator
+// (ThreadSanitizer build: a missing barrier shows up as a data race).
+__device__ __forceinline__ void rc_upper_inverse_regs4(const double (&r)[4][4], double (&x)[4][4],
+                                                       double *dinv, double *rowbuf2, double *colbuf2) {
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (ti == tk) dinv[ti + 32 * a] = 1.0 / r[a][a];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { acc[a][b] = 0.0; x[a][b] = 0.0; }
+  }
+  __syncthreads();  // dinv visible; also separates the caller's last use of the staging buffers
+#pragma unroll
+  for (int la = 3; la >= 0; --la)
+    for (int lm = 31; lm >= 0; --lm) {
+      const int l = la * 32 + lm;
+      double *rowbuf = rowbuf2 + (l & 1) * RC_N, *colbuf = colbuf2 + (l & 1) * RC_N;
+      if (ti == lm) {  // owners of row l of X
+        const double di = dinv[l];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int k = tk + 32 * b;
+          const double v = (k >= l) ? ((k == l ? 1.0 : 0.0) - acc[la][b]) * di : 0.0;
+          x[la][b] = v;
+          rowbuf[k] = v;
+        }
+      }
+      if (tk == lm) {  // owners of column l of R
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int i = ti + 32 * a;
+          colbuf[i] = (i < l) ? r[a][la] : 0.0;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const double ci = colbuf[ti + 32 * a];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = fma(ci, rowbuf[tk + 32 * b], acc[a][b]);
+      }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_chol_inv4(const double *__restrict__ G,
+                                                    const double *__restrict__ Rprev,
+                                                    double *__restrict__ Rout,
+                                                    double *__restrict__ negXout,
+                                                    int *__restrict__ flag) {
+  __shared__ double rowbuf[2 * RC_N], colbuf[2 * RC_N], dinv[RC_N];
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31, lane = t & 63;
+  double g[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) g[a][b] = G[(ti + 32 * a) + (tk + 32 * b) * RC_N];
+
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja)
+    for (int jm = 0; jm < 32; ++jm) {
+      const int j = ja * 32 + jm;
+      // G[j][j] lives in thread (jm, jm): lane (lane & 32) + jm of the half-wave that owns row j.
+      // Every wave executes the shuffle (full EXEC); only the row owners use the value.
+      double d = __shfl(g[ja][ja], (lane & 32) + jm, 64);
+      double *rb = rowbuf + (j & 1) * RC_N;
+      if (ti == jm) {  // owners of row j: R[j,k] = G[j,k] / r (k > j), R[j,j] = r
+        if (!(d > 0.0)) {  // breakdown (or NaN): flag it, keep going with a harmless pivot
+          if (tk == 0) flag[0] = 1;
+          d = 1.0;
+        }
+        const double r = sqrt(d), rinv = 1.0 / r;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int k = tk + 32 * b;
+          const double x = (k == j) ? r : g[ja][b] * rinv;
+          g[ja][b] = x;
+          rb[k] = (k > j) ? x : 0.0;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const double ri = rb[ti + 32 * a];  // 0 for rows <= j
+#pragma unroll
+        for (int b = 0; b < 4; ++b) g[a][b] = fma(-ri, rb[tk + 32 * b], g[a][b]);
+      }
+    }
+  // registers now hold R in the upper triangle
+  if (Rprev) {  // R <- R * Rprev (second CholeskyQR pass)
+    __shared__ double Rl[RC_N * (RC_N + 1) / 2];
+    auto pidx = [](int i, int l) { return i * RC_N - (i * (i - 1)) / 2 + (l - i); };
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = ti + 32 * a, k = tk + 32 * b;
+        if (i <= k) Rl[pidx(i, k)] = g[a][b];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = ti + 32 * a, k = tk + 32 * b;
+        double x = 0.0;
+        if (i <= k)
+          for (int l = i; l <= k; ++l) x = fma(Rl[pidx(i, l)], Rprev[l + k * RC_N], x);
+        g[a][b] = x;
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = ti + 32 * a, k = tk + 32 * b;
+      Rout[i + k * RC_N] = (i <= k) ? g[a][b] : 0.0;
+    }
+  if (!negXout) return;
+  double x[4][4];
+  rc_upper_inverse_regs4(g, x, dinv, rowbuf, colbuf);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) negXout[(ti + 32 * a) + (tk + 32 * b) * RC_N] = -x[a][b];
+}
+
+__global__ __launch_bounds__(1024) void k_recon_top4(const double *__restrict__ P, int64_t ldp,
+                                                     const double *__restrict__ R,
+                                                     double *__restrict__ alpha,
+                                                     double *__restrict__ Rref,
+                                                     double *__restrict__ negMinv) {
+  __shared__ double wrow[2 * RC_N], vcol[2 * RC_N], dinv[RC_N];
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31, lane = t & 63;
+  double a[4][4], r[4][4], mm[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int i = ti + 32 * x, k = tk + 32 * y;
+      a[x][y] = P[i + (int64_t)k * ldp];
+      r[x][y] = R[i + k * RC_N];
+      mm[x][y] = 0.0;
+    }
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja)
+    for (int jm = 0; jm < 32; ++jm) {
+      const int j = ja * 32 + jm;
+      const int src = (lane & 32) + jm;  // thread (jm, jm) inside the half-wave that owns row j
+      const double ajj = __shfl(a[ja][ja], src, 64), rjj = __shfl(r[ja][ja], src, 64);
+      double *wr = wrow + (j & 1) * RC_N, *vc = vcol + (j & 1) * RC_N;
+      if (ti == jm) {  // owners of row j
+        const double s = fabs(rjj);                   // src:129 (norm of the updated column)
+        const double al = s * dhqr_alphafactor(ajj);  // src:130
+        const double q = s * (s + fabs(ajj));         // src:131: f = 1/sqrt(q), v_jj = (a_jj - alpha) f
+        const double sq = sqrt(q);
+        const double u = 1.0 / (ajj - al);            // = f / v_jj
+        const double vinv = sq * u;                   // = 1 / v_jj
+        const double sg = (al == 0.0) ? 0.0 : ((al < 0.0) == (rjj < 0.0) ? 1.0 : -1.0);
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          const int k = tk + 32 * y;
+          const double rr = sg * r[ja][y];
+          const double dl = (k > j) ? (a[ja][y] - rr) : 0.0;
+          wr[k] = dl * u;                                      // f * (v_j' a_k)
+          mm[ja][y] = (k > j) ? dl * vinv : (k == j ? sq : 0.0);  // M[j][k] = v_j' a_k, M[j][j] = 1/f_j
+          Rref[j + k * RC_N] = (k > j) ? rr : 0.0;
+        }
+        if (tk == 0) alpha[j] = al;
+      }
+      if (tk == jm) {  // owners of column j: the unscaled a_ij (i > j); f travels in the row
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int i = ti + 32 * x;
+          vc[i] = (i > j) ? a[x][ja] : 0.0;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const double vi = vc[ti + 32 * x];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) a[x][y] = fma(-vi, wr[tk + 32 * y], a[x][y]);  // src:209, top rows
+      }
+    }
+  double xm[4][4];
+  rc_upper_inverse_regs4(mm, xm, dinv, wrow, vcol);
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) negMinv[(ti + 32 * x) + (tk + 32 * y) * RC_N] = -xm[x][y];
+}
+
+__global__ __launch_bounds__(1024) void k_build_t4(const double *__restrict__ S, int ncols,
+                                                   double *__restrict__ Tout,
+                                                   double *__restrict__ Ttout) {
+  __shared__ double rowbuf[2 * RC_N], colbuf[2 * RC_N], dinv[RC_N];
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
+  double u[4][4], x[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = ti + 32 * a, k = tk + 32 * b;
+      u[a][b] = (i == k) ? 1.0 : ((i < k && k < ncols) ? S[i + k * RC_N] : 0.0);
+    }
+  rc_upper_inverse_regs4(u, x, dinv, rowbuf, colbuf);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = ti + 32 * a, k = tk + 32 * b;
+      Tout[i + k * RC_N] = x[a][b];
+      Ttout[k + i * RC_N] = x[a][b];
+    }
+}
+
 // Vw currently holds P * M^{-1}; finish V = tril((P - alpha E) M^{-1}) on the top 128 rows:
 // Vw[i][j] -= alpha_i * Minv[i][j] (i <= j ... only i == row index < 128), and zero above the diagonal.
 __global__ __launch_bounds__(256) void k_recon_fix(double *__restrict__ Vw, int64_t ldv,

@@ -334,3 +334,31 @@ def test_explicit_q_and_r(pkg, m, n):
     eye = torch.eye(n, dtype=torch.float64, device="cuda:0")
     assert (Q.t() @ Q - eye).abs().max().item() < 1e-12
     assert ((Q @ R - A0).norm() / A0.norm()).item() < 1e-12
+
+
+@pytest.mark.xfail(strict=False, reason="DHQR_SMALLK=4 (one-barrier-per-step panel kernels) is verified on the CPU SIMT "
+                                        "emulator only (tests/test_simt_emulation.py); this is its first hardware run")
+def test_smallk4_panel_kernels_match_oracle(pkg, orc, monkeypatch):
+    """The v4 generation of k_chol_inv / k_recon_top / k_build_t must give the same factorisation with
+    every panel on the fast path (a silent fallback to the step kernels would hide a broken kernel)."""
+    import ctypes
+    import torch
+    monkeypatch.setenv("DHQR_SMALLK", "4")
+    ctx = pkg.Context(0)  # the switch is read when the context is created
+    try:
+        for (m, n) in [(1536, 1024), (700, 384)]:
+            A = pkg.rand_colmajor(m, n, 4, "cuda:0")
+            alpha = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+            f0, b0 = ctx.panel_counters()
+            ctx.use_torch_stream()
+            pkg._lib.check(pkg._lib.lib().dhqr_factor_f64(ctx.handle, ctypes.c_void_p(A.data_ptr()), m, n, m,
+                                                          ctypes.c_void_p(alpha.data_ptr()), 128))
+            torch.cuda.synchronize()
+            f1, b1 = ctx.panel_counters()
+            assert (f1 - f0, b1 - b0) == (n // 128, 0)
+            Ho, ao = orc.householder(orc.rand_matrix(m, n, 4))
+            scale = np.abs(Ho).max()
+            assert np.abs(A.cpu().numpy() - Ho).max() <= 1e-11 * scale
+            assert np.abs(alpha.cpu().numpy() - ao).max() <= 1e-11 * scale
+    finally:
+        ctx.close()

@@ -1,0 +1,122 @@
+"""CPU execution of the UNMODIFIED single-workgroup panel kernels (csrc/dhqr_recon.h) on the SIMT
+emulator of tests/simt/ (one OS thread per HIP thread, ThreadSanitizer build), both generations:
+variant 3 = the kernels the library runs by default, variant 4 = the one-barrier-per-step kernels
+(DHQR_SMALLK=4).  Checks the numerics against numpy / the oracle and that ThreadSanitizer reports no
+data race (= no missing barrier in the LDS staging protocol).  Test infrastructure only; needs the
+host clang++ of the ROCm toolchain (for -fsanitize=thread and the clang vector extensions).
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIMT = os.path.join(ROOT, "tests", "simt")
+CSRC = os.path.join(ROOT, "distributedhouseholderqr.jl_amd", "csrc")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+N = 128
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="host clang++ (ROCm llvm) not found")
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("simt") / "emu_recon_tsan")
+    subprocess.check_call([CLANG, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-Wno-unknown-attributes",
+                           "-I", os.path.join(SIMT, "fake"), "-I", CSRC, os.path.join(SIMT, "emu_recon.cpp"),
+                           "-o", exe, "-lpthread"])
+    return exe
+
+
+def _run(exe, *args):
+    r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=900)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[:3000]
+    assert r.returncode == 0, r.stderr[:3000]
+
+
+def _put(path, M):  # column-major raw float64
+    np.asfortranarray(M).T.tofile(path)
+
+
+def _get(path, shape=(N, N)):
+    return np.fromfile(path).reshape(shape[::-1]).T
+
+
+def test_rig_detects_a_missing_barrier(emu, tmp_path):
+    out = str(tmp_path / "o.bin")
+    _run(emu, "sync", 0, out)
+    o = np.fromfile(out)
+    assert np.array_equal(o, (np.arange(128) + 64) % 128 + 64.0)  # LDS neighbour + wave_sum(1) == 64
+    r = subprocess.run([emu, "racy", "0", out], capture_output=True, text=True, timeout=300)
+    assert "ThreadSanitizer: data race" in r.stderr
+
+
+@pytest.mark.parametrize("variant", [4])
+def test_cholesky_and_inverse(emu, orc, tmp_path, variant):
+    P = orc.rand_matrix(300, N, 5)
+    G = P.T @ P
+    f = {k: str(tmp_path / f"{k}.bin") for k in ("G", "R", "X", "flag", "Rp", "R2", "X2")}
+    _put(f["G"], G)
+    _run(emu, "chol", variant, f["G"], "-", 1, f["R"], f["X"], f["flag"])
+    R, negX = _get(f["R"]), _get(f["X"])
+    Rn = np.linalg.cholesky(G).T
+    assert np.abs(R - Rn).max() < 1e-12 * np.abs(Rn).max()
+    assert np.abs(-negX - np.linalg.inv(Rn)).max() < 1e-12 * np.abs(np.linalg.inv(Rn)).max()
+    assert np.array_equal(np.tril(R, -1), np.zeros((N, N)))
+    assert np.array_equal(np.fromfile(f["flag"]), [0.0, 0.0])
+    if variant == 4:  # second CholeskyQR pass (R <- R * Rprev) and the breakdown flag: once is enough
+        Q1 = P @ np.linalg.inv(Rn)
+        _put(f["G"], Q1.T @ Q1)
+        _put(f["Rp"], Rn)
+        _run(emu, "chol", variant, f["G"], f["Rp"], 0, f["R2"], f["X2"], f["flag"])
+        R2 = _get(f["R2"])
+        Rfull = np.linalg.qr(P, mode="r")
+        Rfull *= np.sign(np.diag(Rfull))[:, None]
+        assert np.abs(R2 - Rfull).max() < 1e-12 * np.abs(Rfull).max()
+        Gbad = G.copy()
+        Gbad[40, 40] = -1.0
+        _put(f["G"], Gbad)
+        _run(emu, "chol", variant, f["G"], "-", 0, f["R2"], f["X2"], f["flag"])
+        assert np.fromfile(f["flag"])[0] == 1.0
+
+
+@pytest.mark.parametrize("variant", [3, 4])
+def test_replay_of_top_block(emu, orc, tmp_path, variant):
+    rows = 300
+    P = orc.rand_matrix(rows, N, 6)
+    Ho, ao = orc.householder(P)                      # the reference algorithm on the whole panel
+    R = np.linalg.qr(P, mode="r")                    # any row signs are accepted by the kernel
+    f = {k: str(tmp_path / f"{k}.bin") for k in ("P", "R", "al", "Rref", "Mi")}
+    _put(f["P"], P[:N])
+    _put(f["R"], R)
+    _run(emu, "recon", variant, f["P"], f["R"], f["al"], f["Rref"], f["Mi"])
+    alpha, Rref, negMinv = np.fromfile(f["al"]), _get(f["Rref"]), _get(f["Mi"])
+    scale = np.abs(Ho).max()
+    assert np.abs(alpha - ao).max() < 1e-12 * scale
+    assert np.abs(Rref - np.triu(Ho[:N], 1)).max() < 1e-12 * scale
+    # what the library does next (one GEMM): V = tril((P - alpha E) M^{-1}) for ALL rows of the panel
+    PE = P.copy()
+    PE[:N] -= np.diag(alpha)
+    V = np.tril(PE @ (-negMinv))
+    assert np.abs(V - np.tril(Ho)).max() < 1e-12 * scale
+
+
+@pytest.mark.parametrize("variant,ncols", [(3, 77), (4, 128), (4, 77)])
+def test_block_reflector_t(emu, orc, tmp_path, variant, ncols):
+    Ho, _ = orc.householder(orc.rand_matrix(300, ncols, 7))
+    V = np.zeros((300, N))
+    V[:, :ncols] = np.tril(Ho)
+    S = V.T @ V
+    f = {k: str(tmp_path / f"{k}.bin") for k in ("S", "T", "Tt")}
+    _put(f["S"], S)
+    _run(emu, "buildt", variant, f["S"], ncols, f["T"], f["Tt"])
+    T, Tt = _get(f["T"]), _get(f["Tt"])
+    Tn = np.linalg.inv(np.eye(N) + np.triu(S, 1))    # compact WY: T^{-1} = I + striu(V'V)
+    assert np.abs(T - Tn).max() < 1e-13
+    assert np.array_equal(Tt, T.T)
+    # H_1 ... H_ncols == I - V T V'
+    Q = np.eye(300)
+    for j in reversed(range(ncols)):
+        Q -= np.outer(V[:, j], V[:, j] @ Q)
+    assert np.abs(Q - (np.eye(300) - V @ T @ V.T)).max() < 1e-13
