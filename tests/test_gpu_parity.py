@@ -336,8 +336,6 @@ def test_explicit_q_and_r(pkg, m, n):
     assert ((Q @ R - A0).norm() / A0.norm()).item() < 1e-12
 
 
-@pytest.mark.xfail(strict=False, reason="DHQR_SMALLK=4 (one-barrier-per-step panel kernels) is verified on the CPU SIMT "
-                                        "emulator only (tests/test_simt_emulation.py); this is its first hardware run")
 def test_smallk4_panel_kernels_match_oracle(pkg, orc, monkeypatch):
     """The v4 generation of k_chol_inv / k_recon_top / k_build_t must give the same factorisation with
     every panel on the fast path (a silent fallback to the step kernels would hide a broken kernel)."""
