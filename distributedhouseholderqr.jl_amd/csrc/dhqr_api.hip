@@ -928,22 +928,30 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
   dhqr_ctx *c = new dhqr_ctx();
   c->device = device;
   memset(&c->st, 0, sizeof(c->st));
-  HIPCHECK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
-  c->stream = c->own;
-  {
-    int lo = 0, hi = 0;
-    HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
-    HIPCHECK(hipStreamCreateWithPriority(&c->hi, hipStreamNonBlocking, hi));
-    for (int i = 0; i < 4; ++i) {
-      HIPCHECK(hipEventCreateWithFlags(&c->ev_panel[i], hipEventDisableTiming));
-      HIPCHECK(hipEventCreateWithFlags(&c->ev_wide[i], hipEventDisableTiming));
+  auto init = [&]() -> int32_t {  // any failure below releases what was created so far (dhqr_destroy)
+    HIPCHECK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
+    c->stream = c->own;
+    {
+      int lo = 0, hi = 0;
+      HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
+      HIPCHECK(hipStreamCreateWithPriority(&c->hi, hipStreamNonBlocking, hi));
+      for (int i = 0; i < 4; ++i) {
+        HIPCHECK(hipEventCreateWithFlags(&c->ev_panel[i], hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&c->ev_wide[i], hipEventDisableTiming));
+      }
     }
+    if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_SWIZZLE")) c->swizzle = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_PAIR_MIN_N")) c->pair_min_n = atoll(e);
+    HIPCHECK(hipHostMalloc((void **)&c->hflag, 4 * sizeof(int), hipHostMallocDefault));
+    return DHQR_OK;
+  };
+  const int32_t rc_init = init();
+  if (rc_init != DHQR_OK) {
+    (void)dhqr_destroy(c);
+    return rc_init;
   }
-  if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
-  if (const char *e = getenv("DHQR_SWIZZLE")) c->swizzle = atoi(e) != 0;
-  if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;
-  if (const char *e = getenv("DHQR_PAIR_MIN_N")) c->pair_min_n = atoll(e);
-  HIPCHECK(hipHostMalloc((void **)&c->hflag, 4 * sizeof(int), hipHostMallocDefault));
   if (const char *e = getenv("DHQR_CHOLQR_PASSES")) c->cholqr_passes = atoi(e) == 2 ? 2 : 1;
   if (const char *e = getenv("DHQR_RECON_TOL")) c->recon_tol = atof(e);
   if (const char *e = getenv("DHQR_SMALLK")) c->smallk = atoi(e) == 4 ? 4 : 3;
