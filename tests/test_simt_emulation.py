@@ -1,7 +1,9 @@
-"""CPU execution of the UNMODIFIED single-workgroup panel kernels (csrc/dhqr_recon.h) on the SIMT
-emulator of tests/simt/ (one OS thread per HIP thread, ThreadSanitizer build), both generations:
-variant 3 = the kernels the library runs by default, variant 4 = the one-barrier-per-step kernels
-(DHQR_SMALLK=4).  Checks the numerics against numpy / the oracle and that ThreadSanitizer reports no
+"""CPU execution of UNMODIFIED HIP kernel sources on the SIMT emulator of tests/simt/ (one OS thread per
+HIP thread, ThreadSanitizer build):
+  * the single-workgroup panel kernels (csrc/dhqr_recon.h), both generations: variant 3 = the kernels the
+    library runs by default, variant 4 = the one-barrier-per-step kernels (DHQR_SMALLK=4);
+  * the unblocked factorisation kernels for Float64 and ComplexF64 (dhqr_rank1.h, dhqr_complex.h) and the
+    solve kernels (dhqr_solve.h, dhqr_complex.h), launched in the library's per-column sequence.  Checks the numerics against numpy / the oracle and that ThreadSanitizer reports no
 data race (= no missing barrier in the LDS staging protocol).  Test infrastructure only; needs the
 host clang++ of the ROCm toolchain (for -fsanitize=thread and the clang vector extensions).
 """
@@ -25,6 +27,15 @@ def emu(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("simt") / "emu_recon_tsan")
     subprocess.check_call([CLANG, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-Wno-unknown-attributes",
                            "-I", os.path.join(SIMT, "fake"), "-I", CSRC, os.path.join(SIMT, "emu_recon.cpp"),
+                           "-o", exe, "-lpthread"])
+    return exe
+
+
+@pytest.fixture(scope="module")
+def emu_paths(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("simt") / "emu_paths_tsan")
+    subprocess.check_call([CLANG, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-Wno-unknown-attributes",
+                           "-I", os.path.join(SIMT, "fake"), "-I", CSRC, os.path.join(SIMT, "emu_paths.cpp"),
                            "-o", exe, "-lpthread"])
     return exe
 
@@ -120,3 +131,60 @@ def test_block_reflector_t(emu, orc, tmp_path, variant, ncols):
     for j in reversed(range(ncols)):
         Q -= np.outer(V[:, j], V[:, j] @ Q)
     assert np.abs(Q - (np.eye(300) - V @ T @ V.T)).max() < 1e-13
+
+
+# ------------------------------------------------------------------ unblocked path / solve kernels
+@pytest.mark.parametrize("m,n,threads", [(70, 9, 256), (71, 6, 256), (40, 5, 0), (41, 4, 0)])
+def test_unblocked_f64_kernels(emu_paths, orc, tmp_path, m, n, threads):
+    """k_reflector + k_rank1_fused<256,8,VEC> (threads=256) / k_rank1_generic<1024,VEC> (threads=0); even m
+    takes the 16-byte (VEC=2) loads, odd m the scalar ones -- one launch per column like the library"""
+    A = orc.rand_matrix(m, n, 3)
+    f = {k: str(tmp_path / f"{k}.bin") for k in ("A", "H", "al")}
+    _put(f["A"], A)
+    _run(emu_paths, "f64", m, n, f["A"], f["H"], f["al"], threads)
+    Ho, ao = orc.householder(A)
+    assert np.abs(_get(f["H"], (m, n)) - Ho).max() < 1e-13 * np.abs(Ho).max()
+    assert np.abs(np.fromfile(f["al"]) - ao).max() < 1e-13 * np.abs(Ho).max()
+
+
+@pytest.mark.parametrize("m,n,threads", [(70, 7, 256), (33, 5, 512), (20, 4, 1024)])
+def test_unblocked_c64_kernels(emu_paths, orc, tmp_path, m, n, threads):
+    A = orc.rand_matrix_c(m, n, 3)
+    f = {k: str(tmp_path / f"{k}.bin") for k in ("A", "H", "al")}
+    A.T.copy().view(np.float64).tofile(f["A"])  # column-major interleaved (re, im)
+    _run(emu_paths, "c64", m, n, f["A"], f["H"], f["al"], threads)
+    H = np.fromfile(f["H"]).view(np.complex128).reshape(n, m).T
+    al = np.fromfile(f["al"]).view(np.complex128)
+    Ho, ao = orc.householder_c(A)
+    assert np.abs(H - Ho).max() < 1e-13 * np.abs(Ho).max()
+    assert np.abs(al - ao).max() < 1e-13 * np.abs(Ho).max()
+
+
+def test_solve_kernels_c64_and_f64(emu_paths, orc, tmp_path):
+    f = {k: str(tmp_path / f"{k}.bin") for k in ("H", "al", "b", "x")}
+    # ComplexF64: Q^H b column by column, then the 32-row blocked back substitution (two blocks + remainder)
+    m, n = 90, 70
+    A = orc.rand_matrix_c(m, n, 8)
+    b = orc.rand_vector_c(m, 9)
+    Ho, ao = orc.householder_c(A)
+    Ho.T.copy().view(np.float64).tofile(f["H"])
+    ao.view(np.float64).tofile(f["al"])
+    b.view(np.float64).tofile(f["b"])
+    _run(emu_paths, "zsolve", m, n, f["H"], f["al"], f["b"], f["x"])
+    x = np.fromfile(f["x"]).view(np.complex128)
+    xo = orc.solve_c(Ho, ao, b)
+    assert np.abs(x - xo).max() < 1e-11 * np.abs(xo).max()
+    # Float64 back substitution (64-row blocks) on b = Q'b
+    m, n = 150, 100
+    A = orc.rand_matrix(m, n, 10)
+    b = orc.rand_vector(m, 11)
+    Ho, ao = orc.householder(A)
+    qtb = b.copy()
+    for j in range(n):
+        qtb[j:] -= Ho[j:, j] * (Ho[j:, j] @ qtb[j:])
+    _put(f["H"], Ho)
+    ao.tofile(f["al"])
+    qtb.tofile(f["b"])
+    _run(emu_paths, "backsub", m, n, f["H"], f["al"], f["b"], f["x"])
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(np.fromfile(f["x"]) - xo).max() < 1e-11 * np.abs(xo).max()
