@@ -239,8 +239,11 @@ def main():
     # ---- roofline of the dominant kernel group (per-launch hipEvent pairs on the launch stream)
     groups = []
     if st["ms_gemm_avw"] > 0:
+        # one timed group = ONE wide k_gemm_nn_sub launch on the caller's stream (rocprofv3 lists the narrow
+        # look-ahead launches of the same template on the second stream as well: profiles/*_by_stream.csv)
         groups.append(dict(kernel="k_gemm_nn_sub (A -= V*W, FP64 MFMA)", bound="mfma", ms=st["ms_gemm_avw"],
                            launches=st["n_gemm_avw"], work=st["flops_gemm_avw"]))
+        # one timed group = the TN launches of one wide update (two per two-panel update) + their split-K reductions
         groups.append(dict(kernel="k_gemm_tn (W = V'*A, FP64 MFMA)", bound="mfma", ms=st["ms_gemm_vta"],
                            launches=st["n_gemm_vta"], work=st["flops_gemm_vta"]))
     if st["ms_panel"] > 0:

@@ -1,5 +1,9 @@
 """rocprofv3 (rocpd sqlite output) -> per-kernel summary CSV, the same columns as --stats.
-usage: python tools/prof_summary.py <results.db> <out.csv> ["command line that was profiled"]"""
+usage: python tools/prof_summary.py <results.db> <out.csv> ["command line that was profiled"]
+       python tools/prof_summary.py --by-stream <results.db> <out.csv> ["command line"]
+--by-stream splits every kernel by HIP stream and by launch size (>= 400 workgroups = "wide"): the
+blocked driver runs the wide trailing update on the caller's stream and the panel / narrow-update lane
+on a second one, and bench.py's hipEvent groups time the caller's stream only."""
 import csv
 import sqlite3
 import sys
@@ -21,5 +25,24 @@ def main(db, out, cmd=""):
     print("wrote", out, "kernels:", len(rows), "total ms:", tot / 1e6)
 
 
+def by_stream(db, out, cmd=""):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute(
+        "select name, stream, case when grid_x*grid_y*grid_z/(workgroup_x*workgroup_y*workgroup_z) >= 400 "
+        "then 'wide' else 'small' end as cls, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+        "from kernels group by name, stream, cls order by 5 desc").fetchall()
+    with open(out, "w", newline="") as f:
+        if cmd:
+            f.write(f"# rocprofv3 --kernel-trace -- {cmd}  (split by stream and launch size)\n")
+        w = csv.writer(f)
+        w.writerow(["Name", "Stream", "LaunchClass", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([r[0], r[1], r[2], r[3], int(r[4]), f"{r[5]:.1f}", int(r[6]), int(r[7])])
+    print("wrote", out, "rows:", len(rows))
+
+
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    if len(sys.argv) > 1 and sys.argv[1] == "--by-stream":
+        by_stream(*sys.argv[2:5])
+    else:
+        main(*sys.argv[1:4])
