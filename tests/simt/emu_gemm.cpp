@@ -1,0 +1,77 @@
+// tests/simt/emu_gemm.cpp -- TEST INFRASTRUCTURE: the FP64-MFMA trailing-update kernels of
+// csrc/dhqr_gemm.h (unmodified source) on the CPU SIMT emulator; v_mfma_f64_16x16x4_f64 is emulated
+// wave-synchronously with the documented operand maps.  Workgroups are independent and run in sequence.
+//   emu_gemm tn <vec> <nbv> <rows> <ncols> <ldv> <ldc> <rps> V C out          out: nsplit x (nbv... ld 128) x ncols
+//   emu_gemm nn <vec> <kw>  <rows> <ncols> <ldv> <ldc> <swz> V W Cin Cout     W: ld = kw
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "dhqr_gemm.h"
+
+static std::vector<double> rd(const char *path, size_t n) {
+  std::vector<double> v(n);
+  FILE *f = fopen(path, "rb");
+  if (!f || fread(v.data(), sizeof(double), n, f) != n) { fprintf(stderr, "cannot read %s\n", path); exit(2); }
+  fclose(f);
+  return v;
+}
+static void wr(const char *path, const std::vector<double> &v) {
+  FILE *f = fopen(path, "wb");
+  if (!f || fwrite(v.data(), sizeof(double), v.size(), f) != v.size()) { fprintf(stderr, "cannot write %s\n", path); exit(2); }
+  fclose(f);
+}
+template <typename F>
+static void grid2(int gx, int gy, int threads, F &&kernel) {
+  simt::launch_grid(gx, gy, threads, kernel);
+}
+
+int main(int argc, char **argv) {
+  if (argc < 10) return 2;
+  const std::string op = argv[1];
+  const int vec = atoi(argv[2]), kparam = atoi(argv[3]);
+  const int64_t rows = atoll(argv[4]), ncols = atoll(argv[5]), ldv = atoll(argv[6]), ldc = atoll(argv[7]);
+  if (op == "tn") {
+    const int64_t rps = atoll(argv[8]);
+    auto V = rd(argv[9], (size_t)ldv * 128);
+    auto C = rd(argv[10], (size_t)ldc * ncols);
+    const int nsplit = (int)((rows + rps - 1) / rps), ntiles = (int)((ncols + 127) / 128);
+    const int64_t ostride = 128 * ncols;
+    std::vector<double> out((size_t)nsplit * ostride, -7.0);
+#define TN(VEC_, NBV_)                                                                                   \
+  grid2(ntiles, nsplit, 256, [&] {                                                                       \
+    k_gemm_tn<VEC_, 1, NBV_>(V.data(), ldv, C.data(), ldc, 1, (int64_t)0, rows, ncols, rps, out.data(),  \
+                             (int64_t)128, ostride);                                                     \
+  })
+    if (vec == 2 && kparam == 128) TN(2, 128);
+    else if (vec == 1 && kparam == 128) TN(1, 128);
+    else if (vec == 2 && kparam == 64) TN(2, 64);
+    else if (vec == 2 && kparam == 32) TN(2, 32);
+    else return 2;
+#undef TN
+    wr(argv[11], out);
+  } else if (op == "nn") {
+    const int swz = atoi(argv[8]);
+    auto V = rd(argv[9], (size_t)ldv * kparam);
+    auto W = rd(argv[10], (size_t)kparam * ncols);
+    auto C = rd(argv[11], (size_t)ldc * ncols);
+    const int gx = (int)((rows + 127) / 128), gy = (int)((ncols + 127) / 128);
+    int lx = gx, ly = gy;
+    if (swz) { lx = (((gx + 7) / 8) * ((gy + 7) / 8) + 7) / 8 * 512; ly = 1; }  // the library's 1-D launch
+#define NN(VEC_, KW_)                                                                                     \
+  grid2(lx, ly, 256, [&] {                                                                                \
+    k_gemm_nn_sub<VEC_, KW_>(V.data(), ldv, W.data(), (int64_t)KW_, C.data(), ldc, rows, ncols, swz);     \
+  })
+    if (vec == 2 && kparam == 128) NN(2, 128);
+    else if (vec == 1 && kparam == 128) NN(1, 128);
+    else if (vec == 2 && kparam == 256) NN(2, 256);
+    else if (vec == 2 && kparam == 64) NN(2, 64);
+    else return 2;
+#undef NN
+    wr(argv[12], C);
+  } else {
+    return 2;
+  }
+  return 0;
+}

@@ -30,7 +30,7 @@ static void wr(const char *path, const std::vector<double> &v) {
 }
 template <typename F>
 static void grid(int blocks, int threads, F &&body) {
-  for (int b = 0; b < blocks; ++b) simt::launch_block(threads, body, (unsigned)b, (unsigned)blocks);
+  simt::launch_grid(blocks, 1, threads, body);
 }
 
 int main(int argc, char **argv) {

@@ -56,6 +56,7 @@ struct Barrier {
 struct Wave {
   Barrier bar;
   uint64_t buf[64];
+  double mfa[64], mfb[64];  // operands of an emulated MFMA
 };
 struct Block {
   Barrier bar;
@@ -97,13 +98,42 @@ inline T __shfl_xor(T v, int mask, int width = 64) {
   return simt_shfl_bits(v, lane ^ mask);
 }
 
+// ---- v_mfma_f64_16x16x4_f64, wave-synchronous like the instruction: every lane contributes one A and one
+// B element, D[i][j] += sum_k A[i][k] B[k][j] with the gfx950 operand maps documented in csrc/dhqr_gemm.h
+//   A: lane l holds A[i = l&15][k = l>>4]   B: lane l holds B[k = l>>4][j = l&15]
+//   C/D: lane l, register g holds D[i = (l>>4) + 4g][j = l&15]
+// (the map itself is pinned on the device by tests/test_gpu_kernels.py::test_mfma_layout_probe)
+typedef double simt_d4 __attribute__((ext_vector_type(4)));
+inline simt_d4 simt_mfma_f64_16x16x4(double a, double b, simt_d4 c) {
+  simt::Wave &w = simt::cur_block()->waves[simt::tl_tid >> 6];
+  const int lane = simt::tl_tid & 63;
+  w.mfa[lane] = a;
+  w.mfb[lane] = b;
+  w.bar.wait();
+  const int j = lane & 15;
+  for (int g = 0; g < 4; ++g) {
+    const int i = (lane >> 4) + 4 * g;
+    double s = c[g];
+    for (int k = 0; k < 4; ++k) s = std::fma(w.mfa[i + 16 * k], w.mfb[j + 16 * k], s);
+    c[g] = s;
+  }
+  w.bar.wait();
+  return c;
+}
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) simt_mfma_f64_16x16x4(a, b, c)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+inline long long clock64() { return 0; }
+
 namespace simt {
-// run `body` (a kernel call) once per thread of a single workgroup of `nthreads` threads
-inline void launch_block(int nthreads, const std::function<void()> &body, unsigned bx = 0, unsigned gx = 1) {
+// Run a gx x gy grid of INDEPENDENT workgroups of `nthreads` threads, one workgroup after the other.
+// The OS threads are created once and walk the grid in lockstep: [fixed barrier] thread 0 re-arms the
+// dynamic barriers [fixed barrier] kernel body, leave() -> next workgroup.  The fixed barriers also keep a
+// fast thread from touching the (static) LDS arrays of workgroup n+1 while a slow one still reads n.
+inline void launch_grid(int gx, int gy, int nthreads, const std::function<void()> &body) {
   Block blk;
-  blk.bar.reset(nthreads);
   blk.waves = std::vector<Wave>((nthreads + 63) / 64);
-  for (int w = 0; w < (int)blk.waves.size(); ++w) blk.waves[w].bar.reset(std::min(64, nthreads - 64 * w));
+  Barrier fence;  // fixed participant count, nobody leaves
+  fence.reset(nthreads);
   cur_block() = &blk;
   std::vector<std::thread> th;
   th.reserve(nthreads);
@@ -111,14 +141,24 @@ inline void launch_block(int nthreads, const std::function<void()> &body, unsign
     th.emplace_back([&, t] {
       tl_tid = t;
       threadIdx = simt_uint3{(unsigned)t, 0, 0};
-      blockIdx = simt_uint3{bx, 0, 0};
       blockDim = dim3(nthreads);
-      gridDim = dim3(gx);
-      body();
-      blk.waves[t >> 6].bar.leave();
-      blk.bar.leave();
+      gridDim = dim3(gx, gy);
+      for (int y = 0; y < gy; ++y)
+        for (int x = 0; x < gx; ++x) {
+          fence.wait();
+          if (t == 0) {
+            blk.bar.reset(nthreads);
+            for (int w = 0; w < (int)blk.waves.size(); ++w) blk.waves[w].bar.reset(std::min(64, nthreads - 64 * w));
+          }
+          fence.wait();
+          blockIdx = simt_uint3{(unsigned)x, (unsigned)y, 0};
+          body();
+          blk.waves[t >> 6].bar.leave();
+          blk.bar.leave();
+        }
     });
   for (auto &x : th) x.join();
   cur_block() = nullptr;
 }
+inline void launch_block(int nthreads, const std::function<void()> &body) { launch_grid(1, 1, nthreads, body); }
 }  // namespace simt
