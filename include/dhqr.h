@@ -18,6 +18,8 @@
  *   - device-resident entry points enqueue work on the context's stream and return without
  *     synchronising unless they hand a host scalar back (documented per function).
  *   - one dhqr_ctx per (host thread, GPU); a ctx is not re-entrant.
+ *   - a matrix without columns (n == 0, m >= 0) is a no-op for the factor / solve entry points, like the
+ *     reference's empty loops (src:127, src:217); m < n, negative sizes and ld < m are DHQR_EINVAL.
  *   - factor format (identical to the reference, src:296-309): after factorisation
  *       A[j:m, j] = v_j  (diagonal INCLUDED, ||v_j||^2 = 2, H_j = I - v_j v_j'),
  *       A[i, j]  = R[i,j] for i < j,   alpha[j] = R[j,j].

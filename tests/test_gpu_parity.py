@@ -360,3 +360,20 @@ def test_smallk4_panel_kernels_match_oracle(pkg, orc, monkeypatch):
             assert np.abs(alpha.cpu().numpy() - ao).max() <= 1e-11 * scale
     finally:
         ctx.close()
+
+
+def test_matrix_without_columns_is_a_noop(pkg):
+    """qr!(zeros(m, 0)) returns an empty alpha and `\\` an empty x in the reference (its loops do not run,
+    src:127, src:217); the C ABI treats n == 0 the same way for host and device, Float64 and ComplexF64."""
+    import torch
+    for dt in (np.float64, np.complex128):
+        A = np.zeros((5, 0), dtype=dt, order="F")
+        H = pkg.qr_(A)
+        assert H.α.shape == (0,) and H.α.dtype == dt
+        x = pkg.ldiv(H, np.ones(5, dtype=dt))
+        assert x.shape == (0,)
+    Ad = torch.zeros((0, 7), dtype=torch.float64, device="cuda:0").t()  # 7 x 0, column-major
+    Hd = pkg.qr_(Ad)
+    assert tuple(Hd.α.shape) == (0,)
+    b = torch.ones(7, dtype=torch.float64, device="cuda:0")
+    assert tuple(pkg.ldiv(Hd, b).shape) == (0,)
