@@ -10,7 +10,7 @@ from ._lib import NB, DHQRError, build
 from .api import (Context, DistributedHouseholderQRStruct, apply_q_, bench_mfma_tflops,
                   bench_stream_gbps, empty_colmajor, get_context, get_q, get_r, householder_, ldiv, partialdot,
                   qr_, rand_colmajor, rand_colmajor_c, rand_vector_device, residual, solve_householder_)
-from .distributed import ColumnCyclicQR, HipBackend
+from .distributed import ColumnCyclicQR, HipBackend, qr_darray_
 from .rowsplit import HipRowBackend, RowSplitQR
 from .partition import BlockCyclicColumns, LocalColumnBlock, contiguous_column_blocks
 
@@ -18,5 +18,5 @@ __all__ = [
     "NB", "DHQRError", "build", "Context", "DistributedHouseholderQRStruct", "apply_q_",
     "bench_mfma_tflops", "bench_stream_gbps", "empty_colmajor", "get_context", "get_q", "get_r", "householder_",
     "ldiv", "partialdot", "qr_", "rand_colmajor", "rand_colmajor_c", "rand_vector_device", "residual",
-    "solve_householder_", "ColumnCyclicQR", "HipBackend", "RowSplitQR", "HipRowBackend", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
+    "solve_householder_", "ColumnCyclicQR", "qr_darray_", "HipBackend", "RowSplitQR", "HipRowBackend", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
 ]

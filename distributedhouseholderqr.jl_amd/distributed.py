@@ -29,7 +29,7 @@ import torch.distributed as dist
 from . import _lib
 from ._lib import NB, check
 from .api import Context, empty_colmajor, get_context
-from .partition import BlockCyclicColumns
+from .partition import BlockCyclicColumns, contiguous_column_blocks
 
 
 class HipBackend:
@@ -346,6 +346,74 @@ class ColumnCyclicQR:
                 u[c0: c0 + w].zero_()
         return x[:n].clone()
 
+    # ------------------------------------------------------------------ the reference's DArray layout
+    # qr!(A::DArray) (src:115-120, test/runtests.jl:71) receives CONTIGUOUS column blocks, one per
+    # process (DistributedArrays' default split).  The factorisation here runs on a block-cyclic layout
+    # (contiguous blocks leave the owners of the early columns idle: <= 5.4x on 8 GPUs), so
+    # a caller holding the reference's layout converts on the way in and out.  One broadcast / reduce of
+    # each rank's block per direction: a one-off O(mn) exchange next to the O(mn^2) factorisation, built
+    # only from collectives every backend has (NCCL/RCCL and gloo).
+    def _stage(self, width):
+        return torch.empty((width, self.m), dtype=self.A.dtype, device=self.A.device)  # == m x width column-major
+
+    def _my_runs(self, cols):
+        """pieces (first global col, count, local col) of the global column range `cols` that this rank
+        owns in the block-cyclic layout (a run never crosses a cyclic block)"""
+        lay, out = self.layout, []
+        if len(cols) == 0:
+            return out
+        for k in range(cols.start // self.nb, (cols.stop - 1) // self.nb + 1):
+            if lay.owner(k) != self.rank:
+                continue
+            lo, hi = max(k * self.nb, cols.start), min((k + 1) * self.nb, cols.stop, self.n)
+            if hi > lo:
+                out.append((lo, hi - lo, lay.local_col_start(k) + lo - k * self.nb))
+        return out
+
+    def load_contiguous_blocks(self, local_block):
+        """Scatter-in: `local_block` (m x w_r, any strides) holds this rank's columns
+        contiguous_column_blocks(n, P)[rank] of the global matrix -- the reference's DArray layout."""
+        blocks = contiguous_column_blocks(self.n, self.P)
+        mine = blocks[self.rank]
+        if tuple(local_block.shape) != (self.m, len(mine)):
+            raise ValueError(f"rank {self.rank} must pass a {self.m} x {len(mine)} block, got {tuple(local_block.shape)}")
+        for s, cols in enumerate(blocks):
+            if len(cols) == 0:
+                continue
+            buf = self._stage(len(cols))
+            if s == self.rank:
+                buf.copy_(local_block.t())
+            if self.P > 1:
+                src = dist.get_global_rank(self.group, s) if self.group is not None else s
+                dist.broadcast(buf, src=src, group=self.group)
+            for g0, cnt, l0 in self._my_runs(cols):
+                self.A[:, l0: l0 + cnt].copy_(buf[g0 - cols.start: g0 - cols.start + cnt].t())
+        return self
+
+    def store_contiguous_blocks(self):
+        """Gather-out: this rank's contiguous column block (m x w_r, column-major) of the FACTORED matrix
+        in the reference's DArray layout; alpha is replicated already (self.alpha, the SharedArray of
+        src:301-304)."""
+        blocks = contiguous_column_blocks(self.n, self.P)
+        out = None
+        for s, cols in enumerate(blocks):
+            if len(cols) == 0:
+                if s == self.rank:
+                    out = self._stage(0).t()
+                continue
+            buf = self._stage(len(cols))
+            buf.zero_()
+            for g0, cnt, l0 in self._my_runs(cols):
+                buf[g0 - cols.start: g0 - cols.start + cnt].copy_(self.A[:, l0: l0 + cnt].t())
+            if self.P > 1:
+                dst = dist.get_global_rank(self.group, s) if self.group is not None else s
+                dist.reduce(buf, dst=dst, group=self.group)  # every column has exactly one non-zero contributor
+            if s == self.rank:
+                out = buf.t()
+        return out
+
+
+
     # ------------------------------------------------------------------ gather (tests / small n)
     def gather_full(self):
         """(H, alpha) as host numpy arrays on every rank -- Array(A::DArray) for small problems."""
@@ -361,3 +429,19 @@ class ColumnCyclicQR:
             for jl in range(blk.shape[1]):
                 H[:, self.layout.global_col(rk, jl)] = blk[:, jl]
         return H, self.alpha.cpu().numpy().copy()
+
+
+def qr_darray_(local_block, n: int, group=None, backend=None, lookahead: bool = True):
+    """qr!(A::DArray) (src:115-120, 311-315) for callers that hold the reference's layout: every rank
+    passes ITS contiguous column block of the m x n matrix (contiguous_column_blocks(n, P)[rank]); the
+    block is overwritten with the factored columns (V on/below the diagonal, R above) and the replicated
+    alpha (the reference's SharedArray) is returned together with the distributed factor object, whose
+    .solve(b) is `H \\ b`.  Internally: scatter to block-cyclic, factor, gather back."""
+    m = local_block.shape[0]
+    q = ColumnCyclicQR(m, n, group=group, backend=backend, lookahead=lookahead)
+    q.load_contiguous_blocks(local_block)
+    q.factor()
+    fac = q.store_contiguous_blocks()
+    if fac.numel():
+        local_block.copy_(fac)
+    return q, q.alpha

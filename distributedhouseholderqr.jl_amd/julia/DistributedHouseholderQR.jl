@@ -22,7 +22,8 @@
 # `qr!(A::DArray)` (src:115-120): one Julia worker per GPU calls `dhqr_panel_factor_f64` /
 # `dhqr_panel_apply_f64` on its block-cyclic local part and broadcasts the packed (V, T, α) panel
 # buffer; the orchestration is the one implemented and tested in
-# distributedhouseholderqr.jl_amd/distributed.py (ColumnCyclicQR).  It is not duplicated here.
+# distributedhouseholderqr.jl_amd/distributed.py (ColumnCyclicQR; `qr_darray_` there takes and returns the
+# DistributedArrays layout of contiguous column blocks).  It is not duplicated here.
 module DistributedHouseholderQR
 
 using LinearAlgebra

@@ -64,6 +64,57 @@ def test_column_cyclic_orchestration(m, n, P, lookahead):
     run_ranks(_cyclic, P, m, n, lookahead)
 
 
+def _darray(rank, P, m, n):
+    """qr!(A::DArray) front-end: every rank passes its CONTIGUOUS column block (the reference's
+    DistributedArrays layout, test/runtests.jl:71) and gets it back factored"""
+    import importlib
+    import torch
+    import __graft_entry__ as g
+    from oracle import dhqr_oracle as orc
+    pkg = g.import_package()
+    part = importlib.import_module("dhqr_amd.partition")
+    A = orc.rand_matrix(m, n, 51)
+    cols = part.contiguous_column_blocks(n, P)[rank]
+    local = torch.from_numpy(np.array(A[:, cols.start: cols.stop], order="F"))
+    # layout round trip first: scatter to block-cyclic and gather back is the identity
+    q0 = pkg.ColumnCyclicQR(m, n, backend=OracleBackend())
+    q0.load_contiguous_blocks(local)
+    back = q0.store_contiguous_blocks()
+    assert tuple(back.shape) == (m, len(cols)) and torch.equal(back, local)
+    H0, _ = q0.gather_full()
+    assert np.array_equal(H0, A)
+    # the front-end proper
+    q, alpha = pkg.qr_darray_(local, n, backend=OracleBackend())
+    Ho, ao = orc.householder(A)
+    scale = np.abs(Ho).max()
+    if len(cols):  # (a rank may own no column at all)
+        assert np.abs(local.numpy() - Ho[:, cols.start: cols.stop]).max() <= 1e-11 * scale
+    assert np.abs(alpha.numpy() - ao).max() <= 1e-11 * scale
+    b = orc.rand_vector(m, 52)
+    x = q.solve(torch.from_numpy(b.copy())).numpy()
+    assert np.abs(x - orc.solve(Ho, ao, b)).max() <= 1e-9 * np.abs(orc.solve(Ho, ao, b)).max()
+    return True
+
+
+@pytest.mark.parametrize("m,n,P", [(300, 260, 2), (400, 385, 3), (130, 5, 3), (200, 2, 3)])
+def test_darray_layout_front_end(m, n, P):
+    """contiguous blocks in, contiguous blocks out (incl. ranks that own few or no columns)"""
+    run_ranks(_darray, P, m, n)
+
+
+def test_darray_front_end_single_rank():
+    import torch
+    import __graft_entry__ as g
+    from oracle import dhqr_oracle as orc
+    pkg = g.import_package()
+    A = orc.rand_matrix(200, 150, 53)
+    local = torch.from_numpy(A.copy(order="F"))
+    q, alpha = pkg.qr_darray_(local, 150, backend=OracleBackend())
+    Ho, ao = orc.householder(A)
+    assert np.abs(local.numpy() - Ho).max() <= 1e-11 * np.abs(Ho).max()
+    assert np.abs(alpha.numpy() - ao).max() <= 1e-11 * np.abs(Ho).max()
+
+
 def test_single_rank_without_process_group():
     import __graft_entry__ as g
     from oracle import dhqr_oracle as orc

@@ -377,3 +377,21 @@ def test_matrix_without_columns_is_a_noop(pkg):
     assert tuple(Hd.α.shape) == (0,)
     b = torch.ones(7, dtype=torch.float64, device="cuda:0")
     assert tuple(pkg.ldiv(Hd, b).shape) == (0,)
+
+
+def test_darray_front_end_single_gpu(pkg, orc):
+    """qr_darray_ (contiguous column blocks in / out, the reference's DArray layout) with the product backend
+    at world size 1; the multi-rank scatter/gather is covered under gloo in tests/test_distributed_cpu.py"""
+    import torch
+    m, n = 700, 520
+    A = pkg.rand_colmajor(m, n, 61, "cuda:0")
+    q, alpha = pkg.qr_darray_(A, n)
+    torch.cuda.synchronize()
+    Ho, ao = orc.householder(orc.rand_matrix(m, n, 61))
+    scale = np.abs(Ho).max()
+    assert np.abs(A.cpu().numpy() - Ho).max() <= 1e-11 * scale
+    assert np.abs(alpha.cpu().numpy() - ao).max() <= 1e-11 * scale
+    b = orc.rand_vector(m, 62)
+    x = q.solve(torch.tensor(b, device="cuda:0")).cpu().numpy()
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
