@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import ctypes
 import math
-from typing import Optional
+
 
 import torch
 import torch.distributed as dist

@@ -2,7 +2,6 @@
 interface as the product's HipBackend, so ColumnCyclicQR's orchestration (ownership, local
 offsets, broadcast order, look-ahead, α gathering, residual and solve pipelines) runs on CPU.
 The product never imports this file."""
-import math
 import os
 import sys
 import traceback
