@@ -36,7 +36,10 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def pkg():
     import __graft_entry__ as g
-    return g.import_package()
+    p = g.import_package()
+    if not os.path.exists(p._lib.SO_PATH):  # normally prebuilt in-tree by __graft_entry__.build()
+        p.build()
+    return p
 
 
 @pytest.fixture(scope="session")
