@@ -1,0 +1,198 @@
+"""The WHOLE library (csrc/dhqr_api.hip + every kernel header, unmodified) compiled with the host clang++
+against tests/simt/fake/hip/hip_runtime.h (fiber mode) and driven through the real C ABI on the CPU.
+
+What this covers that the per-kernel emulation tests do not: the HOST logic -- unblocked / blocked /
+look-ahead / two-panel drivers, panel dispatch (R-first fast path, CholeskyQR2 retry, column-by-column
+fallback, partial last panel), workspace management, solve / apply-Q / residual pipelines, the ComplexF64
+entry points, argument validation -- on tiny problems, against the oracle.  "Device" pointers are numpy
+buffers (hipMalloc is malloc in the emulated runtime).  TEST INFRASTRUCTURE ONLY: the emulated library is
+built into a temporary directory, the product package cannot load it and never falls back to it.
+"""
+import ctypes
+import importlib.util
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIMT = os.path.join(ROOT, "tests", "simt")
+CSRC = os.path.join(ROOT, "distributedhouseholderqr.jl_amd", "csrc")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="host clang++ (ROCm llvm) not found")
+P = ctypes.c_void_p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(P)
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("emu") / "libdhqr_emulated.so")
+    subprocess.check_call([CLANG, "-x", "c++", "-std=c++20", "-O2", "-DSIMT_FIBERS", "-fPIC", "-shared",
+                           "-Wno-unknown-attributes", "-Wno-psabi", "-Wno-unused-value",
+                           "-I", os.path.join(SIMT, "fake"), os.path.join(CSRC, "dhqr_api.hip"), "-o", so])
+    spec = importlib.util.spec_from_file_location(
+        "dhqr_lib_signatures", os.path.join(ROOT, "distributedhouseholderqr.jl_amd", "_lib.py"))
+    sig = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sig)
+    L = ctypes.CDLL(so)
+    for name, (res, args) in sig.SIGNATURES.items():  # same prototypes as the product binding
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    L.Stats = sig.Stats
+    return L
+
+
+def _ctx(L, **env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        h = P()
+        assert L.dhqr_create(ctypes.byref(h), 0) == 0, L.dhqr_last_error()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return h
+
+
+def _counters(L, h):
+    a, b = ctypes.c_int64(), ctypes.c_int64()
+    assert L.dhqr_get_panel_counters(h, ctypes.byref(a), ctypes.byref(b)) == 0
+    return a.value, b.value
+
+
+def _factor(L, h, A0, nb):
+    m, n = A0.shape
+    A = A0.copy(order="F")
+    al = np.zeros(n)
+    rc = L.dhqr_factor_f64(h, _ptr(A), m, n, m, _ptr(al), nb)
+    assert rc == 0, L.dhqr_last_error()
+    return A, al
+
+
+def _check(orc, A0, A, al, tol=1e-12):
+    Ho, ao = orc.householder(A0)
+    scale = np.abs(Ho).max()
+    assert np.abs(A - Ho).max() <= tol * scale
+    assert np.abs(al - ao).max() <= tol * scale
+    return Ho, ao
+
+
+# shapes: unblocked (fused register kernels); blocked with a partial last panel (robust column kernels for
+# the 2-column panel); K = 2 (no look-ahead); K = 4 look-ahead driver
+@pytest.mark.parametrize("m,n,nb", [(60, 20, 0), (201, 33, 0), (200, 130, 128), (300, 256, 128), (700, 512, 128)])
+def test_factor_drivers_vs_oracle(emu, orc, m, n, nb):
+    h = _ctx(emu)
+    A0 = orc.rand_matrix(m, n, 3)
+    A, al = _factor(emu, h, A0, nb)
+    _check(orc, A0, A, al)
+    if nb == 128:
+        fast, fb = _counters(emu, h)
+        # the R-first path takes full 128-column panels with at least 256 rows; none had to be redone
+        assert fast == sum(1 for k in range(n // 128) if m - 128 * k >= 256) and fb == 0
+    assert emu.dhqr_destroy(h) == 0
+
+
+def test_two_panel_driver_and_next_kernel_generation(emu, orc):
+    """factor_blocked_pair (K = 256 wide updates) engages for n >= DHQR_PAIR_MIN_N; DHQR_SMALLK=4 selects the
+    one-barrier-per-step panel kernels -- same factorisation, every panel on the fast path"""
+    A0 = orc.rand_matrix(640, 512, 4)
+    for env in ({"DHQR_PAIR_MIN_N": 512}, {"DHQR_PAIR_MIN_N": 512, "DHQR_SMALLK": 4}, {"DHQR_LOOKAHEAD": 0}):
+        h = _ctx(emu, **env)
+        A, al = _factor(emu, h, A0, 128)
+        _check(orc, A0, A, al)
+        assert _counters(emu, h) == (4, 0)
+        emu.dhqr_destroy(h)
+
+
+def test_ill_conditioned_panel_falls_back_and_stays_stable(emu, orc):
+    """two nearly dependent columns inside panel 1: the fast path must refuse the panel (||v||^2 check, before
+    anything is written), the column-by-column kernels redo it, the result is backward stable"""
+    h = _ctx(emu)
+    m, n = 600, 384
+    A0 = orc.rand_matrix(m, n, 22)
+    A0[:, 200] = A0[:, 199] * (1.0 + 1e-9)
+    A, al = _factor(emu, h, A0, 128)
+    fast, fb = _counters(emu, h)
+    assert fb >= 1 and fast + fb >= 3
+    QR = orc.form_qr(np.asfortranarray(A), al)
+    assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-13
+    emu.dhqr_destroy(h)
+
+
+def test_solve_apply_q_and_residual_entry_points(emu, orc):
+    h = _ctx(emu)
+    m, n = 300, 200
+    A0 = orc.rand_matrix(m, n, 5)
+    A, al = _factor(emu, h, A0, 128)
+    Ho, ao = orc.householder(A0)
+    # solve_householder!(b, H, alpha): b is overwritten, x = b[0:n]
+    b = orc.rand_vector(m, 6)
+    bb = b.copy()
+    assert emu.dhqr_solve_f64(h, _ptr(A), m, n, m, _ptr(al), _ptr(bb)) == 0, emu.dhqr_last_error()
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(bb[:n] - xo).max() <= 1e-10 * np.abs(xo).max()
+    # host drop-in `H \\ b` must not touch b
+    x = np.zeros(n)
+    b2 = b.copy()
+    assert emu.dhqr_ldiv_f64(h, _ptr(A), m, n, m, _ptr(al), _ptr(b2), _ptr(x)) == 0
+    assert np.array_equal(b2, b) and np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    # ||A - QR|| / ||A|| and Q'(Q B) == B
+    work = np.zeros((m, n), order="F")
+    rel = ctypes.c_double()
+    assert emu.dhqr_residual_f64(h, _ptr(A), m, n, m, _ptr(al), _ptr(np.asfortranarray(A0)), m, _ptr(work),
+                                 ctypes.byref(rel)) == 0
+    assert rel.value < 1e-14
+    B0 = orc.rand_matrix(m, 3, 7)
+    B = B0.copy(order="F")
+    assert emu.dhqr_apply_q_f64(h, _ptr(A), m, n, m, _ptr(B), 3, m, 0) == 0
+    assert emu.dhqr_apply_q_f64(h, _ptr(A), m, n, m, _ptr(B), 3, m, 1) == 0
+    assert np.abs(B - B0).max() < 1e-13
+    # host-in / host-out qr!(A)
+    A2 = A0.copy(order="F")
+    al2 = np.zeros(n)
+    assert emu.dhqr_qr_f64(h, _ptr(A2), m, n, m, _ptr(al2), 0) == 0
+    _check(orc, A0, A2, al2)
+    emu.dhqr_destroy(h)
+
+
+def test_complex_entry_points(emu, orc):
+    h = _ctx(emu)
+    m, n = 150, 90
+    A0 = orc.rand_matrix_c(m, n, 8)
+    A = A0.copy(order="F")
+    al = np.zeros(n, dtype=complex)
+    assert emu.dhqr_factor_c64(h, _ptr(A), m, n, m, _ptr(al)) == 0, emu.dhqr_last_error()
+    Ho, ao = orc.householder_c(A0)
+    assert np.abs(A - Ho).max() <= 1e-12 * np.abs(Ho).max() and np.abs(al - ao).max() <= 1e-12 * np.abs(Ho).max()
+    b = orc.rand_vector_c(m, 9)
+    bb = b.copy()
+    assert emu.dhqr_solve_c64(h, _ptr(A), m, n, m, _ptr(al), _ptr(bb)) == 0
+    xo = orc.solve_c(Ho, ao, b)
+    assert np.abs(bb[:n] - xo).max() <= 1e-10 * np.abs(xo).max()
+    out = (ctypes.c_double * 2)()
+    assert emu.dhqr_partialdot_c64(h, _ptr(A0[:, 0].copy()), _ptr(A0[:, 1].copy()), 7, m, out) == 0
+    assert complex(out[0], out[1]) == pytest.approx(np.vdot(A0[7:, 0], A0[7:, 1]), rel=1e-13)
+    emu.dhqr_destroy(h)
+
+
+def test_argument_validation_and_empty_matrix(emu):
+    h = _ctx(emu)
+    A = np.zeros((4, 8), order="F")
+    al = np.zeros(8)
+    assert emu.dhqr_factor_f64(h, _ptr(A), 4, 8, 4, _ptr(al), 128) == -1          # m < n
+    assert b"m >= n" in emu.dhqr_last_error()
+    assert emu.dhqr_factor_f64(h, _ptr(A), 8, 4, 4, _ptr(al), 128) == -1          # lda < m
+    assert emu.dhqr_factor_f64(h, _ptr(A), 8, 4, 8, _ptr(al), 64) == -1           # nb not in {0, 128}
+    assert emu.dhqr_factor_f64(h, None, 8, 4, 8, _ptr(al), 0) == -1               # null matrix
+    assert emu.dhqr_factor_f64(h, _ptr(A), 8, 0, 8, None, 0) == 0                 # no columns: no-op (src:127)
+    assert emu.dhqr_solve_f64(h, _ptr(A), 8, 0, 8, None, None) == 0
+    assert emu.dhqr_factor_f64(None, _ptr(A), 8, 4, 8, _ptr(al), 0) == -1         # null context
+    emu.dhqr_destroy(h)
