@@ -157,6 +157,87 @@ def _entry(fn, rank, world_size, port, q, args):
         q.put((rank, traceback.format_exc(), None))
 
 
+# ---------------------------------------------------------------------------------------------------
+# The product's HipBackend driven by the EMULATED library (tests/simt: the unmodified csrc/ compiled for
+# the CPU): the same marshalling code, the same C entry points, CPU tensors instead of device tensors.
+# Lets the world_size-2/3 gloo tests run the real panel_factor / panel_apply / form_r0 / backsub kernels.
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def build_emulated_library(outdir):
+    """host-compile csrc/dhqr_api.hip against tests/simt/fake (fiber mode) -> path of the .so"""
+    import subprocess
+    so = os.path.join(str(outdir), "libdhqr_emulated.so")
+    subprocess.check_call([CLANG, "-x", "c++", "-std=c++20", "-O2", "-DSIMT_FIBERS", "-fPIC", "-shared",
+                           "-Wno-unknown-attributes", "-Wno-psabi", "-Wno-unused-value",
+                           "-I", os.path.join(ROOT, "tests", "simt", "fake"),
+                           os.path.join(ROOT, "distributedhouseholderqr.jl_amd", "csrc", "dhqr_api.hip"), "-o", so])
+    return so
+
+
+def load_emulated_library(so):
+    import ctypes
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "dhqr_lib_signatures", os.path.join(ROOT, "distributedhouseholderqr.jl_amd", "_lib.py"))
+    sig = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sig)
+    L = ctypes.CDLL(so)
+    for name, (res, args) in sig.SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    return L
+
+
+def make_emu_backend(so):
+    """HipBackend subclass bound to the emulated library (no streams, no look-ahead lane, CPU tensors)"""
+    import contextlib
+    import ctypes
+    import __graft_entry__ as g
+    g.import_package()
+    import importlib
+    HipBackend = importlib.import_module("dhqr_amd.distributed").HipBackend
+
+    class _Ctx:
+        def __init__(self, L):
+            self.handle = ctypes.c_void_p()
+            assert L.dhqr_create(ctypes.byref(self.handle), 0) == 0
+
+        def use_torch_stream(self):
+            pass
+
+    class EmuBackend(HipBackend):
+        def __init__(self):  # deliberately not calling HipBackend.__init__ (it needs a GPU)
+            self.L = load_emulated_library(so)
+            self.ctx = self._lane = _Ctx(self.L)
+            self.device = None
+            self.torch_device = torch.device("cpu")
+
+        # single lane, nothing asynchronous
+        def lane(self, hi):
+            return contextlib.nullcontext()
+
+        def record_main(self):
+            return None
+
+        def hi_wait(self, ev):
+            pass
+
+        def main_wait_hi(self):
+            pass
+
+        def record_current(self):
+            return None
+
+        def wait_event(self, ev):
+            pass
+
+        def synchronize(self):
+            pass
+
+    return EmuBackend()
+
+
 class NumpyRowBackend:
     """Test-only numpy stand-in for the product's HipRowBackend (rowsplit.py): same call interface on
     CPU torch tensors, so RowSplitQR's orchestration (active-row bookkeeping, all-reduce / broadcast

@@ -3,7 +3,13 @@
     512 x 512, nprocs = 2) equals the single-process oracle;
  2. the product's ColumnCyclicQR orchestration (block-cyclic split, one panel broadcast per
     block, look-ahead, α replication, residual and solve pipelines) with an oracle-backed CPU
-    backend injected by the test equals the single-process oracle."""
+    backend injected by the test equals the single-process oracle;
+ 3. the same orchestration with the product's HipBackend marshalling bound to the EMULATED library
+    (tests/simt: csrc/ compiled for the CPU), i.e. the real panel / apply / residual / solve entry
+    points and kernels at world size 2 and 3 -- everything of the multi-GPU data path except RCCL
+    and HIP streams."""
+import os
+
 import numpy as np
 import pytest
 
@@ -113,6 +119,42 @@ def test_darray_front_end_single_rank():
     Ho, ao = orc.householder(A)
     assert np.abs(local.numpy() - Ho).max() <= 1e-11 * np.abs(Ho).max()
     assert np.abs(alpha.numpy() - ao).max() <= 1e-11 * np.abs(Ho).max()
+
+
+def _cyclic_emulated(rank, P, m, n, so):
+    """ColumnCyclicQR with the product's HipBackend marshalling bound to the EMULATED library: the real
+    dhqr_panel_factor / _pack / _apply / form_r0 / diff_norms / backsub_block / fill entry points and kernels
+    under the real orchestration, world size P, gloo"""
+    import torch
+    import __graft_entry__ as g
+    from oracle import dhqr_oracle as orc
+    from dist_helpers import make_emu_backend
+    pkg = g.import_package()
+    q = pkg.ColumnCyclicQR(m, n, backend=make_emu_backend(so))
+    q.fill(71)
+    H0, _ = q.gather_full()
+    A = orc.rand_matrix(m, n, 71)
+    assert np.array_equal(H0, A)  # the device generator with the block-cyclic column map
+    q.factor()
+    H, alpha = q.gather_full()
+    Ho, ao = orc.householder(A)
+    scale = np.abs(Ho).max()
+    assert np.abs(H - Ho).max() <= 1e-11 * scale
+    assert np.abs(alpha - ao).max() <= 1e-11 * scale
+    assert q.residual(71) < 1e-13
+    b = orc.rand_vector(m, 72)
+    x = q.solve(torch.from_numpy(b.copy())).numpy()
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    return True
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="host clang++ (ROCm llvm) not found")
+@pytest.mark.parametrize("m,n,P", [(520, 384, 2), (450, 300, 3)])
+def test_column_cyclic_with_the_emulated_library(tmp_path, m, n, P):
+    from dist_helpers import build_emulated_library
+    so = build_emulated_library(tmp_path)
+    run_ranks(_cyclic_emulated, P, m, n, so)
 
 
 def test_single_rank_without_process_group():

@@ -9,16 +9,12 @@ buffers (hipMalloc is malloc in the emulated runtime).  TEST INFRASTRUCTURE ONLY
 built into a temporary directory, the product package cannot load it and never falls back to it.
 """
 import ctypes
-import importlib.util
 import os
-import subprocess
 
 import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SIMT = os.path.join(ROOT, "tests", "simt")
-CSRC = os.path.join(ROOT, "distributedhouseholderqr.jl_amd", "csrc")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="host clang++ (ROCm llvm) not found")
@@ -31,20 +27,8 @@ def _ptr(a):
 
 @pytest.fixture(scope="module")
 def emu(tmp_path_factory):
-    so = str(tmp_path_factory.mktemp("emu") / "libdhqr_emulated.so")
-    subprocess.check_call([CLANG, "-x", "c++", "-std=c++20", "-O2", "-DSIMT_FIBERS", "-fPIC", "-shared",
-                           "-Wno-unknown-attributes", "-Wno-psabi", "-Wno-unused-value",
-                           "-I", os.path.join(SIMT, "fake"), os.path.join(CSRC, "dhqr_api.hip"), "-o", so])
-    spec = importlib.util.spec_from_file_location(
-        "dhqr_lib_signatures", os.path.join(ROOT, "distributedhouseholderqr.jl_amd", "_lib.py"))
-    sig = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(sig)
-    L = ctypes.CDLL(so)
-    for name, (res, args) in sig.SIGNATURES.items():  # same prototypes as the product binding
-        fn = getattr(L, name)
-        fn.restype, fn.argtypes = res, args
-    L.Stats = sig.Stats
-    return L
+    from dist_helpers import build_emulated_library, load_emulated_library
+    return load_emulated_library(build_emulated_library(tmp_path_factory.mktemp("emu")))  # product prototypes
 
 
 def _ctx(L, **env):
