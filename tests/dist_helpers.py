@@ -238,6 +238,32 @@ def make_emu_backend(so):
     return EmuBackend()
 
 
+def make_emu_row_backend(so):
+    """the product's HipRowBackend (rowsplit.py, dhqr_rs_* entry points) bound to the emulated library"""
+    import ctypes
+    import importlib
+    import __graft_entry__ as g
+    g.import_package()
+    HipRowBackend = importlib.import_module("dhqr_amd.rowsplit").HipRowBackend
+
+    class _Ctx:
+        def __init__(self, L):
+            self.handle = ctypes.c_void_p()
+            assert L.dhqr_create(ctypes.byref(self.handle), 0) == 0
+
+        def use_torch_stream(self):
+            pass
+
+    class EmuRowBackend(HipRowBackend):
+        def __init__(self):  # not calling HipRowBackend.__init__ (it needs a GPU)
+            self.L = load_emulated_library(so)
+            self.ctx = _Ctx(self.L)
+            self.device = None
+            self.tdev = torch.device("cpu")
+
+    return EmuRowBackend()
+
+
 class NumpyRowBackend:
     """Test-only numpy stand-in for the product's HipRowBackend (rowsplit.py): same call interface on
     CPU torch tensors, so RowSplitQR's orchestration (active-row bookkeeping, all-reduce / broadcast

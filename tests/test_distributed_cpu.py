@@ -157,6 +157,40 @@ def test_column_cyclic_with_the_emulated_library(tmp_path, m, n, P):
     run_ranks(_cyclic_emulated, P, m, n, so)
 
 
+def _rowsplit_emulated(rank, P, m, n, so):
+    """RowSplitQR with the product's HipRowBackend marshalling and the dhqr_rs_* entry points of the emulated
+    library: Gram / Cholesky / replay / commit / V'C kernels under the real all-reduce orchestration"""
+    import importlib
+    import torch
+    import __graft_entry__ as g
+    from oracle import dhqr_oracle as orc
+    from dist_helpers import make_emu_row_backend
+    g.import_package()
+    rs = importlib.import_module("dhqr_amd.rowsplit")
+    q = rs.RowSplitQR(m, n, backend=make_emu_row_backend(so))
+    q.fill(81)
+    q.factor()
+    H, alpha = q.gather_full()
+    Ho, ao = orc.householder(orc.rand_matrix(m, n, 81))
+    scale = np.abs(Ho).max()
+    assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
+    assert np.abs(alpha - ao).max() <= 1e-11 * scale
+    assert q.residual(81) < 1e-13
+    b = orc.rand_vector(m, 82)
+    x = q.solve(torch.from_numpy(b[q.row0: q.row0 + q.mloc].copy())).numpy()
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    return True
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="host clang++ (ROCm llvm) not found")
+@pytest.mark.parametrize("m,n,P", [(1200, 256, 2), (1300, 384, 3)])
+def test_row_split_with_the_emulated_library(tmp_path, m, n, P):
+    from dist_helpers import build_emulated_library
+    so = build_emulated_library(tmp_path)
+    run_ranks(_rowsplit_emulated, P, m, n, so)
+
+
 def test_single_rank_without_process_group():
     import __graft_entry__ as g
     from oracle import dhqr_oracle as orc
