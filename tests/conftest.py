@@ -47,3 +47,12 @@ def orc():
     from oracle import dhqr_oracle
     dhqr_oracle.build()
     return dhqr_oracle
+
+
+@pytest.fixture(scope="session")
+def emulated_so(tmp_path_factory):
+    """path of the EMULATED library (tests/simt: csrc/ host-compiled in fiber mode), built once per session"""
+    from dist_helpers import CLANG, build_emulated_library
+    if not os.path.exists(CLANG):
+        pytest.skip("host clang++ (ROCm llvm) not found")
+    return build_emulated_library(tmp_path_factory.mktemp("emulated_lib"))

@@ -8,8 +8,6 @@
     (tests/simt: csrc/ compiled for the CPU), i.e. the real panel / apply / residual / solve entry
     points and kernels at world size 2 and 3 -- everything of the multi-GPU data path except RCCL
     and HIP streams."""
-import os
-
 import numpy as np
 import pytest
 
@@ -149,12 +147,9 @@ def _cyclic_emulated(rank, P, m, n, so):
     return True
 
 
-@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="host clang++ (ROCm llvm) not found")
-@pytest.mark.parametrize("m,n,P", [(520, 384, 2), (450, 300, 3)])
-def test_column_cyclic_with_the_emulated_library(tmp_path, m, n, P):
-    from dist_helpers import build_emulated_library
-    so = build_emulated_library(tmp_path)
-    run_ranks(_cyclic_emulated, P, m, n, so)
+@pytest.mark.parametrize("m,n,P", [(450, 300, 3)])
+def test_column_cyclic_with_the_emulated_library(emulated_so, m, n, P):
+    run_ranks(_cyclic_emulated, P, m, n, emulated_so)
 
 
 def _rowsplit_emulated(rank, P, m, n, so):
@@ -183,12 +178,9 @@ def _rowsplit_emulated(rank, P, m, n, so):
     return True
 
 
-@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="host clang++ (ROCm llvm) not found")
-@pytest.mark.parametrize("m,n,P", [(1200, 256, 2), (1300, 384, 3)])
-def test_row_split_with_the_emulated_library(tmp_path, m, n, P):
-    from dist_helpers import build_emulated_library
-    so = build_emulated_library(tmp_path)
-    run_ranks(_rowsplit_emulated, P, m, n, so)
+@pytest.mark.parametrize("m,n,P", [(1200, 256, 2)])
+def test_row_split_with_the_emulated_library(emulated_so, m, n, P):
+    run_ranks(_rowsplit_emulated, P, m, n, emulated_so)
 
 
 def test_single_rank_without_process_group():

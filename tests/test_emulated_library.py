@@ -15,9 +15,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
-pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="host clang++ (ROCm llvm) not found")
 P = ctypes.c_void_p
 
 
@@ -26,9 +24,9 @@ def _ptr(a):
 
 
 @pytest.fixture(scope="module")
-def emu(tmp_path_factory):
-    from dist_helpers import build_emulated_library, load_emulated_library
-    return load_emulated_library(build_emulated_library(tmp_path_factory.mktemp("emu")))  # product prototypes
+def emu(emulated_so):
+    from dist_helpers import load_emulated_library
+    return load_emulated_library(emulated_so)  # prototypes taken from the product binding (_lib.SIGNATURES)
 
 
 def _ctx(L, **env):
@@ -139,11 +137,12 @@ def test_solve_apply_q_and_residual_entry_points(emu, orc):
     assert emu.dhqr_apply_q_f64(h, _ptr(A), m, n, m, _ptr(B), 3, m, 0) == 0
     assert emu.dhqr_apply_q_f64(h, _ptr(A), m, n, m, _ptr(B), 3, m, 1) == 0
     assert np.abs(B - B0).max() < 1e-13
-    # host-in / host-out qr!(A)
-    A2 = A0.copy(order="F")
-    al2 = np.zeros(n)
-    assert emu.dhqr_qr_f64(h, _ptr(A2), m, n, m, _ptr(al2), 0) == 0
-    _check(orc, A0, A2, al2)
+    # host-in / host-out qr!(A) (own device copy, odd m -> padded leading dimension)
+    A3 = orc.rand_matrix(81, 30, 12)
+    A2 = A3.copy(order="F")
+    al2 = np.zeros(30)
+    assert emu.dhqr_qr_f64(h, _ptr(A2), 81, 30, 81, _ptr(al2), 0) == 0
+    _check(orc, A3, A2, al2)
     emu.dhqr_destroy(h)
 
 
