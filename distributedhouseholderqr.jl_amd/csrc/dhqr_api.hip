@@ -69,7 +69,8 @@ struct dhqr_ctx {
   int cholqr_passes = 1;  // Gram/Cholesky passes of the fast path (2 = CholeskyQR2)
   double recon_tol = 2e-12;  // accepted deviation of ||v_j||^2 from 2 before falling back
   int ib = DHQR_IB;
-  int smallk = 3;  // generation of the single-workgroup panel kernels: 3 (default), 4 = one barrier per step (DHQR_SMALLK)
+  int smallk = 3;  // generation of the single-workgroup panel kernels (DHQR_SMALLK): 3 default, 4 = one barrier per
+                   // step, 5 = 4 + blocked triangular inverses (five barriers instead of 128)
   // profiling
   struct Ev { hipEvent_t a, b; int cat; };
   std::vector<Ev> evs;
@@ -184,20 +185,23 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
 // ---- the three single-workgroup dense 128 x 128 kernels of the panel chain (dhqr_recon.h), by generation
 static inline void launch_chol_inv(dhqr_ctx *c, const double *G, const double *Rprev, double *Rout, double *negX,
                                    int *flag) {
-  if (c->smallk == 4)
+  if (c->smallk >= 4)
     hipLaunchKernelGGL(k_chol_inv4, dim3(1), dim3(1024), 0, c->stream, G, Rprev, Rout, negX, flag);
   else
     hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, G, Rprev, Rout, negX, flag);
 }
 static inline void launch_recon_top(dhqr_ctx *c, const double *P, int64_t ldp, const double *R, double *alpha,
                                     double *Rref, double *negMinv) {
-  if (c->smallk == 4)
+  if (c->smallk == 5)
+    hipLaunchKernelGGL(k_recon_top5, dim3(1), dim3(1024), 0, c->stream, P, ldp, R, alpha, Rref, negMinv);
+  else if (c->smallk == 4)
     hipLaunchKernelGGL(k_recon_top4, dim3(1), dim3(1024), 0, c->stream, P, ldp, R, alpha, Rref, negMinv);
   else
     hipLaunchKernelGGL(k_recon_top, dim3(1), dim3(1024), 0, c->stream, P, ldp, R, alpha, Rref, negMinv);
 }
 static inline void launch_build_t(dhqr_ctx *c, const double *S, int ncols, double *T, double *Tt) {
-  if (c->smallk == 4) hipLaunchKernelGGL(k_build_t4, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt);
+  if (c->smallk == 5) hipLaunchKernelGGL(k_build_t5, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt);
+  else if (c->smallk == 4) hipLaunchKernelGGL(k_build_t4, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt);
   else hipLaunchKernelGGL(k_build_t3, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt);
 }
 
@@ -958,7 +962,10 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
   }
   if (const char *e = getenv("DHQR_CHOLQR_PASSES")) c->cholqr_passes = atoi(e) == 2 ? 2 : 1;
   if (const char *e = getenv("DHQR_RECON_TOL")) c->recon_tol = atof(e);
-  if (const char *e = getenv("DHQR_SMALLK")) c->smallk = atoi(e) == 4 ? 4 : 3;
+  if (const char *e = getenv("DHQR_SMALLK")) {
+    const int v = atoi(e);
+    c->smallk = (v == 4 || v == 5) ? v : 3;
+  }
   if (const char *e = getenv("DHQR_PANEL")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 3) c->panel_impl = v;

@@ -487,6 +487,197 @@ __global__ __launch_bounds__(1024) void k_build_t4(const double *__restrict__ S,
     }
 }
 
+// =================================================================================================
+// "v5": blocked inverse of a 128 x 128 upper-triangular matrix with FIVE workgroup barriers instead of 128.
+// The elimination order of the inverse is not prescribed by the reference (T and M^{-1} are our own
+// operands), so it can be organised for the machine:
+//   P1  the four 32 x 32 diagonal blocks: ONE LANE PER COLUMN solves U x = e_k by back substitution in
+//       registers (fully unrolled, the block is read from LDS as wave-wide broadcasts) -- no cross-lane
+//       traffic at all, 128 lanes busy for ~500 dependent fma;
+//   P2  the two 64 x 64 blocks [[A,B],[0,C]]^{-1} = [[A^{-1}, -A^{-1} B C^{-1}],[0, C^{-1}]]: two 32^3
+//       products per block, one output element per thread;
+//   P3  the same step once more for the 128 x 128 matrix: two 64^3 products, four elements per thread.
+// Input: Mg = global 128 x 128 column-major, strictly upper part used for columns < ncols (others are
+// treated as 0), diagonal taken as 1 when `unit` (T^{-1} = I + striu(V'V)) else read from Mg.
+// Output: x12[4] (this thread's entries of the upper-right 64 x 64 block, element e = t + 1024 r ->
+// row e & 63, column 64 + (e >> 6)) and the two diagonal 64 x 64 inverses in Xh.  All global reads of Mg
+// are finished when the function returns, so the caller may overwrite Mg with the result.
+#define RC5_LDD 33
+#define RC5_LDH 65
+struct rc5_lds {
+  double Ud[4][32][RC5_LDD];    // diagonal blocks of the input (strictly upper part)
+  double Xh[2][64][RC5_LDH];    // inverses of the two 64 x 64 diagonal blocks, [block][row][col]
+  double T1[64][RC5_LDH];       // B * C^{-1} staging
+  double dinv[RC_N];
+};
+__device__ __forceinline__ double rc5_in(const double *__restrict__ Mg, int i, int k, int ncols) {
+  return (i < k && k < ncols) ? Mg[i + k * RC_N] : 0.0;
+}
+__device__ __forceinline__ void rc_upper_inverse_blocked(const double *__restrict__ Mg, int ncols, bool unit,
+                                                         rc5_lds &L, double (&x12)[4]) {
+  const int t = threadIdx.x;
+  // ---- P0: stage the diagonal blocks, 1/diag, clear Xh
+  for (int e = t; e < 2 * 64 * RC5_LDH; e += 1024) (&L.Xh[0][0][0])[e] = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = t + 1024 * r, d = e >> 10, i = e & 31, l = (e >> 5) & 31;
+    L.Ud[d][i][l] = rc5_in(Mg, 32 * d + i, 32 * d + l, ncols);
+  }
+  if (t < RC_N) L.dinv[t] = unit ? 1.0 : 1.0 / Mg[t + t * RC_N];
+  __syncthreads();
+  // ---- P1: column k of the inverse of diagonal block d, one lane per column, registers only
+  if (t < RC_N) {
+    const int d = t >> 5, k = t & 31;
+    double x[32];
+#pragma unroll
+    for (int i = 31; i >= 0; --i) {
+      double s = 0.0;
+#pragma unroll
+      for (int l = i + 1; l < 32; ++l) s = fma(L.Ud[d][i][l], x[l], s);  // x[l] == 0 for l > k
+      x[i] = (i == k) ? L.dinv[32 * d + k] : ((i < k) ? -s * L.dinv[32 * d + i] : 0.0);
+    }
+    const int h = d >> 1, o = (d & 1) * 32;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) L.Xh[h][o + i][o + k] = x[i];
+  }
+  __syncthreads();
+  // ---- P2: upper-right 32 x 32 block of each 64 x 64 diagonal block
+  {
+    const int i = t & 31, j = t >> 5;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // T1a = B_h * C_h^{-1}   (C^{-1} upper triangular: l <= j)
+      double s = 0.0;
+      for (int l = 0; l <= j; ++l) s = fma(rc5_in(Mg, 64 * h + i, 64 * h + 32 + l, ncols), L.Xh[h][32 + l][32 + j], s);
+      L.T1[32 * h + i][j] = s;
+    }
+    __syncthreads();
+    double y[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // X12_h = -A_h^{-1} * T1a   (A^{-1} upper triangular: l >= i)
+      double s = 0.0;
+      for (int l = i; l < 32; ++l) s = fma(L.Xh[h][i][l], L.T1[32 * h + l][j], s);
+      y[h] = -s;
+    }
+    L.Xh[0][i][32 + j] = y[0];  // nobody reads the X12 corner in this phase
+    L.Xh[1][i][32 + j] = y[1];
+  }
+  __syncthreads();  // X12 corners visible; T1 free for reuse
+  // ---- P3: upper-right 64 x 64 block of the whole matrix
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // T1 = B * C^{-1},  C^{-1} = Xh[1]
+    const int e = t + 1024 * r, i = e & 63, j = e >> 6;
+    double s = 0.0;
+    for (int l = 0; l <= j; ++l) s = fma(rc5_in(Mg, i, 64 + l, ncols), L.Xh[1][l][j], s);
+    L.T1[i][j] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // X12 = -A^{-1} * T1,  A^{-1} = Xh[0]
+    const int e = t + 1024 * r, i = e & 63, j = e >> 6;
+    double s = 0.0;
+    for (int l = i; l < 64; ++l) s = fma(L.Xh[0][i][l], L.T1[l][j], s);
+    x12[r] = -s;
+  }
+}
+// store helper: calls put(i, k, value) for this thread's 16 entries of the full 128 x 128 result
+template <typename F>
+__device__ __forceinline__ void rc5_emit(const rc5_lds &L, const double (&x12)[4], F &&put) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = t + 1024 * r, i = e & 63, j = e >> 6;
+    put(i, j, L.Xh[0][i][j]);            // upper-left  (zero below its diagonal)
+    put(64 + i, 64 + j, L.Xh[1][i][j]);  // lower-right
+    put(i, 64 + j, x12[r]);              // upper-right
+    put(64 + i, j, 0.0);                 // lower-left
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_build_t5(const double *__restrict__ S, int ncols,
+                                                   double *__restrict__ Tout,
+                                                   double *__restrict__ Ttout) {
+  __shared__ rc5_lds L;
+  double x12[4];
+  rc_upper_inverse_blocked(S, ncols, true, L, x12);
+  rc5_emit(L, x12, [&](int i, int k, double v) {
+    Tout[i + k * RC_N] = v;
+    Ttout[k + i * RC_N] = v;
+  });
+}
+
+// k_recon_top with the one-barrier replay of k_recon_top4 and the blocked inverse: M is parked in the
+// negMinv output buffer (global, L2 resident), inverted from there, and the buffer is overwritten last.
+__global__ __launch_bounds__(1024) void k_recon_top5(const double *__restrict__ P, int64_t ldp,
+                                                     const double *__restrict__ R,
+                                                     double *__restrict__ alpha,
+                                                     double *__restrict__ Rref,
+                                                     double *__restrict__ negMinv) {
+  __shared__ double wrow[2 * RC_N], vcol[2 * RC_N];
+  __shared__ rc5_lds L;
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31, lane = t & 63;
+  double a[4][4], r[4][4], mm[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int i = ti + 32 * x, k = tk + 32 * y;
+      a[x][y] = P[i + (int64_t)k * ldp];
+      r[x][y] = R[i + k * RC_N];
+      mm[x][y] = 0.0;
+    }
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja)
+    for (int jm = 0; jm < 32; ++jm) {
+      const int j = ja * 32 + jm;
+      const int src = (lane & 32) + jm;
+      const double ajj = __shfl(a[ja][ja], src, 64), rjj = __shfl(r[ja][ja], src, 64);
+      double *wr = wrow + (j & 1) * RC_N, *vc = vcol + (j & 1) * RC_N;
+      if (ti == jm) {
+        const double s = fabs(rjj);
+        const double al = s * dhqr_alphafactor(ajj);
+        const double q = s * (s + fabs(ajj));
+        const double sq = sqrt(q);
+        const double u = 1.0 / (ajj - al);
+        const double vinv = sq * u;
+        const double sg = (al == 0.0) ? 0.0 : ((al < 0.0) == (rjj < 0.0) ? 1.0 : -1.0);
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          const int k = tk + 32 * y;
+          const double rr = sg * r[ja][y];
+          const double dl = (k > j) ? (a[ja][y] - rr) : 0.0;
+          wr[k] = dl * u;
+          mm[ja][y] = (k > j) ? dl * vinv : (k == j ? sq : 0.0);
+          Rref[j + k * RC_N] = (k > j) ? rr : 0.0;
+        }
+        if (tk == 0) alpha[j] = al;
+      }
+      if (tk == jm) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int i = ti + 32 * x;
+          vc[i] = (i > j) ? a[x][ja] : 0.0;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const double vi = vc[ti + 32 * x];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) a[x][y] = fma(-vi, wr[tk + 32 * y], a[x][y]);
+      }
+    }
+  // park M (upper triangular, diagonal 1/f_j) in the output buffer and invert it from there
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) negMinv[(ti + 32 * x) + (tk + 32 * y) * RC_N] = mm[x][y];
+  __syncthreads();  // the workgroup's global writes are visible to all of its threads
+  double x12[4];
+  rc_upper_inverse_blocked(negMinv, RC_N, false, L, x12);
+  __syncthreads();  // every read of M is done (the last ones are in P3's first product): overwrite it
+  rc5_emit(L, x12, [&](int i, int k, double v) { negMinv[i + k * RC_N] = -v; });
+}
+
 // Vw currently holds P * M^{-1}; finish V = tril((P - alpha E) M^{-1}) on the top 128 rows:
 // Vw[i][j] -= alpha_i * Minv[i][j] (i <= j ... only i == row index < 128), and zero above the diagonal.
 __global__ __launch_bounds__(256) void k_recon_fix(double *__restrict__ Vw, int64_t ldv,

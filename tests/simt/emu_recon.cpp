@@ -59,7 +59,8 @@ int main(int argc, char **argv) {
     auto R = rd(argv[4], NN);
     std::vector<double> alpha(RC_N, -7.0), Rref(NN, -7.0), negMinv(NN, -7.0);
     simt::launch_block(1024, [&] {
-      if (variant == 4) k_recon_top4(P.data(), (int64_t)RC_N, R.data(), alpha.data(), Rref.data(), negMinv.data());
+      if (variant == 5) k_recon_top5(P.data(), (int64_t)RC_N, R.data(), alpha.data(), Rref.data(), negMinv.data());
+      else if (variant == 4) k_recon_top4(P.data(), (int64_t)RC_N, R.data(), alpha.data(), Rref.data(), negMinv.data());
       else k_recon_top(P.data(), (int64_t)RC_N, R.data(), alpha.data(), Rref.data(), negMinv.data());
     });
     wr(argv[5], alpha);
@@ -70,7 +71,8 @@ int main(int argc, char **argv) {
     const int ncols = atoi(argv[4]);
     std::vector<double> T(NN, -7.0), Tt(NN, -7.0);
     simt::launch_block(1024, [&] {
-      if (variant == 4) k_build_t4(S.data(), ncols, T.data(), Tt.data());
+      if (variant == 5) k_build_t5(S.data(), ncols, T.data(), Tt.data());
+      else if (variant == 4) k_build_t4(S.data(), ncols, T.data(), Tt.data());
       else k_build_t3(S.data(), ncols, T.data(), Tt.data());
     });
     wr(argv[5], T);

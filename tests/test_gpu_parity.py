@@ -336,12 +336,14 @@ def test_explicit_q_and_r(pkg, m, n):
     assert ((Q @ R - A0).norm() / A0.norm()).item() < 1e-12
 
 
-def test_smallk4_panel_kernels_match_oracle(pkg, orc, monkeypatch):
-    """The v4 generation of k_chol_inv / k_recon_top / k_build_t must give the same factorisation with
+@pytest.mark.parametrize("gen", [4, pytest.param(5, marks=pytest.mark.xfail(
+    strict=False, reason="DHQR_SMALLK=5 is verified on the CPU SIMT emulator only; this is its first hardware run"))])
+def test_smallk4_panel_kernels_match_oracle(pkg, orc, monkeypatch, gen):
+    """The next generations of k_chol_inv / k_recon_top / k_build_t must give the same factorisation with
     every panel on the fast path (a silent fallback to the step kernels would hide a broken kernel)."""
     import ctypes
     import torch
-    monkeypatch.setenv("DHQR_SMALLK", "4")
+    monkeypatch.setenv("DHQR_SMALLK", str(gen))
     ctx = pkg.Context(0)  # the switch is read when the context is created
     try:
         for (m, n) in [(1536, 1024), (700, 384)]:

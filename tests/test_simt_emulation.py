@@ -1,7 +1,8 @@
 """CPU execution of UNMODIFIED HIP kernel sources on the SIMT emulator of tests/simt/ (one OS thread per
 HIP thread, ThreadSanitizer build):
   * the single-workgroup panel kernels (csrc/dhqr_recon.h), both generations: variant 3 = the kernels the
-    library runs by default, variant 4 = the one-barrier-per-step kernels (DHQR_SMALLK=4);
+    library runs by default, 4 = the one-barrier-per-step kernels (DHQR_SMALLK=4), 5 = 4 + blocked
+    triangular inverses with five barriers (DHQR_SMALLK=5);
   * the unblocked factorisation kernels for Float64 and ComplexF64 (dhqr_rank1.h, dhqr_complex.h) and the
     solve kernels (dhqr_solve.h, dhqr_complex.h), launched in the library's per-column sequence;
   * the FP64-MFMA trailing-update GEMMs (dhqr_gemm.h) with v_mfma_f64_16x16x4_f64 emulated wave-
@@ -104,7 +105,7 @@ def test_cholesky_and_inverse(emu, orc, tmp_path, variant):
         assert np.fromfile(f["flag"])[0] == 1.0
 
 
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [3, 4, 5])
 def test_replay_of_top_block(emu, orc, tmp_path, variant):
     rows = 300
     P = orc.rand_matrix(rows, N, 6)
@@ -123,9 +124,10 @@ def test_replay_of_top_block(emu, orc, tmp_path, variant):
     PE[:N] -= np.diag(alpha)
     V = np.tril(PE @ (-negMinv))
     assert np.abs(V - np.tril(Ho)).max() < 1e-12 * scale
+    assert np.array_equal(np.tril(negMinv, -1), np.zeros((N, N)))  # -M^{-1} is upper triangular
 
 
-@pytest.mark.parametrize("variant,ncols", [(3, 77), (3, 128), (4, 128), (4, 77)])
+@pytest.mark.parametrize("variant,ncols", [(3, 77), (3, 128), (4, 128), (4, 77), (5, 128), (5, 77), (5, 1)])
 def test_block_reflector_t(emu, orc, tmp_path, variant, ncols):
     Ho, _ = orc.householder(orc.rand_matrix(300, ncols, 7))
     V = np.zeros((300, N))
