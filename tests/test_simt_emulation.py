@@ -248,3 +248,29 @@ def test_gemm_nn_sub(emu_gemm, tmp_path, vec, kw, rows, ncols, swz):
     ref = C.copy()
     ref[:rows] -= V[:rows] @ W
     assert np.abs(Co - ref).max() < 1e-12   # the padding rows of C keep their value
+
+
+# ------------------------------------------------------------------ memory safety of the new generations
+def test_new_panel_kernels_under_address_sanitizer(orc, tmp_path):
+    """the DHQR_SMALLK=4/5 kernels once more in an AddressSanitizer build of the emulator: no access outside
+    the LDS arrays (static globals with red zones) or the global buffers (heap allocations)"""
+    exe = str(tmp_path / "emu_recon_asan")
+    subprocess.check_call([CLANG, "-std=c++20", "-O1", "-g", "-fsanitize=address", "-Wno-unknown-attributes",
+                           "-I", os.path.join(SIMT, "fake"), "-I", CSRC, os.path.join(SIMT, "emu_recon.cpp"),
+                           "-o", exe, "-lpthread"])
+    P = orc.rand_matrix(300, N, 6)
+    Ho, _ = orc.householder(P)
+    f = {k: str(tmp_path / f"{k}.bin") for k in ("S", "P", "R", "G", "o1", "o2", "o3")}
+    V = np.tril(Ho)
+    _put(f["S"], V.T @ V)
+    _put(f["P"], P[:N])
+    _put(f["R"], np.linalg.qr(P, mode="r"))
+    _put(f["G"], P.T @ P)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    for args in (("buildt", 4, f["S"], 128, f["o1"], f["o2"]), ("buildt", 5, f["S"], 128, f["o1"], f["o2"]),
+                 ("buildt", 5, f["S"], 77, f["o1"], f["o2"]),
+                 ("recon", 4, f["P"], f["R"], f["o1"], f["o2"], f["o3"]),
+                 ("recon", 5, f["P"], f["R"], f["o1"], f["o2"], f["o3"]),
+                 ("chol", 4, f["G"], "-", 1, f["o1"], f["o2"], f["o3"])):
+        r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=600, env=env)
+        assert "AddressSanitizer" not in r.stderr and r.returncode == 0, (args[:2], r.stderr[:2000])
