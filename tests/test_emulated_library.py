@@ -95,6 +95,22 @@ def test_two_panel_driver_and_next_kernel_generation(emu, orc):
         emu.dhqr_destroy(h)
 
 
+_SLOW = pytest.mark.skipif(os.environ.get("DHQR_SLOW") != "1", reason="extra configuration; set DHQR_SLOW=1")
+
+
+@pytest.mark.parametrize("m,env", [(301, {}),                          # odd m: scalar (VEC = 1) loads everywhere
+                                   (300, {"DHQR_PANEL": 2}),           # row-split step kernels for every panel
+                                   pytest.param(300, {"DHQR_PANEL": 2, "DHQR_IB": 32}, marks=_SLOW),
+                                   pytest.param(300, {"DHQR_PANEL": 1}, marks=_SLOW),  # one workgroup per column
+                                   (300, {"DHQR_CHOLQR_PASSES": 2})])  # CholeskyQR2 in the fast path
+def test_panel_implementations_and_switches(emu, orc, m, env):
+    h = _ctx(emu, **env)
+    A0 = orc.rand_matrix(m, 256, 13)
+    A, al = _factor(emu, h, A0, 128)
+    _check(orc, A0, A, al)
+    emu.dhqr_destroy(h)
+
+
 def test_ill_conditioned_panel_falls_back_and_stays_stable(emu, orc):
     """two nearly dependent columns inside panel 1: the fast path must refuse the panel (||v||^2 check, before
     anything is written), the column-by-column kernels redo it, the result is backward stable"""
