@@ -11,7 +11,9 @@ SO_PATH = os.path.join(_PKG, "libdhqr.so")
 CSRC = os.path.join(_PKG, "csrc")
 NB = 128  # DHQR_NB
 
-OK, EINVAL, EHIP, ENOMEM, ENODEVICE = 0, -1, -2, -3, -4
+OK, EINVAL, EHIP, ENOMEM, ENODEVICE, ECOMM = 0, -1, -2, -3, -4, -5
+COMM_SELF, COMM_RCCL, COMM_LOCAL, COMM_CALLBACK = 0, 1, 2, 3
+UNIQUE_ID_BYTES = 128
 
 
 class DHQRError(RuntimeError):
@@ -47,6 +49,10 @@ _i32, _i64, _u64, _f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes
 _p = ctypes.c_void_p
 _pp = ctypes.POINTER(ctypes.c_void_p)
 _pd = ctypes.POINTER(ctypes.c_double)
+_pi32, _pi64 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
+# dhqr_bcast_fn / dhqr_allreduce_fn (include/dhqr.h): the CALLBACK transport
+BCAST_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/dhqr.h one to one
 SIGNATURES = {
@@ -85,6 +91,35 @@ SIGNATURES = {
     "dhqr_form_r0_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i32, _i32]),
     "dhqr_diff_norms_f64": (_i32, [_p, _p, _i64, _p, _i64, _i64, _i64, _pd]),
     "dhqr_panel_apply_f64": (_i32, [_p, _p, _i64, _p, _i64, _i64, _i32]),
+    "dhqr_comm_unique_id": (_i32, [_p]),
+    "dhqr_comm_create_rank": (_i32, [_pp, _p, _i32, _i32, _p]),
+    "dhqr_comm_create_callbacks": (_i32, [_pp, _p, _i32, _i32, BCAST_FN, ALLREDUCE_FN, _p]),
+    "dhqr_comm_destroy": (_i32, [_p]),
+    "dhqr_comm_info": (_i32, [_p, _pi32, _pi32, _pi32, _pi64]),
+    "dhqr_cs_local_cols": (_i64, [_i64, _i32, _i32]),
+    "dhqr_cs_contiguous_range": (None, [_i64, _i32, _i32, _pi64, _pi64]),
+    "dhqr_cs_fill_uniform_f64": (_i32, [_p, _p, _i64, _i64, _i64, _u64]),
+    "dhqr_cs_factor_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
+    "dhqr_cs_residual_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _u64, _p, _p, _pd]),
+    "dhqr_cs_solve_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "dhqr_cs_load_contiguous_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p]),
+    "dhqr_cs_store_contiguous_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p]),
+    "dhqr_cs_qr_darray_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
+    "dhqr_mg_create": (_i32, [_pp, _pi32, _i32]),
+    "dhqr_mg_destroy": (_i32, [_p]),
+    "dhqr_mg_info": (_i32, [_p, _pi32, _pi32, _pi64, _pi64]),
+    "dhqr_mg_alloc_f64": (_i32, [_p, _i64, _i64]),
+    "dhqr_mg_fill_uniform_f64": (_i32, [_p, _u64]),
+    "dhqr_mg_factor_f64": (_i32, [_p]),
+    "dhqr_mg_residual_f64": (_i32, [_p, _u64, _pd]),
+    "dhqr_mg_upload_f64": (_i32, [_p, _p, _i64, _p]),
+    "dhqr_mg_download_f64": (_i32, [_p, _p, _i64, _p]),
+    "dhqr_mg_qr_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
+    "dhqr_mg_solve_f64": (_i32, [_p, _p, _p]),
+    "dhqr_mg_ldiv_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "dhqr_mg_set_profiling": (_i32, [_p, _i32]),
+    "dhqr_mg_reset_stats": (_i32, [_p]),
+    "dhqr_mg_get_stats": (_i32, [_p, _i32, ctypes.POINTER(Stats), _pi64, _pi64, _pi64]),
     "dhqr_rs_gram_f64": (_i32, [_p, _p, _i64, _i64, _p]),
     "dhqr_rs_chol_f64": (_i32, [_p, _p, _p, _p]),
     "dhqr_rs_recon_top_f64": (_i32, [_p, _p, _i64, _p, _p, _p, _p]),

@@ -3,10 +3,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/dhqr.h"
@@ -56,21 +58,22 @@ struct dhqr_ctx {
   struct WS { Buf w1, w1r, w1r2, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
   int cur_ws = 0;
   bool lookahead = true;
-  hipEvent_t ev_panel[4] = {}, ev_wide[4] = {};
-  Buf vbuf, vt, vt2, vts, spart, sfull, scratch, pbuf;
-  Buf pairv[2], pairt;           // two-panel (K = 256) update: [V_a V_b] buffers, T_a/T_b/S_ba side storage
+  Buf vbuf, vt, vts, spart, sfull, scratch, pbuf;
   int pair = 1;                  // 1: wide updates apply two panels per pass (DHQR_PAIR=0 disables)
   int64_t pair_min_n = 20480;    // below this the longer look-ahead lane of the pair driver costs more than it saves
-  int panel_impl = 3;  // 3: R-first (CholeskyQR2 + reconstruction, dhqr_recon.h) with fallback to 2;
+  int panel_impl = 3;  // 3: R-first (CholeskyQR + reconstruction, dhqr_recon.h) with fallback to 2;
                        // 2: row-split sub-panel kernels (dhqr_panel.h); 1: one workgroup per column
-  int *hflag = nullptr;  // pinned host copy of the fast path's verification flags
-  Buf rbuf;              // R1, -R1^{-1}, R, Rref, -M^{-1}, alpha_tmp, flags
+  int *hflag = nullptr;  // pinned host copy of the device status block
+  int *dstat = nullptr;  // device status block (ints): [0] first rejected panel of the running factorisation
+                         // (INT_MAX: none), [1] Cholesky breakdown flag of the panel in flight
+  int epoch = -1;        // >= 0 while an asynchronous factorisation is enqueued: matrix-writing launches carry
+                         // (dstat, epoch) and are no-ops once a panel <= epoch was rejected
+  Buf rbuf;              // R1, -R1^{-1}, R, Rref, -M^{-1}, alpha_tmp
   int64_t n_fast = 0, n_fallback = 0;
   int cholqr_passes = 1;  // Gram/Cholesky passes of the fast path (2 = CholeskyQR2)
   double recon_tol = 2e-12;  // accepted deviation of ||v_j||^2 from 2 before falling back
   int ib = DHQR_IB;
-  int smallk = 3;  // generation of the single-workgroup panel kernels (DHQR_SMALLK): 3 default, 4 = one barrier per
-                   // step, 5 = 4 + blocked triangular inverses (five barriers instead of 128)
+  struct CsState *cs = nullptr;  // streams / events / group buffers of the blocked driver (dhqr_dist.h)
   // profiling
   struct Ev { hipEvent_t a, b; int cat; };
   std::vector<Ev> evs;
@@ -182,36 +185,61 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
   return DHQR_OK;
 }
 
-// ---- the three single-workgroup dense 128 x 128 kernels of the panel chain (dhqr_recon.h), by generation
+// ---- the three single-workgroup dense 128 x 128 kernels of the panel chain (dhqr_recon.h)
 static inline void launch_chol_inv(dhqr_ctx *c, const double *G, const double *Rprev, double *Rout, double *negX,
                                    int *flag) {
-  if (c->smallk >= 4)
-    hipLaunchKernelGGL(k_chol_inv4, dim3(1), dim3(1024), 0, c->stream, G, Rprev, Rout, negX, flag);
-  else
-    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, G, Rprev, Rout, negX, flag);
+  hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(1024), 0, c->stream, G, Rprev, Rout, negX, flag);
 }
 static inline void launch_recon_top(dhqr_ctx *c, const double *P, int64_t ldp, const double *R, double *alpha,
                                     double *Rref, double *negMinv) {
-  if (c->smallk == 5)
-    hipLaunchKernelGGL(k_recon_top5, dim3(1), dim3(1024), 0, c->stream, P, ldp, R, alpha, Rref, negMinv);
-  else if (c->smallk == 4)
-    hipLaunchKernelGGL(k_recon_top4, dim3(1), dim3(1024), 0, c->stream, P, ldp, R, alpha, Rref, negMinv);
-  else
-    hipLaunchKernelGGL(k_recon_top, dim3(1), dim3(1024), 0, c->stream, P, ldp, R, alpha, Rref, negMinv);
+  hipLaunchKernelGGL(k_recon_top, dim3(1), dim3(1024), 0, c->stream, P, ldp, R, alpha, Rref, negMinv);
 }
 static inline void launch_build_t(dhqr_ctx *c, const double *S, int ncols, double *T, double *Tt) {
-  if (c->smallk == 5) hipLaunchKernelGGL(k_build_t5, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt);
-  else if (c->smallk == 4) hipLaunchKernelGGL(k_build_t4, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt);
-  else hipLaunchKernelGGL(k_build_t3, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt);
+  hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt);
 }
 
-// ---- packed panel buffer helpers ------------------------------------------------------------
+// ---- where a factored panel's GEMM operands live --------------------------------------------------
+// V: rows x 128 with leading dimension ldv (R part above the diagonal zeroed, columns >= ncols zero);
+// T / Tt: the upper-triangular compact-WY factor and its transpose (128 x 128 each); alpha: 128 doubles
+// followed by DHQR_STATW status words (word 0: failure index travelling with a broadcast panel).
+// Legacy packed buffer ("VT", dhqr_panel_* entry points):  [ V : ldv x 128 | T | Tt | alpha | status ].
+#define DHQR_STATW 16
+struct PanelBuf {
+  double *V;
+  int64_t ldv;
+  double *T, *Tt, *alpha;
+};
 static inline int64_t panel_ldv(int64_t rows) { return (rows + 15) & ~(int64_t)15; }
-static inline double *vt_T(double *vt, int64_t rows) { return vt + panel_ldv(rows) * DHQR_NBV; }
-static inline double *vt_Tt(double *vt, int64_t rows) { return vt_T(vt, rows) + DHQR_NBV * DHQR_NBV; }
-static inline double *vt_alpha(double *vt, int64_t rows) { return vt_Tt(vt, rows) + DHQR_NBV * DHQR_NBV; }
-static inline int64_t panel_elems(int64_t rows) {
-  return panel_ldv(rows) * DHQR_NBV + 2 * DHQR_NBV * DHQR_NBV + DHQR_NBV;
+static inline int64_t panel_tail_elems() { return 2 * (int64_t)DHQR_NBV * DHQR_NBV + DHQR_NBV + DHQR_STATW; }
+static inline int64_t panel_elems(int64_t rows) { return panel_ldv(rows) * DHQR_NBV + panel_tail_elems(); }
+static inline PanelBuf tail_view(double *V, int64_t ldv, double *tail) {
+  PanelBuf pb;
+  pb.V = V;
+  pb.ldv = ldv;
+  pb.T = tail;
+  pb.Tt = tail + DHQR_NBV * DHQR_NBV;
+  pb.alpha = tail + 2 * DHQR_NBV * DHQR_NBV;
+  return pb;
+}
+static inline PanelBuf vt_view(double *vt, int64_t rows) {
+  return tail_view(vt, panel_ldv(rows), vt + panel_ldv(rows) * DHQR_NBV);
+}
+static inline PanelBuf vt_view(const double *vt, int64_t rows) { return vt_view(const_cast<double *>(vt), rows); }
+
+// (stat, epoch) of a matrix-writing launch: active while an asynchronous factorisation is being enqueued
+static inline const int *pred_stat(dhqr_ctx *c) { return c->epoch >= 0 ? c->dstat : nullptr; }
+
+// C -= V W on the MFMA kernel (dhqr_gemm.h); INIT0: C = -V W.
+template <int KW, bool INIT0 = false>
+static void launch_nn_sub(dhqr_ctx *c, bool vec, dim3 grid, const double *V, int64_t ldv, const double *W, int64_t ldw,
+                          double *C, int64_t ldc, int64_t rows, int64_t ncols, int swz, bool predicated) {
+  const int *st = predicated ? pred_stat(c) : nullptr;
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_nn_sub<2, KW, INIT0>), grid, dim3(256), 0, c->stream, V, ldv, W, ldw, C, ldc, rows, ncols,
+                       swz, st, c->epoch);
+  else
+    hipLaunchKernelGGL((k_gemm_nn_sub<1, KW, INIT0>), grid, dim3(256), 0, c->stream, V, ldv, W, ldw, C, ldc, rows, ncols,
+                       swz, st, c->epoch);
 }
 
 // Split-K factor for k_gemm_tn: `ntiles` column tiles x ns row slabs should fill the 512 resident
@@ -239,37 +267,14 @@ static void pick_split(int64_t rows, int64_t ntiles, int64_t target_wgs, int64_t
   *nsplit = std::max<int64_t>(1, (rows + r - 1) / r);
 }
 
-// T / T' of a packed panel buffer whose V part is already in place (ncols real columns).
-static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *vt, int kw = DHQR_NBV);
-
-// Pack V (R part zeroed) and build T / T' for a factored panel P (rows x ncols, ncols <= 128).
-static int32_t panel_pack_and_t(dhqr_ctx *c, const double *P, int64_t rows, int64_t ncols,
-                                int64_t ldp, const double *alpha, double *vt) {
-  const int64_t ldv = panel_ldv(rows);
-  double *V = vt;
-  CHECK(prof_begin(c, CAT_TBUILD));
-  {
-    dim3 grid((unsigned)std::min<int64_t>((ldv + 255) / 256, 64), DHQR_NBV);
-    hipLaunchKernelGGL(k_pack_v, grid, dim3(256), 0, c->stream, P, ldp, rows, ncols, V, ldv);
-  }
-  CHECK(panel_build_t(c, rows, ncols, vt));
-  if (alpha) {  // nullptr: the caller already placed alpha in the buffer tail (or does not need it)
-    HIPCHECK(hipMemsetAsync(vt_alpha(vt, rows), 0, DHQR_NBV * sizeof(double), c->stream));
-    HIPCHECK(hipMemcpyAsync(vt_alpha(vt, rows), alpha, (size_t)ncols * sizeof(double),
-                            hipMemcpyDeviceToDevice, c->stream));
-  }
-  CHECK(prof_end(c));
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-
-static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *vt, int kw) {
-  const int64_t ldv = panel_ldv(rows);
-  double *V = vt;
+// T / T' of a panel whose V part is already in place (ncols real columns).
+static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, const PanelBuf &pb, int kw = DHQR_NBV) {
   int64_t nsplit, rps;
   pick_split(rows, 1, 128, 128, &nsplit, &rps);
   CHECK(ensure(c, c->spart, (size_t)nsplit * DHQR_NBV * DHQR_NBV));
   CHECK(ensure(c, c->sfull, (size_t)DHQR_NBV * DHQR_NBV));
+  const double *V = pb.V;
+  const int64_t ldv = pb.ldv;
 #define DHQR_SGEMM(KW_)                                                                           \
   hipLaunchKernelGGL((k_gemm_tn<2, 1, KW_>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, V, ldv, \
                      V, ldv, 1, (int64_t)0, rows, (int64_t)KW_, rps, c->spart.p, (int64_t)DHQR_NBV,      \
@@ -281,18 +286,36 @@ static int32_t panel_build_t(dhqr_ctx *c, int64_t rows, int64_t ncols, double *v
   hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(DHQR_NBV * kw / 64)), dim3(256), 0, c->stream,
                      (const double *)c->spart.p, (int)nsplit, (int64_t)DHQR_NBV * DHQR_NBV,
                      (int64_t)DHQR_NBV * kw, c->sfull.p);
-  launch_build_t(c, c->sfull.p, (int)ncols, vt_T(vt, rows), vt_Tt(vt, rows));
+  launch_build_t(c, c->sfull.p, (int)ncols, pb.T, pb.Tt);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+// Pack V (R part zeroed) and build T / T' for a factored panel P (rows x ncols, ncols <= 128).
+static int32_t panel_pack_and_t(dhqr_ctx *c, const double *P, int64_t rows, int64_t ncols,
+                                int64_t ldp, const double *alpha, const PanelBuf &pb) {
+  const int64_t npad = panel_ldv(rows);
+  CHECK(prof_begin(c, CAT_TBUILD));
+  {
+    dim3 grid((unsigned)std::min<int64_t>((npad + 255) / 256, 64), DHQR_NBV);
+    hipLaunchKernelGGL(k_pack_v, grid, dim3(256), 0, c->stream, P, ldp, rows, ncols, pb.V, pb.ldv, npad);
+  }
+  CHECK(panel_build_t(c, rows, ncols, pb));
+  if (alpha)  // nullptr: the caller already placed alpha in the buffer tail (or does not need it)
+    hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, alpha, (int)ncols, (double *)nullptr,
+                       pb.alpha, (const int *)nullptr, 0);
+  CHECK(prof_end(c));
   LAUNCHCHECK();
   return DHQR_OK;
 }
 
 // C (rows x ncols) <- (I - V op(T) V') C with op(T) = T' (trans=1) or T (trans=0).
-static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *C, int64_t ncols,
+static int32_t panel_apply(dhqr_ctx *c, const PanelBuf &pb, int64_t rows, double *C, int64_t ncols,
                            int64_t ldc, int trans, int kw = DHQR_NBV) {
   if (ncols <= 0 || rows <= 0) return DHQR_OK;
-  const int64_t ldv = panel_ldv(rows);
-  const double *V = vt;
-  const double *Top = trans ? vt_T(const_cast<double *>(vt), rows) : vt_Tt(const_cast<double *>(vt), rows);
+  const int64_t ldv = pb.ldv;
+  const double *V = pb.V;
+  const double *Top = trans ? pb.T : pb.Tt;
   const int64_t ntiles = (ncols + 127) / 128;
   int64_t nsplit, rps;
   // narrow updates (one or two column tiles: the look-ahead lane / a rank's single block) are split
@@ -302,7 +325,7 @@ static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *
   CHECK(ensure(c, ws.w1, (size_t)nsplit * DHQR_NBV * (size_t)ncols));
   CHECK(ensure(c, ws.w2, (size_t)DHQR_NBV * (size_t)ncols));
   if (nsplit > 1) CHECK(ensure(c, ws.w1r, (size_t)DHQR_NBV * (size_t)ncols));
-  const bool vec = (ldc % 2 == 0) && (rows % 2 == 0) && aligned16(C);
+  const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(V);
   const int64_t wstride = (int64_t)DHQR_NBV * ncols;
 
   // one instantiation per reflector-block width (32 / 64 inside a panel, 128 for the trailing update)
@@ -334,12 +357,8 @@ static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *
     const int swz_ = (c->swizzle && gx_ >= 16 && ntiles >= 16) ? 1 : 0;                              \
     dim3 grid((unsigned)gx_, (unsigned)ntiles);                                                      \
     if (swz_) grid = dim3((unsigned)((((gx_ + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);      \
-    if (vec)                                                                                         \
-      hipLaunchKernelGGL((k_gemm_nn_sub<2, KW_>), grid, dim3(256), 0, c->stream, V, ldv,             \
-                         (const double *)ws.w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols, swz_);     \
-    else                                                                                             \
-      hipLaunchKernelGGL((k_gemm_nn_sub<1, KW_>), grid, dim3(256), 0, c->stream, V, ldv,             \
-                         (const double *)ws.w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols, swz_);     \
+    launch_nn_sub<KW_>(c, vec, grid, V, ldv, (const double *)ws.w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols, swz_, \
+                       true);                                                                        \
     CHECK(prof_end(c));                                                                              \
   } while (0)
   if (kw == 32) DHQR_APPLY(32);
@@ -355,11 +374,12 @@ static int32_t panel_apply(dhqr_ctx *c, const double *vt, int64_t rows, double *
 }
 
 // ---- panel factorisation, row-split sub-panel version (dhqr_panel.h) --------------------------
-// Factors the rows x w panel P in place, writes alpha[0:w], and leaves the packed V, T, T', alpha in
-// `vt` (the operand of the trailing update / the broadcast buffer).
+// Factors the rows x w panel P in place, writes alpha[0:w], and leaves the V, T, T', alpha operands in pb.
+// The reference algorithm column by column: used for partial / short panels and as the robust fallback.
 static int32_t factor_panel_v2(dhqr_ctx *c, double *P, int64_t rows, int64_t w, int64_t ldp,
-                               double *alpha, double *vt) {
-  const int64_t ldvw = panel_ldv(rows);
+                               double *alpha, const PanelBuf &pb) {
+  const int64_t ldvw = pb.ldv;
+  double *vt = pb.V;
   const int ib = c->ib;
   const int64_t nchmax = (rows + PS_RC - 1) / PS_RC;
   const int64_t rpad = (rows + 31) & ~(int64_t)15;
@@ -371,15 +391,18 @@ static int32_t factor_panel_v2(dhqr_ctx *c, double *P, int64_t rows, int64_t w, 
   const bool vec = (ldp % 2 == 0) && (rows % 2 == 0) && aligned16(P);
   CHECK(prof_begin(c, CAT_PANEL));
   const bool was = c->profiling;
+  const int was_epoch = c->epoch;
   c->profiling = false;  // the nested T builds / GEMMs are accounted to the panel
+  c->epoch = -1;         // robust path: runs unconditionally
   auto body = [&]() -> int32_t {
-    HIPCHECK(hipMemsetAsync(vt, 0, (size_t)ldvw * DHQR_NBV * sizeof(double), c->stream));
+    HIPCHECK(hipMemsetAsync(vt, 0, (size_t)(ldvw * (DHQR_NBV - 1) + panel_ldv(rows)) * sizeof(double), c->stream));
     for (int64_t j0 = 0; j0 < w; j0 += ib) {
       const int ncs = (int)std::min<int64_t>(ib, w - j0);
       const int64_t rows_s = rows - j0;
       double *Ps = P + j0 + j0 * ldp;
       const int nch = (int)((rows_s + PS_RC - 1) / PS_RC);
-      const int64_t ldvs = panel_ldv(rows_s);
+      const PanelBuf sub = vt_view(c->vts.p, rows_s);
+      const int64_t ldvs = sub.ldv;
       HIPCHECK(hipMemsetAsync(c->vts.p, 0, (size_t)ldvs * (ncs <= 32 ? 32 : (ncs <= 64 ? 64 : 128)) * sizeof(double), c->stream));
       if (vec)
         hipLaunchKernelGGL((k_panel_init<2>), dim3(nch, ncs), dim3(256), 0, c->stream, (const double *)Ps, ldp,
@@ -403,23 +426,24 @@ static int32_t factor_panel_v2(dhqr_ctx *c, double *P, int64_t rows, int64_t w, 
       }
       if (j0 + ncs < w) {  // block reflector of this sub-panel onto the rest of the panel (MFMA)
         const int kw = ncs <= 32 ? 32 : (ncs <= 64 ? 64 : 128);
-        CHECK(panel_build_t(c, rows_s, ncs, c->vts.p, kw));
-        CHECK(panel_apply(c, c->vts.p, rows_s, P + j0 + (j0 + ncs) * ldp, w - j0 - ncs, ldp, 1, kw));
+        CHECK(panel_build_t(c, rows_s, ncs, sub, kw));
+        CHECK(panel_apply(c, sub, rows_s, P + j0 + (j0 + ncs) * ldp, w - j0 - ncs, ldp, 1, kw));
       }
     }
     {
       dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), (unsigned)w);
-      hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, P, ldp, rows, w, (const double *)vt, ldvw);
+      hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, P, ldp, rows, w, (const double *)vt, ldvw,
+                         (const int *)nullptr, 0);
     }
-    CHECK(panel_build_t(c, rows, w, vt));
-    HIPCHECK(hipMemsetAsync(vt_alpha(vt, rows), 0, DHQR_NBV * sizeof(double), c->stream));
-    HIPCHECK(hipMemcpyAsync(vt_alpha(vt, rows), alpha, (size_t)w * sizeof(double), hipMemcpyDeviceToDevice,
-                            c->stream));
+    CHECK(panel_build_t(c, rows, w, pb));
+    hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, (const double *)alpha, (int)w,
+                       (double *)nullptr, pb.alpha, (const int *)nullptr, 0);
     LAUNCHCHECK();
     return DHQR_OK;
   };
   const int32_t rc = body();
   c->profiling = was;
+  c->epoch = was_epoch;
   CHECK(rc);
   if (c->profiling) {
     for (int64_t j = 0; j + 1 < w; ++j) c->st.bytes_panel += 16.0 * (double)(rows - j) * (double)(w - j - 1);
@@ -451,187 +475,114 @@ static int32_t gram128(dhqr_ctx *c, const double *X, int64_t ldx, int64_t rows, 
 // out (rows x 128, ld ldo) = X (rows x 128, ld ldx) * Y with negY = -Y given (128 x 128, ld 128)
 static int32_t mul128(dhqr_ctx *c, const double *X, int64_t ldx, int64_t rows, const double *negY, double *out,
                       int64_t ldo) {
-  HIPCHECK(hipMemsetAsync(out, 0, (size_t)ldo * DHQR_NBV * sizeof(double), c->stream));
-  const bool vec = (ldx % 2 == 0) && (rows % 2 == 0) && aligned16(X);
+  const bool vec = (ldx % 2 == 0) && (ldo % 2 == 0) && (rows % 2 == 0) && aligned16(X) && aligned16(out);
   dim3 grid((unsigned)((rows + 127) / 128), 1);
-  if (vec)
-    hipLaunchKernelGGL((k_gemm_nn_sub<2, 128>), grid, dim3(256), 0, c->stream, X, ldx, negY, (int64_t)DHQR_NBV, out,
-                       ldo, rows, (int64_t)DHQR_NBV, 0);
-  else
-    hipLaunchKernelGGL((k_gemm_nn_sub<1, 128>), grid, dim3(256), 0, c->stream, X, ldx, negY, (int64_t)DHQR_NBV, out,
-                       ldo, rows, (int64_t)DHQR_NBV, 0);
+  launch_nn_sub<128, true>(c, vec, grid, X, ldx, negY, (int64_t)DHQR_NBV, out, ldo, rows, (int64_t)DHQR_NBV, 0, false);
   return DHQR_OK;
 }
 
-static int32_t factor_panel_v2(dhqr_ctx *c, double *P, int64_t rows, int64_t w, int64_t ldp, double *alpha,
-                               double *vt);
+// device status block: stat[0] = first failed panel (INT_MAX none), stat[1] = breakdown flag of the panel in flight
+__global__ void k_set_status(int *stat, int v0) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    stat[0] = v0;
+    stat[1] = 0;
+  }
+}
+static int32_t status_reset(dhqr_ctx *c) {
+  hipLaunchKernelGGL(k_set_status, dim3(1), dim3(64), 0, c->stream, c->dstat, INT_MAX);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// host copy of stat[0] (synchronises c->stream)
+static int32_t status_read(dhqr_ctx *c, int *first_failed) {
+  HIPCHECK(hipMemcpyAsync(c->hflag, c->dstat, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  *first_failed = c->hflag[0];
+  return DHQR_OK;
+}
 
-// Full-width panel (w == 128).  Nothing is written to P until the reflectors are verified; on a
-// failed check (ill-conditioned panel) the robust column-by-column path runs on the untouched P.
-// The verification flag is read on the host: one stream synchronisation per panel (the caller has
-// already queued the concurrent trailing update on the other stream).
-static int32_t factor_panel_v3(dhqr_ctx *c, double *P, int64_t rows, int64_t ldp, double *alpha, double *vt) {
-  const int64_t ldv = panel_ldv(rows);
+// Enqueue the R-first factorisation of a full-width panel (w == 128, rows >= 256) WITHOUT waiting for its
+// verification: nothing is written to P, alpha or pb.T/Tt/alpha unless the panel is accepted on the device
+// (k_recon_decide); once a panel has failed every later commit / trailing update with epoch >= its index is a
+// no-op, and the driver resumes from it with factor_panel_sync after its single final synchronisation.
+static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t ldp, double *alpha, const PanelBuf &pb,
+                                  int passes, int panel_idx) {
+  const int64_t ldv = pb.ldv;
   const size_t NN = (size_t)DHQR_NBV * DHQR_NBV;
   CHECK(ensure(c, c->rbuf, 6 * NN + 1024));
-  CHECK(ensure(c, c->vts, (size_t)panel_elems(rows)));
+  if (passes == 2) CHECK(ensure(c, c->vts, (size_t)panel_elems(rows)));
   CHECK(ensure(c, c->sfull, NN));
   double *R1 = c->rbuf.p, *negR1inv = R1 + NN, *Rf = R1 + 2 * NN, *Rref = R1 + 3 * NN, *negMinv = R1 + 4 * NN;
   double *G = R1 + 5 * NN, *altmp = R1 + 6 * NN;
-  int *dflag = (int *)(altmp + 256);
-  double *Q1 = c->vts.p;  // rows x 128 scratch, ld = ldv
+  int *bflag = c->dstat + 1;
   CHECK(prof_begin(c, CAT_PANEL));
   const bool was = c->profiling;
   c->profiling = false;
-  bool ok = false;
-  int passes = c->cholqr_passes;
   auto body = [&]() -> int32_t {
-    HIPCHECK(hipMemsetAsync(dflag, 0, 4 * sizeof(int), c->stream));
     CHECK(gram128(c, P, ldp, rows, G));                                            // G  = P'P
     if (passes == 2) {
-      launch_chol_inv(c, G, nullptr, R1, negR1inv, dflag);                          // R1, -R1^{-1}
-      CHECK(mul128(c, P, ldp, rows, negR1inv, Q1, ldv));                           // Q1 = P R1^{-1}
-      CHECK(gram128(c, Q1, ldv, rows, G));                                         // G2 = Q1'Q1
-      launch_chol_inv(c, G, R1, Rf, nullptr, dflag);                                // R  = chol(G2) R1
+      double *Q1 = c->vts.p;  // rows x 128 scratch
+      const int64_t ldq = panel_ldv(rows);
+      launch_chol_inv(c, G, nullptr, R1, negR1inv, bflag);                          // R1, -R1^{-1}
+      CHECK(mul128(c, P, ldp, rows, negR1inv, Q1, ldq));                           // Q1 = P R1^{-1}
+      CHECK(gram128(c, Q1, ldq, rows, G));                                         // G2 = Q1'Q1
+      launch_chol_inv(c, G, R1, Rf, nullptr, bflag);                                // R  = chol(G2) R1
     } else {
-      launch_chol_inv(c, G, nullptr, Rf, nullptr, dflag);                           // R = chol(P'P)
+      launch_chol_inv(c, G, nullptr, Rf, nullptr, bflag);                           // R = chol(P'P)
     }
     launch_recon_top(c, P, ldp, Rf, altmp, Rref, negMinv);                          // alpha, R_ref, -M^{-1}
-    CHECK(mul128(c, P, ldp, rows, negMinv, vt, ldv));                              // Vw = P M^{-1}
-    hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, vt, ldv, (const double *)altmp,
+    CHECK(mul128(c, P, ldp, rows, negMinv, pb.V, ldv));                            // Vw = P M^{-1}
+    hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, pb.V, ldv, (const double *)altmp,
                        (const double *)negMinv);                                   // Vw = tril((P - aE) M^{-1})
-    CHECK(gram128(c, vt, ldv, rows, c->sfull.p));                                  // S = V'V
-    hipLaunchKernelGGL(k_recon_check, dim3(1), dim3(128), 0, c->stream, (const double *)c->sfull.p, c->recon_tol, dflag);
-    HIPCHECK(hipMemcpyAsync(c->hflag, dflag, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    CHECK(gram128(c, pb.V, ldv, rows, c->sfull.p));                                // S = V'V
+    hipLaunchKernelGGL(k_recon_decide, dim3(1), dim3(128), 0, c->stream, (const double *)c->sfull.p, c->recon_tol,
+                       c->dstat, panel_idx, pb.alpha + DHQR_NBV);
+    // commit (device-side predicate): reflectors, R, alpha; T is only ever read by accepted consumers
+    dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
+    hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, P, ldp, rows, (int64_t)DHQR_NBV, (const double *)pb.V,
+                       ldv, (const int *)c->dstat, panel_idx);
+    hipLaunchKernelGGL(k_recon_write_r, dim3(NN / 256), dim3(256), 0, c->stream, P, ldp, (const double *)Rref,
+                       (const int *)c->dstat, panel_idx);
+    hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, (const double *)altmp, (int)DHQR_NBV, alpha,
+                       pb.alpha, (const int *)c->dstat, panel_idx);
+    launch_build_t(c, c->sfull.p, (int)DHQR_NBV, pb.T, pb.Tt);
     LAUNCHCHECK();
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    ok = (c->hflag[0] == 0 && c->hflag[1] == 0);
-    if (ok) {  // commit: reflectors, R, alpha, T
-      dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
-      hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, P, ldp, rows, (int64_t)DHQR_NBV,
-                         (const double *)vt, ldv);
-      hipLaunchKernelGGL(k_recon_write_r, dim3(NN / 256), dim3(256), 0, c->stream, P, ldp, (const double *)Rref);
-      HIPCHECK(hipMemcpyAsync(alpha, altmp, DHQR_NBV * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-      HIPCHECK(hipMemcpyAsync(vt_alpha(vt, rows), altmp, DHQR_NBV * sizeof(double), hipMemcpyDeviceToDevice,
-                              c->stream));
-      launch_build_t(c, c->sfull.p, (int)DHQR_NBV, vt_T(vt, rows), vt_Tt(vt, rows));
-      LAUNCHCHECK();
-    }
-    return DHQR_OK;
-  };
-  int32_t rc = body();
-  if (rc == DHQR_OK && !ok && passes == 1) {  // moderately ill-conditioned panel: CholeskyQR2 before giving up
-    passes = 2;
-    rc = body();
-  }
-  c->profiling = was;
-  CHECK(rc);
-  if (ok) {
-    c->n_fast++;
-    if (c->profiling)
-      for (int64_t j = 0; j + 1 < DHQR_NBV; ++j)
-        c->st.bytes_panel += 16.0 * (double)(rows - j) * (double)(DHQR_NBV - j - 1);
-    CHECK(prof_end(c));
-    return DHQR_OK;
-  }
-  c->n_fallback++;
-  CHECK(prof_end(c));
-  return factor_panel_v2(c, P, rows, DHQR_NBV, ldp, alpha, vt);
-}
-
-// Factor one panel and leave (V, T, T', alpha) packed in vt.
-static int32_t factor_panel(dhqr_ctx *c, double *P, int64_t rows, int64_t w, int64_t ldp, double *alpha,
-                            double *vt) {
-  if (c->panel_impl == 3 && w == DHQR_NBV && rows >= 2 * DHQR_NBV) return factor_panel_v3(c, P, rows, ldp, alpha, vt);
-  if (c->panel_impl >= 2) return factor_panel_v2(c, P, rows, w, ldp, alpha, vt);
-  CHECK(factor_unblocked_cols(c, P, rows, w, ldp, alpha, CAT_PANEL));
-  return panel_pack_and_t(c, P, rows, w, ldp, alpha, vt);
-}
-
-// ---- blocked driver (BASELINE config 3) ------------------------------------------------------
-// Right-looking with look-ahead depth 1 on two streams of the same GPU:
-//   stream B (high priority): narrow update of block k+1 by panel k, then factorisation of
-//                             panel k+1  (latency-bound, needs few CUs)
-//   stream A (caller's)     : wide update of blocks >= k+2 by panel k  (MFMA-bound)
-// so the panel factorisation the reference serialises in front of every trailing update
-// (src:127-143) runs underneath the previous trailing update.
-static int32_t factor_blocked_pair(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha);
-static int32_t factor_blocked(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
-  const int64_t K = (n + DHQR_NBV - 1) / DHQR_NBV;
-  CHECK(ensure(c, c->vt, (size_t)panel_elems(m)));
-  if (c->lookahead && c->pair && K >= 4 && n % DHQR_NBV == 0 && n >= c->pair_min_n)
-    return factor_blocked_pair(c, dA, m, n, lda, dalpha);
-  if (!c->lookahead || K < 3) {
-    for (int64_t c0 = 0; c0 < n; c0 += DHQR_NBV) {
-      const int64_t w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
-      double *P = dA + c0 + c0 * lda;
-      CHECK(factor_panel(c, P, rows, w, lda, dalpha + c0, c->vt.p));
-      if (c0 + w < n) CHECK(panel_apply(c, c->vt.p, rows, dA + c0 + (c0 + w) * lda, n - c0 - w, lda, 1));
-    }
-    return DHQR_OK;
-  }
-  // size every workspace up front: no (re)allocation while two streams are in flight
-  CHECK(ensure(c, c->vt2, (size_t)panel_elems(m)));
-  CHECK(ensure(c, c->vts, (size_t)panel_elems(m)));
-  {
-    const size_t ntmax = (size_t)((n + 127) / 128);
-    const size_t w1cap = (size_t)DHQR_NBV * DHQR_NBV * (2048 + ntmax + 64);
-    for (int s = 0; s < 2; ++s) {
-      CHECK(ensure(c, c->ws[s].w1, s == 0 ? w1cap : (size_t)DHQR_NBV * DHQR_NBV * 1100));
-      CHECK(ensure(c, c->ws[s].w1r, (size_t)DHQR_NBV * (size_t)n));
-      CHECK(ensure(c, c->ws[s].w2, (size_t)DHQR_NBV * (size_t)n));
-    }
-    CHECK(ensure(c, c->spart, (size_t)128 * DHQR_NBV * DHQR_NBV));
-    CHECK(ensure(c, c->sfull, (size_t)DHQR_NBV * DHQR_NBV));
-  }
-  double *vt[2] = {c->vt.p, c->vt2.p};
-  hipStream_t sU = c->stream, sB = c->hi;          // sU: the caller's stream
-  hipStream_t sA = sU;                             // stream of the wide updates
-  auto on = [&](hipStream_t s, int wsi) { c->stream = s; c->cur_ws = wsi; };
-  auto body = [&]() -> int32_t {
-    // order stream B after whatever the caller queued on A (e.g. the fill)
-    HIPCHECK(hipEventRecord(c->ev_wide[3], sU));
-    HIPCHECK(hipStreamWaitEvent(sB, c->ev_wide[3], 0));
-    if (sA != sU) HIPCHECK(hipStreamWaitEvent(sA, c->ev_wide[3], 0));
-    on(sB, 1);
-    CHECK(factor_panel(c, dA, m, std::min<int64_t>(DHQR_NBV, n), lda, dalpha, vt[0]));
-    HIPCHECK(hipEventRecord(c->ev_panel[0], sB));
-    for (int64_t k = 0; k < K; ++k) {
-      const int64_t c0 = k * DHQR_NBV, w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
-      if (k + 1 < K) {
-        const int64_t c1 = c0 + w, w1 = std::min<int64_t>(DHQR_NBV, n - c1);
-        const int64_t c2 = c1 + w1;
-        // wide update first: the panel path below synchronises its stream on the host once
-        on(sA, 0);
-        HIPCHECK(hipStreamWaitEvent(sA, c->ev_panel[k & 3], 0));
-        if (c2 < n) CHECK(panel_apply(c, vt[k & 1], rows, dA + c0 + c2 * lda, n - c2, lda, 1));
-        HIPCHECK(hipEventRecord(c->ev_wide[k & 3], sA));
-        on(sB, 1);
-        if (k >= 1) HIPCHECK(hipStreamWaitEvent(sB, c->ev_wide[(k - 1) & 3], 0));  // block k+1 is current, vt[(k+1)&1] free
-        {  // narrow (one block column) update of the look-ahead lane: accounted to the panel group
-          CHECK(prof_begin(c, CAT_PANEL));
-          const bool was = c->profiling;
-          c->profiling = false;
-          const int32_t rcn = panel_apply(c, vt[k & 1], rows, dA + c0 + c1 * lda, w1, lda, 1);
-          c->profiling = was;
-          CHECK(rcn);
-          CHECK(prof_end(c));
-        }
-        CHECK(factor_panel(c, dA + c1 + c1 * lda, m - c1, w1, lda, dalpha + c1, vt[(k + 1) & 1]));
-        HIPCHECK(hipEventRecord(c->ev_panel[(k + 1) & 3], sB));
-      }
-    }
-    // the caller's stream owns the result: wait for the last panel (and the last wide update)
-    HIPCHECK(hipStreamWaitEvent(sU, c->ev_panel[(K - 1) & 3], 0));
-    if (sA != sU) {
-      HIPCHECK(hipEventRecord(c->ev_wide[2], sA));
-      HIPCHECK(hipStreamWaitEvent(sU, c->ev_wide[2], 0));
-    }
     return DHQR_OK;
   };
   const int32_t rc = body();
-  on(sU, 0);
-  return rc;
+  c->profiling = was;
+  CHECK(rc);
+  if (c->profiling)
+    for (int64_t j = 0; j + 1 < DHQR_NBV; ++j) c->st.bytes_panel += 16.0 * (double)(rows - j) * (double)(DHQR_NBV - j - 1);
+  CHECK(prof_end(c));
+  return DHQR_OK;
+}
+static inline bool panel_fast_eligible(dhqr_ctx *c, int64_t rows, int64_t w) {
+  return c->panel_impl == 3 && w == DHQR_NBV && rows >= 2 * DHQR_NBV;
+}
+
+// Robust, host-verified panel factorisation: fast path (then CholeskyQR2) with the verification read back,
+// finally the column-by-column kernels on the untouched P.  One or two stream synchronisations; used by the
+// simple (no look-ahead) driver, the dhqr_panel_* entry points and when an asynchronous run resumes.
+static int32_t factor_panel_sync(dhqr_ctx *c, double *P, int64_t rows, int64_t w, int64_t ldp, double *alpha,
+                                 const PanelBuf &pb) {
+  if (panel_fast_eligible(c, rows, w)) {
+    for (int passes = c->cholqr_passes; passes <= 2; ++passes) {
+      CHECK(status_reset(c));
+      CHECK(panel_fast_enqueue(c, P, rows, ldp, alpha, pb, passes, 0));
+      int failed = 0;
+      CHECK(status_read(c, &failed));
+      if (failed == INT_MAX) {
+        c->n_fast++;
+        return DHQR_OK;
+      }
+    }
+    CHECK(status_reset(c));
+    c->n_fallback++;
+  }
+  if (c->panel_impl >= 2) return factor_panel_v2(c, P, rows, w, ldp, alpha, pb);
+  CHECK(factor_unblocked_cols(c, P, rows, w, ldp, alpha, CAT_PANEL));
+  return panel_pack_and_t(c, P, rows, w, ldp, alpha, pb);
 }
 
 // ---- two-panel trailing update (K = 256) ------------------------------------------------------
@@ -640,17 +591,6 @@ static int32_t factor_blocked(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int
 // Vp = [V_a | V_b] (ldv x 256; V_b shifted down by 128 rows, zeros above), rows = rows of panel a.
 // Halves the C read+write traffic of the NN GEMM per flop (0.125 -> 0.094 B/flop through the CU
 // memory pipe), which is what bounds k_gemm_nn_sub.
-__global__ __launch_bounds__(256) void k_copy_vb(const double *__restrict__ Vb, int64_t ldvb, int64_t rows_b,
-                                                 double *__restrict__ Vp, int64_t ldv, int64_t rows_a) {
-  const int64_t p = blockIdx.y;  // column of V_b
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ldv; r += stride) {
-    double x = 0.0;
-    if (r >= DHQR_NBV && r < rows_a && r - DHQR_NBV < rows_b) x = Vb[(r - DHQR_NBV) + p * ldvb];
-    Vp[r + (DHQR_NBV + p) * ldv] = x;
-  }
-}
-
 static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows, const double *Ta,
                           const double *Tb, const double *Sba, double *C, int64_t ncols, int64_t ldc) {
   if (ncols <= 0) return DHQR_OK;
@@ -663,7 +603,7 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   CHECK(ensure(c, ws.w1r, (size_t)DHQR_NBV * (size_t)ncols));
   CHECK(ensure(c, ws.w1r2, (size_t)DHQR_NBV * (size_t)ncols));
   CHECK(ensure(c, ws.w2, (size_t)2 * DHQR_NBV * (size_t)ncols));
-  const bool vec = (ldc % 2 == 0) && (rows % 2 == 0) && aligned16(C);
+  const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(Vp);
   const int64_t wstride = (int64_t)DHQR_NBV * ncols;
   const double *Vb = Vp + DHQR_NBV + (int64_t)DHQR_NBV * ldv;  // first non-zero row of V_b
   const dim3 gtn((unsigned)ntiles, (unsigned)nsplit), gred((unsigned)((wstride + 63) / 64));
@@ -694,9 +634,9 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Ta, (int64_t)DHQR_NBV,
                      (const double *)ws.w1r.p, (int64_t)DHQR_NBV, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols,
                      (int64_t)DHQR_NBV, ws.w2.p, ld2, (int64_t)0);
-  // Y_b -= (V_b' V_a) W_a
-  hipLaunchKernelGGL((k_gemm_nn_sub<2, 128>), dim3(1, (unsigned)ntiles), dim3(256), 0, c->stream, Sba, (int64_t)DHQR_NBV,
-                     (const double *)ws.w2.p, ld2, ws.w1r2.p, (int64_t)DHQR_NBV, (int64_t)DHQR_NBV, ncols, 0);
+  // Y_b -= (V_b' V_a) W_a   (workspace: never predicated)
+  launch_nn_sub<128>(c, true, dim3(1, (unsigned)ntiles), Sba, (int64_t)DHQR_NBV, (const double *)ws.w2.p, ld2, ws.w1r2.p,
+                     (int64_t)DHQR_NBV, (int64_t)DHQR_NBV, ncols, 0, false);
   // W_b = T_b' Y_b  -> rows 128..255 of W2
   hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Tb, (int64_t)DHQR_NBV,
                      (const double *)ws.w1r2.p, (int64_t)DHQR_NBV, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols,
@@ -708,12 +648,7 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
   dim3 grid((unsigned)gx, (unsigned)ntiles);
   if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
-  if (vec)
-    hipLaunchKernelGGL((k_gemm_nn_sub<2, 256>), grid, dim3(256), 0, c->stream, Vp, ldv, (const double *)ws.w2.p, ld2, C,
-                       ldc, rows, ncols, swz);
-  else
-    hipLaunchKernelGGL((k_gemm_nn_sub<1, 256>), grid, dim3(256), 0, c->stream, Vp, ldv, (const double *)ws.w2.p, ld2, C,
-                       ldc, rows, ncols, swz);
+  launch_nn_sub<256>(c, vec, grid, Vp, ldv, (const double *)ws.w2.p, ld2, C, ldc, rows, ncols, swz, true);
   CHECK(prof_end(c));
   if (c->profiling) {
     c->st.flops_gemm_vta += 2.0 * DHQR_NBV * ((double)rows + (double)rows_b) * (double)ncols;
@@ -723,149 +658,83 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   return DHQR_OK;
 }
 
-// Blocked driver, two panels per wide update.  Panels are paired (0,1), (2,3), ...; while the wide
-// stream applies pair q to blocks >= 2q+4, the look-ahead lane brings blocks 2q+2 and 2q+3 up to
-// date, factors them and assembles pair q+1.
-static int32_t factor_blocked_pair(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
-  const int64_t K = (n + DHQR_NBV - 1) / DHQR_NBV, NB = DHQR_NBV;
-  const int64_t ldvmax = panel_ldv(m);
+// S_ba = V_b' V_a (128 x 128) of a pair operand Vp = [V_a | V_b]: the cross term of pair_apply
+static int32_t pair_cross_gram(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows_a, double *Sba) {
+  const int64_t NB = DHQR_NBV, rows_b = rows_a - NB;
   const size_t NN = (size_t)NB * NB;
-  // size everything up front
-  for (int s = 0; s < 2; ++s) CHECK(ensure(c, c->pairv[s], (size_t)ldvmax * 2 * NB + 2 * NN + NB + 1024));
-  CHECK(ensure(c, c->pairt, 2 * 3 * NN));  // per pair buffer: T_a, T_b, S_ba
-  CHECK(ensure(c, c->vt2, (size_t)panel_elems(m)));
-  CHECK(ensure(c, c->vts, (size_t)panel_elems(m)));
-  {
-    const size_t ntmax = (size_t)((n + 127) / 128);
-    const size_t w1cap = (size_t)NB * NB * (2048 + ntmax + 64);
-    for (int s = 0; s < 2; ++s) {
-      CHECK(ensure(c, c->ws[s].w1, s == 0 ? w1cap : (size_t)NB * NB * 1100));
-      CHECK(ensure(c, c->ws[s].w1r, (size_t)NB * (size_t)n));
-      CHECK(ensure(c, c->ws[s].w1r2, (size_t)NB * (size_t)n));
-      CHECK(ensure(c, c->ws[s].w2, (size_t)2 * NB * (size_t)n));
-    }
-    CHECK(ensure(c, c->spart, (size_t)256 * NN));
-    CHECK(ensure(c, c->sfull, NN));
-    CHECK(ensure(c, c->rbuf, 6 * NN + 1024));
-    CHECK(ensure(c, c->scratch, 4096));
-  }
-  hipStream_t sU = c->stream, sB = c->hi, sA = sU;
-  auto on = [&](hipStream_t s, int wsi) { c->stream = s; c->cur_ws = wsi; };
-  auto Ta = [&](int q) { return c->pairt.p + (size_t)(q & 1) * 3 * NN; };
-  auto Tb = [&](int q) { return Ta(q) + NN; };
-  auto Sba = [&](int q) { return Ta(q) + 2 * NN; };
-  auto colptr = [&](int64_t rowblk, int64_t colblk) { return dA + rowblk * NB + colblk * NB * lda; };
-  auto wcols = [&](int64_t k) { return std::min<int64_t>(NB, n - k * NB); };
-
-  // lane helpers (stream sB, workspace set 1), all accounted to the panel group
-  auto lane_single_apply = [&](const double *vt, int64_t k, int64_t blk) -> int32_t {
-    return panel_apply(c, vt, m - k * NB, colptr(k, blk), wcols(blk), lda, 1);
-  };
-  // assemble pair q from panel a (already in pairv[q&1] as a standard VT) and panel b (in vt2)
-  auto build_pair = [&](int q) -> int32_t {
-    const int64_t a = 2 * (int64_t)q, rows_a = m - a * NB, rows_b = rows_a - NB;
-    const int64_t ldva = panel_ldv(rows_a), ldvb = panel_ldv(rows_b);
-    double *pv = c->pairv[q & 1].p;
-    HIPCHECK(hipMemcpyAsync(Ta(q), vt_T(pv, rows_a), NN * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHECK(hipMemcpyAsync(Tb(q), vt_T(c->vt2.p, rows_b), NN * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    dim3 grid((unsigned)std::min<int64_t>((ldva + 255) / 256, 64), (unsigned)NB);
-    hipLaunchKernelGGL(k_copy_vb, grid, dim3(256), 0, c->stream, (const double *)c->vt2.p, ldvb, rows_b, pv, ldva, rows_a);
-    // S_ba = V_b' V_a over the rows of panel b
-    int64_t nsplit, rps;
-    pick_split(rows_b, 1, 512, 256, &nsplit, &rps);
-    const double *Vb = pv + NB + NB * ldva;
-    hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, Vb, ldva,
-                       (const double *)(pv + NB), ldva, 1, (int64_t)0, rows_b, (int64_t)NB, rps, c->spart.p, (int64_t)NB,
+  int64_t nsplit, rps;
+  pick_split(rows_b, 1, 512, 256, &nsplit, &rps);
+  CHECK(ensure(c, c->spart, (size_t)nsplit * NN));
+  const double *Vb = Vp + NB + NB * ldv;
+  const bool vec = (ldv % 2 == 0) && (rows_b % 2 == 0) && aligned16(Vp);
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, Vb, ldv,
+                       (const double *)(Vp + NB), ldv, 1, (int64_t)0, rows_b, (int64_t)NB, rps, c->spart.p, (int64_t)NB,
                        (int64_t)NN);
-    hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(NN / 64)), dim3(256), 0, c->stream, (const double *)c->spart.p,
-                       (int)nsplit, (int64_t)NN, (int64_t)NN, Sba(q));
-    LAUNCHCHECK();
-    return DHQR_OK;
-  };
-
-  auto body = [&]() -> int32_t {
-    HIPCHECK(hipEventRecord(c->ev_wide[3], sU));
-    HIPCHECK(hipStreamWaitEvent(sB, c->ev_wide[3], 0));
-    on(sB, 1);
-    const bool was0 = c->profiling;
-    // ---- pair 0
-    CHECK(factor_panel(c, dA, m, wcols(0), lda, dalpha, c->pairv[0].p));
-    if (K >= 2) {
-      CHECK(prof_begin(c, CAT_PANEL));
-      c->profiling = false;
-      int32_t r1 = lane_single_apply(c->pairv[0].p, 0, 1);
-      c->profiling = was0;
-      CHECK(r1);
-      CHECK(prof_end(c));
-      CHECK(factor_panel(c, colptr(1, 1), m - NB, wcols(1), lda, dalpha + NB, c->vt2.p));
-      if (K >= 3) {
-        CHECK(prof_begin(c, CAT_PANEL));
-        c->profiling = false;
-        r1 = build_pair(0);
-        c->profiling = was0;
-        CHECK(r1);
-        CHECK(prof_end(c));
-      }
-    }
-    HIPCHECK(hipEventRecord(c->ev_panel[0], sB));
-    for (int q = 0;; ++q) {
-      const int64_t a = 2 * (int64_t)q, b = a + 1;
-      if (b + 1 >= K) break;  // no block after panel b: nothing left to update
-      const int64_t A2 = b + 1, B2 = b + 2, W0 = b + 3;  // next pair's panels, first block of the wide update
-      // wide update first (the lane below synchronises its stream on the host)
-      on(sA, 0);
-      HIPCHECK(hipStreamWaitEvent(sA, c->ev_panel[q & 3], 0));
-      if (W0 < K)
-        CHECK(pair_apply(c, c->pairv[q & 1].p, panel_ldv(m - a * NB), m - a * NB, Ta(q), Tb(q), Sba(q), colptr(a, W0),
-                         n - W0 * NB, lda));
-      HIPCHECK(hipEventRecord(c->ev_wide[q & 3], sA));
-      // look-ahead lane: blocks A2, B2
-      on(sB, 1);
-      if (q >= 1) HIPCHECK(hipStreamWaitEvent(sB, c->ev_wide[(q - 1) & 3], 0));
-      const bool was = c->profiling;
-      CHECK(prof_begin(c, CAT_PANEL));
-      c->profiling = false;
-      // blocks A2 and B2 are adjacent: one 256-column pair update brings both up to date
-      int32_t rc2 = pair_apply(c, c->pairv[q & 1].p, panel_ldv(m - a * NB), m - a * NB, Ta(q), Tb(q), Sba(q),
-                               colptr(a, A2), wcols(A2) + (B2 < K ? wcols(B2) : 0), lda);
-      c->profiling = was;
-      CHECK(rc2);
-      CHECK(prof_end(c));
-      CHECK(factor_panel(c, colptr(A2, A2), m - A2 * NB, wcols(A2), lda, dalpha + A2 * NB, c->pairv[(q + 1) & 1].p));
-      if (B2 < K) {
-        CHECK(prof_begin(c, CAT_PANEL));
-        c->profiling = false;
-        rc2 = lane_single_apply(c->pairv[(q + 1) & 1].p, A2, B2);
-        c->profiling = was;
-        CHECK(rc2);
-        CHECK(prof_end(c));
-        CHECK(factor_panel(c, colptr(B2, B2), m - B2 * NB, wcols(B2), lda, dalpha + B2 * NB, c->vt2.p));
-        if (B2 + 1 < K) {
-          CHECK(prof_begin(c, CAT_PANEL));
-          c->profiling = false;
-          rc2 = build_pair(q + 1);
-          c->profiling = was;
-          CHECK(rc2);
-          CHECK(prof_end(c));
-        }
-      }
-      HIPCHECK(hipEventRecord(c->ev_panel[(q + 1) & 3], sB));
-    }
-    // join the lane back into the caller's stream
-    HIPCHECK(hipEventRecord(c->ev_panel[3], sB));
-    HIPCHECK(hipStreamWaitEvent(sU, c->ev_panel[3], 0));
-    return DHQR_OK;
-  };
-  const int32_t rc = body();
-  on(sU, 0);
-  return rc;
-}
-
-static int32_t check_ctx(dhqr_ctx *c) {
-  if (!c) return set_err(DHQR_EINVAL, "null context");
-  HIPCHECK(hipSetDevice(c->device));
+  else
+    hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, Vb, ldv,
+                       (const double *)(Vp + NB), ldv, 1, (int64_t)0, rows_b, (int64_t)NB, rps, c->spart.p, (int64_t)NB,
+                       (int64_t)NN);
+  hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(NN / 64)), dim3(256), 0, c->stream, (const double *)c->spart.p,
+                     (int)nsplit, (int64_t)NN, (int64_t)NN, Sba);
+  LAUNCHCHECK();
   return DHQR_OK;
 }
+
+// ---- simple blocked driver: no look-ahead, host-verified panels (DHQR_LOOKAHEAD=0, matrices of 1-2 panels) ----
+static int32_t factor_blocked_simple(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
+  CHECK(ensure(c, c->vt, (size_t)panel_elems(m)));
+  for (int64_t c0 = 0; c0 < n; c0 += DHQR_NBV) {
+    const int64_t w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
+    double *P = dA + c0 + c0 * lda;
+    const PanelBuf pb = vt_view(c->vt.p, rows);
+    CHECK(factor_panel_sync(c, P, rows, w, lda, dalpha + c0, pb));
+    if (c0 + w < n) CHECK(panel_apply(c, pb, rows, dA + c0 + (c0 + w) * lda, n - c0 - w, lda, 1));
+  }
+  return DHQR_OK;
+}
+
+#include "dhqr_comm.h"
+#include "dhqr_dist.h"
+#include "dhqr_mg.h"
+
+static CsProblem cs_single(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
+  CsProblem pr;
+  pr.c = c;
+  pr.cm = nullptr;
+  pr.A = dA;
+  pr.m = m;
+  pr.n = n;
+  pr.lda = lda;
+  pr.alpha = dalpha;
+  pr.P = 1;
+  pr.r = 0;
+  pr.K = cs_nblocks(n);
+  pr.ncl = n;
+  return pr;
+}
+
+// Every entry point runs on the context's device and restores the caller's current device on return (torch and
+// other HIP users of the process read the current device from the runtime).
+struct DeviceGuard {
+  int prev = -1;
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+static int32_t enter_ctx(dhqr_ctx *c, DeviceGuard &g) {
+  if (!c) return set_err(DHQR_EINVAL, "null context");
+  int cur = -1;
+  HIPCHECK(hipGetDevice(&cur));
+  if (cur != c->device) {
+    HIPCHECK(hipSetDevice(c->device));
+    g.prev = cur;
+  }
+  return DHQR_OK;
+}
+#define ENTER(c_)   \
+  DeviceGuard dg_; \
+  CHECK(enter_ctx(c_, dg_))
 // The reference's loops simply do not execute for a matrix without columns (src:127 `for j in Hl.colrange`,
 // src:217 `for j in 1:n`): qr! returns an empty alpha, `\` an empty x.  Same here: n == 0 is a no-op.
 static inline bool no_columns(int64_t m, int64_t n) { return n == 0 && m >= 0; }
@@ -875,6 +744,9 @@ static int32_t check_mat(const void *A, int64_t m, int64_t n, int64_t lda, bool 
   if (m <= 0 || n <= 0) return set_err(DHQR_EINVAL, "m and n must be positive (m=%lld n=%lld)", (long long)m, (long long)n);
   if (need_tall && m < n) return set_err(DHQR_EINVAL, "m >= n required (m=%lld n=%lld)", (long long)m, (long long)n);
   if (lda < m) return set_err(DHQR_EINVAL, "leading dimension %lld < m=%lld", (long long)lda, (long long)m);
+  // the MFMA kernels address a 128-column tile with 32-bit element offsets from the tile base
+  if (lda > (int64_t)0xFFFFFFFFLL / 128)
+    return set_err(DHQR_EINVAL, "leading dimension %lld too large (128 * ld must stay below 2^32 elements)", (long long)lda);
   return DHQR_OK;
 }
 
@@ -890,11 +762,12 @@ static int32_t apply_q_impl(dhqr_ctx *c, const double *dA, int64_t m, int64_t n,
     const int64_t k = trans ? q : npan - 1 - q;
     const int64_t c0 = k * DHQR_NBV, w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
     const double *P = dA + c0 + c0 * lda;
-    CHECK(panel_pack_and_t(c, P, rows, w, lda, dalpha ? dalpha + c0 : nullptr, c->vt.p));
+    const PanelBuf pb = vt_view(c->vt.p, rows);
+    CHECK(panel_pack_and_t(c, P, rows, w, lda, dalpha ? dalpha + c0 : nullptr, pb));
     if (triangular) {
-      if (nrhs - c0 > 0) CHECK(panel_apply(c, c->vt.p, rows, dB + c0 + c0 * ldb, nrhs - c0, ldb, trans));
+      if (nrhs - c0 > 0) CHECK(panel_apply(c, pb, rows, dB + c0 + c0 * ldb, nrhs - c0, ldb, trans));
     } else {
-      CHECK(panel_apply(c, c->vt.p, rows, dB + c0, nrhs, ldb, trans));
+      CHECK(panel_apply(c, pb, rows, dB + c0, nrhs, ldb, trans));
     }
   }
   return DHQR_OK;
@@ -943,16 +816,16 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
       int lo = 0, hi = 0;
       HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
       HIPCHECK(hipStreamCreateWithPriority(&c->hi, hipStreamNonBlocking, hi));
-      for (int i = 0; i < 4; ++i) {
-        HIPCHECK(hipEventCreateWithFlags(&c->ev_panel[i], hipEventDisableTiming));
-        HIPCHECK(hipEventCreateWithFlags(&c->ev_wide[i], hipEventDisableTiming));
-      }
     }
     if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
     if (const char *e = getenv("DHQR_SWIZZLE")) c->swizzle = atoi(e) != 0;
     if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;
     if (const char *e = getenv("DHQR_PAIR_MIN_N")) c->pair_min_n = atoll(e);
     HIPCHECK(hipHostMalloc((void **)&c->hflag, 4 * sizeof(int), hipHostMallocDefault));
+    HIPCHECK(hipMalloc((void **)&c->dstat, 16 * sizeof(int)));
+    hipLaunchKernelGGL(k_set_status, dim3(1), dim3(64), 0, c->stream, c->dstat, INT_MAX);
+    LAUNCHCHECK();
+    HIPCHECK(hipStreamSynchronize(c->stream));
     return DHQR_OK;
   };
   const int32_t rc_init = init();
@@ -962,10 +835,6 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
   }
   if (const char *e = getenv("DHQR_CHOLQR_PASSES")) c->cholqr_passes = atoi(e) == 2 ? 2 : 1;
   if (const char *e = getenv("DHQR_RECON_TOL")) c->recon_tol = atof(e);
-  if (const char *e = getenv("DHQR_SMALLK")) {
-    const int v = atoi(e);
-    c->smallk = (v == 4 || v == 5) ? v : 3;
-  }
   if (const char *e = getenv("DHQR_PANEL")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 3) c->panel_impl = v;
@@ -982,19 +851,18 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   if (!c) return DHQR_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  Buf *bufs[] = {&c->vbuf, &c->vt, &c->vt2, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w1r2, &c->ws[0].w2, &c->ws[1].w1,
-                 &c->ws[1].w1r, &c->ws[1].w1r2, &c->ws[1].w2, &c->pairv[0], &c->pairv[1], &c->pairt, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf};
+  (void)hipDeviceSynchronize();
+  cs_state_free(c);
+  Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w1r2, &c->ws[0].w2, &c->ws[1].w1,
+                 &c->ws[1].w1r, &c->ws[1].w1r2, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
-  for (int i = 0; i < 4; ++i) {
-    if (c->ev_panel[i]) (void)hipEventDestroy(c->ev_panel[i]);
-    if (c->ev_wide[i]) (void)hipEventDestroy(c->ev_wide[i]);
-  }
   if (c->hflag) (void)hipHostFree(c->hflag);
+  if (c->dstat) (void)hipFree(c->dstat);
   if (c->hi) (void)hipStreamDestroy(c->hi);
   if (c->own) (void)hipStreamDestroy(c->own);
   delete c;
@@ -1002,28 +870,28 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
 }
 
 int32_t dhqr_set_stream(dhqr_ctx *c, void *s) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   c->stream = (hipStream_t)s;  // NULL is the device's default (null) stream, as torch uses it
   return DHQR_OK;
 }
 int32_t dhqr_use_own_stream(dhqr_ctx *c) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   c->stream = c->own;
   return DHQR_OK;
 }
 int32_t dhqr_synchronize(dhqr_ctx *c) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   HIPCHECK(hipStreamSynchronize(c->stream));
   return DHQR_OK;
 }
 int32_t dhqr_set_profiling(dhqr_ctx *c, int32_t on) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (c->profiling && !on) CHECK(prof_resolve(c));
   c->profiling = on != 0;
   return DHQR_OK;
 }
 int32_t dhqr_reset_stats(dhqr_ctx *c) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   HIPCHECK(hipStreamSynchronize(c->stream));
   c->ev_used = 0;
   memset(&c->st, 0, sizeof(c->st));
@@ -1031,7 +899,7 @@ int32_t dhqr_reset_stats(dhqr_ctx *c) {
   return DHQR_OK;
 }
 int32_t dhqr_get_stats(dhqr_ctx *c, dhqr_stats *out) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!out) return set_err(DHQR_EINVAL, "null stats pointer");
   CHECK(prof_resolve(c));
   *out = c->st;
@@ -1039,7 +907,7 @@ int32_t dhqr_get_stats(dhqr_ctx *c, dhqr_stats *out) {
 }
 
 int32_t dhqr_get_panel_counters(dhqr_ctx *c, int64_t *n_fast, int64_t *n_fallback) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (n_fast) *n_fast = c->n_fast;
   if (n_fallback) *n_fallback = c->n_fallback;
   return DHQR_OK;
@@ -1048,7 +916,7 @@ int32_t dhqr_get_panel_counters(dhqr_ctx *c, int64_t *n_fast, int64_t *n_fallbac
 int32_t dhqr_fill_uniform_f64(dhqr_ctx *c, double *dA, int64_t rows, int64_t cols, int64_t lda,
                               uint64_t seed, int64_t global_m, int64_t row0, int64_t colblock,
                               int32_t nranks, int32_t rank) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   CHECK(check_mat(dA, rows, cols, lda, false));
   if (colblock <= 0 || nranks <= 0 || rank < 0 || rank >= nranks || global_m < rows)
     return set_err(DHQR_EINVAL, "bad layout arguments to dhqr_fill_uniform_f64");
@@ -1062,19 +930,21 @@ int32_t dhqr_fill_uniform_f64(dhqr_ctx *c, double *dA, int64_t rows, int64_t col
 
 int32_t dhqr_factor_f64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha,
                         int32_t nb) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (no_columns(m, n)) return DHQR_OK;
   CHECK(check_mat(dA, m, n, lda, true));
   if (!dalpha) return set_err(DHQR_EINVAL, "null alpha pointer");
   if (nb != 0 && nb != DHQR_NB)
     return set_err(DHQR_EINVAL, "nb must be 0 (unblocked) or %d (blocked); got %d", DHQR_NB, nb);
   if (nb == 0) return factor_unblocked_cols(c, dA, m, n, lda, dalpha, CAT_RANK1);
-  return factor_blocked(c, dA, m, n, lda, dalpha);
+  if (!c->lookahead || cs_nblocks(n) < 3) return factor_blocked_simple(c, dA, m, n, lda, dalpha);
+  const CsProblem pr = cs_single(c, dA, m, n, lda, dalpha);
+  return cs_factor(pr);
 }
 
 int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha,
                     int32_t nb) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (no_columns(m, n)) return DHQR_OK;
   CHECK(check_mat(hA, m, n, lda, true));
   if (!halpha) return set_err(DHQR_EINVAL, "null alpha pointer");
@@ -1107,7 +977,7 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
 
 int32_t dhqr_solve_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda,
                        const double *dalpha, double *db) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (no_columns(m, n)) return DHQR_OK;
   CHECK(check_mat(dA, m, n, lda, true));
   if (!dalpha || !db) return set_err(DHQR_EINVAL, "null alpha or b pointer");
@@ -1133,7 +1003,7 @@ int32_t dhqr_solve_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int6
 
 int32_t dhqr_backsub_block_f64(dhqr_ctx *c, const double *dAcols, int64_t lda, const double *dalpha,
                                double *db, int64_t lo, int64_t hi, int32_t do_diag, int32_t do_update) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!dAcols || !dalpha || !db) return set_err(DHQR_EINVAL, "null pointer argument");
   if (lo < 0 || hi <= lo) return set_err(DHQR_EINVAL, "bad block [%lld,%lld)", (long long)lo, (long long)hi);
   for (int64_t h = hi; h > lo; h -= BS_NB) {  // blocks wider than 64 are walked in 64-row steps
@@ -1154,7 +1024,7 @@ int32_t dhqr_backsub_block_f64(dhqr_ctx *c, const double *dAcols, int64_t lda, c
 
 int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64_t lda,
                       const double *halpha, const double *hb, double *hx) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (no_columns(m, n)) return DHQR_OK;
   CHECK(check_mat(hA, m, n, lda, true));
   if (!halpha || !hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
@@ -1184,7 +1054,7 @@ int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64
 
 int32_t dhqr_partialdot_f64(dhqr_ctx *c, const double *da, const double *db, int64_t lo, int64_t hi,
                             double *hout) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!da || !db || !hout) return set_err(DHQR_EINVAL, "null pointer argument");
   if (lo < 0 || hi < lo) return set_err(DHQR_EINVAL, "bad range [%lld,%lld)", (long long)lo, (long long)hi);
   CHECK(ensure(c, c->scratch, 4096));
@@ -1200,7 +1070,7 @@ int32_t dhqr_partialdot_f64(dhqr_ctx *c, const double *da, const double *db, int
 
 int32_t dhqr_partialdot_host_f64(dhqr_ctx *c, const double *ha, const double *hb, int64_t lo, int64_t hi,
                                  double *hout) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!ha || !hb || !hout) return set_err(DHQR_EINVAL, "null pointer argument");
   if (lo < 0 || hi < lo) return set_err(DHQR_EINVAL, "bad range [%lld,%lld)", (long long)lo, (long long)hi);
   if (hi == lo) { *hout = 0.0; return DHQR_OK; }
@@ -1227,7 +1097,7 @@ static int32_t check_zptr(const void *p, const char *what) {
 }
 
 int32_t dhqr_factor_c64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (no_columns(m, n)) return DHQR_OK;
   CHECK(check_mat(dA, m, n, lda, true));
   CHECK(check_zptr(dA, "matrix"));
@@ -1260,7 +1130,7 @@ int32_t dhqr_factor_c64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t l
 }
 
 int32_t dhqr_qr_c64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (no_columns(m, n)) return DHQR_OK;
   CHECK(check_mat(hA, m, n, lda, true));
   if (!halpha) return set_err(DHQR_EINVAL, "null alpha pointer");
@@ -1289,7 +1159,7 @@ int32_t dhqr_qr_c64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
 
 int32_t dhqr_solve_c64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda,
                        const double *dalpha, double *db) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (no_columns(m, n)) return DHQR_OK;
   CHECK(check_mat(dA, m, n, lda, true));
   CHECK(check_zptr(dA, "matrix"));
@@ -1319,7 +1189,7 @@ int32_t dhqr_solve_c64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int6
 
 int32_t dhqr_ldiv_c64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64_t lda,
                       const double *halpha, const double *hb, double *hx) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (no_columns(m, n)) return DHQR_OK;
   CHECK(check_mat(hA, m, n, lda, true));
   if (!halpha || !hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
@@ -1347,7 +1217,7 @@ int32_t dhqr_ldiv_c64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64
 
 int32_t dhqr_partialdot_c64(dhqr_ctx *c, const double *da, const double *db, int64_t lo, int64_t hi,
                             double *hout) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   CHECK(check_zptr(da, "a"));
   CHECK(check_zptr(db, "b"));
   if (!hout) return set_err(DHQR_EINVAL, "null output pointer");
@@ -1368,7 +1238,7 @@ int32_t dhqr_partialdot_c64(dhqr_ctx *c, const double *da, const double *db, int
 
 int32_t dhqr_partialdot_host_c64(dhqr_ctx *c, const double *ha, const double *hb, int64_t lo, int64_t hi,
                                  double *hout) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!ha || !hb || !hout) return set_err(DHQR_EINVAL, "null pointer argument");
   if (lo < 0 || hi < lo) return set_err(DHQR_EINVAL, "bad range [%lld,%lld)", (long long)lo, (long long)hi);
   if (hi == lo) { hout[0] = 0.0; hout[1] = 0.0; return DHQR_OK; }
@@ -1388,7 +1258,7 @@ int32_t dhqr_partialdot_host_c64(dhqr_ctx *c, const double *ha, const double *hb
 
 int32_t dhqr_apply_q_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda, double *dB,
                          int64_t nrhs, int64_t ldb, int32_t trans) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   CHECK(check_mat(dA, m, n, lda, true));
   CHECK(check_mat(dB, m, nrhs, ldb, false));
   return apply_q_impl(c, dA, m, n, lda, nullptr, dB, nrhs, ldb, trans ? 1 : 0, false);
@@ -1397,7 +1267,7 @@ int32_t dhqr_apply_q_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, in
 int32_t dhqr_residual_f64(dhqr_ctx *c, const double *dAfact, int64_t m, int64_t n, int64_t lda,
                           const double *dalpha, const double *dAorig, int64_t ldo, double *dwork,
                           double *hrel) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   CHECK(check_mat(dAfact, m, n, lda, true));
   CHECK(check_mat(dAorig, m, n, ldo, true));
   if (!dalpha || !dwork || !hrel) return set_err(DHQR_EINVAL, "null pointer argument");
@@ -1428,30 +1298,31 @@ int64_t dhqr_panel_buffer_elems(int64_t rows) { return panel_elems(rows); }
 
 int32_t dhqr_panel_factor_f64(dhqr_ctx *c, double *dP, int64_t rows, int64_t ncols, int64_t ldp,
                               double *dVT) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   CHECK(check_mat(dP, rows, ncols, ldp, true));
   if (ncols > DHQR_NB) return set_err(DHQR_EINVAL, "panel wider than %d", DHQR_NB);
   if (!dVT || !aligned16(dVT)) return set_err(DHQR_EINVAL, "dVT must be a 16-byte aligned device buffer");
   // alpha is produced in a small scratch vector and packed into the tail of dVT by factor_panel
   CHECK(ensure(c, c->scratch, 4096));
   double *al = c->scratch.p + 3072;
-  return factor_panel(c, dP, rows, ncols, ldp, al, dVT);
+  return factor_panel_sync(c, dP, rows, ncols, ldp, al, vt_view(dVT, rows));
 }
 
 int32_t dhqr_panel_pack_f64(dhqr_ctx *c, const double *dP, int64_t rows, int64_t ncols, int64_t ldp,
                             double *dVT) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   CHECK(check_mat(dP, rows, ncols, ldp, true));
   if (ncols > DHQR_NB) return set_err(DHQR_EINVAL, "panel wider than %d", DHQR_NB);
   if (!dVT || !aligned16(dVT)) return set_err(DHQR_EINVAL, "dVT must be a 16-byte aligned device buffer");
-  HIPCHECK(hipMemsetAsync(vt_alpha(dVT, rows), 0, DHQR_NBV * sizeof(double), c->stream));
-  return panel_pack_and_t(c, dP, rows, ncols, ldp, nullptr, dVT);
+  const PanelBuf pb = vt_view(dVT, rows);
+  HIPCHECK(hipMemsetAsync(pb.alpha, 0, (DHQR_NBV + DHQR_STATW) * sizeof(double), c->stream));
+  return panel_pack_and_t(c, dP, rows, ncols, ldp, nullptr, pb);
 }
 
 int32_t dhqr_form_r0_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t cols, int64_t lda,
                          const double *dalpha, double *dW, int64_t ldw, int64_t colblock,
                          int32_t nranks, int32_t rank) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (cols == 0) return DHQR_OK;
   CHECK(check_mat(dA, m, cols, lda, false));
   CHECK(check_mat(dW, m, cols, ldw, false));
@@ -1466,7 +1337,7 @@ int32_t dhqr_form_r0_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t cols,
 
 int32_t dhqr_diff_norms_f64(dhqr_ctx *c, const double *dX, int64_t ldx, const double *dY, int64_t ldy,
                             int64_t m, int64_t n, double *hout2) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!hout2) return set_err(DHQR_EINVAL, "null output");
   hout2[0] = hout2[1] = 0.0;
   if (m == 0 || n == 0) return DHQR_OK;
@@ -1486,7 +1357,7 @@ int32_t dhqr_diff_norms_f64(dhqr_ctx *c, const double *dX, int64_t ldx, const do
 // Each call works on the caller's LOCAL row slab; the sums over ranks (Gram matrices, V'C partial
 // dots) are all-reduced by the host layer (rowsplit.py) between calls.
 int32_t dhqr_rs_gram_f64(dhqr_ctx *c, const double *dX, int64_t ldx, int64_t rows, double *dG) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!dX || !dG) return set_err(DHQR_EINVAL, "null pointer argument");
   if (rows <= 0) {  // a rank may own no active rows of this panel
     HIPCHECK(hipMemsetAsync(dG, 0, (size_t)DHQR_NBV * DHQR_NBV * sizeof(double), c->stream));
@@ -1498,7 +1369,7 @@ int32_t dhqr_rs_gram_f64(dhqr_ctx *c, const double *dX, int64_t ldx, int64_t row
 }
 // R = chol(G) (upper, dense 128 x 128).  flags are left on the device: dflag[0] != 0 on breakdown.
 int32_t dhqr_rs_chol_f64(dhqr_ctx *c, const double *dG, double *dR, int32_t *dflag) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!dG || !dR || !dflag) return set_err(DHQR_EINVAL, "null pointer argument");
   launch_chol_inv(c, dG, nullptr, dR, nullptr, (int *)dflag);
   LAUNCHCHECK();
@@ -1507,7 +1378,7 @@ int32_t dhqr_rs_chol_f64(dhqr_ctx *c, const double *dG, double *dR, int32_t *dfl
 // Top-block replay on the rank that owns the panel's diagonal rows: dPtop = &P[diag row, first col].
 int32_t dhqr_rs_recon_top_f64(dhqr_ctx *c, const double *dPtop, int64_t ldp, const double *dR, double *dalpha128,
                               double *dRref, double *dnegMinv) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!dPtop || !dR || !dalpha128 || !dRref || !dnegMinv) return set_err(DHQR_EINVAL, "null pointer argument");
   launch_recon_top(c, dPtop, ldp, dR, dalpha128, dRref, dnegMinv);
   LAUNCHCHECK();
@@ -1516,7 +1387,7 @@ int32_t dhqr_rs_recon_top_f64(dhqr_ctx *c, const double *dPtop, int64_t ldp, con
 // dOut (rows x 128, ld ldo) = dX (rows x 128) * Y, given negY = -Y (128 x 128).
 int32_t dhqr_rs_mul_f64(dhqr_ctx *c, const double *dX, int64_t ldx, int64_t rows, const double *dnegY, double *dOut,
                         int64_t ldo) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (rows <= 0) return DHQR_OK;
   if (!dX || !dnegY || !dOut || ldo < rows) return set_err(DHQR_EINVAL, "bad arguments to dhqr_rs_mul_f64");
   CHECK(mul128(c, dX, ldx, rows, dnegY, dOut, ldo));
@@ -1525,15 +1396,16 @@ int32_t dhqr_rs_mul_f64(dhqr_ctx *c, const double *dX, int64_t ldx, int64_t rows
 }
 // finish V = tril((P - alpha E) M^{-1}) on the 128 diagonal rows (diagonal owner only)
 int32_t dhqr_rs_fix_top_f64(dhqr_ctx *c, double *dVw, int64_t ldv, const double *dalpha128, const double *dnegMinv) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   hipLaunchKernelGGL(k_recon_fix, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream, dVw, ldv, dalpha128,
                      dnegMinv);
   LAUNCHCHECK();
   return DHQR_OK;
 }
 int32_t dhqr_rs_write_r_f64(dhqr_ctx *c, double *dPtop, int64_t ldp, const double *dRref) {
-  CHECK(check_ctx(c));
-  hipLaunchKernelGGL(k_recon_write_r, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream, dPtop, ldp, dRref);
+  ENTER(c);
+  hipLaunchKernelGGL(k_recon_write_r, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream, dPtop, ldp, dRref,
+                     (const int *)nullptr, 0);
   LAUNCHCHECK();
   return DHQR_OK;
 }
@@ -1541,12 +1413,14 @@ int32_t dhqr_rs_write_r_f64(dhqr_ctx *c, double *dPtop, int64_t ldp, const doubl
 // (rows >= column) and the reference-format R above it, every other rank copies all of its rows.
 int32_t dhqr_rs_commit_f64(dhqr_ctx *c, double *dP, int64_t ldp, int64_t rows, const double *dVw, int64_t ldv,
                            int32_t diag_owner, const double *dRref) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (rows <= 0) return DHQR_OK;
   if (diag_owner) {
     dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
-    hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, dP, ldp, rows, (int64_t)DHQR_NBV, dVw, ldv);
-    hipLaunchKernelGGL(k_recon_write_r, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream, dP, ldp, dRref);
+    hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, dP, ldp, rows, (int64_t)DHQR_NBV, dVw, ldv,
+                       (const int *)nullptr, 0);
+    hipLaunchKernelGGL(k_recon_write_r, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream, dP, ldp, dRref,
+                       (const int *)nullptr, 0);
   } else {
     HIPCHECK(hipMemcpy2DAsync(dP, ldp * sizeof(double), dVw, ldv * sizeof(double), rows * sizeof(double), DHQR_NBV,
                               hipMemcpyDeviceToDevice, c->stream));
@@ -1558,11 +1432,11 @@ int32_t dhqr_rs_commit_f64(dhqr_ctx *c, double *dP, int64_t ldp, int64_t rows, c
 // the R part zeroed, other ranks a plain copy of their rows.  dVw: ldv x 128.
 int32_t dhqr_rs_pack_f64(dhqr_ctx *c, const double *dP, int64_t ldp, int64_t rows, double *dVw, int64_t ldv,
                          int32_t diag_owner) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (rows <= 0) return DHQR_OK;
   if (diag_owner) {
     dim3 grid((unsigned)std::min<int64_t>((ldv + 255) / 256, 64), DHQR_NBV);
-    hipLaunchKernelGGL(k_pack_v, grid, dim3(256), 0, c->stream, dP, ldp, rows, (int64_t)DHQR_NBV, dVw, ldv);
+    hipLaunchKernelGGL(k_pack_v, grid, dim3(256), 0, c->stream, dP, ldp, rows, (int64_t)DHQR_NBV, dVw, ldv, ldv);
   } else {
     HIPCHECK(hipMemcpy2DAsync(dVw, ldv * sizeof(double), dP, ldp * sizeof(double), rows * sizeof(double), DHQR_NBV,
                               hipMemcpyDeviceToDevice, c->stream));
@@ -1571,7 +1445,7 @@ int32_t dhqr_rs_pack_f64(dhqr_ctx *c, const double *dP, int64_t ldp, int64_t row
   return DHQR_OK;
 }
 int32_t dhqr_rs_build_t_f64(dhqr_ctx *c, const double *dS, int32_t ncols, double *dT, double *dTt) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   launch_build_t(c, dS, (int)ncols, dT, dTt);
   LAUNCHCHECK();
   return DHQR_OK;
@@ -1579,7 +1453,7 @@ int32_t dhqr_rs_build_t_f64(dhqr_ctx *c, const double *dS, int32_t ncols, double
 // dW1 (128 x ncols, ld 128) = dV' dC over the local rows (split-K partials reduced on the device)
 int32_t dhqr_rs_vtc_f64(dhqr_ctx *c, const double *dV, int64_t ldv, const double *dC, int64_t ldc, int64_t rows,
                         int64_t ncols, double *dW1) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (ncols <= 0) return DHQR_OK;
   const int64_t wstride = (int64_t)DHQR_NBV * ncols;
   if (rows <= 0) {
@@ -1606,7 +1480,7 @@ int32_t dhqr_rs_vtc_f64(dhqr_ctx *c, const double *dV, int64_t ldv, const double
 }
 // dW2 (128 x ncols) = op(T)' dW1 with dTop = T (update) or T' (apply Q)
 int32_t dhqr_rs_tw_f64(dhqr_ctx *c, const double *dTop, const double *dW1, int64_t ncols, double *dW2) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (ncols <= 0) return DHQR_OK;
   const int64_t ntiles = (ncols + 127) / 128;
   hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, dTop, (int64_t)DHQR_NBV,
@@ -1618,31 +1492,26 @@ int32_t dhqr_rs_tw_f64(dhqr_ctx *c, const double *dTop, const double *dW1, int64
 // dC (rows x ncols) -= dV (rows x 128) * dW2 (128 x ncols)
 int32_t dhqr_rs_vw_f64(dhqr_ctx *c, const double *dV, int64_t ldv, const double *dW2, double *dC, int64_t ldc,
                        int64_t rows, int64_t ncols) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (rows <= 0 || ncols <= 0) return DHQR_OK;
   const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(dC) && aligned16(dV);
   dim3 grid((unsigned)((rows + 127) / 128), (unsigned)((ncols + 127) / 128));
-  if (vec)
-    hipLaunchKernelGGL((k_gemm_nn_sub<2, 128>), grid, dim3(256), 0, c->stream, dV, ldv, dW2, (int64_t)DHQR_NBV, dC, ldc,
-                       rows, ncols, 0);
-  else
-    hipLaunchKernelGGL((k_gemm_nn_sub<1, 128>), grid, dim3(256), 0, c->stream, dV, ldv, dW2, (int64_t)DHQR_NBV, dC, ldc,
-                       rows, ncols, 0);
+  launch_nn_sub<128>(c, vec, grid, dV, ldv, dW2, (int64_t)DHQR_NBV, dC, ldc, rows, ncols, 0, false);
   LAUNCHCHECK();
   return DHQR_OK;
 }
 
 int32_t dhqr_panel_apply_f64(dhqr_ctx *c, const double *dVT, int64_t rows, double *dC, int64_t ncols,
                              int64_t ldc, int32_t trans) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!dVT || !aligned16(dVT)) return set_err(DHQR_EINVAL, "dVT must be a 16-byte aligned device buffer");
   if (ncols == 0) return DHQR_OK;
   CHECK(check_mat(dC, rows, ncols, ldc, false));
-  return panel_apply(c, dVT, rows, dC, ncols, ldc, trans ? 1 : 0);
+  return panel_apply(c, vt_view(dVT, rows), rows, dC, ncols, ldc, trans ? 1 : 0);
 }
 
 int32_t dhqr_bench_mfma_f64(dhqr_ctx *c, double *tflops) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!tflops) return set_err(DHQR_EINVAL, "null output");
   const int nblk = 256 * 8, iters = 4000;
   CHECK(ensure(c, c->scratch, (size_t)nblk * 256 + 4096));
@@ -1665,7 +1534,7 @@ int32_t dhqr_bench_mfma_f64(dhqr_ctx *c, double *tflops) {
 
 int32_t dhqr_bench_issue_f64(dhqr_ctx *c, int32_t kind, int32_t nblocks, double *cycles_per_instr,
                              double *tflops) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!cycles_per_instr || !tflops || nblocks <= 0 || nblocks > 4096 || (kind != 0 && kind != 1))
     return set_err(DHQR_EINVAL, "bad arguments");
   const int iters = 2000;
@@ -1697,7 +1566,7 @@ int32_t dhqr_bench_issue_f64(dhqr_ctx *c, int32_t kind, int32_t nblocks, double 
 }
 
 int32_t dhqr_bench_issue2_f64(dhqr_ctx *c, int32_t mode, int32_t threads, int32_t nblocks, double *out4) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!out4 || nblocks <= 0 || nblocks > 4096 || mode < 0 || mode > 2 || threads % 256 || threads > 1024)
     return set_err(DHQR_EINVAL, "bad arguments");
   const int iters = 1000, wpb = threads / 64;
@@ -1734,7 +1603,7 @@ int32_t dhqr_bench_issue2_f64(dhqr_ctx *c, int32_t mode, int32_t threads, int32_
 }
 
 int32_t dhqr_bench_stream_f64(dhqr_ctx *c, int64_t bytes, double *gbps) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   if (!gbps || bytes < 4096) return set_err(DHQR_EINVAL, "bad arguments");
   const int64_t n2 = bytes / 16;
   double *x = nullptr, *y = nullptr;
@@ -1767,10 +1636,459 @@ int32_t dhqr_bench_stream_f64(dhqr_ctx *c, int64_t bytes, double *gbps) {
 // test hook (not in dhqr.h's stable surface, declared in the test binding only):
 // raw MFMA D registers for the documented operand maps
 int32_t dhqr_debug_mfma_probe(dhqr_ctx *c, const double *da, const double *db, double *dout) {
-  CHECK(check_ctx(c));
+  ENTER(c);
   hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, c->stream, da, db, dout);
   LAUNCHCHECK();
   HIPCHECK(hipStreamSynchronize(c->stream));
+  return DHQR_OK;
+}
+
+
+// ============================================================ multi-GPU: communicators (dhqr_comm.h)
+static int32_t comm_new(dhqr_comm **out, dhqr_ctx *c, int kind, int nranks, int rank) {
+  dhqr_comm *cm = new dhqr_comm();
+  cm->ctx = c;
+  cm->kind = kind;
+  cm->nranks = nranks;
+  cm->rank = rank;
+  *out = cm;
+  return DHQR_OK;
+}
+
+int32_t dhqr_comm_unique_id(void *id128) {
+  if (!id128) return set_err(DHQR_EINVAL, "null id buffer");
+  CHECK(rccl_load());
+  ncclUniqueId id;
+  RCCLCHECK(g_rccl.GetUniqueId(&id));
+  static_assert(sizeof(id) == DHQR_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  memcpy(id128, &id, sizeof(id));
+  return DHQR_OK;
+}
+
+int32_t dhqr_comm_create_rank(dhqr_comm **out, dhqr_ctx *c, int32_t nranks, int32_t rank, const void *id128) {
+  if (!out) return set_err(DHQR_EINVAL, "null comm out-pointer");
+  *out = nullptr;
+  ENTER(c);
+  if (nranks < 1 || nranks > DHQR_MAX_RANKS || rank < 0 || rank >= nranks)
+    return set_err(DHQR_EINVAL, "bad rank %d of %d", rank, nranks);
+  if (nranks == 1) return comm_new(out, c, COMM_SELF, 1, 0);
+  if (!id128) return set_err(DHQR_EINVAL, "null unique id");
+  CHECK(rccl_load());
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t nc = nullptr;
+  RCCLCHECK(g_rccl.CommInitRank(&nc, nranks, id, rank));
+  CHECK(comm_new(out, c, COMM_RCCL, nranks, rank));
+  (*out)->nccl = nc;
+  return DHQR_OK;
+}
+
+int32_t dhqr_comm_create_callbacks(dhqr_comm **out, dhqr_ctx *c, int32_t nranks, int32_t rank, dhqr_bcast_fn bcast,
+                                   dhqr_allreduce_fn allreduce, void *user) {
+  if (!out) return set_err(DHQR_EINVAL, "null comm out-pointer");
+  *out = nullptr;
+  ENTER(c);
+  if (nranks < 1 || nranks > DHQR_MAX_RANKS || rank < 0 || rank >= nranks)
+    return set_err(DHQR_EINVAL, "bad rank %d of %d", rank, nranks);
+  if (nranks > 1 && (!bcast || !allreduce)) return set_err(DHQR_EINVAL, "null callback");
+  CHECK(comm_new(out, c, nranks == 1 ? COMM_SELF : COMM_CALLBACK, nranks, rank));
+  (*out)->cb_bcast = bcast;
+  (*out)->cb_allreduce = allreduce;
+  (*out)->cb_user = user;
+  return DHQR_OK;
+}
+
+int32_t dhqr_comm_destroy(dhqr_comm *cm) { return comm_free(cm); }
+
+int32_t dhqr_comm_info(dhqr_comm *cm, int32_t *kind, int32_t *nranks, int32_t *rank, int64_t *bytes_bcast) {
+  if (!cm) return set_err(DHQR_EINVAL, "null communicator");
+  if (kind) *kind = cm->kind;
+  if (nranks) *nranks = cm->nranks;
+  if (rank) *rank = cm->rank;
+  if (bytes_bcast) *bytes_bcast = cm->bytes_bcast;
+  return DHQR_OK;
+}
+
+// ============================================================ multi-GPU: SPMD column-split entry points
+int64_t dhqr_cs_local_cols(int64_t n, int32_t nranks, int32_t rank) {
+  if (n < 0 || nranks < 1 || rank < 0 || rank >= nranks) return -1;
+  return cs_local_cols(n, nranks, rank);
+}
+void dhqr_cs_contiguous_range(int64_t n, int32_t nranks, int32_t rank, int64_t *lo, int64_t *hi) {
+  cs_contig_range(n, nranks, rank, lo, hi);
+}
+
+static int32_t cs_check(dhqr_comm *cm, const void *dA, int64_t m, int64_t n, int64_t lda, CsProblem *pr, bool need_A = true) {
+  if (!cm) return set_err(DHQR_EINVAL, "null communicator");
+  if (m <= 0 || n <= 0 || m < n) return set_err(DHQR_EINVAL, "m >= n >= 1 required (m=%lld n=%lld)", (long long)m, (long long)n);
+  pr->c = cm->ctx;
+  pr->cm = cm;
+  pr->P = cm->nranks;
+  pr->r = cm->rank;
+  pr->m = m;
+  pr->n = n;
+  pr->lda = lda;
+  pr->K = cs_nblocks(n);
+  pr->ncl = cs_local_cols(n, pr->P, pr->r);
+  pr->A = const_cast<double *>((const double *)dA);
+  pr->alpha = nullptr;
+  if (need_A && pr->ncl > 0) CHECK(check_mat(dA, m, pr->ncl, lda, false));
+  return DHQR_OK;
+}
+
+int32_t dhqr_cs_fill_uniform_f64(dhqr_comm *cm, double *dA, int64_t m, int64_t n, int64_t lda, uint64_t seed) {
+  CsProblem pr;
+  CHECK(cs_check(cm, dA, m, n, lda, &pr));
+  if (pr.ncl == 0) return DHQR_OK;
+  return dhqr_fill_uniform_f64(pr.c, dA, m, pr.ncl, lda, seed, m, 0, DHQR_NBV, pr.P, pr.r);
+}
+
+int32_t dhqr_cs_factor_f64(dhqr_comm *cm, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
+  CsProblem pr;
+  CHECK(cs_check(cm, dA, m, n, lda, &pr));
+  ENTER(pr.c);
+  if (!dalpha) return set_err(DHQR_EINVAL, "null alpha pointer");
+  pr.alpha = dalpha;
+  return cs_factor(pr);
+}
+
+int32_t dhqr_cs_residual_f64(dhqr_comm *cm, const double *dA, int64_t m, int64_t n, int64_t lda, const double *dalpha,
+                             uint64_t seed, double *dW, double *dA0, double *hrel) {
+  CsProblem pr;
+  CHECK(cs_check(cm, dA, m, n, lda, &pr));
+  ENTER(pr.c);
+  if (!dalpha || !hrel || (pr.ncl > 0 && (!dW || !dA0))) return set_err(DHQR_EINVAL, "null pointer argument");
+  pr.alpha = const_cast<double *>(dalpha);
+  return cs_residual(pr, seed, dW, dA0, hrel);
+}
+
+int32_t dhqr_cs_solve_f64(dhqr_comm *cm, const double *dA, int64_t m, int64_t n, int64_t lda, const double *dalpha,
+                          double *db, double *dwork) {
+  CsProblem pr;
+  CHECK(cs_check(cm, dA, m, n, lda, &pr));
+  ENTER(pr.c);
+  if (!dalpha || !db || !dwork) return set_err(DHQR_EINVAL, "null pointer argument");
+  pr.alpha = const_cast<double *>(dalpha);
+  return cs_solve(pr, db, dwork);
+}
+
+int32_t dhqr_cs_load_contiguous_f64(dhqr_comm *cm, double *dA, int64_t m, int64_t n, int64_t lda, const double *dBlock,
+                                    int64_t ldb, double *dstage) {
+  CsProblem pr;
+  CHECK(cs_check(cm, dA, m, n, lda, &pr));
+  ENTER(pr.c);
+  if (!dstage) return set_err(DHQR_EINVAL, "null staging buffer");
+  return cs_load_contiguous(pr, dBlock, ldb, dstage);
+}
+int32_t dhqr_cs_store_contiguous_f64(dhqr_comm *cm, const double *dA, int64_t m, int64_t n, int64_t lda, double *dBlock,
+                                     int64_t ldb, double *dstage) {
+  CsProblem pr;
+  CHECK(cs_check(cm, dA, m, n, lda, &pr));
+  ENTER(pr.c);
+  if (!dstage) return set_err(DHQR_EINVAL, "null staging buffer");
+  return cs_store_contiguous(pr, dBlock, ldb, dstage);
+}
+
+// qr!(A::DArray) (src:115-120, 311-315) for ONE process of a multi-process job: hBlock is this process's
+// contiguous column block of the m x n matrix (DistributedArrays' default split, dhqr_cs_contiguous_range), on
+// the HOST; it is overwritten with the factored columns; halpha (n) receives the replicated alpha (the
+// reference's SharedArray, src:301-304).  Collective over the communicator.
+int32_t dhqr_cs_qr_darray_f64(dhqr_comm *cm, double *hBlock, int64_t m, int64_t n, int64_t ldb, double *halpha) {
+  CsProblem pr;
+  CHECK(cs_check(cm, nullptr, m, n, m, &pr, false));
+  ENTER(pr.c);
+  if (!halpha) return set_err(DHQR_EINVAL, "null alpha pointer");
+  int64_t lo, hi;
+  cs_contig_range(n, pr.P, pr.r, &lo, &hi);
+  const int64_t wr = hi - lo, wmax = n / pr.P + 1;
+  if (wr > 0 && (!hBlock || ldb < m)) return set_err(DHQR_EINVAL, "bad local block");
+  const int64_t ldd = (m + 1) & ~(int64_t)1;
+  double *dA = nullptr, *dBlk = nullptr, *dStage = nullptr, *dal = nullptr;
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMalloc((void **)&dA, (size_t)ldd * std::max<int64_t>(pr.ncl, 1) * sizeof(double)));
+    HIPCHECK(hipMalloc((void **)&dBlk, (size_t)m * std::max<int64_t>(wr, 1) * sizeof(double)));
+    HIPCHECK(hipMalloc((void **)&dStage, (size_t)m * std::max<int64_t>(wmax, DHQR_NBV) * sizeof(double)));
+    HIPCHECK(hipMalloc((void **)&dal, (size_t)n * sizeof(double)));
+    pr.A = dA;
+    pr.lda = ldd;
+    pr.alpha = dal;
+    dhqr_ctx *c = pr.c;
+    if (wr > 0)
+      HIPCHECK(hipMemcpy2DAsync(dBlk, m * sizeof(double), hBlock, ldb * sizeof(double), m * sizeof(double), wr,
+                                hipMemcpyHostToDevice, c->stream));
+    CHECK(cs_load_contiguous(pr, dBlk, m, dStage));
+    CHECK(cs_factor(pr));
+    CHECK(cs_store_contiguous(pr, dBlk, m, dStage));
+    if (wr > 0)
+      HIPCHECK(hipMemcpy2DAsync(hBlock, ldb * sizeof(double), dBlk, m * sizeof(double), m * sizeof(double), wr,
+                                hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(halpha, dal, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  (void)hipDeviceSynchronize();
+  double *ps[] = {dA, dBlk, dStage, dal};
+  for (double *p : ps)
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
+// ============================================================ multi-GPU: single-process handle (dhqr_mg.h)
+int32_t dhqr_mg_create(dhqr_mg **out, const int32_t *devices, int32_t ndev) {
+  if (!out) return set_err(DHQR_EINVAL, "null out-pointer");
+  *out = nullptr;
+  if (ndev < 1 || ndev > DHQR_MAX_RANKS) return set_err(DHQR_EINVAL, "ndev must be in [1, %d]", DHQR_MAX_RANKS);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  dhqr_mg *g = new dhqr_mg();
+  g->ndev = ndev;
+  g->rk.resize(ndev);
+  g->rc.assign(ndev, DHQR_OK);
+  g->err.assign(ndev, "");
+  for (int r = 0; r < ndev; ++r) g->dev.push_back(devices ? devices[r] : r);
+  auto init = [&]() -> int32_t {
+    for (int r = 0; r < ndev; ++r) CHECK(dhqr_create(&g->rk[r].c, g->dev[r]));
+    bool distinct = true;
+    for (int a = 0; a < ndev; ++a)
+      for (int b = a + 1; b < ndev; ++b)
+        if (g->dev[a] == g->dev[b]) distinct = false;
+    int want = COMM_RCCL;  // the product default: RCCL over xGMI
+    if (const char *e = getenv("DHQR_TRANSPORT")) {
+      if (!strcmp(e, "local")) want = COMM_LOCAL;
+      else if (!strcmp(e, "rccl")) want = COMM_RCCL;
+    }
+    if (ndev == 1) want = COMM_SELF;
+    else if (!distinct) want = COMM_LOCAL;  // RCCL cannot put two ranks on one device
+    std::vector<ncclComm_t> nc(ndev, nullptr);
+    if (want == COMM_RCCL) {
+      bool ok = rccl_load() == DHQR_OK;
+      if (ok) {
+        const ncclResult_t r = g_rccl.CommInitAll(nc.data(), ndev, g->dev.data());
+        if (r != ncclSuccess) {
+          ok = false;
+          fprintf(stderr, "libdhqr: ncclCommInitAll failed (%s); using peer copies\n", g_rccl.GetErrorString(r));
+        }
+      }
+      if (!ok) {
+        if (const char *e = getenv("DHQR_TRANSPORT"))
+          if (!strcmp(e, "rccl")) return set_err(DHQR_ECOMM, "RCCL requested (DHQR_TRANSPORT=rccl) but not available: %s", g_err);
+        want = COMM_LOCAL;
+      }
+    }
+    LocalWorld *w = nullptr;
+    if (want == COMM_LOCAL) {
+      CHECK(local_world_create(&w, g->dev.data(), ndev));
+      w->refs.store(ndev);
+      for (int a = 0; a < ndev; ++a) {  // peer access for the device-to-device copies (ignored when already on / same device)
+        (void)hipSetDevice(g->dev[a]);
+        for (int b = 0; b < ndev; ++b)
+          if (g->dev[a] != g->dev[b]) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, g->dev[a], g->dev[b]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(g->dev[b], 0);
+          }
+        (void)hipGetLastError();
+      }
+    }
+    for (int r = 0; r < ndev; ++r) {
+      CHECK(comm_new(&g->rk[r].cm, g->rk[r].c, want, ndev, r));
+      g->rk[r].cm->nccl = nc[r];
+      g->rk[r].cm->world = w;
+    }
+    g->transport = want;
+    for (int r = 0; r < ndev; ++r) g->rk[r].th = std::thread(mg_worker, g, r);
+    return DHQR_OK;
+  };
+  const int32_t rc = init();
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (rc != DHQR_OK) {
+    (void)dhqr_mg_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return DHQR_OK;
+}
+
+int32_t dhqr_mg_destroy(dhqr_mg *g) {
+  if (!g) return DHQR_OK;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  bool threads = false;
+  for (auto &k : g->rk) threads |= k.th.joinable();
+  if (threads) {
+    (void)mg_free_matrix(g);
+    {
+      std::lock_guard<std::mutex> lk(g->mu);
+      g->quit = true;
+    }
+    g->cv_job.notify_all();
+    for (auto &k : g->rk)
+      if (k.th.joinable()) k.th.join();
+  }
+  for (auto &k : g->rk) {
+    if (k.cm) (void)comm_free(k.cm);
+    if (k.c) (void)dhqr_destroy(k.c);
+  }
+  delete g;
+  if (prev >= 0) (void)hipSetDevice(prev);
+  return DHQR_OK;
+}
+
+int32_t dhqr_mg_info(dhqr_mg *g, int32_t *ndev, int32_t *transport, int64_t *m, int64_t *n) {
+  if (!g) return set_err(DHQR_EINVAL, "null handle");
+  if (ndev) *ndev = g->ndev;
+  if (transport) *transport = g->transport;
+  if (m) *m = g->m;
+  if (n) *n = g->n;
+  return DHQR_OK;
+}
+
+// Device-resident m x n matrix, block-cyclic columns over the devices (+ replicated alpha).
+int32_t dhqr_mg_alloc_f64(dhqr_mg *g, int64_t m, int64_t n) {
+  if (!g) return set_err(DHQR_EINVAL, "null handle");
+  if (m <= 0 || n <= 0 || m < n) return set_err(DHQR_EINVAL, "m >= n >= 1 required (m=%lld n=%lld)", (long long)m, (long long)n);
+  CHECK(mg_free_matrix(g));
+  g->m = m;
+  g->n = n;
+  return mg_run(g, [g, m, n](int r) -> int32_t {
+    MgRank &k = g->rk[r];
+    k.ncl = cs_local_cols(n, g->ndev, r);
+    k.lda = (m + 1) & ~(int64_t)1;
+    const size_t elems = (size_t)k.lda * std::max<int64_t>(k.ncl, 1);
+    if (hipMalloc((void **)&k.A, elems * sizeof(double)) != hipSuccess)
+      return set_err(DHQR_ENOMEM, "hipMalloc of the %lld x %lld local block failed", (long long)m, (long long)k.ncl);
+    k.capA = elems;
+    if (hipMalloc((void **)&k.alpha, (size_t)n * sizeof(double)) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc of alpha failed");
+    HIPCHECK(hipMemsetAsync(k.alpha, 0, (size_t)n * sizeof(double), k.c->stream));
+    return cs_prepare(mg_problem(g, r));
+  });
+}
+
+int32_t dhqr_mg_fill_uniform_f64(dhqr_mg *g, uint64_t seed) {
+  if (!g || !g->m) return set_err(DHQR_EINVAL, "no matrix allocated");
+  return mg_run(g, [g, seed](int r) -> int32_t {
+    MgRank &k = g->rk[r];
+    if (k.ncl == 0) return DHQR_OK;
+    return dhqr_fill_uniform_f64(k.c, k.A, g->m, k.ncl, k.lda, seed, g->m, 0, DHQR_NBV, g->ndev, r);
+  });
+}
+
+// householder!(A, alpha) over all devices; returns when every device has finished.
+int32_t dhqr_mg_factor_f64(dhqr_mg *g) {
+  if (!g || !g->m) return set_err(DHQR_EINVAL, "no matrix allocated");
+  return mg_run(g, [g](int r) -> int32_t {
+    const CsProblem pr = mg_problem(g, r);
+    CHECK(cs_factor(pr));
+    HIPCHECK(hipStreamSynchronize(pr.c->stream));
+    return DHQR_OK;
+  });
+}
+
+int32_t dhqr_mg_residual_f64(dhqr_mg *g, uint64_t seed, double *hrel) {
+  if (!g || !g->m) return set_err(DHQR_EINVAL, "no matrix allocated");
+  if (!hrel) return set_err(DHQR_EINVAL, "null output");
+  CHECK(mg_run(g, [g, seed](int r) -> int32_t {
+    MgRank &k = g->rk[r];
+    const size_t elems = (size_t)g->m * std::max<int64_t>(k.ncl, 1);
+    if (!k.W && hipMalloc((void **)&k.W, elems * sizeof(double)) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc failed");
+    if (!k.A0 && hipMalloc((void **)&k.A0, elems * sizeof(double)) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc failed");
+    return cs_residual(mg_problem(g, r), seed, k.W, k.A0, &k.resid);
+  }));
+  *hrel = g->rk[0].resid;
+  return DHQR_OK;
+}
+
+// Host matrix <-> the block-cyclic device blocks.
+static int32_t mg_transfer(dhqr_mg *g, double *hA, int64_t lda, double *halpha, bool upload) {
+  return mg_run(g, [g, hA, lda, halpha, upload](int r) -> int32_t {
+    MgRank &k = g->rk[r];
+    const int64_t NB = DHQR_NBV, K = cs_nblocks(g->n);
+    for (int64_t b = r, lc = 0; b < K; b += g->ndev, lc += NB) {
+      const int64_t w = std::min<int64_t>(NB, g->n - b * NB);
+      if (upload)
+        HIPCHECK(hipMemcpy2DAsync(k.A + lc * k.lda, k.lda * sizeof(double), hA + b * NB * lda, lda * sizeof(double),
+                                  g->m * sizeof(double), w, hipMemcpyHostToDevice, k.c->stream));
+      else
+        HIPCHECK(hipMemcpy2DAsync(hA + b * NB * lda, lda * sizeof(double), k.A + lc * k.lda, k.lda * sizeof(double),
+                                  g->m * sizeof(double), w, hipMemcpyDeviceToHost, k.c->stream));
+    }
+    if (halpha) {
+      if (upload)
+        HIPCHECK(hipMemcpyAsync(k.alpha, halpha, (size_t)g->n * sizeof(double), hipMemcpyHostToDevice, k.c->stream));
+      else if (r == 0)
+        HIPCHECK(hipMemcpyAsync(halpha, k.alpha, (size_t)g->n * sizeof(double), hipMemcpyDeviceToHost, k.c->stream));
+    }
+    HIPCHECK(hipStreamSynchronize(k.c->stream));
+    return DHQR_OK;
+  });
+}
+int32_t dhqr_mg_upload_f64(dhqr_mg *g, const double *hA, int64_t lda, const double *halpha) {
+  if (!g || !g->m) return set_err(DHQR_EINVAL, "no matrix allocated");
+  if (!hA || lda < g->m) return set_err(DHQR_EINVAL, "bad host matrix");
+  return mg_transfer(g, const_cast<double *>(hA), lda, const_cast<double *>(halpha), true);
+}
+int32_t dhqr_mg_download_f64(dhqr_mg *g, double *hA, int64_t lda, double *halpha) {
+  if (!g || !g->m) return set_err(DHQR_EINVAL, "no matrix allocated");
+  if (!hA || lda < g->m) return set_err(DHQR_EINVAL, "bad host matrix");
+  return mg_transfer(g, hA, lda, halpha, false);
+}
+
+// qr!(A; ndev) (src:311-315): host in / host out over all devices of the handle.
+int32_t dhqr_mg_qr_f64(dhqr_mg *g, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha) {
+  if (!g) return set_err(DHQR_EINVAL, "null handle");
+  if (no_columns(m, n)) return DHQR_OK;
+  CHECK(check_mat(hA, m, n, lda, true));
+  if (!halpha) return set_err(DHQR_EINVAL, "null alpha pointer");
+  if (g->m != m || g->n != n) CHECK(dhqr_mg_alloc_f64(g, m, n));
+  CHECK(mg_transfer(g, hA, lda, nullptr, true));
+  CHECK(dhqr_mg_factor_f64(g));
+  return mg_transfer(g, hA, lda, halpha, false);
+}
+
+// solve_householder!(b, H, alpha) with the factored matrix resident in the handle: hx[0:n] <- x; hb (m) is not modified.
+int32_t dhqr_mg_solve_f64(dhqr_mg *g, const double *hb, double *hx) {
+  if (!g || !g->m) return set_err(DHQR_EINVAL, "no matrix allocated");
+  if (!hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
+  return mg_run(g, [g, hb, hx](int r) -> int32_t {
+    MgRank &k = g->rk[r];
+    const int64_t m = g->m;
+    if (!k.vec && hipMalloc((void **)&k.vec, (size_t)(2 * m + 2 * DHQR_NBV + 16) * sizeof(double)) != hipSuccess)
+      return set_err(DHQR_ENOMEM, "hipMalloc failed");
+    double *db = k.vec, *du = k.vec + ((m + 15) & ~(int64_t)15);
+    HIPCHECK(hipMemcpyAsync(db, hb, (size_t)m * sizeof(double), hipMemcpyHostToDevice, k.c->stream));  // src:318 copy of b
+    CHECK(cs_solve(mg_problem(g, r), db, du));
+    if (r == 0) HIPCHECK(hipMemcpyAsync(hx, db, (size_t)g->n * sizeof(double), hipMemcpyDeviceToHost, k.c->stream));
+    HIPCHECK(hipStreamSynchronize(k.c->stream));
+    return DHQR_OK;
+  });
+}
+
+// `H \ b` (src:317-321) for a factored HOST matrix: uploads (hA, halpha), solves, returns x.
+int32_t dhqr_mg_ldiv_f64(dhqr_mg *g, const double *hA, int64_t m, int64_t n, int64_t lda, const double *halpha,
+                         const double *hb, double *hx) {
+  if (!g) return set_err(DHQR_EINVAL, "null handle");
+  if (no_columns(m, n)) return DHQR_OK;
+  CHECK(check_mat(hA, m, n, lda, true));
+  if (!halpha || !hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
+  if (g->m != m || g->n != n) CHECK(dhqr_mg_alloc_f64(g, m, n));
+  CHECK(mg_transfer(g, const_cast<double *>(hA), lda, const_cast<double *>(halpha), true));
+  return dhqr_mg_solve_f64(g, hb, hx);
+}
+
+int32_t dhqr_mg_set_profiling(dhqr_mg *g, int32_t on) {
+  if (!g) return set_err(DHQR_EINVAL, "null handle");
+  return mg_run(g, [g, on](int r) -> int32_t { return dhqr_set_profiling(g->rk[r].c, on); });
+}
+int32_t dhqr_mg_reset_stats(dhqr_mg *g) {
+  if (!g) return set_err(DHQR_EINVAL, "null handle");
+  return mg_run(g, [g](int r) -> int32_t { return dhqr_reset_stats(g->rk[r].c); });
+}
+int32_t dhqr_mg_get_stats(dhqr_mg *g, int32_t rank, dhqr_stats *out, int64_t *n_fast, int64_t *n_fallback, int64_t *bytes_bcast) {
+  if (!g || rank < 0 || rank >= g->ndev || !out) return set_err(DHQR_EINVAL, "bad arguments");
+  CHECK(mg_run(g, [g, rank, out](int r) -> int32_t { return r == rank ? dhqr_get_stats(g->rk[r].c, out) : DHQR_OK; }));
+  if (n_fast) *n_fast = g->rk[rank].c->n_fast;
+  if (n_fallback) *n_fallback = g->rk[rank].c->n_fallback;
+  if (bytes_bcast) *bytes_bcast = g->rk[rank].cm->bytes_bcast;
   return DHQR_OK;
 }
 

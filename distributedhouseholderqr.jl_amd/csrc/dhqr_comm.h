@@ -1,0 +1,334 @@
+// dhqr_comm.h -- rank-to-rank transport of the multi-GPU drivers (dhqr_dist.h).
+//
+// The reference ships every reflector to every process with `@spawnat` + `@sync` (src:141-143) and sums
+// partial dots with `sum(fetch.(futures))` (src:262-266).  Here the drivers are SPMD programs -- every rank
+// runs the same sequence of collective calls -- over one of three transports behind the same two operations
+// (broadcast of a device buffer, sum all-reduce of a small device buffer), all stream ordered:
+//
+//   RCCL      ncclBroadcast / ncclAllReduce over xGMI.  librccl.so is dlopen()ed when the first communicator
+//             is created (single-GPU users never load it).  One communicator per rank: created by
+//             ncclCommInitAll (all ranks in this process, one host thread each: dhqr_mg_*) or by
+//             ncclCommInitRank from a 128-byte unique id the host layer ships between processes
+//             (dhqr_comm_unique_id / dhqr_comm_create_rank: one Julia worker / one torchrun rank per GPU).
+//   LOCAL     ranks are host threads of ONE process: the receiver pulls the root's buffer with a peer copy
+//             (hipMemcpyAsync device-to-device; over xGMI when the devices differ) ordered by HIP events, the
+//             host threads hand the events over through a small sequence-numbered mailbox.  Used when RCCL
+//             cannot form the communicator (several ranks on one device, as in the 1-GPU tests) or on request
+//             (DHQR_TRANSPORT=local).
+//   CALLBACK  the host layer supplies the two operations (e.g. MPI.jl, Distributed.jl or torch.distributed):
+//             "bring your own communicator".  Host synchronous.
+//
+// Send-buffer reuse: after bcast() returns, the ROOT may only overwrite the buffer on a stream that has
+// called wait_consumed(ticket) (LOCAL: waits for the receivers' copy events; RCCL: stream order on the comm
+// stream already guarantees it; CALLBACK: synchronous).
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <thread>
+
+#define DHQR_COMM_RING 32   // LOCAL transport: mailbox slots (collectives in flight between host threads)
+#define DHQR_MAX_RANKS 64
+
+// ---- RCCL entry points resolved at run time ------------------------------------------------------
+struct RcclApi {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static std::atomic<int> g_rccl_state{0};  // 0 untried, 1 loaded, -1 unavailable
+
+static int32_t rccl_load() {
+  int st = g_rccl_state.load(std::memory_order_acquire);
+  if (st == 1) return DHQR_OK;
+  if (st == -1) return set_err(DHQR_ECOMM, "librccl.so is not loadable");
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (g_rccl_state.load() == 1) return DHQR_OK;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *h = nullptr;
+  for (const char *nm : names)
+    if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!h) {
+    g_rccl_state.store(-1);
+    return set_err(DHQR_ECOMM, "dlopen(librccl.so) failed: %s", dlerror());
+  }
+  bool ok = true;
+  auto sym = [&](const char *nm) {
+    void *p = dlsym(h, nm);
+    if (!p) ok = false;
+    return p;
+  };
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+  g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+  g_rccl.Broadcast = (decltype(g_rccl.Broadcast))sym("ncclBroadcast");
+  g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+  if (!ok) {
+    g_rccl_state.store(-1);
+    return set_err(DHQR_ECOMM, "librccl.so lacks a required symbol");
+  }
+  g_rccl.handle = h;
+  g_rccl_state.store(1, std::memory_order_release);
+  return DHQR_OK;
+}
+#define RCCLCHECK(expr)                                                                              \
+  do {                                                                                               \
+    ncclResult_t r_ = (expr);                                                                        \
+    if (r_ != ncclSuccess)                                                                           \
+      return set_err(DHQR_ECOMM, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+// ---- LOCAL transport: mailbox shared by the host threads of one process ---------------------------
+struct LocalSlot {
+  std::atomic<int64_t> seq{-1};       // collective sequence number currently published in this slot
+  const void *src[DHQR_MAX_RANKS];    // bcast: src[root]; all-reduce: every rank's buffer
+  hipEvent_t ready[DHQR_MAX_RANKS];   // recorded by the publisher after the data is final on its stream
+  std::atomic<int> posted{0};         // all-reduce: ranks that have published
+  std::atomic<int> pulled{0};         // ranks that have enqueued their copies
+  int need = 0;                       // value of `pulled` at which the slot may be recycled (P-1 bcast, P all-reduce)
+};
+struct LocalWorld {
+  int nranks = 0;
+  LocalSlot slot[DHQR_COMM_RING];
+  hipEvent_t done[DHQR_MAX_RANKS][DHQR_COMM_RING];  // done[r][s]: rank r's copies out of slot s have finished
+  std::atomic<int> refs{0};
+  std::atomic<int> abort{0};          // a rank failed: everybody stops waiting
+  std::atomic<int> bar_count{0};      // host barrier of the rank threads (sense reversing)
+  std::atomic<int> bar_gen{0};
+};
+
+static inline void comm_pause(int &spins) {
+  if (++spins < 2000) return;
+  std::this_thread::yield();
+}
+
+enum CommKind { COMM_SELF = 0, COMM_RCCL = 1, COMM_LOCAL = 2, COMM_CALLBACK = 3 };
+
+struct dhqr_comm {
+  dhqr_ctx *ctx = nullptr;
+  int kind = COMM_SELF, nranks = 1, rank = 0;
+  ncclComm_t nccl = nullptr;
+  LocalWorld *world = nullptr;
+  int64_t seq = 0;                     // LOCAL: number of collectives this rank has issued
+  double *scratch = nullptr;           // LOCAL all-reduce staging (nranks x cap doubles)
+  size_t scratch_cap = 0;
+  dhqr_bcast_fn cb_bcast = nullptr;
+  dhqr_allreduce_fn cb_allreduce = nullptr;
+  void *cb_user = nullptr;
+  int64_t bytes_bcast = 0, n_bcast = 0;  // statistics
+};
+
+__global__ __launch_bounds__(256) void k_sum_ranks(const double *__restrict__ part, int nranks, int64_t stride,
+                                                   int64_t count, double *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  double s = 0.0;
+  for (int r = 0; r < nranks; ++r) s += part[(int64_t)r * stride + e];  // fixed rank order: identical on every rank
+  out[e] = s;
+}
+
+// Broadcast `count` doubles at dbuf from rank `root`, ordered on `stream`.  *ticket (optional) identifies the
+// operation for comm_wait_consumed.
+static int32_t comm_bcast(dhqr_comm *cm, double *dbuf, int64_t count, int root, hipStream_t stream, int64_t *ticket) {
+  if (ticket) *ticket = -1;
+  if (cm->nranks == 1 || count <= 0) return DHQR_OK;
+  cm->bytes_bcast += count * 8;
+  cm->n_bcast++;
+  if (cm->kind == COMM_RCCL) {
+    RCCLCHECK(g_rccl.Broadcast(dbuf, dbuf, (size_t)count, ncclFloat64, root, cm->nccl, stream));
+    return DHQR_OK;
+  }
+  if (cm->kind == COMM_CALLBACK) {
+    HIPCHECK(hipStreamSynchronize(stream));
+    const int32_t rc = cm->cb_bcast(cm->cb_user, dbuf, count * 8, root, (void *)stream);
+    if (rc != 0) return set_err(DHQR_ECOMM, "broadcast callback failed (%d)", rc);
+    return DHQR_OK;
+  }
+  // LOCAL
+  LocalWorld *w = cm->world;
+  const int64_t s = cm->seq++;
+  LocalSlot &sl = w->slot[s % DHQR_COMM_RING];
+  int spins = 0;
+  if (cm->rank == root) {
+    // the slot's previous collective (s - RING) must have been consumed by everybody
+    while (sl.pulled.load(std::memory_order_acquire) < sl.need) {
+      if (w->abort.load()) return set_err(DHQR_ECOMM, "a peer rank failed");
+      comm_pause(spins);
+    }
+    HIPCHECK(hipEventRecord(sl.ready[root], stream));
+    sl.src[root] = dbuf;
+    sl.need = w->nranks - 1;
+    sl.pulled.store(0, std::memory_order_relaxed);
+    sl.posted.store(0, std::memory_order_relaxed);
+    sl.seq.store(s, std::memory_order_release);
+    if (ticket) *ticket = s;
+    return DHQR_OK;
+  }
+  while (sl.seq.load(std::memory_order_acquire) != s) {
+    if (w->abort.load()) return set_err(DHQR_ECOMM, "a peer rank failed");
+    comm_pause(spins);
+  }
+  HIPCHECK(hipStreamWaitEvent(stream, sl.ready[root], 0));
+  HIPCHECK(hipMemcpyAsync(dbuf, sl.src[root], (size_t)count * 8, hipMemcpyDeviceToDevice, stream));
+  HIPCHECK(hipEventRecord(w->done[cm->rank][s % DHQR_COMM_RING], stream));
+  sl.pulled.fetch_add(1, std::memory_order_acq_rel);
+  return DHQR_OK;
+}
+
+// Make `stream` wait until every receiver of broadcast `ticket` (rooted here) has copied the data out.
+static int32_t comm_wait_consumed(dhqr_comm *cm, int64_t ticket, hipStream_t stream) {
+  if (cm->kind != COMM_LOCAL || ticket < 0) return DHQR_OK;
+  LocalWorld *w = cm->world;
+  LocalSlot &sl = w->slot[ticket % DHQR_COMM_RING];
+  int spins = 0;
+  while (sl.seq.load(std::memory_order_acquire) == ticket && sl.pulled.load(std::memory_order_acquire) < w->nranks - 1) {
+    if (w->abort.load()) return set_err(DHQR_ECOMM, "a peer rank failed");
+    comm_pause(spins);
+  }
+  if (sl.seq.load(std::memory_order_acquire) != ticket) return DHQR_OK;
+  for (int r = 0; r < w->nranks; ++r)
+    if (r != cm->rank) HIPCHECK(hipStreamWaitEvent(stream, w->done[r][ticket % DHQR_COMM_RING], 0));
+  return DHQR_OK;
+}
+
+// In-place sum over the ranks of `count` doubles at dbuf (small buffers: partial dots, norms).  The result is
+// bitwise identical on every rank (fixed summation order).
+static int32_t comm_allreduce_sum(dhqr_comm *cm, double *dbuf, int64_t count, hipStream_t stream) {
+  if (cm->nranks == 1 || count <= 0) return DHQR_OK;
+  if (cm->kind == COMM_RCCL) {
+    RCCLCHECK(g_rccl.AllReduce(dbuf, dbuf, (size_t)count, ncclFloat64, ncclSum, cm->nccl, stream));
+    return DHQR_OK;
+  }
+  if (cm->kind == COMM_CALLBACK) {
+    HIPCHECK(hipStreamSynchronize(stream));
+    const int32_t rc = cm->cb_allreduce(cm->cb_user, dbuf, count, (void *)stream);
+    if (rc != 0) return set_err(DHQR_ECOMM, "all-reduce callback failed (%d)", rc);
+    return DHQR_OK;
+  }
+  LocalWorld *w = cm->world;
+  const int P = w->nranks;
+  if ((size_t)count * P > cm->scratch_cap) {
+    HIPCHECK(hipStreamSynchronize(stream));
+    if (cm->scratch) HIPCHECK(hipFree(cm->scratch));
+    cm->scratch = nullptr;
+    cm->scratch_cap = 0;
+    const size_t cap = ((size_t)count * P + 1023) & ~(size_t)1023;
+    if (hipMalloc((void **)&cm->scratch, cap * sizeof(double)) != hipSuccess)
+      return set_err(DHQR_ENOMEM, "hipMalloc of the all-reduce staging buffer failed");
+    cm->scratch_cap = cap;
+  }
+  const int64_t s = cm->seq++;
+  LocalSlot &sl = w->slot[s % DHQR_COMM_RING];
+  int spins = 0;
+  // rank 0 opens the slot (after its previous use was consumed), the others wait for it
+  if (cm->rank == 0) {
+    while (sl.pulled.load(std::memory_order_acquire) < sl.need) {
+      if (w->abort.load()) return set_err(DHQR_ECOMM, "a peer rank failed");
+      comm_pause(spins);
+    }
+    sl.need = P;
+    sl.pulled.store(0, std::memory_order_relaxed);
+    sl.posted.store(0, std::memory_order_relaxed);
+    sl.seq.store(s, std::memory_order_release);
+  } else {
+    while (sl.seq.load(std::memory_order_acquire) != s) {
+      if (w->abort.load()) return set_err(DHQR_ECOMM, "a peer rank failed");
+      comm_pause(spins);
+    }
+  }
+  HIPCHECK(hipEventRecord(sl.ready[cm->rank], stream));
+  sl.src[cm->rank] = dbuf;
+  sl.posted.fetch_add(1, std::memory_order_acq_rel);
+  while (sl.posted.load(std::memory_order_acquire) < P) {
+    if (w->abort.load()) return set_err(DHQR_ECOMM, "a peer rank failed");
+    comm_pause(spins);
+  }
+  for (int r = 0; r < P; ++r) {
+    if (r != cm->rank) HIPCHECK(hipStreamWaitEvent(stream, sl.ready[r], 0));
+    HIPCHECK(hipMemcpyAsync(cm->scratch + (size_t)r * count, sl.src[r], (size_t)count * 8, hipMemcpyDeviceToDevice, stream));
+  }
+  HIPCHECK(hipEventRecord(w->done[cm->rank][s % DHQR_COMM_RING], stream));
+  sl.pulled.fetch_add(1, std::memory_order_acq_rel);
+  // nobody may overwrite its dbuf (below) before every rank has copied it: wait for all copies
+  while (sl.pulled.load(std::memory_order_acquire) < P) {
+    if (w->abort.load()) return set_err(DHQR_ECOMM, "a peer rank failed");
+    comm_pause(spins);
+  }
+  for (int r = 0; r < P; ++r)
+    if (r != cm->rank) HIPCHECK(hipStreamWaitEvent(stream, w->done[r][s % DHQR_COMM_RING], 0));
+  hipLaunchKernelGGL(k_sum_ranks, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, (const double *)cm->scratch, P,
+                     count, count, dbuf);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+// Host barrier of the in-process ranks (LOCAL transport only; a no-op elsewhere): used where a broadcast SOURCE
+// buffer is recycled immediately (residual / solve / layout conversion), after each rank synchronised its stream.
+static int32_t comm_host_barrier(dhqr_comm *cm) {
+  if (!cm || cm->kind != COMM_LOCAL) return DHQR_OK;
+  LocalWorld *w = cm->world;
+  const int gen = w->bar_gen.load(std::memory_order_acquire);
+  if (w->bar_count.fetch_add(1, std::memory_order_acq_rel) == w->nranks - 1) {
+    w->bar_count.store(0, std::memory_order_relaxed);
+    w->bar_gen.store(gen + 1, std::memory_order_release);
+    return DHQR_OK;
+  }
+  int spins = 0;
+  while (w->bar_gen.load(std::memory_order_acquire) == gen) {
+    if (w->abort.load()) return set_err(DHQR_ECOMM, "a peer rank failed");
+    comm_pause(spins);
+  }
+  return DHQR_OK;
+}
+
+static void comm_abort(dhqr_comm *cm) {
+  if (cm && cm->world) cm->world->abort.store(1);
+}
+
+static int32_t comm_free(dhqr_comm *cm) {
+  if (!cm) return DHQR_OK;
+  if (cm->ctx) (void)hipSetDevice(cm->ctx->device);
+  if (cm->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(cm->nccl);
+  if (cm->scratch) (void)hipFree(cm->scratch);
+  if (cm->world && cm->world->refs.fetch_sub(1) == 1) {
+    for (int r = 0; r < cm->world->nranks; ++r)
+      for (int s = 0; s < DHQR_COMM_RING; ++s) {
+        if (cm->world->done[r][s]) (void)hipEventDestroy(cm->world->done[r][s]);
+        if (cm->world->slot[s].ready[r]) (void)hipEventDestroy(cm->world->slot[s].ready[r]);
+      }
+    delete cm->world;
+  }
+  delete cm;
+  return DHQR_OK;
+}
+
+// LOCAL world for `n` in-process ranks on devices dev[0..n): events are created on the owning device.
+static int32_t local_world_create(LocalWorld **out, const int *dev, int n) {
+  LocalWorld *w = new LocalWorld();
+  w->nranks = n;
+  for (int s = 0; s < DHQR_COMM_RING; ++s)
+    for (int r = 0; r < DHQR_MAX_RANKS; ++r) {
+      w->slot[s].ready[r] = nullptr;
+      w->slot[s].src[r] = nullptr;
+      w->done[r][s] = nullptr;
+    }
+  *out = w;
+  for (int r = 0; r < n; ++r) {
+    HIPCHECK(hipSetDevice(dev[r]));
+    for (int s = 0; s < DHQR_COMM_RING; ++s) {
+      HIPCHECK(hipEventCreateWithFlags(&w->slot[s].ready[r], hipEventDisableTiming));
+      HIPCHECK(hipEventCreateWithFlags(&w->done[r][s], hipEventDisableTiming));
+    }
+  }
+  return DHQR_OK;
+}

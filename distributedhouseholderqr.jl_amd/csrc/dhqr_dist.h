@@ -1,0 +1,592 @@
+// dhqr_dist.h -- the blocked factorisation driver, written once for P >= 1 ranks (included by dhqr_api.hip).
+//
+// Replaces householder!(A::DArray, alpha) (src:115-120: owners visited one after the other, every reflector
+// shipped to every process, src:141-143) by an SPMD program over a 1-D BLOCK-CYCLIC column split (block =
+// 128 columns = one panel; rank r owns panels k with k % P == r, stored contiguously: the trailing columns of
+// every rank are a suffix of its local storage).  At P == 1 it is the single-GPU look-ahead driver.
+//
+// Panels are grouped: a group is a PAIR of full-width panels (a, b = a+1) applied to the trailing matrix in one
+// pass (K = 256 MFMA update, pair_apply) or a single panel (last odd / partial panel, or pairing disabled).
+// Per rank three streams:
+//   lane  (high priority)  the critical chain: bring the blocks of the NEXT group's panels this rank owns up to
+//                          date, factor them (asynchronously verified R-first path), assemble the pair;
+//   comm                   one broadcast per panel of its operands [T | T' | alpha | status | V] (root = owner);
+//   wide  (caller's)       apply group g to the local blocks beyond group g+1 -- first the blocks of group g+2
+//                          ("head": the lane needs them next), then the rest.
+// Nothing in the loop waits on the host: panels are committed on the device (k_recon_decide) and the driver
+// reads one status word after the last launch; a rejected panel (ill-conditioned for CholeskyQR) makes every
+// later matrix update a no-op and the run resumes from that panel with the host-verified robust path.
+//
+// Group buffer (ring of CS_NGB, sized for the first group):
+//   [ tail_a | V_a : ldv x 128 | V_b : ldv x 128 | tail_b | S_ba ]      ldv = panel_ldv(rows of panel a)
+// V_b is stored shifted down by 128 rows (zeros above) so [V_a | V_b] is the K = 256 operand; panel a is
+// broadcast as the contiguous range [tail_a | V_a], panel b as [V_b | tail_b]: no repacking on any rank.
+#pragma once
+
+#define CS_NGB 4   // group buffers in flight
+#define CS_EVR 8   // event ring length (groups); panels use 2 * CS_EVR
+
+struct CsState {
+  bool init = false;
+  hipStream_t comm = nullptr;
+  hipEvent_t ev_group[CS_EVR], ev_wide[CS_EVR], ev_head[CS_EVR], ev_lane[CS_EVR];
+  hipEvent_t ev_ready[2 * CS_EVR], ev_recv[2 * CS_EVR];
+  hipEvent_t ev_start = nullptr, ev_end = nullptr;
+  int64_t ticket[2 * CS_EVR];
+  Buf gbuf[CS_NGB];
+  Buf vt;  // legacy packed panel buffer for re-applied panels (resume, residual, solve)
+};
+
+static int32_t cs_state_init(dhqr_ctx *c) {
+  if (!c->cs) c->cs = new CsState();
+  CsState &s = *c->cs;
+  if (s.init) return DHQR_OK;
+  int lo = 0, hi = 0;
+  HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  HIPCHECK(hipStreamCreateWithPriority(&s.comm, hipStreamNonBlocking, hi));
+  for (int i = 0; i < CS_EVR; ++i) {
+    HIPCHECK(hipEventCreateWithFlags(&s.ev_group[i], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&s.ev_wide[i], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&s.ev_head[i], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&s.ev_lane[i], hipEventDisableTiming));
+  }
+  for (int i = 0; i < 2 * CS_EVR; ++i) {
+    HIPCHECK(hipEventCreateWithFlags(&s.ev_ready[i], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&s.ev_recv[i], hipEventDisableTiming));
+    s.ticket[i] = -1;
+  }
+  HIPCHECK(hipEventCreateWithFlags(&s.ev_start, hipEventDisableTiming));
+  HIPCHECK(hipEventCreateWithFlags(&s.ev_end, hipEventDisableTiming));
+  s.init = true;
+  return DHQR_OK;
+}
+static void cs_state_free(dhqr_ctx *c) {
+  if (!c->cs) return;
+  CsState &s = *c->cs;
+  if (s.init) {
+    for (int i = 0; i < CS_EVR; ++i) {
+      (void)hipEventDestroy(s.ev_group[i]);
+      (void)hipEventDestroy(s.ev_wide[i]);
+      (void)hipEventDestroy(s.ev_head[i]);
+      (void)hipEventDestroy(s.ev_lane[i]);
+    }
+    for (int i = 0; i < 2 * CS_EVR; ++i) {
+      (void)hipEventDestroy(s.ev_ready[i]);
+      (void)hipEventDestroy(s.ev_recv[i]);
+    }
+    (void)hipEventDestroy(s.ev_start);
+    (void)hipEventDestroy(s.ev_end);
+    (void)hipStreamDestroy(s.comm);
+  }
+  for (Buf &b : s.gbuf)
+    if (b.p) (void)hipFree(b.p);
+  if (s.vt.p) (void)hipFree(s.vt.p);
+  delete c->cs;
+  c->cs = nullptr;
+}
+
+// ---- block-cyclic column map (block = DHQR_NBV columns) -------------------------------------------
+static inline int64_t cs_nblocks(int64_t n) { return (n + DHQR_NBV - 1) / DHQR_NBV; }
+static inline int64_t cs_local_cols(int64_t n, int P, int r) {
+  const int64_t K = cs_nblocks(n);
+  int64_t cols = 0;
+  for (int64_t k = r; k < K; k += P) cols += std::min<int64_t>(DHQR_NBV, n - k * DHQR_NBV);
+  return cols;
+}
+
+struct CsProblem {
+  dhqr_ctx *c;
+  dhqr_comm *cm;   // nullptr: single rank
+  double *A;       // local block: m x cs_local_cols(n, P, r), leading dimension lda
+  int64_t m, n, lda;
+  double *alpha;   // n doubles, replicated on every rank
+  int P, r;
+  int64_t K, ncl;
+  int64_t width(int64_t k) const { return std::min<int64_t>(DHQR_NBV, n - k * DHQR_NBV); }
+  int owner(int64_t k) const { return (int)(k % P); }
+  bool mine(int64_t k) const { return owner(k) == r; }
+  int64_t lcol(int64_t k) const { return (k / P) * DHQR_NBV; }   // local column of an owned block
+  int64_t first_local_ge(int64_t k) const { return k + (((int64_t)r - k % P) % P + P) % P; }
+  // local columns holding the global blocks >= k: [*lo, ncl)
+  int64_t local_from(int64_t k) const {
+    const int64_t kk = first_local_ge(k);
+    return kk < K ? lcol(kk) : ncl;
+  }
+};
+
+struct CsGroup {
+  int64_t a;      // first panel
+  int np;         // 1 or 2 panels
+  int64_t last() const { return a + np - 1; }
+};
+
+struct CsGroupBuf {
+  double *tailA, *VA, *VB, *tailB, *Sba;
+  int64_t ldv, rows_a;
+  PanelBuf pa() const { return tail_view(VA, ldv, tailA); }
+  PanelBuf pb() const { return tail_view(VB + DHQR_NBV, ldv, tailB); }  // V_b proper starts 128 rows down
+  double *region(int idx) const { return idx == 0 ? tailA : VB; }
+  int64_t region_elems() const { return ldv * DHQR_NBV + panel_tail_elems(); }
+};
+static inline size_t cs_gbuf_elems(int64_t m) {
+  return (size_t)(2 * panel_tail_elems() + 2 * panel_ldv(m) * DHQR_NBV + (int64_t)DHQR_NBV * DHQR_NBV);
+}
+static inline CsGroupBuf cs_gbuf_view(double *base, int64_t rows_a) {
+  CsGroupBuf g;
+  g.rows_a = rows_a;
+  g.ldv = panel_ldv(rows_a);
+  g.tailA = base;
+  g.VA = base + panel_tail_elems();
+  g.VB = g.VA + g.ldv * DHQR_NBV;
+  g.tailB = g.VB + g.ldv * DHQR_NBV;
+  g.Sba = g.tailB + panel_tail_elems();
+  return g;
+}
+
+// One asynchronous pass over the panels [kstart, K).  `robust_first`: panel kstart is factored with the
+// host-verified path (resume after a rejected panel).  Returns in *failed the index of the first rejected panel
+// (INT_MAX: none).  fast_idx collects the panels this rank enqueued on the fast path.
+static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, int *failed, std::vector<int64_t> &fast_idx) {
+  dhqr_ctx *c = pr.c;
+  dhqr_comm *cm = pr.cm;
+  CsState &S = *c->cs;
+  const int64_t NB = DHQR_NBV, K = pr.K, m = pr.m, lda = pr.lda;
+  const int P = pr.P;
+  const bool pairing = c->pair && (pr.n >= c->pair_min_n || P > 1);
+  // ---- groups
+  std::vector<CsGroup> groups;
+  for (int64_t k = kstart; k < K;) {
+    CsGroup g;
+    g.a = k;
+    g.np = (pairing && k + 1 < K && pr.width(k) == NB && pr.width(k + 1) == NB) ? 2 : 1;
+    groups.push_back(g);
+    k += g.np;
+  }
+  const int G = (int)groups.size();
+  if (G == 0) {
+    *failed = INT_MAX;
+    return DHQR_OK;
+  }
+  auto gview = [&](int g) { return cs_gbuf_view(S.gbuf[g % CS_NGB].p, m - groups[g].a * NB); };
+
+  hipStream_t sW = c->stream, sL = c->hi, sC = S.comm;
+  auto on = [&](hipStream_t s, int wsi) { c->stream = s; c->cur_ws = wsi; };
+  const int saved_epoch = c->epoch;
+  auto apply_group = [&](int g, int64_t lstart, int64_t ncols) -> int32_t {  // group g -> local columns [lstart, lstart+ncols)
+    if (ncols <= 0) return DHQR_OK;
+    const CsGroup &gr = groups[g];
+    const CsGroupBuf gb = gview(g);
+    double *C = pr.A + gr.a * NB + lstart * lda;
+    c->epoch = (int)gr.last();
+    int32_t rc;
+    if (gr.np == 2)
+      rc = pair_apply(c, gb.VA, gb.ldv, gb.rows_a, gb.pa().T, gb.pb().T, gb.Sba, C, ncols, lda);
+    else
+      rc = panel_apply(c, gb.pa(), gb.rows_a, C, ncols, lda, 1);
+    return rc;
+  };
+  // lane work accounted to the panel group of the statistics
+  auto lane_begin = [&](bool &was) -> int32_t {
+    CHECK(prof_begin(c, CAT_PANEL));
+    was = c->profiling;
+    c->profiling = false;
+    return DHQR_OK;
+  };
+  auto lane_end = [&](bool was) -> int32_t {
+    c->profiling = was;
+    return prof_end(c);
+  };
+
+  // produce group h: owners update + factor their panels (lane), everybody takes part in the broadcasts (comm),
+  // the pair cross term is built (lane).  prev = h - 1 (or -1 for the first group).
+  auto produce = [&](int h) -> int32_t {
+    const CsGroup &gr = groups[h];
+    const CsGroupBuf gb = gview(h);
+    const int prev = h - 1;
+    // writers into this buffer slot must wait for the readers of group h - CS_NGB
+    auto guard = [&](hipStream_t s) -> int32_t {
+      if (h >= CS_NGB) {
+        HIPCHECK(hipStreamWaitEvent(s, S.ev_wide[(h - CS_NGB) % CS_EVR], 0));
+        HIPCHECK(hipStreamWaitEvent(s, S.ev_lane[(h - CS_NGB + 1) % CS_EVR], 0));
+        if (cm)
+          for (int idx = 0; idx < groups[h - CS_NGB].np; ++idx) {
+            const int64_t y = groups[h - CS_NGB].a + idx;
+            if (pr.mine(y)) CHECK(comm_wait_consumed(cm, S.ticket[y % (2 * CS_EVR)], s));
+          }
+      }
+      return DHQR_OK;
+    };
+    bool merged_update = false;
+    for (int idx = 0; idx < gr.np; ++idx) {
+      const int64_t x = gr.a + idx, w = pr.width(x), rows = m - x * NB;
+      const PanelBuf pbx = idx == 0 ? gb.pa() : gb.pb();
+      const int pe = (int)(x % (2 * CS_EVR));
+      if (pr.mine(x)) {
+        on(sL, 1);
+        CHECK(guard(sL));
+        const int64_t lc = pr.lcol(x);
+        bool was = false;
+        if (prev >= 0 && !merged_update) {
+          // block x must carry every group before `prev`: done by the head (or whole) wide update of prev - 1
+          if (prev >= 1) HIPCHECK(hipStreamWaitEvent(sL, (P > 1 ? S.ev_head : S.ev_wide)[(prev - 1) % CS_EVR], 0));
+          int64_t ncols = w;
+          if (P == 1 && gr.np == 2 && idx == 0) {  // both panels are local and adjacent: one 256-column update
+            ncols += pr.width(x + 1);
+            merged_update = true;
+          }
+          CHECK(lane_begin(was));
+          const int32_t rc = apply_group(prev, lc, ncols);
+          CHECK(lane_end(was));
+          CHECK(rc);
+        }
+        if (idx == 1) {  // panel a of this group -> block b
+          if (!pr.mine(gr.a)) HIPCHECK(hipStreamWaitEvent(sL, S.ev_recv[(int)(gr.a % (2 * CS_EVR))], 0));
+          CHECK(lane_begin(was));
+          c->epoch = (int)gr.a;
+          const int32_t rc = panel_apply(c, gb.pa(), gb.rows_a, pr.A + gr.a * NB + lc * lda, w, lda, 1);
+          CHECK(lane_end(was));
+          CHECK(rc);
+          hipLaunchKernelGGL(k_zero_rows, dim3(DHQR_NBV), dim3(128), 0, sL, gb.VB, gb.ldv, (int)NB);
+        }
+        double *Pp = pr.A + x * NB + lc * lda;
+        c->epoch = saved_epoch;
+        if (panel_fast_eligible(c, rows, w) && !(robust_first && x == kstart)) {
+          CHECK(panel_fast_enqueue(c, Pp, rows, lda, pr.alpha + x * NB, pbx, c->cholqr_passes, (int)x));
+          fast_idx.push_back(x);
+        } else {
+          // Short / partial panels (the last one or two of a factorisation) and the panel a resumed run starts
+          // with use kernels that write unconditionally.  Inside a run they may only execute if no earlier
+          // panel was rejected, which needs the one status read of the lane the asynchronous path avoids.
+          bool run_it = true;
+          if (x != kstart) {
+            int f = 0;
+            CHECK(status_read(c, &f));  // the lane has already waited for every earlier panel's status
+            run_it = (f == INT_MAX);
+          }
+          if (run_it) CHECK(factor_panel_sync(c, Pp, rows, w, lda, pr.alpha + x * NB, pbx));
+          hipLaunchKernelGGL(k_set_statword, dim3(1), dim3(64), 0, sL, (const int *)c->dstat, pbx.alpha + DHQR_NBV);
+        }
+        HIPCHECK(hipEventRecord(S.ev_ready[pe], sL));
+        if (cm && P > 1) {
+          HIPCHECK(hipStreamWaitEvent(sC, S.ev_ready[pe], 0));
+          CHECK(comm_bcast(cm, gb.region(idx), gb.region_elems(), pr.r, sC, &S.ticket[pe]));
+          HIPCHECK(hipEventRecord(S.ev_recv[pe], sC));
+        }
+      } else {
+        CHECK(guard(sC));
+        CHECK(comm_bcast(cm, gb.region(idx), gb.region_elems(), pr.owner(x), sC, nullptr));
+        hipLaunchKernelGGL(k_adopt_status, dim3(1), dim3(64), 0, sC, (const double *)(pbx.alpha + DHQR_NBV), c->dstat);
+        hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, sC, (const double *)pbx.alpha, (int)w,
+                           pr.alpha + x * NB, (double *)nullptr, (const int *)c->dstat, (int)x);
+        HIPCHECK(hipEventRecord(S.ev_recv[pe], sC));
+      }
+    }
+    // assemble the group on the lane: needs every panel of the group locally
+    on(sL, 1);
+    for (int idx = 0; idx < gr.np; ++idx)
+      if (!pr.mine(gr.a + idx)) HIPCHECK(hipStreamWaitEvent(sL, S.ev_recv[(int)((gr.a + idx) % (2 * CS_EVR))], 0));
+    if (gr.np == 2 && gr.last() + 1 < K) {
+      bool was = false;
+      CHECK(lane_begin(was));
+      const int32_t rc = pair_cross_gram(c, gb.VA, gb.ldv, gb.rows_a, gb.Sba);
+      CHECK(lane_end(was));
+      CHECK(rc);
+    }
+    HIPCHECK(hipEventRecord(S.ev_group[h % CS_EVR], sL));
+    HIPCHECK(hipEventRecord(S.ev_lane[h % CS_EVR], sL));
+    LAUNCHCHECK();
+    return DHQR_OK;
+  };
+
+  auto body = [&]() -> int32_t {
+    // order the lane and the comm stream after whatever the caller queued (e.g. the fill)
+    HIPCHECK(hipEventRecord(S.ev_start, sW));
+    HIPCHECK(hipStreamWaitEvent(sL, S.ev_start, 0));
+    HIPCHECK(hipStreamWaitEvent(sC, S.ev_start, 0));
+    CHECK(produce(0));
+    for (int g = 0; g < G; ++g) {
+      const CsGroup &gr = groups[g];
+      if (gr.last() + 1 >= K) break;  // nothing to the right of this group
+      // ---- wide stream: group g -> local blocks beyond group g+1
+      on(sW, 0);
+      HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[g % CS_EVR], 0));
+      const int64_t after_next = groups[g + 1].last() + 1;
+      int64_t lo = pr.local_from(after_next);
+      if (P > 1 && g + 2 < G) {  // head: the blocks of group g+2 this rank owns (needed by the lane next)
+        const int64_t hi = pr.local_from(groups[g + 2].last() + 1);
+        CHECK(apply_group(g, lo, hi - lo));
+        lo = hi;
+      }
+      HIPCHECK(hipEventRecord(S.ev_head[g % CS_EVR], sW));
+      CHECK(apply_group(g, lo, pr.ncl - lo));
+      HIPCHECK(hipEventRecord(S.ev_wide[g % CS_EVR], sW));
+      // ---- lane + comm: group g+1
+      CHECK(produce(g + 1));
+    }
+    // join: the caller's stream owns the result
+    on(sW, 0);
+    HIPCHECK(hipEventRecord(S.ev_end, sL));
+    HIPCHECK(hipStreamWaitEvent(sW, S.ev_end, 0));
+    HIPCHECK(hipEventRecord(S.ev_end, sC));
+    HIPCHECK(hipStreamWaitEvent(sW, S.ev_end, 0));
+    return DHQR_OK;
+  };
+  int32_t rc = body();
+  on(sW, 0);
+  c->epoch = saved_epoch;
+  if (rc == DHQR_OK) rc = status_read(c, failed);
+  return rc;
+}
+
+// Workspaces of one rank sized up front for an m x n problem: nothing is (re)allocated while streams run.
+static int32_t cs_prepare(const CsProblem &pr) {
+  dhqr_ctx *c = pr.c;
+  CHECK(cs_state_init(c));
+  const int64_t NB = DHQR_NBV, m = pr.m;
+  const size_t NN = (size_t)NB * NB;
+  for (int s = 0; s < CS_NGB; ++s) CHECK(ensure(c, c->cs->gbuf[s], cs_gbuf_elems(m)));
+  CHECK(ensure(c, c->cs->vt, (size_t)panel_elems(m)));
+  CHECK(ensure(c, c->vts, (size_t)panel_elems(m)));
+  const size_t ncmax = (size_t)std::max<int64_t>(pr.ncl, 2 * NB);
+  const size_t ntmax = (ncmax + 127) / 128;
+  const size_t w1cap = NN * (2048 + ntmax + 64);
+  for (int s = 0; s < 2; ++s) {
+    CHECK(ensure(c, c->ws[s].w1, s == 0 ? w1cap : NN * 1100));
+    CHECK(ensure(c, c->ws[s].w1r, (size_t)NB * ncmax));
+    CHECK(ensure(c, c->ws[s].w1r2, (size_t)NB * ncmax));
+    CHECK(ensure(c, c->ws[s].w2, (size_t)2 * NB * ncmax));
+  }
+  CHECK(ensure(c, c->spart, (size_t)256 * NN));
+  CHECK(ensure(c, c->sfull, NN));
+  CHECK(ensure(c, c->rbuf, 6 * NN + 1024));
+  CHECK(ensure(c, c->scratch, 4096));
+  return DHQR_OK;
+}
+
+// householder!(A, alpha) / householder!(A::DArray, alpha) (src:113-120) on this rank's block-cyclic columns.
+// Collective over pr.cm; synchronous on return (one status read per pass; a second pass only after a rejected panel).
+static int32_t cs_factor(const CsProblem &pr) {
+  dhqr_ctx *c = pr.c;
+  const int64_t NB = DHQR_NBV;
+  CHECK(cs_prepare(pr));
+  CHECK(status_reset(c));
+  int64_t ks = 0;
+  bool robust = false;
+  std::vector<int64_t> fast_idx;
+  for (int pass = 0; ks < pr.K; ++pass) {
+    if (pass > pr.K + 2) return set_err(DHQR_EINVAL, "internal error: the blocked driver does not make progress");
+    int failed = INT_MAX;
+    fast_idx.clear();
+    CHECK(cs_run(pr, ks, robust, &failed, fast_idx));
+    for (int64_t x : fast_idx)
+      if (x < failed) c->n_fast++;
+    if (failed == INT_MAX) break;
+    // ---- resume: panels < failed are committed; matrix updates with epoch >= failed did not run
+    CHECK(status_reset(c));
+    const bool pairing = c->pair && (pr.n >= c->pair_min_n || pr.P > 1);
+    bool is_b = false;
+    for (int64_t k = ks; k <= failed;) {  // replay the grouping of the failed pass
+      const int np = (pairing && k + 1 < pr.K && pr.width(k) == NB && pr.width(k + 1) == NB) ? 2 : 1;
+      if (np == 2 && k + 1 == failed) is_b = true;
+      k += np;
+    }
+    if (is_b) {
+      // the pair's first panel is committed and was applied to block `failed` only: apply it to the rest
+      const int64_t a = failed - 1, rows_a = pr.m - a * NB;
+      const PanelBuf pb = vt_view(c->cs->vt.p, rows_a);
+      if (pr.mine(a)) CHECK(panel_pack_and_t(c, pr.A + a * NB + pr.lcol(a) * pr.lda, rows_a, NB, pr.lda, pr.alpha + a * NB, pb));
+      if (pr.cm && pr.P > 1) CHECK(comm_bcast(pr.cm, c->cs->vt.p, panel_elems(rows_a), pr.owner(a), c->stream, nullptr));
+      const int64_t lo = pr.local_from(failed + 1);
+      CHECK(panel_apply(c, pb, rows_a, pr.A + a * NB + lo * pr.lda, pr.ncl - lo, pr.lda, 1));
+      if (pr.cm && pr.P > 1) HIPCHECK(hipStreamSynchronize(c->stream));  // vt is reused by the next resume
+    }
+    ks = failed;
+    robust = true;
+  }
+  return DHQR_OK;
+}
+
+// ||A - QR||_F / ||A||_F with A = u01(seed) regenerated on the device: every rank forms its columns of Q*R by
+// re-applying the panels in reverse order (one broadcast per panel again).  dW, dA0: m x ncl scratch (ld = m).
+static int32_t cs_residual(const CsProblem &pr, uint64_t seed, double *dW, double *dA0, double *hrel) {
+  dhqr_ctx *c = pr.c;
+  const int64_t NB = DHQR_NBV, m = pr.m, ncl = pr.ncl;
+  CHECK(cs_prepare(pr));
+  const int64_t ldw = m;
+  if (ncl > 0) {
+    dim3 grid((unsigned)std::min<int64_t>((m + 255) / 256, 128), (unsigned)std::min<int64_t>(ncl, 32768));
+    hipLaunchKernelGGL(k_form_r0, grid, dim3(256), 0, c->stream, (const double *)pr.A, pr.lda, (const double *)pr.alpha, m,
+                       ncl, dW, ldw, NB, pr.P, pr.r);
+  }
+  const bool was = c->profiling;
+  c->profiling = false;
+  auto body = [&]() -> int32_t {
+    for (int64_t k = pr.K - 1; k >= 0; --k) {
+      const int64_t rows = m - k * NB;
+      const PanelBuf pb = vt_view(c->cs->vt.p, rows);
+      if (pr.mine(k))
+        CHECK(panel_pack_and_t(c, pr.A + k * NB + pr.lcol(k) * pr.lda, rows, pr.width(k), pr.lda, nullptr, pb));
+      if (pr.cm && pr.P > 1) CHECK(comm_bcast(pr.cm, c->cs->vt.p, panel_elems(rows), pr.owner(k), c->stream, nullptr));
+      const int64_t lo = pr.local_from(k);
+      if (ncl - lo > 0) CHECK(panel_apply(c, pb, rows, dW + k * NB + lo * ldw, ncl - lo, ldw, 0));
+      // LOCAL transport: the root must not repack the buffer before the others have copied it
+      if (pr.cm && pr.cm->kind == COMM_LOCAL) HIPCHECK(hipStreamSynchronize(c->stream));
+      if (pr.cm && pr.cm->kind == COMM_LOCAL) CHECK(comm_host_barrier(pr.cm));
+    }
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  c->profiling = was;
+  CHECK(rc);
+  double h[2] = {0.0, 0.0};
+  CHECK(ensure(c, c->scratch, 4096));
+  if (ncl > 0) {
+    const int64_t total = m * ncl;
+    const unsigned gridf = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_fill_uniform, dim3(gridf), dim3(256), 0, c->stream, dA0, m, ncl, m, seed, m, (int64_t)0, NB, pr.P,
+                       pr.r);
+    const int nblk = 1024;
+    hipLaunchKernelGGL(k_diff_norms, dim3(nblk), dim3(256), 0, c->stream, (const double *)dA0, m, (const double *)dW, ldw, m,
+                       ncl, c->scratch.p);
+    hipLaunchKernelGGL(k_sum2_final, dim3(1), dim3(256), 0, c->stream, (const double *)c->scratch.p, nblk, c->scratch.p + 2048);
+  } else {
+    HIPCHECK(hipMemsetAsync(c->scratch.p + 2048, 0, 2 * sizeof(double), c->stream));
+  }
+  LAUNCHCHECK();
+  if (pr.cm && pr.P > 1) CHECK(comm_allreduce_sum(pr.cm, c->scratch.p + 2048, 2, c->stream));
+  HIPCHECK(hipMemcpyAsync(h, c->scratch.p + 2048, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  *hrel = std::sqrt(h[0] / h[1]);
+  return DHQR_OK;
+}
+
+// solve_householder!(b, H, alpha) on the column split (src:226-282).  db (length m, the same on every rank) is
+// overwritten; x = db[0:n] on every rank.  Q'b: the owner of each block applies it and hands the updated tail
+// of b on (the reference walks the owners sequentially with b in shared memory, src:226-230).  Back substitution:
+// every rank accumulates the contribution of ITS columns to the rows above; per block one all-reduce sums those
+// partial dots (the reference's sum(fetch.(futures)), src:262-266), the owner solves the diagonal block and
+// broadcasts x.  du: scratch of m + 128 doubles.
+static int32_t cs_solve(const CsProblem &pr, double *db, double *du) {
+  dhqr_ctx *c = pr.c;
+  const int64_t NB = DHQR_NBV, m = pr.m;
+  dhqr_comm *cm = (pr.cm && pr.P > 1) ? pr.cm : nullptr;
+  CHECK(cs_prepare(pr));
+  const bool was = c->profiling;
+  CHECK(prof_begin(c, CAT_SOLVE));
+  c->profiling = false;
+  double *ds = du + m;  // 128 partial dots
+  auto sync_local = [&]() -> int32_t {
+    if (cm && cm->kind == COMM_LOCAL) {
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      CHECK(comm_host_barrier(cm));
+    }
+    return DHQR_OK;
+  };
+  auto body = [&]() -> int32_t {
+    for (int64_t k = 0; k < pr.K; ++k) {
+      const int64_t c0 = k * NB, rows = m - c0;
+      if (pr.mine(k)) {
+        const PanelBuf pb = vt_view(c->cs->vt.p, rows);
+        CHECK(panel_pack_and_t(c, pr.A + c0 + pr.lcol(k) * pr.lda, rows, pr.width(k), pr.lda, nullptr, pb));
+        CHECK(panel_apply(c, pb, rows, db + c0, 1, m, 1));
+      }
+      if (cm) {
+        CHECK(comm_bcast(cm, db + c0, rows, pr.owner(k), c->stream, nullptr));
+        CHECK(sync_local());
+      }
+    }
+    HIPCHECK(hipMemsetAsync(du, 0, (size_t)(m + NB) * sizeof(double), c->stream));
+    for (int64_t k = pr.K - 1; k >= 0; --k) {
+      const int64_t c0 = k * NB, w = pr.width(k);
+      HIPCHECK(hipMemcpyAsync(ds, du + c0, (size_t)w * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      if (cm) CHECK(comm_allreduce_sum(cm, ds, w, c->stream));
+      if (pr.mine(k)) {
+        // global column j of R is read at base + j*lda
+        const double *base = pr.A + (pr.lcol(k) - c0) * pr.lda;
+        hipLaunchKernelGGL(k_axpy1, dim3(1), dim3(128), 0, c->stream, db + c0, (const double *)ds, (int)w);
+        CHECK(dhqr_backsub_block_f64(c, base, pr.lda, pr.alpha, db, c0, c0 + w, 1, 0));
+      }
+      if (cm) {
+        CHECK(comm_bcast(cm, db + c0, w, pr.owner(k), c->stream, nullptr));
+        CHECK(sync_local());
+      }
+      if (pr.mine(k) && c0 > 0) {
+        const double *base = pr.A + (pr.lcol(k) - c0) * pr.lda;
+        HIPCHECK(hipMemcpyAsync(du + c0, db + c0, (size_t)w * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        CHECK(dhqr_backsub_block_f64(c, base, pr.lda, pr.alpha, du, c0, c0 + w, 0, 1));
+        HIPCHECK(hipMemsetAsync(du + c0, 0, (size_t)w * sizeof(double), c->stream));
+      }
+    }
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  c->profiling = was;
+  CHECK(rc);
+  CHECK(prof_end(c));
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+// ---- the reference's DArray layout (src:115-120, test/runtests.jl:71) ----------------------------
+// DistributedArrays' default split gives every process ONE contiguous column block (the first n % P processes get
+// one column more).  The factorisation runs block-cyclically (contiguous blocks idle the owners of the early
+// columns: <= 5.4x on 8 GPUs), so a caller holding the reference's layout converts on the way in and out: one
+// broadcast of every rank's block per direction -- O(mn) traffic next to the O(mn^2) factorisation.
+static inline void cs_contig_range(int64_t n, int P, int s, int64_t *lo, int64_t *hi) {
+  const int64_t q = n / P, rem = n % P;
+  *lo = s * q + std::min<int64_t>(s, rem);
+  *hi = *lo + q + (s < rem ? 1 : 0);
+}
+// contiguous block (dBlk, m x w_r, ld ldb) -> block-cyclic pr.A.  dStage: m x max(n/P + 1, 128) doubles.
+static int32_t cs_load_contiguous(const CsProblem &pr, const double *dBlk, int64_t ldb, double *dStage) {
+  dhqr_ctx *c = pr.c;
+  const int64_t NB = DHQR_NBV, m = pr.m;
+  dhqr_comm *cm = (pr.cm && pr.P > 1) ? pr.cm : nullptr;
+  for (int s = 0; s < pr.P; ++s) {
+    int64_t lo, hi;
+    cs_contig_range(pr.n, pr.P, s, &lo, &hi);
+    const int64_t wblk = hi - lo;
+    if (wblk == 0) continue;
+    if (s == pr.r)
+      HIPCHECK(hipMemcpy2DAsync(dStage, m * sizeof(double), dBlk, ldb * sizeof(double), m * sizeof(double), wblk,
+                                hipMemcpyDeviceToDevice, c->stream));
+    if (cm) CHECK(comm_bcast(cm, dStage, m * wblk, s, c->stream, nullptr));
+    // the pieces of [lo, hi) this rank owns in the block-cyclic layout (a piece never crosses a cyclic block)
+    for (int64_t k = lo / NB; k <= (hi - 1) / NB; ++k) {
+      if (!pr.mine(k)) continue;
+      const int64_t g0 = std::max<int64_t>(k * NB, lo), g1 = std::min<int64_t>(std::min<int64_t>((k + 1) * NB, hi), pr.n);
+      if (g1 <= g0) continue;
+      HIPCHECK(hipMemcpy2DAsync(pr.A + (pr.lcol(k) + g0 - k * NB) * pr.lda, pr.lda * sizeof(double), dStage + (g0 - lo) * m,
+                                m * sizeof(double), m * sizeof(double), g1 - g0, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (cm && cm->kind == COMM_LOCAL) {  // the stage is reused by the next source rank
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      CHECK(comm_host_barrier(cm));
+    }
+  }
+  return DHQR_OK;
+}
+// block-cyclic pr.A -> this rank's contiguous block (dBlk, m x w_r, ld ldb): one broadcast per cyclic block.
+static int32_t cs_store_contiguous(const CsProblem &pr, double *dBlk, int64_t ldb, double *dStage) {
+  dhqr_ctx *c = pr.c;
+  const int64_t NB = DHQR_NBV, m = pr.m;
+  dhqr_comm *cm = (pr.cm && pr.P > 1) ? pr.cm : nullptr;
+  int64_t lo, hi;
+  cs_contig_range(pr.n, pr.P, pr.r, &lo, &hi);
+  for (int64_t k = 0; k < pr.K; ++k) {
+    const int64_t w = pr.width(k), g0 = k * NB;
+    if (pr.mine(k))
+      HIPCHECK(hipMemcpy2DAsync(dStage, m * sizeof(double), pr.A + pr.lcol(k) * pr.lda, pr.lda * sizeof(double),
+                                m * sizeof(double), w, hipMemcpyDeviceToDevice, c->stream));
+    if (cm) CHECK(comm_bcast(cm, dStage, m * w, pr.owner(k), c->stream, nullptr));
+    const int64_t i0 = std::max<int64_t>(g0, lo), i1 = std::min<int64_t>(g0 + w, hi);
+    if (i1 > i0)
+      HIPCHECK(hipMemcpy2DAsync(dBlk + (i0 - lo) * ldb, ldb * sizeof(double), dStage + (i0 - g0) * m, m * sizeof(double),
+                                m * sizeof(double), i1 - i0, hipMemcpyDeviceToDevice, c->stream));
+    if (cm && cm->kind == COMM_LOCAL) {
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      CHECK(comm_host_barrier(cm));
+    }
+  }
+  return DHQR_OK;
+}

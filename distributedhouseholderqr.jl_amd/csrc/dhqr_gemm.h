@@ -194,13 +194,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
 //   r in [0,rows), c in [0,ncols).  grid = (ceil(rows/128), ceil(ncols/128)).
 // The accumulators are initialised with the C tile and the W operand is negated while staging,
 // so the MFMA chain itself performs the subtraction.
-template <int VEC, int KW>
+// INIT0: the accumulators start at zero instead of the C tile (C = -V*W, used for the panel's V = P*M^{-1}).
+// stat/epoch: device-side commit predicate of the asynchronous panel pipeline (dhqr_api.hip): the launch is a
+// no-op when a panel with index <= epoch failed its verification (stat[0] = index of the first failed panel).
+template <int VEC, int KW, bool INIT0 = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict__ V, int64_t ldv,
                                                         const double *__restrict__ W, int64_t ldw,
                                                         double *__restrict__ C, int64_t ldc,
-                                                        int64_t rows, int64_t ncols, int swz) {
+                                                        int64_t rows, int64_t ncols, int swz,
+                                                        const int *__restrict__ stat, int epoch) {
   __shared__ __attribute__((aligned(16))) double Vs[2][G_KT * G_LDR];
   __shared__ __attribute__((aligned(16))) double Ws[2][128 * G_LDK];
+  if (stat != nullptr && stat[0] <= epoch) return;  // uniform: every workgroup of the launch takes the same branch
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int i16 = lane & 15, k4 = lane >> 4;
   const int wr = w & 1, wc = w >> 1;
@@ -287,8 +292,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
       for (int ri = 0; ri < 4; ++ri) {
         const int rl = wr * 64 + ri * 16 + i16;
         const bool ok = cok && rl < nrv;
-        const double x = Cb[co + (uint32_t)(rl < nrv ? rl : 0)];
-        acc[ci][ri][g] = ok ? x : 0.0;
+        if constexpr (INIT0) {
+          acc[ci][ri][g] = 0.0;
+        } else {
+          const double x = Cb[co + (uint32_t)(rl < nrv ? rl : 0)];
+          acc[ci][ri][g] = ok ? x : 0.0;
+        }
       }
     }
 

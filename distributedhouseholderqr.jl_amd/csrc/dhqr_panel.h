@@ -214,9 +214,10 @@ __global__ __launch_bounds__(256) void k_panel_step(
 // A[r, p] <- Vw[r, p] for r >= p (the reflectors, produced out of place by k_panel_step)
 __global__ __launch_bounds__(256) void k_unpack_v(double *__restrict__ P, int64_t ldp, int64_t rows,
                                                   int64_t ncols, const double *__restrict__ Vw,
-                                                  int64_t ldv) {
+                                                  int64_t ldv, const int *__restrict__ stat, int epoch) {
   const int64_t p = blockIdx.y;
   if (p >= ncols) return;
+  if (stat != nullptr && stat[0] <= epoch) return;  // commit predicate (see k_gemm_nn_sub)
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t r = p + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride)
     P[r + p * ldp] = Vw[r + p * ldv];

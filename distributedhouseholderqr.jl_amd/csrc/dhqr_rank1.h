@@ -224,12 +224,13 @@ __global__ __launch_bounds__(T) void k_rank1_generic(double *__restrict__ A, int
 // Pack a factored panel into the clean V operand of the MFMA GEMMs / the broadcast buffer:
 // Vw[r + p*ldv] = P[r + p*ldp] for r >= p, p < ncols; 0 above the diagonal (that is R), in the
 // zero-padded columns p >= ncols and in the pad rows [rows, ldv).
+// `npad` (>= rows) rows of every column are written: rows [rows, npad) are zero padding.
 __global__ __launch_bounds__(256) void k_pack_v(const double *__restrict__ P, int64_t ldp,
                                                 int64_t rows, int64_t ncols,
-                                                double *__restrict__ Vw, int64_t ldv) {
+                                                double *__restrict__ Vw, int64_t ldv, int64_t npad) {
   const int64_t p = blockIdx.y;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ldv; r += stride) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < npad; r += stride) {
     double x = 0.0;
     if (p < ncols && r >= p && r < rows) x = P[r + p * ldp];
     Vw[r + p * ldv] = x;

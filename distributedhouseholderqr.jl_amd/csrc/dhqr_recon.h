@@ -21,247 +21,9 @@
 
 #define RC_N 128
 
-// X = R^{-1} for an upper-triangular 128 x 128 R held in registers in the 4 x 4 cyclic layout of a
-// 1024-thread workgroup (thread (ti,tk) owns R[ti+32a][tk+32b]; entries below the diagonal are
-// ignored).  Row l of X is finished from the running products acc = R[:, l+1:] X[l+1:, :] and
-// immediately folded in as a rank-1 update, exactly the data flow of the Cholesky loop below:
-// per step only one column of R and one row of X travel through LDS.  x gets the same layout.
-__device__ __forceinline__ void rc_upper_inverse_regs(const double (&r)[4][4], double (&x)[4][4],
-                                                      double *dinv, double *rowbuf, double *colbuf) {
-  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
-  double acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    if (ti == tk) dinv[ti + 32 * a] = 1.0 / r[a][a];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { acc[a][b] = 0.0; x[a][b] = 0.0; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int la = 3; la >= 0; --la)
-    for (int lm = 31; lm >= 0; --lm) {
-      const int l = la * 32 + lm;
-      if (ti == lm) {  // owners of row l of X
-        const double di = dinv[l];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int k = tk + 32 * b;
-          const double v = (k >= l) ? ((k == l ? 1.0 : 0.0) - acc[la][b]) * di : 0.0;
-          x[la][b] = v;
-          rowbuf[k] = v;
-        }
-      }
-      if (tk == lm) {  // owners of column l of R
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int i = ti + 32 * a;
-          colbuf[i] = (i < l) ? r[a][la] : 0.0;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const double ci = colbuf[ti + 32 * a];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = fma(ci, rowbuf[tk + 32 * b], acc[a][b]);
-      }
-      __syncthreads();
-    }
-}
-
-// Cholesky G = R'R (upper R) of a 128 x 128 Gram matrix, optional R <- R * Rprev (second
-// CholeskyQR pass), optional output of -R^{-1} (the W operand of k_gemm_nn_sub, which negates it
-// again).  1024 threads; thread (ti,tk) keeps the 4 x 4 cyclic sub-block G[ti+32a][tk+32b] in
-// registers for the whole factorisation; per step only row j travels through LDS.
-// flag[0] is set to 1 when a pivot is not positive (breakdown).
-__global__ __launch_bounds__(1024) void k_chol_inv(const double *__restrict__ G,
-                                                   const double *__restrict__ Rprev,
-                                                   double *__restrict__ Rout,
-                                                   double *__restrict__ negXout,
-                                                   int *__restrict__ flag) {
-  __shared__ double rowbuf[RC_N], colbuf[RC_N], dinv[RC_N];
-  __shared__ double dsh;
-  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
-  double g[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) g[a][b] = G[(ti + 32 * a) + (tk + 32 * b) * RC_N];
-
-#pragma unroll
-  for (int ja = 0; ja < 4; ++ja)  // unrolled so every register-array index is a compile-time constant
-    for (int jm = 0; jm < 32; ++jm) {
-      const int j = ja * 32 + jm;
-      if (ti == jm && tk == jm) dsh = g[ja][ja];
-      __syncthreads();
-      double d = dsh;
-      if (!(d > 0.0)) {  // breakdown (or NaN): flag it, keep going with a harmless pivot
-        if (t == 0) flag[0] = 1;
-        d = 1.0;
-      }
-      const double r = sqrt(d), rinv = 1.0 / r;
-      if (ti == jm) {  // owners of row j: R[j,k] = G[j,k] / r (k > j), R[j,j] = r
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int k = tk + 32 * b;
-          const double x = (k == j) ? r : g[ja][b] * rinv;
-          g[ja][b] = x;
-          rowbuf[k] = (k > j) ? x : 0.0;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int i = ti + 32 * a;
-        const double ri = (i > j) ? rowbuf[i] : 0.0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) g[a][b] = fma(-ri, rowbuf[tk + 32 * b], g[a][b]);
-      }
-    }
-  // registers now hold R in the upper triangle
-  if (Rprev) {  // R <- R * Rprev through LDS-free global reads of Rprev (rare second pass)
-    __shared__ double Rl[RC_N * (RC_N + 1) / 2];
-    auto pidx = [](int i, int l) { return i * RC_N - (i * (i - 1)) / 2 + (l - i); };
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int i = ti + 32 * a, k = tk + 32 * b;
-        if (i <= k) Rl[pidx(i, k)] = g[a][b];
-      }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int i = ti + 32 * a, k = tk + 32 * b;
-        double x = 0.0;
-        if (i <= k)
-          for (int l = i; l <= k; ++l) x = fma(Rl[pidx(i, l)], Rprev[l + k * RC_N], x);
-        g[a][b] = x;
-      }
-  }
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int i = ti + 32 * a, k = tk + 32 * b;
-      Rout[i + k * RC_N] = (i <= k) ? g[a][b] : 0.0;
-    }
-  if (!negXout) return;
-  double x[4][4];
-  __syncthreads();
-  rc_upper_inverse_regs(g, x, dinv, rowbuf, colbuf);
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) negXout[(ti + 32 * a) + (tk + 32 * b) * RC_N] = -x[a][b];
-}
-
-// Replay of the unblocked algorithm on the top 128 x 128 block with R known (see file header).
-// Inputs: P (original panel, ldp), R (128 x 128 upper, any row signs).
-// Outputs: alpha[128]; Rref = strict upper part of the reference's R (row signs fixed so that
-// R_jj = alpha_j), dense 128 x 128; negMinv = -M^{-1} dense 128 x 128.
-__global__ __launch_bounds__(1024) void k_recon_top(const double *__restrict__ P, int64_t ldp,
-                                                    const double *__restrict__ R,
-                                                    double *__restrict__ alpha,
-                                                    double *__restrict__ Rref,
-                                                    double *__restrict__ negMinv) {
-  __shared__ double wrow[RC_N], vcol[RC_N], dinv[RC_N];
-  __shared__ double sh[2];
-  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
-  double a[4][4], r[4][4], mm[4][4];
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) {
-      const int i = ti + 32 * x, k = tk + 32 * y;
-      a[x][y] = P[i + (int64_t)k * ldp];
-      r[x][y] = R[i + k * RC_N];
-      mm[x][y] = 0.0;
-    }
-#pragma unroll
-  for (int ja = 0; ja < 4; ++ja)  // unrolled: constant register-array indices (no scratch)
-    for (int jm = 0; jm < 32; ++jm) {
-      const int j = ja * 32 + jm;
-      if (ti == jm && tk == jm) { sh[0] = a[ja][ja]; sh[1] = r[ja][ja]; }
-      __syncthreads();
-      const double ajj = sh[0], rjj = sh[1];
-      const double s = fabs(rjj);                         // src:129 (norm of the updated column)
-      const double al = s * dhqr_alphafactor(ajj);        // src:130
-      // src:131-135 with no division depending on another one: f = 1/sqrt(q), 1/v_jj = sqrt(q)/(a_jj - alpha)
-      const double q = s * (s + fabs(ajj));
-      const double sq = sqrt(q);
-      const double f = 1.0 / sq;
-      const double vinv = sq / (ajj - al);
-      // row sign so that the reference's R_jj equals alpha_j: al / rjj = -sign(a_jj) * sign(r_jj)
-      const double sg = (al == 0.0) ? 0.0 : ((al < 0.0) == (rjj < 0.0) ? 1.0 : -1.0);
-      if (ti == jm) {  // owners of row j: w_jk = v_j' a_k, R row in the reference's sign convention
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-          const int k = tk + 32 * y;
-          const double rr = sg * r[ja][y];
-          const double w = (k > j) ? (a[ja][y] - rr) * vinv : 0.0;
-          wrow[k] = w;
-          mm[ja][y] = (k > j) ? w : (k == j ? sq : 0.0);  // M[j][k] = w_jk, M[j][j] = 1/f_j = sqrt(q)
-          Rref[j + k * RC_N] = (k > j) ? rr : 0.0;
-        }
-      }
-      if (tk == jm) {  // owners of column j: v_ij = f a_ij (i > j)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const int i = ti + 32 * x;
-          vcol[i] = (i > j) ? f * a[x][ja] : 0.0;
-        }
-      }
-      if (t == 0) alpha[j] = al;
-      __syncthreads();
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const double vi = vcol[ti + 32 * x];
-#pragma unroll
-        for (int y = 0; y < 4; ++y) a[x][y] = fma(-vi, wrow[tk + 32 * y], a[x][y]);  // src:209, top rows
-      }
-    }
-  __syncthreads();
-  double xm[4][4];
-  rc_upper_inverse_regs(mm, xm, dinv, wrow, vcol);
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) negMinv[(ti + 32 * x) + (tk + 32 * y) * RC_N] = -xm[x][y];
-}
-
-// Compact-WY T = (I + striu(S))^{-1} from S = V'V (algebra: dhqr_gemm.h), register-resident
-// inverse.  Columns >= ncols of V are zero padding: T[j][j] = 1, rest of the column 0.
-__global__ __launch_bounds__(1024) void k_build_t3(const double *__restrict__ S, int ncols,
-                                                   double *__restrict__ Tout,
-                                                   double *__restrict__ Ttout) {
-  __shared__ double rowbuf[RC_N], colbuf[RC_N], dinv[RC_N];
-  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
-  double u[4][4], x[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int i = ti + 32 * a, k = tk + 32 * b;
-      u[a][b] = (i == k) ? 1.0 : ((i < k && k < ncols) ? S[i + k * RC_N] : 0.0);
-    }
-  rc_upper_inverse_regs(u, x, dinv, rowbuf, colbuf);
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int i = ti + 32 * a, k = tk + 32 * b;
-      Tout[i + k * RC_N] = x[a][b];   // upper triangular (x is 0 below the diagonal)
-      Ttout[k + i * RC_N] = x[a][b];
-    }
-}
-
 // =================================================================================================
-// "v4" variants of the three single-workgroup kernels: ONE workgroup barrier per elimination step
-// instead of two or three.  They sit on the critical path of every panel (and of the multi-GPU panel
-// chain), where a step costs ~1250 cycles in the kernels above, most of it barrier + LDS round trips.
+// The single-workgroup kernels use ONE workgroup barrier per elimination step.  They sit on the critical
+// path of every panel (and of the multi-GPU panel chain), where a step is mostly barrier + LDS round trips.
 //   * the pivot scalars are broadcast with a wavefront shuffle inside the half-wave that owns the pivot
 //     row (thread (ti,tk) = lane (ti&1)*32 + tk of wave ti>>1), not through LDS + barrier;
 //   * the row / column staging buffers are double buffered by step parity, so the only barrier of a
@@ -269,10 +31,10 @@ __global__ __launch_bounds__(1024) void k_build_t3(const double *__restrict__ S,
 //     s+2 has passed barrier s+1, which every thread reaches only after its reads of step s;
 //   * the replay folds f into the broadcast row (a -= a_ij * ((a_jk - R_jk)/(a_jj - alpha))), so the
 //     column owners need no scalar at all.
-// Same data layout and the same arithmetic up to the order of two multiplications.  Selected with
-// DHQR_SMALLK=4; tests/test_simt_emulation.py runs both generations on the CPU SIMT emulator
-// (ThreadSanitizer build: a missing barrier shows up as a data race).
-__device__ __forceinline__ void rc_upper_inverse_regs4(const double (&r)[4][4], double (&x)[4][4],
+// tests/test_simt_emulation.py runs them on the CPU SIMT emulator (ThreadSanitizer build: a missing barrier
+// shows up as a data race).  Measured on MI355X against the first generation (two or three barriers per step,
+// LDS-broadcast pivots): panel lane of a 32768^2 factorisation 127 -> 108 ms (gpurun_out/smallk_phases_k*.txt).
+__device__ __forceinline__ void rc_upper_inverse_regs(const double (&r)[4][4], double (&x)[4][4],
                                                        double *dinv, double *rowbuf2, double *colbuf2) {
   const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
   double acc[4][4];
@@ -315,7 +77,7 @@ __device__ __forceinline__ void rc_upper_inverse_regs4(const double (&r)[4][4], 
     }
 }
 
-__global__ __launch_bounds__(1024) void k_chol_inv4(const double *__restrict__ G,
+__global__ __launch_bounds__(1024) void k_chol_inv(const double *__restrict__ G,
                                                     const double *__restrict__ Rprev,
                                                     double *__restrict__ Rout,
                                                     double *__restrict__ negXout,
@@ -390,105 +152,15 @@ __global__ __launch_bounds__(1024) void k_chol_inv4(const double *__restrict__ G
     }
   if (!negXout) return;
   double x[4][4];
-  rc_upper_inverse_regs4(g, x, dinv, rowbuf, colbuf);
+  rc_upper_inverse_regs(g, x, dinv, rowbuf, colbuf);
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) negXout[(ti + 32 * a) + (tk + 32 * b) * RC_N] = -x[a][b];
 }
 
-__global__ __launch_bounds__(1024) void k_recon_top4(const double *__restrict__ P, int64_t ldp,
-                                                     const double *__restrict__ R,
-                                                     double *__restrict__ alpha,
-                                                     double *__restrict__ Rref,
-                                                     double *__restrict__ negMinv) {
-  __shared__ double wrow[2 * RC_N], vcol[2 * RC_N], dinv[RC_N];
-  const int t = threadIdx.x, ti = t >> 5, tk = t & 31, lane = t & 63;
-  double a[4][4], r[4][4], mm[4][4];
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) {
-      const int i = ti + 32 * x, k = tk + 32 * y;
-      a[x][y] = P[i + (int64_t)k * ldp];
-      r[x][y] = R[i + k * RC_N];
-      mm[x][y] = 0.0;
-    }
-#pragma unroll
-  for (int ja = 0; ja < 4; ++ja)
-    for (int jm = 0; jm < 32; ++jm) {
-      const int j = ja * 32 + jm;
-      const int src = (lane & 32) + jm;  // thread (jm, jm) inside the half-wave that owns row j
-      const double ajj = __shfl(a[ja][ja], src, 64), rjj = __shfl(r[ja][ja], src, 64);
-      double *wr = wrow + (j & 1) * RC_N, *vc = vcol + (j & 1) * RC_N;
-      if (ti == jm) {  // owners of row j
-        const double s = fabs(rjj);                   // src:129 (norm of the updated column)
-        const double al = s * dhqr_alphafactor(ajj);  // src:130
-        const double q = s * (s + fabs(ajj));         // src:131: f = 1/sqrt(q), v_jj = (a_jj - alpha) f
-        const double sq = sqrt(q);
-        const double u = 1.0 / (ajj - al);            // = f / v_jj
-        const double vinv = sq * u;                   // = 1 / v_jj
-        const double sg = (al == 0.0) ? 0.0 : ((al < 0.0) == (rjj < 0.0) ? 1.0 : -1.0);
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-          const int k = tk + 32 * y;
-          const double rr = sg * r[ja][y];
-          const double dl = (k > j) ? (a[ja][y] - rr) : 0.0;
-          wr[k] = dl * u;                                      // f * (v_j' a_k)
-          mm[ja][y] = (k > j) ? dl * vinv : (k == j ? sq : 0.0);  // M[j][k] = v_j' a_k, M[j][j] = 1/f_j
-          Rref[j + k * RC_N] = (k > j) ? rr : 0.0;
-        }
-        if (tk == 0) alpha[j] = al;
-      }
-      if (tk == jm) {  // owners of column j: the unscaled a_ij (i > j); f travels in the row
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const int i = ti + 32 * x;
-          vc[i] = (i > j) ? a[x][ja] : 0.0;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const double vi = vc[ti + 32 * x];
-#pragma unroll
-        for (int y = 0; y < 4; ++y) a[x][y] = fma(-vi, wr[tk + 32 * y], a[x][y]);  // src:209, top rows
-      }
-    }
-  double xm[4][4];
-  rc_upper_inverse_regs4(mm, xm, dinv, wrow, vcol);
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) negMinv[(ti + 32 * x) + (tk + 32 * y) * RC_N] = -xm[x][y];
-}
-
-__global__ __launch_bounds__(1024) void k_build_t4(const double *__restrict__ S, int ncols,
-                                                   double *__restrict__ Tout,
-                                                   double *__restrict__ Ttout) {
-  __shared__ double rowbuf[2 * RC_N], colbuf[2 * RC_N], dinv[RC_N];
-  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
-  double u[4][4], x[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int i = ti + 32 * a, k = tk + 32 * b;
-      u[a][b] = (i == k) ? 1.0 : ((i < k && k < ncols) ? S[i + k * RC_N] : 0.0);
-    }
-  rc_upper_inverse_regs4(u, x, dinv, rowbuf, colbuf);
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int i = ti + 32 * a, k = tk + 32 * b;
-      Tout[i + k * RC_N] = x[a][b];
-      Ttout[k + i * RC_N] = x[a][b];
-    }
-}
-
 // =================================================================================================
-// "v5": blocked inverse of a 128 x 128 upper-triangular matrix with FIVE workgroup barriers instead of 128.
+// Blocked inverse of a 128 x 128 upper-triangular matrix with FIVE workgroup barriers instead of 128.
 // The elimination order of the inverse is not prescribed by the reference (T and M^{-1} are our own
 // operands), so it can be organised for the machine:
 //   P1  the four 32 x 32 diagonal blocks: ONE LANE PER COLUMN solves U x = e_k by back substitution in
@@ -593,7 +265,7 @@ __device__ __forceinline__ void rc5_emit(const rc5_lds &L, const double (&x12)[4
   }
 }
 
-__global__ __launch_bounds__(1024) void k_build_t5(const double *__restrict__ S, int ncols,
+__global__ __launch_bounds__(1024) void k_build_t(const double *__restrict__ S, int ncols,
                                                    double *__restrict__ Tout,
                                                    double *__restrict__ Ttout) {
   __shared__ rc5_lds L;
@@ -607,7 +279,7 @@ __global__ __launch_bounds__(1024) void k_build_t5(const double *__restrict__ S,
 
 // k_recon_top with the one-barrier replay of k_recon_top4 and the blocked inverse: M is parked in the
 // negMinv output buffer (global, L2 resident), inverted from there, and the buffer is overwritten last.
-__global__ __launch_bounds__(1024) void k_recon_top5(const double *__restrict__ P, int64_t ldp,
+__global__ __launch_bounds__(1024) void k_recon_top(const double *__restrict__ P, int64_t ldp,
                                                      const double *__restrict__ R,
                                                      double *__restrict__ alpha,
                                                      double *__restrict__ Rref,
@@ -691,20 +363,69 @@ __global__ __launch_bounds__(256) void k_recon_fix(double *__restrict__ Vw, int6
   Vw[i + (int64_t)j * ldv] = x;
 }
 
-// flag[1] = 1 unless every ||v_j||^2 (diag of S = V'V) is within tol of 2 (NaN fails too)
-__global__ __launch_bounds__(128) void k_recon_check(const double *__restrict__ S, double tol,
-                                                     int *__restrict__ flag) {
+// ---- device-side commit of the asynchronous panel pipeline ----------------------------------------
+// stat (ints): [0] index of the first panel of the running factorisation whose verification failed
+// (INT_MAX: none), [1] Cholesky breakdown flag of the panel in flight.  The host never waits for a panel: the
+// kernels that write to the matrix carry (stat, epoch) and do nothing once stat[0] <= epoch; the driver reads
+// stat[0] once after the last launch and resumes from the failed panel with the robust kernels.
+//
+// k_recon_decide: panel `panel_idx` is accepted iff every ||v_j||^2 (diag of S = V'V) is within tol of 2 (NaN
+// fails) and the Cholesky did not break down.  statword (in the panel's broadcast buffer) <- stat[0], so the
+// ranks that receive the panel learn of a failure with the data.
+__global__ __launch_bounds__(128) void k_recon_decide(const double *__restrict__ S, double tol,
+                                                      int *__restrict__ stat, int panel_idx,
+                                                      double *__restrict__ statword) {
+  __shared__ int bad[RC_N];
   const int j = threadIdx.x;
   const double d = S[j + j * RC_N];
-  const bool ok = fabs(d - 2.0) <= tol;
-  if (!ok) flag[1] = 1;
+  bad[j] = (fabs(d - 2.0) <= tol) ? 0 : 1;
+  __syncthreads();
+  if (j == 0) {
+    int any = stat[1];
+    for (int q = 0; q < RC_N; ++q) any |= bad[q];
+    if (any && stat[0] > panel_idx) stat[0] = panel_idx;
+    stat[1] = 0;
+    if (statword) *statword = (double)stat[0];
+  }
+}
+// receiver side: adopt the sender's failure index
+__global__ void k_adopt_status(const double *__restrict__ statword, int *__restrict__ stat) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double w = *statword;
+    if (w < (double)stat[0]) stat[0] = (int)w;
+  }
+}
+// commit: alpha of an accepted panel -> the caller's alpha vector (and the panel buffer); `src` may alias dst2
+__global__ __launch_bounds__(128) void k_commit_alpha(const double *__restrict__ src, int w, double *__restrict__ dst1,
+                                                      double *__restrict__ dst2, const int *__restrict__ stat,
+                                                      int epoch) {
+  if (stat != nullptr && stat[0] <= epoch) return;
+  const int j = threadIdx.x;
+  const double a = (j < w) ? src[j] : 0.0;
+  if (dst1 && j < w) dst1[j] = a;
+  if (dst2) dst2[j] = a;
+}
+// zero `nrows` leading rows of `ncols` columns (the rows above a pair's second panel inside the pair operand)
+__global__ __launch_bounds__(128) void k_zero_rows(double *__restrict__ X, int64_t ldx, int nrows) {
+  for (int r = threadIdx.x; r < nrows; r += blockDim.x) X[r + (int64_t)blockIdx.x * ldx] = 0.0;
 }
 
 // commit: strict upper part of the top block <- reference R
 __global__ __launch_bounds__(256) void k_recon_write_r(double *__restrict__ P, int64_t ldp,
-                                                       const double *__restrict__ Rref) {
+                                                       const double *__restrict__ Rref,
+                                                       const int *__restrict__ stat, int epoch) {
+  if (stat != nullptr && stat[0] <= epoch) return;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= RC_N * RC_N) return;
   const int i = idx & (RC_N - 1), j = idx >> 7;
   if (i < j) P[i + (int64_t)j * ldp] = Rref[idx];
+}
+// statword <- stat[0] (a host-verified panel publishes the run's status with its operands)
+__global__ void k_set_statword(const int *__restrict__ stat, double *__restrict__ statword) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *statword = (double)stat[0];
+}
+// x[i] += s[i], i < n <= 128
+__global__ void k_axpy1(double *__restrict__ x, const double *__restrict__ s, int n) {
+  const int i = threadIdx.x;
+  if (i < n) x[i] += s[i];
 }

@@ -33,13 +33,14 @@
 extern "C" {
 #endif
 
-#define DHQR_VERSION 100 /* 0.1.0 */
+#define DHQR_VERSION 200 /* 0.2.0 */
 
 #define DHQR_OK 0
 #define DHQR_EINVAL (-1)   /* bad argument (null pointer, m < n, ld < m, unsupported nb ...) */
 #define DHQR_EHIP (-2)     /* a HIP runtime call failed; text in dhqr_last_error() */
 #define DHQR_ENOMEM (-3)   /* workspace allocation failed */
 #define DHQR_ENODEVICE (-4) /* no gfx950 device visible */
+#define DHQR_ECOMM (-5)    /* rank-to-rank transport failed (RCCL error, peer rank failed, callback error) */
 
 /* Panel (block-reflector) width of the blocked path.  BASELINE.json configs 3/4 fix it at 128. */
 #define DHQR_NB 128
@@ -199,7 +200,7 @@ int32_t dhqr_diff_norms_f64(dhqr_ctx *ctx, const double *dX, int64_t ldx, const 
  * The 1-D column-split driver (one process per GPU, torch.distributed/RCCL broadcast of the panel,
  * replacing the per-column @spawnat fan-out of src:141-143) is built from these two calls.
  *
- * Packed panel buffer ("VT"), doubles:  [ V : ldv x DHQR_NB | T : NB x NB | alpha : NB ]
+ * Packed panel buffer ("VT"), doubles:  [ V : ldv x DHQR_NB | T : NB x NB | T' : NB x NB | alpha : NB | status : 16 ]
  *   ldv = dhqr_panel_ldv(rows); V is the panel's reflectors with the R part above the diagonal
  *   zeroed and columns >= ncols zero; T is the upper-triangular compact-WY factor
  *   (H_1...H_nb = I - V T V').  dhqr_panel_buffer_elems gives the total length. */
@@ -218,6 +219,90 @@ int32_t dhqr_panel_pack_f64(dhqr_ctx *ctx, const double *dP, int64_t rows, int64
  * src:198-213 blocked) or (I - V T V') dC (trans = 0). Async. */
 int32_t dhqr_panel_apply_f64(dhqr_ctx *ctx, const double *dVT, int64_t rows, double *dC,
                              int64_t ncols, int64_t ldc, int32_t trans);
+
+/* ------------------------------------------------------------------ multi-GPU: communicators
+ * The multi-GPU drivers are SPMD programs: every rank (one per GPU) makes the same sequence of collective calls.
+ * A communicator binds a rank to a context and to one of three transports (csrc/dhqr_comm.h):
+ *   RCCL      ncclBroadcast / ncclAllReduce over xGMI (librccl.so is dlopen()ed on first use);
+ *   LOCAL     peer copies + HIP events between the rank threads of ONE process (dhqr_mg_* when several ranks share
+ *             a device, or DHQR_TRANSPORT=local);
+ *   CALLBACK  the host layer supplies broadcast / all-reduce (MPI.jl, Distributed.jl, torch.distributed ...).
+ * Multi-process use (one Julia worker / one torchrun rank per GPU; replaces the `@spawnat` fan-out of src:141-143
+ * and the SharedArray alpha of src:301-304): rank 0 calls dhqr_comm_unique_id, the host layer ships the 128
+ * bytes to the other processes, every process calls dhqr_comm_create_rank (collective: ncclCommInitRank). */
+#define DHQR_UNIQUE_ID_BYTES 128
+#define DHQR_COMM_SELF 0
+#define DHQR_COMM_RCCL 1
+#define DHQR_COMM_LOCAL 2
+#define DHQR_COMM_CALLBACK 3
+typedef struct dhqr_comm dhqr_comm;
+/* dbuf: device pointer; must return 0 on success.  The library synchronises hip_stream before calling; the
+ * callback must have completed (data visible to the device) when it returns. */
+typedef int32_t (*dhqr_bcast_fn)(void *user, void *dbuf, int64_t bytes, int32_t root, void *hip_stream);
+typedef int32_t (*dhqr_allreduce_fn)(void *user, void *dbuf, int64_t count_f64, void *hip_stream); /* in-place sum */
+int32_t dhqr_comm_unique_id(void *id128);
+int32_t dhqr_comm_create_rank(dhqr_comm **comm, dhqr_ctx *ctx, int32_t nranks, int32_t rank, const void *id128);
+int32_t dhqr_comm_create_callbacks(dhqr_comm **comm, dhqr_ctx *ctx, int32_t nranks, int32_t rank,
+                                   dhqr_bcast_fn bcast, dhqr_allreduce_fn allreduce, void *user);
+int32_t dhqr_comm_destroy(dhqr_comm *comm);
+int32_t dhqr_comm_info(dhqr_comm *comm, int32_t *kind, int32_t *nranks, int32_t *rank, int64_t *bytes_bcast);
+
+/* ------------------------------------------------------------------ multi-GPU: 1-D column split (SPMD, collective)
+ * householder!(A::DArray, alpha) (src:115-120).  Layout: BLOCK-CYCLIC columns, block = DHQR_NB: rank r holds the
+ * global column blocks r, r+P, r+2P, ... contiguously (dA: m x dhqr_cs_local_cols(n,P,r), leading dimension lda);
+ * dalpha (n) is replicated.  Per panel ONE broadcast of its (V, T, T', alpha) operands replaces the reference's
+ * per-column fan-out; trailing updates apply two panels per pass (K = 256 MFMA update) under look-ahead.
+ * Every rank of the communicator must make the call.  Synchronous on return.
+ *   dhqr_cs_factor_f64     in-place factorisation of the local blocks, alpha on every rank.
+ *   dhqr_cs_residual_f64   ||A - QR||_F / ||A||_F with A regenerated from `seed` (dhqr_cs_fill_uniform_f64);
+ *                          dW, dA0: m x local_cols scratch matrices (leading dimension m).
+ *   dhqr_cs_solve_f64      solve_householder!(b, H, alpha) (src:226-282): db (m, identical on every rank) is
+ *                          overwritten, x = db[0:n] on every rank; dwork: m + 128 doubles.  One all-reduce of the
+ *                          partial dots per block replaces sum(fetch.(futures)) (src:262-266).
+ *   dhqr_cs_load/store_contiguous_f64   convert between the reference's DArray layout (ONE contiguous column
+ *                          block per process, dhqr_cs_contiguous_range = DistributedArrays' default split) and the
+ *                          block-cyclic layout; dstage: m x max(n/P + 1, 128) doubles.
+ *   dhqr_cs_qr_darray_f64  qr!(A::DArray) for one process: host block in, factored host block + alpha out. */
+int64_t dhqr_cs_local_cols(int64_t n, int32_t nranks, int32_t rank);
+void dhqr_cs_contiguous_range(int64_t n, int32_t nranks, int32_t rank, int64_t *lo, int64_t *hi);
+int32_t dhqr_cs_fill_uniform_f64(dhqr_comm *comm, double *dA, int64_t m, int64_t n, int64_t lda, uint64_t seed);
+int32_t dhqr_cs_factor_f64(dhqr_comm *comm, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha);
+int32_t dhqr_cs_residual_f64(dhqr_comm *comm, const double *dA, int64_t m, int64_t n, int64_t lda,
+                             const double *dalpha, uint64_t seed, double *dW, double *dA0, double *hrel);
+int32_t dhqr_cs_solve_f64(dhqr_comm *comm, const double *dA, int64_t m, int64_t n, int64_t lda,
+                          const double *dalpha, double *db, double *dwork);
+int32_t dhqr_cs_load_contiguous_f64(dhqr_comm *comm, double *dA, int64_t m, int64_t n, int64_t lda,
+                                    const double *dBlock, int64_t ldb, double *dstage);
+int32_t dhqr_cs_store_contiguous_f64(dhqr_comm *comm, const double *dA, int64_t m, int64_t n, int64_t lda,
+                                     double *dBlock, int64_t ldb, double *dstage);
+int32_t dhqr_cs_qr_darray_f64(dhqr_comm *comm, double *hBlock, int64_t m, int64_t n, int64_t ldb, double *halpha);
+
+/* ------------------------------------------------------------------ multi-GPU: single-process handle
+ * One host process drives `ndev` GPUs (devices[i] = HIP device of rank i; NULL = 0..ndev-1): one context, one
+ * communicator rank and one host thread per device run the SPMD drivers above.  Transport: RCCL
+ * (ncclCommInitAll) when the devices are distinct, peer copies otherwise or on DHQR_TRANSPORT=local.
+ * What `qr!(A; ndev = 8)` of the Julia module and `python bench.py --gpus N` bind.
+ *   dhqr_mg_qr_f64 / dhqr_mg_ldiv_f64    host-in / host-out drop-ins for qr!(A) and `H \ b` (src:311-321).
+ *   dhqr_mg_alloc/fill/factor/residual   device-resident path (inputs generated in HBM; what bench.py times).
+ *   dhqr_mg_solve_f64                    `\` with the factored matrix resident in the handle. */
+typedef struct dhqr_mg dhqr_mg;
+int32_t dhqr_mg_create(dhqr_mg **mg, const int32_t *devices, int32_t ndev);
+int32_t dhqr_mg_destroy(dhqr_mg *mg);
+int32_t dhqr_mg_info(dhqr_mg *mg, int32_t *ndev, int32_t *transport, int64_t *m, int64_t *n);
+int32_t dhqr_mg_alloc_f64(dhqr_mg *mg, int64_t m, int64_t n);
+int32_t dhqr_mg_fill_uniform_f64(dhqr_mg *mg, uint64_t seed);
+int32_t dhqr_mg_factor_f64(dhqr_mg *mg);
+int32_t dhqr_mg_residual_f64(dhqr_mg *mg, uint64_t seed, double *hrel);
+int32_t dhqr_mg_upload_f64(dhqr_mg *mg, const double *hA, int64_t lda, const double *halpha);
+int32_t dhqr_mg_download_f64(dhqr_mg *mg, double *hA, int64_t lda, double *halpha);
+int32_t dhqr_mg_qr_f64(dhqr_mg *mg, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha);
+int32_t dhqr_mg_solve_f64(dhqr_mg *mg, const double *hb, double *hx);
+int32_t dhqr_mg_ldiv_f64(dhqr_mg *mg, const double *hA, int64_t m, int64_t n, int64_t lda, const double *halpha,
+                         const double *hb, double *hx);
+int32_t dhqr_mg_set_profiling(dhqr_mg *mg, int32_t on);
+int32_t dhqr_mg_reset_stats(dhqr_mg *mg);
+int32_t dhqr_mg_get_stats(dhqr_mg *mg, int32_t rank, dhqr_stats *out, int64_t *n_fast, int64_t *n_fallback,
+                          int64_t *bytes_bcast);
 
 /* ------------------------------------------------------------------ row-split building blocks
  * BASELINE configs[4] (tall-skinny, ROWS distributed over the ranks; the reference cannot split rows,

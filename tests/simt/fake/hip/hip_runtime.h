@@ -22,6 +22,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 #ifdef SIMT_FIBERS
@@ -351,6 +352,9 @@ inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "h
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
   std::strcpy(p->gcnArchName, "gfx950:sramecc+:xnack-");  // what the emulated kernels are written for
   return hipSuccess;
@@ -390,10 +394,15 @@ inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
 
-// kernel launch: the grid runs to completion on the emulator before the call returns
+// kernel launch: the grid runs to completion on the emulator before the call returns.  One workgroup runs at a
+// time (static LDS, one scheduler), so launches from several host threads (the rank threads of dhqr_mg_*) are
+// serialised by a process-wide mutex: every host thread sees its own launches complete in program order, which
+// is a valid execution of its streams.
+inline std::mutex &simt_launch_mutex() { static std::mutex m; return m; }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                   \
   do {                                                                                                 \
     const dim3 simt_g_ = (grid), simt_b_ = (block);                                                    \
     (void)(stream);                                                                                    \
+    std::lock_guard<std::mutex> simt_lk_(simt_launch_mutex());                                         \
     simt::launch_grid((int)simt_g_.x, (int)simt_g_.y, (int)simt_b_.x, [&] { kernel(__VA_ARGS__); });   \
   } while (0)
