@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X Householder QR hot path (driver contract).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W          one process drives the N GPUs (a host thread per GPU)
+  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...     one process per GPU (same C drivers)
 
 A "step" is one complete device-resident QR factorisation of the workload matrix (synthetic
 U[0,1) input regenerated on the device before every step; the ~3 ms fill is inside the timed
@@ -127,116 +128,13 @@ def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev):
         dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["blocked", "unblocked", "tallskinny"], default="blocked",
-                    help="blocked = BASELINE configs[2]/[3] (default, the metric's configuration); unblocked = configs[1]; "
-                         "tallskinny = configs[4] (262144x4096, rows split over the ranks, all-reduce of partial dots)")
-    ap.add_argument("--n", type=int, default=0, help="matrix order (default 32768 blocked / 8192 unblocked)")
-    ap.add_argument("--m", type=int, default=0, help="rows (default = n)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-residual", action="store_true")
-    ap.add_argument("--no-lookahead", action="store_true")
-    ap.add_argument("--driver", choices=["auto", "c", "python"], default="auto",
-                    help="N=1: 'c' = dhqr_factor_f64 (default), 'python' = the multi-GPU ColumnCyclicQR driver at world size 1")
-    args = ap.parse_args()
+def emit(out, rank=0):
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
-    import torch
-    import torch.distributed as dist
-    import __graft_entry__ as g
-    pkg = g.import_package()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-
-    if args.config == "tallskinny":
-        return tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev)
-    nb = 128 if args.config == "blocked" else 0
-    n = args.n or (32768 if nb else 8192)
-    m = args.m or n
-    seed = 0
-    ctx = pkg.get_context(local_rank)
-
-    use_c = (world == 1 and args.driver != "python")
-    if use_c:
-        A = pkg.empty_colmajor(m, n, dev)
-        alpha = torch.zeros(n, dtype=torch.float64, device=dev)
-        L = pkg._lib.lib()
-        import ctypes
-
-        def step():
-            ctx.use_torch_stream()
-            pkg._lib.check(L.dhqr_fill_uniform_f64(ctx.handle, ctypes.c_void_p(A.data_ptr()), m, n, m, seed, m, 0,
-                                                   pkg.NB, 1, 0))
-            pkg.householder_(A, alpha, nb=nb)
-    else:
-        if nb == 0:
-            raise SystemExit("the unblocked configuration is single-GPU only")
-        q = pkg.ColumnCyclicQR(m, n, lookahead=not args.no_lookahead)
-
-        def step():
-            q.fill(seed)
-            q.factor()
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ctx.reset_stats()
-    ctx.set_profiling(True)
-    if not use_c and hasattr(q.be, "ctx_hi"):
-        q.be.ctx_hi.reset_stats()
-        q.be.ctx_hi.set_profiling(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    st = ctx.stats()
-    ctx.set_profiling(False)
-    if not use_c and hasattr(q.be, "ctx_hi"):  # add the look-ahead lane's share (panels, narrow updates)
-        st2 = q.be.ctx_hi.stats()
-        q.be.ctx_hi.set_profiling(False)
-        st = {k: st[k] + st2[k] for k in st}
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-
-    panel_counts = list(ctx.panel_counters())
-    if not use_c and hasattr(q.be, "ctx_hi"):
-        pc2 = q.be.ctx_hi.panel_counters()
-        panel_counts = [panel_counts[0] + pc2[0], panel_counts[1] + pc2[1]]
-    resid = None
-    if not args.no_residual:
-        if use_c:
-            H = pkg.DistributedHouseholderQRStruct(A, alpha)
-            A0 = pkg.rand_colmajor(m, n, seed, dev)
-            resid = pkg.residual(H, A0)
-            del A0
-        else:
-            resid = q.residual(seed)
-
-    ms_step = dt / args.steps * 1e3
-    value = flops_qr(m, n) / (dt / args.steps) / 1e9
-
-    # ---- roofline of the dominant kernel group (per-launch hipEvent pairs on the launch stream)
+def roofline_groups(st, steps):
+    """per-kernel-group roofline entries from the hipEvent statistics of ONE rank"""
     groups = []
     if st["ms_gemm_avw"] > 0:
         # one timed group = ONE wide k_gemm_nn_sub launch on the caller's stream (rocprofv3 lists the narrow
@@ -261,10 +159,149 @@ def main():
         rl_all.append({"kernel": gr["kernel"], "bound": gr["bound"], "achieved": ach, "peak": peak, "unit": unit,
                        "frac": ach / peak, "traffic": None, "launches": gr["launches"],
                        "avg_launch_ms": gr["ms"] / max(1, gr["launches"]), "total_ms": gr["ms"]})
-    # the north star grades the trailing update: report the slower... no: the DOMINANT (largest total time) MFMA group
+    # the north star grades the trailing update: the DOMINANT (largest total time) MFMA group
     mf = [r for r in rl_all if r["bound"] == "mfma"]
-    dom = max(mf, key=lambda r: r["total_ms"]) if mf else max(rl_all, key=lambda r: r["total_ms"])
+    dom = max(mf, key=lambda r: r["total_ms"]) if mf else (max(rl_all, key=lambda r: r["total_ms"]) if rl_all else None)
+    return dom, rl_all
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=["blocked", "unblocked", "tallskinny"], default="blocked",
+                    help="blocked = BASELINE configs[2]/[3] (default, the metric's configuration); unblocked = configs[1]; "
+                         "tallskinny = configs[4] (262144x4096, rows split over the ranks, all-reduce of partial dots)")
+    ap.add_argument("--n", type=int, default=0, help="matrix order (default 32768 blocked / 8192 unblocked)")
+    ap.add_argument("--m", type=int, default=0, help="rows (default = n)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-residual", action="store_true")
+    ap.add_argument("--logical-ranks", type=int, default=0,
+                    help="development: run R ranks of the multi-GPU driver on ONE GPU (in-process peer-copy transport)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    pkg = g.import_package()
+
+    # Launch modes (same C drivers underneath):
+    #   python bench.py --gpus N                  ONE process drives N GPUs (dhqr_mg_*: a host thread per device, RCCL
+    #                                             communicators from ncclCommInitAll)
+    #   torchrun --nproc-per-node N bench.py ...  one process per GPU (dhqr_cs_* over ncclCommInitRank, the unique id
+    #                                             shipped through torch.distributed)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    spmd = env_world > 1
+    if spmd and env_world != args.gpus:
+        raise SystemExit(f"WORLD_SIZE={env_world} but --gpus {args.gpus}")
+    world = args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if spmd:
+        dist.init_process_group("nccl", device_id=dev)
+
+    if args.config == "tallskinny":
+        return tallskinny(args, pkg, torch, dist, env_world, rank, local_rank, dev)
+    nb = 128 if args.config == "blocked" else 0
+    n = args.n or (32768 if nb else 8192)
+    m = args.m or n
+    seed = 0
+    ctx = pkg.get_context(local_rank)
+    if nb == 0 and (world > 1 or args.logical_ranks):
+        raise SystemExit("the unblocked configuration is single-GPU only")
+
+    mode = "single"
+    mg = q = None
+    if spmd:
+        mode = "spmd"
+        q = pkg.ColumnCyclicQR(m, n, comm=pkg.Communicator.from_torch(ctx))
+
+        def step():
+            q.fill(seed)
+            q.factor()
+    elif world > 1 or args.logical_ranks:
+        mode = "mg"
+        devices = list(range(world)) if world > 1 else [0] * args.logical_ranks
+        mg = pkg.MultiGpuQR(devices=devices)
+        mg.alloc(m, n)
+
+        def step():
+            mg.fill(seed)
+            mg.factor()
+    else:
+        A = pkg.empty_colmajor(m, n, dev)
+        alpha = torch.zeros(n, dtype=torch.float64, device=dev)
+        L = pkg._lib.lib()
+        import ctypes
+
+        def step():
+            ctx.use_torch_stream()
+            pkg._lib.check(L.dhqr_fill_uniform_f64(ctx.handle, ctypes.c_void_p(A.data_ptr()), m, n, m, seed, m, 0,
+                                                   pkg.NB, 1, 0))
+            pkg.householder_(A, alpha, nb=nb)
+
+    def barrier():
+        for d in range(torch.cuda.device_count() if mode == "mg" else 1):
+            torch.cuda.synchronize(d if mode == "mg" else local_rank)
+        if spmd:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if mode == "mg":
+        mg.reset_stats()
+        mg.set_profiling(True)
+    else:
+        ctx.reset_stats()
+        ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    per_rank = None
+    if mode == "mg":
+        per_rank = [mg.stats(r) for r in range(mg.ndev)]
+        mg.set_profiling(False)
+        st = per_rank[0]
+        panel_counts = [sum(s_["panels_fast"] for s_ in per_rank), sum(s_["panels_fallback"] for s_ in per_rank)]
+    else:
+        st = ctx.stats()
+        ctx.set_profiling(False)
+        panel_counts = list(ctx.panel_counters())
+    if spmd:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    resid = None
+    if not args.no_residual:
+        if mode == "single":
+            H = pkg.DistributedHouseholderQRStruct(A, alpha)
+            A0 = pkg.rand_colmajor(m, n, seed, dev)
+            resid = pkg.residual(H, A0)
+            del A0
+        elif mode == "mg":
+            resid = mg.residual(seed)
+        else:
+            resid = q.residual(seed)
+
+    ms_step = dt / args.steps * 1e3
+    value = flops_qr(m, n) / (dt / args.steps) / 1e9
+    dom, rl_all = roofline_groups(st, args.steps)
+
+    if mode == "single":
+        par = "single GPU"
+    elif mode == "mg":
+        par = (f"1-D block-cyclic column split x{mg.ndev}, one process / one host thread per GPU, panel broadcast: {mg.transport}"
+               + ("" if world > 1 else f" ({args.logical_ranks} logical ranks on ONE GPU: development run)"))
+    else:
+        par = f"1-D block-cyclic column split x{world}, one process per GPU, RCCL panel broadcast (ncclCommInitRank)"
     out = {
         "metric": "QR GFLOP/s (F = 2mn^2 - 2/3 n^3), ||A-QR||/||A|| alongside",
         "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -273,16 +310,22 @@ def main():
         "config": {"workload": f"{m}x{n} Float64 dense QR, " +
                                (f"blocked nb=128 (BASELINE configs[{2 if world == 1 else 3}])" if nb else
                                 "unblocked rank-1 (BASELINE configs[1])"),
-                   "m": m, "n": n, "nb": nb,
-                   "parallelism": ("single GPU" if use_c else "single GPU, python column-cyclic driver") if world == 1 else f"1-D block-cyclic column split x{world}, RCCL panel broadcast"},
+                   "m": m, "n": n, "nb": nb, "parallelism": par},
         "residual": resid,
-        "roofline": {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
-                                         "launches", "avg_launch_ms")},
+        "roofline": ({k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
+                                          "launches", "avg_launch_ms")} if dom else None),
         "roofline_all": rl_all,
         "phase_ms_per_step": {k: st[k] / args.steps for k in st if k.startswith("ms_") and st[k] > 0},
         "panels_fast_fallback": panel_counts,
     }
-    if rank == 0 and world == 1:
+    if mode != "single":
+        out["roofline_note"] = "per-GPU figures of rank 0 (every rank runs the same kernels on 1/N of the columns)"
+    if per_rank is not None:
+        out["bcast_bytes_per_step_per_rank"] = per_rank[0]["bytes_bcast"] / args.steps
+        out["per_rank_gemm_ms_per_step"] = [round((s_["ms_gemm_avw"] + s_["ms_gemm_vta"] + s_["ms_gemm_tw"]) / args.steps, 2)
+                                            for s_ in per_rank]
+        out["per_rank_panel_ms_per_step"] = [round(s_["ms_panel"] / args.steps, 2) for s_ in per_rank]
+    if rank == 0 and mode == "single":
         try:
             import ctypes as _ct
             o4 = (_ct.c_double * 4)()   # 4 waves/SIMD, accumulators in VGPRs: the achievable issue rate
@@ -295,14 +338,14 @@ def main():
         except Exception as e:  # diagnostics only
             out["ubench_error"] = repr(e)
         if not args.no_cpu_baseline:
-            if use_c:
-                del A
+            del A
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(m, n)
             out["host_cores"] = os.cpu_count()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    emit(out, rank)
+    if mg is not None:
+        mg.close()
+    if spmd:
         dist.barrier()
         dist.destroy_process_group()
 

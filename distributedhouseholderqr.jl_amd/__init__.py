@@ -3,14 +3,14 @@
 The directory name contains a dot, so it is loaded by path: `__graft_entry__.import_package()`
 registers it in sys.modules as `dhqr_amd`.  Contents: csrc/ (HIP kernels + the C ABI of
 include/dhqr.h), _lib.py (ctypes binding), api.py (host mirror of the reference's Julia API),
-partition.py / distributed.py (1-D column split over torch.distributed), julia/ (ccall wrapper).
+partition.py (index maps), distributed.py (front-ends of the multi-GPU C drivers), rowsplit.py, julia/ (ccall wrapper).
 """
 from . import _lib
 from ._lib import NB, DHQRError, build
 from .api import (Context, DistributedHouseholderQRStruct, apply_q_, bench_mfma_tflops,
                   bench_stream_gbps, empty_colmajor, get_context, get_q, get_r, householder_, ldiv, partialdot,
                   qr_, rand_colmajor, rand_colmajor_c, rand_vector_device, residual, solve_householder_)
-from .distributed import ColumnCyclicQR, HipBackend, qr_darray_
+from .distributed import ColumnCyclicQR, Communicator, MultiGpuQR, qr_darray_, qr_multi_
 from .rowsplit import HipRowBackend, RowSplitQR
 from .partition import BlockCyclicColumns, LocalColumnBlock, contiguous_column_blocks
 
@@ -18,5 +18,5 @@ __all__ = [
     "NB", "DHQRError", "build", "Context", "DistributedHouseholderQRStruct", "apply_q_",
     "bench_mfma_tflops", "bench_stream_gbps", "empty_colmajor", "get_context", "get_q", "get_r", "householder_",
     "ldiv", "partialdot", "qr_", "rand_colmajor", "rand_colmajor_c", "rand_vector_device", "residual",
-    "solve_householder_", "ColumnCyclicQR", "qr_darray_", "HipBackend", "RowSplitQR", "HipRowBackend", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
+    "solve_householder_", "ColumnCyclicQR", "Communicator", "MultiGpuQR", "qr_darray_", "qr_multi_", "RowSplitQR", "HipRowBackend", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
 ]

@@ -105,6 +105,13 @@ def _is_complex(x) -> bool:
     return isinstance(x, np.ndarray) and x.dtype == np.complex128
 
 
+def _host_ld(F) -> int:
+    """leading dimension (in elements) of a column-major host matrix; numpy's relaxed strides report an
+    arbitrary stride for a single column, where the reference's Matrix simply has ld = m"""
+    m, n = F.shape
+    return F.strides[1] // F.itemsize if n > 1 else max(m, 1)
+
+
 def _resolve_nb(A, nb):
     """nb=None: the default of the element type (128 blocked for Float64, 0 unblocked for ComplexF64)"""
     if _is_complex(A):
@@ -213,7 +220,7 @@ def _householder_c64(A, α):
     m, n = A.shape
     F = A if A.flags.f_contiguous else np.asfortranarray(A)
     check(L.dhqr_qr_c64(get_context().handle, F.ctypes.data_as(ctypes.c_void_p), m, n,
-                        max(1, F.strides[1] // 16), α.ctypes.data_as(ctypes.c_void_p)))
+                        _host_ld(F), α.ctypes.data_as(ctypes.c_void_p)))
     if F is not A:
         A[...] = F
     return A, α
@@ -240,7 +247,7 @@ def householder_(A, α, nb: Optional[int] = None):
     m, n = A.shape
     ctx = get_context()
     F = A if A.flags.f_contiguous else np.asfortranarray(A)
-    check(L.dhqr_qr_f64(ctx.handle, F.ctypes.data_as(ctypes.c_void_p), m, n, max(1, F.strides[1] // 8),
+    check(L.dhqr_qr_f64(ctx.handle, F.ctypes.data_as(ctypes.c_void_p), m, n, _host_ld(F),
                         α.ctypes.data_as(ctypes.c_void_p), nb))
     if F is not A:
         A[...] = F  # in-place semantics of qr! for row-major callers
@@ -255,8 +262,9 @@ def qr_(A, nb: Optional[int] = None) -> DistributedHouseholderQRStruct:
 
 
 def solve_householder_(b, H, α):
-    """solve_householder!(b, H, α) (src:284-294): mutates b (b <- Q'b, then back substitution)
-    and returns b[1:n] (a copy, like Julia's b[1:n])."""
+    """solve_householder!(b, H, α) (src:284-294): returns x = b[1:n] (a copy, like Julia's b[1:n]).  A device
+    tensor b is overwritten like the reference's b (b <- Q'b, then back substitution in place); a HOST b is
+    uploaded and left untouched (the solve happens in device memory)."""
     L = _lib.lib()
     if _is_complex(H):
         if _is_tensor(H):
@@ -271,7 +279,7 @@ def solve_householder_(b, H, α):
         x = np.empty(n, dtype=np.complex128)
         bb = np.ascontiguousarray(b, dtype=np.complex128)
         check(L.dhqr_ldiv_c64(get_context().handle, F.ctypes.data_as(ctypes.c_void_p), m, n,
-                              max(1, F.strides[1] // 16),
+                              _host_ld(F),
                               np.ascontiguousarray(α, dtype=np.complex128).ctypes.data_as(ctypes.c_void_p),
                               bb.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p)))
         return x
@@ -286,7 +294,7 @@ def solve_householder_(b, H, α):
     x = np.empty(n)
     bb = np.ascontiguousarray(b, dtype=np.float64)
     ctx = get_context()
-    check(L.dhqr_ldiv_f64(ctx.handle, F.ctypes.data_as(ctypes.c_void_p), m, n, max(1, F.strides[1] // 8),
+    check(L.dhqr_ldiv_f64(ctx.handle, F.ctypes.data_as(ctypes.c_void_p), m, n, _host_ld(F),
                           np.ascontiguousarray(α).ctypes.data_as(ctypes.c_void_p),
                           bb.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p)))
     return x

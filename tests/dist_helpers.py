@@ -1,6 +1,5 @@
-"""Test-only helpers for the world_size-2 gloo tests: an oracle-backed CPU backend with the same
-interface as the product's HipBackend, so ColumnCyclicQR's orchestration (ownership, local
-offsets, broadcast order, look-ahead, α gathering, residual and solve pipelines) runs on CPU.
+"""Test-only helpers: gloo rank spawning, the EMULATED library (tests/simt: csrc/ host-compiled for the CPU),
+gloo-backed communicator callbacks for it, and numpy stand-ins for the row-split backend.
 The product never imports this file."""
 import os
 import sys
@@ -11,114 +10,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NB = 128
-
-
-def _ldv(rows):
-    return (rows + 15) // 16 * 16
-
-
-class OracleBackend:
-    def __init__(self):
-        from oracle import dhqr_oracle
-        self.orc = dhqr_oracle
-
-    def empty(self, m, n):
-        return torch.zeros((max(n, 1), m), dtype=torch.float64).t()
-
-    def zeros_vec(self, n):
-        return torch.zeros(n, dtype=torch.float64)
-
-    def panel_elems(self, rows):
-        return _ldv(rows) * NB + 2 * NB * NB + NB
-
-    def panel_buffer(self, rows):
-        return torch.zeros(self.panel_elems(rows), dtype=torch.float64)
-
-    def alpha_of(self, vt, rows):
-        off = _ldv(rows) * NB + 2 * NB * NB
-        return vt[off: off + NB]
-
-    def _views(self, vt, rows):
-        ldv = _ldv(rows)
-        v = vt.numpy()
-        V = v[: ldv * NB].reshape((ldv, NB), order="F")
-        T = v[ldv * NB: ldv * NB + NB * NB].reshape((NB, NB), order="F")
-        Tt = v[ldv * NB + NB * NB: ldv * NB + 2 * NB * NB].reshape((NB, NB), order="F")
-        al = v[ldv * NB + 2 * NB * NB: ldv * NB + 2 * NB * NB + NB]
-        return V, T, Tt, al
-
-    def fill(self, A, ncols, seed, gm, nb, nranks, rank):
-        a = A.numpy()
-        for jl in range(ncols):
-            gj = ((jl // nb) * nranks + rank) * nb + jl % nb
-            a[:, jl] = self.orc.u01(seed, np.arange(gm, dtype=np.uint64) + np.uint64(gj * gm))
-
-    def _pack(self, P, w, vt, rows, alpha=None):
-        V, T, Tt, al = self._views(vt, rows)
-        V[:] = 0.0
-        V[:rows, :w] = np.tril(P)
-        S = V.T @ V
-        T[:] = 0.0
-        for j in range(NB):
-            T[:j, j] = -T[:j, :j] @ S[:j, j]
-            T[j, j] = 1.0
-        Tt[:] = T.T
-        al[:] = 0.0
-        if alpha is not None:
-            al[:w] = alpha
-
-    def panel_factor(self, A, c0, lc0, w, vt):
-        a = A.numpy()
-        rows = a.shape[0] - c0
-        H, alpha = self.orc.householder(np.asfortranarray(a[c0:, lc0: lc0 + w]))
-        a[c0:, lc0: lc0 + w] = H
-        self._pack(H, w, vt, rows, alpha)
-
-    def panel_pack(self, A, c0, lc0, w, vt):
-        a = A.numpy()
-        self._pack(a[c0:, lc0: lc0 + w], w, vt, a.shape[0] - c0)
-
-    def panel_apply(self, vt, C, c0, lo, cnt, trans):
-        if cnt <= 0:
-            return
-        c = C.numpy()
-        rows = c.shape[0] - c0
-        V, T, Tt, _ = self._views(vt, rows)
-        V = V[:rows]
-        Top = T.T if trans else T
-        if c.ndim == 1:
-            blk = c[c0:]
-            blk -= V @ (Top @ (V.T @ blk))
-        else:
-            blk = c[c0:, lo: lo + cnt]
-            blk -= V @ (Top @ (V.T @ blk))
-
-    def form_r0(self, A, ncols, alpha, W, nb, nranks, rank):
-        a, w, al = A.numpy(), W.numpy(), alpha.numpy()
-        m = a.shape[0]
-        for jl in range(ncols):
-            gj = ((jl // nb) * nranks + rank) * nb + jl % nb
-            w[:, jl] = 0.0
-            w[:gj, jl] = a[:gj, jl]
-            if gj < m:
-                w[gj, jl] = al[gj]
-
-    def diff_norms(self, X, Y, ncols):
-        x, y = X.numpy()[:, :ncols], Y.numpy()[:, :ncols]
-        return float(((x - y) ** 2).sum()), float((x ** 2).sum())
-
-    def backsub_block(self, A, lc0, alpha, b, lo, hi, diag, update):
-        a, al, bb = A.numpy(), alpha.numpy(), b.numpy()
-        w = hi - lo
-        R = a[:, lc0: lc0 + w]
-        if diag:
-            for i in range(hi - 1, lo - 1, -1):
-                bb[i] = (bb[i] - R[i, i - lo + 1: w] @ bb[i + 1: hi]) / al[i]
-        if update and lo > 0:
-            bb[:lo] -= R[:lo, :] @ bb[lo:hi]
-
-    def synchronize(self):
-        pass
 
 
 def run_ranks(fn, world_size, *args):
@@ -186,56 +77,35 @@ def load_emulated_library(so):
     for name, (res, args) in sig.SIGNATURES.items():
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
+    L.Stats = sig.Stats  # the dhqr_stats structure class the prototypes were declared with
     return L
 
 
-def make_emu_backend(so):
-    """HipBackend subclass bound to the emulated library (no streams, no look-ahead lane, CPU tensors)"""
-    import contextlib
+def emulated_rank(so, nranks, rank):
+    """(library, ctx handle, Communicator) of one gloo rank on the EMULATED library: the product's SPMD drivers
+    (dhqr_cs_*) run unmodified; broadcast / all-reduce go through the CALLBACK transport into torch.distributed
+    (gloo) on the numpy-backed "device" memory."""
     import ctypes
+    import importlib
+    import torch.distributed as dist
     import __graft_entry__ as g
     g.import_package()
-    import importlib
-    HipBackend = importlib.import_module("dhqr_amd.distributed").HipBackend
+    D = importlib.import_module("dhqr_amd.distributed")
+    L = load_emulated_library(so)
+    h = ctypes.c_void_p()
+    assert L.dhqr_create(ctypes.byref(h), 0) == 0
 
-    class _Ctx:
-        def __init__(self, L):
-            self.handle = ctypes.c_void_p()
-            assert L.dhqr_create(ctypes.byref(self.handle), 0) == 0
+    def _view(ptr, count):
+        return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_double * count).from_address(ptr)))
 
-        def use_torch_stream(self):
-            pass
+    def bcast(ptr, nbytes, root):
+        dist.broadcast(_view(ptr, nbytes // 8), src=root)
 
-    class EmuBackend(HipBackend):
-        def __init__(self):  # deliberately not calling HipBackend.__init__ (it needs a GPU)
-            self.L = load_emulated_library(so)
-            self.ctx = self._lane = _Ctx(self.L)
-            self.device = None
-            self.torch_device = torch.device("cpu")
+    def allreduce(ptr, count):
+        dist.all_reduce(_view(ptr, count))
 
-        # single lane, nothing asynchronous
-        def lane(self, hi):
-            return contextlib.nullcontext()
-
-        def record_main(self):
-            return None
-
-        def hi_wait(self, ev):
-            pass
-
-        def main_wait_hi(self):
-            pass
-
-        def record_current(self):
-            return None
-
-        def wait_event(self, ev):
-            pass
-
-        def synchronize(self):
-            pass
-
-    return EmuBackend()
+    comm = D.Communicator.from_callbacks(h, L, nranks, rank, bcast, allreduce)
+    return L, h, comm, D
 
 
 def make_emu_row_backend(so):

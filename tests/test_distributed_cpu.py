@@ -1,17 +1,27 @@
-"""world_size-2 gloo tests (CPU):
- 1. the reference's DArray structure restated (oracle/dist_oracle.py, BASELINE config 1:
-    512 x 512, nprocs = 2) equals the single-process oracle;
- 2. the product's ColumnCyclicQR orchestration (block-cyclic split, one panel broadcast per
-    block, look-ahead, α replication, residual and solve pipelines) with an oracle-backed CPU
-    backend injected by the test equals the single-process oracle;
- 3. the same orchestration with the product's HipBackend marshalling bound to the EMULATED library
-    (tests/simt: csrc/ compiled for the CPU), i.e. the real panel / apply / residual / solve entry
-    points and kernels at world size 2 and 3 -- everything of the multi-GPU data path except RCCL
-    and HIP streams."""
+"""Multi-rank tests on the CPU:
+ 1. the reference's DArray structure restated (oracle/dist_oracle.py, BASELINE config 1: 512 x 512, nprocs = 2)
+    equals the single-process oracle (gloo, world size 2/3);
+ 2. the product's multi-GPU drivers -- the SPMD column-split code of csrc/dhqr_dist.h, unmodified, in the EMULATED
+    library (tests/simt: csrc/ host-compiled for the CPU) --
+      a. as `ndev` rank THREADS of one process (dhqr_mg_*: the entry points `qr!(A; ndev)` and
+         `python bench.py --gpus N` bind) over the in-process peer-copy transport,
+      b. as gloo PROCESSES (world size 2/3) over the callback transport (dhqr_cs_* + dhqr_comm_create_callbacks:
+         what a Julia worker per GPU binds), including the reference's DArray layout front-end,
+    against the single-process oracle: look-ahead, two-panel updates, device-side panel verification, the resume
+    path after a rejected panel, residual, solve -- everything of the multi-GPU path except RCCL and real streams;
+ 3. the row-split (BASELINE configs[4]) orchestration."""
+import ctypes
+
 import numpy as np
 import pytest
 
-from dist_helpers import OracleBackend, run_ranks
+from dist_helpers import run_ranks
+
+P_ = ctypes.c_void_p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(P_)
 
 
 def _ref_darray(rank, P, m, n):
@@ -39,117 +49,167 @@ def test_reference_darray_structure(m, n, P):
     run_ranks(_ref_darray, P, m, n)
 
 
-def _cyclic(rank, P, m, n, lookahead):
-    import torch
-    import __graft_entry__ as g
+# ---------------------------------------------------------------- 2a: rank threads of one process (dhqr_mg_*)
+@pytest.fixture(scope="module")
+def emu(emulated_so):
+    from dist_helpers import load_emulated_library
+    return load_emulated_library(emulated_so)
+
+
+def _mg(emu, ndev):
+    h = P_()
+    devs = (ctypes.c_int32 * ndev)(*([0] * ndev))  # every rank on "device" 0: the in-process transport
+    assert emu.dhqr_mg_create(ctypes.byref(h), devs, ndev) == 0, emu.dhqr_last_error()
+    t = ctypes.c_int32()
+    assert emu.dhqr_mg_info(h, None, ctypes.byref(t), None, None) == 0
+    assert t.value == (0 if ndev == 1 else 2)  # DHQR_COMM_SELF / DHQR_COMM_LOCAL
+    return h
+
+
+# (ndev, m, n): pairs on 2 ranks; 3 ranks with a partial last panel; 4 ranks, 8 panels
+@pytest.mark.parametrize("ndev,m,n", [(2, 700, 512), (3, 900, 650), (4, 1100, 1024)])
+def test_multi_device_handle_vs_oracle(emu, orc, ndev, m, n):
+    h = _mg(emu, ndev)
+    # device-resident path: fill (block-cyclic generator map), factor, residual, download
+    assert emu.dhqr_mg_alloc_f64(h, m, n) == 0, emu.dhqr_last_error()
+    assert emu.dhqr_mg_fill_uniform_f64(h, 3) == 0
+    A0 = orc.rand_matrix(m, n, 3)
+    G = np.zeros((m, n), order="F")
+    assert emu.dhqr_mg_download_f64(h, _ptr(G), m, None) == 0
+    assert np.array_equal(G, A0)
+    assert emu.dhqr_mg_factor_f64(h) == 0, emu.dhqr_last_error()
+    H, al = np.zeros((m, n), order="F"), np.zeros(n)
+    assert emu.dhqr_mg_download_f64(h, _ptr(H), m, _ptr(al)) == 0
+    Ho, ao = orc.householder(A0)
+    scale = np.abs(Ho).max()
+    assert np.abs(H - Ho).max() <= 1e-12 * scale and np.abs(al - ao).max() <= 1e-12 * scale
+    rel = ctypes.c_double()
+    assert emu.dhqr_mg_residual_f64(h, 3, ctypes.byref(rel)) == 0, emu.dhqr_last_error()
+    assert rel.value < 1e-14
+    b, x = orc.rand_vector(m, 9), np.zeros(n)
+    assert emu.dhqr_mg_solve_f64(h, _ptr(b), _ptr(x)) == 0, emu.dhqr_last_error()
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    # every full panel with >= 256 rows went through the device-verified fast path, none was redone
+    st = emu.Stats()
+    nf = nfb = 0
+    for r in range(ndev):
+        a_, b_, c_ = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        assert emu.dhqr_mg_get_stats(h, r, ctypes.byref(st), ctypes.byref(a_), ctypes.byref(b_), ctypes.byref(c_)) == 0
+        nf, nfb = nf + a_.value, nfb + b_.value
+        assert c_.value > 0  # bytes broadcast
+    assert nfb == 0 and nf == sum(1 for k in range(n // 128) if m - 128 * k >= 256)
+    assert emu.dhqr_mg_destroy(h) == 0
+
+
+def test_multi_device_host_drop_in_and_rejected_panel(emu, orc):
+    """qr!(A; ndev) host-in/host-out; two nearly dependent columns in the SECOND panel of the first pair: the device
+    verification rejects it, later updates become no-ops, the run resumes with the robust kernels (on 2 ranks)"""
+    h = _mg(emu, 2)
+    m, n = 600, 384
+    A0 = orc.rand_matrix(m, n, 22)
+    A0[:, 200] = A0[:, 199] * (1.0 + 1e-9)
+    A, al = A0.copy(order="F"), np.zeros(n)
+    assert emu.dhqr_mg_qr_f64(h, _ptr(A), m, n, m, _ptr(al)) == 0, emu.dhqr_last_error()
+    QR = orc.form_qr(np.asfortranarray(A), al)
+    assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-13
+    st = emu.Stats()
+    a_, b_ = ctypes.c_int64(), ctypes.c_int64()
+    assert emu.dhqr_mg_get_stats(h, 1, ctypes.byref(st), ctypes.byref(a_), ctypes.byref(b_), None) == 0
+    assert b_.value >= 1  # rank 1 owns panel 1 and had to fall back
+    # `H \\ b` through the handle from a factored HOST matrix (well conditioned, shape change re-allocates)
+    m, n = 500, 260
+    A1 = orc.rand_matrix(m, n, 23)
+    A, al = A1.copy(order="F"), np.zeros(n)
+    assert emu.dhqr_mg_qr_f64(h, _ptr(A), m, n, m, _ptr(al)) == 0, emu.dhqr_last_error()
+    Ho, ao = orc.householder(A1)
+    assert np.abs(A - Ho).max() <= 1e-12 * np.abs(Ho).max()
+    b, x = orc.rand_vector(m, 4), np.zeros(n)
+    bkeep = b.copy()
+    assert emu.dhqr_mg_ldiv_f64(h, _ptr(A), m, n, m, _ptr(al), _ptr(b), _ptr(x)) == 0, emu.dhqr_last_error()
+    xo = orc.solve(Ho, ao, bkeep)
+    assert np.array_equal(b, bkeep) and np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    assert emu.dhqr_mg_destroy(h) == 0
+    # argument validation
+    assert emu.dhqr_mg_create(ctypes.byref(P_()), None, 0) == -1
+
+
+# ---------------------------------------------------------------- 2b: gloo processes + callback transport (dhqr_cs_*)
+def _cs_gloo(rank, P, m, n, so):
+    from dist_helpers import emulated_rank
     from oracle import dhqr_oracle as orc
-    pkg = g.import_package()
-    q = pkg.ColumnCyclicQR(m, n, backend=OracleBackend(), lookahead=lookahead)
-    q.fill(5)
+    L, h, comm, D = emulated_rank(so, P, rank)
+    q = D.ColumnCyclicQR(m, n, comm=comm, mem=D._HostMem())
+    q.fill(71)
+    A = orc.rand_matrix(m, n, 71)
+    cols = [((jl // 128) * P + rank) * 128 + jl % 128 for jl in range(q.ncl)]
+    loc, _ = q.local_numpy()
+    assert np.array_equal(loc, A[:, cols])  # the device generator with the block-cyclic column map
     q.factor()
-    H, alpha = q.gather_full()
-    A = orc.rand_matrix(m, n, 5)
+    loc, alpha = q.local_numpy()
     Ho, ao = orc.householder(A)
     scale = np.abs(Ho).max()
-    assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
-    assert np.abs(alpha - ao).max() <= 1e-11 * scale
-    res = q.residual(5)
-    assert res < 1e-13, res
-    b = orc.rand_vector(m, 6)
-    x = q.solve(torch.from_numpy(b.copy())).numpy()
+    assert np.abs(loc - Ho[:, cols]).max() <= 1e-12 * scale
+    assert np.abs(alpha - ao).max() <= 1e-12 * scale
+    assert q.residual(71) < 1e-14
+    b = orc.rand_vector(m, 72)
+    x = q.solve(b)
     xo = orc.solve(Ho, ao, b)
-    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
-    return res
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    return True
 
 
-@pytest.mark.parametrize("lookahead", [True, False])
-@pytest.mark.parametrize("m,n,P", [(300, 260, 2), (700, 520, 2), (400, 385, 3), (200, 100, 2), (640, 640, 2)])
-def test_column_cyclic_orchestration(m, n, P, lookahead):
-    run_ranks(_cyclic, P, m, n, lookahead)
+@pytest.mark.parametrize("m,n,P", [(450, 300, 3), (700, 512, 2)])
+def test_column_split_processes_with_callback_transport(emulated_so, m, n, P):
+    run_ranks(_cs_gloo, P, m, n, emulated_so)
 
 
-def _darray(rank, P, m, n):
-    """qr!(A::DArray) front-end: every rank passes its CONTIGUOUS column block (the reference's
-    DistributedArrays layout, test/runtests.jl:71) and gets it back factored"""
-    import importlib
-    import torch
-    import __graft_entry__ as g
+def _darray(rank, P, m, n, so):
+    """qr!(A::DArray) front-end: every rank passes its CONTIGUOUS column block (the reference's DistributedArrays
+    layout, test/runtests.jl:71) and gets it back factored"""
+    from dist_helpers import emulated_rank
     from oracle import dhqr_oracle as orc
-    pkg = g.import_package()
-    part = importlib.import_module("dhqr_amd.partition")
+    L, h, comm, D = emulated_rank(so, P, rank)
+    mem = D._HostMem()
     A = orc.rand_matrix(m, n, 51)
-    cols = part.contiguous_column_blocks(n, P)[rank]
-    local = torch.from_numpy(np.array(A[:, cols.start: cols.stop], order="F"))
+    q0 = D.ColumnCyclicQR(m, n, comm=comm, mem=mem)
+    cols = q0.contiguous_range()
+    import importlib
+    part = importlib.import_module("dhqr_amd.partition")
+    assert cols == part.contiguous_column_blocks(n, P)[rank]  # DistributedArrays' default split
+    local = np.array(A[:, cols.start: cols.stop], order="F") if len(cols) else np.zeros((m, 0), order="F")
     # layout round trip first: scatter to block-cyclic and gather back is the identity
-    q0 = pkg.ColumnCyclicQR(m, n, backend=OracleBackend())
     q0.load_contiguous_blocks(local)
-    back = q0.store_contiguous_blocks()
-    assert tuple(back.shape) == (m, len(cols)) and torch.equal(back, local)
-    H0, _ = q0.gather_full()
-    assert np.array_equal(H0, A)
-    # the front-end proper
-    q, alpha = pkg.qr_darray_(local, n, backend=OracleBackend())
+    gcols = [((jl // 128) * P + rank) * 128 + jl % 128 for jl in range(q0.ncl)]
+    assert np.array_equal(q0.local_numpy()[0], A[:, gcols])
+    back = np.zeros_like(local)
+    q0.store_contiguous_blocks(back)
+    assert np.array_equal(back, local)
+    # the front-end proper (device-memory flavour) ...
+    q, alpha = D.qr_darray_(local, n, comm=comm, mem=mem)
     Ho, ao = orc.householder(A)
     scale = np.abs(Ho).max()
     if len(cols):  # (a rank may own no column at all)
-        assert np.abs(local.numpy() - Ho[:, cols.start: cols.stop]).max() <= 1e-11 * scale
-    assert np.abs(alpha.numpy() - ao).max() <= 1e-11 * scale
+        assert np.abs(local - Ho[:, cols.start: cols.stop]).max() <= 1e-12 * scale
+    assert np.abs(alpha[:n] - ao).max() <= 1e-12 * scale
     b = orc.rand_vector(m, 52)
-    x = q.solve(torch.from_numpy(b.copy())).numpy()
-    assert np.abs(x - orc.solve(Ho, ao, b)).max() <= 1e-9 * np.abs(orc.solve(Ho, ao, b)).max()
+    x = q.solve(b)
+    assert np.abs(x - orc.solve(Ho, ao, b)).max() <= 1e-10 * np.abs(orc.solve(Ho, ao, b)).max()
+    # ... and the one-call HOST entry point a Julia worker binds (dhqr_cs_qr_darray_f64)
+    blk = np.array(A[:, cols.start: cols.stop], order="F") if len(cols) else np.zeros((m, 1), order="F")
+    al = np.zeros(n)
+    rc = L.dhqr_cs_qr_darray_f64(comm.handle, blk.ctypes.data_as(ctypes.c_void_p), m, n, m, al.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0, L.dhqr_last_error()
+    if len(cols):
+        assert np.abs(blk - Ho[:, cols.start: cols.stop]).max() <= 1e-12 * scale
+    assert np.abs(al - ao).max() <= 1e-12 * scale
     return True
 
 
-@pytest.mark.parametrize("m,n,P", [(300, 260, 2), (400, 385, 3), (130, 5, 3), (200, 2, 3)])
-def test_darray_layout_front_end(m, n, P):
+@pytest.mark.parametrize("m,n,P", [(400, 385, 3), (200, 2, 3)])
+def test_darray_layout_front_end(emulated_so, m, n, P):
     """contiguous blocks in, contiguous blocks out (incl. ranks that own few or no columns)"""
-    run_ranks(_darray, P, m, n)
-
-
-def test_darray_front_end_single_rank():
-    import torch
-    import __graft_entry__ as g
-    from oracle import dhqr_oracle as orc
-    pkg = g.import_package()
-    A = orc.rand_matrix(200, 150, 53)
-    local = torch.from_numpy(A.copy(order="F"))
-    q, alpha = pkg.qr_darray_(local, 150, backend=OracleBackend())
-    Ho, ao = orc.householder(A)
-    assert np.abs(local.numpy() - Ho).max() <= 1e-11 * np.abs(Ho).max()
-    assert np.abs(alpha.numpy() - ao).max() <= 1e-11 * np.abs(Ho).max()
-
-
-def _cyclic_emulated(rank, P, m, n, so):
-    """ColumnCyclicQR with the product's HipBackend marshalling bound to the EMULATED library: the real
-    dhqr_panel_factor / _pack / _apply / form_r0 / diff_norms / backsub_block / fill entry points and kernels
-    under the real orchestration, world size P, gloo"""
-    import torch
-    import __graft_entry__ as g
-    from oracle import dhqr_oracle as orc
-    from dist_helpers import make_emu_backend
-    pkg = g.import_package()
-    q = pkg.ColumnCyclicQR(m, n, backend=make_emu_backend(so))
-    q.fill(71)
-    H0, _ = q.gather_full()
-    A = orc.rand_matrix(m, n, 71)
-    assert np.array_equal(H0, A)  # the device generator with the block-cyclic column map
-    q.factor()
-    H, alpha = q.gather_full()
-    Ho, ao = orc.householder(A)
-    scale = np.abs(Ho).max()
-    assert np.abs(H - Ho).max() <= 1e-11 * scale
-    assert np.abs(alpha - ao).max() <= 1e-11 * scale
-    assert q.residual(71) < 1e-13
-    b = orc.rand_vector(m, 72)
-    x = q.solve(torch.from_numpy(b.copy())).numpy()
-    xo = orc.solve(Ho, ao, b)
-    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
-    return True
-
-
-@pytest.mark.parametrize("m,n,P", [(450, 300, 3)])
-def test_column_cyclic_with_the_emulated_library(emulated_so, m, n, P):
-    run_ranks(_cyclic_emulated, P, m, n, emulated_so)
+    run_ranks(_darray, P, m, n, emulated_so)
 
 
 def _rowsplit_emulated(rank, P, m, n, so):
@@ -181,19 +241,6 @@ def _rowsplit_emulated(rank, P, m, n, so):
 @pytest.mark.parametrize("m,n,P", [(1200, 256, 2)])
 def test_row_split_with_the_emulated_library(emulated_so, m, n, P):
     run_ranks(_rowsplit_emulated, P, m, n, emulated_so)
-
-
-def test_single_rank_without_process_group():
-    import __graft_entry__ as g
-    from oracle import dhqr_oracle as orc
-    pkg = g.import_package()
-    q = pkg.ColumnCyclicQR(300, 200, backend=OracleBackend())
-    q.fill(2)
-    q.factor()
-    H, alpha = q.gather_full()
-    Ho, ao = orc.householder(orc.rand_matrix(300, 200, 2))
-    assert np.abs(H - Ho).max() <= 1e-11 * np.abs(Ho).max()
-    assert q.residual(2) < 1e-13
 
 
 def _rowsplit(rank, P, m, n):

@@ -149,13 +149,13 @@ def test_full_size_properties(pkg, n, nb):
 
 @pytest.mark.parametrize("m,n", [(700, 520), (1300, 1290)])
 def test_column_cyclic_driver_single_rank(pkg, orc, m, n):
-    """The multi-GPU driver with the product HipBackend at world size 1 (no process group): same
-    orchestration code the N-GPU bench runs, checked against the oracle incl. residual and solve."""
+    """The SPMD multi-GPU entry points (dhqr_cs_*) at world size 1 (no process group): same driver code the
+    N-GPU bench runs, checked against the oracle incl. residual and solve."""
     import torch
     q = pkg.ColumnCyclicQR(m, n)
     q.fill(8)
     q.factor()
-    H, alpha = q.gather_full()
+    H, alpha = q.local_numpy()
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 8))
     scale = np.abs(Ho).max()
     assert np.abs(H - Ho).max() <= 1e-11 * scale
@@ -167,36 +167,91 @@ def test_column_cyclic_driver_single_rank(pkg, orc, m, n):
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
 
 
-def _two_rank_gpu(rank, P, m, n):
-    """both ranks share cuda:0; gloo moves the device tensors -- exercises the product HipBackend
-    (two lanes, panel events, async broadcast ordering) at world size 2 on a 1-GPU box"""
+@pytest.mark.parametrize("ranks,m,n", [(2, 1500, 1300), (2, 2304, 2304), (3, 2000, 1700), (8, 4096, 4096)])
+def test_multi_device_handle_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
+    """dhqr_mg_* with `ranks` rank threads all on cuda:0 (RCCL cannot put two ranks on one device, so the
+    in-process peer-copy transport carries the panel broadcasts): the real streams / events / look-ahead /
+    two-panel updates / device-side verification of the N-GPU driver on a 1-GPU box, against the oracle."""
+    mg = pkg.MultiGpuQR(devices=[0] * ranks)
+    try:
+        assert mg.transport == "local-peer-copy"
+        mg.alloc(m, n).fill(11)
+        A0, _ = mg.download()
+        Ah = orc.rand_matrix(m, n, 11)
+        assert np.array_equal(A0, Ah)
+        mg.factor()
+        H, alpha = mg.download()
+        res = mg.residual(11)
+        assert res < 1e-12, res
+        if m <= 2304:
+            Ho, ao = orc.householder(Ah)
+            scale = np.abs(Ho).max()
+            assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
+            assert np.abs(alpha - ao).max() <= 1e-11 * scale
+            b = orc.rand_vector(m, 12)
+            x = mg.solve(b)
+            xo = orc.solve(Ho, ao, b)
+            assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+        st = [mg.stats(r) for r in range(ranks)]
+        assert sum(s_["panels_fallback"] for s_ in st) == 0
+        assert sum(s_["panels_fast"] for s_ in st) >= n // 128 - 1
+        # a second factorisation on the same handle (buffers, events and mailboxes are reused)
+        mg.fill(12).factor()
+        assert mg.residual(12) < 1e-12
+    finally:
+        mg.close()
+
+
+def test_multi_device_host_drop_in_and_rejected_panel_gpu(pkg, orc):
+    """qr!(A; ndev) host-in / host-out on 2 logical ranks, with a panel the device-side verification must reject"""
+    m, n = 1100, 768
+    A0 = orc.rand_matrix(m, n, 22)
+    A0[:, 300] = A0[:, 299] * (1.0 + 1e-9)   # second panel of the second pair
+    mg = pkg.MultiGpuQR(devices=[0, 0])
+    try:
+        A = A0.copy(order="F")
+        A, al = mg.qr_(A)
+        QR = orc.form_qr(np.asfortranarray(A), al)
+        assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-13
+        assert sum(mg.stats(r)["panels_fallback"] for r in range(2)) >= 1
+        A1 = orc.rand_matrix(900, 520, 23)
+        Ho, ao = orc.householder(A1)
+        F, al = mg.qr_(A1.copy(order="F"))
+        assert np.abs(F - Ho).max() <= 1e-11 * np.abs(Ho).max()
+        b = orc.rand_vector(900, 24)
+        x = mg.ldiv(F, al, b)
+        xo = orc.solve(Ho, ao, b)
+        assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    finally:
+        mg.close()
+
+
+def _rccl_one_rank(rank, P, m, n):
+    """RCCL bootstrap exactly as a multi-process job does it (unique id -> ncclCommInitRank) on the one GPU of the
+    box: world size 1, so the collectives are trivial, but librccl.so is dlopen()ed and the communicator is real"""
+    import ctypes
     import torch
     import __graft_entry__ as g
     from oracle import dhqr_oracle as orc
     torch.cuda.set_device(0)
     pkg = g.import_package()
-    q = pkg.ColumnCyclicQR(m, n)
-    q.fill(11)
-    q.factor()
-    torch.cuda.synchronize()
-    H, alpha = q.gather_full()
-    Ho, ao = orc.householder(orc.rand_matrix(m, n, 11))
-    scale = np.abs(Ho).max()
-    assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
-    assert np.abs(alpha - ao).max() <= 1e-11 * scale
-    res = q.residual(11)
-    assert res < 1e-12, res
-    b = orc.rand_vector(m, 12)
-    x = q.solve(torch.tensor(b, device="cuda:0")).cpu().numpy()
-    xo = orc.solve(Ho, ao, b)
-    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
-    return res
+    L = pkg._lib.lib()
+    idbuf = (ctypes.c_char * 128)()
+    pkg._lib.check(L.dhqr_comm_unique_id(idbuf))
+    assert any(idbuf.raw)
+    comm = pkg.Communicator.from_torch(pkg.get_context(0))
+    assert (comm.nranks, comm.rank) == (1, 0)
+    q = pkg.ColumnCyclicQR(m, n, comm=comm)
+    q.fill(3).factor()
+    H, alpha = q.local_numpy()
+    Ho, ao = orc.householder(orc.rand_matrix(m, n, 3))
+    assert np.abs(H - Ho).max() <= 1e-11 * np.abs(Ho).max()
+    return True
 
 
-@pytest.mark.parametrize("m,n", [(1500, 1300), (2304, 2304)])
-def test_column_cyclic_driver_two_ranks_one_gpu(m, n):
+def test_rccl_loads_and_world_size_one_process_group():
     from dist_helpers import run_ranks
-    run_ranks(_two_rank_gpu, 2, m, n)
+    run_ranks(_rccl_one_rank, 1, 700, 520)
 
 
 def test_tall_skinny_single_gpu(pkg, orc):
@@ -336,15 +391,12 @@ def test_explicit_q_and_r(pkg, m, n):
     assert ((Q @ R - A0).norm() / A0.norm()).item() < 1e-12
 
 
-@pytest.mark.parametrize("gen", [4, pytest.param(5, marks=pytest.mark.xfail(
-    strict=False, reason="DHQR_SMALLK=5 is verified on the CPU SIMT emulator only; this is its first hardware run"))])
-def test_smallk4_panel_kernels_match_oracle(pkg, orc, monkeypatch, gen):
-    """The next generations of k_chol_inv / k_recon_top / k_build_t must give the same factorisation with
-    every panel on the fast path (a silent fallback to the step kernels would hide a broken kernel)."""
+def test_panel_kernels_keep_every_panel_on_the_fast_path(pkg, orc):
+    """k_chol_inv / k_recon_top / k_build_t must give the reference's factorisation with every panel on the
+    device-verified fast path (a silent fallback to the step kernels would hide a broken kernel)."""
     import ctypes
     import torch
-    monkeypatch.setenv("DHQR_SMALLK", str(gen))
-    ctx = pkg.Context(0)  # the switch is read when the context is created
+    ctx = pkg.Context(0)
     try:
         for (m, n) in [(1536, 1024), (700, 384)]:
             A = pkg.rand_colmajor(m, n, 4, "cuda:0")
@@ -382,8 +434,8 @@ def test_matrix_without_columns_is_a_noop(pkg):
 
 
 def test_darray_front_end_single_gpu(pkg, orc):
-    """qr_darray_ (contiguous column blocks in / out, the reference's DArray layout) with the product backend
-    at world size 1; the multi-rank scatter/gather is covered under gloo in tests/test_distributed_cpu.py"""
+    """qr_darray_ (contiguous column blocks in / out, the reference's DArray layout) at world size 1; the
+    multi-rank scatter/gather is covered under gloo in tests/test_distributed_cpu.py"""
     import torch
     m, n = 700, 520
     A = pkg.rand_colmajor(m, n, 61, "cuda:0")
