@@ -429,3 +429,4 @@ __global__ void k_axpy1(double *__restrict__ x, const double *__restrict__ s, in
   const int i = threadIdx.x;
   if (i < n) x[i] += s[i];
 }
+

@@ -19,14 +19,17 @@
 #   -> dhqr_ldiv_c64, partialdot(a, b, is, ComplexF64) -> dhqr_partialdot_host_c64.  A Ptr{ComplexF64}
 #   is the interleaved (re, im) `double *` of include/dhqr.h.
 #
-# `qr!(A::DArray)` (src:115-120): one Julia worker per GPU calls `dhqr_panel_factor_f64` /
-# `dhqr_panel_apply_f64` on its block-cyclic local part and broadcasts the packed (V, T, α) panel
-# buffer; the orchestration is the one implemented and tested in
-# distributedhouseholderqr.jl_amd/distributed.py (ColumnCyclicQR; `qr_darray_` there takes and returns the
-# DistributedArrays layout of contiguous column blocks).  It is not duplicated here.
+#   qr!(A; ndev=8)              (new)         one process, `ndev` GPUs        -> dhqr_mg_qr_f64 / dhqr_mg_ldiv_f64
+#   qr!(A::DArray)              src:115-120   one Julia worker per GPU        -> dhqr_comm_create_rank + dhqr_cs_qr_darray_f64
+#     householder!(A::DArray,α) src:115-120   (owners visited sequentially, every reflector sent to every process with
+#     `@spawnat` src:141-143, α::SharedArray src:301-304) becomes ONE collective call per worker: the library converts
+#     the DistributedArrays layout (one contiguous column block per worker) to block-cyclic columns, factors with one
+#     RCCL broadcast per 128-column panel, converts back, and returns the replicated α.  The only thing Julia ships
+#     between the workers is the 128-byte RCCL unique id (Distributed.jl remotecall), like an MPI bootstrap.
 module DistributedHouseholderQR
 
 using LinearAlgebra
+using Distributed          # only for the DArray method (worker bootstrap), like the reference
 
 const libdhqr = get(ENV, "DHQR_LIB", joinpath(@__DIR__, "..", "libdhqr.so"))
 const DHQR_NB = 128
@@ -140,6 +143,102 @@ function partialdot(a::Vector{Float64}, b::Vector{Float64}, is::UnitRange{Int}, 
               (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ref{Float64}),
               context(), a, b, first(is) - 1, last(is), out))     # 1-based inclusive -> 0-based half-open
   return out[]
+end
+
+# ---- several GPUs, ONE process: qr!(A; ndev) ---------------------------------------------------------------
+# The library runs one host thread + one RCCL rank per device (include/dhqr.h, "single-process handle").
+const _mg = Dict{Int, Ptr{Cvoid}}()
+function multigpu(ndev::Integer)
+  get!(_mg, Int(ndev)) do
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dhqr_mg_create, libdhqr), Int32, (Ref{Ptr{Cvoid}}, Ptr{Int32}, Int32), h, C_NULL, Int32(ndev)))
+    atexit(() -> ccall((:dhqr_mg_destroy, libdhqr), Int32, (Ptr{Cvoid},), h[]))
+    h[]
+  end
+end
+
+function householder!(A::StridedMatrix{Float64}, α::Vector{Float64}, ndev::Integer)
+  m, n = size(A)
+  stride(A, 1) == 1 || throw(ArgumentError("column-major storage required"))
+  check(ccall((:dhqr_mg_qr_f64, libdhqr), Int32,
+              (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}),
+              multigpu(ndev), A, m, n, stride(A, 2), α))
+  return (A, α)
+end
+
+function qr!(A::StridedMatrix{Float64}, ndev::Integer)   # qr!(A, 8): the 8 GPUs of the node
+  H = DistributedHouseholderQRStruct(A)
+  householder!(H.A, H.α, ndev)
+  return H
+end
+
+function solve_householder!(b::Vector{Float64}, H::StridedMatrix{Float64}, α::Vector{Float64}, ndev::Integer)
+  m, n = size(H)
+  x = Vector{Float64}(undef, n)
+  check(ccall((:dhqr_mg_ldiv_f64, libdhqr), Int32,
+              (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+              multigpu(ndev), H, m, n, stride(H, 2), α, b, x))
+  b[1:n] .= x
+  return x
+end
+
+# ---- one Julia worker per GPU: the reference's own calling convention, qr!(A::DArray) (src:115-120, 311-315;
+# test/runtests.jl:71-78).  Written against DistributedArrays' API (procs(A), localpart(A), size(A)); the package is
+# loaded by the caller exactly as with the reference.  `devices[i]` is the HIP device of the i-th worker of A.
+const _comm = Ref{Ptr{Cvoid}}(C_NULL)
+
+"RCCL unique id (128 bytes): created on ONE worker, shipped to the others by the caller"
+function comm_unique_id()
+  id = zeros(UInt8, 128)
+  check(ccall((:dhqr_comm_unique_id, libdhqr), Int32, (Ptr{UInt8},), id))
+  return id
+end
+
+"collective over the workers: bind this worker (rank `rank` of `nranks`, 0-based) to GPU `device`"
+function comm_init(id::Vector{UInt8}, nranks::Integer, rank::Integer, device::Integer)
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  check(ccall((:dhqr_comm_create_rank, libdhqr), Int32,
+              (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}),
+              h, context(device), Int32(nranks), Int32(rank), id))
+  _comm[] = h[]
+  return nothing
+end
+
+"this worker's part of householder!(A::DArray, α): `Al` is its contiguous column block (localpart), m x n the global size"
+function householder_local!(Al::StridedMatrix{Float64}, m::Integer, n::Integer, α::Vector{Float64})
+  check(ccall((:dhqr_cs_qr_darray_f64, libdhqr), Int32,
+              (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}),
+              _comm[], Al, m, n, max(stride(Al, 2), m), α))
+  return α
+end
+
+# The DArray method itself needs DistributedArrays (not a dependency of this file: the method is defined when the
+# caller has loaded it, the way the reference's src:115-120 is written against it).
+function __init_darray_methods__(DistributedArrays)
+  @eval begin
+    function householder!(A::$(DistributedArrays).DArray{Float64, 2}, α::Vector{Float64}; devices=nothing)
+      ws = vec(procs(A))
+      np = length(ws)
+      m, n = size(A)
+      devs = devices === nothing ? collect(0:np-1) : devices
+      id = remotecall_fetch(comm_unique_id, ws[1])                       # replaces the SharedArray bootstrap (src:301-304)
+      @sync for (i, p) in enumerate(ws)                                  # ncclCommInitRank is collective
+        @async remotecall_wait(comm_init, p, id, np, i - 1, devs[i])
+      end
+      futs = [remotecall(p) do                                           # ONE call per worker (src:115-120 visits owners
+                al = zeros(Float64, n)                                   #   sequentially and fans out every column)
+                householder_local!($(DistributedArrays).localpart(A), m, n, al)
+              end for p in ws]
+      α .= fetch(futs[1])                                                # α is replicated (SharedArray in the reference)
+      foreach(wait, futs)
+      return (A, α)
+    end
+    function qr!(A::$(DistributedArrays).DArray{Float64, 2}; devices=nothing)   # src:311-315
+      H = DistributedHouseholderQRStruct(A, zeros(Float64, size(A, 2)))
+      householder!(H.A, H.α; devices=devices)
+      return H
+    end
+  end
 end
 
 alphafactor(x::Real) = -sign(x)   # src:8 (kept for API completeness; the device applies the same rule)

@@ -61,7 +61,7 @@ int main(int argc, char **argv) {
     if (swz) { lx = (((gx + 7) / 8) * ((gy + 7) / 8) + 7) / 8 * 512; ly = 1; }  // the library's 1-D launch
 #define NN(VEC_, KW_)                                                                                     \
   grid2(lx, ly, 256, [&] {                                                                                \
-    k_gemm_nn_sub<VEC_, KW_>(V.data(), ldv, W.data(), (int64_t)KW_, C.data(), ldc, rows, ncols, swz);     \
+    k_gemm_nn_sub<VEC_, KW_>(V.data(), ldv, W.data(), (int64_t)KW_, C.data(), ldc, rows, ncols, swz, nullptr, 0);     \
   })
     if (vec == 2 && kparam == 128) NN(2, 128);
     else if (vec == 1 && kparam == 128) NN(1, 128);

@@ -35,7 +35,8 @@ __global__ void k_selftest(double *out) {
 int main(int argc, char **argv) {
   if (argc < 3) return 2;
   const std::string op = argv[1];
-  const int variant = atoi(argv[2]);
+  const int variant = atoi(argv[2]);  // kernel generation (one at present)
+  (void)variant;
   const size_t NN = RC_N * RC_N;
   if (op == "chol") {  // chol <variant> G Rprev|- want_inv outR outNegX outFlag
     auto G = rd(argv[3], NN);
@@ -46,10 +47,7 @@ int main(int argc, char **argv) {
     std::vector<double> R(NN, -7.0), X(NN, -7.0);
     int flag[2] = {0, 0};
     simt::launch_block(1024, [&] {
-      if (variant == 4)
-        k_chol_inv4(G.data(), has_prev ? Rprev.data() : nullptr, R.data(), want_inv ? X.data() : nullptr, flag);
-      else
-        k_chol_inv(G.data(), has_prev ? Rprev.data() : nullptr, R.data(), want_inv ? X.data() : nullptr, flag);
+      k_chol_inv(G.data(), has_prev ? Rprev.data() : nullptr, R.data(), want_inv ? X.data() : nullptr, flag);
     });
     wr(argv[6], R);
     wr(argv[7], X);
@@ -59,9 +57,7 @@ int main(int argc, char **argv) {
     auto R = rd(argv[4], NN);
     std::vector<double> alpha(RC_N, -7.0), Rref(NN, -7.0), negMinv(NN, -7.0);
     simt::launch_block(1024, [&] {
-      if (variant == 5) k_recon_top5(P.data(), (int64_t)RC_N, R.data(), alpha.data(), Rref.data(), negMinv.data());
-      else if (variant == 4) k_recon_top4(P.data(), (int64_t)RC_N, R.data(), alpha.data(), Rref.data(), negMinv.data());
-      else k_recon_top(P.data(), (int64_t)RC_N, R.data(), alpha.data(), Rref.data(), negMinv.data());
+      k_recon_top(P.data(), (int64_t)RC_N, R.data(), alpha.data(), Rref.data(), negMinv.data());
     });
     wr(argv[5], alpha);
     wr(argv[6], Rref);
@@ -71,9 +67,7 @@ int main(int argc, char **argv) {
     const int ncols = atoi(argv[4]);
     std::vector<double> T(NN, -7.0), Tt(NN, -7.0);
     simt::launch_block(1024, [&] {
-      if (variant == 5) k_build_t5(S.data(), ncols, T.data(), Tt.data());
-      else if (variant == 4) k_build_t4(S.data(), ncols, T.data(), Tt.data());
-      else k_build_t3(S.data(), ncols, T.data(), Tt.data());
+      k_build_t(S.data(), ncols, T.data(), Tt.data());
     });
     wr(argv[5], T);
     wr(argv[6], Tt);

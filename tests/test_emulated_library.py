@@ -82,12 +82,11 @@ def test_factor_drivers_vs_oracle(emu, orc, m, n, nb):
     assert emu.dhqr_destroy(h) == 0
 
 
-def test_two_panel_driver_and_next_kernel_generation(emu, orc):
-    """factor_blocked_pair (K = 256 wide updates) engages for n >= DHQR_PAIR_MIN_N; DHQR_SMALLK=4 selects the
-    one-barrier-per-step panel kernels, 5 adds the blocked inverses -- same factorisation, every panel fast"""
+def test_two_panel_driver_and_switches(emu, orc):
+    """two-panel groups (K = 256 wide updates) engage for n >= DHQR_PAIR_MIN_N; DHQR_PAIR=0 keeps single-panel
+    groups, DHQR_LOOKAHEAD=0 the simple host-verified loop -- same factorisation, every panel on the fast path"""
     A0 = orc.rand_matrix(640, 512, 4)
-    for env in ({"DHQR_PAIR_MIN_N": 512}, {"DHQR_PAIR_MIN_N": 512, "DHQR_SMALLK": 4}, {"DHQR_SMALLK": 5},
-                {"DHQR_LOOKAHEAD": 0}):
+    for env in ({"DHQR_PAIR_MIN_N": 512}, {"DHQR_PAIR": 0}, {"DHQR_LOOKAHEAD": 0}):
         h = _ctx(emu, **env)
         A, al = _factor(emu, h, A0, 128)
         _check(orc, A0, A, al)

@@ -1,8 +1,7 @@
 """CPU execution of UNMODIFIED HIP kernel sources on the SIMT emulator of tests/simt/ (one OS thread per
 HIP thread, ThreadSanitizer build):
-  * the single-workgroup panel kernels (csrc/dhqr_recon.h), both generations: variant 3 = the kernels the
-    library runs by default, 4 = the one-barrier-per-step kernels (DHQR_SMALLK=4), 5 = 4 + blocked
-    triangular inverses with five barriers (DHQR_SMALLK=5);
+  * the single-workgroup panel kernels (csrc/dhqr_recon.h): one-barrier-per-step Cholesky / replay, blocked
+    triangular inverses with five barriers;
   * the unblocked factorisation kernels for Float64 and ComplexF64 (dhqr_rank1.h, dhqr_complex.h) and the
     solve kernels (dhqr_solve.h, dhqr_complex.h), launched in the library's per-column sequence;
   * the FP64-MFMA trailing-update GEMMs (dhqr_gemm.h) with v_mfma_f64_16x16x4_f64 emulated wave-
@@ -76,7 +75,7 @@ def test_rig_detects_a_missing_barrier(emu, tmp_path):
     assert "ThreadSanitizer: data race" in r.stderr
 
 
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [5])
 def test_cholesky_and_inverse(emu, orc, tmp_path, variant):
     P = orc.rand_matrix(300, N, 5)
     G = P.T @ P
@@ -89,7 +88,7 @@ def test_cholesky_and_inverse(emu, orc, tmp_path, variant):
     assert np.abs(-negX - np.linalg.inv(Rn)).max() < 1e-12 * np.abs(np.linalg.inv(Rn)).max()
     assert np.array_equal(np.tril(R, -1), np.zeros((N, N)))
     assert np.array_equal(np.fromfile(f["flag"]), [0.0, 0.0])
-    if variant == 4:  # second CholeskyQR pass (R <- R * Rprev) and the breakdown flag: once is enough
+    if True:  # second CholeskyQR pass (R <- R * Rprev) and the breakdown flag: once is enough
         Q1 = P @ np.linalg.inv(Rn)
         _put(f["G"], Q1.T @ Q1)
         _put(f["Rp"], Rn)
@@ -105,7 +104,7 @@ def test_cholesky_and_inverse(emu, orc, tmp_path, variant):
         assert np.fromfile(f["flag"])[0] == 1.0
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5])
+@pytest.mark.parametrize("variant", [5])
 def test_replay_of_top_block(emu, orc, tmp_path, variant):
     rows = 300
     P = orc.rand_matrix(rows, N, 6)
@@ -127,7 +126,7 @@ def test_replay_of_top_block(emu, orc, tmp_path, variant):
     assert np.array_equal(np.tril(negMinv, -1), np.zeros((N, N)))  # -M^{-1} is upper triangular
 
 
-@pytest.mark.parametrize("variant,ncols", [(3, 77), (3, 128), (4, 128), (4, 77), (5, 128), (5, 77), (5, 1)])
+@pytest.mark.parametrize("variant,ncols", [(5, 128), (5, 77), (5, 1)])
 def test_block_reflector_t(emu, orc, tmp_path, variant, ncols):
     Ho, _ = orc.householder(orc.rand_matrix(300, ncols, 7))
     V = np.zeros((300, N))
@@ -252,7 +251,7 @@ def test_gemm_nn_sub(emu_gemm, tmp_path, vec, kw, rows, ncols, swz):
 
 # ------------------------------------------------------------------ memory safety of the new generations
 def test_new_panel_kernels_under_address_sanitizer(orc, tmp_path):
-    """the DHQR_SMALLK=4/5 kernels once more in an AddressSanitizer build of the emulator: no access outside
+    """the panel kernels once more in an AddressSanitizer build of the emulator: no access outside
     the LDS arrays (static globals with red zones) or the global buffers (heap allocations)"""
     exe = str(tmp_path / "emu_recon_asan")
     subprocess.check_call([CLANG, "-std=c++20", "-O1", "-g", "-fsanitize=address", "-Wno-unknown-attributes",
@@ -267,10 +266,9 @@ def test_new_panel_kernels_under_address_sanitizer(orc, tmp_path):
     _put(f["R"], np.linalg.qr(P, mode="r"))
     _put(f["G"], P.T @ P)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
-    for args in (("buildt", 4, f["S"], 128, f["o1"], f["o2"]), ("buildt", 5, f["S"], 128, f["o1"], f["o2"]),
+    for args in (("buildt", 5, f["S"], 128, f["o1"], f["o2"]),
                  ("buildt", 5, f["S"], 77, f["o1"], f["o2"]),
-                 ("recon", 4, f["P"], f["R"], f["o1"], f["o2"], f["o3"]),
                  ("recon", 5, f["P"], f["R"], f["o1"], f["o2"], f["o3"]),
-                 ("chol", 4, f["G"], "-", 1, f["o1"], f["o2"], f["o3"])):
+                 ("chol", 5, f["G"], "-", 1, f["o1"], f["o2"], f["o3"])):
         r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=600, env=env)
         assert "AddressSanitizer" not in r.stderr and r.returncode == 0, (args[:2], r.stderr[:2000])
