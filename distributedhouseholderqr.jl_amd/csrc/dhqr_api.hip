@@ -55,7 +55,7 @@ struct dhqr_ctx {
   bool profiling = false;
   hipStream_t hi = nullptr;      // high-priority stream: panel factorisation under look-ahead
   int swizzle = 1;               // XCD-aware tile order in k_gemm_nn_sub (+1.5 % at 32768^2; DHQR_SWIZZLE=0 disables)
-  struct WS { Buf w1, w1r, w1r2, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
+  struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
   int cur_ws = 0;
   bool lookahead = true;
   Buf vbuf, vt, vts, spart, sfull, scratch, pbuf;
@@ -195,7 +195,7 @@ static inline void launch_recon_top(dhqr_ctx *c, const double *P, int64_t ldp, c
   hipLaunchKernelGGL(k_recon_top, dim3(1), dim3(1024), 0, c->stream, P, ldp, R, alpha, Rref, negMinv);
 }
 static inline void launch_build_t(dhqr_ctx *c, const double *S, int ncols, double *T, double *Tt) {
-  hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt);
+  hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt, 0.0, (int *)nullptr, 0, (double *)nullptr);
 }
 
 // ---- where a factored panel's GEMM operands live --------------------------------------------------
@@ -245,8 +245,7 @@ static void launch_nn_sub(dhqr_ctx *c, bool vec, dim3 grid, const double *V, int
 // Split-K factor for k_gemm_tn: `ntiles` column tiles x ns row slabs should fill the 512 resident
 // workgroup slots (256 CUs x 2) in whole waves -- 765 workgroups on 512 slots run at 75 %.
 static void pick_split(int64_t rows, int64_t ntiles, int64_t target_wgs, int64_t max_split,
-                       int64_t *nsplit, int64_t *rps) {
-  const int64_t slots = 512;
+                       int64_t *nsplit, int64_t *rps, int64_t slots = 512) {
   int64_t cap = std::min<int64_t>(max_split, std::max<int64_t>(1, rows / 128));
   int64_t best = 1;
   double best_score = -1.0;
@@ -503,7 +502,7 @@ static int32_t status_read(dhqr_ctx *c, int *first_failed) {
 
 // Enqueue the R-first factorisation of a full-width panel (w == 128, rows >= 256) WITHOUT waiting for its
 // verification: nothing is written to P, alpha or pb.T/Tt/alpha unless the panel is accepted on the device
-// (k_recon_decide); once a panel has failed every later commit / trailing update with epoch >= its index is a
+// (k_build_t); once a panel has failed every later commit / trailing update with epoch >= its index is a
 // no-op, and the driver resumes from it with factor_panel_sync after its single final synchronisation.
 static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t ldp, double *alpha, const PanelBuf &pb,
                                   int passes, int panel_idx) {
@@ -527,16 +526,18 @@ static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t 
       CHECK(mul128(c, P, ldp, rows, negR1inv, Q1, ldq));                           // Q1 = P R1^{-1}
       CHECK(gram128(c, Q1, ldq, rows, G));                                         // G2 = Q1'Q1
       launch_chol_inv(c, G, R1, Rf, nullptr, bflag);                                // R  = chol(G2) R1
-    } else {
-      launch_chol_inv(c, G, nullptr, Rf, nullptr, bflag);                           // R = chol(P'P)
+      launch_recon_top(c, P, ldp, Rf, altmp, Rref, negMinv);                        // alpha, R_ref, -M^{-1}
+    } else {  // R = chol(P'P), replay, -M^{-1} in one launch
+      hipLaunchKernelGGL(k_panel_top, dim3(1), dim3(1024), 0, c->stream, (const double *)G, (const double *)P, ldp, altmp,
+                         Rref, negMinv, bflag);
     }
-    launch_recon_top(c, P, ldp, Rf, altmp, Rref, negMinv);                          // alpha, R_ref, -M^{-1}
     CHECK(mul128(c, P, ldp, rows, negMinv, pb.V, ldv));                            // Vw = P M^{-1}
     hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, pb.V, ldv, (const double *)altmp,
                        (const double *)negMinv);                                   // Vw = tril((P - aE) M^{-1})
     CHECK(gram128(c, pb.V, ldv, rows, c->sfull.p));                                // S = V'V
-    hipLaunchKernelGGL(k_recon_decide, dim3(1), dim3(128), 0, c->stream, (const double *)c->sfull.p, c->recon_tol,
-                       c->dstat, panel_idx, pb.alpha + DHQR_NBV);
+    // T from S, fused with the acceptance decision (before the predicated commits)
+    hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sfull.p, (int)DHQR_NBV, pb.T, pb.Tt,
+                       c->recon_tol, c->dstat, panel_idx, pb.alpha + DHQR_NBV);
     // commit (device-side predicate): reflectors, R, alpha; T is only ever read by accepted consumers
     dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
     hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, P, ldp, rows, (int64_t)DHQR_NBV, (const double *)pb.V,
@@ -545,7 +546,6 @@ static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t 
                        (const int *)c->dstat, panel_idx);
     hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, (const double *)altmp, (int)DHQR_NBV, alpha,
                        pb.alpha, (const int *)c->dstat, panel_idx);
-    launch_build_t(c, c->sfull.p, (int)DHQR_NBV, pb.T, pb.Tt);
     LAUNCHCHECK();
     return DHQR_OK;
   };
@@ -590,57 +590,49 @@ static int32_t factor_panel_sync(dhqr_ctx *c, double *P, int64_t rows, int64_t w
 //   W_a = T_a' (V_a' C),  W_b = T_b' (V_b' C - (V_b' V_a) W_a),  C -= [V_a V_b] [W_a; W_b].
 // Vp = [V_a | V_b] (ldv x 256; V_b shifted down by 128 rows, zeros above), rows = rows of panel a.
 // Halves the C read+write traffic of the NN GEMM per flop (0.125 -> 0.094 B/flop through the CU
-// memory pipe), which is what bounds k_gemm_nn_sub.
+// memory pipe), which is what bounds k_gemm_nn_sub; the TN pass (k_gemm_tn2) reads C once for both panels.
 static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows, const double *Ta,
                           const double *Tb, const double *Sba, double *C, int64_t ncols, int64_t ldc) {
   if (ncols <= 0) return DHQR_OK;
   const int64_t rows_b = rows - DHQR_NBV;
   const int64_t ntiles = (ncols + 127) / 128;
   int64_t nsplit, rps;
-  pick_split(rows, ntiles, 512, ntiles <= 2 ? 256 : 64, &nsplit, &rps);
+  // k_gemm_tn2 workgroups have 512 threads and 110 KB of LDS: one per CU, 256 resident
+  pick_split(rows, ntiles, 256, ntiles <= 2 ? 256 : 64, &nsplit, &rps, 256);
   dhqr_ctx::WS &ws = c->ws[c->cur_ws];
-  CHECK(ensure(c, ws.w1, (size_t)nsplit * DHQR_NBV * (size_t)ncols));
-  CHECK(ensure(c, ws.w1r, (size_t)DHQR_NBV * (size_t)ncols));
-  CHECK(ensure(c, ws.w1r2, (size_t)DHQR_NBV * (size_t)ncols));
-  CHECK(ensure(c, ws.w2, (size_t)2 * DHQR_NBV * (size_t)ncols));
+  const int64_t ld2 = 2 * DHQR_NBV;
+  CHECK(ensure(c, ws.w1, (size_t)nsplit * ld2 * (size_t)ncols));
+  CHECK(ensure(c, ws.w1r, (size_t)ld2 * (size_t)ncols));
+  CHECK(ensure(c, ws.w2, (size_t)ld2 * (size_t)ncols));
   const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(Vp);
-  const int64_t wstride = (int64_t)DHQR_NBV * ncols;
-  const double *Vb = Vp + DHQR_NBV + (int64_t)DHQR_NBV * ldv;  // first non-zero row of V_b
+  const int64_t wstride = ld2 * ncols;
   const dim3 gtn((unsigned)ntiles, (unsigned)nsplit), gred((unsigned)((wstride + 63) / 64));
 
+  // Y = [V_a V_b]' C: ONE pass over C for both panels (stacked 256 x ncols result), then the split-K reduction
   CHECK(prof_begin(c, CAT_VTA));
-  if (vec) {
-    hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), gtn, dim3(256), 0, c->stream, Vp, ldv, (const double *)C, ldc, 1,
-                       (int64_t)0, rows, ncols, rps, ws.w1.p, (int64_t)DHQR_NBV, wstride);
-    hipLaunchKernelGGL(k_reduce_splits, gred, dim3(256), 0, c->stream, (const double *)ws.w1.p, (int)nsplit, wstride,
-                       wstride, ws.w1r.p);
-    hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), gtn, dim3(256), 0, c->stream, Vb, ldv, (const double *)(C + DHQR_NBV),
-                       ldc, 1, (int64_t)0, rows_b, ncols, rps, ws.w1.p, (int64_t)DHQR_NBV, wstride);
-  } else {
-    hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), gtn, dim3(256), 0, c->stream, Vp, ldv, (const double *)C, ldc, 1,
-                       (int64_t)0, rows, ncols, rps, ws.w1.p, (int64_t)DHQR_NBV, wstride);
-    hipLaunchKernelGGL(k_reduce_splits, gred, dim3(256), 0, c->stream, (const double *)ws.w1.p, (int)nsplit, wstride,
-                       wstride, ws.w1r.p);
-    hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), gtn, dim3(256), 0, c->stream, Vb, ldv, (const double *)(C + DHQR_NBV),
-                       ldc, 1, (int64_t)0, rows_b, ncols, rps, ws.w1.p, (int64_t)DHQR_NBV, wstride);
-  }
-  hipLaunchKernelGGL(k_reduce_splits, gred, dim3(256), 0, c->stream, (const double *)ws.w1.p, (int)nsplit, wstride,
-                     wstride, ws.w1r2.p);
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_tn2<2>), gtn, dim3(512), 0, c->stream, Vp, ldv, (const double *)C, ldc, rows, ncols, rps,
+                       ws.w1.p, wstride);
+  else
+    hipLaunchKernelGGL((k_gemm_tn2<1>), gtn, dim3(512), 0, c->stream, Vp, ldv, (const double *)C, ldc, rows, ncols, rps,
+                       ws.w1.p, wstride);
+  hipLaunchKernelGGL(k_reduce_splits, gred, dim3(256), 0, c->stream, (const double *)ws.w1.p, (int)nsplit, wstride, wstride,
+                     ws.w1r.p);
   CHECK(prof_end(c));
 
   CHECK(prof_begin(c, CAT_TW));
-  const int64_t ld2 = 2 * DHQR_NBV;
+  double *Ya = ws.w1r.p, *Yb = ws.w1r.p + DHQR_NBV;  // rows 0..127 / 128..255 of Y (ld 256)
   // W_a = T_a' Y_a  -> rows 0..127 of W2 (ld 256)
   hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Ta, (int64_t)DHQR_NBV,
-                     (const double *)ws.w1r.p, (int64_t)DHQR_NBV, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols,
-                     (int64_t)DHQR_NBV, ws.w2.p, ld2, (int64_t)0);
+                     (const double *)Ya, ld2, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV, ws.w2.p, ld2,
+                     (int64_t)0);
   // Y_b -= (V_b' V_a) W_a   (workspace: never predicated)
-  launch_nn_sub<128>(c, true, dim3(1, (unsigned)ntiles), Sba, (int64_t)DHQR_NBV, (const double *)ws.w2.p, ld2, ws.w1r2.p,
-                     (int64_t)DHQR_NBV, (int64_t)DHQR_NBV, ncols, 0, false);
+  launch_nn_sub<128>(c, true, dim3(1, (unsigned)ntiles), Sba, (int64_t)DHQR_NBV, (const double *)ws.w2.p, ld2, Yb, ld2,
+                     (int64_t)DHQR_NBV, ncols, 0, false);
   // W_b = T_b' Y_b  -> rows 128..255 of W2
   hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Tb, (int64_t)DHQR_NBV,
-                     (const double *)ws.w1r2.p, (int64_t)DHQR_NBV, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols,
-                     (int64_t)DHQR_NBV, ws.w2.p + DHQR_NBV, ld2, (int64_t)0);
+                     (const double *)Yb, ld2, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV,
+                     ws.w2.p + DHQR_NBV, ld2, (int64_t)0);
   CHECK(prof_end(c));
 
   CHECK(prof_begin(c, CAT_AVW));
@@ -853,8 +845,8 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   (void)hipDeviceSynchronize();
   cs_state_free(c);
-  Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w1r2, &c->ws[0].w2, &c->ws[1].w1,
-                 &c->ws[1].w1r, &c->ws[1].w1r2, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf};
+  Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
+                 &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {

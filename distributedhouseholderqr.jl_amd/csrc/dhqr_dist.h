@@ -13,7 +13,7 @@
 //   comm                   one broadcast per panel of its operands [T | T' | alpha | status | V] (root = owner);
 //   wide  (caller's)       apply group g to the local blocks beyond group g+1 -- first the blocks of group g+2
 //                          ("head": the lane needs them next), then the rest.
-// Nothing in the loop waits on the host: panels are committed on the device (k_recon_decide) and the driver
+// Nothing in the loop waits on the host: panels are committed on the device (k_build_t) and the driver
 // reads one status word after the last launch; a rejected panel (ill-conditioned for CholeskyQR) makes every
 // later matrix update a no-op and the run resumes from that panel with the host-verified robust path.
 //
@@ -349,11 +349,10 @@ static int32_t cs_prepare(const CsProblem &pr) {
   CHECK(ensure(c, c->vts, (size_t)panel_elems(m)));
   const size_t ncmax = (size_t)std::max<int64_t>(pr.ncl, 2 * NB);
   const size_t ntmax = (ncmax + 127) / 128;
-  const size_t w1cap = NN * (2048 + ntmax + 64);
+  const size_t w1cap = NN * (2048 + 2 * ntmax + 128);  // split-K partials of k_gemm_tn (128 rows) / k_gemm_tn2 (256 rows)
   for (int s = 0; s < 2; ++s) {
-    CHECK(ensure(c, c->ws[s].w1, s == 0 ? w1cap : NN * 1100));
-    CHECK(ensure(c, c->ws[s].w1r, (size_t)NB * ncmax));
-    CHECK(ensure(c, c->ws[s].w1r2, (size_t)NB * ncmax));
+    CHECK(ensure(c, c->ws[s].w1, s == 0 ? w1cap : NN * 2200));
+    CHECK(ensure(c, c->ws[s].w1r, (size_t)2 * NB * ncmax));
     CHECK(ensure(c, c->ws[s].w2, (size_t)2 * NB * ncmax));
   }
   CHECK(ensure(c, c->spart, (size_t)256 * NN));

@@ -190,6 +190,139 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
 }
 
 // -------------------------------------------------------------------------------------------
+// k_gemm_tn2:  the W = [V_a V_b]' C pass of a TWO-panel update in one kernel, so C is read once:
+//   out[y][p + c*256] = sum_{r in slab y} V[r + p*ldv] * C[r + c*ldc],   p in [0,256)
+// (V_b is stored shifted down by 128 rows with zeros above, dhqr_dist.h, so both halves share the row range.)
+// 512 threads = 8 waves as 2 (columns) x 4 (p), each wave the same 64 x 64 block of 4 x 4 MFMA tiles as in
+// k_gemm_tn; output tile 128 columns x 256 reflectors.  Per K-tile the workgroup stages 48 KB for 1.05 MFLOP
+// (21.8 flop/B through the CU memory pipe, against 16 for two 128-reflector passes).  One workgroup per CU
+// (110 KB of LDS), i.e. the same 2 waves per SIMD as two k_gemm_tn workgroups.
+template <int VEC>
+__global__ __launch_bounds__(512) void k_gemm_tn2(const double *__restrict__ V, int64_t ldv,
+                                                  const double *__restrict__ C, int64_t ldc, int64_t rows,
+                                                  int64_t ncols, int64_t rps, double *__restrict__ out,
+                                                  int64_t osplit_stride) {
+  constexpr int NP = 256;
+  __shared__ __attribute__((aligned(16))) double Vs[2][NP * G_LDK];
+  __shared__ __attribute__((aligned(16))) double Cs[2][128 * G_LDK];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int i16 = lane & 15, k4 = lane >> 4;
+  const int wc = w >> 2, wp = w & 3;
+  const int64_t c0 = (int64_t)blockIdx.x * 128;
+  const int64_t rbeg = (int64_t)blockIdx.y * rps;
+  const int64_t rend = (rbeg + rps < rows) ? rbeg + rps : rows;
+  const int nkt = (int)((rend - rbeg + G_KT - 1) / G_KT);
+  const int ncv = (int)((ncols - c0 < 128) ? ncols - c0 : 128);
+
+  dhqr_d4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+
+  // staging: V tile = 256 columns x 16 rows = 2048 row pairs (4 per thread), C tile = 128 x 16 = 1024 (2 per thread)
+  const double *Vb = V + rbeg;
+  const double *Cb = C + rbeg + c0 * ldc;
+  uint32_t offv[4], offc[2];
+  bool okc[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) offv[i] = (uint32_t)(((t + i * 512) >> 3) * ldv);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int col = (t + i * 512) >> 3;
+    okc[i] = col < ncv;
+    offc[i] = (uint32_t)((okc[i] ? col : 0) * ldc);
+  }
+  double2 sv[4], sc[2];
+  auto load_tile = [&](int kt) {  // issue only (see k_gemm_tn)
+    const int left = (int)(rend - rbeg) - kt * G_KT;
+    const double *Vt = Vb + kt * G_KT;
+    const double *Ct = Cb + kt * G_KT;
+    const int rp = t & 7;
+    if constexpr (VEC == 2) {
+      const uint32_t ro = (2 * rp < left) ? 2 * rp : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sv[i] = *reinterpret_cast<const double2 *>(Vt + (offv[i] + ro));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) sc[i] = *reinterpret_cast<const double2 *>(Ct + (offc[i] + ro));
+    } else {
+      const uint32_t r0o = (2 * rp < left) ? 2 * rp : 0, r1o = (2 * rp + 1 < left) ? 2 * rp + 1 : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        sv[i].x = Vt[offv[i] + r0o];
+        sv[i].y = Vt[offv[i] + r1o];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        sc[i].x = Ct[offc[i] + r0o];
+        sc[i].y = Ct[offc[i] + r1o];
+      }
+    }
+  };
+  auto store_tile = [&](int buf, int kt) {
+    const int left = (int)(rend - rbeg) - kt * G_KT;
+    const int rp = t & 7;
+    const bool ok0 = 2 * rp < left, ok1 = 2 * rp + 1 < left;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double2 x = sv[i];
+      if (!ok0) x.x = 0.0;
+      if (!ok1) x.y = 0.0;
+      *reinterpret_cast<double2 *>(&Vs[buf][((t + i * 512) >> 3) * G_LDK + 2 * rp]) = x;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      double2 y = sc[i];
+      if (!ok0) y.x = 0.0;
+      if (!ok1) y.y = 0.0;
+      if (!okc[i]) y = make_double2(0.0, 0.0);
+      *reinterpret_cast<double2 *>(&Cs[buf][((t + i * 512) >> 3) * G_LDK + 2 * rp]) = y;
+    }
+  };
+
+  if (nkt > 0) {
+    load_tile(0);
+    store_tile(0, 0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const double *cs = &Cs[buf][(wc * 64 + i16) * G_LDK + k4];
+    const double *vs = &Vs[buf][(wp * 64 + i16) * G_LDK + k4];
+#pragma unroll
+    for (int kk = 0; kk < G_KT / 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        a[x] = cs[x * 16 * G_LDK + kk * 4];
+        b[x] = vs[x * 16 * G_LDK + kk * 4];
+      }
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) acc[ci][pi] = mfma_f64(a[ci], b[pi], acc[ci][pi]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nkt) store_tile(buf ^ 1, kt + 1);
+    __syncthreads();
+  }
+
+  double *o = out + (int64_t)blockIdx.y * osplit_stride + c0 * NP;
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
+      if (cl < ncv) {
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) o[(uint32_t)(wp * 64 + pi * 16 + i16) + (uint32_t)(cl * NP)] = acc[ci][pi][g];
+      }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // k_gemm_nn_sub:  C[r + c*ldc] -= sum_{p<128} V[r + p*ldv] * W[p + c*ldw]
 //   r in [0,rows), c in [0,ncols).  grid = (ceil(rows/128), ceil(ncols/128)).
 // The accumulators are initialised with the C tile and the W operand is negated while staging,

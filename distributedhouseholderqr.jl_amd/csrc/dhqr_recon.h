@@ -77,19 +77,11 @@ __device__ __forceinline__ void rc_upper_inverse_regs(const double (&r)[4][4], d
     }
 }
 
-__global__ __launch_bounds__(1024) void k_chol_inv(const double *__restrict__ G,
-                                                    const double *__restrict__ Rprev,
-                                                    double *__restrict__ Rout,
-                                                    double *__restrict__ negXout,
-                                                    int *__restrict__ flag) {
-  __shared__ double rowbuf[2 * RC_N], colbuf[2 * RC_N], dinv[RC_N];
+// Cholesky G = R'R (upper R) of a 128 x 128 matrix held in registers in the 4 x 4 cyclic layout (thread (ti,tk)
+// owns G[ti+32a][tk+32b]); on return the upper triangle of g is R (entries below the diagonal are scratch).
+// One barrier per step; rowbuf: 2 x 128 doubles of LDS.  flag[0] = 1 when a pivot is not positive (breakdown).
+__device__ __forceinline__ void rc_cholesky_regs(double (&g)[4][4], double *rowbuf, int *__restrict__ flag) {
   const int t = threadIdx.x, ti = t >> 5, tk = t & 31, lane = t & 63;
-  double g[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) g[a][b] = G[(ti + 32 * a) + (tk + 32 * b) * RC_N];
-
 #pragma unroll
   for (int ja = 0; ja < 4; ++ja)
     for (int jm = 0; jm < 32; ++jm) {
@@ -120,6 +112,22 @@ __global__ __launch_bounds__(1024) void k_chol_inv(const double *__restrict__ G,
         for (int b = 0; b < 4; ++b) g[a][b] = fma(-ri, rb[tk + 32 * b], g[a][b]);
       }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_chol_inv(const double *__restrict__ G,
+                                                    const double *__restrict__ Rprev,
+                                                    double *__restrict__ Rout,
+                                                    double *__restrict__ negXout,
+                                                    int *__restrict__ flag) {
+  __shared__ double rowbuf[2 * RC_N], colbuf[2 * RC_N], dinv[RC_N];
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
+  double g[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) g[a][b] = G[(ti + 32 * a) + (tk + 32 * b) * RC_N];
+
+  rc_cholesky_regs(g, rowbuf, flag);
   // registers now hold R in the upper triangle
   if (Rprev) {  // R <- R * Rprev (second CholeskyQR pass)
     __shared__ double Rl[RC_N * (RC_N + 1) / 2];
@@ -265,10 +273,27 @@ __device__ __forceinline__ void rc5_emit(const rc5_lds &L, const double (&x12)[4
   }
 }
 
+// stat != nullptr: fused with the panel's acceptance decision (see "device-side commit" below), taken BEFORE the launches
+// that commit the panel: one launch less on the critical chain.
 __global__ __launch_bounds__(1024) void k_build_t(const double *__restrict__ S, int ncols,
                                                    double *__restrict__ Tout,
-                                                   double *__restrict__ Ttout) {
+                                                   double *__restrict__ Ttout, double tol,
+                                                   int *__restrict__ stat, int panel_idx,
+                                                   double *__restrict__ statword) {
   __shared__ rc5_lds L;
+  __shared__ int bad[RC_N];
+  if (stat != nullptr) {
+    const int j = threadIdx.x;
+    if (j < RC_N) bad[j] = (fabs(S[j + j * RC_N] - 2.0) <= tol) ? 0 : 1;
+    __syncthreads();
+    if (j == 0) {
+      int any = stat[1];
+      for (int q = 0; q < RC_N; ++q) any |= bad[q];
+      if (any && stat[0] > panel_idx) stat[0] = panel_idx;
+      stat[1] = 0;
+      if (statword) *statword = (double)stat[0];
+    }
+  }
   double x12[4];
   rc_upper_inverse_blocked(S, ncols, true, L, x12);
   rc5_emit(L, x12, [&](int i, int k, double v) {
@@ -277,26 +302,20 @@ __global__ __launch_bounds__(1024) void k_build_t(const double *__restrict__ S, 
   });
 }
 
-// k_recon_top with the one-barrier replay of k_recon_top4 and the blocked inverse: M is parked in the
-// negMinv output buffer (global, L2 resident), inverted from there, and the buffer is overwritten last.
-__global__ __launch_bounds__(1024) void k_recon_top(const double *__restrict__ P, int64_t ldp,
-                                                     const double *__restrict__ R,
-                                                     double *__restrict__ alpha,
-                                                     double *__restrict__ Rref,
-                                                     double *__restrict__ negMinv) {
-  __shared__ double wrow[2 * RC_N], vcol[2 * RC_N];
-  __shared__ rc5_lds L;
+// Replay of the unblocked algorithm on the top 128 x 128 block with R known (see the file header), then
+// -M^{-1} by the blocked inverse.  a: top block of P, r: R (upper triangle used, any row signs), both in the
+// 4 x 4 cyclic register layout.  Outputs: alpha[128]; Rref = strict upper part of the reference's R (row signs
+// fixed so that R_jj = alpha_j), dense; negMinv = -M^{-1}, dense.  M is parked in the negMinv buffer (global,
+// L2 resident), inverted from there, and the buffer is overwritten last.
+__device__ __forceinline__ void rc_replay_and_invert(double (&a)[4][4], const double (&r)[4][4], double *wrow,
+                                                     double *vcol, rc5_lds &L, double *__restrict__ alpha,
+                                                     double *__restrict__ Rref, double *__restrict__ negMinv) {
   const int t = threadIdx.x, ti = t >> 5, tk = t & 31, lane = t & 63;
-  double a[4][4], r[4][4], mm[4][4];
+  double mm[4][4];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) {
-      const int i = ti + 32 * x, k = tk + 32 * y;
-      a[x][y] = P[i + (int64_t)k * ldp];
-      r[x][y] = R[i + k * RC_N];
-      mm[x][y] = 0.0;
-    }
+    for (int y = 0; y < 4; ++y) mm[x][y] = 0.0;
 #pragma unroll
   for (int ja = 0; ja < 4; ++ja)
     for (int jm = 0; jm < 32; ++jm) {
@@ -305,25 +324,25 @@ __global__ __launch_bounds__(1024) void k_recon_top(const double *__restrict__ P
       const double ajj = __shfl(a[ja][ja], src, 64), rjj = __shfl(r[ja][ja], src, 64);
       double *wr = wrow + (j & 1) * RC_N, *vc = vcol + (j & 1) * RC_N;
       if (ti == jm) {
-        const double s = fabs(rjj);
-        const double al = s * dhqr_alphafactor(ajj);
-        const double q = s * (s + fabs(ajj));
+        const double s = fabs(rjj);                   // src:129 (norm of the updated column)
+        const double al = s * dhqr_alphafactor(ajj);  // src:130
+        const double q = s * (s + fabs(ajj));         // src:131: f = 1/sqrt(q), v_jj = (a_jj - alpha) f
         const double sq = sqrt(q);
-        const double u = 1.0 / (ajj - al);
-        const double vinv = sq * u;
+        const double u = 1.0 / (ajj - al);            // = f / v_jj
+        const double vinv = sq * u;                   // = 1 / v_jj
         const double sg = (al == 0.0) ? 0.0 : ((al < 0.0) == (rjj < 0.0) ? 1.0 : -1.0);
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
           const int k = tk + 32 * y;
           const double rr = sg * r[ja][y];
           const double dl = (k > j) ? (a[ja][y] - rr) : 0.0;
-          wr[k] = dl * u;
-          mm[ja][y] = (k > j) ? dl * vinv : (k == j ? sq : 0.0);
+          wr[k] = dl * u;                                              // f * (v_j' a_k)
+          mm[ja][y] = (k > j) ? dl * vinv : (k == j ? sq : 0.0);       // M[j][k] = v_j' a_k, M[j][j] = 1/f_j
           Rref[j + k * RC_N] = (k > j) ? rr : 0.0;
         }
         if (tk == 0) alpha[j] = al;
       }
-      if (tk == jm) {
+      if (tk == jm) {  // owners of column j: the unscaled a_ij (i > j); f travels in the row
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
           const int i = ti + 32 * x;
@@ -335,10 +354,9 @@ __global__ __launch_bounds__(1024) void k_recon_top(const double *__restrict__ P
       for (int x = 0; x < 4; ++x) {
         const double vi = vc[ti + 32 * x];
 #pragma unroll
-        for (int y = 0; y < 4; ++y) a[x][y] = fma(-vi, wr[tk + 32 * y], a[x][y]);
+        for (int y = 0; y < 4; ++y) a[x][y] = fma(-vi, wr[tk + 32 * y], a[x][y]);  // src:209, top rows
       }
     }
-  // park M (upper triangular, diagonal 1/f_j) in the output buffer and invert it from there
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -348,6 +366,52 @@ __global__ __launch_bounds__(1024) void k_recon_top(const double *__restrict__ P
   rc_upper_inverse_blocked(negMinv, RC_N, false, L, x12);
   __syncthreads();  // every read of M is done (the last ones are in P3's first product): overwrite it
   rc5_emit(L, x12, [&](int i, int k, double v) { negMinv[i + k * RC_N] = -v; });
+}
+
+// Replay with R given in global memory (row-split driver: R comes from the all-reduced Gram matrix; second
+// CholeskyQR pass).
+__global__ __launch_bounds__(1024) void k_recon_top(const double *__restrict__ P, int64_t ldp,
+                                                     const double *__restrict__ R,
+                                                     double *__restrict__ alpha,
+                                                     double *__restrict__ Rref,
+                                                     double *__restrict__ negMinv) {
+  __shared__ double wrow[2 * RC_N], vcol[2 * RC_N];
+  __shared__ rc5_lds L;
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
+  double a[4][4], r[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int i = ti + 32 * x, k = tk + 32 * y;
+      a[x][y] = P[i + (int64_t)k * ldp];
+      r[x][y] = R[i + k * RC_N];
+    }
+  rc_replay_and_invert(a, r, wrow, vcol, L, alpha, Rref, negMinv);
+}
+
+// The whole top block of an R-first panel in ONE single-workgroup launch: G = P'P -> R = chol(G) (registers) ->
+// replay -> -M^{-1}.  One launch (and one wait for an idle CU under the trailing-update GEMMs) less per panel
+// than k_chol_inv + k_recon_top, and R never leaves the registers.
+__global__ __launch_bounds__(1024) void k_panel_top(const double *__restrict__ G, const double *__restrict__ P,
+                                                     int64_t ldp, double *__restrict__ alpha,
+                                                     double *__restrict__ Rref, double *__restrict__ negMinv,
+                                                     int *__restrict__ flag) {
+  __shared__ double wrow[2 * RC_N], vcol[2 * RC_N];
+  __shared__ rc5_lds L;
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
+  double g[4][4], a[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) g[x][y] = G[(ti + 32 * x) + (tk + 32 * y) * RC_N];
+  rc_cholesky_regs(g, wrow, flag);
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) a[x][y] = P[(ti + 32 * x) + (int64_t)(tk + 32 * y) * ldp];
+  __syncthreads();  // the last Cholesky step's readers of wrow are done before the replay reuses it
+  rc_replay_and_invert(a, g, wrow, vcol, L, alpha, Rref, negMinv);
 }
 
 // Vw currently holds P * M^{-1}; finish V = tril((P - alpha E) M^{-1}) on the top 128 rows:
@@ -369,25 +433,9 @@ __global__ __launch_bounds__(256) void k_recon_fix(double *__restrict__ Vw, int6
 // kernels that write to the matrix carry (stat, epoch) and do nothing once stat[0] <= epoch; the driver reads
 // stat[0] once after the last launch and resumes from the failed panel with the robust kernels.
 //
-// k_recon_decide: panel `panel_idx` is accepted iff every ||v_j||^2 (diag of S = V'V) is within tol of 2 (NaN
-// fails) and the Cholesky did not break down.  statword (in the panel's broadcast buffer) <- stat[0], so the
-// ranks that receive the panel learn of a failure with the data.
-__global__ __launch_bounds__(128) void k_recon_decide(const double *__restrict__ S, double tol,
-                                                      int *__restrict__ stat, int panel_idx,
-                                                      double *__restrict__ statword) {
-  __shared__ int bad[RC_N];
-  const int j = threadIdx.x;
-  const double d = S[j + j * RC_N];
-  bad[j] = (fabs(d - 2.0) <= tol) ? 0 : 1;
-  __syncthreads();
-  if (j == 0) {
-    int any = stat[1];
-    for (int q = 0; q < RC_N; ++q) any |= bad[q];
-    if (any && stat[0] > panel_idx) stat[0] = panel_idx;
-    stat[1] = 0;
-    if (statword) *statword = (double)stat[0];
-  }
-}
+// The decision itself is taken by k_build_t (above): panel `panel_idx` is accepted iff every ||v_j||^2 (diag of
+// S = V'V) is within tol of 2 (NaN fails) and the Cholesky did not break down; statword (in the panel's broadcast
+// buffer) <- stat[0], so the ranks that receive the panel learn of a failure with the data.
 // receiver side: adopt the sender's failure index
 __global__ void k_adopt_status(const double *__restrict__ statword, int *__restrict__ stat) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {

@@ -51,6 +51,16 @@ int main(int argc, char **argv) {
     else return 2;
 #undef TN
     wr(argv[11], out);
+  } else if (op == "tn2") {  // two-panel W = [V_a V_b]' C (k_gemm_tn2): V has 256 columns, out[slab][column][256]
+    const int64_t rps = atoll(argv[8]);
+    auto V = rd(argv[9], (size_t)ldv * 256);
+    auto C = rd(argv[10], (size_t)ldc * ncols);
+    const int nsplit = (int)((rows + rps - 1) / rps), ntiles = (int)((ncols + 127) / 128);
+    const int64_t ostride = 256 * ncols;
+    std::vector<double> out((size_t)nsplit * ostride, -7.0);
+    if (vec == 2) grid2(ntiles, nsplit, 512, [&] { k_gemm_tn2<2>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride); });
+    else grid2(ntiles, nsplit, 512, [&] { k_gemm_tn2<1>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride); });
+    wr(argv[11], out);
   } else if (op == "nn") {
     const int swz = atoi(argv[8]);
     auto V = rd(argv[9], (size_t)ldv * kparam);

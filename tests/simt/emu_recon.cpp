@@ -67,10 +67,32 @@ int main(int argc, char **argv) {
     const int ncols = atoi(argv[4]);
     std::vector<double> T(NN, -7.0), Tt(NN, -7.0);
     simt::launch_block(1024, [&] {
-      k_build_t(S.data(), ncols, T.data(), Tt.data());
+      k_build_t(S.data(), ncols, T.data(), Tt.data(), 0.0, nullptr, 0, nullptr);
     });
     wr(argv[5], T);
     wr(argv[6], Tt);
+  } else if (op == "top") {  // top 0 G P outAlpha outRref outNegMinv outFlag: the fused top-block kernel
+    auto G = rd(argv[3], NN);
+    auto P = rd(argv[4], NN);
+    std::vector<double> alpha(RC_N, -7.0), Rref(NN, -7.0), negMinv(NN, -7.0);
+    int flag[2] = {0, 0};
+    simt::launch_block(1024, [&] {
+      k_panel_top(G.data(), P.data(), (int64_t)RC_N, alpha.data(), Rref.data(), negMinv.data(), flag);
+    });
+    wr(argv[5], alpha);
+    wr(argv[6], Rref);
+    wr(argv[7], negMinv);
+    wr(argv[8], std::vector<double>{(double)flag[0], (double)flag[1]});
+  } else if (op == "decide") {  // decide 0 S tol outT outTt outStat: k_build_t with the acceptance decision
+    auto S = rd(argv[3], NN);
+    const double tol = atof(argv[4]);
+    std::vector<double> T(NN, -7.0), Tt(NN, -7.0);
+    int stat[2] = {2147483647, 0};
+    double statword = -1.0;
+    simt::launch_block(1024, [&] { k_build_t(S.data(), RC_N, T.data(), Tt.data(), tol, stat, 5, &statword); });
+    wr(argv[5], T);
+    wr(argv[6], Tt);
+    wr(argv[7], std::vector<double>{(double)stat[0], (double)stat[1], statword});
   } else if (op == "racy" || op == "sync") {  // <op> 0 out
     std::vector<double> out(128, -1.0);
     if (op == "racy") simt::launch_block(128, [&] { k_selftest<false>(out.data()); });

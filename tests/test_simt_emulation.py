@@ -226,6 +226,27 @@ def test_gemm_tn_split_k(emu_gemm, tmp_path, vec, nbv, rows, ncols, rps):
     assert np.abs(W - V[:rows, :nbv].T @ C[:rows]).max() < 1e-12
 
 
+@pytest.mark.parametrize("vec,rows,ncols,rps", [(2, 200, 150, 80), (1, 131, 129, 64)])
+def test_gemm_tn_two_panels(emu_gemm, tmp_path, vec, rows, ncols, rps):
+    """W = [V_a V_b]' C in one pass over C (k_gemm_tn2: 512 threads, 128 x 256 output tile): partial column tile,
+    short last slab, scalar / 16-byte loads, padding rows never read"""
+    rng = np.random.default_rng(3)
+    ldv, ldc = rows + rows % 2 + 2, rows + rows % 2 + 4
+    V = np.full((ldv, 256), 7.0)
+    V[:rows] = rng.standard_normal((rows, 256))
+    V[:128, 128:] = 0.0  # the second panel starts 128 rows further down
+    C = np.full((ldc, ncols), 9.0)
+    C[:rows] = rng.standard_normal((rows, ncols))
+    f = {k: str(tmp_path / f"{k}.bin") for k in ("V", "C", "o")}
+    _put(f["V"], V)
+    _put(f["C"], C)
+    _run(emu_gemm, "tn2", vec, 256, rows, ncols, ldv, ldc, rps, f["V"], f["C"], f["o"])
+    ns = (rows + rps - 1) // rps
+    out = np.fromfile(f["o"]).reshape(ns, ncols, 256)  # [slab][column][p]
+    W = out.sum(axis=0).T
+    assert np.abs(W - V[:rows].T @ C[:rows]).max() < 1e-12
+
+
 @pytest.mark.parametrize("vec,kw,rows,ncols,swz", [(2, 128, 200, 150, 0), (1, 128, 131, 129, 0),
                                                    (2, 256, 256, 128, 0), (2, 128, 300, 260, 1)])
 def test_gemm_nn_sub(emu_gemm, tmp_path, vec, kw, rows, ncols, swz):
