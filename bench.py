@@ -133,7 +133,27 @@ def emit(out, rank=0):
         print(json.dumps(out), flush=True)
 
 
-def roofline_groups(st, steps):
+def pmc_traffic(kernel, m, n, nb, launches, work):
+    """HBM bytes per launch of a roofline group from the committed counter runs (profiles/r02_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/pmc_driver, gfx950 x2 FETCH correction,
+    calibrated on a streaming kernel).  Counters cannot be read from inside this process, so the figure is the one
+    measured for the SAME kernel on the SAME workload; None when no matching measurement is committed."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+    except Exception:
+        return None
+    if nb and (m, n) == (32768, 32768):
+        key = ("k_gemm_nn_sub<2,256>" if kernel.startswith("k_gemm_nn_sub") else
+               ("k_gemm_tn2<2>" if kernel.startswith("k_gemm_tn") else None))
+        e = pm.get("blocked32768_summary", {}).get(key) if key else None
+        return e["bytes_per_launch"] if e else None
+    if not nb and kernel.startswith("k_rank1"):
+        # measured on the same kernel at 4096^2: HBM bytes = 1.0036 x the algorithmic 16 B / element / reflector
+        return pm["unblocked4096_k_rank1"]["ratio"] * work / max(1, launches)
+    return None
+
+
+def roofline_groups(st, steps, m=0, n=0, nb=0):
     """per-kernel-group roofline entries from the hipEvent statistics of ONE rank"""
     groups = []
     if st["ms_gemm_avw"] > 0:
@@ -142,7 +162,7 @@ def roofline_groups(st, steps):
         groups.append(dict(kernel="k_gemm_nn_sub (A -= V*W, FP64 MFMA)", bound="mfma", ms=st["ms_gemm_avw"],
                            launches=st["n_gemm_avw"], work=st["flops_gemm_avw"]))
         # one timed group = the TN launches of one wide update (two per two-panel update) + their split-K reductions
-        groups.append(dict(kernel="k_gemm_tn (W = V'*A, FP64 MFMA)", bound="mfma", ms=st["ms_gemm_vta"],
+        groups.append(dict(kernel="k_gemm_tn2 / k_gemm_tn (W = [V_a V_b]'*A, FP64 MFMA)", bound="mfma", ms=st["ms_gemm_vta"],
                            launches=st["n_gemm_vta"], work=st["flops_gemm_vta"]))
     if st["ms_panel"] > 0:
         groups.append(dict(kernel="panel lane: Gram/Cholesky/replay/narrow-update kernels (dhqr_recon.h)", bound="hbm", ms=st["ms_panel"],
@@ -157,7 +177,8 @@ def roofline_groups(st, steps):
         else:
             ach, peak, unit = gr["work"] / gr["ms"] / 1e6, PEAK_HBM_GBPS, "GB/s"
         rl_all.append({"kernel": gr["kernel"], "bound": gr["bound"], "achieved": ach, "peak": peak, "unit": unit,
-                       "frac": ach / peak, "traffic": None, "launches": gr["launches"],
+                       "frac": ach / peak, "traffic": pmc_traffic(gr["kernel"], m, n, nb, gr["launches"], gr["work"]),
+                       "launches": gr["launches"],
                        "avg_launch_ms": gr["ms"] / max(1, gr["launches"]), "total_ms": gr["ms"]})
     # the north star grades the trailing update: the DOMINANT (largest total time) MFMA group
     mf = [r for r in rl_all if r["bound"] == "mfma"]
@@ -293,7 +314,7 @@ def main():
 
     ms_step = dt / args.steps * 1e3
     value = flops_qr(m, n) / (dt / args.steps) / 1e9
-    dom, rl_all = roofline_groups(st, args.steps)
+    dom, rl_all = roofline_groups(st, args.steps, m, n, nb)
 
     if mode == "single":
         par = "single GPU"
@@ -315,6 +336,9 @@ def main():
         "roofline": ({k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
                                           "launches", "avg_launch_ms")} if dom else None),
         "roofline_all": rl_all,
+        "traffic_note": "HBM bytes per launch (read + write) from rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE, separate "
+                        "passes, profiles/r02_pmc_traffic.json; algorithmic C bytes per wide two-panel launch: 2.88 GB (NN: read + "
+                        "write) / 1.44 GB (TN: read) -> measured 4.03 / 1.78 GB",
         "phase_ms_per_step": {k: st[k] / args.steps for k in st if k.startswith("ms_") and st[k] > 0},
         "panels_fast_fallback": panel_counts,
     }
