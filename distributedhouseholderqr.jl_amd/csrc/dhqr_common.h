@@ -43,6 +43,74 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
   return s;
 }
 
+// ---- extended-precision sum of squares for the column norm.  The reference's norm (src:129) is BLAS
+// dnrm2 / dznrm2, which OpenBLAS accumulates in x87 extended precision on x86-64 (the CPU test oracle
+// restates that with long double).  The reflector of the dominant direction is what the reference's
+// acceptance metric ||A^H (A x - b)|| is most sensitive to, so the device keeps the same accuracy:
+// a double-double (hi, lo) accumulator built from error-free transforms (TwoSum, FMA TwoProd), carried
+// through the wavefront butterfly and the cross-wave sum.  Only the pivot workgroup pays for it.
+struct dhqr_dd { double hi, lo; };
+// (contraction is switched off inside the transforms: fusing `a + x*x` into an fma would break them)
+__device__ __forceinline__ void dd_two_sum(double a, double b, double &s, double &e) {
+#pragma clang fp contract(off)
+  s = a + b;
+  const double bb = s - a;
+  e = (a - (s - bb)) + (b - bb);  // exact: a + b == s + e
+}
+__device__ __forceinline__ void dd_add_sq(dhqr_dd &acc, double x) {  // acc += x*x
+#pragma clang fp contract(off)
+  const double p = x * x;
+  const double pe = fma(x, x, -p);  // exact: x*x == p + pe
+  double s, e;
+  dd_two_sum(acc.hi, p, s, e);
+  acc.hi = s;
+  acc.lo += e + pe;
+}
+__device__ __forceinline__ dhqr_dd dd_add(const dhqr_dd a, const dhqr_dd b) {  // symmetric in (a, b)
+#pragma clang fp contract(off)
+  double s, e;
+  dd_two_sum(a.hi, b.hi, s, e);
+  e += a.lo + b.lo;
+  dhqr_dd r;
+  r.hi = s + e;
+  r.lo = e - (r.hi - s);
+  return r;
+}
+// All THREADS threads call; every thread returns the same (hi + lo rounded once). red >= 2*THREADS/64.
+template <int THREADS>
+__device__ __forceinline__ double dd_block_sum(dhqr_dd v, double *red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    dhqr_dd o;
+    o.hi = __shfl_xor(v.hi, off, 64);
+    o.lo = __shfl_xor(v.lo, off, 64);
+    v = dd_add(v, o);
+  }
+  constexpr int NW = THREADS / 64;
+  if constexpr (NW > 1) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();  // protect `red` against a previous use
+    if (lane == 0) {
+      red[2 * w] = v.hi;
+      red[2 * w + 1] = v.lo;
+    }
+    __syncthreads();
+    dhqr_dd s;
+    s.hi = red[0];
+    s.lo = red[1];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) {
+      dhqr_dd o;
+      o.hi = red[2 * i];
+      o.lo = red[2 * i + 1];
+      s = dd_add(s, o);
+    }
+    v = s;
+  }
+  return v.hi + v.lo;
+}
+
+
 // src:8  alphafactor(x::Real) = -sign(x)  (sign(0) == 0 in Julia: a zero pivot gives alpha = -0*s)
 __device__ __forceinline__ double dhqr_alphafactor(double x) {
   return x > 0.0 ? -1.0 : (x < 0.0 ? 1.0 : -x);

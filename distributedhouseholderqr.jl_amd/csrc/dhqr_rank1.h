@@ -34,15 +34,12 @@ template <int T>
 __global__ __launch_bounds__(T) void k_reflector(double *__restrict__ col, int64_t m, int64_t j,
                                                  double *__restrict__ vnext,
                                                  double *__restrict__ alpha_j) {
-  __shared__ double red[T / 64 + 1];
+  __shared__ double red[2 * (T / 64) + 2];
   const int t = threadIdx.x;
   const double h = col[j];
-  double s2 = 0.0;
-  for (int64_t i = j + t; i < m; i += T) {
-    const double x = col[i];
-    s2 = fma(x, x, s2);
-  }
-  s2 = block_sum<T>(s2, red);
+  dhqr_dd acc = {0.0, 0.0};  // double-double sum of squares: the reference's dnrm2 is extended precision too
+  for (int64_t i = j + t; i < m; i += T) dd_add_sq(acc, col[i]);
+  const double s2 = dd_block_sum<T>(acc, red);
   const double s = sqrt(s2);                       // src:129
   const double al = s * dhqr_alphafactor(h);       // src:130
   const double f = 1.0 / sqrt(s * (s + fabs(h)));  // src:131
@@ -66,7 +63,8 @@ __global__ __launch_bounds__(T) void k_rank1_fused(double *__restrict__ A, int64
                                                    int64_t j, const double *__restrict__ vcur,
                                                    double *__restrict__ vnext,
                                                    double *__restrict__ alpha) {
-  __shared__ double red[T / 64 + 2];
+  __shared__ double red[2 * (T / 64) + 2];
+  constexpr int HSLOT = 2 * (T / 64);  // pivot element of the next column
   const int t = threadIdx.x;
   const int64_t c = j + 1 + blockIdx.x;
   double *__restrict__ col = A + c * lda;
@@ -107,16 +105,16 @@ __global__ __launch_bounds__(T) void k_rank1_fused(double *__restrict__ A, int64
   const bool pivot = (blockIdx.x == 0);  // this workgroup owns column j+1: build its reflector
   if (pivot) {
     const int64_t jp = j + 1;
-    double s2 = 0.0;
+    dhqr_dd acc = {0.0, 0.0};  // extended-precision column norm (src:129: dnrm2), pivot workgroup only
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int64_t row = (VEC == 2) ? r0 + 2 * ((int64_t)t + (int64_t)(e >> 1) * T) + (e & 1)
                                      : r0 + t + (int64_t)e * T;
-      if (row == jp) red[T / 64] = a[e];
-      if (row >= jp && row < m) s2 = fma(a[e], a[e], s2);
+      if (row == jp) red[HSLOT] = a[e];
+      if (row >= jp && row < m) dd_add_sq(acc, a[e]);
     }
-    s2 = block_sum<T>(s2, red);  // barriers inside also publish red[T/64]
-    const double h = red[T / 64];
+    const double s2 = dd_block_sum<T>(acc, red);  // barriers inside also publish red[HSLOT]
+    const double h = red[HSLOT];
     const double sn = sqrt(s2);                        // src:129
     const double al = sn * dhqr_alphafactor(h);        // src:130
     const double f = 1.0 / sqrt(sn * (sn + fabs(h)));  // src:131
@@ -160,7 +158,7 @@ __global__ __launch_bounds__(T) void k_rank1_generic(double *__restrict__ A, int
                                                      const double *__restrict__ vcur,
                                                      double *__restrict__ vnext,
                                                      double *__restrict__ alpha) {
-  __shared__ double red[T / 64 + 2];
+  __shared__ double red[2 * (T / 64) + 2];
   const int t = threadIdx.x;
   const int64_t c = j + 1 + blockIdx.x;
   double *col = A + c * lda;
@@ -194,18 +192,18 @@ __global__ __launch_bounds__(T) void k_rank1_generic(double *__restrict__ A, int
   const int64_t jp = j + 1;
   __syncthreads();  // column j+1 fully updated and visible inside this workgroup
   const double h = col[jp];
-  double s2 = 0.0;
+  dhqr_dd acc = {0.0, 0.0};  // extended-precision column norm (src:129: dnrm2)
   if constexpr (VEC == 2) {
     for (int64_t row = r0 + 2 * (int64_t)t; row < m; row += 2 * T) {
       const double2 x = *reinterpret_cast<const double2 *>(col + row);
-      if (row >= jp) s2 = fma(x.x, x.x, s2);
-      if (row + 1 >= jp) s2 = fma(x.y, x.y, s2);
+      if (row >= jp) dd_add_sq(acc, x.x);
+      if (row + 1 >= jp) dd_add_sq(acc, x.y);
     }
   } else {
     for (int64_t row = r0 + t; row < m; row += T)
-      if (row >= jp) s2 = fma(col[row], col[row], s2);
+      if (row >= jp) dd_add_sq(acc, col[row]);
   }
-  s2 = block_sum<T>(s2, red);
+  const double s2 = dd_block_sum<T>(acc, red);
   const double sn = sqrt(s2);
   const double al = sn * dhqr_alphafactor(h);
   const double f = 1.0 / sqrt(sn * (sn + fabs(h)));

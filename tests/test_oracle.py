@@ -99,3 +99,24 @@ def test_zero_pivot_matches_reference_semantics(orc):
     H, alpha = orc.householder(A)
     assert alpha[0] == 0.0
     assert np.allclose(H[:, 0], [0.0, 0.6, 0.8])
+
+
+def test_oracle_against_reference_fixtures(orc):
+    """Element-wise pin of the oracle against outputs of THE REFERENCE (real Julia DistributedHouseholderQR.qr! and
+    `\\`): fixtures are produced by oracle/_ref_recipe/make_ref_fixtures.jl, which needs a Julia toolchain -- absent
+    from this image, so the fixtures do not exist yet and the element-wise parity is "unpinned" (DESIGN.md)."""
+    ref = os.path.join(GOLDEN, "ref")
+    man = os.path.join(ref, "manifest.txt")
+    if not os.path.exists(man):
+        pytest.skip("no reference-generated fixtures (no Julia toolchain in this image): parity unpinned")
+    for line in open(man):
+        tag, m, n, seed = line.split()
+        m, n, seed = int(m), int(n), int(seed)
+        rd = lambda name, shape: np.fromfile(os.path.join(ref, f"{tag}_{name}.bin")).reshape(shape, order="F")
+        A, H, alpha = rd("A", (m, n)), rd("H", (m, n)), rd("alpha", (n,))
+        b, x = rd("b", (m,)), rd("x", (n,))
+        assert np.array_equal(A, orc.rand_matrix(m, n, seed))  # the generator twin in Julia
+        Ho, ao = orc.householder(A)
+        scale = np.abs(H).max()
+        assert np.abs(Ho - H).max() <= 1e-12 * scale and np.abs(ao - alpha).max() <= 1e-12 * scale
+        assert np.abs(orc.solve(Ho, ao, b) - x).max() <= 1e-9 * np.abs(x).max()
