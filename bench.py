@@ -80,50 +80,79 @@ def cpu_baseline(m, n, budget_s=20.0):
     }
 
 
-def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev):
-    """BASELINE configs[4]: 262144 x 4096 Float64, rows split over the ranks (RowSplitQR)."""
+def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd):
+    """BASELINE configs[4]: 262144 x 4096 Float64, rows split over the ranks (dhqr_rs_* / dhqr_mg_rs_*)."""
     m = args.m or 262144
     n = args.n or 4096
-    q = pkg.RowSplitQR(m, n)
+    mg = q = None
+    if spmd:
+        q = pkg.RowSplitQR(m, n, comm=pkg.Communicator.from_torch(pkg.get_context(local_rank)))
+        ctxs = [pkg.get_context(local_rank)]
+
+        def step():
+            q.fill(0)
+            q.factor()
+    else:
+        devices = list(range(world)) if (world > 1 or not args.logical_ranks) else [0] * args.logical_ranks
+        mg = pkg.MultiGpuQR(devices=devices)
+        mg.rs_alloc(m, n)
+
+        def step():
+            mg.rs_fill(0)
+            mg.rs_factor()
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
+        for d in range(torch.cuda.device_count() if mg is not None else 1):
+            torch.cuda.synchronize(d if mg is not None else local_rank)
+        if spmd:
             dist.barrier()
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        q.fill(0)
-        q.factor()
+        step()
     barrier()
+    if mg is not None:
+        mg.reset_stats()
+        mg.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        q.fill(0)
-        q.factor()
+        step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    st = None
+    if mg is not None:
+        st = mg.stats(0)
+        mg.set_profiling(False)
+    if spmd:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    resid = None if args.no_residual else q.residual(0)
+    resid = None
+    if not args.no_residual:
+        resid = mg.rs_residual(0) if mg is not None else q.residual(0)
     value = flops_qr(m, n) / (dt / args.steps) / 1e9
+    nranks = world if world > 1 else (args.logical_ranks or 1)
     out = {
         "metric": "QR GFLOP/s (F = 2mn^2 - 2/3 n^3), ||A-QR||/||A|| alongside",
         "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{m}x{n} Float64 tall-skinny QR, row split (BASELINE configs[4])", "m": m, "n": n,
-                   "nb": 128, "parallelism": f"rows split x{world}, all-reduce of Gram matrices and V'C partial dots"},
+                   "nb": 128, "parallelism": f"rows split x{nranks} (128-row aligned slabs), all-reduce of Gram matrices and V'C "
+                                             f"partial dots" + (f", transport {mg.transport}" if mg is not None else ", RCCL")},
         "residual": resid,
-        "roofline": {"bound": "mfma", "achieved": value / 1e3 / world, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": value / 1e3 / world / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+        "roofline": {"bound": "mfma", "achieved": value / 1e3 / max(world, 1), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": value / 1e3 / max(world, 1) / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
                      "kernel": "whole row-split factorisation per GPU (not a single kernel)"},
-        "rowsplit_stats": q.stats,
     }
+    if st is not None:
+        out["phase_ms_per_step"] = {k: st[k] / args.steps for k in st if k.startswith("ms_") and st[k] > 0}
+        out["panels_fast_fallback"] = [st["panels_fast"], st["panels_fallback"]]
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if mg is not None:
+        mg.close()
+    if spmd:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -225,7 +254,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     if args.config == "tallskinny":
-        return tallskinny(args, pkg, torch, dist, env_world, rank, local_rank, dev)
+        return tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd)
     nb = 128 if args.config == "blocked" else 0
     n = args.n or (32768 if nb else 8192)
     m = args.m or n

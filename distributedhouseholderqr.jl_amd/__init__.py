@@ -11,12 +11,12 @@ from .api import (Context, DistributedHouseholderQRStruct, apply_q_, bench_mfma_
                   bench_stream_gbps, empty_colmajor, get_context, get_q, get_r, householder_, ldiv, partialdot,
                   qr_, rand_colmajor, rand_colmajor_c, rand_vector_device, residual, solve_householder_)
 from .distributed import ColumnCyclicQR, Communicator, MultiGpuQR, qr_darray_, qr_multi_
-from .rowsplit import HipRowBackend, RowSplitQR
+from .rowsplit import RowSplitQR
 from .partition import BlockCyclicColumns, LocalColumnBlock, contiguous_column_blocks
 
 __all__ = [
     "NB", "DHQRError", "build", "Context", "DistributedHouseholderQRStruct", "apply_q_",
     "bench_mfma_tflops", "bench_stream_gbps", "empty_colmajor", "get_context", "get_q", "get_r", "householder_",
     "ldiv", "partialdot", "qr_", "rand_colmajor", "rand_colmajor_c", "rand_vector_device", "residual",
-    "solve_householder_", "ColumnCyclicQR", "Communicator", "MultiGpuQR", "qr_darray_", "qr_multi_", "RowSplitQR", "HipRowBackend", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
+    "solve_householder_", "ColumnCyclicQR", "Communicator", "MultiGpuQR", "qr_darray_", "qr_multi_", "RowSplitQR", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
 ]

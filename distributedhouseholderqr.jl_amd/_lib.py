@@ -120,18 +120,17 @@ SIGNATURES = {
     "dhqr_mg_set_profiling": (_i32, [_p, _i32]),
     "dhqr_mg_reset_stats": (_i32, [_p]),
     "dhqr_mg_get_stats": (_i32, [_p, _i32, ctypes.POINTER(Stats), _pi64, _pi64, _pi64]),
-    "dhqr_rs_gram_f64": (_i32, [_p, _p, _i64, _i64, _p]),
-    "dhqr_rs_chol_f64": (_i32, [_p, _p, _p, _p]),
-    "dhqr_rs_recon_top_f64": (_i32, [_p, _p, _i64, _p, _p, _p, _p]),
-    "dhqr_rs_mul_f64": (_i32, [_p, _p, _i64, _i64, _p, _p, _i64]),
-    "dhqr_rs_fix_top_f64": (_i32, [_p, _p, _i64, _p, _p]),
-    "dhqr_rs_write_r_f64": (_i32, [_p, _p, _i64, _p]),
-    "dhqr_rs_commit_f64": (_i32, [_p, _p, _i64, _i64, _p, _i64, _i32, _p]),
-    "dhqr_rs_pack_f64": (_i32, [_p, _p, _i64, _i64, _p, _i64, _i32]),
-    "dhqr_rs_build_t_f64": (_i32, [_p, _p, _i32, _p, _p]),
-    "dhqr_rs_vtc_f64": (_i32, [_p, _p, _i64, _p, _i64, _i64, _i64, _p]),
-    "dhqr_rs_tw_f64": (_i32, [_p, _p, _p, _i64, _p]),
-    "dhqr_rs_vw_f64": (_i32, [_p, _p, _i64, _p, _p, _i64, _i64, _i64]),
+    "dhqr_rs_row_range": (None, [_i64, _i32, _i32, _pi64, _pi64]),
+    "dhqr_rs_fill_uniform_f64": (_i32, [_p, _p, _i64, _i64, _i64, _u64]),
+    "dhqr_rs_factor_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
+    "dhqr_rs_residual_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _u64, _p, _p, _pd]),
+    "dhqr_rs_solve_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "dhqr_mg_rs_alloc_f64": (_i32, [_p, _i64, _i64]),
+    "dhqr_mg_rs_fill_uniform_f64": (_i32, [_p, _u64]),
+    "dhqr_mg_rs_factor_f64": (_i32, [_p]),
+    "dhqr_mg_rs_residual_f64": (_i32, [_p, _u64, _pd]),
+    "dhqr_mg_rs_transfer_f64": (_i32, [_p, _p, _i64, _p, _i32]),
+    "dhqr_mg_rs_solve_f64": (_i32, [_p, _p, _p]),
     "dhqr_bench_mfma_f64": (_i32, [_p, _pd]),
     "dhqr_bench_issue_f64": (_i32, [_p, _i32, _i32, _pd, _pd]),
     "dhqr_bench_issue2_f64": (_i32, [_p, _i32, _i32, _i32, _pd]),

@@ -688,6 +688,7 @@ static int32_t factor_blocked_simple(dhqr_ctx *c, double *dA, int64_t m, int64_t
 
 #include "dhqr_comm.h"
 #include "dhqr_dist.h"
+#include "dhqr_rowsplit.h"
 #include "dhqr_mg.h"
 
 static CsProblem cs_single(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
@@ -1345,154 +1346,6 @@ int32_t dhqr_diff_norms_f64(dhqr_ctx *c, const double *dX, int64_t ldx, const do
   return DHQR_OK;
 }
 
-// ---- row-split building blocks (BASELINE configs[4]: tall-skinny, rows distributed over ranks) ----
-// Each call works on the caller's LOCAL row slab; the sums over ranks (Gram matrices, V'C partial
-// dots) are all-reduced by the host layer (rowsplit.py) between calls.
-int32_t dhqr_rs_gram_f64(dhqr_ctx *c, const double *dX, int64_t ldx, int64_t rows, double *dG) {
-  ENTER(c);
-  if (!dX || !dG) return set_err(DHQR_EINVAL, "null pointer argument");
-  if (rows <= 0) {  // a rank may own no active rows of this panel
-    HIPCHECK(hipMemsetAsync(dG, 0, (size_t)DHQR_NBV * DHQR_NBV * sizeof(double), c->stream));
-    return DHQR_OK;
-  }
-  CHECK(gram128(c, dX, ldx, rows, dG));
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-// R = chol(G) (upper, dense 128 x 128).  flags are left on the device: dflag[0] != 0 on breakdown.
-int32_t dhqr_rs_chol_f64(dhqr_ctx *c, const double *dG, double *dR, int32_t *dflag) {
-  ENTER(c);
-  if (!dG || !dR || !dflag) return set_err(DHQR_EINVAL, "null pointer argument");
-  launch_chol_inv(c, dG, nullptr, dR, nullptr, (int *)dflag);
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-// Top-block replay on the rank that owns the panel's diagonal rows: dPtop = &P[diag row, first col].
-int32_t dhqr_rs_recon_top_f64(dhqr_ctx *c, const double *dPtop, int64_t ldp, const double *dR, double *dalpha128,
-                              double *dRref, double *dnegMinv) {
-  ENTER(c);
-  if (!dPtop || !dR || !dalpha128 || !dRref || !dnegMinv) return set_err(DHQR_EINVAL, "null pointer argument");
-  launch_recon_top(c, dPtop, ldp, dR, dalpha128, dRref, dnegMinv);
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-// dOut (rows x 128, ld ldo) = dX (rows x 128) * Y, given negY = -Y (128 x 128).
-int32_t dhqr_rs_mul_f64(dhqr_ctx *c, const double *dX, int64_t ldx, int64_t rows, const double *dnegY, double *dOut,
-                        int64_t ldo) {
-  ENTER(c);
-  if (rows <= 0) return DHQR_OK;
-  if (!dX || !dnegY || !dOut || ldo < rows) return set_err(DHQR_EINVAL, "bad arguments to dhqr_rs_mul_f64");
-  CHECK(mul128(c, dX, ldx, rows, dnegY, dOut, ldo));
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-// finish V = tril((P - alpha E) M^{-1}) on the 128 diagonal rows (diagonal owner only)
-int32_t dhqr_rs_fix_top_f64(dhqr_ctx *c, double *dVw, int64_t ldv, const double *dalpha128, const double *dnegMinv) {
-  ENTER(c);
-  hipLaunchKernelGGL(k_recon_fix, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream, dVw, ldv, dalpha128,
-                     dnegMinv);
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-int32_t dhqr_rs_write_r_f64(dhqr_ctx *c, double *dPtop, int64_t ldp, const double *dRref) {
-  ENTER(c);
-  hipLaunchKernelGGL(k_recon_write_r, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream, dPtop, ldp, dRref,
-                     (const int *)nullptr, 0);
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-// commit one panel's reflectors into the local slab: the diagonal owner writes the lower trapezoid
-// (rows >= column) and the reference-format R above it, every other rank copies all of its rows.
-int32_t dhqr_rs_commit_f64(dhqr_ctx *c, double *dP, int64_t ldp, int64_t rows, const double *dVw, int64_t ldv,
-                           int32_t diag_owner, const double *dRref) {
-  ENTER(c);
-  if (rows <= 0) return DHQR_OK;
-  if (diag_owner) {
-    dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
-    hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, dP, ldp, rows, (int64_t)DHQR_NBV, dVw, ldv,
-                       (const int *)nullptr, 0);
-    hipLaunchKernelGGL(k_recon_write_r, dim3(DHQR_NBV * DHQR_NBV / 256), dim3(256), 0, c->stream, dP, ldp, dRref,
-                       (const int *)nullptr, 0);
-  } else {
-    HIPCHECK(hipMemcpy2DAsync(dP, ldp * sizeof(double), dVw, ldv * sizeof(double), rows * sizeof(double), DHQR_NBV,
-                              hipMemcpyDeviceToDevice, c->stream));
-  }
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-// V operand of an ALREADY factored panel for re-applying Q: the diagonal owner gets its rows with
-// the R part zeroed, other ranks a plain copy of their rows.  dVw: ldv x 128.
-int32_t dhqr_rs_pack_f64(dhqr_ctx *c, const double *dP, int64_t ldp, int64_t rows, double *dVw, int64_t ldv,
-                         int32_t diag_owner) {
-  ENTER(c);
-  if (rows <= 0) return DHQR_OK;
-  if (diag_owner) {
-    dim3 grid((unsigned)std::min<int64_t>((ldv + 255) / 256, 64), DHQR_NBV);
-    hipLaunchKernelGGL(k_pack_v, grid, dim3(256), 0, c->stream, dP, ldp, rows, (int64_t)DHQR_NBV, dVw, ldv, ldv);
-  } else {
-    HIPCHECK(hipMemcpy2DAsync(dVw, ldv * sizeof(double), dP, ldp * sizeof(double), rows * sizeof(double), DHQR_NBV,
-                              hipMemcpyDeviceToDevice, c->stream));
-  }
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-int32_t dhqr_rs_build_t_f64(dhqr_ctx *c, const double *dS, int32_t ncols, double *dT, double *dTt) {
-  ENTER(c);
-  launch_build_t(c, dS, (int)ncols, dT, dTt);
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-// dW1 (128 x ncols, ld 128) = dV' dC over the local rows (split-K partials reduced on the device)
-int32_t dhqr_rs_vtc_f64(dhqr_ctx *c, const double *dV, int64_t ldv, const double *dC, int64_t ldc, int64_t rows,
-                        int64_t ncols, double *dW1) {
-  ENTER(c);
-  if (ncols <= 0) return DHQR_OK;
-  const int64_t wstride = (int64_t)DHQR_NBV * ncols;
-  if (rows <= 0) {
-    HIPCHECK(hipMemsetAsync(dW1, 0, (size_t)wstride * sizeof(double), c->stream));
-    return DHQR_OK;
-  }
-  const int64_t ntiles = (ncols + 127) / 128;
-  int64_t nsplit, rps;
-  pick_split(rows, ntiles, 512, ntiles <= 2 ? 256 : 64, &nsplit, &rps);
-  dhqr_ctx::WS &ws = c->ws[c->cur_ws];
-  CHECK(ensure(c, ws.w1, (size_t)nsplit * DHQR_NBV * (size_t)ncols));
-  const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(dC) && aligned16(dV);
-  const dim3 gtn((unsigned)ntiles, (unsigned)nsplit);
-  if (vec)
-    hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), gtn, dim3(256), 0, c->stream, dV, ldv, dC, ldc, 1, (int64_t)0, rows, ncols,
-                       rps, ws.w1.p, (int64_t)DHQR_NBV, wstride);
-  else
-    hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), gtn, dim3(256), 0, c->stream, dV, ldv, dC, ldc, 1, (int64_t)0, rows, ncols,
-                       rps, ws.w1.p, (int64_t)DHQR_NBV, wstride);
-  hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)((wstride + 63) / 64)), dim3(256), 0, c->stream,
-                     (const double *)ws.w1.p, (int)nsplit, wstride, wstride, dW1);
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-// dW2 (128 x ncols) = op(T)' dW1 with dTop = T (update) or T' (apply Q)
-int32_t dhqr_rs_tw_f64(dhqr_ctx *c, const double *dTop, const double *dW1, int64_t ncols, double *dW2) {
-  ENTER(c);
-  if (ncols <= 0) return DHQR_OK;
-  const int64_t ntiles = (ncols + 127) / 128;
-  hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, dTop, (int64_t)DHQR_NBV,
-                     dW1, (int64_t)DHQR_NBV, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV, dW2,
-                     (int64_t)DHQR_NBV, (int64_t)0);
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-// dC (rows x ncols) -= dV (rows x 128) * dW2 (128 x ncols)
-int32_t dhqr_rs_vw_f64(dhqr_ctx *c, const double *dV, int64_t ldv, const double *dW2, double *dC, int64_t ldc,
-                       int64_t rows, int64_t ncols) {
-  ENTER(c);
-  if (rows <= 0 || ncols <= 0) return DHQR_OK;
-  const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(dC) && aligned16(dV);
-  dim3 grid((unsigned)((rows + 127) / 128), (unsigned)((ncols + 127) / 128));
-  launch_nn_sub<128>(c, vec, grid, dV, ldv, dW2, (int64_t)DHQR_NBV, dC, ldc, rows, ncols, 0, false);
-  LAUNCHCHECK();
-  return DHQR_OK;
-}
-
 int32_t dhqr_panel_apply_f64(dhqr_ctx *c, const double *dVT, int64_t rows, double *dC, int64_t ncols,
                              int64_t ldc, int32_t trans) {
   ENTER(c);
@@ -1942,6 +1795,7 @@ int32_t dhqr_mg_alloc_f64(dhqr_mg *g, int64_t m, int64_t n) {
   CHECK(mg_free_matrix(g));
   g->m = m;
   g->n = n;
+  g->rowsplit = false;
   return mg_run(g, [g, m, n](int r) -> int32_t {
     MgRank &k = g->rk[r];
     k.ncl = cs_local_cols(n, g->ndev, r);
@@ -1957,7 +1811,7 @@ int32_t dhqr_mg_alloc_f64(dhqr_mg *g, int64_t m, int64_t n) {
 }
 
 int32_t dhqr_mg_fill_uniform_f64(dhqr_mg *g, uint64_t seed) {
-  if (!g || !g->m) return set_err(DHQR_EINVAL, "no matrix allocated");
+  if (!g || !g->m || g->rowsplit) return set_err(DHQR_EINVAL, "no column-split matrix allocated");
   return mg_run(g, [g, seed](int r) -> int32_t {
     MgRank &k = g->rk[r];
     if (k.ncl == 0) return DHQR_OK;
@@ -1967,7 +1821,7 @@ int32_t dhqr_mg_fill_uniform_f64(dhqr_mg *g, uint64_t seed) {
 
 // householder!(A, alpha) over all devices; returns when every device has finished.
 int32_t dhqr_mg_factor_f64(dhqr_mg *g) {
-  if (!g || !g->m) return set_err(DHQR_EINVAL, "no matrix allocated");
+  if (!g || !g->m || g->rowsplit) return set_err(DHQR_EINVAL, "no column-split matrix allocated");
   return mg_run(g, [g](int r) -> int32_t {
     const CsProblem pr = mg_problem(g, r);
     CHECK(cs_factor(pr));
@@ -1977,7 +1831,7 @@ int32_t dhqr_mg_factor_f64(dhqr_mg *g) {
 }
 
 int32_t dhqr_mg_residual_f64(dhqr_mg *g, uint64_t seed, double *hrel) {
-  if (!g || !g->m) return set_err(DHQR_EINVAL, "no matrix allocated");
+  if (!g || !g->m || g->rowsplit) return set_err(DHQR_EINVAL, "no column-split matrix allocated");
   if (!hrel) return set_err(DHQR_EINVAL, "null output");
   CHECK(mg_run(g, [g, seed](int r) -> int32_t {
     MgRank &k = g->rk[r];
@@ -1992,6 +1846,7 @@ int32_t dhqr_mg_residual_f64(dhqr_mg *g, uint64_t seed, double *hrel) {
 
 // Host matrix <-> the block-cyclic device blocks.
 static int32_t mg_transfer(dhqr_mg *g, double *hA, int64_t lda, double *halpha, bool upload) {
+  if (g->rowsplit) return set_err(DHQR_EINVAL, "the handle holds a row-split matrix (use dhqr_mg_rs_transfer_f64)");
   return mg_run(g, [g, hA, lda, halpha, upload](int r) -> int32_t {
     MgRank &k = g->rk[r];
     const int64_t NB = DHQR_NBV, K = cs_nblocks(g->n);
@@ -2039,7 +1894,7 @@ int32_t dhqr_mg_qr_f64(dhqr_mg *g, double *hA, int64_t m, int64_t n, int64_t lda
 
 // solve_householder!(b, H, alpha) with the factored matrix resident in the handle: hx[0:n] <- x; hb (m) is not modified.
 int32_t dhqr_mg_solve_f64(dhqr_mg *g, const double *hb, double *hx) {
-  if (!g || !g->m) return set_err(DHQR_EINVAL, "no matrix allocated");
+  if (!g || !g->m || g->rowsplit) return set_err(DHQR_EINVAL, "no column-split matrix allocated");
   if (!hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
   return mg_run(g, [g, hb, hx](int r) -> int32_t {
     MgRank &k = g->rk[r];
@@ -2082,6 +1937,171 @@ int32_t dhqr_mg_get_stats(dhqr_mg *g, int32_t rank, dhqr_stats *out, int64_t *n_
   if (n_fallback) *n_fallback = g->rk[rank].c->n_fallback;
   if (bytes_bcast) *bytes_bcast = g->rk[rank].cm->bytes_bcast;
   return DHQR_OK;
+}
+
+
+// ============================================================ multi-GPU: row split (BASELINE configs[4]), SPMD
+void dhqr_rs_row_range(int64_t m, int32_t nranks, int32_t rank, int64_t *row0, int64_t *mloc) {
+  rs_row_range(m, nranks, rank, row0, mloc);
+}
+static int32_t rs_check(dhqr_comm *cm, const void *dA, int64_t m, int64_t n, int64_t lda, RsProblem *pr) {
+  if (!cm) return set_err(DHQR_EINVAL, "null communicator");
+  if (m <= 0 || n <= 0 || m < n) return set_err(DHQR_EINVAL, "m >= n >= 1 required (m=%lld n=%lld)", (long long)m, (long long)n);
+  pr->c = cm->ctx;
+  pr->cm = cm;
+  pr->P = cm->nranks;
+  pr->r = cm->rank;
+  pr->m = m;
+  pr->n = n;
+  pr->lda = lda;
+  rs_row_range(m, pr->P, pr->r, &pr->row0, &pr->mloc);
+  pr->A = const_cast<double *>((const double *)dA);
+  pr->alpha = nullptr;
+  if (pr->mloc > 0) CHECK(check_mat(dA, pr->mloc, n, lda, false));
+  return DHQR_OK;
+}
+int32_t dhqr_rs_fill_uniform_f64(dhqr_comm *cm, double *dA, int64_t m, int64_t n, int64_t lda, uint64_t seed) {
+  RsProblem pr;
+  CHECK(rs_check(cm, dA, m, n, lda, &pr));
+  if (pr.mloc == 0) return DHQR_OK;
+  return dhqr_fill_uniform_f64(pr.c, dA, pr.mloc, n, lda, seed, m, pr.row0, DHQR_NBV, 1, 0);
+}
+int32_t dhqr_rs_factor_f64(dhqr_comm *cm, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
+  RsProblem pr;
+  CHECK(rs_check(cm, dA, m, n, lda, &pr));
+  ENTER(pr.c);
+  if (!dalpha) return set_err(DHQR_EINVAL, "null alpha pointer");
+  pr.alpha = dalpha;
+  return rs_factor(pr);
+}
+int32_t dhqr_rs_residual_f64(dhqr_comm *cm, const double *dA, int64_t m, int64_t n, int64_t lda, const double *dalpha,
+                             uint64_t seed, double *dB, double *dA0, double *hrel) {
+  RsProblem pr;
+  CHECK(rs_check(cm, dA, m, n, lda, &pr));
+  ENTER(pr.c);
+  if (!dalpha || !hrel || (pr.mloc > 0 && (!dB || !dA0))) return set_err(DHQR_EINVAL, "null pointer argument");
+  pr.alpha = const_cast<double *>(dalpha);
+  return rs_residual(pr, seed, dB, dA0, hrel);
+}
+int32_t dhqr_rs_solve_f64(dhqr_comm *cm, const double *dA, int64_t m, int64_t n, int64_t lda, const double *dalpha,
+                          double *db, double *dx) {
+  RsProblem pr;
+  CHECK(rs_check(cm, dA, m, n, lda, &pr));
+  ENTER(pr.c);
+  if (!dalpha || !dx || (pr.mloc > 0 && !db)) return set_err(DHQR_EINVAL, "null pointer argument");
+  pr.alpha = const_cast<double *>(dalpha);
+  return rs_solve(pr, db, dx);
+}
+
+// single-process handle, row split: device-resident m x n matrix, 128-row aligned slabs over the devices
+static RsProblem mg_rs_problem(dhqr_mg *g, int r) {
+  RsProblem pr;
+  MgRank &k = g->rk[r];
+  pr.c = k.c;
+  pr.cm = k.cm;
+  pr.A = k.A;
+  pr.m = g->m;
+  pr.n = g->n;
+  pr.lda = k.lda;
+  pr.alpha = k.alpha;
+  pr.P = g->ndev;
+  pr.r = r;
+  rs_row_range(g->m, g->ndev, r, &pr.row0, &pr.mloc);
+  return pr;
+}
+int32_t dhqr_mg_rs_alloc_f64(dhqr_mg *g, int64_t m, int64_t n) {
+  if (!g) return set_err(DHQR_EINVAL, "null handle");
+  if (m <= 0 || n <= 0 || m < n) return set_err(DHQR_EINVAL, "m >= n >= 1 required (m=%lld n=%lld)", (long long)m, (long long)n);
+  CHECK(mg_free_matrix(g));
+  g->m = m;
+  g->n = n;
+  g->rowsplit = true;
+  return mg_run(g, [g, m, n](int r) -> int32_t {
+    MgRank &k = g->rk[r];
+    int64_t row0, mloc;
+    rs_row_range(m, g->ndev, r, &row0, &mloc);
+    k.ncl = n;
+    k.lda = std::max<int64_t>((mloc + 1) & ~(int64_t)1, 2);
+    const size_t elems = (size_t)k.lda * n;
+    if (hipMalloc((void **)&k.A, elems * sizeof(double)) != hipSuccess)
+      return set_err(DHQR_ENOMEM, "hipMalloc of the %lld x %lld local slab failed", (long long)mloc, (long long)n);
+    k.capA = elems;
+    if (hipMalloc((void **)&k.alpha, (size_t)n * sizeof(double)) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc of alpha failed");
+    HIPCHECK(hipMemsetAsync(k.alpha, 0, (size_t)n * sizeof(double), k.c->stream));
+    RsWork w;
+    return rs_prepare(mg_rs_problem(g, r), &w);
+  });
+}
+int32_t dhqr_mg_rs_fill_uniform_f64(dhqr_mg *g, uint64_t seed) {
+  if (!g || !g->m || !g->rowsplit) return set_err(DHQR_EINVAL, "no row-split matrix allocated");
+  return mg_run(g, [g, seed](int r) -> int32_t {
+    const RsProblem pr = mg_rs_problem(g, r);
+    if (pr.mloc == 0) return DHQR_OK;
+    return dhqr_fill_uniform_f64(pr.c, pr.A, pr.mloc, pr.n, pr.lda, seed, pr.m, pr.row0, DHQR_NBV, 1, 0);
+  });
+}
+int32_t dhqr_mg_rs_factor_f64(dhqr_mg *g) {
+  if (!g || !g->m || !g->rowsplit) return set_err(DHQR_EINVAL, "no row-split matrix allocated");
+  return mg_run(g, [g](int r) -> int32_t {
+    const RsProblem pr = mg_rs_problem(g, r);
+    CHECK(rs_factor(pr));
+    HIPCHECK(hipStreamSynchronize(pr.c->stream));
+    return DHQR_OK;
+  });
+}
+int32_t dhqr_mg_rs_residual_f64(dhqr_mg *g, uint64_t seed, double *hrel) {
+  if (!g || !g->m || !g->rowsplit) return set_err(DHQR_EINVAL, "no row-split matrix allocated");
+  if (!hrel) return set_err(DHQR_EINVAL, "null output");
+  CHECK(mg_run(g, [g, seed](int r) -> int32_t {
+    MgRank &k = g->rk[r];
+    const RsProblem pr = mg_rs_problem(g, r);
+    const size_t elems = (size_t)std::max<int64_t>(pr.mloc, 1) * pr.n;
+    if (!k.W && hipMalloc((void **)&k.W, elems * sizeof(double)) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc failed");
+    if (!k.A0 && hipMalloc((void **)&k.A0, elems * sizeof(double)) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc failed");
+    return rs_residual(pr, seed, k.W, k.A0, &k.resid);
+  }));
+  *hrel = g->rk[0].resid;
+  return DHQR_OK;
+}
+// host rows <-> device slabs (hA: m x n column-major, lda); halpha from rank 0 on download
+int32_t dhqr_mg_rs_transfer_f64(dhqr_mg *g, double *hA, int64_t lda, double *halpha, int32_t upload) {
+  if (!g || !g->m || !g->rowsplit) return set_err(DHQR_EINVAL, "no row-split matrix allocated");
+  if (!hA || lda < g->m) return set_err(DHQR_EINVAL, "bad host matrix");
+  return mg_run(g, [g, hA, lda, halpha, upload](int r) -> int32_t {
+    const RsProblem pr = mg_rs_problem(g, r);
+    if (pr.mloc > 0) {
+      if (upload)
+        HIPCHECK(hipMemcpy2DAsync(pr.A, pr.lda * sizeof(double), hA + pr.row0, lda * sizeof(double), pr.mloc * sizeof(double),
+                                  pr.n, hipMemcpyHostToDevice, pr.c->stream));
+      else
+        HIPCHECK(hipMemcpy2DAsync(hA + pr.row0, lda * sizeof(double), pr.A, pr.lda * sizeof(double), pr.mloc * sizeof(double),
+                                  pr.n, hipMemcpyDeviceToHost, pr.c->stream));
+    }
+    if (halpha && !upload && r == 0)
+      HIPCHECK(hipMemcpyAsync(halpha, pr.alpha, (size_t)pr.n * sizeof(double), hipMemcpyDeviceToHost, pr.c->stream));
+    if (halpha && upload)
+      HIPCHECK(hipMemcpyAsync(pr.alpha, halpha, (size_t)pr.n * sizeof(double), hipMemcpyHostToDevice, pr.c->stream));
+    HIPCHECK(hipStreamSynchronize(pr.c->stream));
+    return DHQR_OK;
+  });
+}
+// `H \ b` on the resident row-split factorisation: hb (m) is not modified, hx (n) <- x
+int32_t dhqr_mg_rs_solve_f64(dhqr_mg *g, const double *hb, double *hx) {
+  if (!g || !g->m || !g->rowsplit) return set_err(DHQR_EINVAL, "no row-split matrix allocated");
+  if (!hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
+  return mg_run(g, [g, hb, hx](int r) -> int32_t {
+    MgRank &k = g->rk[r];
+    const RsProblem pr = mg_rs_problem(g, r);
+    const size_t need = (size_t)std::max<int64_t>(pr.mloc, 1) + (size_t)pr.n + 64;
+    if (!k.vec && hipMalloc((void **)&k.vec, need * sizeof(double)) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc failed");
+    double *db = k.vec, *dx = k.vec + ((std::max<int64_t>(pr.mloc, 1) + 15) & ~(int64_t)15);
+    if (pr.mloc > 0)
+      HIPCHECK(hipMemcpyAsync(db, hb + pr.row0, (size_t)pr.mloc * sizeof(double), hipMemcpyHostToDevice, pr.c->stream));
+    CHECK(rs_solve(pr, db, dx));
+    if (r == 0) HIPCHECK(hipMemcpyAsync(hx, dx, (size_t)pr.n * sizeof(double), hipMemcpyDeviceToHost, pr.c->stream));
+    HIPCHECK(hipStreamSynchronize(pr.c->stream));
+    return DHQR_OK;
+  });
 }
 
 }  // extern "C"

@@ -26,6 +26,7 @@ struct dhqr_mg {
   std::vector<MgRank> rk;
   int transport = COMM_SELF;
   int64_t m = 0, n = 0;
+  bool rowsplit = false;  // layout of the resident matrix: block-cyclic columns (default) or 128-row aligned row slabs
   // job dispatch
   std::mutex mu;
   std::condition_variable cv_job, cv_done;

@@ -222,3 +222,22 @@ __global__ __launch_bounds__(256) void k_unpack_v(double *__restrict__ P, int64_
   for (int64_t r = p + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride)
     P[r + p * ldp] = Vw[r + p * ldv];
 }
+
+// Row-split driver (dhqr_rowsplit.h): ranks that do not hold the panel's diagonal rows move whole rows.
+// Vw[r + p*ldv] = P[r + p*ldp] for p < ncols, 0 in the padding columns and in the pad rows [rows, npad).
+__global__ __launch_bounds__(256) void k_pack_rows(const double *__restrict__ P, int64_t ldp, int64_t rows,
+                                                   int64_t ncols, double *__restrict__ Vw, int64_t ldv, int64_t npad) {
+  const int64_t p = blockIdx.y;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < npad; r += stride)
+    Vw[r + p * ldv] = (p < ncols && r < rows) ? P[r + p * ldp] : 0.0;
+}
+__global__ __launch_bounds__(256) void k_unpack_rows(double *__restrict__ P, int64_t ldp, int64_t rows, int64_t ncols,
+                                                     const double *__restrict__ Vw, int64_t ldv,
+                                                     const int *__restrict__ stat, int epoch) {
+  const int64_t p = blockIdx.y;
+  if (p >= ncols) return;
+  if (stat != nullptr && stat[0] <= epoch) return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) P[r + p * ldp] = Vw[r + p * ldv];
+}

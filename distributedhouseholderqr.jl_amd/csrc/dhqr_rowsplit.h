@@ -1,0 +1,512 @@
+// dhqr_rowsplit.h -- tall-skinny factorisation with the ROWS split over the ranks (BASELINE configs[4]:
+// 262144 x 4096 over 8 GPUs).  Included by dhqr_api.hip.  The reference cannot split rows
+// (`@assert rowrange == 1:size(A,1)`, src:33); its algorithm needs one cross-rank reduction per COLUMN (norm,
+// src:129, and the partial dots, src:208).  Here the R-first panel (dhqr_recon.h) needs cross-rank sums only per
+// 128-column panel, all through the communicator's all-reduce ("RCCL all-reduce of the cross-partition partial
+// dots"):
+//     G = sum_r P_r' P_r   (128 x 128)        -> R = chol(G), replay of the top block on the rank that owns the
+//                                                 panel's diagonal rows, broadcast of (-M^{-1}, alpha)
+//     S = sum_r V_r' V_r   (128 x 128)        -> acceptance decision (identical on every rank: same S) and T
+//     W = sum_r V_r' C_r   (128 x ncols)      -> trailing update C_r -= V_r (T' W), local
+// Row slabs are 128-row aligned (rs_row_range), so a panel's diagonal block lives on exactly one rank -- whichever
+// holds those rows.  Nothing waits on the host: panels are verified and committed on the device like in the
+// column-split driver; a rejected panel (or a partial last panel) is redone column by column ACROSS the ranks
+// (rs_panel_columns: the reference's algorithm with one small all-reduce + one small broadcast per column).
+// Factor format = the reference's, distributed by rows: V rows live where the matrix rows live, R in the top n rows.
+#pragma once
+
+static inline void rs_row_range(int64_t m, int P, int r, int64_t *row0, int64_t *mloc) {
+  const int64_t NB = DHQR_NBV, blocks = (m + NB - 1) / NB, q = blocks / P, rem = blocks % P;
+  const int64_t b0 = (int64_t)r * q + std::min<int64_t>(r, rem), nb = q + (r < rem ? 1 : 0);
+  *row0 = std::min<int64_t>(m, b0 * NB);
+  *mloc = std::min<int64_t>(m, (b0 + nb) * NB) - *row0;
+}
+
+struct RsProblem {
+  dhqr_ctx *c;
+  dhqr_comm *cm;  // nullptr: single rank
+  double *A;      // local rows [row0, row0 + mloc) of the m x n matrix, leading dimension lda
+  int64_t m, n, lda, row0, mloc;
+  double *alpha;  // n, replicated
+  int P, r;
+  int owner_of_row(int64_t grow) const {
+    for (int q = 0; q < P; ++q) {
+      int64_t r0, ml;
+      rs_row_range(m, P, q, &r0, &ml);
+      if (grow >= r0 && grow < r0 + ml) return q;
+    }
+    return P - 1;
+  }
+  // local rows taking part in the panel whose diagonal starts at global row c0: [off, off + rows)
+  void active(int64_t c0, int64_t *off, int64_t *rows) const {
+    const int64_t lo = std::max<int64_t>(0, c0 - row0);
+    *off = std::min<int64_t>(lo, mloc);
+    *rows = mloc - *off;
+  }
+};
+
+// ---- column-by-column kernels of the robust path --------------------------------------------------
+// partial[blk][k] = sum over this block's active rows of a_j[i] * a_{j+k}[i],  k in [0, nk)
+__global__ __launch_bounds__(256) void k_rs_coldots(const double *__restrict__ Pp, int64_t ldp, int64_t rows,
+                                                    int64_t lo, int j, int nk, double *__restrict__ partial) {
+  __shared__ double red[8];
+  const int t = threadIdx.x;
+  double aj[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t i = lo + (int64_t)blockIdx.x * 1024 + t + e * 256;
+    aj[e] = (i < rows) ? Pp[i + (int64_t)j * ldp] : 0.0;
+  }
+  for (int k = 0; k < nk; ++k) {
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = lo + (int64_t)blockIdx.x * 1024 + t + e * 256;
+      if (i < rows) s = fma(aj[e], Pp[i + (int64_t)(j + k) * ldp], s);
+    }
+    s = block_sum<256>(s, red);
+    if (t == 0) partial[(int64_t)blockIdx.x * nk + k] = s;
+  }
+}
+// owner of the diagonal row: bc = [alpha, f, s_1 .. s_{nk-1}] from the all-reduced dots d (d[0] = ||a_j||^2)
+// and its diagonal row; s_k = v' a_{j+k} = f (d_k - alpha a_{j,j+k})   (src:129-131, 208)
+__global__ __launch_bounds__(128) void k_rs_colscalars(const double *__restrict__ d, const double *__restrict__ diagrow,
+                                                       int64_t ldp, int nk, double *__restrict__ bc,
+                                                       double *__restrict__ alpha_j) {
+  const int k = threadIdx.x;
+  const double ajj = diagrow[0];
+  const double s = sqrt(d[0]);
+  const double al = s * dhqr_alphafactor(ajj);
+  const double f = 1.0 / sqrt(s * (s + fabs(ajj)));
+  if (k == 0) {
+    bc[0] = al;
+    bc[1] = f;
+    *alpha_j = al;
+  } else if (k < nk) {
+    bc[1 + k] = f * (d[k] - al * diagrow[(int64_t)k * ldp]);
+  }
+}
+// everybody: column j <- v, columns j+k (k >= 1) -= v s_k on the active rows (src:132-135, 209)
+__global__ __launch_bounds__(256) void k_rs_colupdate(double *__restrict__ Pp, int64_t ldp, int64_t rows, int64_t lo,
+                                                      int64_t diag, int j, int nk, const double *__restrict__ bc) {
+  __shared__ double sk[RC_N + 2];
+  const int t = threadIdx.x;
+  for (int k = t; k < nk + 1; k += 256) sk[k] = bc[k];
+  __syncthreads();
+  const double al = sk[0], f = sk[1];
+  for (int e = 0; e < 4; ++e) {
+    const int64_t i = lo + (int64_t)blockIdx.x * 1024 + t + e * 256;
+    if (i >= rows) continue;
+    const double a = Pp[i + (int64_t)j * ldp];
+    const double v = (i == diag) ? (a - al) * f : a * f;
+    Pp[i + (int64_t)j * ldp] = v;
+    for (int k = 1; k < nk; ++k) Pp[i + (int64_t)(j + k) * ldp] = fma(-v, sk[1 + k], Pp[i + (int64_t)(j + k) * ldp]);
+  }
+}
+__global__ void k_rs_set_breakdown(const double *__restrict__ word, int *__restrict__ stat) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && *word != 0.0) stat[1] = 1;
+}
+__global__ void k_rs_get_breakdown(int *__restrict__ stat, double *__restrict__ word) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *word = stat[1] ? 1.0 : 0.0;
+    stat[1] = 0;
+  }
+}
+
+struct RsWork {  // device workspaces of one rank (views into ctx buffers)
+  double *Vw;    // ldv x 128
+  int64_t ldv;
+  double *G, *S, *Rref, *T, *Tt, *bc, *W1, *W2, *altmp, *part;
+};
+
+static int32_t rs_prepare(const RsProblem &pr, RsWork *w) {
+  dhqr_ctx *c = pr.c;
+  const int64_t NB = DHQR_NBV;
+  const size_t NN = (size_t)NB * NB;
+  w->ldv = panel_ldv(std::max<int64_t>(pr.mloc, 1));
+  CHECK(ensure(c, c->vts, (size_t)w->ldv * NB + 1024));
+  CHECK(ensure(c, c->rbuf, 8 * NN + 4096));
+  CHECK(ensure(c, c->ws[0].w1r, (size_t)NB * std::max<int64_t>(pr.n, NB)));
+  CHECK(ensure(c, c->ws[0].w2, (size_t)NB * std::max<int64_t>(pr.n, NB)));
+  CHECK(ensure(c, c->spart, (size_t)256 * NN));
+  CHECK(ensure(c, c->sfull, NN));
+  CHECK(ensure(c, c->scratch, 4096));
+  const size_t nblk = (size_t)((pr.mloc + 1023) / 1024 + 1);
+  CHECK(ensure(c, c->pbuf, nblk * NB + 1024));
+  {
+    const int64_t ntiles = (pr.n + 127) / 128;
+    int64_t ns, rps;
+    pick_split(std::max<int64_t>(pr.mloc, 128), ntiles, 512, ntiles <= 2 ? 256 : 64, &ns, &rps);
+    CHECK(ensure(c, c->ws[0].w1, (size_t)(ns + 1) * NB * (size_t)std::max<int64_t>(pr.n, NB)));
+  }
+  w->Vw = c->vts.p;
+  double *r = c->rbuf.p;
+  w->G = r;
+  w->S = r + NN;
+  w->Rref = r + 2 * NN;
+  w->T = r + 3 * NN;
+  w->Tt = r + 4 * NN;
+  w->bc = r + 5 * NN;        // [-M^{-1} (NN) | alpha (128) | breakdown word | ...]
+  w->altmp = r + 5 * NN + NN;
+  w->W1 = c->ws[0].w1r.p;
+  w->W2 = c->ws[0].w2.p;
+  w->part = c->pbuf.p;
+  return DHQR_OK;
+}
+
+// W1 (128 x ncols, ld 128) = Vw' C over the local active rows, summed over the ranks
+static int32_t rs_vtc_allreduce(const RsProblem &pr, const RsWork &w, const double *C, int64_t ldc, int64_t rows,
+                                int64_t ncols) {
+  dhqr_ctx *c = pr.c;
+  const int64_t NB = DHQR_NBV, wstride = NB * ncols;
+  if (rows <= 0) {
+    HIPCHECK(hipMemsetAsync(w.W1, 0, (size_t)wstride * sizeof(double), c->stream));
+  } else {
+    const int64_t ntiles = (ncols + 127) / 128;
+    int64_t nsplit, rps;
+    pick_split(rows, ntiles, 512, ntiles <= 2 ? 256 : 64, &nsplit, &rps);
+    CHECK(ensure(c, c->ws[0].w1, (size_t)nsplit * NB * (size_t)ncols));
+    const bool vec = (ldc % 2 == 0) && (w.ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(w.Vw);
+    const dim3 gtn((unsigned)ntiles, (unsigned)nsplit);
+    if (vec)
+      hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), gtn, dim3(256), 0, c->stream, (const double *)w.Vw, w.ldv, C, ldc, 1,
+                         (int64_t)0, rows, ncols, rps, c->ws[0].w1.p, NB, wstride);
+    else
+      hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), gtn, dim3(256), 0, c->stream, (const double *)w.Vw, w.ldv, C, ldc, 1,
+                         (int64_t)0, rows, ncols, rps, c->ws[0].w1.p, NB, wstride);
+    hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)((wstride + 63) / 64)), dim3(256), 0, c->stream,
+                       (const double *)c->ws[0].w1.p, (int)nsplit, wstride, wstride, w.W1);
+  }
+  LAUNCHCHECK();
+  if (pr.cm && pr.P > 1) CHECK(comm_allreduce_sum(pr.cm, w.W1, wstride, c->stream));
+  return DHQR_OK;
+}
+// C (rows x ncols) -= Vw (op(T)' W1): W2 = Top' W1, then the NN GEMM (predicated when `pred`)
+static int32_t rs_apply_w(const RsProblem &pr, const RsWork &w, const double *Top, double *C, int64_t ldc, int64_t rows,
+                          int64_t ncols, bool pred) {
+  dhqr_ctx *c = pr.c;
+  const int64_t NB = DHQR_NBV, ntiles = (ncols + 127) / 128;
+  hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top, NB, (const double *)w.W1,
+                     NB, 1, (int64_t)0, NB, ncols, NB, w.W2, NB, (int64_t)0);
+  if (rows > 0) {
+    const bool vec = (ldc % 2 == 0) && (w.ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(w.Vw);
+    dim3 grid((unsigned)((rows + 127) / 128), (unsigned)ntiles);
+    launch_nn_sub<128>(c, vec, grid, w.Vw, w.ldv, (const double *)w.W2, NB, C, ldc, rows, ncols, 0, pred);
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// S = sum over ranks of Vw' Vw
+static int32_t rs_gram_allreduce(const RsProblem &pr, const double *X, int64_t ldx, int64_t rows, double *out) {
+  dhqr_ctx *c = pr.c;
+  const size_t NN = (size_t)DHQR_NBV * DHQR_NBV;
+  if (rows <= 0) HIPCHECK(hipMemsetAsync(out, 0, NN * sizeof(double), c->stream));
+  else CHECK(gram128(c, X, ldx, rows, out));
+  LAUNCHCHECK();
+  if (pr.cm && pr.P > 1) CHECK(comm_allreduce_sum(pr.cm, out, (int64_t)NN, c->stream));
+  return DHQR_OK;
+}
+// Vw <- the V operand of an already factored panel (diag owner: R part zeroed; others: plain copy of their rows)
+static int32_t rs_pack(const RsProblem &pr, const RsWork &w, int64_t c0, int64_t wcols, int64_t off, int64_t rows, bool diag_owner) {
+  dhqr_ctx *c = pr.c;
+  if (rows <= 0) return DHQR_OK;
+  const double *P = pr.A + off + c0 * pr.lda;
+  const int64_t npad = panel_ldv(rows);
+  dim3 grid((unsigned)std::min<int64_t>((npad + 255) / 256, 64), DHQR_NBV);
+  if (diag_owner) {
+    hipLaunchKernelGGL(k_pack_v, grid, dim3(256), 0, c->stream, P, pr.lda, rows, wcols, w.Vw, w.ldv, npad);
+  } else {
+    // all rows are below the diagonal: pack with a "diagonal" far above (rows >= p always) = copy + zero padding columns
+    hipLaunchKernelGGL(k_pack_rows, grid, dim3(256), 0, c->stream, P, pr.lda, rows, wcols, w.Vw, w.ldv, npad);
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+// Robust panel: the reference's algorithm column by column across the ranks (any width <= 128).
+static int32_t rs_panel_columns(const RsProblem &pr, const RsWork &w, int64_t c0, int64_t wcols) {
+  dhqr_ctx *c = pr.c;
+  dhqr_comm *cm = (pr.cm && pr.P > 1) ? pr.cm : nullptr;
+  int64_t off, rows;
+  pr.active(c0, &off, &rows);
+  const int downer = pr.owner_of_row(c0);
+  const bool diag_owner = downer == pr.r;
+  double *Pp = pr.A + off + c0 * pr.lda;  // local active rows of the panel; on the diag owner row 0 is global row c0
+  double *d = w.altmp + 256, *bcs = w.altmp + 512;  // dots (<= 128), scalars (<= 130)
+  for (int64_t j = 0; j < wcols; ++j) {
+    const int nk = (int)(wcols - j);
+    // active rows of column j: global row >= c0 + j
+    const int64_t lo = diag_owner ? j : 0;
+    const int64_t nrow = std::max<int64_t>(rows - lo, 0);
+    const unsigned nblk = (unsigned)std::max<int64_t>((nrow + 1023) / 1024, 1);
+    if (nrow > 0) {
+      hipLaunchKernelGGL(k_rs_coldots, dim3(nblk), dim3(256), 0, c->stream, (const double *)Pp, pr.lda, rows, lo, (int)j, nk,
+                         w.part);
+      hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0, c->stream, (const double *)w.part,
+                         (int)nblk, (int64_t)nk, (int64_t)nk, d);
+    } else {
+      HIPCHECK(hipMemsetAsync(d, 0, (size_t)nk * sizeof(double), c->stream));
+    }
+    if (cm) CHECK(comm_allreduce_sum(cm, d, nk, c->stream));
+    if (diag_owner)
+      hipLaunchKernelGGL(k_rs_colscalars, dim3(1), dim3(128), 0, c->stream, (const double *)d,
+                         (const double *)(Pp + j + j * pr.lda), pr.lda, nk, bcs, pr.alpha + c0 + j);
+    if (cm) CHECK(comm_bcast(cm, bcs, nk + 1, downer, c->stream, nullptr));
+    if (!diag_owner)
+      hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, (const double *)bcs, 1, pr.alpha + c0 + j,
+                         (double *)nullptr, (const int *)nullptr, 0);
+    if (nrow > 0)
+      hipLaunchKernelGGL(k_rs_colupdate, dim3(nblk), dim3(256), 0, c->stream, Pp, pr.lda, rows, lo, diag_owner ? j : (int64_t)-1,
+                         (int)j, nk, (const double *)bcs);
+    LAUNCHCHECK();
+    if (cm && cm->kind == COMM_LOCAL) {  // the tiny broadcast source is reused by the next column
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      CHECK(comm_host_barrier(cm));
+    }
+  }
+  // operands of the trailing update: V packed, S all-reduced, T
+  if (rows > 0) CHECK(rs_pack(pr, w, c0, wcols, off, rows, diag_owner));
+  CHECK(rs_gram_allreduce(pr, w.Vw, w.ldv, rows, w.S));
+  launch_build_t(c, w.S, (int)wcols, w.T, w.Tt);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+// One asynchronous pass over the panels [kstart, K); returns the first rejected panel in *failed (INT_MAX: none).
+static int32_t rs_run(const RsProblem &pr, const RsWork &w, int64_t kstart, bool robust_first, int *failed, int64_t *nfast) {
+  dhqr_ctx *c = pr.c;
+  dhqr_comm *cm = (pr.cm && pr.P > 1) ? pr.cm : nullptr;
+  const int64_t NB = DHQR_NBV, n = pr.n, K = (n + NB - 1) / NB;
+  const size_t NN = (size_t)NB * NB;
+  const int saved_epoch = c->epoch;
+  auto body = [&]() -> int32_t {
+    for (int64_t k = kstart; k < K; ++k) {
+      const int64_t c0 = k * NB, wcols = std::min<int64_t>(NB, n - c0);
+      int64_t off, rows;
+      pr.active(c0, &off, &rows);
+      const int downer = pr.owner_of_row(c0);
+      const bool diag_owner = downer == pr.r;
+      const bool fast = c->panel_impl == 3 && wcols == NB && pr.m - c0 >= 2 * NB && !(robust_first && k == kstart);
+      double *P = pr.A + off + c0 * pr.lda;
+      c->epoch = -1;
+      if (fast) {
+        CHECK(prof_begin(c, CAT_PANEL));
+        CHECK(rs_gram_allreduce(pr, P, pr.lda, rows, w.G));                       // G = sum P_r' P_r
+        if (diag_owner) {
+          hipLaunchKernelGGL(k_panel_top, dim3(1), dim3(1024), 0, c->stream, (const double *)w.G, (const double *)P, pr.lda,
+                             w.bc + NN, w.Rref, w.bc, c->dstat + 1);             // alpha -> bc tail, -M^{-1} -> bc
+          hipLaunchKernelGGL(k_rs_get_breakdown, dim3(1), dim3(64), 0, c->stream, c->dstat, w.bc + NN + NB);
+        }
+        if (cm) CHECK(comm_bcast(cm, w.bc, (int64_t)NN + NB + 8, downer, c->stream, nullptr));
+        hipLaunchKernelGGL(k_rs_set_breakdown, dim3(1), dim3(64), 0, c->stream, (const double *)(w.bc + NN + NB), c->dstat);
+        if (rows > 0) CHECK(mul128(c, P, pr.lda, rows, w.bc, w.Vw, w.ldv));        // Vw = P M^{-1}
+        if (diag_owner)
+          hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, w.Vw, w.ldv, (const double *)(w.bc + NN),
+                             (const double *)w.bc);
+        CHECK(rs_gram_allreduce(pr, w.Vw, w.ldv, rows, w.S));                      // S = sum V_r' V_r: same on every rank
+        hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, (const double *)w.S, (int)NB, w.T, w.Tt, c->recon_tol,
+                           c->dstat, (int)k, (double *)nullptr);                   // same decision on every rank
+        if (rows > 0) {
+          if (diag_owner) {
+            dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
+            hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, P, pr.lda, rows, NB, (const double *)w.Vw, w.ldv,
+                               (const int *)c->dstat, (int)k);
+            hipLaunchKernelGGL(k_recon_write_r, dim3(NN / 256), dim3(256), 0, c->stream, P, pr.lda, (const double *)w.Rref,
+                               (const int *)c->dstat, (int)k);
+          } else {
+            dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
+            hipLaunchKernelGGL(k_unpack_rows, grid, dim3(256), 0, c->stream, P, pr.lda, rows, NB, (const double *)w.Vw, w.ldv,
+                               (const int *)c->dstat, (int)k);
+          }
+        }
+        hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, (const double *)(w.bc + NN), (int)NB,
+                           pr.alpha + c0, (double *)nullptr, (const int *)c->dstat, (int)k);
+        LAUNCHCHECK();
+        CHECK(prof_end(c));
+        (*nfast)++;
+        if (cm && cm->kind == COMM_LOCAL) {  // bc is the broadcast source of the next panel
+          HIPCHECK(hipStreamSynchronize(c->stream));
+          CHECK(comm_host_barrier(cm));
+        }
+      } else {
+        // partial / short panels and the panel a resumed pass starts with: column by column.  Inside a pass they may
+        // only run if nothing was rejected before (one status read; every rank holds the same status).
+        if (k != kstart) {
+          int f = 0;
+          CHECK(status_read(c, &f));
+          if (f != INT_MAX) break;
+        }
+        CHECK(prof_begin(c, CAT_PANEL));
+        CHECK(rs_panel_columns(pr, w, c0, wcols));
+        CHECK(prof_end(c));
+      }
+      // trailing update of the local rows: W = sum_r V_r' C_r, C_r -= V_r (T' W)
+      const int64_t ncols = n - c0 - wcols;
+      if (ncols > 0) {
+        c->epoch = fast ? (int)k : -1;
+        double *C = pr.A + off + (c0 + wcols) * pr.lda;
+        CHECK(prof_begin(c, CAT_VTA));
+        CHECK(rs_vtc_allreduce(pr, w, C, pr.lda, rows, ncols));
+        CHECK(prof_end(c));
+        CHECK(prof_begin(c, CAT_AVW));
+        CHECK(rs_apply_w(pr, w, w.T, C, pr.lda, rows, ncols, true));
+        CHECK(prof_end(c));
+        if (c->profiling) {
+          c->st.flops_gemm_vta += 2.0 * NB * (double)rows * (double)ncols;
+          c->st.flops_gemm_avw += 2.0 * NB * (double)rows * (double)ncols;
+        }
+      }
+    }
+    return DHQR_OK;
+  };
+  int32_t rc = body();
+  c->epoch = saved_epoch;
+  if (rc == DHQR_OK) rc = status_read(c, failed);
+  return rc;
+}
+
+static int32_t rs_factor(const RsProblem &pr) {
+  dhqr_ctx *c = pr.c;
+  RsWork w;
+  CHECK(rs_prepare(pr, &w));
+  CHECK(status_reset(c));
+  const int64_t K = (pr.n + DHQR_NBV - 1) / DHQR_NBV;
+  int64_t ks = 0;
+  bool robust = false;
+  for (int pass = 0; ks < K; ++pass) {
+    if (pass > K + 2) return set_err(DHQR_EINVAL, "internal error: the row-split driver does not make progress");
+    int failed = INT_MAX;
+    int64_t nfast = 0;
+    CHECK(rs_run(pr, w, ks, robust, &failed, &nfast));
+    if (failed == INT_MAX) {
+      c->n_fast += nfast;
+      break;
+    }
+    c->n_fast += std::max<int64_t>(0, std::min<int64_t>(nfast, failed - ks));
+    c->n_fallback++;
+    CHECK(status_reset(c));
+    ks = failed;
+    robust = true;
+  }
+  return DHQR_OK;
+}
+
+// ||A - QR||_F / ||A||_F: every rank forms ITS ROWS of Q*R by re-applying the panels in reverse order to [R; 0]
+// (one all-reduce of V'B per panel), A regenerated from `seed`.  dB, dA0: mloc x n scratch (ld = max(mloc,1)).
+static int32_t rs_residual(const RsProblem &pr, uint64_t seed, double *dB, double *dA0, double *hrel) {
+  dhqr_ctx *c = pr.c;
+  RsWork w;
+  CHECK(rs_prepare(pr, &w));
+  const int64_t NB = DHQR_NBV, n = pr.n, K = (n + NB - 1) / NB, ldb = std::max<int64_t>(pr.mloc, 1);
+  const bool was = c->profiling;
+  c->profiling = false;
+  c->epoch = -1;
+  auto body = [&]() -> int32_t {
+    if (pr.mloc > 0) {
+      // [R; 0] rows of this rank: global row g = row0 + i carries R[g, :] for g < n
+      dim3 grid((unsigned)std::min<int64_t>((pr.mloc + 255) / 256, 128), (unsigned)std::min<int64_t>(n, 32768));
+      hipLaunchKernelGGL(k_form_r0_rows, grid, dim3(256), 0, c->stream, (const double *)pr.A, pr.lda, (const double *)pr.alpha,
+                         pr.mloc, n, pr.row0, dB, ldb);
+    }
+    for (int64_t k = K - 1; k >= 0; --k) {
+      const int64_t c0 = k * NB, wcols = std::min<int64_t>(NB, n - c0);
+      int64_t off, rows;
+      pr.active(c0, &off, &rows);
+      const bool diag_owner = pr.owner_of_row(c0) == pr.r;
+      if (rows > 0) CHECK(rs_pack(pr, w, c0, wcols, off, rows, diag_owner));
+      CHECK(rs_gram_allreduce(pr, w.Vw, w.ldv, rows, w.S));
+      launch_build_t(c, w.S, (int)wcols, w.T, w.Tt);
+      const int64_t ncols = n - c0;
+      double *C = dB + off + c0 * ldb;
+      CHECK(rs_vtc_allreduce(pr, w, C, ldb, rows, ncols));
+      CHECK(rs_apply_w(pr, w, w.Tt, C, ldb, rows, ncols, false));  // Q (not Q'): op(T) = T
+    }
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  c->profiling = was;
+  CHECK(rc);
+  double h[2] = {0.0, 0.0};
+  if (pr.mloc > 0) {
+    const int64_t total = pr.mloc * n;
+    const unsigned gridf = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_fill_uniform, dim3(gridf), dim3(256), 0, c->stream, dA0, pr.mloc, n, ldb, seed, pr.m, pr.row0, NB, 1, 0);
+    const int nblk = 1024;
+    hipLaunchKernelGGL(k_diff_norms, dim3(nblk), dim3(256), 0, c->stream, (const double *)dA0, ldb, (const double *)dB, ldb,
+                       pr.mloc, n, c->scratch.p);
+    hipLaunchKernelGGL(k_sum2_final, dim3(1), dim3(256), 0, c->stream, (const double *)c->scratch.p, nblk, c->scratch.p + 2048);
+  } else {
+    HIPCHECK(hipMemsetAsync(c->scratch.p + 2048, 0, 2 * sizeof(double), c->stream));
+  }
+  LAUNCHCHECK();
+  if (pr.cm && pr.P > 1) CHECK(comm_allreduce_sum(pr.cm, c->scratch.p + 2048, 2, c->stream));
+  HIPCHECK(hipMemcpyAsync(h, c->scratch.p + 2048, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  *hrel = std::sqrt(h[0] / h[1]);
+  return DHQR_OK;
+}
+
+// `H \ b` (src:317-321) for the row split: db = this rank's rows of b (mloc, overwritten); dx (n) <- x on every rank.
+// Q'b (src:215-242): per panel the partial dots V_r' b_r are all-reduced (a 128-vector), then b_r -= V_r (T' w)
+// locally.  The back substitution (src:244-254) needs R = the top n rows: each 128-row block is solved by the rank
+// that owns those rows and broadcast; the ranks owning rows above subtract their part.
+static int32_t rs_solve(const RsProblem &pr, double *db, double *dx) {
+  dhqr_ctx *c = pr.c;
+  dhqr_comm *cm = (pr.cm && pr.P > 1) ? pr.cm : nullptr;
+  RsWork w;
+  CHECK(rs_prepare(pr, &w));
+  const int64_t NB = DHQR_NBV, n = pr.n, K = (n + NB - 1) / NB, ldb = std::max<int64_t>(pr.mloc, 1);
+  const bool was = c->profiling;
+  CHECK(prof_begin(c, CAT_SOLVE));
+  c->profiling = false;
+  c->epoch = -1;
+  auto sync_local = [&]() -> int32_t {
+    if (cm && cm->kind == COMM_LOCAL) {
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      CHECK(comm_host_barrier(cm));
+    }
+    return DHQR_OK;
+  };
+  auto body = [&]() -> int32_t {
+    for (int64_t k = 0; k < K; ++k) {
+      const int64_t c0 = k * NB, wcols = std::min<int64_t>(NB, n - c0);
+      int64_t off, rows;
+      pr.active(c0, &off, &rows);
+      const bool diag_owner = pr.owner_of_row(c0) == pr.r;
+      if (rows > 0) CHECK(rs_pack(pr, w, c0, wcols, off, rows, diag_owner));
+      CHECK(rs_gram_allreduce(pr, w.Vw, w.ldv, rows, w.S));
+      launch_build_t(c, w.S, (int)wcols, w.T, w.Tt);
+      CHECK(rs_vtc_allreduce(pr, w, db + off, ldb, rows, 1));
+      CHECK(rs_apply_w(pr, w, w.T, db + off, ldb, rows, 1, false));
+    }
+    // back substitution, block by block from the bottom of R: x_blk solved by the owner of rows [c0, c0 + w)
+    HIPCHECK(hipMemsetAsync(dx, 0, (size_t)n * sizeof(double), c->stream));
+    for (int64_t k = K - 1; k >= 0; --k) {
+      const int64_t c0 = k * NB, wcols = std::min<int64_t>(NB, n - c0);
+      const int downer = pr.owner_of_row(c0);
+      if (downer == pr.r) {
+        // rows [c0, c0 + w) are local rows [c0 - row0, ...): R block rows sit in pr.A at those local rows;
+        // dhqr_backsub_block addresses column j of R at base + j*lda and rows by GLOBAL index i: shift the base
+        const double *base = pr.A - pr.row0;  // so that (global row i, column j) is base[i + j*lda]
+        CHECK(dhqr_backsub_block_f64(c, base, pr.lda, pr.alpha, db - pr.row0, c0, c0 + wcols, 1, 0));
+        HIPCHECK(hipMemcpyAsync(dx + c0, db + (c0 - pr.row0), (size_t)wcols * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      }
+      if (cm) {
+        CHECK(comm_bcast(cm, dx + c0, wcols, downer, c->stream, nullptr));
+        CHECK(sync_local());
+      }
+      // every rank that owns R rows above the block subtracts R[rows, blk] x_blk from its part of b
+      const int64_t lo = pr.row0, hi = std::min<int64_t>(pr.row0 + pr.mloc, c0);
+      if (hi > lo)
+        hipLaunchKernelGGL(k_rs_backsub_update, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double *)pr.A, pr.lda, db, hi - lo, c0, (int)wcols, (const double *)(dx + c0));
+      LAUNCHCHECK();
+    }
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  c->profiling = was;
+  CHECK(rc);
+  CHECK(prof_end(c));
+  return DHQR_OK;
+}

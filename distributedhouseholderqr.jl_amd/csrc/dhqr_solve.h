@@ -148,3 +148,25 @@ __global__ __launch_bounds__(256) void k_sum2_final(const double *__restrict__ p
     out[1] = s1;
   }
 }
+
+// Row-split driver: this rank's rows of [R; 0] (local row i is global row row0 + i; alpha = diag(R))
+__global__ __launch_bounds__(256) void k_form_r0_rows(const double *__restrict__ A, int64_t lda,
+                                                      const double *__restrict__ alpha, int64_t mloc, int64_t n,
+                                                      int64_t row0, double *__restrict__ B, int64_t ldb) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = blockIdx.y; j < n; j += gridDim.y)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mloc; i += stride) {
+      const int64_t g = row0 + i;
+      B[i + j * ldb] = (g < j) ? A[i + j * lda] : (g == j ? alpha[j] : 0.0);
+    }
+}
+// Row-split back substitution: b[i] -= sum_{k<w} R[i, c0+k] x[k] for the first `nrows` local rows (all above the block)
+__global__ __launch_bounds__(256) void k_rs_backsub_update(const double *__restrict__ A, int64_t lda,
+                                                           double *__restrict__ b, int64_t nrows, int64_t c0, int w,
+                                                           const double *__restrict__ x) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows) return;
+  double s = 0.0;
+  for (int k = 0; k < w; ++k) s = fma(A[i + (c0 + k) * lda], x[k], s);
+  b[i] -= s;
+}

@@ -348,6 +348,42 @@ class MultiGpuQR:
         self.m, self.n = m, n
         return x
 
+    # row split (BASELINE configs[4]): device-resident tall-skinny matrix, 128-row aligned slabs over the devices
+    def rs_alloc(self, m, n):
+        self._check(self.L.dhqr_mg_rs_alloc_f64(self._h, m, n))
+        self.m, self.n = m, n
+        return self
+
+    def rs_fill(self, seed):
+        self._check(self.L.dhqr_mg_rs_fill_uniform_f64(self._h, seed))
+        return self
+
+    def rs_factor(self):
+        self._check(self.L.dhqr_mg_rs_factor_f64(self._h))
+        return self
+
+    def rs_residual(self, seed) -> float:
+        out = ctypes.c_double()
+        self._check(self.L.dhqr_mg_rs_residual_f64(self._h, seed, ctypes.byref(out)))
+        return out.value
+
+    def rs_upload(self, A):
+        F = np.asfortranarray(A, dtype=np.float64)
+        self._check(self.L.dhqr_mg_rs_transfer_f64(self._h, F.ctypes.data_as(_P), F.shape[0], None, 1))
+        return self
+
+    def rs_download(self):
+        H = np.zeros((self.m, self.n), order="F")
+        al = np.zeros(self.n)
+        self._check(self.L.dhqr_mg_rs_transfer_f64(self._h, H.ctypes.data_as(_P), self.m, al.ctypes.data_as(_P), 0))
+        return H, al
+
+    def rs_solve(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros(self.n)
+        self._check(self.L.dhqr_mg_rs_solve_f64(self._h, b.ctypes.data_as(_P), x.ctypes.data_as(_P)))
+        return x
+
     # statistics
     def set_profiling(self, on):
         self._check(self.L.dhqr_mg_set_profiling(self._h, 1 if on else 0))

@@ -304,31 +304,31 @@ int32_t dhqr_mg_reset_stats(dhqr_mg *mg);
 int32_t dhqr_mg_get_stats(dhqr_mg *mg, int32_t rank, dhqr_stats *out, int64_t *n_fast, int64_t *n_fallback,
                           int64_t *bytes_bcast);
 
-/* ------------------------------------------------------------------ row-split building blocks
- * BASELINE configs[4] (tall-skinny, ROWS distributed over the ranks; the reference cannot split rows,
- * src:33).  One panel = the R-first algorithm of csrc/dhqr_recon.h with the sums over ranks done by
- * the host layer (distributedhouseholderqr.jl_amd/rowsplit.py) through all-reduce: Gram matrices
- * (128 x 128) and the V'C partial dots (128 x ncols) -- "RCCL all-reduce of the cross-partition
- * partial dots".  All pointers are device pointers to the caller's LOCAL row slab; all calls async. */
-int32_t dhqr_rs_gram_f64(dhqr_ctx *ctx, const double *dX, int64_t ldx, int64_t rows, double *dG);
-int32_t dhqr_rs_chol_f64(dhqr_ctx *ctx, const double *dG, double *dR, int32_t *dflag);
-int32_t dhqr_rs_recon_top_f64(dhqr_ctx *ctx, const double *dPtop, int64_t ldp, const double *dR,
-                              double *dalpha128, double *dRref, double *dnegMinv);
-int32_t dhqr_rs_mul_f64(dhqr_ctx *ctx, const double *dX, int64_t ldx, int64_t rows, const double *dnegY,
-                        double *dOut, int64_t ldo);
-int32_t dhqr_rs_fix_top_f64(dhqr_ctx *ctx, double *dVw, int64_t ldv, const double *dalpha128,
-                            const double *dnegMinv);
-int32_t dhqr_rs_write_r_f64(dhqr_ctx *ctx, double *dPtop, int64_t ldp, const double *dRref);
-int32_t dhqr_rs_commit_f64(dhqr_ctx *ctx, double *dP, int64_t ldp, int64_t rows, const double *dVw, int64_t ldv,
-                           int32_t diag_owner, const double *dRref);
-int32_t dhqr_rs_pack_f64(dhqr_ctx *ctx, const double *dP, int64_t ldp, int64_t rows, double *dVw, int64_t ldv,
-                         int32_t diag_owner);
-int32_t dhqr_rs_build_t_f64(dhqr_ctx *ctx, const double *dS, int32_t ncols, double *dT, double *dTt);
-int32_t dhqr_rs_vtc_f64(dhqr_ctx *ctx, const double *dV, int64_t ldv, const double *dC, int64_t ldc,
-                        int64_t rows, int64_t ncols, double *dW1);
-int32_t dhqr_rs_tw_f64(dhqr_ctx *ctx, const double *dTop, const double *dW1, int64_t ncols, double *dW2);
-int32_t dhqr_rs_vw_f64(dhqr_ctx *ctx, const double *dV, int64_t ldv, const double *dW2, double *dC,
-                       int64_t ldc, int64_t rows, int64_t ncols);
+/* ------------------------------------------------------------------ multi-GPU: row split (BASELINE configs[4])
+ * Tall-skinny matrices with the ROWS distributed (the reference cannot: `@assert rowrange == 1:size(A,1)`, src:33;
+ * its per-column norm / partial dots, src:129,208, would need one cross-rank reduction per column).  SPMD and
+ * collective like the column split.  Layout: rank r holds the rows [row0, row0 + mloc) of dhqr_rs_row_range
+ * (128-row aligned slabs, so a panel's diagonal block lives on exactly one rank) as an mloc x n column-major
+ * block; alpha (n) replicated.  Per 128-column panel: all-reduce of the 128 x 128 Gram matrices, broadcast of the
+ * top-block result from the rank holding the diagonal rows, all-reduce of the V'C partial dots (128 x ncols) --
+ * the "RCCL all-reduce of the cross-partition partial dots".  Panels are verified on the device; a rejected or
+ * partial panel is redone column by column across the ranks (reference algorithm, one small all-reduce + broadcast
+ * per column).  Same factor format, distributed by rows.  Synchronous on return.
+ *   dhqr_rs_solve_f64: db = this rank's rows of b (overwritten), dx (n) <- x on every rank (src:215-254). */
+void dhqr_rs_row_range(int64_t m, int32_t nranks, int32_t rank, int64_t *row0, int64_t *mloc);
+int32_t dhqr_rs_fill_uniform_f64(dhqr_comm *comm, double *dA, int64_t m, int64_t n, int64_t lda, uint64_t seed);
+int32_t dhqr_rs_factor_f64(dhqr_comm *comm, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha);
+int32_t dhqr_rs_residual_f64(dhqr_comm *comm, const double *dA, int64_t m, int64_t n, int64_t lda,
+                             const double *dalpha, uint64_t seed, double *dB, double *dA0, double *hrel);
+int32_t dhqr_rs_solve_f64(dhqr_comm *comm, const double *dA, int64_t m, int64_t n, int64_t lda,
+                          const double *dalpha, double *db, double *dx);
+/* the same through the single-process handle (one host thread per device) */
+int32_t dhqr_mg_rs_alloc_f64(dhqr_mg *mg, int64_t m, int64_t n);
+int32_t dhqr_mg_rs_fill_uniform_f64(dhqr_mg *mg, uint64_t seed);
+int32_t dhqr_mg_rs_factor_f64(dhqr_mg *mg);
+int32_t dhqr_mg_rs_residual_f64(dhqr_mg *mg, uint64_t seed, double *hrel);
+int32_t dhqr_mg_rs_transfer_f64(dhqr_mg *mg, double *hA, int64_t lda, double *halpha, int32_t upload);
+int32_t dhqr_mg_rs_solve_f64(dhqr_mg *mg, const double *hb, double *hx);
 
 /* ------------------------------------------------------------------ micro-benchmarks
  * Device ceilings measured on the box itself (bench.py reports them next to the spec peaks):

@@ -212,69 +212,81 @@ def test_darray_layout_front_end(emulated_so, m, n, P):
     run_ranks(_darray, P, m, n, emulated_so)
 
 
-def _rowsplit_emulated(rank, P, m, n, so):
-    """RowSplitQR with the product's HipRowBackend marshalling and the dhqr_rs_* entry points of the emulated
-    library: Gram / Cholesky / replay / commit / V'C kernels under the real all-reduce orchestration"""
-    import importlib
-    import torch
-    import __graft_entry__ as g
-    from oracle import dhqr_oracle as orc
-    from dist_helpers import make_emu_row_backend
-    g.import_package()
-    rs = importlib.import_module("dhqr_amd.rowsplit")
-    q = rs.RowSplitQR(m, n, backend=make_emu_row_backend(so))
-    q.fill(81)
-    q.factor()
-    H, alpha = q.gather_full()
-    Ho, ao = orc.householder(orc.rand_matrix(m, n, 81))
+# ---------------------------------------------------------------- 3: row split (BASELINE configs[4]), emulated library
+# (ndev, m, n): diagonal blocks on several ranks (n > rows of rank 0); partial last panel; more ranks than row blocks
+@pytest.mark.parametrize("ndev,m,n", [(2, 1024, 384), (3, 1200, 300), (4, 500, 200)])
+def test_row_split_rank_threads_vs_oracle(emu, orc, ndev, m, n):
+    h = _mg(emu, ndev)
+    assert emu.dhqr_mg_rs_alloc_f64(h, m, n) == 0, emu.dhqr_last_error()
+    assert emu.dhqr_mg_rs_fill_uniform_f64(h, 31) == 0
+    A0 = orc.rand_matrix(m, n, 31)
+    G = np.zeros((m, n), order="F")
+    assert emu.dhqr_mg_rs_transfer_f64(h, _ptr(G), m, None, 0) == 0
+    assert np.array_equal(G, A0)  # the device generator with the row offset of every slab
+    assert emu.dhqr_mg_rs_factor_f64(h) == 0, emu.dhqr_last_error()
+    H, al = np.zeros((m, n), order="F"), np.zeros(n)
+    assert emu.dhqr_mg_rs_transfer_f64(h, _ptr(H), m, _ptr(al), 0) == 0
+    Ho, ao = orc.householder(A0)
     scale = np.abs(Ho).max()
-    assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
-    assert np.abs(alpha - ao).max() <= 1e-11 * scale
-    assert q.residual(81) < 1e-13
-    b = orc.rand_vector(m, 82)
-    x = q.solve(torch.from_numpy(b[q.row0: q.row0 + q.mloc].copy())).numpy()
+    assert np.abs(H - Ho).max() <= 1e-12 * scale, np.abs(H - Ho).max()
+    assert np.abs(al - ao).max() <= 1e-12 * scale
+    rel = ctypes.c_double()
+    assert emu.dhqr_mg_rs_residual_f64(h, 31, ctypes.byref(rel)) == 0, emu.dhqr_last_error()
+    assert rel.value < 1e-14
+    b, x = orc.rand_vector(m, 32), np.zeros(n)
+    assert emu.dhqr_mg_rs_solve_f64(h, _ptr(b), _ptr(x)) == 0, emu.dhqr_last_error()
     xo = orc.solve(Ho, ao, b)
-    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    assert emu.dhqr_mg_destroy(h) == 0
+
+
+def test_row_split_rejected_panel_is_redone_column_by_column(emu, orc):
+    """two nearly dependent columns inside the second panel: every rank takes the same device-side decision, later
+    updates become no-ops, the panel is redone with the cross-rank column-by-column kernels, the run continues"""
+    h = _mg(emu, 2)
+    m, n = 1024, 384
+    A0 = orc.rand_matrix(m, n, 22)
+    A0[:, 200] = A0[:, 199] * (1.0 + 1e-9)
+    assert emu.dhqr_mg_rs_alloc_f64(h, m, n) == 0
+    assert emu.dhqr_mg_rs_transfer_f64(h, _ptr(np.asfortranarray(A0)), m, None, 1) == 0
+    assert emu.dhqr_mg_rs_factor_f64(h) == 0, emu.dhqr_last_error()
+    H, al = np.zeros((m, n), order="F"), np.zeros(n)
+    assert emu.dhqr_mg_rs_transfer_f64(h, _ptr(H), m, _ptr(al), 0) == 0
+    QR = orc.form_qr(np.asfortranarray(H), al)
+    assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-13
+    st = emu.Stats()
+    a_, b_ = ctypes.c_int64(), ctypes.c_int64()
+    assert emu.dhqr_mg_get_stats(h, 0, ctypes.byref(st), ctypes.byref(a_), ctypes.byref(b_), None) == 0
+    assert b_.value >= 1
+    assert emu.dhqr_mg_destroy(h) == 0
+
+
+def _rs_gloo(rank, P, m, n, so):
+    """dhqr_rs_* under gloo processes with the callback transport (what a Julia worker per GPU binds)"""
+    import importlib
+    from dist_helpers import emulated_rank
+    from oracle import dhqr_oracle as orc
+    L, h, comm, D = emulated_rank(so, P, rank)
+    RS = importlib.import_module("dhqr_amd.rowsplit")
+    q = RS.RowSplitQR(m, n, comm=comm, mem=D._HostMem())
+    q.fill(81)
+    A = orc.rand_matrix(m, n, 81)
+    loc, _ = q.local_numpy()
+    assert np.array_equal(loc, A[q.row0: q.row0 + q.mloc])
+    q.factor()
+    loc, alpha = q.local_numpy()
+    Ho, ao = orc.householder(A)
+    scale = np.abs(Ho).max()
+    assert np.abs(loc - Ho[q.row0: q.row0 + q.mloc]).max() <= 1e-12 * scale
+    assert np.abs(alpha - ao).max() <= 1e-12 * scale
+    assert q.residual(81) < 1e-14
+    b = orc.rand_vector(m, 82)
+    x = q.solve(b[q.row0: q.row0 + q.mloc])
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
     return True
 
 
-@pytest.mark.parametrize("m,n,P", [(1200, 256, 2)])
-def test_row_split_with_the_emulated_library(emulated_so, m, n, P):
-    run_ranks(_rowsplit_emulated, P, m, n, emulated_so)
-
-
-def _rowsplit(rank, P, m, n):
-    import importlib
-    import __graft_entry__ as g
-    from oracle import dhqr_oracle as orc
-    from dist_helpers import NumpyRowBackend
-    pkg = g.import_package()
-    rs = importlib.import_module("dhqr_amd.rowsplit")
-    q = rs.RowSplitQR(m, n, backend=NumpyRowBackend())
-    q.fill(31)
-    q.factor()
-    H, alpha = q.gather_full()
-    Ho, ao = orc.householder(orc.rand_matrix(m, n, 31))
-    scale = np.abs(Ho).max()
-    assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
-    assert np.abs(alpha - ao).max() <= 1e-11 * scale
-    res = q.residual(31)
-    assert res < 1e-13, res
-    import torch
-    b = orc.rand_vector(m, 32)
-    x = q.solve(torch.from_numpy(b[q.row0: q.row0 + q.mloc].copy())).numpy()
-    xo = orc.solve(Ho, ao, b)
-    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
-    return res
-
-
-@pytest.mark.parametrize("m,n,P", [(2048, 256, 2), (3000, 384, 3), (1024, 128, 2), (1536, 512, 1)])
-def test_row_split_orchestration(m, n, P):
-    """BASELINE configs[4] structure (rows split over ranks, all-reduce of Gram matrices and of the
-    V'C partial dots) with the numpy backend under gloo, against the single-process oracle."""
-    if P == 1:
-        import torch.distributed as dist
-        assert not dist.is_initialized()
-        _rowsplit(0, 1, m, n)
-    else:
-        run_ranks(_rowsplit, P, m, n)
+@pytest.mark.parametrize("m,n,P", [(1200, 256, 2), (900, 300, 3)])
+def test_row_split_processes_with_callback_transport(emulated_so, m, n, P):
+    run_ranks(_rs_gloo, P, m, n, emulated_so)

@@ -323,55 +323,66 @@ def test_robustness_across_input_classes(pkg, kind):
     assert res < 1e-12
 
 
-@pytest.mark.parametrize("m,n", [(20000, 512), (8192, 1024), (4097, 256)])
+@pytest.mark.parametrize("m,n", [(20000, 512), (8192, 1024), (4097, 300)])
 def test_row_split_driver_single_rank(pkg, orc, m, n):
-    """BASELINE configs[4] path (rows split over ranks) with the product backend at world size 1."""
+    """BASELINE configs[4] path (dhqr_rs_*, rows split over the ranks) at world size 1, incl. a partial last panel."""
+    import torch
     q = pkg.RowSplitQR(m, n)
     q.fill(41)
     q.factor()
-    H, alpha = q.gather_full()
+    H, alpha = q.local_numpy()
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 41))
     scale = np.abs(Ho).max()
     assert np.abs(H - Ho).max() <= 1e-11 * scale
     assert np.abs(alpha - ao).max() <= 1e-11 * scale
     assert q.residual(41) < 1e-12
-    assert q.stats["panels"] == n // 128
-    import torch
     b = orc.rand_vector(m, 42)
     x = q.solve(torch.tensor(b, device="cuda:0")).cpu().numpy()
     xo = orc.solve(Ho, ao, b)
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
 
 
-def _two_rank_rowsplit(rank, P, m, n):
-    import torch
-    import __graft_entry__ as g
-    from oracle import dhqr_oracle as orc
-    torch.cuda.set_device(0)
-    pkg = g.import_package()
-    q = pkg.RowSplitQR(m, n)
-    q.fill(43)
-    q.factor()
-    torch.cuda.synchronize()
-    H, alpha = q.gather_full()
-    Ho, ao = orc.householder(orc.rand_matrix(m, n, 43))
-    scale = np.abs(Ho).max()
-    assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
-    assert np.abs(alpha - ao).max() <= 1e-11 * scale
-    res = q.residual(43)
-    assert res < 1e-12, res
-    b = orc.rand_vector(m, 44)
-    x = q.solve(torch.tensor(b[q.row0: q.row0 + q.mloc], device="cuda:0")).cpu().numpy()
-    xo = orc.solve(Ho, ao, b)
-    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
-    return res
+@pytest.mark.parametrize("ranks,m,n", [(2, 6000, 512), (2, 16384, 1024), (8, 16384, 2048), (3, 3000, 1100)])
+def test_row_split_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
+    """dhqr_mg_rs_* with `ranks` rank threads on cuda:0 (in-process transport): diagonal blocks move from rank to
+    rank when n exceeds a rank's rows ((8, 16384, 2048): 2048 rows per rank), partial last panel ((3, 3000, 1100))"""
+    mg = pkg.MultiGpuQR(devices=[0] * ranks)
+    try:
+        mg.rs_alloc(m, n).rs_fill(43)
+        A0, _ = mg.rs_download()
+        Ah = orc.rand_matrix(m, n, 43)
+        assert np.array_equal(A0, Ah)
+        mg.rs_factor()
+        H, alpha = mg.rs_download()
+        Ho, ao = orc.householder(Ah)
+        scale = np.abs(Ho).max()
+        assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
+        assert np.abs(alpha - ao).max() <= 1e-11 * scale
+        assert mg.rs_residual(43) < 1e-12
+        b = orc.rand_vector(m, 44)
+        x = mg.rs_solve(b)
+        xo = orc.solve(Ho, ao, b)
+        assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+        assert sum(mg.stats(r)["panels_fallback"] for r in range(ranks)) == 0
+    finally:
+        mg.close()
 
 
-@pytest.mark.parametrize("m,n", [(6000, 512), (16384, 1024)])
-def test_row_split_driver_two_ranks_one_gpu(m, n):
-    """two processes share cuda:0; gloo all-reduces the Gram matrices and the V'C partial dots"""
-    from dist_helpers import run_ranks
-    run_ranks(_two_rank_rowsplit, 2, m, n)
+def test_row_split_rejected_panel_gpu(pkg, orc):
+    """a numerically rank-deficient panel: the fast path is refused on every rank (same all-reduced S), the panel is
+    redone column by column across the ranks instead of raising (round-1 behaviour)"""
+    m, n = 8192, 512
+    A0 = orc.rand_matrix(m, n, 22)
+    A0[:, 300] = A0[:, 299] * (1.0 + 1e-9)
+    mg = pkg.MultiGpuQR(devices=[0, 0])
+    try:
+        mg.rs_alloc(m, n).rs_upload(A0).rs_factor()
+        H, al = mg.rs_download()
+        QR = orc.form_qr(np.asfortranarray(H), al)
+        assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-13
+        assert mg.stats(0)["panels_fallback"] >= 1
+    finally:
+        mg.close()
 
 
 @pytest.mark.parametrize("m,n", [(300, 128), (1000, 333)])
