@@ -10,6 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libdhqr.so")
 CSRC = os.path.join(_PKG, "csrc")
 NB = 128  # DHQR_NB
+ZNB = 64  # DHQR_ZNB: complex reflectors per panel of the blocked ComplexF64 path
 
 OK, EINVAL, EHIP, ENOMEM, ENODEVICE, ECOMM = 0, -1, -2, -3, -4, -5
 COMM_SELF, COMM_RCCL, COMM_LOCAL, COMM_CALLBACK = 0, 1, 2, 3
@@ -78,6 +79,8 @@ SIGNATURES = {
     "dhqr_partialdot_host_f64": (_i32, [_p, _p, _p, _i64, _i64, _pd]),
     "dhqr_factor_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
     "dhqr_qr_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
+    "dhqr_factor_c64_nb": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32]),
+    "dhqr_qr_c64_nb": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32]),
     "dhqr_solve_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "dhqr_ldiv_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "dhqr_partialdot_c64": (_i32, [_p, _p, _p, _i64, _i64, _pd]),

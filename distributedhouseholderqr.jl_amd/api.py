@@ -113,12 +113,14 @@ def _host_ld(F) -> int:
 
 
 def _resolve_nb(A, nb):
-    """nb=None: the default of the element type (128 blocked for Float64, 0 unblocked for ComplexF64)"""
+    """nb=None: the default of the element type (128 blocked for Float64; ComplexF64: 64 blocked -- the trailing
+    update runs on the FP64 MFMA kernels through the real embedding -- for n >= 256, unblocked below)"""
     if _is_complex(A):
-        if nb not in (None, 0):
-            raise ValueError("ComplexF64 runs the unblocked path only (nb=None or 0); a blocked complex "
-                             "MFMA path is not built yet")
-        return 0
+        if nb not in (None, 0, _lib.ZNB):
+            raise ValueError(f"ComplexF64: nb must be None, 0 (unblocked) or {_lib.ZNB} (blocked)")
+        if nb is None:
+            return _lib.ZNB if A.shape[1] >= 256 else 0
+        return nb
     return NB if nb is None else nb
 
 
@@ -206,21 +208,21 @@ class DistributedHouseholderQRStruct:
         return f"DistributedHouseholderQRStruct(A={tuple(self.A.shape)}, α={tuple(self.α.shape)})"
 
 
-def _householder_c64(A, α):
-    """ComplexF64 method of householder! (src:9, 51-59, 122-148, 171-213): unblocked HIP path."""
+def _householder_c64(A, α, nb=0):
+    """ComplexF64 method of householder! (src:9, 51-59, 122-148, 171-213): nb = 0 unblocked, 64 blocked."""
     L = _lib.lib()
     if _is_tensor(A):
         ptr, m, n, lda, dev = _dev_matrix(A, torch.complex128)
         ctx = get_context(dev)
         ctx.use_torch_stream()
-        check(L.dhqr_factor_c64(ctx.handle, ptr, m, n, lda, _dev_vector(α, n, torch.complex128)))
+        check(L.dhqr_factor_c64_nb(ctx.handle, ptr, m, n, lda, _dev_vector(α, n, torch.complex128), nb))
         return A, α
     if not isinstance(α, np.ndarray) or α.dtype != np.complex128 or α.size < A.shape[1] or not α.flags.c_contiguous:
         raise TypeError("α must be a contiguous complex128 numpy vector of length n")
     m, n = A.shape
     F = A if A.flags.f_contiguous else np.asfortranarray(A)
-    check(L.dhqr_qr_c64(get_context().handle, F.ctypes.data_as(ctypes.c_void_p), m, n,
-                        _host_ld(F), α.ctypes.data_as(ctypes.c_void_p)))
+    check(L.dhqr_qr_c64_nb(get_context().handle, F.ctypes.data_as(ctypes.c_void_p), m, n,
+                           _host_ld(F), α.ctypes.data_as(ctypes.c_void_p), nb))
     if F is not A:
         A[...] = F
     return A, α
@@ -233,7 +235,7 @@ def householder_(A, α, nb: Optional[int] = None):
     L = _lib.lib()
     nb = _resolve_nb(A, nb)
     if _is_complex(A):
-        return _householder_c64(A, α)
+        return _householder_c64(A, α, nb)
     if _is_tensor(A):
         ptr, m, n, lda, dev = _dev_matrix(A)
         ctx = get_context(dev)

@@ -1122,6 +1122,69 @@ int32_t dhqr_factor_c64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t l
   return DHQR_OK;
 }
 
+// Blocked ComplexF64 factorisation: panels of DHQR_ZNB = 64 complex columns are factored by the unblocked complex
+// kernels, their block reflector is applied to the trailing matrix by the Float64 MFMA kernels through the real
+// embedding (dhqr_complex.h).  nb = 0: unblocked (dhqr_factor_c64), nb = 64: blocked.
+int32_t dhqr_factor_c64_nb(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha, int32_t nb) {
+  if (nb == 0) return dhqr_factor_c64(c, dA, m, n, lda, dalpha);
+  ENTER(c);
+  if (no_columns(m, n)) return DHQR_OK;
+  if (nb != DHQR_ZNB) return set_err(DHQR_EINVAL, "ComplexF64: nb must be 0 (unblocked) or %d (blocked); got %d", DHQR_ZNB, nb);
+  CHECK(check_mat(dA, m, n, lda, true));
+  CHECK(check_zptr(dA, "matrix"));
+  CHECK(check_zptr(dalpha, "alpha"));
+  const int64_t ZB = DHQR_ZNB;
+  CHECK(ensure(c, c->vt, (size_t)panel_elems(2 * m)));
+  for (int64_t c0 = 0; c0 < n; c0 += ZB) {
+    const int64_t w = std::min<int64_t>(ZB, n - c0), rows = m - c0;
+    double *P = dA + 2 * (c0 + c0 * lda);
+    CHECK(dhqr_factor_c64(c, P, rows, w, lda, dalpha + 2 * c0));  // src:122-148,171-213 inside the panel
+    const int64_t ncols = n - c0 - w;
+    if (ncols <= 0) break;
+    const PanelBuf pb = vt_view(c->vt.p, 2 * rows);
+    const int64_t npad = panel_ldv(2 * rows);
+    CHECK(prof_begin(c, CAT_TBUILD));
+    {
+      dim3 grid((unsigned)std::min<int64_t>((npad / 2 + 255) / 256, 64), (unsigned)ZB);
+      hipLaunchKernelGGL(k_zpack_emb, grid, dim3(256), 0, c->stream, reinterpret_cast<const double2 *>(P), lda, rows, (int)w,
+                         pb.V, pb.ldv, npad);
+    }
+    CHECK(panel_build_t(c, 2 * rows, -2 * w, pb));  // negative: strict upper part at the 2 x 2 block level
+    CHECK(prof_end(c));
+    CHECK(panel_apply(c, pb, 2 * rows, dA + 2 * (c0 + (c0 + w) * lda), ncols, 2 * lda, 1));
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+int32_t dhqr_qr_c64_nb(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha, int32_t nb) {
+  ENTER(c);
+  if (no_columns(m, n)) return DHQR_OK;
+  CHECK(check_mat(hA, m, n, lda, true));
+  if (!halpha) return set_err(DHQR_EINVAL, "null alpha pointer");
+  double *dA = nullptr, *dal = nullptr;
+  const size_t esz = 2 * sizeof(double);
+  if (hipMalloc((void **)&dA, (size_t)m * n * esz) != hipSuccess)
+    return set_err(DHQR_ENOMEM, "hipMalloc of the %lld x %lld complex matrix failed", (long long)m, (long long)n);
+  if (hipMalloc((void **)&dal, (size_t)n * esz) != hipSuccess) {
+    (void)hipFree(dA);
+    return set_err(DHQR_ENOMEM, "hipMalloc of alpha failed");
+  }
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMemcpy2DAsync(dA, m * esz, hA, lda * esz, m * esz, n, hipMemcpyHostToDevice, c->stream));
+    CHECK(dhqr_factor_c64_nb(c, dA, m, n, m, dal, nb));
+    HIPCHECK(hipMemcpy2DAsync(hA, lda * esz, dA, m * esz, m * esz, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(halpha, dal, n * esz, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(dA);
+  (void)hipFree(dal);
+  return rc;
+}
+
 int32_t dhqr_qr_c64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha) {
   ENTER(c);
   if (no_columns(m, n)) return DHQR_OK;

@@ -206,3 +206,28 @@ __global__ __launch_bounds__(256) void k_zpartialdot_partial(const double2 *__re
     part[2 * blockIdx.x + 1] = s.y;
   }
 }
+
+
+// ---- blocked ComplexF64 update through the real embedding -------------------------------------------------
+// A complex m x n matrix in interleaved storage IS a real (2m) x n matrix (rows Re a_0, Im a_0, Re a_1, ...).  For a
+// block of k complex reflectors V (H_1 ... H_k = I - V T V^H) the real 2 x 2 embedding
+//     Vemb[2i  ][2p] = Re v_ip   Vemb[2i  ][2p+1] = -Im v_ip
+//     Vemb[2i+1][2p] = Im v_ip   Vemb[2i+1][2p+1] =  Re v_ip
+// turns  C -= V (T^H (V^H C))  into the REAL block-reflector update  C_r -= Vemb (Temb' (Vemb' C_r))  with the same flop
+// count (8 real flop per complex multiply-add, no redundancy: only the [Re; Im] column of the embedding of C is
+// carried).  With k = 64 complex reflectors Vemb has 128 real columns: the FP64 MFMA kernels of the Float64 path
+// (dhqr_gemm.h) run the ComplexF64 trailing update unchanged.  Temb = (I + blockstriu(Vemb' Vemb))^{-1} (k_build_t with
+// ncols < 0).  Replaces the complex hotloop!/partialdot of src:51-59,171-196 for 64 reflectors at a time.
+#define DHQR_ZNB 64  // complex reflectors per panel of the blocked ComplexF64 path
+__global__ __launch_bounds__(256) void k_zpack_emb(const double2 *__restrict__ P, int64_t ldp, int64_t rows, int w,
+                                                   double *__restrict__ Vemb, int64_t ldv, int64_t npad) {
+  const int p = blockIdx.y;  // complex column of the panel (0 .. 63)
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; 2 * i < npad; i += stride) {
+    double2 v = make_double2(0.0, 0.0);
+    if (p < w && i >= p && i < rows) v = P[i + (int64_t)p * ldp];  // rows above the diagonal hold R
+    double *c0 = Vemb + (int64_t)(2 * p) * ldv + 2 * i, *c1 = c0 + ldv;
+    *reinterpret_cast<double2 *>(c0) = make_double2(v.x, v.y);     // column 2p  : ( Re, Im)
+    *reinterpret_cast<double2 *>(c1) = make_double2(-v.y, v.x);    // column 2p+1: (-Im, Re)
+  }
+}

@@ -190,8 +190,13 @@ struct rc5_lds {
   double T1[64][RC5_LDH];       // B * C^{-1} staging
   double dinv[RC_N];
 };
+// ncols < 0: real embedding of -ncols/2 complex reflectors (dhqr_complex.h): the strict upper part is taken at the
+// level of the 2 x 2 blocks [[Re, -Im], [Im, Re]] -- the (2p, 2p+1) entry of a diagonal block is the imaginary part of
+// ||v_p||^2 (zero up to rounding) and does not belong to striu(V^H V).
 __device__ __forceinline__ double rc5_in(const double *__restrict__ Mg, int i, int k, int ncols) {
-  return (i < k && k < ncols) ? Mg[i + k * RC_N] : 0.0;
+  const bool upper = (ncols < 0) ? ((i >> 1) < (k >> 1)) : (i < k);
+  const int nc = ncols < 0 ? -ncols : ncols;
+  return (upper && k < nc) ? Mg[i + k * RC_N] : 0.0;
 }
 __device__ __forceinline__ void rc_upper_inverse_blocked(const double *__restrict__ Mg, int ncols, bool unit,
                                                          rc5_lds &L, double (&x12)[4]) {

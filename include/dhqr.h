@@ -161,7 +161,15 @@ int32_t dhqr_partialdot_host_f64(dhqr_ctx *ctx, const double *ha, const double *
  * dhqr_partialdot_c64 / _host_c64
  *                   partialdot(a, b, lo:hi, ComplexF64) = sum conj(a[i]) b[i] (src:51-59) -- the
  *                   function the reference's only known-answer test exercises
- *                   (test/partialdot.jl:12-20); hout[0] = re, hout[1] = im. Synchronous. */
+ *                   (test/partialdot.jl:12-20); hout[0] = re, hout[1] = im. Synchronous.
+ *
+ * dhqr_factor_c64_nb / dhqr_qr_c64_nb: the same with a panel width: nb = 0 unblocked, nb = DHQR_ZNB (64 complex columns)
+ *                   BLOCKED: the panel's block reflector I - V T V^H is applied to the trailing matrix by the Float64
+ *                   MFMA kernels through the real 2 x 2 embedding of the 64 complex reflectors (= 128 real columns);
+ *                   identical factor format and values (to rounding). */
+#define DHQR_ZNB 64
+int32_t dhqr_factor_c64_nb(dhqr_ctx *ctx, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha, int32_t nb);
+int32_t dhqr_qr_c64_nb(dhqr_ctx *ctx, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha, int32_t nb);
 int32_t dhqr_factor_c64(dhqr_ctx *ctx, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha);
 int32_t dhqr_qr_c64(dhqr_ctx *ctx, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha);
 int32_t dhqr_solve_c64(dhqr_ctx *ctx, const double *dA, int64_t m, int64_t n, int64_t lda,

@@ -182,6 +182,24 @@ def test_complex_entry_points(emu, orc):
     emu.dhqr_destroy(h)
 
 
+def test_complex_blocked_through_the_real_embedding(emu, orc):
+    """dhqr_factor_c64_nb(nb = 64): panels by the unblocked complex kernels, trailing update by the Float64 MFMA kernels
+    on the real embedding of the 64 complex reflectors; last panel partial (8 columns).  Same factorisation."""
+    h = _ctx(emu)
+    m, n = 300, 200
+    A0 = orc.rand_matrix_c(m, n, 18)
+    A = A0.copy(order="F")
+    al = np.zeros(n, dtype=complex)
+    assert emu.dhqr_factor_c64_nb(h, _ptr(A), m, n, m, _ptr(al), 64) == 0, emu.dhqr_last_error()
+    Ho, ao = orc.householder_c(A0)
+    assert np.abs(A - Ho).max() <= 1e-12 * np.abs(Ho).max() and np.abs(al - ao).max() <= 1e-12 * np.abs(Ho).max()
+    A2, al2 = A0.copy(order="F"), np.zeros(n, dtype=complex)
+    assert emu.dhqr_qr_c64_nb(h, _ptr(A2), m, n, m, _ptr(al2), 64) == 0
+    assert np.array_equal(A2, A) and np.array_equal(al2, al)
+    assert emu.dhqr_factor_c64_nb(h, _ptr(A2), m, n, m, _ptr(al2), 32) == -1  # unsupported width
+    emu.dhqr_destroy(h)
+
+
 def test_argument_validation_and_empty_matrix(emu):
     h = _ctx(emu)
     A = np.zeros((4, 8), order="F")

@@ -113,6 +113,48 @@ def test_reference_acceptance_inequality_complex(pkg, orc, m, n):
         assert np.abs(v2 - 2.0).max() < 1e-12
 
 
+@pytest.mark.parametrize("m,n", [(300, 200), (1100, 1000), (2100, 2048), (5000, 130)])
+def test_blocked_complex_vs_oracle_and_unblocked(pkg, orc, m, n):
+    """nb = 64: panels by the unblocked complex kernels, trailing update by the FP64 MFMA kernels on the real embedding of
+    the 64 complex reflectors (dhqr_factor_c64_nb): the reference's factorisation, element by element"""
+    import torch
+    A = pkg.rand_colmajor_c(m, n, 3, "cuda:0")
+    A0 = A.cpu().numpy().copy()
+    H = pkg.qr_(A, nb=64)
+    torch.cuda.synchronize()
+    Hd, ad = H.A.cpu().numpy(), H.α.cpu().numpy()
+    if n <= 1000:
+        Ho, ao = orc.householder_c(A0)
+    else:  # the device's own unblocked path (itself oracle-checked above) as the comparator at larger sizes
+        A2 = pkg.rand_colmajor_c(m, n, 3, "cuda:0")
+        H2 = pkg.qr_(A2, nb=0)
+        torch.cuda.synchronize()
+        Ho, ao = H2.A.cpu().numpy(), H2.α.cpu().numpy()
+    scale = np.abs(Ho).max()
+    assert np.abs(Hd - Ho).max() <= 1e-11 * scale, np.abs(Hd - Ho).max() / scale
+    assert np.abs(ad - ao).max() <= 1e-11 * scale
+    QR = orc.form_qr_c(np.asfortranarray(Hd), ad)
+    assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-12
+    b = torch.from_numpy(orc.rand_vector_c(m, 4)).cuda()
+    x = pkg.ldiv(H, b).cpu().numpy()
+    xr = np.linalg.lstsq(A0, b.cpu().numpy(), rcond=None)[0]
+    assert np.abs(x - xr).max() <= 1e-8 * np.abs(xr).max()
+
+
+@pytest.mark.parametrize("m,n", REF_SHAPES)
+def test_reference_acceptance_inequality_complex_blocked(pkg, orc, m, n):
+    """test/runtests.jl:42-63 with T = ComplexF64 through the BLOCKED path (host drop-in, nb = 64)"""
+    A = orc.rand_matrix_c(m, n, 0)
+    b = orc.rand_vector_c(m, 1)
+    q, r = np.linalg.qr(A)
+    x1 = sl.solve_triangular(r, q.conj().T @ b)
+    Ah = A.conj().T
+    stdliberr = np.linalg.norm(Ah @ (A @ x1) - Ah @ b)
+    H = pkg.qr_(A.copy(order="F"), nb=64)
+    x2 = pkg.ldiv(H, b)
+    assert np.linalg.norm(Ah @ (A @ x2) - Ah @ b) < 8 * stdliberr
+
+
 def test_zero_pivot_complex(pkg, orc):
     # angle(0) == 0 => alpha = -||a|| and a proper reflection (src:9); the Real method gives alpha = 0
     A = np.asfortranarray(np.array([[0.0, 1.0], [3.0j, 2.0], [4.0, 5.0j]], dtype=complex))
@@ -126,6 +168,6 @@ def test_zero_pivot_complex(pkg, orc):
 def test_complex_argument_errors(pkg):
     A = np.asfortranarray(np.ones((8, 4), dtype=complex))
     with pytest.raises(ValueError):
-        pkg.qr_(A, nb=128)  # no blocked ComplexF64 path
+        pkg.qr_(A, nb=128)  # ComplexF64 panels are 64 wide (128 real columns)
     with pytest.raises(pkg.DHQRError):
         pkg.qr_(np.asfortranarray(np.ones((3, 5), dtype=complex)))  # m < n

@@ -1,4 +1,4 @@
-"""Timing of the ComplexF64 unblocked path on one GPU: n x n device-resident factorisation,
+"""Timing of the ComplexF64 paths (argv: n [nb = 0 | 64]) on one GPU: n x n device-resident factorisation,
 algorithmic HBM rate = 32 B per trailing element per reflector.  Prints one JSON line."""
 import json
 import os
@@ -12,8 +12,9 @@ import __graft_entry__ as g  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    nb = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # 0 unblocked, 64 blocked (real-embedding MFMA update)
     pkg = g.import_package()
-    out = {"n": n}
+    out = {"n": n, "nb": nb}
     times = []
     for it in range(2):
         A = pkg.rand_colmajor_c(n, n, 0, "cuda:0")
@@ -21,7 +22,7 @@ def main():
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        pkg.householder_(A, alpha)
+        pkg.householder_(A, alpha, nb=nb)
         e1.record()
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1))
