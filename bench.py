@@ -80,6 +80,24 @@ def cpu_baseline(m, n, budget_s=20.0):
     }
 
 
+def cpu_baseline_distributed(procs=2, orders=(512, 2048, 4096), timeout_s=120):
+    """The reference's Distributed.jl STRUCTURE on the host cores (BASELINE configs[0]: 512 x 512, nprocs = 2, and larger
+    orders): oracle/dist_oracle.py run as `procs` gloo processes x (cores / procs) OpenMP threads -- contiguous column
+    blocks, one broadcast of the dense column per reflector (src:115-148).  Julia itself is not installed."""
+    import subprocess
+    cores = os.cpu_count() or 2
+    env = dict(os.environ, OMP_NUM_THREADS=str(max(1, min(64, cores // procs))))
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={procs}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "oracle", "dist_bench.py")] + [str(n) for n in orders]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("[{")][-1]
+        return json.loads(line)
+    except Exception as e:  # a reported baseline, never fatal
+        return {"error": repr(e)[:200]}
+
+
 def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd):
     """BASELINE configs[4]: 262144 x 4096 Float64, rows split over the ranks (dhqr_rs_* / dhqr_mg_rs_*)."""
     m = args.m or 262144
@@ -394,6 +412,7 @@ def main():
             del A
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(m, n)
+            out["cpu_baseline"]["distributed_structure"] = cpu_baseline_distributed()
             out["host_cores"] = os.cpu_count()
     emit(out, rank)
     if mg is not None:
