@@ -17,14 +17,15 @@
 // (16 accumulators x 4 doubles = 128 VGPRs), K-tile 16, operands staged global -> registers ->
 // LDS (double buffered, one barrier per K-tile, next tile's global loads in flight during the
 // 64 MFMAs of the current one).  LDS strides are chosen so the fragment reads (ds_read_b64,
-// 64-bank) are conflict free: 18 doubles (36 dwords) for k-contiguous tiles, 144 doubles for the
-// row-contiguous V tile.
+// 64-bank) are conflict free: 18 doubles (36 dwords) for k-contiguous tiles, 130 doubles for the
+// row-contiguous V tile of k_gemm_nn_sub (read with ds_read_b128).
 #pragma once
 #include "dhqr_common.h"
+#include <type_traits>
 
 #define G_KT 16          // K-tile depth
 #define G_LDK 18         // LDS stride (doubles) of a k-contiguous tile column
-#define G_LDR 144        // LDS stride (doubles) of a row-contiguous 128-row tile column
+#define G_LDR 130        // LDS stride (doubles) of a row-contiguous 128-row tile column (see k_gemm_nn_sub)
 
 __device__ __forceinline__ dhqr_d4 mfma_f64(double a, double b, dhqr_d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -280,15 +281,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn2(const double *__restrict__ V, 
     }
   };
 
-  if (nkt > 0) {
-    load_tile(0);
-    store_tile(0, 0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
-    __builtin_amdgcn_sched_barrier(0);
+  auto mma_tile = [&](int buf) {
     const double *cs = &Cs[buf][(wc * 64 + i16) * G_LDK + k4];
     const double *vs = &Vs[buf][(wp * 64 + i16) * G_LDK + k4];
 #pragma unroll
@@ -304,6 +297,17 @@ __global__ __launch_bounds__(512) void k_gemm_tn2(const double *__restrict__ V, 
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) acc[ci][pi] = mfma_f64(a[ci], b[pi], acc[ci][pi]);
     }
+  };
+  if (nkt > 0) {
+    load_tile(0);
+    store_tile(0, 0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tile(buf);
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nkt) store_tile(buf ^ 1, kt + 1);
     __syncthreads();
@@ -330,7 +334,10 @@ __global__ __launch_bounds__(512) void k_gemm_tn2(const double *__restrict__ V, 
 // INIT0: the accumulators start at zero instead of the C tile (C = -V*W, used for the panel's V = P*M^{-1}).
 // stat/epoch: device-side commit predicate of the asynchronous panel pipeline (dhqr_api.hip): the launch is a
 // no-op when a panel with index <= epoch failed its verification (stat[0] = index of the first failed panel).
-template <int VEC, int KW, bool INIT0 = false>
+// Phase clock of the TIME instantiation (micro-benchmark only): summed shader cycles of wave 0 per phase.
+__device__ unsigned long long g_nn_phase[8];
+
+template <int VEC, int KW, bool INIT0 = false, bool TIME = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict__ V, int64_t ldv,
                                                         const double *__restrict__ W, int64_t ldw,
                                                         double *__restrict__ C, int64_t ldc,
@@ -339,6 +346,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
   __shared__ __attribute__((aligned(16))) double Vs[2][G_KT * G_LDR];
   __shared__ __attribute__((aligned(16))) double Ws[2][128 * G_LDK];
   if (stat != nullptr && stat[0] <= epoch) return;  // uniform: every workgroup of the launch takes the same branch
+  long long tph[5] = {0, 0, 0, 0, 0};
+  if constexpr (TIME) tph[0] = clock64();
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int i16 = lane & 15, k4 = lane >> 4;
   const int wr = w & 1, wc = w >> 1;
@@ -411,71 +420,139 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
 
   load_tile(0);
 
-  // accumulators <- C tile.  lane (i16,k4), register g of tile (ci,ri) holds
-  // C[r0 + wr*64 + ri*16 + i16][c0 + wc*64 + ci*16 + k4 + 4g]
+  // accumulators <- C tile.  The 16 x 16 MFMA tile ri of a wave does NOT hold 16 consecutive rows: lane i16 of tile
+  // ri owns row 4*i16 + ri of the wave's 64 rows (the V fragments below are read with the same map), so the four tiles
+  // together give every lane FOUR CONSECUTIVE ROWS per column:  lane (i16,k4), register g of tile (ci,ri) holds
+  //     C[r0 + wr*64 + 4*i16 + ri][c0 + wc*64 + ci*16 + k4 + 4g].
+  // Interior tiles move C with 16-byte accesses (32 B per lane and column, 512 contiguous bytes per 16 lanes; half the
+  // memory instructions of the element-wise map) and have all 32 loads of a thread in flight at once.  Measured
+  // (phase clock, 32768^2): the C tile + first operand tile cost 37.9k of a tile's 170k cycles with the masked
+  // 8-byte loads.
+  const bool full = (VEC == 2) && nrv == 128 && ncv == 128;
   dhqr_d4 acc[4][4];
+  if (INIT0) {
 #pragma unroll
-  for (int ci = 0; ci < 4; ++ci)
+    for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
-      const bool cok = cl < ncv;
-      const uint32_t co = (uint32_t)((cok ? cl : 0) * ldc);
+      for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+  } else if (full) {
 #pragma unroll
-      for (int ri = 0; ri < 4; ++ri) {
-        const int rl = wr * 64 + ri * 16 + i16;
-        const bool ok = cok && rl < nrv;
-        if constexpr (INIT0) {
-          acc[ci][ri][g] = 0.0;
-        } else {
-          const double x = Cb[co + (uint32_t)(rl < nrv ? rl : 0)];
-          acc[ci][ri][g] = ok ? x : 0.0;
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const double *cp = Cb + ((uint32_t)((wc * 64 + ci * 16 + k4 + 4 * g) * ldc) + (uint32_t)(wr * 64 + 4 * i16));
+        const double2 x0 = *reinterpret_cast<const double2 *>(cp), x1 = *reinterpret_cast<const double2 *>(cp + 2);
+        acc[ci][0][g] = x0.x;
+        acc[ci][1][g] = x0.y;
+        acc[ci][2][g] = x1.x;
+        acc[ci][3][g] = x1.y;
+      }
+  } else {  // edge tiles / unaligned operands: clamped addresses, all loads issued before the first mask is applied
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
+        const uint32_t co = (uint32_t)((cl < ncv ? cl : 0) * ldc);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+          const int rl = wr * 64 + 4 * i16 + ri;
+          acc[ci][ri][g] = Cb[co + (uint32_t)(rl < nrv ? rl : 0)];
         }
       }
-    }
+    if constexpr (VEC == 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const bool cok = wc * 64 + ci * 16 + k4 + 4 * g < ncv;
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri)
+          if (!(cok && wr * 64 + 4 * i16 + ri < nrv)) acc[ci][ri][g] = 0.0;
+      }
+  }
 
   store_tile(0);
   __syncthreads();
+  if constexpr (TIME) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the C tile has arrived
+    tph[1] = clock64();
+  }
   constexpr int NKT = KW / G_KT;
-#pragma unroll 1
-  for (int kt = 0; kt < NKT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < NKT) load_tile(kt + 1);
-    __builtin_amdgcn_sched_barrier(0);
+  auto mma_tile = [&](int buf) {
     const double *ws = &Ws[buf][(wc * 64 + i16) * G_LDK + k4];
-    const double *vs = &Vs[buf][k4 * G_LDR + wr * 64 + i16];
+    const double *vs = &Vs[buf][k4 * G_LDR + wr * 64 + 4 * i16];  // rows 4*i16 .. 4*i16+3: the four b fragments
 #pragma unroll
     for (int kk = 0; kk < G_KT / 4; ++kk) {
       double a[4], b[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        a[x] = ws[x * 16 * G_LDK + kk * 4];
-        b[x] = vs[kk * 4 * G_LDR + x * 16];
-      }
+      for (int x = 0; x < 4; ++x) a[x] = ws[x * 16 * G_LDK + kk * 4];
+      // two ds_read_b128; stride 130 doubles puts the four k rows of a read 4 banks apart: conflict free
+      const double2 b01 = *reinterpret_cast<const double2 *>(vs + kk * 4 * G_LDR);
+      const double2 b23 = *reinterpret_cast<const double2 *>(vs + kk * 4 * G_LDR + 2);
+      b[0] = b01.x;
+      b[1] = b01.y;
+      b[2] = b23.x;
+      b[3] = b23.y;
 #pragma unroll
       for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = mfma_f64(a[ci], b[ri], acc[ci][ri]);
     }
+  };
+#pragma unroll 1
+  for (int kt = 0; kt < NKT - 1; ++kt) {
+    const int buf = kt & 1;
+    load_tile(kt + 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < NKT) store_tile(buf ^ 1);
+    mma_tile(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile(buf ^ 1);
     __syncthreads();
   }
 
+  {
+    mma_tile((NKT - 1) & 1);
+    if constexpr (TIME) {
+      __builtin_amdgcn_sched_barrier(0);
+      tph[2] = clock64();
+    }
+    if (full) {  // uniform branch: interior tiles store 16 bytes at a time, no masks
 #pragma unroll
-  for (int ci = 0; ci < 4; ++ci)
+      for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
-      if (cl < ncv) {
-        const uint32_t co = (uint32_t)(cl * ldc);
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) {
-          const int rl = wr * 64 + ri * 16 + i16;
-          if (rl < nrv) Cb[co + (uint32_t)rl] = acc[ci][ri][g];
+        for (int g = 0; g < 4; ++g) {
+          double *cp = Cb + ((uint32_t)((wc * 64 + ci * 16 + k4 + 4 * g) * ldc) + (uint32_t)(wr * 64 + 4 * i16));
+          *reinterpret_cast<double2 *>(cp) = make_double2(acc[ci][0][g], acc[ci][1][g]);
+          *reinterpret_cast<double2 *>(cp + 2) = make_double2(acc[ci][2][g], acc[ci][3][g]);
         }
+    } else {
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
+          if (cl < ncv) {
+            const uint32_t co = (uint32_t)(cl * ldc);
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+              const int rl = wr * 64 + 4 * i16 + ri;
+              if (rl < nrv) Cb[co + (uint32_t)rl] = acc[ci][ri][g];
+            }
+          }
+        }
+    }
+    if constexpr (TIME) {
+      __builtin_amdgcn_sched_barrier(0);
+      tph[3] = clock64();
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // the stores have left the wave
+      tph[4] = clock64();
+      if (threadIdx.x == 0) {
+        for (int q = 0; q < 4; ++q) atomicAdd(&g_nn_phase[q], (unsigned long long)(tph[q + 1] - tph[q]));
+        atomicAdd(&g_nn_phase[4], 1ull);
       }
     }
+  }
 }
 
 // out[e] = sum_{s<nsplit} in[s*stride + e], e < count  (split-K reduction, deterministic order).
@@ -605,6 +682,88 @@ __global__ __launch_bounds__(1024) void k_issue_probe2(double *__restrict__ sink
   }
   sink[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + wave] = t1 - t0;
+}
+
+// Shader-clock probe: one wave sleeps for `wall_ticks` ticks of the constant-rate counter (wall_clock64) and reports
+// how many shader cycles (s_memtime) passed: launched beside a GEMM on a second stream it gives the clock the chip
+// sustains under that kernel (the chip clocks to its power budget).  out = {shader cycles, wall ticks}.
+__global__ void k_clock_probe(long long *__restrict__ out, long long wall_ticks) {
+  const long long w0 = wall_clock64(), c0 = clock64();
+  while (wall_clock64() - w0 < wall_ticks) __builtin_amdgcn_s_sleep(64);
+  const long long c1 = clock64(), w1 = wall_clock64();
+  if (threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = w1 - w0;
+  }
+}
+
+// MFMA cadence probe: the inner loop of the GEMM kernels (4 x 4 MFMA tiles per wave, fragments from LDS) without
+// staging, barriers or global memory: cycles per MFMA per wave (s_memtime).  MODE 0: register operands only;
+// 1: fragments by ds_read from the k-contiguous layout, stride S = 18 doubles (what k_gemm_tn* use; the compiler
+// merges the kk / kk+1 reads into ds_read2_b64); 2: same layout, one opaque base per kk (plain ds_read_b64 only);
+// 3: stride 17 (odd: conflict-free for ds_read2_b64's 16-lane groups); 4: the NN kernel's operands (V tile
+// row-contiguous with stride 144, W tile stride 18).  blockDim 256 (one wave per SIMD) or 512 (two).
+template <int MODE>
+__global__ __launch_bounds__(512) void k_mma_probe(double *__restrict__ sink, long long *__restrict__ cyc, int iters) {
+  constexpr int S = (MODE == 3) ? 17 : G_LDK;
+  __shared__ double Vs[256 * 19];
+  __shared__ double Cs[128 * 19];
+  __shared__ double Vr[G_KT * G_LDR];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int i16 = lane & 15, k4 = lane >> 4;
+  for (int e = t; e < 256 * 19; e += blockDim.x) Vs[e] = 1.0 + 1e-6 * e;
+  for (int e = t; e < 128 * 19; e += blockDim.x) Cs[e] = 1.0 - 1e-6 * e;
+  for (int e = t; e < G_KT * G_LDR; e += blockDim.x) Vr[e] = 0.5 + 1e-6 * e;
+  __syncthreads();
+  const int wc = (w >> 2) & 1, wp = w & 3;
+  dhqr_d4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+  const double *cs = &Cs[(wc * 64 + i16) * S + k4];
+  const double *vs = (MODE == 4) ? &Vr[k4 * G_LDR + (wp & 1) * 64 + i16] : &Vs[(wp * 64 + i16) * S + k4];
+  int offc[4], offv[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    offc[kk] = kk * 4;
+    offv[kk] = (MODE == 4) ? kk * 4 * G_LDR : kk * 4;
+    if (MODE == 2) {  // opaque offsets: the kk and kk+1 reads cannot be paired into ds_read2_b64
+      asm volatile("" : "+v"(offc[kk]));
+      asm volatile("" : "+v"(offv[kk]));
+    }
+  }
+  double ra[4] = {1.0 + lane * 1e-9, 1.1, 1.2, 1.3}, rb[4] = {1.0 - lane * 1e-9, 0.9, 0.8, 0.7};
+  const long long t0 = clock64();
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("" ::: "memory");  // the fragments are re-read every iteration, as in the GEMM kernels
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        if (MODE == 0) {
+          a[x] = ra[x];
+          b[x] = rb[x];
+        } else {
+          a[x] = cs[offc[kk] + x * 16 * S];
+          b[x] = (MODE == 4) ? vs[offv[kk] + x * 16] : vs[offv[kk] + x * 16 * S];
+        }
+      }
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) acc[ci][pi] = mfma_f64(a[ci], b[pi], acc[ci][pi]);
+    }
+  }
+  const long long t1 = clock64();
+  double sum = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) sum += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+  sink[(int64_t)blockIdx.x * blockDim.x + t] = sum;
+  if (lane == 0) cyc[blockIdx.x * (blockDim.x >> 6) + w] = t1 - t0;
 }
 
 // streaming read+write micro-benchmark (y = x + 1 on double2)

@@ -360,6 +360,17 @@ int32_t dhqr_debug_mfma_probe(dhqr_ctx *ctx, const double *da, const double *db,
  * rest VALU).  out4 = {cycles/MFMA/wave, cycles/v_fma_f64/wave, MFMA TFLOP/s, VALU TFLOP/s}. */
 int32_t dhqr_bench_issue2_f64(dhqr_ctx *ctx, int32_t mode, int32_t threads, int32_t nblocks, double *out4);
 
+/* GEMM micro-benchmark of the two wide trailing-update kernels on synthetic operands: kind 0 = C -= [V_a V_b] W
+ * (k_gemm_nn_sub, K = 256), kind 1 = Y = [V_a V_b]' C (k_gemm_tn2); rows, ncols multiples of 128.
+ * out4 = {ms per launch, TFLOP/s, shader clock in MHz sustained under the kernel (one-wave s_memtime probe on a
+ * second stream), 0}.  Synchronous. */
+int32_t dhqr_bench_gemm_f64(dhqr_ctx *ctx, int32_t kind, int64_t rows, int64_t ncols, int32_t reps, double *out4);
+/* MFMA cadence probe: the GEMM kernels' inner loop (4 x 4 MFMA tiles per wave, fragments from LDS) alone; mode 0 register
+ * operands, 1 k-contiguous LDS layout stride 18 (merged ds_read2_b64), 2 same with plain ds_read_b64, 3 stride 17,
+ * 4 the NN kernel's operand layouts; threads = 256 / 512 (one / two waves per SIMD).
+ * out2 = {cycles per MFMA per wave, TFLOP/s}.  Synchronous. */
+int32_t dhqr_bench_mma_probe_f64(dhqr_ctx *ctx, int32_t mode, int32_t threads, double *out2);
+
 #ifdef __cplusplus
 }
 #endif

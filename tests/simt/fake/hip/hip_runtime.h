@@ -243,6 +243,15 @@ inline simt_d4 simt_mfma_f64_16x16x4(double a, double b, simt_d4 c) {
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) simt_mfma_f64_16x16x4(a, b, c)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 inline long long clock64() { return 0; }
+inline long long wall_clock64() {
+  static std::atomic<long long> t{0};
+  return t += 1000;  // every poll advances the fake constant-rate counter: bounded spins terminate
+}
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
+  return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
 
 namespace simt {
 #ifndef SIMT_FIBERS

@@ -1,6 +1,6 @@
 // tools/pmc_driver.cpp -- torch-free driver for hardware-counter runs (rocprofv3 --pmc ...): a handful of launches
 // with KNOWN byte counts (the streaming-copy micro-benchmark: 2 x `bytes` per launch) followed by one factorisation.
-//   pmc_driver stream <MiB> | unblocked <n> | blocked <n>
+//   pmc_driver stream <MiB> | unblocked <n> | blocked <n> | gemm <kind 0 NN256 / 1 TN2> <rows> <ncols> <reps>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -23,7 +23,12 @@ int main(int argc, char **argv) {
   dhqr_ctx *c = nullptr;
   CK(dhqr_create(&c, 0));
   const long v = atol(argv[2]);
-  if (!strcmp(argv[1], "stream")) {
+  if (!strcmp(argv[1], "gemm")) {
+    if (argc < 6) return 2;
+    double out[4] = {0, 0, 0, 0};
+    CK(dhqr_bench_gemm_f64(c, (int32_t)v, atol(argv[3]), atol(argv[4]), (int32_t)atol(argv[5]), out));
+    printf("gemm kind %ld %sx%s: %.3f ms/launch, %.2f TFLOP/s, shader clock %.0f MHz\n", v, argv[3], argv[4], out[0], out[1], out[2]);
+  } else if (!strcmp(argv[1], "stream")) {
     double gbps = 0;
     CK(dhqr_bench_stream_f64(c, (int64_t)v << 20, &gbps));
     printf("stream %ld MiB: %.1f GB/s (6 launches of k_stream_bench, each reads and writes %ld MiB)\n", v, gbps, v);
