@@ -420,16 +420,114 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
 
   load_tile(0);
 
-  // accumulators <- C tile.  The 16 x 16 MFMA tile ri of a wave does NOT hold 16 consecutive rows: lane i16 of tile
-  // ri owns row 4*i16 + ri of the wave's 64 rows (the V fragments below are read with the same map), so the four tiles
-  // together give every lane FOUR CONSECUTIVE ROWS per column:  lane (i16,k4), register g of tile (ci,ri) holds
+  // Accumulator map.  The 16 x 16 MFMA tile ri of a wave does NOT hold 16 consecutive rows: lane i16 of tile ri owns
+  // row 4*i16 + ri of the wave's 64 rows (the V fragments are read with the same map), so the four tiles together
+  // give every lane FOUR CONSECUTIVE ROWS per column:  lane (i16,k4), register g of tile (ci,ri) holds
   //     C[r0 + wr*64 + 4*i16 + ri][c0 + wc*64 + ci*16 + k4 + 4g].
-  // Interior tiles move C with 16-byte accesses (32 B per lane and column, 512 contiguous bytes per 16 lanes; half the
-  // memory instructions of the element-wise map) and have all 32 loads of a thread in flight at once.  Measured
-  // (phase clock, 32768^2): the C tile + first operand tile cost 37.9k of a tile's 170k cycles with the masked
-  // 8-byte loads.
+  // Interior tiles move C with 16-byte accesses (32 B per lane and column, 512 contiguous bytes per 16 lanes).
   const bool full = (VEC == 2) && nrv == 128 && ncv == 128;
+  constexpr int NKT = KW / G_KT;
   dhqr_d4 acc[4][4];
+  auto mma_tile = [&](int buf) {
+    const double *ws = &Ws[buf][(wc * 64 + i16) * G_LDK + k4];
+    const double *vs = &Vs[buf][k4 * G_LDR + wr * 64 + 4 * i16];  // rows 4*i16 .. 4*i16+3: the four b fragments
+#pragma unroll
+    for (int kk = 0; kk < G_KT / 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) a[x] = ws[x * 16 * G_LDK + kk * 4];
+      // two ds_read_b128; stride 130 doubles puts the four k rows of a read 4 banks apart: conflict free
+      const double2 b01 = *reinterpret_cast<const double2 *>(vs + kk * 4 * G_LDR);
+      const double2 b23 = *reinterpret_cast<const double2 *>(vs + kk * 4 * G_LDR + 2);
+      b[0] = b01.x;
+      b[1] = b01.y;
+      b[2] = b23.x;
+      b[3] = b23.y;
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = mfma_f64(a[ci], b[ri], acc[ci][ri]);
+    }
+  };
+  // the lane's sixteen (column, 4-row) units of an interior tile: unit n = 4*ci + g is column wc*64 + k4 + 4n, so the
+  // units are one pointer walking with the uniform stride 4*ldc
+  double *const cunit0 = Cb + ((uint32_t)((wc * 64 + k4) * ldc) + (uint32_t)(wr * 64 + 4 * i16));
+  const int64_t cstep = 4 * ldc;
+  auto store_full = [&]() {  // interior tiles: 16 bytes per store, no masks
+    double *cp = cunit0;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      *reinterpret_cast<double2 *>(cp) = make_double2(acc[n >> 2][0][n & 3], acc[n >> 2][1][n & 3]);
+      *reinterpret_cast<double2 *>(cp + 2) = make_double2(acc[n >> 2][2][n & 3], acc[n >> 2][3][n & 3]);
+      cp += cstep;
+    }
+  };
+  auto time_end = [&]() {
+    if constexpr (TIME) {
+      __builtin_amdgcn_sched_barrier(0);
+      tph[3] = clock64();
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // the stores have left the wave
+      tph[4] = clock64();
+      if (threadIdx.x == 0) {
+        for (int q = 0; q < 4; ++q) atomicAdd(&g_nn_phase[q], (unsigned long long)(tph[q + 1] - tph[q]));
+        atomicAdd(&g_nn_phase[4], 1ull);
+      }
+    }
+  };
+
+  // ---- interior tiles of the trailing updates: C streams in DURING the K loop --------------------------------------
+  // acc = C - V W is a sum: the accumulators start at zero and every K-tile adds 16 / NKT of the lane's sixteen
+  // (column, 4-row) units of C, requested at the top of the K-tile and added below its 64 MFMAs.  The tile has no
+  // C prologue any more.  Why: with the C tile fetched up front the whole chip falls into a convoy -- every workgroup
+  // waits for its 128 KB while the HBM serves all 512 of them at once (phase clock: 28k of a tile's 167k cycles with
+  // idle matrix pipes; during the K loops the two waves of a SIMD saturate the pipe, 2 x 1024 x 64 cycles), and waiting
+  // on a saturated memory re-forms the convoy after any perturbation (random start phases changed nothing).  Streaming
+  // spreads the same reads evenly over the K loops.
+  constexpr bool STREAM = !INIT0 && VEC == 2 && (KW == 256 || KW == 128);
+  if (STREAM && full) {  // uniform branch
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+    store_tile(0);
+    __syncthreads();
+    if constexpr (TIME) tph[1] = clock64();
+    constexpr int UPT = STREAM ? 16 / NKT : 1;  // units per K-tile
+    const double *cin = cunit0;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      double2 cu[UPT][2];
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) {
+        cu[u][0] = *reinterpret_cast<const double2 *>(cin);
+        cu[u][1] = *reinterpret_cast<const double2 *>(cin + 2);
+        cin += cstep;
+      }
+      if (kt + 1 < NKT) load_tile(kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_tile(kt & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < NKT) store_tile((kt & 1) ^ 1);
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) {
+        const int ci = (kt * UPT + u) >> 2, g = (kt * UPT + u) & 3;
+        acc[ci][0][g] += cu[u][0].x;
+        acc[ci][1][g] += cu[u][0].y;
+        acc[ci][2][g] += cu[u][1].x;
+        acc[ci][3][g] += cu[u][1].y;
+      }
+      if (kt + 1 < NKT) __syncthreads();
+    }
+    if constexpr (TIME) {
+      __builtin_amdgcn_sched_barrier(0);
+      tph[2] = clock64();
+    }
+    store_full();
+    time_end();
+    return;
+  }
+
+  // ---- general path (edge tiles, unaligned operands, INIT0, narrow reflector blocks): C first -------------------------
   if (INIT0) {
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci)
@@ -440,14 +538,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
     for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const double *cp = Cb + ((uint32_t)((wc * 64 + ci * 16 + k4 + 4 * g) * ldc) + (uint32_t)(wr * 64 + 4 * i16));
+        const double *cp = cunit0 + (4 * ci + g) * cstep;
         const double2 x0 = *reinterpret_cast<const double2 *>(cp), x1 = *reinterpret_cast<const double2 *>(cp + 2);
         acc[ci][0][g] = x0.x;
         acc[ci][1][g] = x0.y;
         acc[ci][2][g] = x1.x;
         acc[ci][3][g] = x1.y;
       }
-  } else {  // edge tiles / unaligned operands: clamped addresses, all loads issued before the first mask is applied
+  } else {  // clamped addresses, all loads issued before the first mask is applied
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
@@ -478,28 +576,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the C tile has arrived
     tph[1] = clock64();
   }
-  constexpr int NKT = KW / G_KT;
-  auto mma_tile = [&](int buf) {
-    const double *ws = &Ws[buf][(wc * 64 + i16) * G_LDK + k4];
-    const double *vs = &Vs[buf][k4 * G_LDR + wr * 64 + 4 * i16];  // rows 4*i16 .. 4*i16+3: the four b fragments
-#pragma unroll
-    for (int kk = 0; kk < G_KT / 4; ++kk) {
-      double a[4], b[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) a[x] = ws[x * 16 * G_LDK + kk * 4];
-      // two ds_read_b128; stride 130 doubles puts the four k rows of a read 4 banks apart: conflict free
-      const double2 b01 = *reinterpret_cast<const double2 *>(vs + kk * 4 * G_LDR);
-      const double2 b23 = *reinterpret_cast<const double2 *>(vs + kk * 4 * G_LDR + 2);
-      b[0] = b01.x;
-      b[1] = b01.y;
-      b[2] = b23.x;
-      b[3] = b23.y;
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = mfma_f64(a[ci], b[ri], acc[ci][ri]);
-    }
-  };
 #pragma unroll 1
   for (int kt = 0; kt < NKT - 1; ++kt) {
     const int buf = kt & 1;
@@ -510,49 +586,30 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
     store_tile(buf ^ 1);
     __syncthreads();
   }
-
-  {
-    mma_tile((NKT - 1) & 1);
-    if constexpr (TIME) {
-      __builtin_amdgcn_sched_barrier(0);
-      tph[2] = clock64();
-    }
-    if (full) {  // uniform branch: interior tiles store 16 bytes at a time, no masks
+  mma_tile((NKT - 1) & 1);
+  if constexpr (TIME) {
+    __builtin_amdgcn_sched_barrier(0);
+    tph[2] = clock64();
+  }
+  if (full) {
+    store_full();
+  } else {
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
+    for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          double *cp = Cb + ((uint32_t)((wc * 64 + ci * 16 + k4 + 4 * g) * ldc) + (uint32_t)(wr * 64 + 4 * i16));
-          *reinterpret_cast<double2 *>(cp) = make_double2(acc[ci][0][g], acc[ci][1][g]);
-          *reinterpret_cast<double2 *>(cp + 2) = make_double2(acc[ci][2][g], acc[ci][3][g]);
-        }
-    } else {
+      for (int g = 0; g < 4; ++g) {
+        const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
+        if (cl < ncv) {
+          const uint32_t co = (uint32_t)(cl * ldc);
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
-          if (cl < ncv) {
-            const uint32_t co = (uint32_t)(cl * ldc);
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-              const int rl = wr * 64 + 4 * i16 + ri;
-              if (rl < nrv) Cb[co + (uint32_t)rl] = acc[ci][ri][g];
-            }
+          for (int ri = 0; ri < 4; ++ri) {
+            const int rl = wr * 64 + 4 * i16 + ri;
+            if (rl < nrv) Cb[co + (uint32_t)rl] = acc[ci][ri][g];
           }
         }
-    }
-    if constexpr (TIME) {
-      __builtin_amdgcn_sched_barrier(0);
-      tph[3] = clock64();
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // the stores have left the wave
-      tph[4] = clock64();
-      if (threadIdx.x == 0) {
-        for (int q = 0; q < 4; ++q) atomicAdd(&g_nn_phase[q], (unsigned long long)(tph[q + 1] - tph[q]));
-        atomicAdd(&g_nn_phase[4], 1ull);
       }
-    }
   }
+  time_end();
 }
 
 // out[e] = sum_{s<nsplit} in[s*stride + e], e < count  (split-K reduction, deterministic order).
