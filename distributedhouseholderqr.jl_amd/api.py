@@ -71,6 +71,19 @@ class Context:
         check(_lib.lib().dhqr_get_panel_counters(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def set_r_source(self, source: int):
+        """1 Gram/Cholesky (default), 2 CholeskyQR2, 3 TSQR-HR (csrc/dhqr_tsqr.h) for the R-first panel path"""
+        check(_lib.lib().dhqr_set_r_source(self._h, int(source)))
+
+    def set_tsqr_rung(self, on: bool):
+        """False: rejected panels skip the TSQR-HR rung (straight to the column-by-column kernels)"""
+        check(_lib.lib().dhqr_set_tsqr_rung(self._h, 1 if on else 0))
+
+    def tsqr_count(self) -> int:
+        a = ctypes.c_int64()
+        check(_lib.lib().dhqr_get_tsqr_count(self._h, ctypes.byref(a)))
+        return a.value
+
     def close(self):
         if self._h:
             _lib.lib().dhqr_destroy(self._h)
@@ -361,7 +374,7 @@ def apply_q_(H: DistributedHouseholderQRStruct, B, trans: bool):
 
 
 def get_r(H: DistributedHouseholderQRStruct):
-    """n x n upper-triangular R of a Float64 device factorisation (strict upper part of H.A + α on the
+    r"""n x n upper-triangular R of a Float64 device factorisation (strict upper part of H.A + α on the
     diagonal, src:296-309), as a new column-major device tensor.  The reference exposes R only
     implicitly through `\`; SURVEY.md section 8f rank 2 asks for the explicit extraction."""
     ptr, m, n, lda, dev = _dev_matrix(H.A)

@@ -19,6 +19,7 @@
 #include "dhqr_rank1.h"
 #include "dhqr_recon.h"
 #include "dhqr_solve.h"
+#include "dhqr_tsqr.h"
 
 static thread_local char g_err[512] = "";
 static int32_t set_err(int32_t code, const char *fmt, ...) {
@@ -69,8 +70,13 @@ struct dhqr_ctx {
   int epoch = -1;        // >= 0 while an asynchronous factorisation is enqueued: matrix-writing launches carry
                          // (dstat, epoch) and are no-ops once a panel <= epoch was rejected
   Buf rbuf;              // R1, -R1^{-1}, R, Rref, -M^{-1}, alpha_tmp
+  Buf tsq;               // R factors, reflectors and Q of the TSQR tree (dhqr_tsqr.h)
+  int tsqr_rung = -1;    // rejected panels try TSQR-HR before the column-by-column kernels: 1 yes, 0 no, -1 (default)
+                         // only where the last rung costs collectives per column (row split over more than one rank):
+                         // on one GPU the column kernels redo a panel in ~1 ms, the tree takes ~7 ms at 32768 rows
+  int n_tsqr = 0;        // panels whose R came from the TSQR tree (dhqr_get_panel_counters: counted as fast)
   int64_t n_fast = 0, n_fallback = 0;
-  int cholqr_passes = 1;  // Gram/Cholesky passes of the fast path (2 = CholeskyQR2)
+  int cholqr_passes = 1;  // where the fast path gets R from: 1 Gram/Cholesky, 2 CholeskyQR2, 3 TSQR tree (DHQR_TSQR=1)
   double recon_tol = 2e-12;  // accepted deviation of ||v_j||^2 from 2 before falling back
   int ib = DHQR_IB;
   struct CsState *cs = nullptr;  // streams / events / group buffers of the blocked driver (dhqr_dist.h)
@@ -500,6 +506,129 @@ static int32_t status_read(dhqr_ctx *c, int *first_failed) {
   return DHQR_OK;
 }
 
+// ---- TSQR tree (dhqr_tsqr.h), all launches on c->stream ------------------------------------------------------------
+// Pair levels over `count` stacked 128 x 128 R factors.  cnt[0] = count, cnt[l] = ceil(cnt[l-1] / 2) down to 1; the
+// reflectors of level l >= 1 live at Ybase + yoff[l] node blocks (256 x 128 each) when Ybase != nullptr.
+struct TsqrLevels {
+  std::vector<int64_t> cnt, yoff;
+  explicit TsqrLevels(int64_t count) {
+    cnt.push_back(count);
+    yoff.push_back(0);
+    int64_t off = 0;
+    while (cnt.back() > 1) {
+      const int64_t n = (cnt.back() + 1) / 2;
+      yoff.push_back(off);
+      off += n;
+      cnt.push_back(n);
+    }
+  }
+  int L() const { return (int)cnt.size() - 1; }
+  static int64_t node_blocks(int64_t count) { return count + 64; }  // upper bound of sum_l cnt[l], l >= 1
+};
+static const size_t TSQR_NN = (size_t)DHQR_NBV * DHQR_NBV;
+// bottom-up: Rroot <- R of the stacked blocks Rin[0 .. count); ping / pong: (count + 1) / 2 blocks each
+static int32_t tsqr_pairs_up(dhqr_ctx *c, const double *Rin, int64_t count, double *Rroot, double *Ybase, double *ping,
+                             double *pong) {
+  if (count <= 0) {
+    HIPCHECK(hipMemsetAsync(Rroot, 0, TSQR_NN * sizeof(double), c->stream));
+    return DHQR_OK;
+  }
+  if (count == 1) {
+    HIPCHECK(hipMemcpyAsync(Rroot, Rin, TSQR_NN * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return DHQR_OK;
+  }
+  const TsqrLevels lv(count);
+  const double *in = Rin;
+  double *bufs[2] = {ping, pong};
+  for (int l = 1; l <= lv.L(); ++l) {
+    double *out = (l == lv.L()) ? Rroot : bufs[l & 1];
+    hipLaunchKernelGGL(k_tsqr_node, dim3((unsigned)lv.cnt[l]), dim3(1024), 0, c->stream, (const double *)nullptr, (int64_t)0,
+                       (int64_t)0, in, (int)lv.cnt[l - 1], out, Ybase ? Ybase + (size_t)lv.yoff[l] * 2 * TSQR_NN : nullptr,
+                       (int64_t)0);
+    in = out;
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// top-down: *Cleaf <- the `count` C blocks of the bottom level, starting from Croot (nullptr: identity) at the root;
+// ping / pong: `count` blocks each
+static int32_t tsqr_pairs_down(dhqr_ctx *c, int64_t count, const double *Ybase, const double *Croot, double *ping,
+                               double *pong, const double **Cleaf) {
+  if (count <= 1) {
+    if (Croot == nullptr) {
+      hipLaunchKernelGGL(k_tsqr_identity, dim3((unsigned)(TSQR_NN / 256)), dim3(256), 0, c->stream, ping);
+      LAUNCHCHECK();
+      *Cleaf = ping;
+    } else {
+      *Cleaf = Croot;
+    }
+    return DHQR_OK;
+  }
+  const TsqrLevels lv(count);
+  const double *in = Croot;
+  double *bufs[2] = {ping, pong};
+  for (int l = lv.L(); l >= 1; --l) {
+    double *out = bufs[l & 1];
+    hipLaunchKernelGGL(k_tsqr_apply, dim3((unsigned)lv.cnt[l]), dim3(1024), 0, c->stream, in,
+                       Ybase + (size_t)lv.yoff[l] * 2 * TSQR_NN, (int64_t)0, 0, (int)lv.cnt[l - 1], out, (double *)nullptr,
+                       (int64_t)0);
+    in = out;
+  }
+  LAUNCHCHECK();
+  *Cleaf = in;
+  return DHQR_OK;
+}
+// Workspace of a local tree over `rows` rows inside c->tsq (after `reserve` doubles the caller keeps for itself).
+struct TsqrLocal {
+  int64_t rows = 0, nleaf = 0, ldy = 0;
+  double *R0 = nullptr, *ping = nullptr, *pong = nullptr, *Yl = nullptr, *Yp = nullptr;
+  static size_t elems(int64_t rows) {
+    const size_t nl = (size_t)std::max<int64_t>(1, (rows + TSQR_LEAF - 1) / TSQR_LEAF);
+    return (3 * nl + 2) * TSQR_NN + nl * 2 * TSQR_NN + (size_t)TsqrLevels::node_blocks((int64_t)nl) * 2 * TSQR_NN;
+  }
+  void place(double *base, int64_t rows_) {
+    rows = rows_;
+    nleaf = std::max<int64_t>(1, (rows + TSQR_LEAF - 1) / TSQR_LEAF);
+    ldy = nleaf * TSQR_LEAF;
+    R0 = base;
+    ping = R0 + (size_t)nleaf * TSQR_NN;
+    pong = ping + (size_t)(nleaf + 1) * TSQR_NN;
+    Yl = pong + (size_t)(nleaf + 1) * TSQR_NN;
+    Yp = Yl + (size_t)nleaf * 2 * TSQR_NN;
+  }
+};
+// up: Rroot <- R of the local rows (keep: reflectors stored for tsqr_local_down)
+static int32_t tsqr_local_up(dhqr_ctx *c, const TsqrLocal &t, const double *P, int64_t ldp, double *Rroot, bool keep) {
+  if (t.rows <= 0) {
+    HIPCHECK(hipMemsetAsync(Rroot, 0, TSQR_NN * sizeof(double), c->stream));
+    if (keep) HIPCHECK(hipMemsetAsync(t.Yl, 0, (size_t)t.nleaf * 2 * TSQR_NN * sizeof(double), c->stream));
+    return DHQR_OK;
+  }
+  double *lvl0 = (t.nleaf == 1) ? Rroot : t.R0;
+  hipLaunchKernelGGL(k_tsqr_node, dim3((unsigned)t.nleaf), dim3(1024), 0, c->stream, P, ldp, t.rows, (const double *)nullptr, 0,
+                     lvl0, keep ? t.Yl : (double *)nullptr, t.ldy);
+  LAUNCHCHECK();
+  if (t.nleaf == 1) return DHQR_OK;
+  return tsqr_pairs_up(c, lvl0, t.nleaf, Rroot, keep ? t.Yp : nullptr, t.ping, t.pong);
+}
+// down: the local rows of the explicit Q -> t.Yl (leading dimension t.ldy), from Croot (nullptr: identity)
+static int32_t tsqr_local_down(dhqr_ctx *c, const TsqrLocal &t, const double *Croot) {
+  if (t.rows <= 0) return DHQR_OK;
+  const double *Cleaf = nullptr;
+  CHECK(tsqr_pairs_down(c, t.nleaf, t.Yp, Croot, t.ping, t.pong, &Cleaf));
+  hipLaunchKernelGGL(k_tsqr_apply, dim3((unsigned)t.nleaf), dim3(1024), 0, c->stream, Cleaf, (const double *)t.Yl, t.ldy, 1, 0,
+                     (double *)nullptr, t.Yl, t.ldy);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// R only (dhqr_tsqr_r_f64)
+static int32_t tsqr_local_r(dhqr_ctx *c, const double *P, int64_t ldp, int64_t rows, double *Rout) {
+  CHECK(ensure(c, c->tsq, TsqrLocal::elems(rows)));
+  TsqrLocal t;
+  t.place(c->tsq.p, rows);
+  return tsqr_local_up(c, t, P, ldp, Rout, false);
+}
+
 // Enqueue the R-first factorisation of a full-width panel (w == 128, rows >= 256) WITHOUT waiting for its
 // verification: nothing is written to P, alpha or pb.T/Tt/alpha unless the panel is accepted on the device
 // (k_build_t); once a panel has failed every later commit / trailing update with epoch >= its index is a
@@ -510,6 +639,7 @@ static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t 
   const size_t NN = (size_t)DHQR_NBV * DHQR_NBV;
   CHECK(ensure(c, c->rbuf, 6 * NN + 1024));
   if (passes == 2) CHECK(ensure(c, c->vts, (size_t)panel_elems(rows)));
+  if (passes == 3) CHECK(ensure(c, c->tsq, TsqrLocal::elems(rows)));
   CHECK(ensure(c, c->sfull, NN));
   double *R1 = c->rbuf.p, *negR1inv = R1 + NN, *Rf = R1 + 2 * NN, *Rref = R1 + 3 * NN, *negMinv = R1 + 4 * NN;
   double *G = R1 + 5 * NN, *altmp = R1 + 6 * NN;
@@ -518,8 +648,20 @@ static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t 
   const bool was = c->profiling;
   c->profiling = false;
   auto body = [&]() -> int32_t {
-    CHECK(gram128(c, P, ldp, rows, G));                                            // G  = P'P
-    if (passes == 2) {
+    const double *X = P;  // what the reflectors are reconstructed from: the panel, or its explicit Q factor
+    int64_t ldx = ldp;
+    if (passes == 3) {  // TSQR-HR (dhqr_tsqr.h): R_t and the explicit Q from the tree, replay of Q with R(Q) = I
+      TsqrLocal t;
+      t.place(c->tsq.p, rows);
+      CHECK(tsqr_local_up(c, t, P, ldp, Rf, true));
+      CHECK(tsqr_local_down(c, t, nullptr));
+      hipLaunchKernelGGL(k_tsqr_identity, dim3((unsigned)(NN / 256)), dim3(256), 0, c->stream, R1);
+      X = t.Yl;
+      ldx = t.ldy;
+      launch_recon_top(c, X, ldx, R1, G, Rref, negMinv);                            // G[0..128) = alpha(Q) = +-1
+      hipLaunchKernelGGL(k_tsqr_sign_cols, dim3((unsigned)(NN / 256)), dim3(256), 0, c->stream, negMinv, (const double *)Rf);
+    } else if (passes == 2) {
+      CHECK(gram128(c, P, ldp, rows, G));                                          // G  = P'P
       double *Q1 = c->vts.p;  // rows x 128 scratch
       const int64_t ldq = panel_ldv(rows);
       launch_chol_inv(c, G, nullptr, R1, negR1inv, bflag);                          // R1, -R1^{-1}
@@ -528,12 +670,16 @@ static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t 
       launch_chol_inv(c, G, R1, Rf, nullptr, bflag);                                // R  = chol(G2) R1
       launch_recon_top(c, P, ldp, Rf, altmp, Rref, negMinv);                        // alpha, R_ref, -M^{-1}
     } else {  // R = chol(P'P), replay, -M^{-1} in one launch
+      CHECK(gram128(c, P, ldp, rows, G));
       hipLaunchKernelGGL(k_panel_top, dim3(1), dim3(1024), 0, c->stream, (const double *)G, (const double *)P, ldp, altmp,
                          Rref, negMinv, bflag);
     }
-    CHECK(mul128(c, P, ldp, rows, negMinv, pb.V, ldv));                            // Vw = P M^{-1}
-    hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, pb.V, ldv, (const double *)altmp,
-                       (const double *)negMinv);                                   // Vw = tril((P - aE) M^{-1})
+    CHECK(mul128(c, X, ldx, rows, negMinv, pb.V, ldv));                            // Vw = X M^{-1}
+    hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, pb.V, ldv,
+                       (const double *)(passes == 3 ? G : altmp), (const double *)negMinv);  // Vw = tril((X - aE) M^{-1})
+    if (passes == 3)  // R = D R_t, alpha = diag(R)
+      hipLaunchKernelGGL(k_tsqr_final_r, dim3(NN / 256), dim3(256), 0, c->stream, (const double *)Rf, (const double *)G, Rref,
+                         altmp);
     CHECK(gram128(c, pb.V, ldv, rows, c->sfull.p));                                // S = V'V
     // T from S, fused with the acceptance decision (before the predicated commits)
     hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sfull.p, (int)DHQR_NBV, pb.T, pb.Tt,
@@ -567,13 +713,16 @@ static inline bool panel_fast_eligible(dhqr_ctx *c, int64_t rows, int64_t w) {
 static int32_t factor_panel_sync(dhqr_ctx *c, double *P, int64_t rows, int64_t w, int64_t ldp, double *alpha,
                                  const PanelBuf &pb) {
   if (panel_fast_eligible(c, rows, w)) {
-    for (int passes = c->cholqr_passes; passes <= 2; ++passes) {
+    // ladder: Gram/Cholesky -> CholeskyQR2 -> TSQR tree (each verified on the device, nothing written on rejection)
+    const int last_rung = std::max(c->cholqr_passes, c->tsqr_rung == 1 ? 3 : 2);
+    for (int passes = c->cholqr_passes; passes <= last_rung; ++passes) {
       CHECK(status_reset(c));
       CHECK(panel_fast_enqueue(c, P, rows, ldp, alpha, pb, passes, 0));
       int failed = 0;
       CHECK(status_read(c, &failed));
       if (failed == INT_MAX) {
         c->n_fast++;
+        if (passes == 3) c->n_tsqr++;
         return DHQR_OK;
       }
     }
@@ -827,6 +976,10 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     return rc_init;
   }
   if (const char *e = getenv("DHQR_CHOLQR_PASSES")) c->cholqr_passes = atoi(e) == 2 ? 2 : 1;
+  if (const char *e = getenv("DHQR_TSQR")) {  // 1: every panel through TSQR-HR
+    if (atoi(e) != 0) c->cholqr_passes = 3;
+  }
+  if (const char *e = getenv("DHQR_TSQR_RUNG")) c->tsqr_rung = atoi(e) != 0 ? 1 : 0;
   if (const char *e = getenv("DHQR_RECON_TOL")) c->recon_tol = atof(e);
   if (const char *e = getenv("DHQR_PANEL")) {
     const int v = atoi(e);
@@ -847,7 +1000,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   (void)hipDeviceSynchronize();
   cs_state_free(c);
   Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
-                 &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf};
+                 &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {
@@ -889,6 +1042,7 @@ int32_t dhqr_reset_stats(dhqr_ctx *c) {
   c->ev_used = 0;
   memset(&c->st, 0, sizeof(c->st));
   c->n_fast = c->n_fallback = 0;
+  c->n_tsqr = 0;
   return DHQR_OK;
 }
 int32_t dhqr_get_stats(dhqr_ctx *c, dhqr_stats *out) {
@@ -896,6 +1050,32 @@ int32_t dhqr_get_stats(dhqr_ctx *c, dhqr_stats *out) {
   if (!out) return set_err(DHQR_EINVAL, "null stats pointer");
   CHECK(prof_resolve(c));
   *out = c->st;
+  return DHQR_OK;
+}
+
+// R (128 x 128, upper triangular, row signs as the tree produces them) of a device-resident rows x 128 panel.  Async.
+int32_t dhqr_tsqr_r_f64(dhqr_ctx *c, const double *dP, int64_t rows, int64_t ldp, double *dR) {
+  ENTER(c);
+  if (!dP || !dR) return set_err(DHQR_EINVAL, "null pointer argument");
+  if (rows < 1 || ldp < rows) return set_err(DHQR_EINVAL, "bad panel shape: rows=%lld ldp=%lld", (long long)rows, (long long)ldp);
+  return tsqr_local_r(c, dP, ldp, rows, dR);
+}
+
+int32_t dhqr_set_r_source(dhqr_ctx *c, int32_t source) {
+  if (!c || source < 1 || source > 3) return set_err(DHQR_EINVAL, "R source must be 1 (Cholesky), 2 (CholeskyQR2) or 3 (TSQR tree)");
+  c->cholqr_passes = source;
+  return DHQR_OK;
+}
+
+int32_t dhqr_set_tsqr_rung(dhqr_ctx *c, int32_t on) {
+  if (!c) return set_err(DHQR_EINVAL, "null context");
+  c->tsqr_rung = on != 0 ? 1 : 0;
+  return DHQR_OK;
+}
+
+int32_t dhqr_get_tsqr_count(dhqr_ctx *c, int64_t *n_tsqr) {
+  if (!c || !n_tsqr) return set_err(DHQR_EINVAL, "null argument");
+  *n_tsqr = c->n_tsqr;
   return DHQR_OK;
 }
 

@@ -21,10 +21,33 @@ __host__ __device__ __forceinline__ double dhqr_u01(uint64_t seed, uint64_t idx)
 // ---- reductions: wavefront xor-shuffle butterfly (every lane ends with the total), then one
 // LDS slot per wave.  This is the GPU form of the reference's partialdot accumulation
 // (src:42-49, @simd => order unspecified).
+// One DPP step on a double: every lane of the enabled rows receives the value of its source lane (0.0 in the disabled
+// rows / where the pattern has no source), VALU only -- no LDS crossbar round trip like ds_bpermute (__shfl_xor).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int rlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  const int rhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(rhi, rlo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+// The same sum with DPP moves instead of ds_bpermute.  quad_perm [1,0,3,2] / [2,3,0,1] and row_ror:4 / :8 leave every
+// lane of a 16-lane row with the row's sum; row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the sums
+// across the rows into lane 63, which is read back with v_readlane.  For kernels that do many reductions per step
+// (k_tsqr_node / k_tsqr_apply: 8 per step and wave -- the butterfly was LDS-throughput bound there, 1.4 - 1.7 x
+// slower); the streaming kernels keep the butterfly (k_rank1_fused measured 2 % slower with this one).
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_f64<0xB1, 0xf>(v);
+  v += dpp_f64<0x4E, 0xf>(v);
+  v += dpp_f64<0x124, 0xf>(v);
+  v += dpp_f64<0x128, 0xf>(v);
+  v += dpp_f64<0x142, 0xa>(v);
+  v += dpp_f64<0x143, 0xc>(v);
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // All THREADS threads must call; every thread returns the same total. `red` >= THREADS/64 doubles.

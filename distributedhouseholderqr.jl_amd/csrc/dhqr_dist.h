@@ -358,6 +358,7 @@ static int32_t cs_prepare(const CsProblem &pr) {
   CHECK(ensure(c, c->spart, (size_t)256 * NN));
   CHECK(ensure(c, c->sfull, NN));
   CHECK(ensure(c, c->rbuf, 6 * NN + 1024));
+  if (c->cholqr_passes == 3) CHECK(ensure(c, c->tsq, TsqrLocal::elems(m)));  // TSQR-HR for every panel
   CHECK(ensure(c, c->scratch, 4096));
   return DHQR_OK;
 }
@@ -378,7 +379,10 @@ static int32_t cs_factor(const CsProblem &pr) {
     fast_idx.clear();
     CHECK(cs_run(pr, ks, robust, &failed, fast_idx));
     for (int64_t x : fast_idx)
-      if (x < failed) c->n_fast++;
+      if (x < failed) {
+        c->n_fast++;
+        if (c->cholqr_passes == 3) c->n_tsqr++;
+      }
     if (failed == INT_MAX) break;
     // ---- resume: panels < failed are committed; matrix updates with epoch >= failed did not run
     CHECK(status_reset(c));

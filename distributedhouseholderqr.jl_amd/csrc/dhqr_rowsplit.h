@@ -272,8 +272,39 @@ static int32_t rs_panel_columns(const RsProblem &pr, const RsWork &w, int64_t c0
   return DHQR_OK;
 }
 
-// One asynchronous pass over the panels [kstart, K); returns the first rejected panel in *failed (INT_MAX: none).
-static int32_t rs_run(const RsProblem &pr, const RsWork &w, int64_t kstart, bool robust_first, int *failed, int64_t *nfast) {
+// TSQR-HR of the row-split panel (dhqr_tsqr.h): local tree up, gather of the P local R factors through one all-reduce
+// of a zero-padded buffer, the same tree over them on every rank (up: R_t, down: this rank's block C_r), local tree
+// down from C_r.  Rt <- the tree's R (128 x 128, identical on every rank); *Q / *ldq <- the local rows of the explicit
+// orthonormal factor (inside c->tsq).
+static int32_t rs_tsqr_hr(const RsProblem &pr, const double *P, int64_t rows, double *Rt, const double **Q, int64_t *ldq) {
+  dhqr_ctx *c = pr.c;
+  const size_t NN = TSQR_NN;
+  const bool multi = pr.cm && pr.P > 1;
+  const size_t Pn = multi ? (size_t)pr.P : 0;
+  const size_t top = Pn ? (5 * Pn + 4) * NN + (size_t)TsqrLevels::node_blocks((int64_t)Pn) * 2 * NN : 0;
+  CHECK(ensure(c, c->tsq, top + TsqrLocal::elems(rows)));
+  TsqrLocal t;
+  t.place(c->tsq.p + top, rows);
+  *Q = t.Yl;
+  *ldq = t.ldy;
+  if (!multi) {
+    CHECK(tsqr_local_up(c, t, P, pr.lda, Rt, true));
+    return tsqr_local_down(c, t, nullptr);
+  }
+  double *gather = c->tsq.p, *ping = gather + Pn * NN, *pong = ping + (Pn + 1) * NN, *cping = pong + (Pn + 1) * NN,
+         *cpong = cping + (Pn + 1) * NN, *Ytop = cpong + (Pn + 1) * NN;
+  HIPCHECK(hipMemsetAsync(gather, 0, Pn * NN * sizeof(double), c->stream));
+  CHECK(tsqr_local_up(c, t, P, pr.lda, gather + (size_t)pr.r * NN, true));
+  CHECK(comm_allreduce_sum(pr.cm, gather, (int64_t)(Pn * NN), c->stream));
+  CHECK(tsqr_pairs_up(c, gather, pr.P, Rt, Ytop, ping, pong));
+  const double *Cblocks = nullptr;
+  CHECK(tsqr_pairs_down(c, pr.P, Ytop, nullptr, cping, cpong, &Cblocks));
+  return tsqr_local_down(c, t, Cblocks + (size_t)pr.r * NN);
+}
+
+// level: how the FIRST panel of the pass is factored -- 0 like the others, 1 R from the TSQR tree (a panel the
+// Gram/Cholesky path was rejected on), 2 column by column.
+static int32_t rs_run(const RsProblem &pr, const RsWork &w, int64_t kstart, int level, int *failed, int64_t *nfast) {
   dhqr_ctx *c = pr.c;
   dhqr_comm *cm = (pr.cm && pr.P > 1) ? pr.cm : nullptr;
   const int64_t NB = DHQR_NBV, n = pr.n, K = (n + NB - 1) / NB;
@@ -286,20 +317,39 @@ static int32_t rs_run(const RsProblem &pr, const RsWork &w, int64_t kstart, bool
       pr.active(c0, &off, &rows);
       const int downer = pr.owner_of_row(c0);
       const bool diag_owner = downer == pr.r;
-      const bool fast = c->panel_impl == 3 && wcols == NB && pr.m - c0 >= 2 * NB && !(robust_first && k == kstart);
+      const bool fast = c->panel_impl == 3 && wcols == NB && pr.m - c0 >= 2 * NB && !(level == 2 && k == kstart);
+      const bool tsqr = c->cholqr_passes == 3 || (level == 1 && k == kstart);
       double *P = pr.A + off + c0 * pr.lda;
       c->epoch = -1;
       if (fast) {
         CHECK(prof_begin(c, CAT_PANEL));
-        CHECK(rs_gram_allreduce(pr, P, pr.lda, rows, w.G));                       // G = sum P_r' P_r
-        if (diag_owner) {
-          hipLaunchKernelGGL(k_panel_top, dim3(1), dim3(1024), 0, c->stream, (const double *)w.G, (const double *)P, pr.lda,
-                             w.bc + NN, w.Rref, w.bc, c->dstat + 1);             // alpha -> bc tail, -M^{-1} -> bc
-          hipLaunchKernelGGL(k_rs_get_breakdown, dim3(1), dim3(64), 0, c->stream, c->dstat, w.bc + NN + NB);
+        const double *X = P;  // what the reflectors are reconstructed from: the panel rows, or the rows of its Q factor
+        int64_t ldx = pr.lda;
+        const double *alpha_commit = w.bc + NN;
+        if (tsqr) {
+          CHECK(rs_tsqr_hr(pr, P, rows, w.G, &X, &ldx));                           // w.G = R_t, X = local rows of Q
+          if (diag_owner) {
+            hipLaunchKernelGGL(k_tsqr_identity, dim3((unsigned)(NN / 256)), dim3(256), 0, c->stream, w.S);
+            launch_recon_top(c, X, ldx, w.S, w.bc + NN, w.Rref, w.bc);             // R(Q) = I: alpha(Q) = +-1, -M^{-1}
+            hipLaunchKernelGGL(k_tsqr_sign_cols, dim3((unsigned)(NN / 256)), dim3(256), 0, c->stream, w.bc, (const double *)w.G);
+            hipLaunchKernelGGL(k_rs_get_breakdown, dim3(1), dim3(64), 0, c->stream, c->dstat, w.bc + NN + NB);
+          }
+        } else {
+          CHECK(rs_gram_allreduce(pr, P, pr.lda, rows, w.G));                     // G = sum P_r' P_r
+          if (diag_owner) {
+            hipLaunchKernelGGL(k_panel_top, dim3(1), dim3(1024), 0, c->stream, (const double *)w.G, (const double *)P, pr.lda,
+                               w.bc + NN, w.Rref, w.bc, c->dstat + 1);           // alpha -> bc tail, -M^{-1} -> bc
+            hipLaunchKernelGGL(k_rs_get_breakdown, dim3(1), dim3(64), 0, c->stream, c->dstat, w.bc + NN + NB);
+          }
         }
         if (cm) CHECK(comm_bcast(cm, w.bc, (int64_t)NN + NB + 8, downer, c->stream, nullptr));
         hipLaunchKernelGGL(k_rs_set_breakdown, dim3(1), dim3(64), 0, c->stream, (const double *)(w.bc + NN + NB), c->dstat);
-        if (rows > 0) CHECK(mul128(c, P, pr.lda, rows, w.bc, w.Vw, w.ldv));        // Vw = P M^{-1}
+        if (tsqr) {  // R = D R_t, alpha = diag(R) with D = alpha(Q) from the broadcast (every rank: same values)
+          hipLaunchKernelGGL(k_tsqr_final_r, dim3(NN / 256), dim3(256), 0, c->stream, (const double *)w.G,
+                             (const double *)(w.bc + NN), w.Rref, w.altmp + 1024);
+          alpha_commit = w.altmp + 1024;
+        }
+        if (rows > 0) CHECK(mul128(c, X, ldx, rows, w.bc, w.Vw, w.ldv));           // Vw = X M^{-1}
         if (diag_owner)
           hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, w.Vw, w.ldv, (const double *)(w.bc + NN),
                              (const double *)w.bc);
@@ -319,7 +369,7 @@ static int32_t rs_run(const RsProblem &pr, const RsWork &w, int64_t kstart, bool
                                (const int *)c->dstat, (int)k);
           }
         }
-        hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, (const double *)(w.bc + NN), (int)NB,
+        hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, alpha_commit, (int)NB,
                            pr.alpha + c0, (double *)nullptr, (const int *)c->dstat, (int)k);
         LAUNCHCHECK();
         CHECK(prof_end(c));
@@ -372,21 +422,26 @@ static int32_t rs_factor(const RsProblem &pr) {
   CHECK(status_reset(c));
   const int64_t K = (pr.n + DHQR_NBV - 1) / DHQR_NBV;
   int64_t ks = 0;
-  bool robust = false;
+  int level = 0;  // ladder for a rejected panel: Gram/Cholesky (0) -> TSQR tree (1) -> column by column (2)
   for (int pass = 0; ks < K; ++pass) {
-    if (pass > K + 2) return set_err(DHQR_EINVAL, "internal error: the row-split driver does not make progress");
+    if (pass > 2 * K + 2) return set_err(DHQR_EINVAL, "internal error: the row-split driver does not make progress");
     int failed = INT_MAX;
     int64_t nfast = 0;
-    CHECK(rs_run(pr, w, ks, robust, &failed, &nfast));
-    if (failed == INT_MAX) {
-      c->n_fast += nfast;
-      break;
-    }
-    c->n_fast += std::max<int64_t>(0, std::min<int64_t>(nfast, failed - ks));
-    c->n_fallback++;
+    CHECK(rs_run(pr, w, ks, level, &failed, &nfast));
+    const int64_t accepted = (failed == INT_MAX) ? nfast : std::max<int64_t>(0, std::min<int64_t>(nfast, failed - ks));
+    c->n_fast += accepted;
+    if (c->cholqr_passes == 3) c->n_tsqr += (int)accepted;
+    else if (level == 1 && accepted > 0) c->n_tsqr++;
+    if (failed == INT_MAX) break;
     CHECK(status_reset(c));
+    if (failed == ks && level >= 1) {
+      level = 2;  // the tree's R did not pass either: the reference's column-by-column algorithm
+    } else {
+      const bool rung = c->tsqr_rung == 1 || (c->tsqr_rung < 0 && pr.cm && pr.P > 1);
+      level = (c->cholqr_passes == 3 || !rung) ? 2 : 1;
+    }
+    if (level == 2) c->n_fallback++;
     ks = failed;
-    robust = true;
   }
   return DHQR_OK;
 }

@@ -86,6 +86,23 @@ int32_t dhqr_get_stats(dhqr_ctx *ctx, dhqr_stats *out); /* synchronises the ctx 
 /* Panels factored since the last dhqr_reset_stats() by the R-first fast path (csrc/dhqr_recon.h)
  * and panels whose verification failed and were redone by the column-by-column path. */
 int32_t dhqr_get_panel_counters(dhqr_ctx *ctx, int64_t *n_fast, int64_t *n_fallback);
+/* Where the R-first panel path takes its factors from (all drivers): 1 = Gram matrix + Cholesky, reflectors from the
+ * panel itself (default), 2 = CholeskyQR2, 3 = TSQR-HR (csrc/dhqr_tsqr.h: 256-row leaves, pairwise reduction of the
+ * 128 x 128 R factors -- across the ranks in the row-split driver --, explicit orthonormal Q back down the tree,
+ * reflectors from Q: accuracy independent of the panel's condition number).  A panel rejected by the on-device
+ * verification climbs the ladder 1 -> 2 (-> 3, see dhqr_set_tsqr_rung; row split: 1 -> 3) before it is redone column
+ * by column.  Environment: DHQR_CHOLQR_PASSES=2, DHQR_TSQR=1, DHQR_TSQR_RUNG=0/1.
+ * dhqr_get_tsqr_count: accepted panels that went through the tree since the last dhqr_reset_stats(). */
+int32_t dhqr_set_r_source(dhqr_ctx *ctx, int32_t source);
+/* The TSQR-HR rung of the ladder: on = 1 always, on = 0 never.  Default (neither called nor DHQR_TSQR_RUNG set): only in
+ * the row-split driver on more than one rank, where the column-by-column rung costs two collectives per column; on a
+ * single GPU the column kernels redo a panel faster than the tree. */
+int32_t dhqr_set_tsqr_rung(dhqr_ctx *ctx, int32_t on);
+/* The tree alone: R (128 x 128, column-major, upper triangular, zeros below) of a device-resident rows x 128 panel
+ * (leading dimension ldp), unique up to the sign of each row (the replay of csrc/dhqr_recon.h fixes the reference's
+ * signs R_jj = alpha_j when the tree feeds a factorisation).  Async on the ctx stream. */
+int32_t dhqr_tsqr_r_f64(dhqr_ctx *ctx, const double *dP, int64_t rows, int64_t ldp, double *dR);
+int32_t dhqr_get_tsqr_count(dhqr_ctx *ctx, int64_t *n_tsqr);
 
 /* ------------------------------------------------------------------ synthetic inputs
  * Replaces rand(T,m,n) / rand(T,m) of test/runtests.jl:45-46 with the portable counter-based

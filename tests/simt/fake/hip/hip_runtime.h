@@ -218,6 +218,38 @@ inline T __shfl_xor(T v, int mask, int width = 64) {
   return simt_shfl_bits(v, lane ^ mask);
 }
 
+// ---- DPP (v_mov_b32_dpp through __builtin_amdgcn_update_dpp) and v_readlane: wave-synchronous exchanges too.  The
+// controls the kernels use: quad_perm (0x00-0xFF), row_shr:n (0x111-0x11F), row_ror:n (0x121-0x12F), row_mirror (0x140),
+// row_half_mirror (0x141), row_bcast:15 (0x142), row_bcast:31 (0x143); bank_mask must be 0xf; disabled rows and lanes
+// without a source keep `old` (bound_ctrl = false).
+inline int simt_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  const int lane = simt::cur_tid() & 63, row = lane >> 4, r = lane & 15;
+  int s = -1;  // source lane, -1: none
+  if (ctrl >= 0x00 && ctrl <= 0xFF) s = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  else if (ctrl >= 0x111 && ctrl <= 0x11F) s = (r - (ctrl & 15) >= 0) ? lane - (ctrl & 15) : -1;
+  else if (ctrl >= 0x121 && ctrl <= 0x12F) s = (lane & ~15) | ((r - (ctrl & 15)) & 15);
+  else if (ctrl == 0x140) s = (lane & ~15) | (15 - r);
+  else if (ctrl == 0x141) s = (lane & ~7) | (7 - (lane & 7));
+  else if (ctrl == 0x142) s = (row >= 1) ? 16 * (row - 1) + 15 : -1;
+  else if (ctrl == 0x143) s = (row >= 2) ? 31 : -1;
+  const int got = simt_shfl_bits(src, s < 0 ? lane : s);  // every lane takes part in the exchange
+  if (bank_mask != 0xf) std::abort();
+  if (!((row_mask >> row) & 1)) return old;
+  if (s < 0) return bound_ctrl ? 0 : old;
+  return got;
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) simt_update_dpp(old, src, ctrl, rm, bm, bc)
+inline int simt_readlane(int v, int l) { return simt_shfl_bits(v, l); }
+#define __builtin_amdgcn_readlane(v, l) simt_readlane(v, l)
+inline int __double2loint(double d) { uint64_t b; std::memcpy(&b, &d, 8); return (int)(uint32_t)b; }
+inline int __double2hiint(double d) { uint64_t b; std::memcpy(&b, &d, 8); return (int)(uint32_t)(b >> 32); }
+inline double __hiloint2double(int hi, int lo) {
+  const uint64_t b = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+  double d;
+  std::memcpy(&d, &b, 8);
+  return d;
+}
+
 // ---- v_mfma_f64_16x16x4_f64, wave-synchronous like the instruction: every lane contributes one A and one
 // B element, D[i][j] += sum_k A[i][k] B[k][j] with the gfx950 operand maps documented in csrc/dhqr_gemm.h
 //   A: lane l holds A[i = l&15][k = l>>4]   B: lane l holds B[k = l>>4][j = l&15]
@@ -381,6 +413,11 @@ inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind
   std::memmove(d, s, n);
   return hipSuccess;
 }
+#define HIP_SYMBOL(x) (&(x))
+inline hipError_t hipMemcpyToSymbol(void *sym, const void *s, size_t n) { std::memmove(sym, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyFromSymbol(void *d, const void *sym, size_t n) { std::memmove(d, sym, n); return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1 };
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 100000; return hipSuccess; }
 inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height,
                                    hipMemcpyKind, hipStream_t) {
   for (size_t r = 0; r < height; ++r) std::memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width);

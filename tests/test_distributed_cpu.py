@@ -11,6 +11,7 @@
     path after a rejected panel, residual, solve -- everything of the multi-GPU path except RCCL and real streams;
  3. the row-split (BASELINE configs[4]) orchestration."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -54,6 +55,21 @@ def test_reference_darray_structure(m, n, P):
 def emu(emulated_so):
     from dist_helpers import load_emulated_library
     return load_emulated_library(emulated_so)
+
+
+class _env:
+    """environment switches read by dhqr_create (the rank contexts are created inside dhqr_mg_create)"""
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def _mg(emu, ndev):
@@ -102,10 +118,13 @@ def test_multi_device_handle_vs_oracle(emu, orc, ndev, m, n):
     assert emu.dhqr_mg_destroy(h) == 0
 
 
-def test_multi_device_host_drop_in_and_rejected_panel(emu, orc):
+@pytest.mark.parametrize("rung", [1, 0])
+def test_multi_device_host_drop_in_and_rejected_panel(emu, orc, rung):
     """qr!(A; ndev) host-in/host-out; two nearly dependent columns in the SECOND panel of the first pair: the device
-    verification rejects it, later updates become no-ops, the run resumes with the robust kernels (on 2 ranks)"""
-    h = _mg(emu, 2)
+    verification rejects it, later updates become no-ops, the run resumes with the robust ladder on 2 ranks: TSQR-HR
+    takes the panel (DHQR_TSQR_RUNG=1, no column-by-column fallback), or the column kernels do (column-split default)"""
+    with _env(**({"DHQR_TSQR_RUNG": 1} if rung else {})):
+        h = _mg(emu, 2)
     m, n = 600, 384
     A0 = orc.rand_matrix(m, n, 22)
     A0[:, 200] = A0[:, 199] * (1.0 + 1e-9)
@@ -116,7 +135,7 @@ def test_multi_device_host_drop_in_and_rejected_panel(emu, orc):
     st = emu.Stats()
     a_, b_ = ctypes.c_int64(), ctypes.c_int64()
     assert emu.dhqr_mg_get_stats(h, 1, ctypes.byref(st), ctypes.byref(a_), ctypes.byref(b_), None) == 0
-    assert b_.value >= 1  # rank 1 owns panel 1 and had to fall back
+    assert (b_.value == 0) if rung else (b_.value >= 1)  # rank 1 owns panel 1
     # `H \\ b` through the handle from a factored HOST matrix (well conditioned, shape change re-allocates)
     m, n = 500, 260
     A1 = orc.rand_matrix(m, n, 23)
@@ -214,9 +233,12 @@ def test_darray_layout_front_end(emulated_so, m, n, P):
 
 # ---------------------------------------------------------------- 3: row split (BASELINE configs[4]), emulated library
 # (ndev, m, n): diagonal blocks on several ranks (n > rows of rank 0); partial last panel; more ranks than row blocks
-@pytest.mark.parametrize("ndev,m,n", [(2, 1024, 384), (3, 1200, 300), (4, 500, 200)])
-def test_row_split_rank_threads_vs_oracle(emu, orc, ndev, m, n):
-    h = _mg(emu, ndev)
+# tsqr = 1: every panel through TSQR-HR (local trees, gather of the rank R factors, the cross-rank tree, explicit Q)
+@pytest.mark.parametrize("ndev,m,n,tsqr", [(2, 1024, 384, 0), (3, 1200, 300, 0), (4, 500, 200, 0),
+                                           (2, 640, 256, 1), (3, 700, 128, 1)])
+def test_row_split_rank_threads_vs_oracle(emu, orc, ndev, m, n, tsqr):
+    with _env(**({"DHQR_TSQR": 1} if tsqr else {})):
+        h = _mg(emu, ndev)
     assert emu.dhqr_mg_rs_alloc_f64(h, m, n) == 0, emu.dhqr_last_error()
     assert emu.dhqr_mg_rs_fill_uniform_f64(h, 31) == 0
     A0 = orc.rand_matrix(m, n, 31)
@@ -240,10 +262,14 @@ def test_row_split_rank_threads_vs_oracle(emu, orc, ndev, m, n):
     assert emu.dhqr_mg_destroy(h) == 0
 
 
-def test_row_split_rejected_panel_is_redone_column_by_column(emu, orc):
+@pytest.mark.parametrize("rung", [1, 0])
+def test_row_split_rejected_panel_climbs_the_ladder(emu, orc, rung):
     """two nearly dependent columns inside the second panel: every rank takes the same device-side decision, later
-    updates become no-ops, the panel is redone with the cross-rank column-by-column kernels, the run continues"""
-    h = _mg(emu, 2)
+    updates become no-ops, the panel is redone by TSQR-HR across the ranks (the row-split default on P > 1: three
+    collectives) or, with DHQR_TSQR_RUNG=0, by the cross-rank column-by-column kernels (two small collectives per
+    column); the run continues"""
+    with _env(**({} if rung else {"DHQR_TSQR_RUNG": 0})):
+        h = _mg(emu, 2)
     m, n = 1024, 384
     A0 = orc.rand_matrix(m, n, 22)
     A0[:, 200] = A0[:, 199] * (1.0 + 1e-9)
@@ -257,7 +283,7 @@ def test_row_split_rejected_panel_is_redone_column_by_column(emu, orc):
     st = emu.Stats()
     a_, b_ = ctypes.c_int64(), ctypes.c_int64()
     assert emu.dhqr_mg_get_stats(h, 0, ctypes.byref(st), ctypes.byref(a_), ctypes.byref(b_), None) == 0
-    assert b_.value >= 1
+    assert (b_.value == 0 and a_.value == 3) if rung else (b_.value >= 1)
     assert emu.dhqr_mg_destroy(h) == 0
 
 

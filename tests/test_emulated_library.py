@@ -29,6 +29,9 @@ def emu(emulated_so):
     return load_emulated_library(emulated_so)  # prototypes taken from the product binding (_lib.SIGNATURES)
 
 
+_SLOW = pytest.mark.skipif(os.environ.get("DHQR_SLOW") != "1", reason="extra configuration; set DHQR_SLOW=1")
+
+
 def _ctx(L, **env):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update({k: str(v) for k, v in env.items()})
@@ -94,7 +97,6 @@ def test_two_panel_driver_and_switches(emu, orc):
         emu.dhqr_destroy(h)
 
 
-_SLOW = pytest.mark.skipif(os.environ.get("DHQR_SLOW") != "1", reason="extra configuration; set DHQR_SLOW=1")
 
 
 @pytest.mark.parametrize("m,env", [(301, {}),                          # odd m: scalar (VEC = 1) loads everywhere
@@ -110,16 +112,76 @@ def test_panel_implementations_and_switches(emu, orc, m, env):
     emu.dhqr_destroy(h)
 
 
+def _tsqr_count(L, h):
+    a = ctypes.c_int64()
+    assert L.dhqr_get_tsqr_count(h, ctypes.byref(a)) == 0
+    return a.value
+
+
+@pytest.mark.parametrize("rows", [100, 300, 700])
+def test_tsqr_tree_r_factor(emu, rows):
+    """csrc/dhqr_tsqr.h alone: R of a rows x 128 panel through leaves of 256 rows and the pairwise reduction (odd leaf
+    counts, a short last leaf, fewer rows than columns) against LAPACK's R"""
+    h = _ctx(emu)
+    rng = np.random.default_rng(rows)
+    Pm = np.asfortranarray(rng.random((rows, 128)))
+    R = np.zeros((128, 128), order="F")
+    assert emu.dhqr_tsqr_r_f64(h, _ptr(Pm), rows, rows, _ptr(R)) == 0, emu.dhqr_last_error()
+    assert emu.dhqr_synchronize(h) == 0
+    Rl = np.linalg.qr(Pm, mode="r")
+    k = min(rows, 128)
+    assert np.abs(np.tril(R, -1)).max() == 0.0
+    # R is unique up to the sign of each row; the tree's signs depend on the leaf structure (every node applies the
+    # reference's rule alpha = -sign(pivot) norm to ITS pivot), the replay of dhqr_recon.h restores the reference's
+    sg = np.sign(np.diag(R)[:k]) * np.sign(np.diag(Rl)[:k])
+    assert np.all(np.abs(sg) == 1.0)
+    assert np.abs(sg[:, None] * R[:k] - Rl[:k]).max() <= 1e-13 * np.abs(Rl).max()
+    if rows < 128:
+        assert np.abs(R[rows:]).max() == 0.0
+    emu.dhqr_destroy(h)
+
+
+@pytest.mark.parametrize("m,n", [(300, 256), pytest.param(700, 512, marks=_SLOW)])
+def test_tsqr_as_the_r_source_of_every_panel(emu, orc, m, n):
+    """DHQR_TSQR=1: every R-first panel takes R from the tree, then the same replay / reconstruction"""
+    h = _ctx(emu, DHQR_TSQR=1)
+    A0 = orc.rand_matrix(m, n, 5)
+    A, al = _factor(emu, h, A0, 128)
+    _check(orc, A0, A, al)
+    fast, fb = _counters(emu, h)
+    assert fb == 0 and fast >= 1 and _tsqr_count(emu, h) == fast
+    emu.dhqr_destroy(h)
+
+
+@pytest.mark.parametrize("delta", [pytest.param(1e-6, marks=_SLOW), 1e-12])
+def test_tsqr_rung_of_the_fallback_ladder(emu, orc, delta):
+    """two nearly dependent columns inside panel 1 (kappa(panel) ~ 1e7 / 1e13): the Gram/Cholesky path must refuse the
+    panel (||v||^2 check, before anything is written); TSQR-HR -- Householder R from the tree, reflectors from the
+    explicit orthonormal Q -- takes it at full accuracy; the column-by-column kernels are never needed"""
+    h = _ctx(emu, DHQR_TSQR_RUNG=1)
+    m, n = 600, 384
+    A0 = orc.rand_matrix(m, n, 22)
+    A0[:, 200] = A0[:, 199] + delta * A0[:, 200]
+    A, al = _factor(emu, h, A0, 128)
+    fast, fb = _counters(emu, h)
+    assert fb == 0 and fast == 3 and _tsqr_count(emu, h) == 1, (fast, fb, _tsqr_count(emu, h))
+    QR = orc.form_qr(np.asfortranarray(A), al)
+    assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-14
+    v2 = (np.tril(A) ** 2).sum(axis=0)
+    assert np.abs(v2 - 2.0).max() < 1e-12
+    emu.dhqr_destroy(h)
+
+
 def test_ill_conditioned_panel_falls_back_and_stays_stable(emu, orc):
-    """two nearly dependent columns inside panel 1: the fast path must refuse the panel (||v||^2 check, before
-    anything is written), the column-by-column kernels redo it, the result is backward stable"""
+    """the same kind of panel without the TSQR rung (the single-GPU default): the column-by-column kernels redo it,
+    the result is backward stable"""
     h = _ctx(emu)
     m, n = 600, 384
     A0 = orc.rand_matrix(m, n, 22)
     A0[:, 200] = A0[:, 199] * (1.0 + 1e-9)
     A, al = _factor(emu, h, A0, 128)
     fast, fb = _counters(emu, h)
-    assert fb >= 1 and fast + fb >= 3
+    assert fb >= 1 and fast + fb >= 3 and _tsqr_count(emu, h) == 0
     QR = orc.form_qr(np.asfortranarray(A), al)
     assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-13
     emu.dhqr_destroy(h)

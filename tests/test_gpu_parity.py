@@ -202,8 +202,12 @@ def test_multi_device_handle_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
         mg.close()
 
 
-def test_multi_device_host_drop_in_and_rejected_panel_gpu(pkg, orc):
-    """qr!(A; ndev) host-in / host-out on 2 logical ranks, with a panel the device-side verification must reject"""
+@pytest.mark.parametrize("rung", [1, 0])
+def test_multi_device_host_drop_in_and_rejected_panel_gpu(pkg, orc, rung, monkeypatch):
+    """qr!(A; ndev) host-in / host-out on 2 logical ranks, with a panel the device-side verification must reject: it
+    is redone by TSQR-HR (DHQR_TSQR_RUNG=1: no column-by-column fallback) or by the column kernels (default)"""
+    if rung:
+        monkeypatch.setenv("DHQR_TSQR_RUNG", "1")  # read by dhqr_create of the rank contexts
     m, n = 1100, 768
     A0 = orc.rand_matrix(m, n, 22)
     A0[:, 300] = A0[:, 299] * (1.0 + 1e-9)   # second panel of the second pair
@@ -213,7 +217,8 @@ def test_multi_device_host_drop_in_and_rejected_panel_gpu(pkg, orc):
         A, al = mg.qr_(A)
         QR = orc.form_qr(np.asfortranarray(A), al)
         assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-13
-        assert sum(mg.stats(r)["panels_fallback"] for r in range(2)) >= 1
+        nfb = sum(mg.stats(r)["panels_fallback"] for r in range(2))
+        assert (nfb == 0) if rung else (nfb >= 1)
         A1 = orc.rand_matrix(900, 520, 23)
         Ho, ao = orc.householder(A1)
         F, al = mg.qr_(A1.copy(order="F"))
@@ -266,10 +271,51 @@ def test_tall_skinny_single_gpu(pkg, orc):
         assert pkg.residual(H, A0) < 1e-12
 
 
+def test_tsqr_tree_r_factor_gpu(pkg):
+    """csrc/dhqr_tsqr.h alone on the device: R of tall panels (odd leaf counts, a short last leaf) against LAPACK's
+    R up to the sign of each row"""
+    import ctypes
+    import torch
+    ctx = pkg.get_context(0)
+    L = pkg._lib.lib()
+    for rows in (200, 3000, 70000):
+        Pd = pkg.rand_colmajor(rows, 128, 100 + rows, "cuda:0")
+        R = pkg.empty_colmajor(128, 128, torch.device("cuda", 0))
+        ctx.use_torch_stream()
+        pkg._lib.check(L.dhqr_tsqr_r_f64(ctx.handle, ctypes.c_void_p(Pd.data_ptr()), rows, rows, ctypes.c_void_p(R.data_ptr())))
+        torch.cuda.synchronize()
+        Rg = R.cpu().numpy()
+        Rl = np.linalg.qr(Pd.cpu().numpy(), mode="r")
+        sg = np.sign(np.diag(Rg)) * np.sign(np.diag(Rl))
+        assert np.abs(np.tril(Rg, -1)).max() == 0.0 and np.all(np.abs(sg) == 1.0)
+        assert np.abs(sg[:, None] * Rg - Rl).max() <= 1e-12 * np.abs(Rl).max()
+
+
+@pytest.mark.parametrize("m,n", [(1500, 640), (9000, 300), (33000, 256)])
+def test_tsqr_hr_as_the_source_of_every_panel_gpu(pkg, orc, m, n):
+    """dhqr_set_r_source(ctx, 3): every R-first panel goes through TSQR-HR (tree R, explicit Q, reflectors from Q);
+    the reference's factorisation element by element, like the default path"""
+    import torch
+    ctx = pkg.get_context(0)
+    ctx.set_r_source(3)
+    try:
+        ctx.reset_stats()
+        H, A0 = _factor_dev(pkg, m, n, 31, 128)
+        fast, fb = ctx.panel_counters()
+        assert fb == 0 and fast >= 1 and ctx.tsqr_count() == fast
+        Ho, ao = orc.householder(orc.rand_matrix(m, n, 31))
+        scale = np.abs(Ho).max()
+        assert np.abs(H.A.cpu().numpy() - Ho).max() <= 1e-11 * scale
+        assert np.abs(H.α.cpu().numpy() - ao).max() <= 1e-11 * scale
+        assert pkg.residual(H, A0) < 1e-12
+    finally:
+        ctx.set_r_source(1)
+
+
 def test_fast_panel_path_is_used_and_falls_back(pkg, orc):
     """The R-first panel path must (a) actually run on well-conditioned input and (b) detect an
-    ill-conditioned panel (two nearly dependent columns), redo it with the column-by-column kernels
-    and still deliver a backward-stable factorisation."""
+    ill-conditioned panel (two nearly dependent columns) and redo it -- by TSQR-HR at full accuracy, or, with that
+    rung switched off, by the column-by-column kernels -- and still deliver a backward-stable factorisation."""
     import torch
     ctx = pkg.get_context(0)
     m, n = 1500, 640
@@ -283,11 +329,23 @@ def test_fast_panel_path_is_used_and_falls_back(pkg, orc):
     A[:, 200] = A[:, 199] * (1.0 + 1e-9)
     A0 = A.clone()
     Ah = A0.cpu().numpy()
+    ctx.set_tsqr_rung(True)
+    try:
+        ctx.reset_stats()
+        H = pkg.qr_(A.clone(), nb=128)
+        torch.cuda.synchronize()
+        fast, fb = ctx.panel_counters()
+        assert fb == 0 and fast == 5 and ctx.tsqr_count() == 1, (fast, fb, ctx.tsqr_count())
+        assert pkg.residual(H, A0) < 1e-13
+        v2 = (torch.tril(H.A) ** 2).sum(dim=0)
+        assert float((v2 - 2).abs().max()) < 1e-12
+    finally:
+        ctx.set_tsqr_rung(False)  # the single-GPU default: straight to the column kernels
     ctx.reset_stats()
     H = pkg.qr_(A, nb=128)
     torch.cuda.synchronize()
     fast, fb = ctx.panel_counters()
-    assert fb >= 1, (fast, fb)
+    assert fb >= 1 and ctx.tsqr_count() == 0, (fast, fb)
     assert pkg.residual(H, A0) < 1e-12
     Ho, ao = orc.householder(np.asfortranarray(Ah))
     # R agrees with the oracle where it is well determined (|R| not tiny)
@@ -342,10 +400,14 @@ def test_row_split_driver_single_rank(pkg, orc, m, n):
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
 
 
-@pytest.mark.parametrize("ranks,m,n", [(2, 6000, 512), (2, 16384, 1024), (8, 16384, 2048), (3, 3000, 1100)])
-def test_row_split_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
+@pytest.mark.parametrize("ranks,m,n,tsqr", [(2, 6000, 512, 0), (2, 16384, 1024, 0), (8, 16384, 2048, 0), (3, 3000, 1100, 0),
+                                            (2, 6000, 512, 1), (8, 16384, 1024, 1), (3, 3000, 1100, 1)])
+def test_row_split_logical_ranks_one_gpu(pkg, orc, ranks, m, n, tsqr, monkeypatch):
     """dhqr_mg_rs_* with `ranks` rank threads on cuda:0 (in-process transport): diagonal blocks move from rank to
-    rank when n exceeds a rank's rows ((8, 16384, 2048): 2048 rows per rank), partial last panel ((3, 3000, 1100))"""
+    rank when n exceeds a rank's rows ((8, 16384, 2048): 2048 rows per rank), partial last panel ((3, 3000, 1100)).
+    tsqr = 1: every panel through TSQR-HR across the ranks (local trees, gather, cross-rank tree up and down)."""
+    if tsqr:
+        monkeypatch.setenv("DHQR_TSQR", "1")  # read by dhqr_create of the rank contexts
     mg = pkg.MultiGpuQR(devices=[0] * ranks)
     try:
         mg.rs_alloc(m, n).rs_fill(43)
@@ -368,9 +430,13 @@ def test_row_split_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
         mg.close()
 
 
-def test_row_split_rejected_panel_gpu(pkg, orc):
-    """a numerically rank-deficient panel: the fast path is refused on every rank (same all-reduced S), the panel is
-    redone column by column across the ranks instead of raising (round-1 behaviour)"""
+@pytest.mark.parametrize("rung", [1, 0])
+def test_row_split_rejected_panel_gpu(pkg, orc, rung, monkeypatch):
+    """a numerically rank-deficient panel: the fast path is refused on every rank (same all-reduced S); the panel is
+    redone by TSQR-HR across the ranks (row-split default on P > 1) or column by column across the ranks
+    (DHQR_TSQR_RUNG=0)"""
+    if not rung:
+        monkeypatch.setenv("DHQR_TSQR_RUNG", "0")
     m, n = 8192, 512
     A0 = orc.rand_matrix(m, n, 22)
     A0[:, 300] = A0[:, 299] * (1.0 + 1e-9)
@@ -380,7 +446,8 @@ def test_row_split_rejected_panel_gpu(pkg, orc):
         H, al = mg.rs_download()
         QR = orc.form_qr(np.asfortranarray(H), al)
         assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-13
-        assert mg.stats(0)["panels_fallback"] >= 1
+        st = mg.stats(0)
+        assert (st["panels_fallback"] == 0 and st["panels_fast"] == 4) if rung else (st["panels_fallback"] >= 1)
     finally:
         mg.close()
 
