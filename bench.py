@@ -384,8 +384,9 @@ def main():
                                           "launches", "avg_launch_ms")} if dom else None),
         "roofline_all": rl_all,
         "traffic_note": "HBM bytes per launch (read + write) from rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE, separate "
-                        "passes, profiles/r02_pmc_traffic.json; algorithmic C bytes per wide two-panel launch: 2.88 GB (NN: read + "
-                        "write) / 1.44 GB (TN: read) -> measured 4.03 / 1.78 GB",
+                        "passes, profiles/r02_pmc_traffic.json (collected before the NN kernel streamed its C tile; the "
+                        "bytes per launch are unchanged by that); algorithmic C bytes per wide two-panel launch: 2.88 GB (NN: "
+                        "read + write) / 1.44 GB (TN: read) -> measured 4.03 / 1.78 GB",
         "phase_ms_per_step": {k: st[k] / args.steps for k in st if k.startswith("ms_") and st[k] > 0},
         "panels_fast_fallback": panel_counts,
     }
@@ -406,6 +407,15 @@ def main():
                                             "(16 AGPR accumulators per wave issue at half rate: %.1f TFLOP/s)"
                                             % pkg.bench_mfma_tflops(local_rank))
             out["stream_ubench_gbps"] = pkg.bench_stream_gbps(1 << 30, local_rank)
+            # the wide kernels alone on synthetic operands of the first (largest) update + the shader clock under them
+            g4 = (_ct.c_double * 4)()
+            iso = {}
+            for kind, name in ((0, "k_gemm_nn_sub K=256"), (1, "k_gemm_tn2")):
+                pkg._lib.check(pkg._lib.lib().dhqr_bench_gemm_f64(ctx.handle, kind, 16384, 16384, 3, g4))
+                iso[name] = {"tflops": g4[1], "frac_of_peak": g4[1] / PEAK_FP64_MFMA_TFLOPS, "shader_mhz": g4[2]}
+            out["gemm_kernels_in_isolation_16384"] = iso
+            out["power_note"] = ("rocm-smi while the kernels run (profiles/r02_power_telemetry.txt): MFMA-only loop 924 W, "
+                                 "k_gemm_tn2 1164 W, k_gemm_nn_sub 1245 W (peaks 1327 W) of the 1400 W cap at 2.38-2.39 GHz")
         except Exception as e:  # diagnostics only
             out["ubench_error"] = repr(e)
         if not args.no_cpu_baseline:
