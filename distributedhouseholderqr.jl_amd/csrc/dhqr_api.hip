@@ -80,6 +80,7 @@ struct dhqr_ctx {
   double recon_tol = 2e-12;  // accepted deviation of ||v_j||^2 from 2 before falling back
   int ib = DHQR_IB;
   struct CsState *cs = nullptr;  // streams / events / group buffers of the blocked driver (dhqr_dist.h)
+  struct RsState *rs = nullptr;  // events / group ring of the row-split driver (dhqr_rowsplit.h)
   // profiling
   struct Ev { hipEvent_t a, b; int cat; };
   std::vector<Ev> evs;
@@ -740,10 +741,15 @@ static int32_t factor_panel_sync(dhqr_ctx *c, double *P, int64_t rows, int64_t w
 // Vp = [V_a | V_b] (ldv x 256; V_b shifted down by 128 rows, zeros above), rows = rows of panel a.
 // Halves the C read+write traffic of the NN GEMM per flop (0.125 -> 0.094 B/flop through the CU
 // memory pipe), which is what bounds k_gemm_nn_sub; the TN pass (k_gemm_tn2) reads C once for both panels.
+// ar / rows_b_in (row split, dhqr_rowsplit.h): Y is summed over the ranks of `ar` before T is applied (the "all-reduce of
+// the cross-partition partial dots"), and V_b may start fewer than 128 rows below V_a on a rank that does not hold
+// the pair's diagonal blocks (statistics only).
+static int32_t comm_allreduce_sum(dhqr_comm *cm, double *dbuf, int64_t count, hipStream_t stream);
 static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows, const double *Ta,
-                          const double *Tb, const double *Sba, double *C, int64_t ncols, int64_t ldc) {
+                          const double *Tb, const double *Sba, double *C, int64_t ncols, int64_t ldc,
+                          dhqr_comm *ar = nullptr, int64_t rows_b_in = -1) {
   if (ncols <= 0) return DHQR_OK;
-  const int64_t rows_b = rows - DHQR_NBV;
+  const int64_t rows_b = rows_b_in >= 0 ? rows_b_in : rows - DHQR_NBV;
   const int64_t ntiles = (ncols + 127) / 128;
   int64_t nsplit, rps;
   // k_gemm_tn2 workgroups have 512 threads and 110 KB of LDS: one per CU, 256 resident
@@ -770,6 +776,7 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   CHECK(prof_end(c));
 
   CHECK(prof_begin(c, CAT_TW));
+  if (ar) CHECK(comm_allreduce_sum(ar, ws.w1r.p, wstride, c->stream));
   double *Ya = ws.w1r.p, *Yb = ws.w1r.p + DHQR_NBV;  // rows 0..127 / 128..255 of Y (ld 256)
   // W_a = T_a' Y_a  -> rows 0..127 of W2 (ld 256)
   hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Ta, (int64_t)DHQR_NBV,
@@ -999,6 +1006,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   (void)hipDeviceSynchronize();
   cs_state_free(c);
+  rs_state_free(c);
   Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
                  &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq};
   for (Buf *b : bufs)
@@ -1313,26 +1321,70 @@ int32_t dhqr_factor_c64_nb(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_
   CHECK(check_mat(dA, m, n, lda, true));
   CHECK(check_zptr(dA, "matrix"));
   CHECK(check_zptr(dalpha, "alpha"));
-  const int64_t ZB = DHQR_ZNB;
-  CHECK(ensure(c, c->vt, (size_t)panel_elems(2 * m)));
-  for (int64_t c0 = 0; c0 < n; c0 += ZB) {
-    const int64_t w = std::min<int64_t>(ZB, n - c0), rows = m - c0;
+  const int64_t ZB = DHQR_ZNB, K = (n + ZB - 1) / ZB;
+  // Look-ahead (same structure as the Float64 driver, dhqr_dist.h): the high-priority lane applies panel k to the 64
+  // columns of panel k+1 only and factors them (64 latency-bound rank-1 launches) while the caller's stream applies panel k
+  // to everything beyond.  Two operand buffers: panel k+2 is packed only after the wide update of panel k has finished.
+  const bool la = c->lookahead && K >= 3;
+  CHECK(cs_state_init(c));
+  CsState &S = *c->cs;
+  const size_t pe = (size_t)panel_elems(2 * m);
+  CHECK(ensure(c, c->vt, (la ? 2 : 1) * pe));
+  hipStream_t sW = c->stream, sL = la ? c->hi : c->stream;
+  auto on = [&](hipStream_t s, int wsi) { c->stream = s; c->cur_ws = wsi; };
+  auto factor_and_pack = [&](int64_t k) -> int32_t {  // on c->stream: src:122-148,171-213 inside the panel, then V / T
+    const int64_t c0 = k * ZB, w = std::min<int64_t>(ZB, n - c0), rows = m - c0;
     double *P = dA + 2 * (c0 + c0 * lda);
-    CHECK(dhqr_factor_c64(c, P, rows, w, lda, dalpha + 2 * c0));  // src:122-148,171-213 inside the panel
-    const int64_t ncols = n - c0 - w;
-    if (ncols <= 0) break;
-    const PanelBuf pb = vt_view(c->vt.p, 2 * rows);
+    CHECK(dhqr_factor_c64(c, P, rows, w, lda, dalpha + 2 * c0));
+    if (c0 + w >= n) return DHQR_OK;
+    const PanelBuf pb = vt_view(c->vt.p + (la ? (size_t)(k & 1) * pe : 0), 2 * rows);
     const int64_t npad = panel_ldv(2 * rows);
     CHECK(prof_begin(c, CAT_TBUILD));
-    {
-      dim3 grid((unsigned)std::min<int64_t>((npad / 2 + 255) / 256, 64), (unsigned)ZB);
-      hipLaunchKernelGGL(k_zpack_emb, grid, dim3(256), 0, c->stream, reinterpret_cast<const double2 *>(P), lda, rows, (int)w,
-                         pb.V, pb.ldv, npad);
-    }
+    dim3 grid((unsigned)std::min<int64_t>((npad / 2 + 255) / 256, 64), (unsigned)ZB);
+    hipLaunchKernelGGL(k_zpack_emb, grid, dim3(256), 0, c->stream, reinterpret_cast<const double2 *>(P), lda, rows, (int)w, pb.V,
+                       pb.ldv, npad);
     CHECK(panel_build_t(c, 2 * rows, -2 * w, pb));  // negative: strict upper part at the 2 x 2 block level
-    CHECK(prof_end(c));
-    CHECK(panel_apply(c, pb, 2 * rows, dA + 2 * (c0 + (c0 + w) * lda), ncols, 2 * lda, 1));
-  }
+    return prof_end(c);
+  };
+  auto apply = [&](int64_t k, int64_t col0, int64_t ncols) -> int32_t {  // panel k -> columns [col0, col0 + ncols)
+    if (ncols <= 0) return DHQR_OK;
+    const int64_t c0 = k * ZB, rows = m - c0;
+    const PanelBuf pb = vt_view(c->vt.p + (la ? (size_t)(k & 1) * pe : 0), 2 * rows);
+    return panel_apply(c, pb, 2 * rows, dA + 2 * (c0 + col0 * lda), ncols, 2 * lda, 1);
+  };
+  auto body = [&]() -> int32_t {
+    if (!la) {
+      for (int64_t k = 0; k < K; ++k) {
+        CHECK(factor_and_pack(k));
+        CHECK(apply(k, (k + 1) * ZB, n - (k + 1) * ZB));
+      }
+      return DHQR_OK;
+    }
+    HIPCHECK(hipEventRecord(S.ev_start, sW));
+    HIPCHECK(hipStreamWaitEvent(sL, S.ev_start, 0));
+    on(sL, 1);
+    CHECK(factor_and_pack(0));
+    HIPCHECK(hipEventRecord(S.ev_group[0], sL));
+    for (int64_t k = 0; k + 1 < K; ++k) {
+      const int64_t c1 = (k + 1) * ZB, w1 = std::min<int64_t>(ZB, n - c1);
+      on(sW, 0);  // wide: panel k -> the columns beyond panel k+1
+      HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[k % CS_EVR], 0));
+      CHECK(apply(k, c1 + w1, n - c1 - w1));
+      HIPCHECK(hipEventRecord(S.ev_wide[k % CS_EVR], sW));
+      on(sL, 1);  // lane: panel k -> the columns of panel k+1 (complete up to panel k-1 once wide(k-1) is done), factor it
+      if (k >= 1) HIPCHECK(hipStreamWaitEvent(sL, S.ev_wide[(k - 1) % CS_EVR], 0));
+      CHECK(apply(k, c1, w1));
+      CHECK(factor_and_pack(k + 1));
+      HIPCHECK(hipEventRecord(S.ev_group[(k + 1) % CS_EVR], sL));
+    }
+    on(sW, 0);
+    HIPCHECK(hipEventRecord(S.ev_end, sL));
+    HIPCHECK(hipStreamWaitEvent(sW, S.ev_end, 0));
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  on(sW, 0);
+  CHECK(rc);
   LAUNCHCHECK();
   return DHQR_OK;
 }
@@ -1873,6 +1925,10 @@ int32_t dhqr_debug_mfma_probe(dhqr_ctx *c, const double *da, const double *db, d
 
 
 // ============================================================ multi-GPU: communicators (dhqr_comm.h)
+static bool lane_channel_wanted() {  // DHQR_LANE_CHANNEL=0: the row-split lane shares the wide stream's channel
+  const char *e = getenv("DHQR_LANE_CHANNEL");
+  return !(e && atoi(e) == 0);
+}
 static int32_t comm_new(dhqr_comm **out, dhqr_ctx *c, int kind, int nranks, int rank) {
   dhqr_comm *cm = new dhqr_comm();
   cm->ctx = c;
@@ -1908,6 +1964,29 @@ int32_t dhqr_comm_create_rank(dhqr_comm **out, dhqr_ctx *c, int32_t nranks, int3
   RCCLCHECK(g_rccl.CommInitRank(&nc, nranks, id, rank));
   CHECK(comm_new(out, c, COMM_RCCL, nranks, rank));
   (*out)->nccl = nc;
+  // second channel for the look-ahead lane of the row-split driver: rank 0 draws another unique id and ships it over
+  // the first communicator (no change for the host layer)
+  if (lane_channel_wanted()) {
+    ncclUniqueId id2;
+    memset(&id2, 0, sizeof(id2));
+    if (rank == 0) RCCLCHECK(g_rccl.GetUniqueId(&id2));
+    void *dbuf = nullptr;
+    HIPCHECK(hipMalloc(&dbuf, sizeof(id2)));
+    auto ship = [&]() -> int32_t {
+      HIPCHECK(hipMemcpyAsync(dbuf, &id2, sizeof(id2), hipMemcpyHostToDevice, c->stream));
+      RCCLCHECK(g_rccl.Broadcast(dbuf, dbuf, sizeof(id2), ncclChar, 0, nc, c->stream));
+      HIPCHECK(hipMemcpyAsync(&id2, dbuf, sizeof(id2), hipMemcpyDeviceToHost, c->stream));
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      return DHQR_OK;
+    };
+    const int32_t rc = ship();
+    (void)hipFree(dbuf);
+    CHECK(rc);
+    ncclComm_t nc2 = nullptr;
+    RCCLCHECK(g_rccl.CommInitRank(&nc2, nranks, id2, rank));
+    CHECK(comm_new(&(*out)->lane, c, COMM_RCCL, nranks, rank));
+    (*out)->lane->nccl = nc2;
+  }
   return DHQR_OK;
 }
 
@@ -2122,6 +2201,27 @@ int32_t dhqr_mg_create(dhqr_mg **out, const int32_t *devices, int32_t ndev) {
       CHECK(comm_new(&g->rk[r].cm, g->rk[r].c, want, ndev, r));
       g->rk[r].cm->nccl = nc[r];
       g->rk[r].cm->world = w;
+    }
+    if (ndev > 1 && lane_channel_wanted()) {  // second channel (look-ahead lane of the row-split driver)
+      std::vector<ncclComm_t> nc2(ndev, nullptr);
+      LocalWorld *w2 = nullptr;
+      bool ok = true;
+      if (want == COMM_RCCL) {
+        const ncclResult_t r = g_rccl.CommInitAll(nc2.data(), ndev, g->dev.data());
+        if (r != ncclSuccess) {
+          ok = false;
+          fprintf(stderr, "libdhqr: second ncclCommInitAll failed (%s); the lane shares the first channel\n", g_rccl.GetErrorString(r));
+        }
+      } else {
+        CHECK(local_world_create(&w2, g->dev.data(), ndev));
+        w2->refs.store(ndev);
+      }
+      if (ok)
+        for (int r = 0; r < ndev; ++r) {
+          CHECK(comm_new(&g->rk[r].cm->lane, g->rk[r].c, want, ndev, r));
+          g->rk[r].cm->lane->nccl = nc2[r];
+          g->rk[r].cm->lane->world = w2;
+        }
     }
     g->transport = want;
     for (int r = 0; r < ndev; ++r) g->rk[r].th = std::thread(mg_worker, g, r);

@@ -126,6 +126,10 @@ struct dhqr_comm {
   dhqr_allreduce_fn cb_allreduce = nullptr;
   void *cb_user = nullptr;
   int64_t bytes_bcast = 0, n_bcast = 0;  // statistics
+  // Second channel over the same ranks (own RCCL communicator / own mailbox): the row-split driver's look-ahead lane
+  // issues its small latency-bound collectives here so they do not queue behind the wide stream's all-reduces (the
+  // operations of ONE channel are ordered).  nullptr: CALLBACK transport (host synchronous anyway) or a single rank.
+  dhqr_comm *lane = nullptr;
 };
 
 __global__ __launch_bounds__(256) void k_sum_ranks(const double *__restrict__ part, int nranks, int64_t stride,
@@ -293,10 +297,13 @@ static int32_t comm_host_barrier(dhqr_comm *cm) {
 
 static void comm_abort(dhqr_comm *cm) {
   if (cm && cm->world) cm->world->abort.store(1);
+  if (cm && cm->lane && cm->lane->world) cm->lane->world->abort.store(1);
 }
 
 static int32_t comm_free(dhqr_comm *cm) {
   if (!cm) return DHQR_OK;
+  if (cm->lane) (void)comm_free(cm->lane);
+  cm->lane = nullptr;
   if (cm->ctx) (void)hipSetDevice(cm->ctx->device);
   if (cm->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(cm->nccl);
   if (cm->scratch) (void)hipFree(cm->scratch);

@@ -113,33 +113,100 @@ __global__ void k_rs_get_breakdown(int *__restrict__ stat, double *__restrict__ 
   }
 }
 
+// ---- state of the grouped / look-ahead driver ------------------------------------------------------------------
+// Ring slot = operands of one group (a PAIR of panels applied in one K = 256 pass, or a single panel):
+//   [ V : ldv x 256 = [V_a | V_b] | T_a | T_a' | T_b | T_b' | S2 = [V_b'V_a | V_b'V_b] | bc_a | bc_b ]
+// V_b sits `shift` rows below V_a (zeros above): 128 on the rank that holds the pair's diagonal blocks, 0 on a rank
+// whose rows all lie below them.  bc_x = [-M^{-1} (128 x 128) | alpha (128) | breakdown word ...] is what the owner of
+// the diagonal rows broadcasts per panel.
+#define RS_RING 2
+#define RS_BC ((size_t)DHQR_NBV * DHQR_NBV + 256)
+struct RsState {
+  bool init = false;
+  hipEvent_t ev_group[2 * RS_RING], ev_wide[2 * RS_RING], ev_start = nullptr, ev_end = nullptr;
+  Buf ring[RS_RING];
+  int64_t ticket[RS_RING][2];  // LOCAL transport: the broadcast this rank rooted out of bc_x (its readers must be done)
+};
+struct RsSlot {
+  double *V, *T[2], *Tt[2], *S2, *bc[2];
+};
+static inline size_t rs_slot_elems(int64_t ldv) {
+  return (size_t)ldv * 2 * DHQR_NBV + 6 * (size_t)DHQR_NBV * DHQR_NBV + 2 * RS_BC;
+}
+static inline RsSlot rs_slot_view(double *base, int64_t ldv) {
+  const size_t NN = (size_t)DHQR_NBV * DHQR_NBV;
+  RsSlot s;
+  s.V = base;
+  double *t = base + (size_t)ldv * 2 * DHQR_NBV;
+  s.T[0] = t;
+  s.Tt[0] = t + NN;
+  s.T[1] = t + 2 * NN;
+  s.Tt[1] = t + 3 * NN;
+  s.S2 = t + 4 * NN;
+  s.bc[0] = t + 6 * NN;
+  s.bc[1] = t + 6 * NN + RS_BC;
+  return s;
+}
+static int32_t rs_state_init(dhqr_ctx *c) {
+  if (!c->rs) c->rs = new RsState();
+  RsState &s = *c->rs;
+  if (s.init) return DHQR_OK;
+  for (int i = 0; i < 2 * RS_RING; ++i) {
+    HIPCHECK(hipEventCreateWithFlags(&s.ev_group[i], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&s.ev_wide[i], hipEventDisableTiming));
+  }
+  HIPCHECK(hipEventCreateWithFlags(&s.ev_start, hipEventDisableTiming));
+  HIPCHECK(hipEventCreateWithFlags(&s.ev_end, hipEventDisableTiming));
+  for (int i = 0; i < RS_RING; ++i) s.ticket[i][0] = s.ticket[i][1] = -1;
+  s.init = true;
+  return DHQR_OK;
+}
+static void rs_state_free(dhqr_ctx *c) {
+  if (!c->rs) return;
+  RsState &s = *c->rs;
+  if (s.init) {
+    for (int i = 0; i < 2 * RS_RING; ++i) {
+      (void)hipEventDestroy(s.ev_group[i]);
+      (void)hipEventDestroy(s.ev_wide[i]);
+    }
+    (void)hipEventDestroy(s.ev_start);
+    (void)hipEventDestroy(s.ev_end);
+  }
+  for (Buf &b : s.ring)
+    if (b.p) (void)hipFree(b.p);
+  delete c->rs;
+  c->rs = nullptr;
+}
+
 struct RsWork {  // device workspaces of one rank (views into ctx buffers)
-  double *Vw;    // ldv x 128
+  double *Vw;    // ldv x 128: V operand of a re-applied panel (residual, solve, resume) = ring slot 0
   int64_t ldv;
-  double *G, *S, *Rref, *T, *Tt, *bc, *W1, *W2, *altmp, *part;
+  double *G, *S, *Rref, *T, *Tt, *bc, *altmp, *part;
+  RsSlot slot[RS_RING];
 };
 
 static int32_t rs_prepare(const RsProblem &pr, RsWork *w) {
   dhqr_ctx *c = pr.c;
   const int64_t NB = DHQR_NBV;
   const size_t NN = (size_t)NB * NB;
+  CHECK(rs_state_init(c));
   w->ldv = panel_ldv(std::max<int64_t>(pr.mloc, 1));
-  CHECK(ensure(c, c->vts, (size_t)w->ldv * NB + 1024));
+  for (int i = 0; i < RS_RING; ++i) CHECK(ensure(c, c->rs->ring[i], rs_slot_elems(w->ldv)));
   CHECK(ensure(c, c->rbuf, 8 * NN + 4096));
-  CHECK(ensure(c, c->ws[0].w1r, (size_t)NB * std::max<int64_t>(pr.n, NB)));
-  CHECK(ensure(c, c->ws[0].w2, (size_t)NB * std::max<int64_t>(pr.n, NB)));
-  CHECK(ensure(c, c->spart, (size_t)256 * NN));
+  // split-K partials / reduced Y / W of the two streams (nothing is reallocated while they run): [0] wide, [1] lane
+  const size_t ncmax = (size_t)std::max<int64_t>(pr.n, 2 * NB), ntmax = (ncmax + 127) / 128;
+  for (int s = 0; s < 2; ++s) {
+    CHECK(ensure(c, c->ws[s].w1, s == 0 ? NN * (2048 + 2 * ntmax + 128) : NN * 2200));
+    CHECK(ensure(c, c->ws[s].w1r, 2 * NB * ncmax));
+    CHECK(ensure(c, c->ws[s].w2, 2 * NB * ncmax));
+  }
+  CHECK(ensure(c, c->spart, (size_t)512 * NN));
   CHECK(ensure(c, c->sfull, NN));
   CHECK(ensure(c, c->scratch, 4096));
   const size_t nblk = (size_t)((pr.mloc + 1023) / 1024 + 1);
   CHECK(ensure(c, c->pbuf, nblk * NB + 1024));
-  {
-    const int64_t ntiles = (pr.n + 127) / 128;
-    int64_t ns, rps;
-    pick_split(std::max<int64_t>(pr.mloc, 128), ntiles, 512, ntiles <= 2 ? 256 : 64, &ns, &rps);
-    CHECK(ensure(c, c->ws[0].w1, (size_t)(ns + 1) * NB * (size_t)std::max<int64_t>(pr.n, NB)));
-  }
-  w->Vw = c->vts.p;
+  for (int i = 0; i < RS_RING; ++i) w->slot[i] = rs_slot_view(c->rs->ring[i].p, w->ldv);
+  w->Vw = w->slot[0].V;
   double *r = c->rbuf.p;
   w->G = r;
   w->S = r + NN;
@@ -148,85 +215,121 @@ static int32_t rs_prepare(const RsProblem &pr, RsWork *w) {
   w->Tt = r + 4 * NN;
   w->bc = r + 5 * NN;        // [-M^{-1} (NN) | alpha (128) | breakdown word | ...]
   w->altmp = r + 5 * NN + NN;
-  w->W1 = c->ws[0].w1r.p;
-  w->W2 = c->ws[0].w2.p;
   w->part = c->pbuf.p;
   return DHQR_OK;
 }
 
-// W1 (128 x ncols, ld 128) = Vw' C over the local active rows, summed over the ranks
-static int32_t rs_vtc_allreduce(const RsProblem &pr, const RsWork &w, const double *C, int64_t ldc, int64_t rows,
-                                int64_t ncols) {
+// Y (128 x ncols, ld 128, in the current workspace's w1r) = V' C over the local active rows, summed over the ranks of cmx
+static int32_t rs_vtc_allreduce(const RsProblem &pr, dhqr_comm *cmx, const double *V, int64_t ldv, const double *C,
+                                int64_t ldc, int64_t rows, int64_t ncols) {
   dhqr_ctx *c = pr.c;
+  dhqr_ctx::WS &ws = c->ws[c->cur_ws];
   const int64_t NB = DHQR_NBV, wstride = NB * ncols;
+  CHECK(ensure(c, ws.w1r, (size_t)wstride));
   if (rows <= 0) {
-    HIPCHECK(hipMemsetAsync(w.W1, 0, (size_t)wstride * sizeof(double), c->stream));
+    HIPCHECK(hipMemsetAsync(ws.w1r.p, 0, (size_t)wstride * sizeof(double), c->stream));
   } else {
     const int64_t ntiles = (ncols + 127) / 128;
     int64_t nsplit, rps;
     pick_split(rows, ntiles, 512, ntiles <= 2 ? 256 : 64, &nsplit, &rps);
-    CHECK(ensure(c, c->ws[0].w1, (size_t)nsplit * NB * (size_t)ncols));
-    const bool vec = (ldc % 2 == 0) && (w.ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(w.Vw);
+    CHECK(ensure(c, ws.w1, (size_t)nsplit * NB * (size_t)ncols));
+    const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(V);
     const dim3 gtn((unsigned)ntiles, (unsigned)nsplit);
     if (vec)
-      hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), gtn, dim3(256), 0, c->stream, (const double *)w.Vw, w.ldv, C, ldc, 1,
-                         (int64_t)0, rows, ncols, rps, c->ws[0].w1.p, NB, wstride);
+      hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), gtn, dim3(256), 0, c->stream, V, ldv, C, ldc, 1, (int64_t)0, rows, ncols, rps,
+                         ws.w1.p, NB, wstride);
     else
-      hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), gtn, dim3(256), 0, c->stream, (const double *)w.Vw, w.ldv, C, ldc, 1,
-                         (int64_t)0, rows, ncols, rps, c->ws[0].w1.p, NB, wstride);
+      hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), gtn, dim3(256), 0, c->stream, V, ldv, C, ldc, 1, (int64_t)0, rows, ncols, rps,
+                         ws.w1.p, NB, wstride);
     hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)((wstride + 63) / 64)), dim3(256), 0, c->stream,
-                       (const double *)c->ws[0].w1.p, (int)nsplit, wstride, wstride, w.W1);
+                       (const double *)ws.w1.p, (int)nsplit, wstride, wstride, ws.w1r.p);
   }
   LAUNCHCHECK();
-  if (pr.cm && pr.P > 1) CHECK(comm_allreduce_sum(pr.cm, w.W1, wstride, c->stream));
+  if (cmx && cmx->nranks > 1) CHECK(comm_allreduce_sum(cmx, ws.w1r.p, wstride, c->stream));
   return DHQR_OK;
 }
-// C (rows x ncols) -= Vw (op(T)' W1): W2 = Top' W1, then the NN GEMM (predicated when `pred`)
-static int32_t rs_apply_w(const RsProblem &pr, const RsWork &w, const double *Top, double *C, int64_t ldc, int64_t rows,
-                          int64_t ncols, bool pred) {
+// C (rows x ncols) -= V (op(T)' Y): W = Top' Y, then the NN GEMM (predicated when `pred`)
+static int32_t rs_apply_w(const RsProblem &pr, const double *V, int64_t ldv, const double *Top, double *C, int64_t ldc,
+                          int64_t rows, int64_t ncols, bool pred) {
   dhqr_ctx *c = pr.c;
+  dhqr_ctx::WS &ws = c->ws[c->cur_ws];
   const int64_t NB = DHQR_NBV, ntiles = (ncols + 127) / 128;
-  hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top, NB, (const double *)w.W1,
-                     NB, 1, (int64_t)0, NB, ncols, NB, w.W2, NB, (int64_t)0);
+  CHECK(ensure(c, ws.w2, (size_t)NB * (size_t)ncols));
+  hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top, NB,
+                     (const double *)ws.w1r.p, NB, 1, (int64_t)0, NB, ncols, NB, ws.w2.p, NB, (int64_t)0);
   if (rows > 0) {
-    const bool vec = (ldc % 2 == 0) && (w.ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(w.Vw);
-    dim3 grid((unsigned)((rows + 127) / 128), (unsigned)ntiles);
-    launch_nn_sub<128>(c, vec, grid, w.Vw, w.ldv, (const double *)w.W2, NB, C, ldc, rows, ncols, 0, pred);
+    const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(V);
+    const int64_t gx = (rows + 127) / 128;
+    const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
+    dim3 grid((unsigned)gx, (unsigned)ntiles);
+    if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
+    launch_nn_sub<128>(c, vec, grid, V, ldv, (const double *)ws.w2.p, NB, C, ldc, rows, ncols, swz, pred);
   }
   LAUNCHCHECK();
   return DHQR_OK;
 }
-// S = sum over ranks of Vw' Vw
-static int32_t rs_gram_allreduce(const RsProblem &pr, const double *X, int64_t ldx, int64_t rows, double *out) {
+// out (128 x 128) = sum over the ranks of cmx of X' X
+static int32_t rs_gram_allreduce(const RsProblem &pr, dhqr_comm *cmx, const double *X, int64_t ldx, int64_t rows, double *out) {
   dhqr_ctx *c = pr.c;
   const size_t NN = (size_t)DHQR_NBV * DHQR_NBV;
   if (rows <= 0) HIPCHECK(hipMemsetAsync(out, 0, NN * sizeof(double), c->stream));
   else CHECK(gram128(c, X, ldx, rows, out));
   LAUNCHCHECK();
-  if (pr.cm && pr.P > 1) CHECK(comm_allreduce_sum(pr.cm, out, (int64_t)NN, c->stream));
+  if (cmx && cmx->nranks > 1) CHECK(comm_allreduce_sum(cmx, out, (int64_t)NN, c->stream));
   return DHQR_OK;
 }
-// Vw <- the V operand of an already factored panel (diag owner: R part zeroed; others: plain copy of their rows)
-static int32_t rs_pack(const RsProblem &pr, const RsWork &w, int64_t c0, int64_t wcols, int64_t off, int64_t rows, bool diag_owner) {
+// out2 (128 x 256, ld 128) = sum over the ranks of Vb' [Va | Vb]: the pair's cross term V_b'V_a and S_b = V_b'V_b from ONE
+// GEMM and ONE all-reduce.  VaVb = the pair operand at V_b's first row (ld ldv, V_b 128 columns to the right of V_a).
+static int32_t rs_gram_cross_allreduce(const RsProblem &pr, dhqr_comm *cmx, const double *VaVb, int64_t ldv, int64_t rows,
+                                       double *out2) {
+  dhqr_ctx *c = pr.c;
+  const int64_t NB = DHQR_NBV;
+  const size_t NN = (size_t)NB * NB;
+  if (rows <= 0) {
+    HIPCHECK(hipMemsetAsync(out2, 0, 2 * NN * sizeof(double), c->stream));
+  } else {
+    int64_t nsplit, rps;
+    pick_split(rows, 2, 512, 256, &nsplit, &rps);
+    CHECK(ensure(c, c->spart, (size_t)nsplit * 2 * NN));
+    const double *Vb = VaVb + NB * ldv;
+    const bool vec = (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(VaVb);
+    if (vec)
+      hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3(2, (unsigned)nsplit), dim3(256), 0, c->stream, Vb, ldv, VaVb, ldv, 1,
+                         (int64_t)0, rows, 2 * NB, rps, c->spart.p, NB, (int64_t)(2 * NN));
+    else
+      hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), dim3(2, (unsigned)nsplit), dim3(256), 0, c->stream, Vb, ldv, VaVb, ldv, 1,
+                         (int64_t)0, rows, 2 * NB, rps, c->spart.p, NB, (int64_t)(2 * NN));
+    hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(2 * NN / 64)), dim3(256), 0, c->stream, (const double *)c->spart.p,
+                       (int)nsplit, (int64_t)(2 * NN), (int64_t)(2 * NN), out2);
+  }
+  LAUNCHCHECK();
+  if (cmx && cmx->nranks > 1) CHECK(comm_allreduce_sum(cmx, out2, (int64_t)(2 * NN), c->stream));
+  return DHQR_OK;
+}
+// Vdst <- the V operand of an already factored panel (diag owner: R part zeroed; others: plain copy of their rows)
+static int32_t rs_pack(const RsProblem &pr, double *Vdst, int64_t ldv, int64_t c0, int64_t wcols, int64_t off, int64_t rows,
+                       bool diag_owner) {
   dhqr_ctx *c = pr.c;
   if (rows <= 0) return DHQR_OK;
   const double *P = pr.A + off + c0 * pr.lda;
   const int64_t npad = panel_ldv(rows);
   dim3 grid((unsigned)std::min<int64_t>((npad + 255) / 256, 64), DHQR_NBV);
   if (diag_owner) {
-    hipLaunchKernelGGL(k_pack_v, grid, dim3(256), 0, c->stream, P, pr.lda, rows, wcols, w.Vw, w.ldv, npad);
+    hipLaunchKernelGGL(k_pack_v, grid, dim3(256), 0, c->stream, P, pr.lda, rows, wcols, Vdst, ldv, npad);
   } else {
     // all rows are below the diagonal: pack with a "diagonal" far above (rows >= p always) = copy + zero padding columns
-    hipLaunchKernelGGL(k_pack_rows, grid, dim3(256), 0, c->stream, P, pr.lda, rows, wcols, w.Vw, w.ldv, npad);
+    hipLaunchKernelGGL(k_pack_rows, grid, dim3(256), 0, c->stream, P, pr.lda, rows, wcols, Vdst, ldv, npad);
   }
   LAUNCHCHECK();
   return DHQR_OK;
 }
 
-// Robust panel: the reference's algorithm column by column across the ranks (any width <= 128).
-static int32_t rs_panel_columns(const RsProblem &pr, const RsWork &w, int64_t c0, int64_t wcols) {
+// Robust panel: the reference's algorithm column by column across the ranks (any width <= 128).  Leaves the operands
+// of the trailing update in Vdst (ld w.ldv), T, Tt.
+static int32_t rs_panel_columns(const RsProblem &pr, const RsWork &w, dhqr_comm *cmx, int64_t c0, int64_t wcols, double *Vdst,
+                                double *T, double *Tt) {
   dhqr_ctx *c = pr.c;
-  dhqr_comm *cm = (pr.cm && pr.P > 1) ? pr.cm : nullptr;
+  dhqr_comm *cm = (cmx && cmx->nranks > 1) ? cmx : nullptr;
   int64_t off, rows;
   pr.active(c0, &off, &rows);
   const int downer = pr.owner_of_row(c0);
@@ -265,9 +368,9 @@ static int32_t rs_panel_columns(const RsProblem &pr, const RsWork &w, int64_t c0
     }
   }
   // operands of the trailing update: V packed, S all-reduced, T
-  if (rows > 0) CHECK(rs_pack(pr, w, c0, wcols, off, rows, diag_owner));
-  CHECK(rs_gram_allreduce(pr, w.Vw, w.ldv, rows, w.S));
-  launch_build_t(c, w.S, (int)wcols, w.T, w.Tt);
+  if (rows > 0) CHECK(rs_pack(pr, Vdst, w.ldv, c0, wcols, off, rows, diag_owner));
+  CHECK(rs_gram_allreduce(pr, cmx, Vdst, w.ldv, rows, w.S));
+  launch_build_t(c, w.S, (int)wcols, T, Tt);
   LAUNCHCHECK();
   return DHQR_OK;
 }
@@ -276,10 +379,11 @@ static int32_t rs_panel_columns(const RsProblem &pr, const RsWork &w, int64_t c0
 // of a zero-padded buffer, the same tree over them on every rank (up: R_t, down: this rank's block C_r), local tree
 // down from C_r.  Rt <- the tree's R (128 x 128, identical on every rank); *Q / *ldq <- the local rows of the explicit
 // orthonormal factor (inside c->tsq).
-static int32_t rs_tsqr_hr(const RsProblem &pr, const double *P, int64_t rows, double *Rt, const double **Q, int64_t *ldq) {
+static int32_t rs_tsqr_hr(const RsProblem &pr, dhqr_comm *cmx, const double *P, int64_t rows, double *Rt, const double **Q,
+                          int64_t *ldq) {
   dhqr_ctx *c = pr.c;
   const size_t NN = TSQR_NN;
-  const bool multi = pr.cm && pr.P > 1;
+  const bool multi = cmx && cmx->nranks > 1;
   const size_t Pn = multi ? (size_t)pr.P : 0;
   const size_t top = Pn ? (5 * Pn + 4) * NN + (size_t)TsqrLevels::node_blocks((int64_t)Pn) * 2 * NN : 0;
   CHECK(ensure(c, c->tsq, top + TsqrLocal::elems(rows)));
@@ -295,123 +399,293 @@ static int32_t rs_tsqr_hr(const RsProblem &pr, const double *P, int64_t rows, do
          *cpong = cping + (Pn + 1) * NN, *Ytop = cpong + (Pn + 1) * NN;
   HIPCHECK(hipMemsetAsync(gather, 0, Pn * NN * sizeof(double), c->stream));
   CHECK(tsqr_local_up(c, t, P, pr.lda, gather + (size_t)pr.r * NN, true));
-  CHECK(comm_allreduce_sum(pr.cm, gather, (int64_t)(Pn * NN), c->stream));
+  CHECK(comm_allreduce_sum(cmx, gather, (int64_t)(Pn * NN), c->stream));
   CHECK(tsqr_pairs_up(c, gather, pr.P, Rt, Ytop, ping, pong));
   const double *Cblocks = nullptr;
   CHECK(tsqr_pairs_down(c, pr.P, Ytop, nullptr, cping, cpong, &Cblocks));
   return tsqr_local_down(c, t, Cblocks + (size_t)pr.r * NN);
 }
 
-// level: how the FIRST panel of the pass is factored -- 0 like the others, 1 R from the TSQR tree (a panel the
-// Gram/Cholesky path was rejected on), 2 column by column.
-static int32_t rs_run(const RsProblem &pr, const RsWork &w, int64_t kstart, int level, int *failed, int64_t *nfast) {
+// R-first factorisation of the full-width panel k, enqueued on c->stream over the channel cmx; nothing is written to the
+// matrix, alpha or T unless the panel is accepted on the device (k_build_t: the same decision on every rank from the
+// same all-reduced S).  Vdst (ld w.ldv) <- this rank's rows of V, T / Tt <- the compact-WY factor, bcbuf = the panel's
+// broadcast block.  cross != nullptr (second panel of a pair): cross = the pair operand at this panel's first local
+// row, S2 <- [V_b'V_a | V_b'V_b] from one GEMM + one all-reduce.  tsqr: R from the TSQR tree instead of Gram/Cholesky.
+static int32_t rs_panel_fast(const RsProblem &pr, const RsWork &w, dhqr_comm *cmx, int64_t k, bool tsqr, double *Vdst, double *T,
+                             double *Tt, double *bcbuf, int64_t *ticket, const double *cross, double *S2) {
   dhqr_ctx *c = pr.c;
-  dhqr_comm *cm = (pr.cm && pr.P > 1) ? pr.cm : nullptr;
-  const int64_t NB = DHQR_NBV, n = pr.n, K = (n + NB - 1) / NB;
+  dhqr_comm *cm = (cmx && cmx->nranks > 1) ? cmx : nullptr;
+  const int64_t NB = DHQR_NBV, c0 = k * NB;
   const size_t NN = (size_t)NB * NB;
+  int64_t off, rows;
+  pr.active(c0, &off, &rows);
+  const int downer = pr.owner_of_row(c0);
+  const bool diag_owner = downer == pr.r;
+  double *P = pr.A + off + c0 * pr.lda;
+  const double *X = P;  // what the reflectors are reconstructed from: the panel rows, or the rows of its Q factor
+  int64_t ldx = pr.lda;
+  const double *alpha_commit = bcbuf + NN;
+  // LOCAL transport: the readers of the broadcast this rank last rooted out of bcbuf must be done before it changes
+  if (cm && ticket) CHECK(comm_wait_consumed(cm, *ticket, c->stream));
+  if (tsqr) {
+    CHECK(rs_tsqr_hr(pr, cmx, P, rows, w.G, &X, &ldx));                       // w.G = R_t, X = local rows of Q
+    if (diag_owner) {
+      hipLaunchKernelGGL(k_tsqr_identity, dim3((unsigned)(NN / 256)), dim3(256), 0, c->stream, w.S);
+      launch_recon_top(c, X, ldx, w.S, bcbuf + NN, w.Rref, bcbuf);            // R(Q) = I: alpha(Q) = +-1, -M^{-1}
+      hipLaunchKernelGGL(k_tsqr_sign_cols, dim3((unsigned)(NN / 256)), dim3(256), 0, c->stream, bcbuf, (const double *)w.G);
+      hipLaunchKernelGGL(k_rs_get_breakdown, dim3(1), dim3(64), 0, c->stream, c->dstat, bcbuf + NN + NB);
+    }
+  } else {
+    CHECK(rs_gram_allreduce(pr, cmx, P, pr.lda, rows, w.G));                  // G = sum P_r' P_r
+    if (diag_owner) {
+      hipLaunchKernelGGL(k_panel_top, dim3(1), dim3(1024), 0, c->stream, (const double *)w.G, (const double *)P, pr.lda,
+                         bcbuf + NN, w.Rref, bcbuf, c->dstat + 1);            // alpha -> bc tail, -M^{-1} -> bc
+      hipLaunchKernelGGL(k_rs_get_breakdown, dim3(1), dim3(64), 0, c->stream, c->dstat, bcbuf + NN + NB);
+    }
+  }
+  if (cm) CHECK(comm_bcast(cm, bcbuf, (int64_t)NN + NB + 8, downer, c->stream, ticket));
+  hipLaunchKernelGGL(k_rs_set_breakdown, dim3(1), dim3(64), 0, c->stream, (const double *)(bcbuf + NN + NB), c->dstat);
+  if (tsqr) {  // R = D R_t, alpha = diag(R) with D = alpha(Q) from the broadcast (every rank: same values)
+    hipLaunchKernelGGL(k_tsqr_final_r, dim3(NN / 256), dim3(256), 0, c->stream, (const double *)w.G,
+                       (const double *)(bcbuf + NN), w.Rref, w.altmp + 1024);
+    alpha_commit = w.altmp + 1024;
+  }
+  if (rows > 0) CHECK(mul128(c, X, ldx, rows, bcbuf, Vdst, w.ldv));           // V = X M^{-1}
+  if (diag_owner)
+    hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, Vdst, w.ldv, (const double *)(bcbuf + NN),
+                       (const double *)bcbuf);
+  const double *S = w.S;
+  if (cross) {
+    CHECK(rs_gram_cross_allreduce(pr, cmx, cross, w.ldv, rows, S2));          // [V_b'V_a | V_b'V_b]
+    S = S2 + NN;
+  } else {
+    CHECK(rs_gram_allreduce(pr, cmx, Vdst, w.ldv, rows, w.S));                // S = sum V_r' V_r: same on every rank
+  }
+  hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, S, (int)NB, T, Tt, c->recon_tol, c->dstat, (int)k,
+                     (double *)nullptr);                                      // same decision on every rank
+  if (rows > 0) {
+    dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
+    if (diag_owner) {
+      hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, P, pr.lda, rows, NB, (const double *)Vdst, w.ldv,
+                         (const int *)c->dstat, (int)k);
+      hipLaunchKernelGGL(k_recon_write_r, dim3(NN / 256), dim3(256), 0, c->stream, P, pr.lda, (const double *)w.Rref,
+                         (const int *)c->dstat, (int)k);
+    } else {
+      hipLaunchKernelGGL(k_unpack_rows, grid, dim3(256), 0, c->stream, P, pr.lda, rows, NB, (const double *)Vdst, w.ldv,
+                         (const int *)c->dstat, (int)k);
+    }
+  }
+  hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, alpha_commit, (int)NB, pr.alpha + c0,
+                     (double *)nullptr, (const int *)c->dstat, (int)k);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+struct RsGroup {
+  int64_t a;    // first panel
+  int np;       // 1 or 2 panels
+  bool fast;    // every panel of the group goes through the asynchronous, device-verified path
+  int64_t last() const { return a + np - 1; }
+};
+
+// Group g (operands in `sl`) applied to this rank's active rows of the columns [col0, col0 + ncols) on c->stream, the
+// partial dots summed over the channel cmx.  A rank without active rows still joins the all-reduce (with zeros).
+static int32_t rs_group_apply(const RsProblem &pr, const RsWork &w, const RsSlot &sl, const RsGroup &gr, int64_t col0,
+                              int64_t ncols, dhqr_comm *cmx) {
+  dhqr_ctx *c = pr.c;
+  if (ncols <= 0) return DHQR_OK;
+  const int64_t NB = DHQR_NBV;
+  dhqr_comm *cm = (cmx && cmx->nranks > 1) ? cmx : nullptr;
+  int64_t off, rows;
+  pr.active(gr.a * NB, &off, &rows);
+  double *C = pr.A + off + col0 * pr.lda;
+  c->epoch = gr.fast ? (int)gr.last() : -1;
+  if (gr.np == 2) {
+    int64_t offb, rowsb;
+    pr.active((gr.a + 1) * NB, &offb, &rowsb);
+    if (rows <= 0) {
+      dhqr_ctx::WS &ws = c->ws[c->cur_ws];
+      if (cm) {
+        HIPCHECK(hipMemsetAsync(ws.w1r.p, 0, (size_t)(2 * NB * ncols) * sizeof(double), c->stream));
+        CHECK(comm_allreduce_sum(cm, ws.w1r.p, 2 * NB * ncols, c->stream));
+      }
+      return DHQR_OK;
+    }
+    return pair_apply(c, sl.V, w.ldv, rows, sl.T[0], sl.T[1], sl.S2, C, ncols, pr.lda, cm, rowsb);
+  }
+  CHECK(prof_begin(c, CAT_VTA));
+  CHECK(rs_vtc_allreduce(pr, cmx, sl.V, w.ldv, C, pr.lda, rows, ncols));
+  CHECK(prof_end(c));
+  CHECK(prof_begin(c, CAT_AVW));
+  CHECK(rs_apply_w(pr, sl.V, w.ldv, sl.T[0], C, pr.lda, rows, ncols, true));
+  CHECK(prof_end(c));
+  if (c->profiling) {
+    c->st.flops_gemm_vta += 2.0 * NB * (double)rows * (double)ncols;
+    c->st.flops_gemm_avw += 2.0 * NB * (double)rows * (double)ncols;
+  }
+  return DHQR_OK;
+}
+
+// One asynchronous pass over the panels [kstart, K).  level: how the FIRST panel of the pass is factored -- 0 like the
+// others, 1 R from the TSQR tree (a panel the Gram/Cholesky path was rejected on), 2 column by column.
+//
+// Panels are grouped like in the column-split driver (dhqr_dist.h): a group is a PAIR of full-width panels applied in
+// one K = 256 pass, or a single panel.  Two streams, each with its own communicator channel (the collectives of one
+// channel are ordered; the lane's small latency-bound all-reduces must not queue behind the wide stream's):
+//   lane (high priority, cm->lane)  group g+1: the previous group applied to ITS columns only, the panels factored
+//                                   (Gram all-reduce -> top block on the diagonal owner -> broadcast -> V -> S
+//                                   all-reduce -> T), panel a applied to panel b's columns, the pair's cross term;
+//   wide (caller's stream, cm)      group g applied to the columns beyond group g+1 (one all-reduce of the 256 x ncols
+//                                   partial dots per pair), overlapping the lane's chain of small collectives.
+// c->lookahead == false: both roles on the caller's stream and one channel, in the same order.
+// pair_b <- the second panels of the pairs formed (what rs_factor needs to resume after a rejected panel).
+static int32_t rs_run(const RsProblem &pr, const RsWork &w, int64_t kstart, int level, int *failed, int64_t *nfast,
+                      std::vector<int64_t> &pair_b) {
+  dhqr_ctx *c = pr.c;
+  RsState &S = *c->rs;
+  const int64_t NB = DHQR_NBV, n = pr.n, K = (n + NB - 1) / NB;
+  auto is_fast = [&](int64_t k) {
+    const int64_t c0 = k * NB;
+    return c->panel_impl == 3 && std::min<int64_t>(NB, n - c0) == NB && pr.m - c0 >= 2 * NB && !(level == 2 && k == kstart);
+  };
+  auto is_tsqr = [&](int64_t k) { return c->cholqr_passes == 3 || (level == 1 && k == kstart); };
+  std::vector<RsGroup> groups;
+  for (int64_t k = kstart; k < K;) {
+    RsGroup g;
+    g.a = k;
+    g.fast = is_fast(k);
+    g.np = (c->pair && g.fast && !is_tsqr(k) && k + 1 < K && is_fast(k + 1) && !is_tsqr(k + 1)) ? 2 : 1;
+    if (g.np == 2) pair_b.push_back(k + 1);
+    groups.push_back(g);
+    k += g.np;
+  }
+  const int G = (int)groups.size();
+  const bool la = c->lookahead && G >= 2;
+  dhqr_comm *cmW = pr.cm, *cmL = (la && pr.cm && pr.cm->lane) ? pr.cm->lane : pr.cm;
+  hipStream_t sW = c->stream, sL = la ? c->hi : c->stream;
+  auto on = [&](hipStream_t s, int wsi) { c->stream = s; c->cur_ws = wsi; };
   const int saved_epoch = c->epoch;
-  auto body = [&]() -> int32_t {
-    for (int64_t k = kstart; k < K; ++k) {
-      const int64_t c0 = k * NB, wcols = std::min<int64_t>(NB, n - c0);
-      int64_t off, rows;
-      pr.active(c0, &off, &rows);
-      const int downer = pr.owner_of_row(c0);
-      const bool diag_owner = downer == pr.r;
-      const bool fast = c->panel_impl == 3 && wcols == NB && pr.m - c0 >= 2 * NB && !(level == 2 && k == kstart);
-      const bool tsqr = c->cholqr_passes == 3 || (level == 1 && k == kstart);
-      double *P = pr.A + off + c0 * pr.lda;
-      c->epoch = -1;
-      if (fast) {
-        CHECK(prof_begin(c, CAT_PANEL));
-        const double *X = P;  // what the reflectors are reconstructed from: the panel rows, or the rows of its Q factor
-        int64_t ldx = pr.lda;
-        const double *alpha_commit = w.bc + NN;
-        if (tsqr) {
-          CHECK(rs_tsqr_hr(pr, P, rows, w.G, &X, &ldx));                           // w.G = R_t, X = local rows of Q
-          if (diag_owner) {
-            hipLaunchKernelGGL(k_tsqr_identity, dim3((unsigned)(NN / 256)), dim3(256), 0, c->stream, w.S);
-            launch_recon_top(c, X, ldx, w.S, w.bc + NN, w.Rref, w.bc);             // R(Q) = I: alpha(Q) = +-1, -M^{-1}
-            hipLaunchKernelGGL(k_tsqr_sign_cols, dim3((unsigned)(NN / 256)), dim3(256), 0, c->stream, w.bc, (const double *)w.G);
-            hipLaunchKernelGGL(k_rs_get_breakdown, dim3(1), dim3(64), 0, c->stream, c->dstat, w.bc + NN + NB);
+  bool stop = false;
+
+  // lane: bring group h's columns up to date and factor its panels
+  auto produce = [&](int h) -> int32_t {
+    const RsGroup &gr = groups[h];
+    const RsSlot &sl = w.slot[h % RS_RING];
+    on(sL, la ? 1 : 0);
+    // the slot's previous readers (wide update of group h-2) are done, and the columns of group h carry every group
+    // before h-1, once the wide update of group h-2 has finished
+    if (la && h >= 2) HIPCHECK(hipStreamWaitEvent(sL, S.ev_wide[(h - 2) % (2 * RS_RING)], 0));
+    bool was = c->profiling;
+    CHECK(prof_begin(c, CAT_PANEL));
+    c->profiling = false;
+    auto body = [&]() -> int32_t {
+      int64_t ncols_g = 0;
+      for (int idx = 0; idx < gr.np; ++idx) ncols_g += std::min<int64_t>(NB, n - (gr.a + idx) * NB);
+      if (la && h >= 1) CHECK(rs_group_apply(pr, w, w.slot[(h - 1) % RS_RING], groups[h - 1], gr.a * NB, ncols_g, cmL));
+      int64_t offa, rowsa;
+      pr.active(gr.a * NB, &offa, &rowsa);
+      for (int idx = 0; idx < gr.np; ++idx) {
+        const int64_t k = gr.a + idx, c0 = k * NB, wcols = std::min<int64_t>(NB, n - c0);
+        int64_t off, rows;
+        pr.active(c0, &off, &rows);
+        const int64_t shift = off - offa;  // 0 or 128 (<= rows of panel a)
+        double *Vdst = sl.V + (size_t)idx * NB * w.ldv + shift;
+        c->epoch = -1;
+        if (gr.fast) {
+          if (idx == 1) {  // panel a -> the columns of panel b, then the rows of V_b above its first row
+            RsGroup ga = gr;
+            ga.np = 1;
+            CHECK(rs_group_apply(pr, w, sl, ga, c0, wcols, cmL));
+            c->epoch = -1;
+            if (shift > 0)
+              hipLaunchKernelGGL(k_zero_rows, dim3(DHQR_NBV), dim3(128), 0, c->stream, sl.V + (size_t)NB * w.ldv, w.ldv, (int)shift);
           }
+          CHECK(rs_panel_fast(pr, w, cmL, k, is_tsqr(k), Vdst, sl.T[idx], sl.Tt[idx], sl.bc[idx], &S.ticket[h % RS_RING][idx],
+                              idx == 1 ? sl.V + shift : nullptr, sl.S2));
+          (*nfast)++;
         } else {
-          CHECK(rs_gram_allreduce(pr, P, pr.lda, rows, w.G));                     // G = sum P_r' P_r
-          if (diag_owner) {
-            hipLaunchKernelGGL(k_panel_top, dim3(1), dim3(1024), 0, c->stream, (const double *)w.G, (const double *)P, pr.lda,
-                               w.bc + NN, w.Rref, w.bc, c->dstat + 1);           // alpha -> bc tail, -M^{-1} -> bc
-            hipLaunchKernelGGL(k_rs_get_breakdown, dim3(1), dim3(64), 0, c->stream, c->dstat, w.bc + NN + NB);
+          // partial / short panels and the panel a resumed pass starts with: column by column.  Inside a pass they may
+          // only run if nothing was rejected before (one status read; every rank holds the same status).
+          if (k != kstart) {
+            int f = 0;
+            CHECK(status_read(c, &f));
+            if (f != INT_MAX) {
+              stop = true;
+              return DHQR_OK;
+            }
           }
+          CHECK(rs_panel_columns(pr, w, cmL, c0, wcols, Vdst, sl.T[idx], sl.Tt[idx]));
         }
-        if (cm) CHECK(comm_bcast(cm, w.bc, (int64_t)NN + NB + 8, downer, c->stream, nullptr));
-        hipLaunchKernelGGL(k_rs_set_breakdown, dim3(1), dim3(64), 0, c->stream, (const double *)(w.bc + NN + NB), c->dstat);
-        if (tsqr) {  // R = D R_t, alpha = diag(R) with D = alpha(Q) from the broadcast (every rank: same values)
-          hipLaunchKernelGGL(k_tsqr_final_r, dim3(NN / 256), dim3(256), 0, c->stream, (const double *)w.G,
-                             (const double *)(w.bc + NN), w.Rref, w.altmp + 1024);
-          alpha_commit = w.altmp + 1024;
-        }
-        if (rows > 0) CHECK(mul128(c, X, ldx, rows, w.bc, w.Vw, w.ldv));           // Vw = X M^{-1}
-        if (diag_owner)
-          hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, w.Vw, w.ldv, (const double *)(w.bc + NN),
-                             (const double *)w.bc);
-        CHECK(rs_gram_allreduce(pr, w.Vw, w.ldv, rows, w.S));                      // S = sum V_r' V_r: same on every rank
-        hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, (const double *)w.S, (int)NB, w.T, w.Tt, c->recon_tol,
-                           c->dstat, (int)k, (double *)nullptr);                   // same decision on every rank
-        if (rows > 0) {
-          if (diag_owner) {
-            dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
-            hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, P, pr.lda, rows, NB, (const double *)w.Vw, w.ldv,
-                               (const int *)c->dstat, (int)k);
-            hipLaunchKernelGGL(k_recon_write_r, dim3(NN / 256), dim3(256), 0, c->stream, P, pr.lda, (const double *)w.Rref,
-                               (const int *)c->dstat, (int)k);
-          } else {
-            dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
-            hipLaunchKernelGGL(k_unpack_rows, grid, dim3(256), 0, c->stream, P, pr.lda, rows, NB, (const double *)w.Vw, w.ldv,
-                               (const int *)c->dstat, (int)k);
-          }
-        }
-        hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, alpha_commit, (int)NB,
-                           pr.alpha + c0, (double *)nullptr, (const int *)c->dstat, (int)k);
-        LAUNCHCHECK();
-        CHECK(prof_end(c));
-        (*nfast)++;
-        if (cm && cm->kind == COMM_LOCAL) {  // bc is the broadcast source of the next panel
-          HIPCHECK(hipStreamSynchronize(c->stream));
-          CHECK(comm_host_barrier(cm));
-        }
+      }
+      return DHQR_OK;
+    };
+    const int32_t rc = body();
+    c->profiling = was;
+    CHECK(rc);
+    CHECK(prof_end(c));
+    if (la) HIPCHECK(hipEventRecord(S.ev_group[h % (2 * RS_RING)], sL));
+    LAUNCHCHECK();
+    return DHQR_OK;
+  };
+
+  auto body = [&]() -> int32_t {
+    if (la) {  // order the lane after whatever the caller queued (e.g. the fill)
+      HIPCHECK(hipEventRecord(S.ev_start, sW));
+      HIPCHECK(hipStreamWaitEvent(sL, S.ev_start, 0));
+    }
+    CHECK(produce(0));
+    for (int g = 0; g < G && !stop; ++g) {
+      const RsGroup &gr = groups[g];
+      if (gr.last() + 1 >= K) break;  // nothing to the right of this group
+      on(sW, 0);
+      if (la) {
+        // wide: group g -> the columns beyond group g+1 (group g+1's own columns are the lane's: produce(g+1))
+        HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[g % (2 * RS_RING)], 0));
+        const int64_t col0 = std::min<int64_t>(n, (groups[g + 1].last() + 1) * NB);
+        CHECK(rs_group_apply(pr, w, w.slot[g % RS_RING], gr, col0, n - col0, cmW));
+        HIPCHECK(hipEventRecord(S.ev_wide[g % (2 * RS_RING)], sW));
       } else {
-        // partial / short panels and the panel a resumed pass starts with: column by column.  Inside a pass they may
-        // only run if nothing was rejected before (one status read; every rank holds the same status).
-        if (k != kstart) {
-          int f = 0;
-          CHECK(status_read(c, &f));
-          if (f != INT_MAX) break;
-        }
-        CHECK(prof_begin(c, CAT_PANEL));
-        CHECK(rs_panel_columns(pr, w, c0, wcols));
-        CHECK(prof_end(c));
+        // one stream: the group is applied to everything to its right in one pass, then the next group is factored
+        const int64_t col0 = (gr.last() + 1) * NB;
+        CHECK(rs_group_apply(pr, w, w.slot[g % RS_RING], gr, col0, n - col0, cmW));
       }
-      // trailing update of the local rows: W = sum_r V_r' C_r, C_r -= V_r (T' W)
-      const int64_t ncols = n - c0 - wcols;
-      if (ncols > 0) {
-        c->epoch = fast ? (int)k : -1;
-        double *C = pr.A + off + (c0 + wcols) * pr.lda;
-        CHECK(prof_begin(c, CAT_VTA));
-        CHECK(rs_vtc_allreduce(pr, w, C, pr.lda, rows, ncols));
-        CHECK(prof_end(c));
-        CHECK(prof_begin(c, CAT_AVW));
-        CHECK(rs_apply_w(pr, w, w.T, C, pr.lda, rows, ncols, true));
-        CHECK(prof_end(c));
-        if (c->profiling) {
-          c->st.flops_gemm_vta += 2.0 * NB * (double)rows * (double)ncols;
-          c->st.flops_gemm_avw += 2.0 * NB * (double)rows * (double)ncols;
-        }
-      }
+      CHECK(produce(g + 1));
+    }
+    on(sW, 0);
+    if (la) {  // join: the caller's stream owns the result
+      HIPCHECK(hipEventRecord(S.ev_end, sL));
+      HIPCHECK(hipStreamWaitEvent(sW, S.ev_end, 0));
     }
     return DHQR_OK;
   };
   int32_t rc = body();
+  on(sW, 0);
   c->epoch = saved_epoch;
   if (rc == DHQR_OK) rc = status_read(c, failed);
+  return rc;
+}
+
+// Panel k (already factored and committed) applied again to the columns [col0, n): the resume after the SECOND panel of
+// a pair was rejected -- the pair's first panel had reached that panel's columns only.
+static int32_t rs_reapply_panel(const RsProblem &pr, const RsWork &w, int64_t k, int64_t col0) {
+  dhqr_ctx *c = pr.c;
+  const int64_t NB = DHQR_NBV, c0 = k * NB, ncols = pr.n - col0;
+  if (ncols <= 0) return DHQR_OK;
+  int64_t off, rows;
+  pr.active(c0, &off, &rows);
+  const bool diag_owner = pr.owner_of_row(c0) == pr.r;
+  const int saved_epoch = c->epoch;
+  c->epoch = -1;
+  auto body = [&]() -> int32_t {
+    if (rows > 0) CHECK(rs_pack(pr, w.Vw, w.ldv, c0, NB, off, rows, diag_owner));
+    CHECK(rs_gram_allreduce(pr, pr.cm, w.Vw, w.ldv, rows, w.S));
+    launch_build_t(c, w.S, (int)NB, w.T, w.Tt);
+    double *C = pr.A + off + col0 * pr.lda;
+    CHECK(rs_vtc_allreduce(pr, pr.cm, w.Vw, w.ldv, C, pr.lda, rows, ncols));
+    return rs_apply_w(pr, w.Vw, w.ldv, w.T, C, pr.lda, rows, ncols, false);
+  };
+  const int32_t rc = body();
+  c->epoch = saved_epoch;
   return rc;
 }
 
@@ -423,17 +697,22 @@ static int32_t rs_factor(const RsProblem &pr) {
   const int64_t K = (pr.n + DHQR_NBV - 1) / DHQR_NBV;
   int64_t ks = 0;
   int level = 0;  // ladder for a rejected panel: Gram/Cholesky (0) -> TSQR tree (1) -> column by column (2)
+  std::vector<int64_t> pair_b;
   for (int pass = 0; ks < K; ++pass) {
     if (pass > 2 * K + 2) return set_err(DHQR_EINVAL, "internal error: the row-split driver does not make progress");
     int failed = INT_MAX;
     int64_t nfast = 0;
-    CHECK(rs_run(pr, w, ks, level, &failed, &nfast));
+    pair_b.clear();
+    CHECK(rs_run(pr, w, ks, level, &failed, &nfast, pair_b));
     const int64_t accepted = (failed == INT_MAX) ? nfast : std::max<int64_t>(0, std::min<int64_t>(nfast, failed - ks));
     c->n_fast += accepted;
     if (c->cholqr_passes == 3) c->n_tsqr += (int)accepted;
     else if (level == 1 && accepted > 0) c->n_tsqr++;
     if (failed == INT_MAX) break;
     CHECK(status_reset(c));
+    // the rejected panel was the second of a pair: its (committed) first panel has only reached the rejected panel's columns
+    if (std::find(pair_b.begin(), pair_b.end(), (int64_t)failed) != pair_b.end())
+      CHECK(rs_reapply_panel(pr, w, failed - 1, ((int64_t)failed + 1) * DHQR_NBV));
     if (failed == ks && level >= 1) {
       level = 2;  // the tree's R did not pass either: the reference's column-by-column algorithm
     } else {
@@ -468,13 +747,13 @@ static int32_t rs_residual(const RsProblem &pr, uint64_t seed, double *dB, doubl
       int64_t off, rows;
       pr.active(c0, &off, &rows);
       const bool diag_owner = pr.owner_of_row(c0) == pr.r;
-      if (rows > 0) CHECK(rs_pack(pr, w, c0, wcols, off, rows, diag_owner));
-      CHECK(rs_gram_allreduce(pr, w.Vw, w.ldv, rows, w.S));
+      if (rows > 0) CHECK(rs_pack(pr, w.Vw, w.ldv, c0, wcols, off, rows, diag_owner));
+      CHECK(rs_gram_allreduce(pr, pr.cm, w.Vw, w.ldv, rows, w.S));
       launch_build_t(c, w.S, (int)wcols, w.T, w.Tt);
       const int64_t ncols = n - c0;
       double *C = dB + off + c0 * ldb;
-      CHECK(rs_vtc_allreduce(pr, w, C, ldb, rows, ncols));
-      CHECK(rs_apply_w(pr, w, w.Tt, C, ldb, rows, ncols, false));  // Q (not Q'): op(T) = T
+      CHECK(rs_vtc_allreduce(pr, pr.cm, w.Vw, w.ldv, C, ldb, rows, ncols));
+      CHECK(rs_apply_w(pr, w.Vw, w.ldv, w.Tt, C, ldb, rows, ncols, false));  // Q (not Q'): op(T) = T
     }
     return DHQR_OK;
   };
@@ -528,11 +807,11 @@ static int32_t rs_solve(const RsProblem &pr, double *db, double *dx) {
       int64_t off, rows;
       pr.active(c0, &off, &rows);
       const bool diag_owner = pr.owner_of_row(c0) == pr.r;
-      if (rows > 0) CHECK(rs_pack(pr, w, c0, wcols, off, rows, diag_owner));
-      CHECK(rs_gram_allreduce(pr, w.Vw, w.ldv, rows, w.S));
+      if (rows > 0) CHECK(rs_pack(pr, w.Vw, w.ldv, c0, wcols, off, rows, diag_owner));
+      CHECK(rs_gram_allreduce(pr, pr.cm, w.Vw, w.ldv, rows, w.S));
       launch_build_t(c, w.S, (int)wcols, w.T, w.Tt);
-      CHECK(rs_vtc_allreduce(pr, w, db + off, ldb, rows, 1));
-      CHECK(rs_apply_w(pr, w, w.T, db + off, ldb, rows, 1, false));
+      CHECK(rs_vtc_allreduce(pr, pr.cm, w.Vw, w.ldv, db + off, ldb, rows, 1));
+      CHECK(rs_apply_w(pr, w.Vw, w.ldv, w.T, db + off, ldb, rows, 1, false));
     }
     // back substitution, block by block from the bottom of R: x_blk solved by the owner of rows [c0, c0 + w)
     HIPCHECK(hipMemsetAsync(dx, 0, (size_t)n * sizeof(double), c->stream));

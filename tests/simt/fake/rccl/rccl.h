@@ -7,5 +7,5 @@
 typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
 typedef struct ncclComm *ncclComm_t;
 typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1 } ncclResult_t;
-typedef enum { ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclChar = 0, ncclFloat64 = 8 } ncclDataType_t;
 typedef enum { ncclSum = 0 } ncclRedOp_t;
