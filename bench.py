@@ -390,6 +390,10 @@ def main():
         "phase_ms_per_step": {k: st[k] / args.steps for k in st if k.startswith("ms_") and st[k] > 0},
         "panels_fast_fallback": panel_counts,
     }
+    if mode == "mg" and mg.transport == "rccl":
+        out["bcast_tuning"] = mg.bcast_tuning()
+    elif mode == "spmd":
+        out["bcast_tuning"] = q.comm.bcast_tuning()
     if mode != "single":
         out["roofline_note"] = "per-GPU figures of rank 0 (every rank runs the same kernels on 1/N of the columns)"
     if per_rank is not None:

@@ -1321,70 +1321,28 @@ int32_t dhqr_factor_c64_nb(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_
   CHECK(check_mat(dA, m, n, lda, true));
   CHECK(check_zptr(dA, "matrix"));
   CHECK(check_zptr(dalpha, "alpha"));
-  const int64_t ZB = DHQR_ZNB, K = (n + ZB - 1) / ZB;
-  // Look-ahead (same structure as the Float64 driver, dhqr_dist.h): the high-priority lane applies panel k to the 64
-  // columns of panel k+1 only and factors them (64 latency-bound rank-1 launches) while the caller's stream applies panel k
-  // to everything beyond.  Two operand buffers: panel k+2 is packed only after the wide update of panel k has finished.
-  const bool la = c->lookahead && K >= 3;
-  CHECK(cs_state_init(c));
-  CsState &S = *c->cs;
-  const size_t pe = (size_t)panel_elems(2 * m);
-  CHECK(ensure(c, c->vt, (la ? 2 : 1) * pe));
-  hipStream_t sW = c->stream, sL = la ? c->hi : c->stream;
-  auto on = [&](hipStream_t s, int wsi) { c->stream = s; c->cur_ws = wsi; };
-  auto factor_and_pack = [&](int64_t k) -> int32_t {  // on c->stream: src:122-148,171-213 inside the panel, then V / T
-    const int64_t c0 = k * ZB, w = std::min<int64_t>(ZB, n - c0), rows = m - c0;
+  const int64_t ZB = DHQR_ZNB;
+  // No look-ahead lane here: measured (profiles/r02_ab_c64_blocked_lookahead.txt), the 1024-thread rank-1 launches of a
+  // lane wait for a CU behind the wide update's GEMM workgroups and the lane takes as long as the wide stream.
+  CHECK(ensure(c, c->vt, (size_t)panel_elems(2 * m)));
+  for (int64_t c0 = 0; c0 < n; c0 += ZB) {
+    const int64_t w = std::min<int64_t>(ZB, n - c0), rows = m - c0;
     double *P = dA + 2 * (c0 + c0 * lda);
-    CHECK(dhqr_factor_c64(c, P, rows, w, lda, dalpha + 2 * c0));
-    if (c0 + w >= n) return DHQR_OK;
-    const PanelBuf pb = vt_view(c->vt.p + (la ? (size_t)(k & 1) * pe : 0), 2 * rows);
+    CHECK(dhqr_factor_c64(c, P, rows, w, lda, dalpha + 2 * c0));  // src:122-148,171-213 inside the panel
+    const int64_t ncols = n - c0 - w;
+    if (ncols <= 0) break;
+    const PanelBuf pb = vt_view(c->vt.p, 2 * rows);
     const int64_t npad = panel_ldv(2 * rows);
     CHECK(prof_begin(c, CAT_TBUILD));
-    dim3 grid((unsigned)std::min<int64_t>((npad / 2 + 255) / 256, 64), (unsigned)ZB);
-    hipLaunchKernelGGL(k_zpack_emb, grid, dim3(256), 0, c->stream, reinterpret_cast<const double2 *>(P), lda, rows, (int)w, pb.V,
-                       pb.ldv, npad);
+    {
+      dim3 grid((unsigned)std::min<int64_t>((npad / 2 + 255) / 256, 64), (unsigned)ZB);
+      hipLaunchKernelGGL(k_zpack_emb, grid, dim3(256), 0, c->stream, reinterpret_cast<const double2 *>(P), lda, rows, (int)w,
+                         pb.V, pb.ldv, npad);
+    }
     CHECK(panel_build_t(c, 2 * rows, -2 * w, pb));  // negative: strict upper part at the 2 x 2 block level
-    return prof_end(c);
-  };
-  auto apply = [&](int64_t k, int64_t col0, int64_t ncols) -> int32_t {  // panel k -> columns [col0, col0 + ncols)
-    if (ncols <= 0) return DHQR_OK;
-    const int64_t c0 = k * ZB, rows = m - c0;
-    const PanelBuf pb = vt_view(c->vt.p + (la ? (size_t)(k & 1) * pe : 0), 2 * rows);
-    return panel_apply(c, pb, 2 * rows, dA + 2 * (c0 + col0 * lda), ncols, 2 * lda, 1);
-  };
-  auto body = [&]() -> int32_t {
-    if (!la) {
-      for (int64_t k = 0; k < K; ++k) {
-        CHECK(factor_and_pack(k));
-        CHECK(apply(k, (k + 1) * ZB, n - (k + 1) * ZB));
-      }
-      return DHQR_OK;
-    }
-    HIPCHECK(hipEventRecord(S.ev_start, sW));
-    HIPCHECK(hipStreamWaitEvent(sL, S.ev_start, 0));
-    on(sL, 1);
-    CHECK(factor_and_pack(0));
-    HIPCHECK(hipEventRecord(S.ev_group[0], sL));
-    for (int64_t k = 0; k + 1 < K; ++k) {
-      const int64_t c1 = (k + 1) * ZB, w1 = std::min<int64_t>(ZB, n - c1);
-      on(sW, 0);  // wide: panel k -> the columns beyond panel k+1
-      HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[k % CS_EVR], 0));
-      CHECK(apply(k, c1 + w1, n - c1 - w1));
-      HIPCHECK(hipEventRecord(S.ev_wide[k % CS_EVR], sW));
-      on(sL, 1);  // lane: panel k -> the columns of panel k+1 (complete up to panel k-1 once wide(k-1) is done), factor it
-      if (k >= 1) HIPCHECK(hipStreamWaitEvent(sL, S.ev_wide[(k - 1) % CS_EVR], 0));
-      CHECK(apply(k, c1, w1));
-      CHECK(factor_and_pack(k + 1));
-      HIPCHECK(hipEventRecord(S.ev_group[(k + 1) % CS_EVR], sL));
-    }
-    on(sW, 0);
-    HIPCHECK(hipEventRecord(S.ev_end, sL));
-    HIPCHECK(hipStreamWaitEvent(sW, S.ev_end, 0));
-    return DHQR_OK;
-  };
-  const int32_t rc = body();
-  on(sW, 0);
-  CHECK(rc);
+    CHECK(prof_end(c));
+    CHECK(panel_apply(c, pb, 2 * rows, dA + 2 * (c0 + (c0 + w) * lda), ncols, 2 * lda, 1));
+  }
   LAUNCHCHECK();
   return DHQR_OK;
 }
@@ -1987,7 +1945,7 @@ int32_t dhqr_comm_create_rank(dhqr_comm **out, dhqr_ctx *c, int32_t nranks, int3
     CHECK(comm_new(&(*out)->lane, c, COMM_RCCL, nranks, rank));
     (*out)->lane->nccl = nc2;
   }
-  return DHQR_OK;
+  return comm_tune_bcast(*out, c->stream);  // ring broadcast vs scatter + all-gather, measured on this node
 }
 
 int32_t dhqr_comm_create_callbacks(dhqr_comm **out, dhqr_ctx *c, int32_t nranks, int32_t rank, dhqr_bcast_fn bcast,
@@ -2013,6 +1971,14 @@ int32_t dhqr_comm_info(dhqr_comm *cm, int32_t *kind, int32_t *nranks, int32_t *r
   if (nranks) *nranks = cm->nranks;
   if (rank) *rank = cm->rank;
   if (bytes_bcast) *bytes_bcast = cm->bytes_bcast;
+  return DHQR_OK;
+}
+
+int32_t dhqr_comm_get_bcast_tuning(dhqr_comm *cm, int32_t *algo, double *ms_ring, double *ms_sag) {
+  if (!cm) return set_err(DHQR_EINVAL, "null communicator");
+  if (algo) *algo = cm->bcast_algo;
+  if (ms_ring) *ms_ring = cm->tune_ms[0];
+  if (ms_sag) *ms_sag = cm->tune_ms[1];
   return DHQR_OK;
 }
 
@@ -2225,6 +2191,8 @@ int32_t dhqr_mg_create(dhqr_mg **out, const int32_t *devices, int32_t ndev) {
     }
     g->transport = want;
     for (int r = 0; r < ndev; ++r) g->rk[r].th = std::thread(mg_worker, g, r);
+    if (want == COMM_RCCL)  // ring broadcast vs scatter + all-gather, measured on this node (collective: rank threads)
+      CHECK(mg_run(g, [g](int r) -> int32_t { return comm_tune_bcast(g->rk[r].cm, g->rk[r].c->stream); }));
     return DHQR_OK;
   };
   const int32_t rc = init();
@@ -2260,6 +2228,11 @@ int32_t dhqr_mg_destroy(dhqr_mg *g) {
   delete g;
   if (prev >= 0) (void)hipSetDevice(prev);
   return DHQR_OK;
+}
+
+int32_t dhqr_mg_get_bcast_tuning(dhqr_mg *g, int32_t *algo, double *ms_ring, double *ms_sag) {
+  if (!g || g->rk.empty()) return set_err(DHQR_EINVAL, "null handle");
+  return dhqr_comm_get_bcast_tuning(g->rk[0].cm, algo, ms_ring, ms_sag);
 }
 
 int32_t dhqr_mg_info(dhqr_mg *g, int32_t *ndev, int32_t *transport, int64_t *m, int64_t *n) {

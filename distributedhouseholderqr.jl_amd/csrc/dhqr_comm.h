@@ -40,7 +40,14 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  // optional (scatter + all-gather broadcast); when one is missing the plain ncclBroadcast is the only algorithm
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool has_sag() const { return AllGather && Send && Recv && GroupStart && GroupEnd; }
 };
 static RcclApi g_rccl;
 static std::atomic<int> g_rccl_state{0};  // 0 untried, 1 loaded, -1 unavailable
@@ -77,6 +84,11 @@ static int32_t rccl_load() {
     g_rccl_state.store(-1);
     return set_err(DHQR_ECOMM, "librccl.so lacks a required symbol");
   }
+  g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+  g_rccl.Send = (decltype(g_rccl.Send))dlsym(h, "ncclSend");
+  g_rccl.Recv = (decltype(g_rccl.Recv))dlsym(h, "ncclRecv");
+  g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(h, "ncclGroupStart");
+  g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(h, "ncclGroupEnd");
   g_rccl.handle = h;
   g_rccl_state.store(1, std::memory_order_release);
   return DHQR_OK;
@@ -130,6 +142,13 @@ struct dhqr_comm {
   // issues its small latency-bound collectives here so they do not queue behind the wide stream's all-reduces (the
   // operations of ONE channel are ordered).  nullptr: CALLBACK transport (host synchronous anyway) or a single rank.
   dhqr_comm *lane = nullptr;
+  // RCCL: algorithm of large broadcasts.  0 = ncclBroadcast (rings: the panel travels link by link), 1 = scatter +
+  // all-gather (the root sends 1/P of the panel to every peer over its own xGMI link, then an all-gather among all ranks:
+  // every link of the fully connected node carries 1/P of the bytes).  Chosen by comm_tune_bcast (a timed trial of both
+  // on this node when the communicator is created) or DHQR_BCAST=ring|sag.
+  int bcast_algo = 0;
+  int64_t bcast_sag_min = (int64_t)1 << 17;  // doubles (1 MiB): below this a single ncclBroadcast
+  double tune_ms[2] = {0.0, 0.0};            // what the trial measured (ring, scatter + all-gather), 16 MiB
 };
 
 __global__ __launch_bounds__(256) void k_sum_ranks(const double *__restrict__ part, int nranks, int64_t stride,
@@ -141,6 +160,75 @@ __global__ __launch_bounds__(256) void k_sum_ranks(const double *__restrict__ pa
   out[e] = s;
 }
 
+// RCCL broadcast as scatter + all-gather (count % nranks == 0): chunk q of the buffer goes from the root to rank q
+// (P - 1 concurrent point-to-point sends, one per xGMI link of the root), then an in-place all-gather.
+static int32_t rccl_bcast_sag(dhqr_comm *cm, double *dbuf, int64_t count, int root, hipStream_t stream) {
+  const int P = cm->nranks;
+  const size_t chunk = (size_t)(count / P);
+  RCCLCHECK(g_rccl.GroupStart());
+  if (cm->rank == root) {
+    for (int q = 0; q < P; ++q)
+      if (q != root) RCCLCHECK(g_rccl.Send(dbuf + (size_t)q * chunk, chunk, ncclFloat64, q, cm->nccl, stream));
+  } else {
+    RCCLCHECK(g_rccl.Recv(dbuf + (size_t)cm->rank * chunk, chunk, ncclFloat64, root, cm->nccl, stream));
+  }
+  RCCLCHECK(g_rccl.GroupEnd());
+  RCCLCHECK(g_rccl.AllGather(dbuf + (size_t)cm->rank * chunk, dbuf, chunk, ncclFloat64, cm->nccl, stream));
+  return DHQR_OK;
+}
+
+// Timed trial of the two broadcast algorithms on THIS node (collective over cm; RCCL only): 16 MiB from root 0 and from
+// the last rank, 3 repetitions after a warm-up that also sets up the point-to-point connections.  Every rank takes the
+// same decision from the all-reduced (summed) times.  DHQR_BCAST=ring|sag skips the trial.
+static int32_t comm_tune_bcast(dhqr_comm *cm, hipStream_t stream) {
+  if (!cm || cm->kind != COMM_RCCL || cm->nranks < 2) return DHQR_OK;
+  if (const char *e = getenv("DHQR_BCAST")) {
+    if (!strcmp(e, "ring")) { cm->bcast_algo = 0; return DHQR_OK; }
+    if (!strcmp(e, "sag")) { cm->bcast_algo = g_rccl.has_sag() ? 1 : 0; return DHQR_OK; }
+  }
+  if (!g_rccl.has_sag()) return DHQR_OK;
+  const int P = cm->nranks;
+  const int64_t count = ((int64_t)2 << 20) / P * P;  // ~16 MiB of doubles, divisible by P
+  double *buf = nullptr, *dt = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipMalloc((void **)&buf, (size_t)count * 8) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc of the broadcast trial buffer failed");
+  auto trial = [&]() -> int32_t {
+    HIPCHECK(hipMalloc((void **)&dt, 2 * sizeof(double)));
+    HIPCHECK(hipMemsetAsync(buf, 0, (size_t)count * 8, stream));
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    double ms[2] = {0.0, 0.0};
+    for (int algo = 0; algo < 2; ++algo) {
+      for (int rep = -1; rep < 3; ++rep) {  // rep -1: warm-up
+        if (rep == 0) HIPCHECK(hipEventRecord(e0, stream));
+        for (int root : {0, P - 1}) {
+          if (algo == 0) RCCLCHECK(g_rccl.Broadcast(buf, buf, (size_t)count, ncclFloat64, root, cm->nccl, stream));
+          else CHECK(rccl_bcast_sag(cm, buf, count, root, stream));
+        }
+      }
+      HIPCHECK(hipEventRecord(e1, stream));
+      HIPCHECK(hipStreamSynchronize(stream));
+      float t = 0.f;
+      HIPCHECK(hipEventElapsedTime(&t, e0, e1));
+      ms[algo] = (double)t / 6.0;
+    }
+    HIPCHECK(hipMemcpyAsync(dt, ms, 2 * sizeof(double), hipMemcpyHostToDevice, stream));
+    RCCLCHECK(g_rccl.AllReduce(dt, dt, 2, ncclFloat64, ncclSum, cm->nccl, stream));
+    HIPCHECK(hipMemcpyAsync(ms, dt, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    cm->tune_ms[0] = ms[0] / P;
+    cm->tune_ms[1] = ms[1] / P;
+    cm->bcast_algo = (ms[1] < 0.9 * ms[0]) ? 1 : 0;  // the same sums on every rank: the same decision
+    return DHQR_OK;
+  };
+  const int32_t rc = trial();
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (dt) (void)hipFree(dt);
+  (void)hipFree(buf);
+  return rc;
+}
+
 // Broadcast `count` doubles at dbuf from rank `root`, ordered on `stream`.  *ticket (optional) identifies the
 // operation for comm_wait_consumed.
 static int32_t comm_bcast(dhqr_comm *cm, double *dbuf, int64_t count, int root, hipStream_t stream, int64_t *ticket) {
@@ -149,6 +237,7 @@ static int32_t comm_bcast(dhqr_comm *cm, double *dbuf, int64_t count, int root, 
   cm->bytes_bcast += count * 8;
   cm->n_bcast++;
   if (cm->kind == COMM_RCCL) {
+    if (cm->bcast_algo == 1 && count >= cm->bcast_sag_min && count % cm->nranks == 0) return rccl_bcast_sag(cm, dbuf, count, root, stream);
     RCCLCHECK(g_rccl.Broadcast(dbuf, dbuf, (size_t)count, ncclFloat64, root, cm->nccl, stream));
     return DHQR_OK;
   }

@@ -139,6 +139,13 @@ class Communicator:
             raise _lib.DHQRError(rc, lib.dhqr_last_error().decode(errors="replace"))
         return cls(h, lib, nranks, rank, keepalive=(cb_b, cb_a))
 
+    def bcast_tuning(self) -> dict:
+        """which algorithm the panel broadcasts use and what the trial at creation measured (RCCL transport)"""
+        a, r, g = ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
+        check(self.L.dhqr_comm_get_bcast_tuning(self.handle, ctypes.byref(a), ctypes.byref(r), ctypes.byref(g)))
+        return {"algorithm": {0: "ncclBroadcast", 1: "scatter + all-gather"}[a.value], "trial_ms_16MiB_ncclBroadcast": r.value,
+                "trial_ms_16MiB_scatter_allgather": g.value}
+
     def close(self):
         if self.handle:
             self.L.dhqr_comm_destroy(self.handle)
@@ -289,6 +296,13 @@ class MultiGpuQR:
         t = ctypes.c_int32()
         self._check(self.L.dhqr_mg_info(self._h, None, ctypes.byref(t), None, None))
         return {0: "self", 1: "rccl", 2: "local-peer-copy", 3: "callback"}[t.value]
+
+    def bcast_tuning(self) -> dict:
+        """which algorithm the panel broadcasts use and what the trial at creation measured (RCCL transport)"""
+        a, r, g = ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
+        self._check(self.L.dhqr_mg_get_bcast_tuning(self._h, ctypes.byref(a), ctypes.byref(r), ctypes.byref(g)))
+        return {"algorithm": {0: "ncclBroadcast", 1: "scatter + all-gather"}[a.value], "trial_ms_16MiB_ncclBroadcast": r.value,
+                "trial_ms_16MiB_scatter_allgather": g.value}
 
     # device-resident path (what bench.py times)
     def alloc(self, m, n):

@@ -271,6 +271,11 @@ int32_t dhqr_comm_create_callbacks(dhqr_comm **comm, dhqr_ctx *ctx, int32_t nran
                                    dhqr_bcast_fn bcast, dhqr_allreduce_fn allreduce, void *user);
 int32_t dhqr_comm_destroy(dhqr_comm *comm);
 int32_t dhqr_comm_info(dhqr_comm *comm, int32_t *kind, int32_t *nranks, int32_t *rank, int64_t *bytes_bcast);
+/* RCCL transport: which algorithm large panel broadcasts use -- 0 ncclBroadcast (rings), 1 scatter + all-gather (the root
+ * sends 1/P of the panel to each peer over its own xGMI link, then ncclAllGather) -- and what the timed trial at
+ * communicator creation measured for a 16 MiB broadcast with each (ms; 0 when no trial ran: other transports, or
+ * DHQR_BCAST=ring|sag set).  dhqr_mg_get_bcast_tuning: the same for rank 0 of a single-process handle. */
+int32_t dhqr_comm_get_bcast_tuning(dhqr_comm *comm, int32_t *algo, double *ms_ring, double *ms_scatter_allgather);
 
 /* ------------------------------------------------------------------ multi-GPU: 1-D column split (SPMD, collective)
  * householder!(A::DArray, alpha) (src:115-120).  Layout: BLOCK-CYCLIC columns, block = DHQR_NB: rank r holds the
@@ -314,6 +319,7 @@ typedef struct dhqr_mg dhqr_mg;
 int32_t dhqr_mg_create(dhqr_mg **mg, const int32_t *devices, int32_t ndev);
 int32_t dhqr_mg_destroy(dhqr_mg *mg);
 int32_t dhqr_mg_info(dhqr_mg *mg, int32_t *ndev, int32_t *transport, int64_t *m, int64_t *n);
+int32_t dhqr_mg_get_bcast_tuning(dhqr_mg *mg, int32_t *algo, double *ms_ring, double *ms_scatter_allgather);
 int32_t dhqr_mg_alloc_f64(dhqr_mg *mg, int64_t m, int64_t n);
 int32_t dhqr_mg_fill_uniform_f64(dhqr_mg *mg, uint64_t seed);
 int32_t dhqr_mg_factor_f64(dhqr_mg *mg);
