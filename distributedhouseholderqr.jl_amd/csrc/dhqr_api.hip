@@ -251,9 +251,12 @@ static void launch_nn_sub(dhqr_ctx *c, bool vec, dim3 grid, const double *V, int
 
 // Split-K factor for k_gemm_tn: `ntiles` column tiles x ns row slabs should fill the 512 resident
 // workgroup slots (256 CUs x 2) in whole waves -- 765 workgroups on 512 slots run at 75 %.
+// min_rows: smallest row slab of a split.  The latency-critical narrow products of the panel lane (one or two column
+// tiles: Gram matrices, the look-ahead update) go down to 64 rows per workgroup: a workgroup's time is its K loop
+// (1.7 us of MFMA per 16-row K-tile on one CU), so at 8192 rows 128 workgroups x 4 K-tiles beat 64 x 8.
 static void pick_split(int64_t rows, int64_t ntiles, int64_t target_wgs, int64_t max_split,
-                       int64_t *nsplit, int64_t *rps, int64_t slots = 512) {
-  int64_t cap = std::min<int64_t>(max_split, std::max<int64_t>(1, rows / 128));
+                       int64_t *nsplit, int64_t *rps, int64_t slots = 512, int64_t min_rows = 128) {
+  int64_t cap = std::min<int64_t>(max_split, std::max<int64_t>(1, rows / min_rows));
   int64_t best = 1;
   double best_score = -1.0;
   for (int64_t ns = 1; ns <= cap; ++ns) {
@@ -321,12 +324,12 @@ static int32_t panel_apply(dhqr_ctx *c, const PanelBuf &pb, int64_t rows, double
   if (ncols <= 0 || rows <= 0) return DHQR_OK;
   const int64_t ldv = pb.ldv;
   const double *V = pb.V;
-  const double *Top = trans ? pb.T : pb.Tt;
+  const double *Top = trans ? pb.T : pb.Tt, *TopT = trans ? pb.Tt : pb.T;
   const int64_t ntiles = (ncols + 127) / 128;
   int64_t nsplit, rps;
   // narrow updates (one or two column tiles: the look-ahead lane / a rank's single block) are split
   // over up to 256 row slabs so the latency-critical chain uses the whole chip
-  pick_split(rows, ntiles, 512, ntiles <= 2 ? 256 : 64, &nsplit, &rps);
+  pick_split(rows, ntiles, 512, ntiles <= 2 ? 256 : 64, &nsplit, &rps, 512, ntiles <= 2 ? 64 : 128);
   dhqr_ctx::WS &ws = c->ws[c->cur_ws];
   CHECK(ensure(c, ws.w1, (size_t)nsplit * DHQR_NBV * (size_t)ncols));
   CHECK(ensure(c, ws.w2, (size_t)DHQR_NBV * (size_t)ncols));
@@ -354,6 +357,10 @@ static int32_t panel_apply(dhqr_ctx *c, const PanelBuf &pb, int64_t rows, double
                          c->stream, (const double *)ws.w1.p, (int)nsplit, wstride, wstride, ws.w1r.p); \
       w1sum = ws.w1r.p;                                                                              \
     }                                                                                                \
+    if (KW_ == DHQR_NBV && ntiles <= 2) /* the lane's narrow updates: k_tw_fused (dhqr_gemm.h) */    \
+      hipLaunchKernelGGL((k_tw_fused<false>), dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, c->stream, w1sum, ncols, \
+                         TopT, (const double *)nullptr, (const double *)nullptr, ws.w2.p);              \
+    else                                                                                             \
     hipLaunchKernelGGL((k_gemm_tn<2, 1, KW_>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top, \
                        (int64_t)DHQR_NBV, w1sum, (int64_t)DHQR_NBV, 1, (int64_t)0, (int64_t)KW_, ncols,  \
                        (int64_t)KW_, ws.w2.p, (int64_t)DHQR_NBV, (int64_t)0);                            \
@@ -462,7 +469,7 @@ static int32_t factor_panel_v2(dhqr_ctx *c, double *P, int64_t rows, int64_t w, 
 // G = X'X (128 x 128) for a rows x 128 operand: split-K TN GEMM + deterministic reduction.
 static int32_t gram128(dhqr_ctx *c, const double *X, int64_t ldx, int64_t rows, double *out) {
   int64_t nsplit, rps;
-  pick_split(rows, 1, 512, 256, &nsplit, &rps);
+  pick_split(rows, 1, 512, 256, &nsplit, &rps, 512, 64);
   CHECK(ensure(c, c->spart, (size_t)nsplit * DHQR_NBV * DHQR_NBV));
   const bool vec = (ldx % 2 == 0) && (rows % 2 == 0) && aligned16(X);
   if (vec)
@@ -672,7 +679,7 @@ static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t 
       launch_recon_top(c, P, ldp, Rf, altmp, Rref, negMinv);                        // alpha, R_ref, -M^{-1}
     } else {  // R = chol(P'P), replay, -M^{-1} in one launch
       CHECK(gram128(c, P, ldp, rows, G));
-      hipLaunchKernelGGL(k_panel_top, dim3(1), dim3(1024), 0, c->stream, (const double *)G, (const double *)P, ldp, altmp,
+      hipLaunchKernelGGL((k_panel_top<false>), dim3(1), dim3(1024), 0, c->stream, (const double *)G, (const double *)P, ldp, altmp,
                          Rref, negMinv, bflag);
     }
     CHECK(mul128(c, X, ldx, rows, negMinv, pb.V, ldv));                            // Vw = X M^{-1}
@@ -753,7 +760,7 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   const int64_t ntiles = (ncols + 127) / 128;
   int64_t nsplit, rps;
   // k_gemm_tn2 workgroups have 512 threads and 110 KB of LDS: one per CU, 256 resident
-  pick_split(rows, ntiles, 256, ntiles <= 2 ? 256 : 64, &nsplit, &rps, 256);
+  pick_split(rows, ntiles, 256, ntiles <= 2 ? 256 : 64, &nsplit, &rps, 256, ntiles <= 2 ? 64 : 128);
   dhqr_ctx::WS &ws = c->ws[c->cur_ws];
   const int64_t ld2 = 2 * DHQR_NBV;
   CHECK(ensure(c, ws.w1, (size_t)nsplit * ld2 * (size_t)ncols));
@@ -778,6 +785,13 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   CHECK(prof_begin(c, CAT_TW));
   if (ar) CHECK(comm_allreduce_sum(ar, ws.w1r.p, wstride, c->stream));
   double *Ya = ws.w1r.p, *Yb = ws.w1r.p + DHQR_NBV;  // rows 0..127 / 128..255 of Y (ld 256)
+  if (ntiles <= 2) {
+    // the lane's narrow update: all three T products in one launch (k_tw_fused, dhqr_gemm.h); T' of a panel sits right
+    // behind its T in every operand buffer ([T | T' | alpha]: PanelBuf tails, row-split slots)
+    const int64_t NN_ = (int64_t)DHQR_NBV * DHQR_NBV;
+    hipLaunchKernelGGL((k_tw_fused<true>), dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, c->stream, (const double *)ws.w1r.p, ncols,
+                       Ta + NN_, Tb + NN_, Sba, ws.w2.p);
+  } else {
   // W_a = T_a' Y_a  -> rows 0..127 of W2 (ld 256)
   hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Ta, (int64_t)DHQR_NBV,
                      (const double *)Ya, ld2, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV, ws.w2.p, ld2,
@@ -789,6 +803,7 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Tb, (int64_t)DHQR_NBV,
                      (const double *)Yb, ld2, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV,
                      ws.w2.p + DHQR_NBV, ld2, (int64_t)0);
+  }
   CHECK(prof_end(c));
 
   CHECK(prof_begin(c, CAT_AVW));
@@ -811,7 +826,7 @@ static int32_t pair_cross_gram(dhqr_ctx *c, const double *Vp, int64_t ldv, int64
   const int64_t NB = DHQR_NBV, rows_b = rows_a - NB;
   const size_t NN = (size_t)NB * NB;
   int64_t nsplit, rps;
-  pick_split(rows_b, 1, 512, 256, &nsplit, &rps);
+  pick_split(rows_b, 1, 512, 256, &nsplit, &rps, 512, 64);
   CHECK(ensure(c, c->spart, (size_t)nsplit * NN));
   const double *Vb = Vp + NB + NB * ldv;
   const bool vec = (ldv % 2 == 0) && (rows_b % 2 == 0) && aligned16(Vp);

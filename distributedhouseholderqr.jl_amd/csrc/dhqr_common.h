@@ -134,6 +134,38 @@ __device__ __forceinline__ double dd_block_sum(dhqr_dd v, double *red) {
 }
 
 
+// sqrt(d) and 1/sqrt(d) of a positive, normally scaled d (the pivots of a panel's Gram matrix) without the range scaling,
+// special-case selects and the second division chain of `sqrt(d); 1.0 / r`: v_rsq_f64, one coupled Goldschmidt step and two
+// residual corrections -- the compiler's own sequence for the square root, same result -- and the reciprocal root falls
+// out of it with one Newton step.  On the critical chain of k_panel_top (dhqr_recon.h) the row owners execute ~110
+// dependent FP64 instructions per elimination step while fifteen waves wait at the barrier; this halves them.
+// inf / NaN propagate (a broken panel is rejected by its verification).
+__device__ __forceinline__ void dhqr_sqrt_rsqrt(double d, double &r, double &rinv) {
+  const double y = __builtin_amdgcn_rsq(d);
+  double g = d * y, h = 0.5 * y;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  e = fma(-g, g, d);
+  g = fma(e, h, g);
+  e = fma(-g, g, d);
+  g = fma(e, h, g);
+  double x = h + h;
+  e = fma(-g, x, 1.0);
+  x = fma(x, e, x);
+  r = g;
+  rinv = x;
+}
+// 1/x to within an ulp for a normally scaled x: v_rcp_f64 + two Newton steps (no div_scale / div_fmas / div_fixup)
+__device__ __forceinline__ double dhqr_rcp(double x) {
+  double z = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, z, 1.0);
+  z = fma(z, e, z);
+  e = fma(-x, z, 1.0);
+  z = fma(z, e, z);
+  return z;
+}
+
 // src:8  alphafactor(x::Real) = -sign(x)  (sign(0) == 0 in Julia: a zero pivot gives alpha = -0*s)
 __device__ __forceinline__ double dhqr_alphafactor(double x) {
   return x > 0.0 ? -1.0 : (x < 0.0 ? 1.0 : -x);

@@ -630,6 +630,63 @@ __global__ __launch_bounds__(256) void k_reduce_splits(const double *__restrict_
   if (grp == 0 && e < count) out[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+// The T products of a NARROW update (one or two column tiles: the look-ahead lane) in one launch, Y = the reduced
+// split-K sums (ldy x ncols; ldy = 128, or 256 = [y_a; y_b] for a pair of panels):
+//   w_a = Top_a' y_a;   pair:  y_b -= Sba w_a,  w_b = Top_b' y_b;      W2 <- [w_a; w_b]
+// with TaT / TbT = the TRANSPOSES of Top_a / Top_b (column-major, so a wave reads 64 consecutive doubles per term).
+// Through the GEMM kernels these were one to three 128 x 128 x ncols products of ONE workgroup per 128 columns -- 23 us
+// each (a workgroup's K loop on one CU), up to 70 us of a pair's critical chain; here 4 columns per workgroup (64
+// workgroups for 256 columns), a few microseconds.  Deterministic: fixed summation order.
+template <bool PAIR>
+__global__ __launch_bounds__(256) void k_tw_fused(const double *__restrict__ Y, int64_t ncols, const double *__restrict__ TaT,
+                                                  const double *__restrict__ TbT, const double *__restrict__ Sba,
+                                                  double *__restrict__ W2) {
+  constexpr int LDY = PAIR ? 256 : 128, NC = 4;
+  __shared__ double y[NC][LDY], wa[NC][128];
+  const int t = threadIdx.x, p = t & 127, ch = t >> 7;  // this thread: output row p of columns 2 ch, 2 ch + 1
+  const int64_t c0 = (int64_t)blockIdx.x * NC;
+  for (int e = t; e < NC * LDY; e += 256) {  // the 4-column slab of Y
+    const int c = e / LDY, r = e - c * LDY;
+    y[c][r] = (c0 + c < ncols) ? Y[r + (c0 + c) * LDY] : 0.0;
+  }
+  __syncthreads();
+  auto tprod = [&](const double *__restrict__ TT, const double (*v)[LDY], int off, double &o0, double &o1) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < 128; ++r) {
+      const double tv = TT[p + r * 128];
+      s0 = fma(tv, v[2 * ch][off + r], s0);
+      s1 = fma(tv, v[2 * ch + 1][off + r], s1);
+    }
+    o0 = s0;
+    o1 = s1;
+  };
+  double a0, a1;
+  tprod(TaT, y, 0, a0, a1);  // w_a = Top_a' y_a
+  if (c0 + 2 * ch < ncols) W2[p + (c0 + 2 * ch) * LDY] = a0;
+  if (c0 + 2 * ch + 1 < ncols) W2[p + (c0 + 2 * ch + 1) * LDY] = a1;
+  if constexpr (PAIR) {
+    wa[2 * ch][p] = a0;
+    wa[2 * ch + 1][p] = a1;
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;  // y_b -= Sba w_a  (Sba = V_b'V_a, column-major)
+#pragma unroll 8
+    for (int q = 0; q < 128; ++q) {
+      const double sv = Sba[p + q * 128];
+      s0 = fma(sv, wa[2 * ch][q], s0);
+      s1 = fma(sv, wa[2 * ch + 1][q], s1);
+    }
+    __syncthreads();  // nobody reads y_a any more; y_b rows are private to their (p, ch) owners until the barrier below
+    y[2 * ch][128 + p] -= s0;
+    y[2 * ch + 1][128 + p] -= s1;
+    __syncthreads();
+    double b0, b1;
+    tprod(TbT, y, 128, b0, b1);  // w_b = Top_b' y_b
+    if (c0 + 2 * ch < ncols) W2[128 + p + (c0 + 2 * ch) * LDY] = b0;
+    if (c0 + 2 * ch + 1 < ncols) W2[128 + p + (c0 + 2 * ch + 1) * LDY] = b1;
+  }
+}
+
 // Compact-WY algebra used by the T kernel (k_build_t3, dhqr_recon.h): for reflectors
 // H_j = I - v_j v_j' (tau_j == 1 because ||v_j||^2 = 2), H_1...H_nb = I - V T V' with
 //   T^{-1} = I + striu(V'V),  equivalently  T[0:j, j] = -T[0:j,0:j] (V'V)[0:j, j], T[j][j] = 1.

@@ -105,11 +105,16 @@ __device__ __forceinline__ void rc_cholesky_regs(double (&g)[4][4], double *rowb
         }
       }
       __syncthreads();
+      // Only the blocks that still change and are read later: rows > j live in the cyclic blocks a >= ja, and only the
+      // upper triangle of G is ever used (block b >= a).  The skipped products are exact zeros (rb[k] = 0 for k <= j)
+      // or land strictly below the diagonal: 10 / 6 / 3 / 1 of the 16 blocks per thread for ja = 0 .. 3.
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
+        if (a < ja) continue;
         const double ri = rb[ti + 32 * a];  // 0 for rows <= j
 #pragma unroll
-        for (int b = 0; b < 4; ++b) g[a][b] = fma(-ri, rb[tk + 32 * b], g[a][b]);
+        for (int b = 0; b < 4; ++b)
+          if (b >= a) g[a][b] = fma(-ri, rb[tk + 32 * b], g[a][b]);
       }
     }
 }
@@ -179,8 +184,8 @@ __global__ __launch_bounds__(1024) void k_chol_inv(const double *__restrict__ G,
 //   P3  the same step once more for the 128 x 128 matrix: two 64^3 products, four elements per thread.
 // Input: Mg = global 128 x 128 column-major, strictly upper part used for columns < ncols (others are
 // treated as 0), diagonal taken as 1 when `unit` (T^{-1} = I + striu(V'V)) else read from Mg.
-// Output: x12[4] (this thread's entries of the upper-right 64 x 64 block, element e = t + 1024 r ->
-// row e & 63, column 64 + (e >> 6)) and the two diagonal 64 x 64 inverses in Xh.  All global reads of Mg
+// Output: x12[4] (this thread's entries of the upper-right 64 x 64 block in the MFMA tile map: wave w = t >> 6 owns tile
+// (w & 3, w >> 2), register g of lane l is row 16 (w & 3) + (l >> 4) + 4 g, column 64 + 16 (w >> 2) + (l & 15)) and the two diagonal 64 x 64 inverses in Xh.  All global reads of Mg
 // are finished when the function returns, so the caller may overwrite Mg with the result.
 #define RC5_LDD 33
 #define RC5_LDH 65
@@ -193,23 +198,37 @@ struct rc5_lds {
 // ncols < 0: real embedding of -ncols/2 complex reflectors (dhqr_complex.h): the strict upper part is taken at the
 // level of the 2 x 2 blocks [[Re, -Im], [Im, Re]] -- the (2p, 2p+1) entry of a diagonal block is the imaginary part of
 // ||v_p||^2 (zero up to rounding) and does not belong to striu(V^H V).
-__device__ __forceinline__ double rc5_in(const double *__restrict__ Mg, int i, int k, int ncols) {
+// rs != nullptr (k_panel_top): the matrix is given as D * Mg off the diagonal with D = diag(rs[0..128)) and its diagonal
+// in rs[128..256) (LDS): M[j][k] = dl_jk / v_jj is stored unscaled by the elimination loop, whose owners know v_jj only
+// after a square root that is kept off their critical chain.
+__device__ __forceinline__ double rc5_in(const double *__restrict__ Mg, int i, int k, int ncols, const double *rs = nullptr) {
   const bool upper = (ncols < 0) ? ((i >> 1) < (k >> 1)) : (i < k);
   const int nc = ncols < 0 ? -ncols : ncols;
-  return (upper && k < nc) ? Mg[i + k * RC_N] : 0.0;
+  const double v = (upper && k < nc) ? Mg[i + k * RC_N] : 0.0;
+  return rs ? v * rs[i] : v;
 }
+#ifdef RC5_TIME
+__device__ unsigned long long g_rc5_phase[8];
+#define RC5_MARK(q) do { if (threadIdx.x == 0) { const long long now_ = clock64(); g_rc5_phase[q] += (unsigned long long)(now_ - tm_); tm_ = now_; } } while (0)
+#else
+#define RC5_MARK(q) do { } while (0)
+#endif
 __device__ __forceinline__ void rc_upper_inverse_blocked(const double *__restrict__ Mg, int ncols, bool unit,
-                                                         rc5_lds &L, double (&x12)[4]) {
+                                                         rc5_lds &L, double (&x12)[4], const double *rs = nullptr) {
   const int t = threadIdx.x;
+#ifdef RC5_TIME
+  long long tm_ = clock64();
+#endif
   // ---- P0: stage the diagonal blocks, 1/diag, clear Xh
   for (int e = t; e < 2 * 64 * RC5_LDH; e += 1024) (&L.Xh[0][0][0])[e] = 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int e = t + 1024 * r, d = e >> 10, i = e & 31, l = (e >> 5) & 31;
-    L.Ud[d][i][l] = rc5_in(Mg, 32 * d + i, 32 * d + l, ncols);
+    L.Ud[d][i][l] = rc5_in(Mg, 32 * d + i, 32 * d + l, ncols, rs);
   }
-  if (t < RC_N) L.dinv[t] = unit ? 1.0 : 1.0 / Mg[t + t * RC_N];
+  if (t < RC_N) L.dinv[t] = unit ? 1.0 : 1.0 / (rs ? rs[RC_N + t] : Mg[t + t * RC_N]);
   __syncthreads();
+  RC5_MARK(0);
   // ---- P1: column k of the inverse of diagonal block d, one lane per column, registers only
   if (t < RC_N) {
     const int d = t >> 5, k = t & 31;
@@ -226,43 +245,85 @@ __device__ __forceinline__ void rc_upper_inverse_blocked(const double *__restric
     for (int i = 0; i < 32; ++i) L.Xh[h][o + i][o + k] = x[i];
   }
   __syncthreads();
-  // ---- P2: upper-right 32 x 32 block of each 64 x 64 diagonal block
-  {
-    const int i = t & 31, j = t >> 5;
+  RC5_MARK(1);
+  // The off-diagonal blocks the next phases multiply with are read from global memory HERE, once, coalesced (b3: the
+  // 64 x 64 block B of P3, parked in registers until P2 is done; the two 32 x 32 blocks B_h of P2 go straight to LDS: the Ud
+  // array is free now, Bh[h][i][l] = L.Ud[h][i][l]).  With the loads inside the product loops (data-dependent trip counts,
+  // one L2 round trip per iteration) the inverse took 114k of the kernel's 315k cycles (tools/top_probe); loading them
+  // before P1 instead would keep 12 more registers alive across its 32-element solution vectors (spills).
+  double b3[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {  // T1a = B_h * C_h^{-1}   (C^{-1} upper triangular: l <= j)
-      double s = 0.0;
-      for (int l = 0; l <= j; ++l) s = fma(rc5_in(Mg, 64 * h + i, 64 * h + 32 + l, ncols), L.Xh[h][32 + l][32 + j], s);
-      L.T1[32 * h + i][j] = s;
-    }
-    __syncthreads();
-    double y[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {  // X12_h = -A_h^{-1} * T1a   (A^{-1} upper triangular: l >= i)
-      double s = 0.0;
-      for (int l = i; l < 32; ++l) s = fma(L.Xh[h][i][l], L.T1[32 * h + l][j], s);
-      y[h] = -s;
-    }
-    L.Xh[0][i][32 + j] = y[0];  // nobody reads the X12 corner in this phase
-    L.Xh[1][i][32 + j] = y[1];
+  for (int r = 0; r < 4; ++r) {
+    const int e = t + 1024 * r;
+    b3[r] = rc5_in(Mg, e & 63, 64 + (e >> 6), ncols, rs);
   }
-  __syncthreads();  // X12 corners visible; T1 free for reuse
-  // ---- P3: upper-right 64 x 64 block of the whole matrix
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {  // T1 = B * C^{-1},  C^{-1} = Xh[1]
-    const int e = t + 1024 * r, i = e & 63, j = e >> 6;
-    double s = 0.0;
-    for (int l = 0; l <= j; ++l) s = fma(rc5_in(Mg, i, 64 + l, ncols), L.Xh[1][l][j], s);
-    L.T1[i][j] = s;
+  {
+    const int i = t & 31, l = t >> 5;
+    L.Ud[0][i][l] = rc5_in(Mg, i, 32 + l, ncols, rs);
+    L.Ud[1][i][l] = rc5_in(Mg, 64 + i, 96 + l, ncols, rs);
   }
   __syncthreads();
+  // ---- P2 / P3 on the matrix cores.  The triangular products are small dense GEMMs (the zeros below the diagonals are
+  // stored zeros): v_mfma_f64_16x16x4_f64, one 16 x 16 output tile per wave, fragments straight from LDS.  The scalar
+  // version (one dot product of up to 64 terms per output, two LDS reads per fma) was LDS-bandwidth bound: 49k of the
+  // kernel's cycles (tools/top_probe).  Operand maps as in dhqr_gemm.h: A lane (i = l & 15, k = l >> 4), B lane
+  // (k = l >> 4, j = l & 15), D register g of lane l = D[(l >> 4) + 4 g][l & 15].
+  const int lane = t & 63, w = t >> 6, fi = lane & 15, fk = lane >> 4;
+  // ---- P2: upper-right 32 x 32 block of each 64 x 64 diagonal block: X12_h = -A_h^{-1} (B_h C_h^{-1})
+  {
+    const int h = w >> 2, ti = (w >> 1) & 1, tj = w & 1;  // waves 0..7: one tile of T1a_h each
+    if (w < 8) {
+      dhqr_d4 acc = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {  // X12 = -A^{-1} * T1,  A^{-1} = Xh[0]
-    const int e = t + 1024 * r, i = e & 63, j = e >> 6;
-    double s = 0.0;
-    for (int l = i; l < 64; ++l) s = fma(L.Xh[0][i][l], L.T1[l][j], s);
-    x12[r] = -s;
+      for (int ks = 0; ks < 8; ++ks)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L.Ud[h][16 * ti + fi][4 * ks + fk], L.Xh[h][32 + 4 * ks + fk][32 + 16 * tj + fi],
+                                                  acc, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) L.T1[32 * h + 16 * ti + fk + 4 * g][16 * tj + fi] = acc[g];
+    }
+    __syncthreads();
+    dhqr_d4 acc = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+    if (w < 8) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L.Xh[h][16 * ti + fi][4 * ks + fk], L.T1[32 * h + 4 * ks + fk][16 * tj + fi], acc, 0,
+                                                  0, 0);
+    }
+    if (w < 8) {  // the X12 corners (columns 32..63 of Xh[h]) are read by nobody in this phase
+#pragma unroll
+      for (int g = 0; g < 4; ++g) L.Xh[h][16 * ti + fk + 4 * g][32 + 16 * tj + fi] = -acc[g];
+    }
+    // the block B of P3 -> LDS: B3[i][l] at (&L.Ud[0][0][0])[i * RC5_LDH + l] (the B_h copies were last read before the
+    // first barrier of this phase)
+    double *B3w = &L.Ud[0][0][0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = t + 1024 * r;
+      B3w[(e & 63) * RC5_LDH + (e >> 6)] = b3[r];
+    }
   }
+  __syncthreads();  // X12 corners and B visible; T1 free for reuse
+  RC5_MARK(2);
+  // ---- P3: upper-right 64 x 64 block of the whole matrix: X12 = -A^{-1} (B C^{-1}), A^{-1} = Xh[0], C^{-1} = Xh[1]
+  {
+    const double *B3 = &L.Ud[0][0][0];
+    const int ti = w & 3, tj = w >> 2;  // 16 waves: one tile each
+    dhqr_d4 acc = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(B3[(16 * ti + fi) * RC5_LDH + 4 * ks + fk], L.Xh[1][4 * ks + fk][16 * tj + fi], acc, 0, 0,
+                                                0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) L.T1[16 * ti + fk + 4 * g][16 * tj + fi] = acc[g];
+    __syncthreads();
+    acc = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L.Xh[0][16 * ti + fi][4 * ks + fk], L.T1[4 * ks + fk][16 * tj + fi], acc, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) x12[g] = -acc[g];  // X12[16 ti + fk + 4 g][16 tj + fi]
+  }
+  RC5_MARK(3);
 }
 // store helper: calls put(i, k, value) for this thread's 16 entries of the full 128 x 128 result
 template <typename F>
@@ -273,7 +334,7 @@ __device__ __forceinline__ void rc5_emit(const rc5_lds &L, const double (&x12)[4
     const int e = t + 1024 * r, i = e & 63, j = e >> 6;
     put(i, j, L.Xh[0][i][j]);            // upper-left  (zero below its diagonal)
     put(64 + i, 64 + j, L.Xh[1][i][j]);  // lower-right
-    put(i, 64 + j, x12[r]);              // upper-right
+    put(16 * ((t >> 6) & 3) + ((t & 63) >> 4) + 4 * r, 64 + 16 * (t >> 8) + (t & 15), x12[r]);  // upper-right (MFMA tile map)
     put(64 + i, j, 0.0);                 // lower-left
   }
 }
@@ -355,11 +416,14 @@ __device__ __forceinline__ void rc_replay_and_invert(double (&a)[4][4], const do
         }
       }
       __syncthreads();
+      // rows / columns <= j are finished (vc[i] = 0, wr[k] = 0 there): only the cyclic blocks x, y >= ja still change
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
+        if (x < ja) continue;
         const double vi = vc[ti + 32 * x];
 #pragma unroll
-        for (int y = 0; y < 4; ++y) a[x][y] = fma(-vi, wr[tk + 32 * y], a[x][y]);  // src:209, top rows
+        for (int y = 0; y < 4; ++y)
+          if (y >= ja) a[x][y] = fma(-vi, wr[tk + 32 * y], a[x][y]);  // src:209, top rows
       }
     }
 #pragma unroll
@@ -371,6 +435,119 @@ __device__ __forceinline__ void rc_replay_and_invert(double (&a)[4][4], const do
   rc_upper_inverse_blocked(negMinv, RC_N, false, L, x12);
   __syncthreads();  // every read of M is done (the last ones are in P3's first product): overwrite it
   rc5_emit(L, x12, [&](int i, int k, double v) { negMinv[i + k * RC_N] = -v; });
+}
+
+// Cholesky and replay in ONE loop (k_panel_top): row j of R is final after Cholesky step j and the replay's step j
+// needs nothing else of R, and the thread that owns row j of G owns row j of the top block too -- so step j of both
+// runs between the same two barriers: 128 barriers per panel instead of 256, and the latencies of one step's scalar
+// chain (sqrt, reciprocal) overlap the other's.  Arithmetic identical to rc_cholesky_regs + rc_replay_and_invert.
+// rb / wr / vc: 2 x 128 doubles of LDS each (double buffered by step parity).
+// Phase clock of the TIME instantiation (tools/top_probe.cpp only): summed shader cycles of wave 0 per phase --
+// [0] pivot shuffles, [1] row / column owners' work (the scalar chain when wave 0 owns the row), [2] wait at the barrier
+// (= the owners' chain seen by everybody else), [3] rank-1 updates, [4] blocked inverse + stores, [5] steps.
+__device__ unsigned long long g_top_phase[8];
+template <bool TIME = false>
+__device__ __forceinline__ void rc_chol_replay_invert(double (&g)[4][4], double (&a)[4][4], double *rbuf, double *wrow,
+                                                      double *vcol, rc5_lds &L, double *__restrict__ alpha,
+                                                      double *__restrict__ Rref, double *__restrict__ negMinv,
+                                                      int *__restrict__ flag) {
+  const int t = threadIdx.x, ti = t >> 5, tk = t & 31, lane = t & 63;
+  double *qu = &L.T1[0][0];  // q_j, u_j of every row (2 x 128 doubles; T1 is not used before P2 of the inverse)
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja)
+    for (int jm = 0; jm < 32; ++jm) {
+      const int j = ja * 32 + jm;
+      const int src = (lane & 32) + jm;
+      long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
+      if constexpr (TIME) tq0 = clock64();
+      double d = __shfl(g[ja][ja], src, 64);
+      const double ajj = __shfl(a[ja][ja], src, 64);
+      if constexpr (TIME) {
+        asm volatile("" : "+v"(d));
+        tq1 = clock64();
+      }
+      double *rb = rbuf + (j & 1) * RC_N, *wr = wrow + (j & 1) * RC_N, *vc = vcol + (j & 1) * RC_N;
+      if (ti == jm) {  // owners of row j of G and of the top block
+        if (!(d > 0.0)) {  // breakdown (or NaN): flag it, keep going with a harmless pivot
+          if (tk == 0) flag[0] = 1;
+          d = 1.0;
+        }
+        double r, rinv;
+        dhqr_sqrt_rsqrt(d, r, rinv);                  // R_jj > 0 and its reciprocal (dhqr_common.h)
+        const double al = r * dhqr_alphafactor(ajj);  // src:129-130 with s = |R_jj|
+        const double u = dhqr_rcp(ajj - al);          // = f / v_jj
+        // src:131: f = 1/sqrt(q), v_jj = (a_jj - alpha) f.  Only M needs sqrt(q) (M[j][j] = 1/f_j, M[j][k] = dl / v_jj),
+        // and M is not used before the loop ends: q and u are parked in LDS and the square root leaves the critical chain
+        if (tk == 0) {
+          qu[j] = r * (r + fabs(ajj));
+          qu[RC_N + j] = u;
+        }
+        const double sg = (al == 0.0) ? 0.0 : (al < 0.0 ? -1.0 : 1.0);  // row sign of the reference's R: R_jj = alpha_j
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          const int k = tk + 32 * y;
+          const double x = (k == j) ? r : g[ja][y] * rinv;  // R[j,k]
+          g[ja][y] = x;
+          rb[k] = (k > j) ? x : 0.0;
+          const double rr = sg * x;
+          const double dl = (k > j) ? (a[ja][y] - rr) : 0.0;
+          wr[k] = dl * u;                                              // f * (v_j' a_k)
+          negMinv[j + k * RC_N] = dl;                                  // M[j][k] = dl / v_jj: the scale joins in the inverse
+          Rref[j + k * RC_N] = (k > j) ? rr : 0.0;
+        }
+        if (tk == 0) alpha[j] = al;
+      }
+      if (tk == jm) {  // owners of column j of the top block: the unscaled a_ij (i > j); f travels in the row
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int i = ti + 32 * x;
+          vc[i] = (i > j) ? a[x][ja] : 0.0;
+        }
+      }
+      if constexpr (TIME) tq2 = clock64();
+      __syncthreads();
+      if constexpr (TIME) tq3 = clock64();
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        if (x < ja) continue;
+        const double ri = rb[ti + 32 * x], vi = vc[ti + 32 * x];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          if (y < ja) continue;
+          const double rk = rb[tk + 32 * y];
+          if (y >= x) g[x][y] = fma(-ri, rk, g[x][y]);
+          a[x][y] = fma(-vi, wr[tk + 32 * y], a[x][y]);  // src:209, top rows
+        }
+      }
+      if constexpr (TIME) {
+        asm volatile("" : "+v"(a[3][3]), "+v"(g[3][3]));
+        const long long tq4 = clock64();
+        if (t == 0) {
+          g_top_phase[0] += (unsigned long long)(tq1 - tq0);
+          g_top_phase[1] += (unsigned long long)(tq2 - tq1);
+          g_top_phase[2] += (unsigned long long)(tq3 - tq2);
+          g_top_phase[3] += (unsigned long long)(tq4 - tq3);
+          g_top_phase[5] += 1ull;
+        }
+      }
+    }
+  long long tinv = 0;
+  if constexpr (TIME) tinv = clock64();
+  __syncthreads();  // qu of the last rows visible
+  if (t < RC_N) {  // M[j][j] = 1/f_j = sqrt(q_j); row scale of M: 1 / v_jj = sqrt(q_j) u_j
+    const double sq = sqrt(qu[t]);
+    qu[t] = sq * qu[RC_N + t];
+    qu[RC_N + t] = sq;
+  }
+  __syncthreads();  // the workgroup's global writes are visible to all of its threads
+  double x12[4];
+  rc_upper_inverse_blocked(negMinv, RC_N, false, L, x12, qu);
+  __syncthreads();  // every read of M is done (the last ones are in P3's first product): overwrite it
+  rc5_emit(L, x12, [&](int i, int k, double v) { negMinv[i + k * RC_N] = -v; });
+  if constexpr (TIME) {
+    __builtin_amdgcn_s_waitcnt(0);
+    if (t == 0) g_top_phase[4] += (unsigned long long)(clock64() - tinv);
+  }
 }
 
 // Replay with R given in global memory (row-split driver: R comes from the all-reduced Gram matrix; second
@@ -398,25 +575,23 @@ __global__ __launch_bounds__(1024) void k_recon_top(const double *__restrict__ P
 // The whole top block of an R-first panel in ONE single-workgroup launch: G = P'P -> R = chol(G) (registers) ->
 // replay -> -M^{-1}.  One launch (and one wait for an idle CU under the trailing-update GEMMs) less per panel
 // than k_chol_inv + k_recon_top, and R never leaves the registers.
+template <bool TIME = false>
 __global__ __launch_bounds__(1024) void k_panel_top(const double *__restrict__ G, const double *__restrict__ P,
                                                      int64_t ldp, double *__restrict__ alpha,
                                                      double *__restrict__ Rref, double *__restrict__ negMinv,
                                                      int *__restrict__ flag) {
-  __shared__ double wrow[2 * RC_N], vcol[2 * RC_N];
+  __shared__ double rbuf[2 * RC_N], wrow[2 * RC_N], vcol[2 * RC_N];
   __shared__ rc5_lds L;
   const int t = threadIdx.x, ti = t >> 5, tk = t & 31;
   double g[4][4], a[4][4];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) g[x][y] = G[(ti + 32 * x) + (tk + 32 * y) * RC_N];
-  rc_cholesky_regs(g, wrow, flag);
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) a[x][y] = P[(ti + 32 * x) + (int64_t)(tk + 32 * y) * ldp];
-  __syncthreads();  // the last Cholesky step's readers of wrow are done before the replay reuses it
-  rc_replay_and_invert(a, g, wrow, vcol, L, alpha, Rref, negMinv);
+    for (int y = 0; y < 4; ++y) {
+      g[x][y] = G[(ti + 32 * x) + (tk + 32 * y) * RC_N];
+      a[x][y] = P[(ti + 32 * x) + (int64_t)(tk + 32 * y) * ldp];
+    }
+  rc_chol_replay_invert<TIME>(g, a, rbuf, wrow, vcol, L, alpha, Rref, negMinv, flag);
 }
 
 // Vw currently holds P * M^{-1}; finish V = tril((P - alpha E) M^{-1}) on the top 128 rows:

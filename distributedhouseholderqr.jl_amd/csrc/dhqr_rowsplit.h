@@ -231,7 +231,7 @@ static int32_t rs_vtc_allreduce(const RsProblem &pr, dhqr_comm *cmx, const doubl
   } else {
     const int64_t ntiles = (ncols + 127) / 128;
     int64_t nsplit, rps;
-    pick_split(rows, ntiles, 512, ntiles <= 2 ? 256 : 64, &nsplit, &rps);
+    pick_split(rows, ntiles, 512, ntiles <= 2 ? 256 : 64, &nsplit, &rps, 512, ntiles <= 2 ? 64 : 128);
     CHECK(ensure(c, ws.w1, (size_t)nsplit * NB * (size_t)ncols));
     const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(V);
     const dim3 gtn((unsigned)ntiles, (unsigned)nsplit);
@@ -249,12 +249,17 @@ static int32_t rs_vtc_allreduce(const RsProblem &pr, dhqr_comm *cmx, const doubl
   return DHQR_OK;
 }
 // C (rows x ncols) -= V (op(T)' Y): W = Top' Y, then the NN GEMM (predicated when `pred`)
+// TopT: the transpose of Top when the caller has it (narrow updates then use k_tw_fused, dhqr_gemm.h), else nullptr.
 static int32_t rs_apply_w(const RsProblem &pr, const double *V, int64_t ldv, const double *Top, double *C, int64_t ldc,
-                          int64_t rows, int64_t ncols, bool pred) {
+                          int64_t rows, int64_t ncols, bool pred, const double *TopT = nullptr) {
   dhqr_ctx *c = pr.c;
   dhqr_ctx::WS &ws = c->ws[c->cur_ws];
   const int64_t NB = DHQR_NBV, ntiles = (ncols + 127) / 128;
   CHECK(ensure(c, ws.w2, (size_t)NB * (size_t)ncols));
+  if (TopT && ntiles <= 2)
+    hipLaunchKernelGGL((k_tw_fused<false>), dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, c->stream, (const double *)ws.w1r.p, ncols,
+                       TopT, (const double *)nullptr, (const double *)nullptr, ws.w2.p);
+  else
   hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top, NB,
                      (const double *)ws.w1r.p, NB, 1, (int64_t)0, NB, ncols, NB, ws.w2.p, NB, (int64_t)0);
   if (rows > 0) {
@@ -289,7 +294,7 @@ static int32_t rs_gram_cross_allreduce(const RsProblem &pr, dhqr_comm *cmx, cons
     HIPCHECK(hipMemsetAsync(out2, 0, 2 * NN * sizeof(double), c->stream));
   } else {
     int64_t nsplit, rps;
-    pick_split(rows, 2, 512, 256, &nsplit, &rps);
+    pick_split(rows, 2, 512, 256, &nsplit, &rps, 512, 64);
     CHECK(ensure(c, c->spart, (size_t)nsplit * 2 * NN));
     const double *Vb = VaVb + NB * ldv;
     const bool vec = (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(VaVb);
@@ -438,7 +443,7 @@ static int32_t rs_panel_fast(const RsProblem &pr, const RsWork &w, dhqr_comm *cm
   } else {
     CHECK(rs_gram_allreduce(pr, cmx, P, pr.lda, rows, w.G));                  // G = sum P_r' P_r
     if (diag_owner) {
-      hipLaunchKernelGGL(k_panel_top, dim3(1), dim3(1024), 0, c->stream, (const double *)w.G, (const double *)P, pr.lda,
+      hipLaunchKernelGGL((k_panel_top<false>), dim3(1), dim3(1024), 0, c->stream, (const double *)w.G, (const double *)P, pr.lda,
                          bcbuf + NN, w.Rref, bcbuf, c->dstat + 1);            // alpha -> bc tail, -M^{-1} -> bc
       hipLaunchKernelGGL(k_rs_get_breakdown, dim3(1), dim3(64), 0, c->stream, c->dstat, bcbuf + NN + NB);
     }
@@ -517,7 +522,7 @@ static int32_t rs_group_apply(const RsProblem &pr, const RsWork &w, const RsSlot
   CHECK(rs_vtc_allreduce(pr, cmx, sl.V, w.ldv, C, pr.lda, rows, ncols));
   CHECK(prof_end(c));
   CHECK(prof_begin(c, CAT_AVW));
-  CHECK(rs_apply_w(pr, sl.V, w.ldv, sl.T[0], C, pr.lda, rows, ncols, true));
+  CHECK(rs_apply_w(pr, sl.V, w.ldv, sl.T[0], C, pr.lda, rows, ncols, true, sl.Tt[0]));
   CHECK(prof_end(c));
   if (c->profiling) {
     c->st.flops_gemm_vta += 2.0 * NB * (double)rows * (double)ncols;

@@ -77,7 +77,7 @@ int main(int argc, char **argv) {
     std::vector<double> alpha(RC_N, -7.0), Rref(NN, -7.0), negMinv(NN, -7.0);
     int flag[2] = {0, 0};
     simt::launch_block(1024, [&] {
-      k_panel_top(G.data(), P.data(), (int64_t)RC_N, alpha.data(), Rref.data(), negMinv.data(), flag);
+      k_panel_top<false>(G.data(), P.data(), (int64_t)RC_N, alpha.data(), Rref.data(), negMinv.data(), flag);
     });
     wr(argv[5], alpha);
     wr(argv[6], Rref);

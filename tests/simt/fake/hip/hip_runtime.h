@@ -274,6 +274,8 @@ inline simt_d4 simt_mfma_f64_16x16x4(double a, double b, simt_d4 c) {
 }
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) simt_mfma_f64_16x16x4(a, b, c)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt((double)(x)))  // v_rsq_f64 / v_rcp_f64: the refinement steps that follow
+#define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))             // them in csrc/ are run as written
 inline long long clock64() { return 0; }
 inline long long wall_clock64() {
   static std::atomic<long long> t{0};

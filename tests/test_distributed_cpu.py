@@ -45,6 +45,10 @@ def _ref_darray(rank, P, m, n):
     return float(np.abs(Al - Ho[:, lo:hi]).max())
 
 
+# larger / redundant configurations of the emulated multi-rank drivers (minutes on 8 cores): opt in with DHQR_SLOW=1
+_SLOW = pytest.mark.skipif(os.environ.get("DHQR_SLOW") != "1", reason="extra configuration; set DHQR_SLOW=1")
+
+
 @pytest.mark.parametrize("m,n,P", [(512, 512, 2), (110, 100, 2), (67, 33, 3)])
 def test_reference_darray_structure(m, n, P):
     run_ranks(_ref_darray, P, m, n)
@@ -83,7 +87,8 @@ def _mg(emu, ndev):
 
 
 # (ndev, m, n): pairs on 2 ranks; 3 ranks with a partial last panel; 4 ranks, 8 panels
-@pytest.mark.parametrize("ndev,m,n", [(2, 700, 512), (3, 900, 650), (4, 1100, 1024)])
+@pytest.mark.parametrize("ndev,m,n", [(2, 700, 512), pytest.param(3, 900, 650, marks=_SLOW),
+                                      pytest.param(4, 1100, 1024, marks=_SLOW)])
 def test_multi_device_handle_vs_oracle(emu, orc, ndev, m, n):
     h = _mg(emu, ndev)
     # device-resident path: fill (block-cyclic generator map), factor, residual, download
@@ -118,7 +123,7 @@ def test_multi_device_handle_vs_oracle(emu, orc, ndev, m, n):
     assert emu.dhqr_mg_destroy(h) == 0
 
 
-@pytest.mark.parametrize("rung", [1, 0])
+@pytest.mark.parametrize("rung", [pytest.param(1, marks=_SLOW), 0])
 def test_multi_device_host_drop_in_and_rejected_panel(emu, orc, rung):
     """qr!(A; ndev) host-in/host-out; two nearly dependent columns in the SECOND panel of the first pair: the device
     verification rejects it, later updates become no-ops, the run resumes with the robust ladder on 2 ranks: TSQR-HR
@@ -178,7 +183,7 @@ def _cs_gloo(rank, P, m, n, so):
     return True
 
 
-@pytest.mark.parametrize("m,n,P", [(450, 300, 3), (700, 512, 2)])
+@pytest.mark.parametrize("m,n,P", [(450, 300, 3), pytest.param(700, 512, 2, marks=_SLOW)])
 def test_column_split_processes_with_callback_transport(emulated_so, m, n, P):
     run_ranks(_cs_gloo, P, m, n, emulated_so)
 
@@ -234,8 +239,9 @@ def test_darray_layout_front_end(emulated_so, m, n, P):
 # ---------------------------------------------------------------- 3: row split (BASELINE configs[4]), emulated library
 # (ndev, m, n): diagonal blocks on several ranks (n > rows of rank 0); partial last panel; more ranks than row blocks
 # tsqr = 1: every panel through TSQR-HR (local trees, gather of the rank R factors, the cross-rank tree, explicit Q)
-@pytest.mark.parametrize("ndev,m,n,tsqr", [(2, 1024, 384, 0), (3, 1200, 300, 0), (4, 500, 200, 0),
-                                           (2, 640, 256, 1), (3, 700, 128, 1)])
+@pytest.mark.parametrize("ndev,m,n,tsqr", [(2, 1024, 384, 0), pytest.param(3, 1200, 300, 0, marks=_SLOW), (4, 500, 200, 0),
+                                           (2, 384, 128, 1), pytest.param(2, 640, 256, 1, marks=_SLOW),
+                                           pytest.param(3, 700, 128, 1, marks=_SLOW)])
 def test_row_split_rank_threads_vs_oracle(emu, orc, ndev, m, n, tsqr):
     with _env(**({"DHQR_TSQR": 1} if tsqr else {})):
         h = _mg(emu, ndev)
@@ -262,7 +268,7 @@ def test_row_split_rank_threads_vs_oracle(emu, orc, ndev, m, n, tsqr):
     assert emu.dhqr_mg_destroy(h) == 0
 
 
-@pytest.mark.parametrize("rung", [1, 0])
+@pytest.mark.parametrize("rung", [pytest.param(1, marks=_SLOW), 0])
 def test_row_split_rejected_panel_climbs_the_ladder(emu, orc, rung):
     """two nearly dependent columns inside the second panel: every rank takes the same device-side decision, later
     updates become no-ops, the panel is redone by TSQR-HR across the ranks (the row-split default on P > 1: three
@@ -313,6 +319,6 @@ def _rs_gloo(rank, P, m, n, so):
     return True
 
 
-@pytest.mark.parametrize("m,n,P", [(1200, 256, 2), (900, 300, 3)])
+@pytest.mark.parametrize("m,n,P", [(1200, 256, 2), pytest.param(900, 300, 3, marks=_SLOW)])
 def test_row_split_processes_with_callback_transport(emulated_so, m, n, P):
     run_ranks(_rs_gloo, P, m, n, emulated_so)

@@ -118,7 +118,7 @@ def _tsqr_count(L, h):
     return a.value
 
 
-@pytest.mark.parametrize("rows", [100, 300, 700])
+@pytest.mark.parametrize("rows", [100, 300, pytest.param(700, marks=_SLOW)])
 def test_tsqr_tree_r_factor(emu, rows):
     """csrc/dhqr_tsqr.h alone: R of a rows x 128 panel through leaves of 256 rows and the pairwise reduction (odd leaf
     counts, a short last leaf, fewer rows than columns) against LAPACK's R"""
@@ -141,7 +141,7 @@ def test_tsqr_tree_r_factor(emu, rows):
     emu.dhqr_destroy(h)
 
 
-@pytest.mark.parametrize("m,n", [(300, 256), pytest.param(700, 512, marks=_SLOW)])
+@pytest.mark.parametrize("m,n", [(300, 128), pytest.param(300, 256, marks=_SLOW), pytest.param(700, 512, marks=_SLOW)])
 def test_tsqr_as_the_r_source_of_every_panel(emu, orc, m, n):
     """DHQR_TSQR=1: every R-first panel takes R from the tree, then the same replay / reconstruction"""
     h = _ctx(emu, DHQR_TSQR=1)

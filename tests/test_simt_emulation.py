@@ -126,6 +126,28 @@ def test_replay_of_top_block(emu, orc, tmp_path, variant):
     assert np.array_equal(np.tril(negMinv, -1), np.zeros((N, N)))  # -M^{-1} is upper triangular
 
 
+def test_fused_panel_top(emu, orc, tmp_path):
+    """k_panel_top: Cholesky of the Gram matrix and the replay of the top block in ONE loop (one barrier per column for
+    both), then -M^{-1}: the reference's alpha, R and (after the library's GEMM) V; ThreadSanitizer-clean"""
+    rows = 300
+    P = orc.rand_matrix(rows, N, 6)
+    Ho, ao = orc.householder(P)
+    f = {k: str(tmp_path / f"{k}.bin") for k in ("G", "P", "al", "Rref", "Mi", "flag")}
+    _put(f["G"], P.T @ P)
+    _put(f["P"], P[:N])
+    _run(emu, "top", 0, f["G"], f["P"], f["al"], f["Rref"], f["Mi"], f["flag"])
+    alpha, Rref, negMinv = np.fromfile(f["al"]), _get(f["Rref"]), _get(f["Mi"])
+    scale = np.abs(Ho).max()
+    assert np.abs(alpha - ao).max() < 1e-12 * scale
+    assert np.abs(Rref - np.triu(Ho[:N], 1)).max() < 1e-12 * scale
+    PE = P.copy()
+    PE[:N] -= np.diag(alpha)
+    V = np.tril(PE @ (-negMinv))
+    assert np.abs(V - np.tril(Ho)).max() < 1e-12 * scale
+    assert np.array_equal(np.tril(negMinv, -1), np.zeros((N, N)))
+    assert np.array_equal(np.fromfile(f["flag"]), [0.0, 0.0])
+
+
 @pytest.mark.parametrize("variant,ncols", [(5, 128), (5, 77), (5, 1)])
 def test_block_reflector_t(emu, orc, tmp_path, variant, ncols):
     Ho, _ = orc.householder(orc.rand_matrix(300, ncols, 7))
