@@ -61,7 +61,7 @@ struct dhqr_ctx {
   bool lookahead = true;
   Buf vbuf, vt, vts, spart, sfull, scratch, pbuf;
   int pair = 1;                  // 1: wide updates apply two panels per pass (DHQR_PAIR=0 disables)
-  int64_t pair_min_n = 20480;    // below this the longer look-ahead lane of the pair driver costs more than it saves
+  int64_t pair_min_n = 12288;    // below this the longer look-ahead lane of the pair driver costs more than it saves (profiles/r02_ab_pair_tail_and_threshold.txt)
   int panel_impl = 3;  // 3: R-first (CholeskyQR + reconstruction, dhqr_recon.h) with fallback to 2;
                        // 2: row-split sub-panel kernels (dhqr_panel.h); 1: one workgroup per column
   int *hflag = nullptr;  // pinned host copy of the device status block
@@ -692,14 +692,10 @@ static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t 
     // T from S, fused with the acceptance decision (before the predicated commits)
     hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sfull.p, (int)DHQR_NBV, pb.T, pb.Tt,
                        c->recon_tol, c->dstat, panel_idx, pb.alpha + DHQR_NBV);
-    // commit (device-side predicate): reflectors, R, alpha; T is only ever read by accepted consumers
+    // commit (device-side predicate): reflectors, R, alpha in one launch; T is only ever read by accepted consumers
     dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
-    hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, P, ldp, rows, (int64_t)DHQR_NBV, (const double *)pb.V,
-                       ldv, (const int *)c->dstat, panel_idx);
-    hipLaunchKernelGGL(k_recon_write_r, dim3(NN / 256), dim3(256), 0, c->stream, P, ldp, (const double *)Rref,
-                       (const int *)c->dstat, panel_idx);
-    hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, (const double *)altmp, (int)DHQR_NBV, alpha,
-                       pb.alpha, (const int *)c->dstat, panel_idx);
+    hipLaunchKernelGGL(k_commit_panel, grid, dim3(256), 0, c->stream, P, ldp, rows, (const double *)pb.V, ldv, (const double *)Rref,
+                       (const double *)altmp, alpha, pb.alpha, (const int *)c->dstat, panel_idx);
     LAUNCHCHECK();
     return DHQR_OK;
   };

@@ -649,6 +649,27 @@ __global__ __launch_bounds__(256) void k_recon_write_r(double *__restrict__ P, i
   if (i < j) P[i + (int64_t)j * ldp] = Rref[idx];
 }
 // statword <- stat[0] (a host-verified panel publishes the run's status with its operands)
+// The three commits of an accepted R-first panel in ONE predicated launch (one launch gap instead of three on the lane's
+// chain): reflectors P[r, p] <- Vw[r, p] for r >= p (k_unpack_v), the reference's R above the diagonal of the top block
+// (k_recon_write_r), alpha -> the caller's vector and the panel buffer (k_commit_alpha).  grid (x, 128), 256 threads.
+__global__ __launch_bounds__(256) void k_commit_panel(double *__restrict__ P, int64_t ldp, int64_t rows,
+                                                      const double *__restrict__ Vw, int64_t ldv,
+                                                      const double *__restrict__ Rref, const double *alpha_src,
+                                                      double *alpha_dst1, double *alpha_dst2,
+                                                      const int *__restrict__ stat, int epoch) {
+  if (stat != nullptr && stat[0] <= epoch) return;
+  const int64_t p = blockIdx.y;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = p + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) P[r + p * ldp] = Vw[r + p * ldv];
+  if (blockIdx.x == 0) {
+    for (int64_t r = threadIdx.x; r < p; r += blockDim.x) P[r + p * ldp] = Rref[r + p * RC_N];
+    if (threadIdx.x == 0) {
+      const double a = alpha_src[p];
+      if (alpha_dst1) alpha_dst1[p] = a;
+      if (alpha_dst2) alpha_dst2[p] = a;
+    }
+  }
+}
 __global__ void k_set_statword(const int *__restrict__ stat, double *__restrict__ statword) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *statword = (double)stat[0];
 }

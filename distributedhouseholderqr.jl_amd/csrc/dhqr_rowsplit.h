@@ -470,18 +470,17 @@ static int32_t rs_panel_fast(const RsProblem &pr, const RsWork &w, dhqr_comm *cm
                      (double *)nullptr);                                      // same decision on every rank
   if (rows > 0) {
     dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
-    if (diag_owner) {
-      hipLaunchKernelGGL(k_unpack_v, grid, dim3(256), 0, c->stream, P, pr.lda, rows, NB, (const double *)Vdst, w.ldv,
-                         (const int *)c->dstat, (int)k);
-      hipLaunchKernelGGL(k_recon_write_r, dim3(NN / 256), dim3(256), 0, c->stream, P, pr.lda, (const double *)w.Rref,
-                         (const int *)c->dstat, (int)k);
+    if (diag_owner) {  // reflectors, R and alpha in one launch
+      hipLaunchKernelGGL(k_commit_panel, grid, dim3(256), 0, c->stream, P, pr.lda, rows, (const double *)Vdst, w.ldv,
+                         (const double *)w.Rref, alpha_commit, pr.alpha + c0, (double *)nullptr, (const int *)c->dstat, (int)k);
     } else {
       hipLaunchKernelGGL(k_unpack_rows, grid, dim3(256), 0, c->stream, P, pr.lda, rows, NB, (const double *)Vdst, w.ldv,
                          (const int *)c->dstat, (int)k);
     }
   }
-  hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, alpha_commit, (int)NB, pr.alpha + c0,
-                     (double *)nullptr, (const int *)c->dstat, (int)k);
+  if (!(diag_owner && rows > 0))
+    hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, c->stream, alpha_commit, (int)NB, pr.alpha + c0,
+                       (double *)nullptr, (const int *)c->dstat, (int)k);
   LAUNCHCHECK();
   return DHQR_OK;
 }
