@@ -10,6 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libdhqr.so")
 CSRC = os.path.join(_PKG, "csrc")
 NB = 128  # DHQR_NB
+CS_BLOCK = 256  # DHQR_CS_BLOCK: cyclic block of the multi-GPU column split (a pair of panels)
 ZNB = 64  # DHQR_ZNB: complex reflectors per panel of the blocked ComplexF64 path
 
 OK, EINVAL, EHIP, ENOMEM, ENODEVICE, ECOMM = 0, -1, -2, -3, -4, -5

@@ -2024,7 +2024,7 @@ int32_t dhqr_cs_fill_uniform_f64(dhqr_comm *cm, double *dA, int64_t m, int64_t n
   CsProblem pr;
   CHECK(cs_check(cm, dA, m, n, lda, &pr));
   if (pr.ncl == 0) return DHQR_OK;
-  return dhqr_fill_uniform_f64(pr.c, dA, m, pr.ncl, lda, seed, m, 0, DHQR_NBV, pr.P, pr.r);
+  return dhqr_fill_uniform_f64(pr.c, dA, m, pr.ncl, lda, seed, m, 0, CS_CB, pr.P, pr.r);
 }
 
 int32_t dhqr_cs_factor_f64(dhqr_comm *cm, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
@@ -2282,7 +2282,7 @@ int32_t dhqr_mg_fill_uniform_f64(dhqr_mg *g, uint64_t seed) {
   return mg_run(g, [g, seed](int r) -> int32_t {
     MgRank &k = g->rk[r];
     if (k.ncl == 0) return DHQR_OK;
-    return dhqr_fill_uniform_f64(k.c, k.A, g->m, k.ncl, k.lda, seed, g->m, 0, DHQR_NBV, g->ndev, r);
+    return dhqr_fill_uniform_f64(k.c, k.A, g->m, k.ncl, k.lda, seed, g->m, 0, CS_CB, g->ndev, r);
   });
 }
 
@@ -2316,9 +2316,11 @@ static int32_t mg_transfer(dhqr_mg *g, double *hA, int64_t lda, double *halpha, 
   if (g->rowsplit) return set_err(DHQR_EINVAL, "the handle holds a row-split matrix (use dhqr_mg_rs_transfer_f64)");
   return mg_run(g, [g, hA, lda, halpha, upload](int r) -> int32_t {
     MgRank &k = g->rk[r];
+    const CsProblem pr = mg_problem(g, r);
     const int64_t NB = DHQR_NBV, K = cs_nblocks(g->n);
-    for (int64_t b = r, lc = 0; b < K; b += g->ndev, lc += NB) {
-      const int64_t w = std::min<int64_t>(NB, g->n - b * NB);
+    for (int64_t b = 0; b < K; ++b) {
+      if (!pr.mine(b)) continue;
+      const int64_t lc = pr.lcol(b), w = std::min<int64_t>(NB, g->n - b * NB);
       if (upload)
         HIPCHECK(hipMemcpy2DAsync(k.A + lc * k.lda, k.lda * sizeof(double), hA + b * NB * lda, lda * sizeof(double),
                                   g->m * sizeof(double), w, hipMemcpyHostToDevice, k.c->stream));

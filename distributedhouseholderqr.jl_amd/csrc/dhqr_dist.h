@@ -1,9 +1,13 @@
 // dhqr_dist.h -- the blocked factorisation driver, written once for P >= 1 ranks (included by dhqr_api.hip).
 //
 // Replaces householder!(A::DArray, alpha) (src:115-120: owners visited one after the other, every reflector
-// shipped to every process, src:141-143) by an SPMD program over a 1-D BLOCK-CYCLIC column split (block =
-// 128 columns = one panel; rank r owns panels k with k % P == r, stored contiguously: the trailing columns of
-// every rank are a suffix of its local storage).  At P == 1 it is the single-GPU look-ahead driver.
+// shipped to every process, src:141-143) by an SPMD program over a 1-D BLOCK-CYCLIC column split: cyclic block =
+// CS_CB = 256 columns = TWO panels; rank r owns the panel pairs q with q % P == r, stored contiguously: the trailing
+// columns of every rank are a suffix of its local storage.  Both panels of a pair live on one rank, so the second is
+// brought up to date and factored without waiting for a broadcast, and the broadcast of the first runs behind it: per
+// pair ONE broadcast sits on the critical chain (narrow update -> panel a -> panel b -> broadcast of b) instead of two
+// (tools/scaling_model.py: 8 GPUs 5.7x -> 6.2x at 100 GB/s, 4.8x -> 5.8x at 50 GB/s).  At P == 1 it is the single-GPU
+// look-ahead driver.
 //
 // Panels are grouped: a group is a PAIR of full-width panels (a, b = a+1) applied to the trailing matrix in one
 // pass (K = 256 MFMA update, pair_apply) or a single panel (last odd / partial panel, or pairing disabled).
@@ -85,12 +89,15 @@ static void cs_state_free(dhqr_ctx *c) {
   c->cs = nullptr;
 }
 
-// ---- block-cyclic column map (block = DHQR_NBV columns) -------------------------------------------
-static inline int64_t cs_nblocks(int64_t n) { return (n + DHQR_NBV - 1) / DHQR_NBV; }
+// ---- block-cyclic column map (cyclic block = CS_CB = DHQR_CS_BLOCK columns = two panels) -----------
+#define CS_CB ((int64_t)DHQR_CS_BLOCK)
+static_assert(DHQR_CS_BLOCK == 2 * DHQR_NBV, "the cyclic block is a pair of panels");
+static inline int64_t cs_nblocks(int64_t n) { return (n + DHQR_NBV - 1) / DHQR_NBV; }  // panels
 static inline int64_t cs_local_cols(int64_t n, int P, int r) {
   const int64_t K = cs_nblocks(n);
   int64_t cols = 0;
-  for (int64_t k = r; k < K; k += P) cols += std::min<int64_t>(DHQR_NBV, n - k * DHQR_NBV);
+  for (int64_t k = 0; k < K; ++k)
+    if ((k / 2) % P == r) cols += std::min<int64_t>(DHQR_NBV, n - k * DHQR_NBV);
   return cols;
 }
 
@@ -103,10 +110,14 @@ struct CsProblem {
   int P, r;
   int64_t K, ncl;
   int64_t width(int64_t k) const { return std::min<int64_t>(DHQR_NBV, n - k * DHQR_NBV); }
-  int owner(int64_t k) const { return (int)(k % P); }
+  int owner(int64_t k) const { return (int)((k / 2) % P); }      // panel k belongs to the pair k / 2
   bool mine(int64_t k) const { return owner(k) == r; }
-  int64_t lcol(int64_t k) const { return (k / P) * DHQR_NBV; }   // local column of an owned block
-  int64_t first_local_ge(int64_t k) const { return k + (((int64_t)r - k % P) % P + P) % P; }
+  int64_t lcol(int64_t k) const { return ((k / 2) / P) * CS_CB + (k % 2) * DHQR_NBV; }   // local column of an owned panel
+  int64_t first_local_ge(int64_t k) const {  // smallest panel index >= k this rank owns (may be >= K)
+    const int64_t q = k / 2;
+    if (q % P == r) return k;
+    return 2 * (q + (((int64_t)r - q % P) % P + P) % P);
+  }
   // local columns holding the global blocks >= k: [*lo, ncl)
   int64_t local_from(int64_t k) const {
     const int64_t kk = first_local_ge(k);
@@ -230,8 +241,8 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
           // block x must carry every group before `prev`: done by the head (or whole) wide update of prev - 1
           if (prev >= 1) HIPCHECK(hipStreamWaitEvent(sL, (P > 1 ? S.ev_head : S.ev_wide)[(prev - 1) % CS_EVR], 0));
           int64_t ncols = w;
-          if (P == 1 && gr.np == 2 && idx == 0) {  // both panels are local and adjacent: one 256-column update
-            ncols += pr.width(x + 1);
+          if (gr.np == 2 && idx == 0 && pr.mine(x + 1) && pr.lcol(x + 1) == lc + w) {
+            ncols += pr.width(x + 1);  // both panels are local and adjacent (a whole cyclic block): one 256-column update
             merged_update = true;
           }
           CHECK(lane_begin(was));
@@ -419,7 +430,7 @@ static int32_t cs_residual(const CsProblem &pr, uint64_t seed, double *dW, doubl
   if (ncl > 0) {
     dim3 grid((unsigned)std::min<int64_t>((m + 255) / 256, 128), (unsigned)std::min<int64_t>(ncl, 32768));
     hipLaunchKernelGGL(k_form_r0, grid, dim3(256), 0, c->stream, (const double *)pr.A, pr.lda, (const double *)pr.alpha, m,
-                       ncl, dW, ldw, NB, pr.P, pr.r);
+                       ncl, dW, ldw, CS_CB, pr.P, pr.r);
   }
   const bool was = c->profiling;
   c->profiling = false;
@@ -446,7 +457,7 @@ static int32_t cs_residual(const CsProblem &pr, uint64_t seed, double *dW, doubl
   if (ncl > 0) {
     const int64_t total = m * ncl;
     const unsigned gridf = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL(k_fill_uniform, dim3(gridf), dim3(256), 0, c->stream, dA0, m, ncl, m, seed, m, (int64_t)0, NB, pr.P,
+    hipLaunchKernelGGL(k_fill_uniform, dim3(gridf), dim3(256), 0, c->stream, dA0, m, ncl, m, seed, m, (int64_t)0, CS_CB, pr.P,
                        pr.r);
     const int nblk = 1024;
     hipLaunchKernelGGL(k_diff_norms, dim3(nblk), dim3(256), 0, c->stream, (const double *)dA0, m, (const double *)dW, ldw, m,
@@ -554,7 +565,7 @@ static int32_t cs_load_contiguous(const CsProblem &pr, const double *dBlk, int64
       HIPCHECK(hipMemcpy2DAsync(dStage, m * sizeof(double), dBlk, ldb * sizeof(double), m * sizeof(double), wblk,
                                 hipMemcpyDeviceToDevice, c->stream));
     if (cm) CHECK(comm_bcast(cm, dStage, m * wblk, s, c->stream, nullptr));
-    // the pieces of [lo, hi) this rank owns in the block-cyclic layout (a piece never crosses a cyclic block)
+    // the pieces of [lo, hi) this rank owns in the block-cyclic layout, panel by panel
     for (int64_t k = lo / NB; k <= (hi - 1) / NB; ++k) {
       if (!pr.mine(k)) continue;
       const int64_t g0 = std::max<int64_t>(k * NB, lo), g1 = std::min<int64_t>(std::min<int64_t>((k + 1) * NB, hi), pr.n);

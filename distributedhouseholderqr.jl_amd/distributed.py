@@ -88,6 +88,14 @@ class Communicator:
     def __init__(self, handle, lib, nranks, rank, keepalive=()):
         self.handle, self.L, self.nranks, self.rank = handle, lib, nranks, rank
         self._keep = keepalive
+        self.ctx = None
+
+    def order_with_torch(self, mem):
+        """Device tensors (torch memory) are produced and consumed on torch's current stream: make it the library's
+        caller stream for the call that follows (as api.py does for every entry point), so that e.g. the copy of b into
+        the work vector is ordered before dhqr_cs_solve_f64 reads it.  No-op for host-memory stand-ins."""
+        if self.ctx is not None and isinstance(mem, _TorchMem):
+            self.ctx.use_torch_stream()
 
     @classmethod
     def from_torch(cls, ctx, group=None):
@@ -109,7 +117,9 @@ class Communicator:
             idbuf.raw = box[0]
         h = _P()
         check(L.dhqr_comm_create_rank(ctypes.byref(h), ctx.handle, nranks, rank, idbuf))
-        return cls(h, L, nranks, rank)
+        comm = cls(h, L, nranks, rank)
+        comm.ctx = ctx  # device tensors of this rank are ordered with the library through torch's current stream
+        return comm
 
     @classmethod
     def from_callbacks(cls, ctx_handle, lib, nranks, rank, bcast, allreduce):
@@ -186,17 +196,20 @@ class ColumnCyclicQR:
 
     def fill(self, seed: int):
         """synthetic input: the local columns of A[i,j] = u01(seed, i + j*m)"""
+        self.comm.order_with_torch(self.mem)
         p, ld = self._ptrA()
         self._check(self.L.dhqr_cs_fill_uniform_f64(self.comm.handle, p, self.m, self.n, ld, seed))
         return self
 
     def factor(self):
+        self.comm.order_with_torch(self.mem)
         p, ld = self._ptrA()
         self._check(self.L.dhqr_cs_factor_f64(self.comm.handle, p, self.m, self.n, ld, self.mem.ptr(self.alpha)))
         return self
 
     def residual(self, seed: int) -> float:
         """||A - QR||_F / ||A||_F with A regenerated from `seed`"""
+        self.comm.order_with_torch(self.mem)
         p, ld = self._ptrA()
         W, A0 = self.mem.empty(self.m, self.ncl), self.mem.empty(self.m, self.ncl)
         out = ctypes.c_double()
@@ -207,6 +220,7 @@ class ColumnCyclicQR:
     def solve(self, b):
         """`H \\ b` on the column split (src:317-321, 226-282): b (length m, the same on every rank) is not
         modified; returns x (length n) on every rank."""
+        self.comm.order_with_torch(self.mem)
         p, ld = self._ptrA()
         y = self.mem.vec(self.m)
         if isinstance(y, np.ndarray):
@@ -231,6 +245,7 @@ class ColumnCyclicQR:
 
     def load_contiguous_blocks(self, local_block):
         """local_block: this rank's m x len(contiguous_range()) column-major block (device memory)"""
+        self.comm.order_with_torch(self.mem)
         p, ld = self._ptrA()
         w = len(self.contiguous_range())
         if tuple(local_block.shape) != (self.m, w):
@@ -241,6 +256,7 @@ class ColumnCyclicQR:
         return self
 
     def store_contiguous_blocks(self, local_block):
+        self.comm.order_with_torch(self.mem)
         p, ld = self._ptrA()
         w = len(self.contiguous_range())
         bp = self.mem.ptr(local_block) if w else _P()

@@ -48,16 +48,19 @@ class RowSplitQR:
         return self.mem.ptr(self.A), self.mem.ld(self.A)
 
     def fill(self, seed: int):
+        self.comm.order_with_torch(self.mem)
         p, ld = self._ptrA()
         self._check(self.L.dhqr_rs_fill_uniform_f64(self.comm.handle, p, self.m, self.n, ld, seed))
         return self
 
     def factor(self):
+        self.comm.order_with_torch(self.mem)
         p, ld = self._ptrA()
         self._check(self.L.dhqr_rs_factor_f64(self.comm.handle, p, self.m, self.n, ld, self.mem.ptr(self.alpha)))
         return self
 
     def residual(self, seed: int) -> float:
+        self.comm.order_with_torch(self.mem)
         p, ld = self._ptrA()
         B, A0 = self.mem.empty(max(self.mloc, 1), self.n), self.mem.empty(max(self.mloc, 1), self.n)
         out = ctypes.c_double()
@@ -67,6 +70,7 @@ class RowSplitQR:
 
     def solve(self, b_loc):
         """`H \\ b`: b_loc = this rank's rows of b (length mloc, not modified); returns x (length n) on every rank"""
+        self.comm.order_with_torch(self.mem)
         p, ld = self._ptrA()
         y = self.mem.vec(max(self.mloc, 1))
         x = self.mem.vec(self.n)

@@ -44,6 +44,9 @@ extern "C" {
 
 /* Panel (block-reflector) width of the blocked path.  BASELINE.json configs 3/4 fix it at 128. */
 #define DHQR_NB 128
+/* Cyclic block of the 1-D block-cyclic column split (dhqr_cs_*, dhqr_mg_*): TWO panels.  Global column j lives on rank
+ * (j / DHQR_CS_BLOCK) % P at local column ((j / DHQR_CS_BLOCK) / P) * DHQR_CS_BLOCK + j % DHQR_CS_BLOCK. */
+#define DHQR_CS_BLOCK 256
 
 typedef struct dhqr_ctx dhqr_ctx; /* opaque: device id, stream, workspaces, event pools */
 
@@ -278,8 +281,8 @@ int32_t dhqr_comm_info(dhqr_comm *comm, int32_t *kind, int32_t *nranks, int32_t 
 int32_t dhqr_comm_get_bcast_tuning(dhqr_comm *comm, int32_t *algo, double *ms_ring, double *ms_scatter_allgather);
 
 /* ------------------------------------------------------------------ multi-GPU: 1-D column split (SPMD, collective)
- * householder!(A::DArray, alpha) (src:115-120).  Layout: BLOCK-CYCLIC columns, block = DHQR_NB: rank r holds the
- * global column blocks r, r+P, r+2P, ... contiguously (dA: m x dhqr_cs_local_cols(n,P,r), leading dimension lda);
+ * householder!(A::DArray, alpha) (src:115-120).  Layout: BLOCK-CYCLIC columns, block = DHQR_CS_BLOCK (a pair of
+ * panels): rank r holds the global column blocks r, r+P, r+2P, ... contiguously (dA: m x dhqr_cs_local_cols(n,P,r), leading dimension lda);
  * dalpha (n) is replicated.  Per panel ONE broadcast of its (V, T, T', alpha) operands replaces the reference's
  * per-column fan-out; trailing updates apply two panels per pass (K = 256 MFMA update) under look-ahead.
  * Every rank of the communicator must make the call.  Synchronous on return.

@@ -25,6 +25,13 @@ def test_header_symbols_exported(pkg):
     assert sorted(pkg._lib.SIGNATURES) == names
 
 
+def test_layout_constants_match_the_header(pkg):
+    hdr = open(os.path.join(ROOT, "include", "dhqr.h")).read()
+    macro = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(DHQR_NB|DHQR_CS_BLOCK|DHQR_ZNB)\s+(\d+)", hdr)}
+    assert macro["DHQR_NB"] == pkg._lib.NB and macro["DHQR_CS_BLOCK"] == pkg._lib.CS_BLOCK == 2 * pkg._lib.NB
+    assert macro.get("DHQR_ZNB", pkg._lib.ZNB) == pkg._lib.ZNB
+
+
 def test_version_and_error_string(pkg):
     L = pkg._lib.lib()
     assert L.dhqr_version() == 200

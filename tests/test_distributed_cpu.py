@@ -139,8 +139,8 @@ def test_multi_device_host_drop_in_and_rejected_panel(emu, orc, rung):
     assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-13
     st = emu.Stats()
     a_, b_ = ctypes.c_int64(), ctypes.c_int64()
-    assert emu.dhqr_mg_get_stats(h, 1, ctypes.byref(st), ctypes.byref(a_), ctypes.byref(b_), None) == 0
-    assert (b_.value == 0) if rung else (b_.value >= 1)  # rank 1 owns panel 1
+    assert emu.dhqr_mg_get_stats(h, 0, ctypes.byref(st), ctypes.byref(a_), ctypes.byref(b_), None) == 0
+    assert (b_.value == 0) if rung else (b_.value >= 1)  # rank 0 owns panels 0 and 1 (cyclic block = a pair of panels)
     # `H \\ b` through the handle from a factored HOST matrix (well conditioned, shape change re-allocates)
     m, n = 500, 260
     A1 = orc.rand_matrix(m, n, 23)
@@ -166,14 +166,14 @@ def _cs_gloo(rank, P, m, n, so):
     q = D.ColumnCyclicQR(m, n, comm=comm, mem=D._HostMem())
     q.fill(71)
     A = orc.rand_matrix(m, n, 71)
-    cols = [((jl // 128) * P + rank) * 128 + jl % 128 for jl in range(q.ncl)]
+    cols = [((jl // 256) * P + rank) * 256 + jl % 256 for jl in range(q.ncl)]  # DHQR_CS_BLOCK = 256
     loc, _ = q.local_numpy()
     assert np.array_equal(loc, A[:, cols])  # the device generator with the block-cyclic column map
     q.factor()
     loc, alpha = q.local_numpy()
     Ho, ao = orc.householder(A)
     scale = np.abs(Ho).max()
-    assert np.abs(loc - Ho[:, cols]).max() <= 1e-12 * scale
+    assert q.ncl == 0 or np.abs(loc - Ho[:, cols]).max() <= 1e-12 * scale  # (a rank may own no column at all)
     assert np.abs(alpha - ao).max() <= 1e-12 * scale
     assert q.residual(71) < 1e-14
     b = orc.rand_vector(m, 72)
@@ -204,7 +204,7 @@ def _darray(rank, P, m, n, so):
     local = np.array(A[:, cols.start: cols.stop], order="F") if len(cols) else np.zeros((m, 0), order="F")
     # layout round trip first: scatter to block-cyclic and gather back is the identity
     q0.load_contiguous_blocks(local)
-    gcols = [((jl // 128) * P + rank) * 128 + jl % 128 for jl in range(q0.ncl)]
+    gcols = [((jl // 256) * P + rank) * 256 + jl % 256 for jl in range(q0.ncl)]  # DHQR_CS_BLOCK = 256
     assert np.array_equal(q0.local_numpy()[0], A[:, gcols])
     back = np.zeros_like(local)
     q0.store_contiguous_blocks(back)

@@ -147,10 +147,12 @@ def test_full_size_properties(pkg, n, nb):
     assert (B.reshape(-1) - b).abs().max().item() < 1e-11
 
 
-@pytest.mark.parametrize("m,n", [(700, 520), (1300, 1290)])
+@pytest.mark.parametrize("m,n", [(700, 520), (1300, 1290), (300, 128), (700, 384)])
 def test_column_cyclic_driver_single_rank(pkg, orc, m, n):
     """The SPMD multi-GPU entry points (dhqr_cs_*) at world size 1 (no process group): same driver code the
-    N-GPU bench runs, checked against the oracle incl. residual and solve."""
+    N-GPU bench runs, checked against the oracle incl. residual and solve.  b arrives as a DEVICE tensor: its copy into
+    the work vector runs on torch's stream and must be ordered before the library reads it (the front-end makes torch's
+    current stream the library's caller stream; without that the solve read a half-written vector)."""
     import torch
     q = pkg.ColumnCyclicQR(m, n)
     q.fill(8)

@@ -7,18 +7,21 @@ the blocks of pair g+2 first); a panel is available to the other ranks one broad
 
 Inputs measured on one MI355X this round (profiles/r02_*):
   trailing GEMMs in situ                          54 TFLOP/s per GPU (K = 256 pair update, both passes)
-  panel chain, uncontended                        0.20 ms single-workgroup kernels + launch gaps (fixed)
-                                                + 0.18 ms * rows/32768 (Gram / product GEMMs, unpack)
+  panel chain, uncontended                        0.215 ms single-workgroup kernels + small GEMMs + launch gaps (fixed)
+                                                + 0.035 ms * rows/32768 (Gram / product GEMMs, commit)
+                                                  [fit to the per-panel time of the no-look-ahead driver at 8192^2 /
+                                                  16384^2 / 24576^2 minus its host synchronisation, profiles/r02_panel_chain.txt;
+                                                  before this round's panel-kernel work: 0.32 + 0.05]
   narrow update of one 128-column block           0.03 ms + 0.10 ms * rows/32768   (pair: x 1.6)
   pair cross term V_b' V_a                        0.02 ms + 0.04 ms * rows/32768
 Assumed (NOT measured): broadcast of one panel = latency + bytes / bandwidth.
 
-  python tools/scaling_model.py [--small-ms 0.20] [--bw-gbps 100] [--lat-us 40]
+  python tools/scaling_model.py [--small-ms 0.215] [--var-ms 0.035] [--bw-gbps 100] [--lat-us 40]
 """
 import argparse
 
 
-def simulate(P, n=32768, nb=128, gemm_tflops=54.0, small_ms=0.20, var_ms=0.18, bw_gbps=100.0, lat_us=40.0):
+def simulate(P, n=32768, nb=128, gemm_tflops=54.0, small_ms=0.215, var_ms=0.035, bw_gbps=100.0, lat_us=40.0):
     K = n // nb
     G = K // 2
     rows = lambda k: n - k * nb
@@ -73,16 +76,17 @@ def simulate(P, n=32768, nb=128, gemm_tflops=54.0, small_ms=0.20, var_ms=0.18, b
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--small-ms", type=float, default=0.20)
+    ap.add_argument("--small-ms", type=float, default=0.215)
+    ap.add_argument("--var-ms", type=float, default=0.035)
     ap.add_argument("--bw-gbps", type=float, default=100.0)
     ap.add_argument("--lat-us", type=float, default=40.0)
     a = ap.parse_args()
-    t1 = simulate(1, small_ms=a.small_ms)
+    t1 = simulate(1, small_ms=a.small_ms, var_ms=a.var_ms)
     print(f"fixed part of the panel chain {a.small_ms:.2f} ms, broadcast {a.bw_gbps:.0f} GB/s + {a.lat_us:.0f} us (assumed)")
-    print("  P   model time [ms]   vs model P=1   (measured 1 GPU: 912 ms; the model's P=1 has no contention between lane and wide)")
+    print("  P   model time [ms]   vs model P=1   (measured 1 GPU: 0.90 s; the model's P=1 has no contention between lane and wide)")
     for P in (1, 2, 4, 8):
-        t = simulate(P, small_ms=a.small_ms, bw_gbps=a.bw_gbps, lat_us=a.lat_us)
-        print(f"  {P}   {t * 1e3:8.1f}        {t1 / t:5.2f}x        vs measured 0.912 s: {0.912 / t:5.2f}x")
+        t = simulate(P, small_ms=a.small_ms, var_ms=a.var_ms, bw_gbps=a.bw_gbps, lat_us=a.lat_us)
+        print(f"  {P}   {t * 1e3:8.1f}        {t1 / t:5.2f}x        vs measured 0.90 s: {0.90 / t:5.2f}x")
 
 
 if __name__ == "__main__":
