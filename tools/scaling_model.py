@@ -3,7 +3,9 @@ GPUs -- a MODEL, not a measurement (no multi-GPU node is reachable from the buil
 
 Mirrors the driver's structure: panels in pairs; per rank a LANE timeline (narrow updates of its own next panels,
 their factorisation, the pair's cross term) and a WIDE timeline (apply pair g to the local blocks beyond pair g+1,
-the blocks of pair g+2 first); a panel is available to the other ranks one broadcast after it is factored.
+the blocks of pair g+2 first); a panel is available to the other ranks one broadcast after it is factored.  Cyclic block
+= a pair of panels (--own 2, the shipped layout: the second panel of a pair never waits for a broadcast) or one panel
+(--own 1, the layout until mid round 2).
 
 Inputs measured on one MI355X this round (profiles/r02_*):
   trailing GEMMs in situ                          54 TFLOP/s per GPU (K = 256 pair update, both passes)
@@ -16,12 +18,13 @@ Inputs measured on one MI355X this round (profiles/r02_*):
   pair cross term V_b' V_a                        0.02 ms + 0.04 ms * rows/32768
 Assumed (NOT measured): broadcast of one panel = latency + bytes / bandwidth.
 
-  python tools/scaling_model.py [--small-ms 0.215] [--var-ms 0.035] [--bw-gbps 100] [--lat-us 40]
+  python tools/scaling_model.py [--small-ms 0.215] [--var-ms 0.035] [--bw-gbps 100] [--lat-us 40] [--own 2]
 """
 import argparse
 
 
-def simulate(P, n=32768, nb=128, gemm_tflops=54.0, small_ms=0.215, var_ms=0.035, bw_gbps=100.0, lat_us=40.0):
+def simulate(P, n=32768, nb=128, gemm_tflops=54.0, small_ms=0.215, var_ms=0.035, bw_gbps=100.0, lat_us=40.0, own=2):
+    # own = panels per cyclic block: 2 (DHQR_CS_BLOCK = 256: the shipped layout) or 1 (the earlier 128-column blocks)
     K = n // nb
     G = K // 2
     rows = lambda k: n - k * nb
@@ -38,20 +41,22 @@ def simulate(P, n=32768, nb=128, gemm_tflops=54.0, small_ms=0.215, var_ms=0.035,
     wide_done = [[0.0] * P for _ in range(G)]
 
     def local_cols(r, lo_blk, hi_blk):
-        return sum(nb for j in range(lo_blk, min(hi_blk, K)) if j % P == r)
+        return sum(nb for j in range(lo_blk, min(hi_blk, K)) if (j // own) % P == r)
 
     def produce(h):
         a, b = 2 * h, 2 * h + 1
         for idx, x in enumerate((a, b)):
-            o = x % P
+            o = (x // own) % P
             t = lane[o]
             if h >= 1:
                 t = max(t, group_ready[h - 1])                                   # pair h-1 assembled
                 if h >= 2:
                     t = max(t, (head_done if P > 1 else wide_done)[h - 2][o])   # block x carries pair h-2
-                t += t_narrow(2 * (h - 1), True)
+                # own = 2: both panels are local and adjacent: ONE merged 256-column update (charged to the first)
+                t += t_narrow(2 * (h - 1), True) if (own == 1 or idx == 0) else 0.0
             if idx == 1:
-                t = max(t, avail[a]) + t_narrow(a, False)
+                # panel a -> block b: local when the pair lives on one rank, else after a's broadcast has arrived
+                t = (t if own == 2 else max(t, avail[a])) + t_narrow(a, False)
             t += t_panel(x)
             lane[o] = t
             avail[x] = t + t_bcast(x)
@@ -80,12 +85,13 @@ def main():
     ap.add_argument("--var-ms", type=float, default=0.035)
     ap.add_argument("--bw-gbps", type=float, default=100.0)
     ap.add_argument("--lat-us", type=float, default=40.0)
+    ap.add_argument("--own", type=int, default=2, help="panels per cyclic block: 2 (shipped) or 1 (128-column blocks)")
     a = ap.parse_args()
     t1 = simulate(1, small_ms=a.small_ms, var_ms=a.var_ms)
     print(f"fixed part of the panel chain {a.small_ms:.2f} ms, broadcast {a.bw_gbps:.0f} GB/s + {a.lat_us:.0f} us (assumed)")
     print("  P   model time [ms]   vs model P=1   (measured 1 GPU: 0.90 s; the model's P=1 has no contention between lane and wide)")
     for P in (1, 2, 4, 8):
-        t = simulate(P, small_ms=a.small_ms, var_ms=a.var_ms, bw_gbps=a.bw_gbps, lat_us=a.lat_us)
+        t = simulate(P, small_ms=a.small_ms, var_ms=a.var_ms, bw_gbps=a.bw_gbps, lat_us=a.lat_us, own=a.own)
         print(f"  {P}   {t * 1e3:8.1f}        {t1 / t:5.2f}x        vs measured 0.90 s: {0.90 / t:5.2f}x")
 
 
