@@ -164,6 +164,7 @@ def _cs_gloo(rank, P, m, n, so):
     from oracle import dhqr_oracle as orc
     L, h, comm, D = emulated_rank(so, P, rank)
     q = D.ColumnCyclicQR(m, n, comm=comm, mem=D._HostMem())
+    assert comm.bcast_tuning()["algorithm"] == "ncclBroadcast"  # the timed broadcast trial exists for RCCL communicators only
     q.fill(71)
     A = orc.rand_matrix(m, n, 71)
     cols = [((jl // 256) * P + rank) * 256 + jl % 256 for jl in range(q.ncl)]  # DHQR_CS_BLOCK = 256
