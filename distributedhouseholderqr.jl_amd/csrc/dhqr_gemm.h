@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256) void k_tw_fused(const double *__restrict__ Y, 
   }
 }
 
-// Compact-WY algebra used by the T kernel (k_build_t3, dhqr_recon.h): for reflectors
+// Compact-WY algebra used by the T kernel (k_build_t, dhqr_recon.h): for reflectors
 // H_j = I - v_j v_j' (tau_j == 1 because ||v_j||^2 = 2), H_1...H_nb = I - V T V' with
 //   T^{-1} = I + striu(V'V),  equivalently  T[0:j, j] = -T[0:j,0:j] (V'V)[0:j, j], T[j][j] = 1.
 // This holds for ANY vectors v_j, so the reference's zero-pivot reflectors (||v||^2 != 2, src:8)
