@@ -98,18 +98,21 @@ function LinearAlgebra.:(\)(H::DistributedHouseholderQRStruct, b::AbstractVector
   return solve_householder!(s, H.A, H.α)
 end
 
-# ---- ComplexF64 methods (unblocked device path) ------------------------------------------------
-function householder!(A::StridedMatrix{ComplexF64}, α::Vector{ComplexF64}; nb::Integer=0)
-  nb == 0 || throw(ArgumentError("ComplexF64 runs the unblocked path (nb = 0)"))
+# ---- ComplexF64 methods ------------------------------------------------------------------------
+# nb = 64 (default for n >= 256): panels of 64 complex reflectors, trailing update on the FP64 MFMA kernels through the
+# real 2 x 2 embedding; nb = 0: the reference's unblocked order (src:171-196).  Same factorisation either way.
+const DHQR_ZNB = 64
+function householder!(A::StridedMatrix{ComplexF64}, α::Vector{ComplexF64}; nb::Integer=(size(A, 2) >= 256 ? DHQR_ZNB : 0))
+  (nb == 0 || nb == DHQR_ZNB) || throw(ArgumentError("ComplexF64: nb must be 0 (unblocked) or $(DHQR_ZNB) (blocked)"))
   m, n = size(A)
   stride(A, 1) == 1 || throw(ArgumentError("column-major storage required"))
-  check(ccall((:dhqr_qr_c64, libdhqr), Int32,
-              (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Int64, Int64, Ptr{ComplexF64}),
-              context(), A, m, n, stride(A, 2), α))
+  check(ccall((:dhqr_qr_c64_nb, libdhqr), Int32,
+              (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Int64, Int64, Ptr{ComplexF64}, Int32),
+              context(), A, m, n, stride(A, 2), α, Int32(nb)))
   return (A, α)
 end
 
-function qr!(A::StridedMatrix{ComplexF64}; nb::Integer=0)   # src:311-315
+function qr!(A::StridedMatrix{ComplexF64}; nb::Integer=(size(A, 2) >= 256 ? DHQR_ZNB : 0))   # src:311-315
   H = DistributedHouseholderQRStruct(A)
   householder!(H.A, H.α; nb=nb)
   return H
