@@ -55,6 +55,7 @@ struct dhqr_ctx {
   hipStream_t own = nullptr, stream = nullptr;
   bool profiling = false;
   hipStream_t hi = nullptr;      // high-priority stream: panel factorisation under look-ahead
+  int nn_tr64 = 1;               // narrow C -= V W products on 64-row tiles (DHQR_NN_TR64=0: always 128)
   int swizzle = 1;               // XCD-aware tile order in k_gemm_nn_sub (+1.5 % at 32768^2; DHQR_SWIZZLE=0 disables)
   struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
   int cur_ws = 0;
@@ -237,10 +238,19 @@ static inline PanelBuf vt_view(const double *vt, int64_t rows) { return vt_view(
 static inline const int *pred_stat(dhqr_ctx *c) { return c->epoch >= 0 ? c->dstat : nullptr; }
 
 // C -= V W on the MFMA kernel (dhqr_gemm.h); INIT0: C = -V W.
+// Narrow products (one or two column tiles) that would not fill the chip with 128-row tiles run with 64-row tiles
+// (k_gemm_nn_sub<..., TR = 64>): twice the workgroups, half the K-loop time each -- the lane's critical chain.
 template <int KW, bool INIT0 = false>
 static void launch_nn_sub(dhqr_ctx *c, bool vec, dim3 grid, const double *V, int64_t ldv, const double *W, int64_t ldw,
                           double *C, int64_t ldc, int64_t rows, int64_t ncols, int swz, bool predicated) {
   const int *st = predicated ? pred_stat(c) : nullptr;
+  const int64_t ntiles = (ncols + 127) / 128;
+  if (vec && !swz && ntiles <= 2 && ((rows + 127) / 128) * ntiles < 512 && c->nn_tr64) {
+    const dim3 g64((unsigned)((rows + 63) / 64), (unsigned)ntiles);
+    hipLaunchKernelGGL((k_gemm_nn_sub<2, KW, INIT0, false, 64>), g64, dim3(256), 0, c->stream, V, ldv, W, ldw, C, ldc, rows, ncols,
+                       0, st, c->epoch);
+    return;
+  }
   if (vec)
     hipLaunchKernelGGL((k_gemm_nn_sub<2, KW, INIT0>), grid, dim3(256), 0, c->stream, V, ldv, W, ldw, C, ldc, rows, ncols,
                        swz, st, c->epoch);
@@ -979,6 +989,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     }
     if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
     if (const char *e = getenv("DHQR_SWIZZLE")) c->swizzle = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_NN_TR64")) c->nn_tr64 = atoi(e) != 0;
     if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;
     if (const char *e = getenv("DHQR_PAIR_MIN_N")) c->pair_min_n = atoll(e);
     HIPCHECK(hipHostMalloc((void **)&c->hflag, 4 * sizeof(int), hipHostMallocDefault));

@@ -337,22 +337,32 @@ __global__ __launch_bounds__(512) void k_gemm_tn2(const double *__restrict__ V, 
 // Phase clock of the TIME instantiation (micro-benchmark only): summed shader cycles of wave 0 per phase.
 __device__ unsigned long long g_nn_phase[8];
 
-template <int VEC, int KW, bool INIT0 = false, bool TIME = false>
+// TR = rows of the output tile: 128 (the trailing update: each wave 64 x 64) or 64 (four waves side by side, each 64 rows x
+// 32 columns).  A workgroup's time is its K loop on one CU (13.7 us for a 128 x 128 x 128 tile); the latency-critical
+// products of the panel lane (V = P M^{-1}, the narrow look-ahead update) at a few thousand rows fill a fraction of the
+// chip with 128-row tiles, so they run with TR = 64: twice the workgroups, half the time each.
+template <int VEC, int KW, bool INIT0 = false, bool TIME = false, int TR = 128>
 __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict__ V, int64_t ldv,
                                                         const double *__restrict__ W, int64_t ldw,
                                                         double *__restrict__ C, int64_t ldc,
                                                         int64_t rows, int64_t ncols, int swz,
                                                         const int *__restrict__ stat, int epoch) {
-  __shared__ __attribute__((aligned(16))) double Vs[2][G_KT * G_LDR];
+  static_assert(TR == 128 || TR == 64, "tile rows");
+  constexpr int NCI = TR / 32;                     // 16-column MFMA tiles per wave: 4 (64 columns) or 2 (32 columns)
+  constexpr int WCOLS = NCI * 16;                  // columns per wave
+  constexpr int LDRV = (TR == 128) ? G_LDR : 66;   // LDS stride of a V tile column (k rows 4 banks apart for ds_read_b128)
+  constexpr int NVL = TR / 32;                     // V staging chunks per thread: 16 p x TR/2 row pairs / 256 threads
+  constexpr int RPSH = (TR == 128) ? 6 : 5;        // log2(row pairs per tile column)
+  __shared__ __attribute__((aligned(16))) double Vs[2][G_KT * LDRV];
   __shared__ __attribute__((aligned(16))) double Ws[2][128 * G_LDK];
   if (stat != nullptr && stat[0] <= epoch) return;  // uniform: every workgroup of the launch takes the same branch
   long long tph[5] = {0, 0, 0, 0, 0};
   if constexpr (TIME) tph[0] = clock64();
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int i16 = lane & 15, k4 = lane >> 4;
-  const int wr = w & 1, wc = w >> 1;
+  const int wr = (TR == 128) ? (w & 1) : 0, wc = (TR == 128) ? (w >> 1) : w;
   int64_t tr = blockIdx.x, tc = blockIdx.y;
-  if (swz) {
+  if (TR == 128 && swz) {
     // XCD-aware order (1-D launch): workgroup L runs on XCD L % 8 (observed dispatch rule, speed
     // only).  Each XCD walks its own 8 x 8 blocks of tiles so the V row-tiles and W column-tiles it
     // re-reads (8 + 8 tiles x 128 KiB = 2 MiB) stay in its private 4 MiB L2.
@@ -365,9 +375,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
     tc = (blk / bx) * 8 + (idx >> 3);
     if (tr >= gx || tc >= gy) return;
   }
-  const int64_t r0 = tr * 128;
+  const int64_t r0 = tr * TR;
   const int64_t c0 = tc * 128;
-  const int nrv = (int)((rows - r0 < 128) ? rows - r0 : 128);    // valid rows in this tile
+  const int nrv = (int)((rows - r0 < TR) ? rows - r0 : TR);      // valid rows in this tile
   const int ncv = (int)((ncols - c0 < 128) ? ncols - c0 : 128);  // valid columns
 
   const double *Vb = V + r0;
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = t + i * 256;
-    const int p = q >> 6, rp = q & 63;  // V tile: 16 p-columns x 128 rows (one wave = 1 KiB run)
+    const int p = (q >> RPSH) & (G_KT - 1), rp = q & ((1 << RPSH) - 1);  // V tile: 16 p-columns x TR rows (i < NVL)
     okv0[i] = 2 * rp < nrv;
     okv1[i] = 2 * rp + 1 < nrv;
     offv[i] = (uint32_t)(p * ldv) + (okv0[i] ? 2 * rp : 0);
@@ -395,11 +405,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (VEC == 2) {
-        sv[i] = *reinterpret_cast<const double2 *>(Vt + offv[i]);  // rows even: pair all-or-nothing
+        if (i < NVL) sv[i] = *reinterpret_cast<const double2 *>(Vt + offv[i]);  // rows even: pair all-or-nothing
         sw[i] = *reinterpret_cast<const double2 *>(Wt + offw[i]);
       } else {
-        sv[i].x = Vt[offv[i]];
-        sv[i].y = Vt[offv[i] + (okv1[i] ? 1 : 0)];
+        if (i < NVL) {
+          sv[i].x = Vt[offv[i]];
+          sv[i].y = Vt[offv[i] + (okv1[i] ? 1 : 0)];
+        }
         sw[i].x = Wt[offw[i]];
         sw[i].y = Wt[offw[i] + 1];
       }
@@ -413,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
       if (!okv0[i]) x.x = 0.0;
       if (!okv1[i]) x.y = 0.0;
       if (!okw[i]) y = make_double2(0.0, 0.0);
-      *reinterpret_cast<double2 *>(&Vs[buf][(q >> 6) * G_LDR + 2 * (q & 63)]) = x;
+      if (i < NVL) *reinterpret_cast<double2 *>(&Vs[buf][(q >> RPSH) * LDRV + 2 * (q & ((1 << RPSH) - 1))]) = x;
       *reinterpret_cast<double2 *>(&Ws[buf][(q >> 3) * G_LDK + 2 * (q & 7)]) = make_double2(-y.x, -y.y);
     }
   };
@@ -425,38 +437,38 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
   // give every lane FOUR CONSECUTIVE ROWS per column:  lane (i16,k4), register g of tile (ci,ri) holds
   //     C[r0 + wr*64 + 4*i16 + ri][c0 + wc*64 + ci*16 + k4 + 4g].
   // Interior tiles move C with 16-byte accesses (32 B per lane and column, 512 contiguous bytes per 16 lanes).
-  const bool full = (VEC == 2) && nrv == 128 && ncv == 128;
+  const bool full = (VEC == 2) && nrv == TR && ncv == 128;
   constexpr int NKT = KW / G_KT;
-  dhqr_d4 acc[4][4];
+  dhqr_d4 acc[NCI][4];
   auto mma_tile = [&](int buf) {
-    const double *ws = &Ws[buf][(wc * 64 + i16) * G_LDK + k4];
-    const double *vs = &Vs[buf][k4 * G_LDR + wr * 64 + 4 * i16];  // rows 4*i16 .. 4*i16+3: the four b fragments
+    const double *ws = &Ws[buf][(wc * WCOLS + i16) * G_LDK + k4];
+    const double *vs = &Vs[buf][k4 * LDRV + wr * 64 + 4 * i16];  // rows 4*i16 .. 4*i16+3: the four b fragments
 #pragma unroll
     for (int kk = 0; kk < G_KT / 4; ++kk) {
-      double a[4], b[4];
+      double a[NCI], b[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) a[x] = ws[x * 16 * G_LDK + kk * 4];
-      // two ds_read_b128; stride 130 doubles puts the four k rows of a read 4 banks apart: conflict free
-      const double2 b01 = *reinterpret_cast<const double2 *>(vs + kk * 4 * G_LDR);
-      const double2 b23 = *reinterpret_cast<const double2 *>(vs + kk * 4 * G_LDR + 2);
+      for (int x = 0; x < NCI; ++x) a[x] = ws[x * 16 * G_LDK + kk * 4];
+      // two ds_read_b128; stride 130 (66) doubles puts the four k rows of a read 4 banks apart: conflict free
+      const double2 b01 = *reinterpret_cast<const double2 *>(vs + kk * 4 * LDRV);
+      const double2 b23 = *reinterpret_cast<const double2 *>(vs + kk * 4 * LDRV + 2);
       b[0] = b01.x;
       b[1] = b01.y;
       b[2] = b23.x;
       b[3] = b23.y;
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
+      for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = mfma_f64(a[ci], b[ri], acc[ci][ri]);
     }
   };
-  // the lane's sixteen (column, 4-row) units of an interior tile: unit n = 4*ci + g is column wc*64 + k4 + 4n, so the
+  // the lane's 4 NCI (column, 4-row) units of an interior tile: unit n = 4*ci + g is column wc*WCOLS + k4 + 4n, so the
   // units are one pointer walking with the uniform stride 4*ldc
-  double *const cunit0 = Cb + ((uint32_t)((wc * 64 + k4) * ldc) + (uint32_t)(wr * 64 + 4 * i16));
+  double *const cunit0 = Cb + ((uint32_t)((wc * WCOLS + k4) * ldc) + (uint32_t)(wr * 64 + 4 * i16));
   const int64_t cstep = 4 * ldc;
   auto store_full = [&]() {  // interior tiles: 16 bytes per store, no masks
     double *cp = cunit0;
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
+    for (int n = 0; n < 4 * NCI; ++n) {
       *reinterpret_cast<double2 *>(cp) = make_double2(acc[n >> 2][0][n & 3], acc[n >> 2][1][n & 3]);
       *reinterpret_cast<double2 *>(cp + 2) = make_double2(acc[n >> 2][2][n & 3], acc[n >> 2][3][n & 3]);
       cp += cstep;
@@ -483,8 +495,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
   // idle matrix pipes; during the K loops the two waves of a SIMD saturate the pipe, 2 x 1024 x 64 cycles), and waiting
   // on a saturated memory re-forms the convoy after any perturbation (random start phases changed nothing).  Streaming
   // spreads the same reads evenly over the K loops.
-  constexpr bool STREAM = !INIT0 && VEC == 2 && (KW == 256 || KW == 128);
-  if (STREAM && full) {  // uniform branch
+  constexpr bool STREAM = !INIT0 && VEC == 2 && (KW == 256 || KW == 128) && TR == 128;
+  if constexpr (STREAM) if (full) {  // uniform branch
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
@@ -530,12 +542,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
   // ---- general path (edge tiles, unaligned operands, INIT0, narrow reflector blocks): C first -------------------------
   if (INIT0) {
 #pragma unroll
-    for (int ci = 0; ci < 4; ++ci)
+    for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
       for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
   } else if (full) {
 #pragma unroll
-    for (int ci = 0; ci < 4; ++ci)
+    for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const double *cp = cunit0 + (4 * ci + g) * cstep;
@@ -547,10 +559,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
       }
   } else {  // clamped addresses, all loads issued before the first mask is applied
 #pragma unroll
-    for (int ci = 0; ci < 4; ++ci)
+    for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
+        const int cl = wc * WCOLS + ci * 16 + k4 + 4 * g;
         const uint32_t co = (uint32_t)((cl < ncv ? cl : 0) * ldc);
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri) {
@@ -560,10 +572,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
       }
     if constexpr (VEC == 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ci = 0; ci < 4; ++ci)
+    for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const bool cok = wc * 64 + ci * 16 + k4 + 4 * g < ncv;
+        const bool cok = wc * WCOLS + ci * 16 + k4 + 4 * g < ncv;
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri)
           if (!(cok && wr * 64 + 4 * i16 + ri < nrv)) acc[ci][ri][g] = 0.0;
@@ -595,10 +607,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
     store_full();
   } else {
 #pragma unroll
-    for (int ci = 0; ci < 4; ++ci)
+    for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
+        const int cl = wc * WCOLS + ci * 16 + k4 + 4 * g;
         if (cl < ncv) {
           const uint32_t co = (uint32_t)(cl * ldc);
 #pragma unroll

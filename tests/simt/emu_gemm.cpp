@@ -73,6 +73,12 @@ int main(int argc, char **argv) {
   grid2(lx, ly, 256, [&] {                                                                                \
     k_gemm_nn_sub<VEC_, KW_>(V.data(), ldv, W.data(), (int64_t)KW_, C.data(), ldc, rows, ncols, swz, nullptr, 0);     \
   })
+    if (swz == 2) {  // 64-row tiles (the lane's narrow products): grid (ceil(rows / 64), gy)
+      const int g64 = (int)((rows + 63) / 64);
+      if (kparam == 128) grid2(g64, gy, 256, [&] { k_gemm_nn_sub<2, 128, false, false, 64>(V.data(), ldv, W.data(), (int64_t)128, C.data(), ldc, rows, ncols, 0, nullptr, 0); });
+      else if (kparam == 256) grid2(g64, gy, 256, [&] { k_gemm_nn_sub<2, 256, false, false, 64>(V.data(), ldv, W.data(), (int64_t)256, C.data(), ldc, rows, ncols, 0, nullptr, 0); });
+      else return 2;
+    } else
     if (vec == 2 && kparam == 128) NN(2, 128);
     else if (vec == 1 && kparam == 128) NN(1, 128);
     else if (vec == 2 && kparam == 256) NN(2, 256);

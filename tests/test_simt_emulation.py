@@ -270,10 +270,12 @@ def test_gemm_tn_two_panels(emu_gemm, tmp_path, vec, rows, ncols, rps):
 
 
 @pytest.mark.parametrize("vec,kw,rows,ncols,swz", [(2, 128, 200, 150, 0), (1, 128, 131, 129, 0),
-                                                   (2, 256, 256, 128, 0), (2, 128, 300, 260, 1)])
+                                                   (2, 256, 256, 128, 0), (2, 128, 300, 260, 1),
+                                                   (2, 128, 200, 150, 2), (2, 256, 192, 256, 2)])  # swz 2: 64-row tiles
 def test_gemm_nn_sub(emu_gemm, tmp_path, vec, kw, rows, ncols, swz):
-    """C -= V W (k_gemm_nn_sub<VEC,KW>): edge tiles in both directions, K = 256 (two-panel update) and the
-    XCD-aware 1-D launch (swz = 1: every tile exactly once, surplus workgroups exit)"""
+    """C -= V W (k_gemm_nn_sub<VEC,KW>): edge tiles in both directions, K = 256 (two-panel update), the
+    XCD-aware 1-D launch (swz = 1: every tile exactly once, surplus workgroups exit) and the 64-row tiles of the lane's
+    narrow products (swz = 2 in this harness)"""
     rng = np.random.default_rng(2)
     ldv, ldc = rows + rows % 2 + 2, rows + rows % 2 + 4
     V = np.full((ldv, kw), 5.0)
