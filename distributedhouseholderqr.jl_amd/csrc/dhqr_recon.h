@@ -176,9 +176,8 @@ __global__ __launch_bounds__(1024) void k_chol_inv(const double *__restrict__ G,
 // Blocked inverse of a 128 x 128 upper-triangular matrix with FIVE workgroup barriers instead of 128.
 // The elimination order of the inverse is not prescribed by the reference (T and M^{-1} are our own
 // operands), so it can be organised for the machine:
-//   P1  the four 32 x 32 diagonal blocks: ONE LANE PER COLUMN solves U x = e_k by back substitution in
-//       registers (fully unrolled, the block is read from LDS as wave-wide broadcasts) -- no cross-lane
-//       traffic at all, 128 lanes busy for ~500 dependent fma;
+//   P1  the four 32 x 32 diagonal blocks: their 16 x 16 diagonal blocks by ONE LANE PER COLUMN (U x = e_k by back
+//       substitution in registers, fully unrolled, the block read from LDS as broadcasts), then one 16^3 merge per block;
 //   P2  the two 64 x 64 blocks [[A,B],[0,C]]^{-1} = [[A^{-1}, -A^{-1} B C^{-1}],[0, C^{-1}]]: two 32^3
 //       products per block, one output element per thread;
 //   P3  the same step once more for the 128 x 128 matrix: two 64^3 products, four elements per thread.
@@ -229,20 +228,38 @@ __device__ __forceinline__ void rc_upper_inverse_blocked(const double *__restric
   if (t < RC_N) L.dinv[t] = unit ? 1.0 : 1.0 / (rs ? rs[RC_N + t] : Mg[t + t * RC_N]);
   __syncthreads();
   RC5_MARK(0);
-  // ---- P1: column k of the inverse of diagonal block d, one lane per column, registers only
+  // ---- P1: the four 32 x 32 diagonal blocks.  P1a: their eight 16 x 16 diagonal blocks, ONE LANE PER COLUMN (back
+  // substitution in registers: 120 dependent fma instead of the 496 of a 32-column solve); P1b: the upper-right
+  // 16 x 16 block of each, X12 = -A^{-1} (B C^{-1}), on the matrix cores by one wave per block -- the D registers of the
+  // first product ARE the B fragments of the second (register g of lane (fk, fi) holds row 4 g + fk, column fi), so
+  // nothing goes through LDS in between.
   if (t < RC_N) {
-    const int d = t >> 5, k = t & 31;
-    double x[32];
+    const int d = t >> 5, hb = (t >> 4) & 1, k = t & 15, q = 16 * hb;
+    double x[16];
 #pragma unroll
-    for (int i = 31; i >= 0; --i) {
+    for (int i = 15; i >= 0; --i) {
       double s = 0.0;
 #pragma unroll
-      for (int l = i + 1; l < 32; ++l) s = fma(L.Ud[d][i][l], x[l], s);  // x[l] == 0 for l > k
-      x[i] = (i == k) ? L.dinv[32 * d + k] : ((i < k) ? -s * L.dinv[32 * d + i] : 0.0);
+      for (int l = i + 1; l < 16; ++l) s = fma(L.Ud[d][q + i][q + l], x[l], s);  // x[l] == 0 for l > k
+      x[i] = (i == k) ? L.dinv[32 * d + q + k] : ((i < k) ? -s * L.dinv[32 * d + q + i] : 0.0);
     }
-    const int h = d >> 1, o = (d & 1) * 32;
+    const int h = d >> 1, o = (d & 1) * 32 + q;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) L.Xh[h][o + i][o + k] = x[i];
+    for (int i = 0; i < 16; ++i) L.Xh[h][o + i][o + k] = x[i];
+  }
+  __syncthreads();
+  if (t < 256) {  // waves 0..3: diagonal block d = wave
+    const int d = t >> 6, ln = t & 63, pi = ln & 15, pk = ln >> 4, h = d >> 1, o = (d & 1) * 32;
+    dhqr_d4 tb = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)  // T = B C^{-1}
+      tb = __builtin_amdgcn_mfma_f64_16x16x4f64(L.Ud[d][pi][16 + 4 * ks + pk], L.Xh[h][o + 16 + 4 * ks + pk][o + 16 + pi], tb, 0, 0, 0);
+    dhqr_d4 xb = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)  // A^{-1} T
+      xb = __builtin_amdgcn_mfma_f64_16x16x4f64(L.Xh[h][o + pi][o + 4 * ks + pk], tb[ks], xb, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) L.Xh[h][o + pk + 4 * g][o + 16 + pi] = -xb[g];  // read by nobody in this phase
   }
   __syncthreads();
   RC5_MARK(1);
