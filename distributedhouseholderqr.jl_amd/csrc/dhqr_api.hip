@@ -55,6 +55,9 @@ struct dhqr_ctx {
   hipStream_t own = nullptr, stream = nullptr;
   bool profiling = false;
   hipStream_t hi = nullptr;      // high-priority stream: panel factorisation under look-ahead
+  int tn_model = 1;              // wide k_gemm_tn2 launches: split-K factor from the round / partial-traffic estimate (DHQR_TN_MODEL=0: round filling only)
+  int tn_model_min_tiles = 128;  // ... for launches of at least this many column tiles (below, the lane is the critical path and
+                                 // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
   int nn_tr64 = 1;               // narrow C -= V W products on 64-row tiles (DHQR_NN_TR64=0: always 128)
   int swizzle = 1;               // XCD-aware tile order in k_gemm_nn_sub (+1.5 % at 32768^2; DHQR_SWIZZLE=0 disables)
   struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
@@ -767,6 +770,29 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   int64_t nsplit, rps;
   // k_gemm_tn2 workgroups have 512 threads and 110 KB of LDS: one per CU, 256 resident
   pick_split(rows, ntiles, 256, ntiles <= 2 ? 256 : 64, &nsplit, &rps, 256, ntiles <= 2 ? 64 : 128);
+  if (ntiles >= c->tn_model_min_tiles && c->tn_model) {
+    // Wide launches: k_gemm_tn2 runs ONE workgroup per CU, all of the same size, so a launch takes
+    // ceil(ntiles * ns / 256) rounds of rows / ns rows each -- 224 column tiles at ns = 1..4 idle an eighth of the chip,
+    // at ns = 8 they are exactly seven full rounds.  Estimated time in "rows of one workgroup" (2.85e-7 s each at the
+    // kernel's per-CU rate): rounds * slab + the split-K partials written and read back (ns * ncols * 4 KiB at ~3 TB/s)
+    // + ~10 us of prologue / epilogue per round; smallest estimate wins (in situ the per-launch rate varied between
+    // 53.7 and 63.6 TFLOP/s with the number of column tiles, profiles/r02_ab_gemm_variants.txt section 7).
+    const int64_t cap = std::min<int64_t>(64, std::max<int64_t>(1, rows / 512));
+    double best = 1e300;
+    int64_t bns = 1;
+    for (int64_t ns = 1; ns <= cap; ++ns) {
+      if (ns > 1 && ntiles * ns > 3072) break;  // partial buffer: at most 12 rounds (cs_prepare / rs_prepare size it for that)
+      int64_t r = (rows + ns - 1) / ns;
+      r = (r + G_KT - 1) / G_KT * G_KT;
+      const int64_t rounds = (ntiles * ns + 255) / 256;
+      const double est = (double)rounds * (double)r + (double)ns * (double)ncols * 4.79e-3 + 40.0 * (double)rounds;
+      if (est < best) { best = est; bns = ns; }
+    }
+    int64_t r = (rows + bns - 1) / bns;
+    r = (r + G_KT - 1) / G_KT * G_KT;
+    rps = r;
+    nsplit = std::max<int64_t>(1, (rows + r - 1) / r);
+  }
   dhqr_ctx::WS &ws = c->ws[c->cur_ws];
   const int64_t ld2 = 2 * DHQR_NBV;
   CHECK(ensure(c, ws.w1, (size_t)nsplit * ld2 * (size_t)ncols));
@@ -990,6 +1016,8 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
     if (const char *e = getenv("DHQR_SWIZZLE")) c->swizzle = atoi(e) != 0;
     if (const char *e = getenv("DHQR_NN_TR64")) c->nn_tr64 = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_TN_MODEL")) c->tn_model = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_TN_MODEL_MIN_TILES")) c->tn_model_min_tiles = atoi(e);
     if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;
     if (const char *e = getenv("DHQR_PAIR_MIN_N")) c->pair_min_n = atoll(e);
     HIPCHECK(hipHostMalloc((void **)&c->hflag, 4 * sizeof(int), hipHostMallocDefault));

@@ -360,7 +360,7 @@ static int32_t cs_prepare(const CsProblem &pr) {
   CHECK(ensure(c, c->vts, (size_t)panel_elems(m)));
   const size_t ncmax = (size_t)std::max<int64_t>(pr.ncl, 2 * NB);
   const size_t ntmax = (ncmax + 127) / 128;
-  const size_t w1cap = NN * (2048 + 2 * ntmax + 128);  // split-K partials of k_gemm_tn (128 rows) / k_gemm_tn2 (256 rows)
+  const size_t w1cap = NN * (6144 + 2 * ntmax + 128);  // split-K partials of k_gemm_tn (128 rows) / k_gemm_tn2 (256 rows)
   for (int s = 0; s < 2; ++s) {
     CHECK(ensure(c, c->ws[s].w1, s == 0 ? w1cap : NN * 2200));
     CHECK(ensure(c, c->ws[s].w1r, (size_t)2 * NB * ncmax));

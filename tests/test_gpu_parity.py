@@ -169,6 +169,24 @@ def test_column_cyclic_driver_single_rank(pkg, orc, m, n):
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
 
 
+def test_wide_tn_split_model_on_a_small_matrix(pkg, orc, monkeypatch):
+    """the split-K choice of the wide k_gemm_tn2 launches (round / partial-traffic estimate, normally for >= 128 column
+    tiles = matrices beyond 16384 columns) forced onto a 2304^2 matrix: same factorisation as the oracle's"""
+    monkeypatch.setenv("DHQR_TN_MODEL_MIN_TILES", "3")  # read by dhqr_create of the rank context
+    m = n = 2304
+    mg = pkg.MultiGpuQR(devices=[0])
+    try:
+        mg.alloc(m, n).fill(15)
+        mg.factor()
+        H, alpha = mg.download()
+        assert mg.residual(15) < 1e-12
+        Ho, ao = orc.householder(orc.rand_matrix(m, n, 15))
+        scale = np.abs(Ho).max()
+        assert np.abs(H - Ho).max() <= 1e-11 * scale and np.abs(alpha - ao).max() <= 1e-11 * scale
+    finally:
+        mg.close()
+
+
 @pytest.mark.parametrize("ranks,m,n", [(2, 1500, 1300), (2, 2304, 2304), (3, 2000, 1700), (8, 4096, 4096)])
 def test_multi_device_handle_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
     """dhqr_mg_* with `ranks` rank threads all on cuda:0 (RCCL cannot put two ranks on one device, so the
