@@ -80,6 +80,28 @@ def cpu_baseline(m, n, budget_s=20.0):
     }
 
 
+def cpu_baseline_lapack(n=8192):
+    """'Good CPU' reference point (what test/runtests.jl:53 compares against): LAPACK dgeqrf from SciPy's
+    OpenBLAS on the host cores, n x n of the same generator.  Not the reference's algorithm (blocked, BLAS-3)."""
+    try:
+        import numpy as np
+        from scipy.linalg import lapack
+        from oracle import dhqr_oracle as orc
+        out = None
+        for k in (n // 2, n):  # the larger order only if the smaller one says it fits ~20 s
+            if out is not None and out["seconds"] * 8 > 20.0:
+                break
+            A = np.empty((k, k), order="F")
+            orc.lib().dhqr_oracle_fill(orc._ptr(A), k, k, k, 0)
+            t0 = time.perf_counter()
+            _, _, _, info = lapack.dgeqrf(A, overwrite_a=True)
+            dt = time.perf_counter() - t0
+            out = {"n": k, "seconds": dt, "gflops": flops_qr(k, k) / dt / 1e9, "info": int(info)}
+        return out
+    except Exception as e:  # a reported baseline, never fatal
+        return {"error": repr(e)[:200]}
+
+
 def cpu_baseline_distributed(procs=2, orders=(512, 2048, 4096), timeout_s=120):
     """The reference's Distributed.jl STRUCTURE on the host cores (BASELINE configs[0]: 512 x 512, nprocs = 2, and larger
     orders): oracle/dist_oracle.py run as `procs` gloo processes x (cores / procs) OpenMP threads -- contiguous column
@@ -427,6 +449,7 @@ def main():
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(m, n)
             out["cpu_baseline"]["distributed_structure"] = cpu_baseline_distributed()
+            out["cpu_baseline"]["lapack_dgeqrf"] = cpu_baseline_lapack()
             out["host_cores"] = os.cpu_count()
     emit(out, rank)
     if mg is not None:
