@@ -80,28 +80,16 @@ def cpu_baseline(m, n, budget_s=20.0):
     }
 
 
-def cpu_baseline_lapack(n=4096):
+def cpu_baseline_lapack(n=4096, timeout_s=90):
     """'Good CPU' reference point (what test/runtests.jl:53 compares against): LAPACK dgeqrf from SciPy's
-    OpenBLAS on the host cores, n x n of the same generator.  Not the reference's algorithm (blocked, BLAS-3).  The pool's
-    hosts run this OpenBLAS FASTER with few threads (4096^2: 16 s with the default 64 threads, 2.1 s with 16), so the best
-    of two small thread counts is reported together with that count."""
+    OpenBLAS on the host cores (oracle/lapack_bench.py, in a subprocess: a reported baseline must never be able to take the
+    bench line down).  Not the reference's algorithm (blocked, BLAS-3)."""
+    import subprocess
     try:
-        import numpy as np
-        from scipy.linalg import lapack
-        from threadpoolctl import threadpool_limits
-        from oracle import dhqr_oracle as orc
-        best = None
-        for threads in (16, 8):
-            A = np.empty((n, n), order="F")
-            orc.lib().dhqr_oracle_fill(orc._ptr(A), n, n, n, 0)
-            with threadpool_limits(limits=threads):
-                t0 = time.perf_counter()
-                _, _, _, info = lapack.dgeqrf(A, overwrite_a=True)
-                dt = time.perf_counter() - t0
-            cur = {"n": n, "threads": threads, "seconds": dt, "gflops": flops_qr(n, n) / dt / 1e9, "info": int(info)}
-            if best is None or cur["gflops"] > best["gflops"]:
-                best = cur
-        return best
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "lapack_bench.py"), str(n)], capture_output=True,
+                           text=True, timeout=timeout_s)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)
     except Exception as e:  # a reported baseline, never fatal
         return {"error": repr(e)[:200]}
 
