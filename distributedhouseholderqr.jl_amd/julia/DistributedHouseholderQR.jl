@@ -185,6 +185,36 @@ function solve_householder!(b::Vector{Float64}, H::StridedMatrix{Float64}, α::V
   return x
 end
 
+# ---- tall-skinny matrices, ROWS split over the GPUs of one process (BASELINE configs[4]; the reference cannot split
+# rows, src:33): qr!(A, ndev; split=:rows).  Same factor format; per panel the partial Gram matrices and the V'C partial
+# dots are all-reduced over the devices (include/dhqr.h, dhqr_mg_rs_*).
+function householder!(A::StridedMatrix{Float64}, α::Vector{Float64}, ndev::Integer, split::Symbol)
+  split === :rows || return householder!(A, α, ndev)
+  m, n = size(A)
+  stride(A, 1) == 1 || throw(ArgumentError("column-major storage required"))
+  g = multigpu(ndev)
+  check(ccall((:dhqr_mg_rs_alloc_f64, libdhqr), Int32, (Ptr{Cvoid}, Int64, Int64), g, m, n))
+  check(ccall((:dhqr_mg_rs_transfer_f64, libdhqr), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Int32),
+              g, A, stride(A, 2), C_NULL, Int32(1)))                                    # upload
+  check(ccall((:dhqr_mg_rs_factor_f64, libdhqr), Int32, (Ptr{Cvoid},), g))
+  check(ccall((:dhqr_mg_rs_transfer_f64, libdhqr), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Int32),
+              g, A, stride(A, 2), α, Int32(0)))                                        # download: factor + α
+  return (A, α)
+end
+
+function qr!(A::StridedMatrix{Float64}, ndev::Integer, split::Symbol)   # qr!(A, 8, :rows)
+  H = DistributedHouseholderQRStruct(A)
+  householder!(H.A, H.α, ndev, split)
+  return H
+end
+
+"`H \\ b` on the row-split factor that is still resident on the devices (right after qr!(A, ndev, :rows))"
+function solve_rowsplit(b::Vector{Float64}, n::Integer, ndev::Integer)
+  x = Vector{Float64}(undef, n)
+  check(ccall((:dhqr_mg_rs_solve_f64, libdhqr), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), multigpu(ndev), b, x))
+  return x
+end
+
 # ---- one Julia worker per GPU: the reference's own calling convention, qr!(A::DArray) (src:115-120, 311-315;
 # test/runtests.jl:71-78).  Written against DistributedArrays' API (procs(A), localpart(A), size(A)); the package is
 # loaded by the caller exactly as with the reference.  `devices[i]` is the HIP device of the i-th worker of A.
