@@ -397,10 +397,10 @@ def main():
         "roofline": ({k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
                                           "launches", "avg_launch_ms")} if dom else None),
         "roofline_all": rl_all,
-        "traffic_note": "HBM bytes per launch (read + write) from rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE, separate "
-                        "passes, profiles/r02_pmc_traffic.json (collected before the NN kernel streamed its C tile; the "
-                        "bytes per launch are unchanged by that); algorithmic C bytes per wide two-panel launch: 2.88 GB (NN: "
-                        "read + write) / 1.44 GB (TN: read) -> measured 4.03 / 1.78 GB",
+        "traffic_note": "HBM bytes per WIDE launch (read + write) from rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE, separate "
+                        "passes over the torch-free driver with the end-of-round kernels (tools/gpu_pmc3.sh, profiles/r02_pmc_traffic.json); "
+                        "algorithmic C bytes per wide two-panel launch: 5.78 GB (NN: read + write) / 2.89 GB (TN: read) -> measured "
+                        "8.97 / 3.64 GB",
         "phase_ms_per_step": {k: st[k] / args.steps for k in st if k.startswith("ms_") and st[k] > 0},
         "panels_fast_fallback": panel_counts,
     }
