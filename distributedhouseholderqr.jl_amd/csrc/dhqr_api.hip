@@ -58,6 +58,7 @@ struct dhqr_ctx {
   int tn_model = 1;              // wide k_gemm_tn2 launches: split-K factor from the round / partial-traffic estimate (DHQR_TN_MODEL=0: round filling only)
   int tn_model_min_tiles = 128;  // ... for launches of at least this many column tiles (below, the lane is the critical path and
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
+  int rankk = 3;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..4)
   int nn_tr64 = 1;               // narrow C -= V W products on 64-row tiles (DHQR_NN_TR64=0: always 128)
   int swizzle = 1;               // XCD-aware tile order in k_gemm_nn_sub (+1.5 % at 32768^2; DHQR_SWIZZLE=0 disables)
   struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
@@ -170,26 +171,94 @@ static void launch_rank1(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
 #undef DHQR_R1
 }
 
+// K steps per pass over the columns >= c0 (k_rankk_fused): the `kold` reflectors in `vold` are applied, the lead
+// workgroup builds the next K into `vnew`
+template <int VEC, int K>
+static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int64_t ncols, int64_t c0, int64_t jlo,
+                         int kold, const double *vold, double *vnew, int64_t vlen, double *alpha) {
+  const int64_t rtop = (VEC == 2) ? (jlo & ~(int64_t)1) : jlo;
+  const int64_t cov = rows - rtop;
+  const int64_t nwg = (kold == 0) ? 1 : std::max<int64_t>(1, ncols - c0 - (K - 1));
+  dim3 grid((unsigned)nwg);
+#define DHQR_RK(T_, E_)                                                                                  \
+  hipLaunchKernelGGL((k_rankk_fused<T_, E_, VEC, K>), grid, dim3(T_), 0, c->stream, P, ldp, rows, ncols, \
+                     c0, rtop, kold, vold, vnew, vlen, alpha)
+  if (cov <= 256 * 2) DHQR_RK(256, 2);
+  else if (cov <= 256 * 4) DHQR_RK(256, 4);
+  else if (cov <= 256 * 8) DHQR_RK(256, 8);
+  else if (cov <= 512 * 8) DHQR_RK(512, 8);
+  else DHQR_RK(1024, 8);
+#undef DHQR_RK
+}
+static void launch_rankk(dhqr_ctx *c, bool vec, int K, double *P, int64_t ldp, int64_t rows, int64_t ncols, int64_t c0,
+                         int64_t jlo, int kold, const double *vold, double *vnew, int64_t vlen, double *alpha) {
+#define DHQR_RKK(K_)                                                                              \
+  (vec ? launch_rankk<2, K_>(c, P, ldp, rows, ncols, c0, jlo, kold, vold, vnew, vlen, alpha)      \
+       : launch_rankk<1, K_>(c, P, ldp, rows, ncols, c0, jlo, kold, vold, vnew, vlen, alpha))
+  if (K == 2) DHQR_RKK(2);
+  else if (K == 3) DHQR_RKK(3);
+  else DHQR_RKK(4);
+#undef DHQR_RKK
+}
+
 static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64_t ncols,
                                      int64_t ldp, double *alpha, int cat) {
+  const int K = c->rankk;  // reflectors per pass over the trailing columns (1: one launch per reflector)
   const size_t vlen = (size_t)((rows + 17) & ~(int64_t)15);
-  CHECK(ensure(c, c->vbuf, 2 * vlen));
-  double *vb[2] = {c->vbuf.p, c->vbuf.p + vlen};
+  CHECK(ensure(c, c->vbuf, 2 * (size_t)std::max(K, 1) * vlen));
+  double *vset[2] = {c->vbuf.p, c->vbuf.p + (size_t)std::max(K, 1) * vlen};  // two sets of K reflectors
   const bool vec = (ldp % 2 == 0) && (rows % 2 == 0) && aligned16(P);
-  CHECK(prof_begin(c, cat));
-  hipLaunchKernelGGL((k_reflector<1024>), dim3(1), dim3(1024), 0, c->stream, P, rows, (int64_t)0,
-                     vb[0], alpha);
-  CHECK(prof_end(c));
-  for (int64_t j = 0; j + 1 < ncols; ++j) {
-    const int64_t nupd = ncols - (j + 1);
+  auto account = [&](int64_t jlo, int64_t ncol_upd) {
+    if (!c->profiling) return;
+    // algorithmic HBM bytes of the launch as implemented: every column it touches is read once and written once
+    const double by = 16.0 * (double)(rows - jlo) * (double)ncol_upd;
+    if (cat == CAT_RANK1) c->st.bytes_rank1 += by;
+    else c->st.bytes_panel += by;
+  };
+  // Phase 1 -- columns taller than one workgroup's registers (> 8192 rows below the diagonal), or DHQR_RANKK=1: one
+  // reflector per launch, v_j / v_j+1 ping-pong between slot 0 of the two sets.
+  int64_t j = 0;
+  int cur = 0;
+  auto tall = [&](int64_t jj) { return K < 2 || rows - (vec ? (jj & ~(int64_t)1) : jj) > 1024 * 8; };
+  bool have_v = false;  // v_j built (in vset[cur][0])
+  if (tall(0)) {
     CHECK(prof_begin(c, cat));
-    if (vec) launch_rank1<2>(c, P, ldp, rows, j, nupd, vb[j & 1], vb[(j + 1) & 1], alpha);
-    else launch_rank1<1>(c, P, ldp, rows, j, nupd, vb[j & 1], vb[(j + 1) & 1], alpha);
+    hipLaunchKernelGGL((k_reflector<1024>), dim3(1), dim3(1024), 0, c->stream, P, rows, (int64_t)0, vset[0], alpha);
     CHECK(prof_end(c));
-    if (c->profiling) {
-      const double by = 16.0 * (double)(rows - j) * (double)nupd;
-      if (cat == CAT_RANK1) c->st.bytes_rank1 += by;
-      else c->st.bytes_panel += by;
+    have_v = true;
+    for (; j + 1 < ncols && tall(j); ++j) {
+      const int64_t nupd = ncols - (j + 1);
+      CHECK(prof_begin(c, cat));
+      if (vec) launch_rank1<2>(c, P, ldp, rows, j, nupd, vset[cur], vset[cur ^ 1], alpha);
+      else launch_rank1<1>(c, P, ldp, rows, j, nupd, vset[cur], vset[cur ^ 1], alpha);
+      CHECK(prof_end(c));
+      account(j, nupd);
+      cur ^= 1;
+    }
+  }
+  // Phase 2 -- K reflectors per pass: each trailing column is loaded once, updated by v_jlo .. v_jlo+K-1 in the
+  // reference's order and arithmetic, and stored once (16/K B of HBM traffic per element and reflector); the lead
+  // workgroup of the pass builds the next K reflectors, so one launch per K columns.
+  if (K >= 2 && (have_v ? j + 1 < ncols : ncols > 0)) {
+    int64_t jlo;  // oldest reflector not yet applied to the trailing columns
+    int kold;
+    if (have_v) {  // continue from phase 1: v_j alone
+      jlo = j;
+      kold = 1;
+    } else {       // first K reflectors from scratch (one workgroup)
+      jlo = 0;
+      kold = 0;
+    }
+    for (;;) {
+      const int64_t c0 = jlo + kold;  // first column not yet final
+      if (c0 >= ncols) break;
+      CHECK(prof_begin(c, cat));
+      launch_rankk(c, vec, K, P, ldp, rows, ncols, c0, jlo, kold, vset[cur], vset[cur ^ 1], (int64_t)vlen, alpha);
+      CHECK(prof_end(c));
+      account(jlo, kold == 0 ? std::min<int64_t>(K, ncols) : ncols - c0);
+      cur ^= 1;
+      jlo = c0;
+      kold = K;
     }
   }
   LAUNCHCHECK();
@@ -1016,6 +1085,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
     if (const char *e = getenv("DHQR_SWIZZLE")) c->swizzle = atoi(e) != 0;
     if (const char *e = getenv("DHQR_NN_TR64")) c->nn_tr64 = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(4, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_TN_MODEL")) c->tn_model = atoi(e) != 0;
     if (const char *e = getenv("DHQR_TN_MODEL_MIN_TILES")) c->tn_model_min_tiles = atoi(e);
     if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;

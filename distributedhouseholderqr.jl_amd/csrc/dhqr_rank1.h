@@ -150,6 +150,122 @@ __global__ __launch_bounds__(T) void k_rank1_fused(double *__restrict__ A, int64
   }
 }
 
+// K steps in ONE pass over the trailing columns.  The K reflectors v_jlo .. v_jlo+kold-1 already exist (`vold`, one
+// every `vlen` doubles); a workgroup loads its column once, applies them one after the other -- each with its own dot
+// product over the column as updated so far, i.e. exactly the arithmetic of `kold` consecutive k_rank1_fused launches
+// (src:208-209 per step) -- and stores the column once: 16/K bytes of HBM traffic per (element, reflector) instead of
+// 16.  The LEAD workgroup (blockIdx 0) owns the next K columns c0 .. c0+K-1 instead of one: column by column it also
+// applies the reflectors it has just built (re-read from `vnew`: each thread reads back only elements it wrote itself)
+// and builds the column's own reflector (src:129-140), so the launch hands v_c0 .. v_c0+K-1 to the next one and no
+// single-workgroup launch sits between two passes.  Workgroup b >= 1 owns column c0 + K-1 + b.
+// kold = 0 with a grid of ONE workgroup builds the first K reflectors of a matrix / panel from scratch; kold = 1
+// continues from the one-reflector kernels of the tall-column phase.  Rows covered: [rtop, rtop + T*EPT), rtop = jlo
+// (rounded down to even for VEC = 2); every reflector is zero above its diagonal.
+template <int T, int EPT, int VEC, int K>
+__global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
+                                                   int64_t c0, int64_t rtop, int kold,
+                                                   const double *__restrict__ vold, double *vnew, int64_t vlen,
+                                                   double *__restrict__ alpha) {
+  __shared__ double red[2 * (T / 64) + 2];
+  constexpr int HSLOT = 2 * (T / 64);
+  const int t = threadIdx.x;
+  const bool lead = (blockIdx.x == 0);
+  const int64_t mlast = m - VEC;
+  double a[EPT], w[EPT], v[K][EPT];
+
+  auto row_of = [&](int e) -> int64_t {
+    return (VEC == 2) ? rtop + 2 * ((int64_t)t + (int64_t)(e >> 1) * T) + (e & 1) : rtop + t + (int64_t)e * T;
+  };
+  auto load = [&](const double *__restrict__ src, double *dst) {
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
+        const bool ok = row < m;
+        const double2 x = *reinterpret_cast<const double2 *>(src + (ok ? row : mlast));
+        dst[2 * i] = ok ? x.x : 0.0;
+        dst[2 * i + 1] = ok ? x.y : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t row = rtop + t + (int64_t)e * T;
+        const bool ok = row < m;
+        const double x = src[ok ? row : mlast];
+        dst[e] = ok ? x : 0.0;
+      }
+    }
+  };
+  auto store = [&](double *dst, const double *src) {
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
+        if (row < m) *reinterpret_cast<double2 *>(dst + row) = make_double2(src[2 * i], src[2 * i + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t row = rtop + t + (int64_t)e * T;
+        if (row < m) dst[row] = src[e];
+      }
+    }
+  };
+  auto apply = [&](const double *x) {  // one step on the column in a[]: src:208 partialdot, src:209 hotloop!
+    double dot = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) dot = fma(a[e], x[e], dot);
+    const double s = block_sum<T>(dot, red);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) a[e] = fma(-x[e], s, a[e]);
+  };
+
+  const int64_t cfirst = lead ? c0 : c0 + (K - 1) + blockIdx.x;
+  const int nown = lead ? (int)((ncols - c0 < K) ? (ncols - c0) : K) : 1;
+  load(A + cfirst * lda, a);  // the column first: its loads are in flight while the reflectors arrive
+#pragma unroll
+  for (int p = 0; p < K; ++p)
+    if (p < kold) load(vold + (int64_t)p * vlen, v[p]);
+
+  for (int q = 0; q < nown; ++q) {
+    const int64_t c = cfirst + q;
+    double *__restrict__ col = A + c * lda;
+    if (q > 0) load(col, a);
+#pragma unroll
+    for (int p = 0; p < K; ++p)
+      if (p < kold) apply(v[p]);
+    if (lead) {
+      for (int p = 0; p < q; ++p) {  // the reflectors this workgroup built in this launch
+        load(vnew + (int64_t)p * vlen, w);
+        apply(w);
+      }
+      dhqr_dd acc = {0.0, 0.0};  // extended-precision column norm (src:129: dnrm2)
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t row = row_of(e);
+        if (row == c) red[HSLOT] = a[e];
+        if (row >= c && row < m) dd_add_sq(acc, a[e]);
+      }
+      const double sq = dd_block_sum<T>(acc, red);  // barriers inside also publish red[HSLOT]
+      const double h = red[HSLOT];
+      const double sn = sqrt(sq);                        // src:129
+      const double al = sn * dhqr_alphafactor(h);        // src:130
+      const double f = 1.0 / sqrt(sn * (sn + fabs(h)));  // src:131
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t row = row_of(e);
+        if (row == c) a[e] = (h - al) * f;  // src:132-135
+        else if (row > c) a[e] *= f;
+        w[e] = (row >= c) ? a[e] : 0.0;     // outgoing Hj (src:138-140)
+      }
+      if (t == 0) alpha[c] = al;
+      store(vnew + (int64_t)q * vlen, w);
+      __syncthreads();  // red[HSLOT] is rewritten for the next column
+    }
+    store(col, a);
+  }
+}
+
 // Fused step j for columns taller than 1024*8 rows: same contract, the column is streamed twice
 // (the second pass hits L2: a 32768-row column is 256 KiB).
 template <int T, int VEC>

@@ -85,6 +85,24 @@ def test_factor_drivers_vs_oracle(emu, orc, m, n, nb):
     assert emu.dhqr_destroy(h) == 0
 
 
+@pytest.mark.parametrize("m,n", [(200, 64), (131, 37), (70, 70)])
+def test_unblocked_k_reflectors_per_pass_is_the_same_arithmetic(emu, orc, m, n):
+    """nb = 0: k_rankk_fused applies K reflectors in one pass over every trailing column (1/K of the HBM traffic) --
+    element by element the operations of K k_rank1_fused launches; only the summation order of the dot products differs
+    (they are summed from the pass's first row, and the first column's norm by the lead workgroup instead of k_reflector)"""
+    A0 = orc.rand_matrix(m, n, 14)
+    res = {}
+    for K in (1, 2, 3, 4):
+        h = _ctx(emu, DHQR_RANKK=K)
+        A, al = _factor(emu, h, A0, 0)
+        _check(orc, A0, A, al)
+        res[K] = (A, al)
+        emu.dhqr_destroy(h)
+    scale = np.abs(res[1][0]).max()
+    for K in (2, 3, 4):
+        assert np.abs(res[K][0] - res[1][0]).max() <= 1e-13 * scale and np.abs(res[K][1] - res[1][1]).max() <= 1e-13 * scale
+
+
 def test_two_panel_driver_and_switches(emu, orc):
     """two-panel groups (K = 256 wide updates) engage for n >= DHQR_PAIR_MIN_N; DHQR_PAIR=0 keeps single-panel
     groups, DHQR_LOOKAHEAD=0 the simple host-verified loop -- same factorisation, every panel on the fast path"""

@@ -47,7 +47,10 @@ def test_golden_fixtures(pkg, path, nb):
 # every kernel variant of the unblocked path: register-resident (<=512 ... <=8192 rows), the
 # two-pass tall kernel (>8192 rows), even/odd m (16-byte vs scalar loads), m == n
 @pytest.mark.parametrize("m,n", [(5, 3), (64, 64), (111, 100), (500, 40), (1000, 64), (2000, 48), (4000, 32),
-                                 (8192, 24), (9001, 16), (20000, 12), (33, 33)])
+                                 (8192, 24), (9001, 16), (20000, 12), (33, 33),
+                                 # several reflectors per pass (k_rankk_fused): down the workgroup-size ladder, and
+                                 # continuing from the tall-column kernels once a column fits (even / odd m)
+                                 (1030, 600), (8210, 48), (8201, 30)])
 def test_unblocked_vs_oracle(pkg, orc, m, n):
     H, A0 = _factor_dev(pkg, m, n, 3, 0)
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 3))
@@ -55,6 +58,26 @@ def test_unblocked_vs_oracle(pkg, orc, m, n):
     assert np.abs(H.A.cpu().numpy() - Ho).max() <= 1e-11 * scale
     assert np.abs(H.α.cpu().numpy() - ao).max() <= 1e-11 * scale
     assert pkg.residual(H, A0) < 1e-12
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4])
+@pytest.mark.parametrize("m,n", [(2100, 300), (8203, 41), (517, 517)])
+def test_unblocked_reflectors_per_pass(pkg, orc, m, n, K, monkeypatch):
+    """DHQR_RANKK = 1..4 reflectors per pass over the trailing columns: the same factorisation as the oracle's"""
+    monkeypatch.setenv("DHQR_RANKK", str(K))  # read by dhqr_create
+    api = pkg.api
+    old = api._contexts.pop(0, None)
+    try:
+        H, A0 = _factor_dev(pkg, m, n, 5, 0)
+        Ho, ao = orc.householder(orc.rand_matrix(m, n, 5))
+        scale = np.abs(Ho).max()
+        assert np.abs(H.A.cpu().numpy() - Ho).max() <= 1e-11 * scale
+        assert np.abs(H.α.cpu().numpy() - ao).max() <= 1e-11 * scale
+        assert pkg.residual(H, A0) < 1e-12
+    finally:
+        api._contexts.pop(0, None)
+        if old is not None:
+            api._contexts[0] = old
 
 
 @pytest.mark.parametrize("m,n", [(128, 128), (129, 129), (300, 128), (300, 200), (1000, 999), (2050, 1030),
