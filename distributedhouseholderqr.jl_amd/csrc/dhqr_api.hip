@@ -58,6 +58,7 @@ struct dhqr_ctx {
   int tn_model = 1;              // wide k_gemm_tn2 launches: split-K factor from the round / partial-traffic estimate (DHQR_TN_MODEL=0: round filling only)
   int tn_model_min_tiles = 128;  // ... for launches of at least this many column tiles (below, the lane is the critical path and
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
+  int rankk_wgs = 256;           // ... bulk workgroups of 1024 threads resident at once (CU count; DHQR_RANKK_WGS)
   int rankk = 3;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..4)
   int nn_tr64 = 1;               // narrow C -= V W products on 64-row tiles (DHQR_NN_TR64=0: always 128)
   int swizzle = 1;               // XCD-aware tile order in k_gemm_nn_sub (+1.5 % at 32768^2; DHQR_SWIZZLE=0 disables)
@@ -178,15 +179,21 @@ static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
                          int kold, const double *vold, double *vnew, int64_t vlen, double *alpha) {
   const int64_t rtop = (VEC == 2) ? (jlo & ~(int64_t)1) : jlo;
   const int64_t cov = rows - rtop;
-  const int64_t nwg = (kold == 0) ? 1 : std::max<int64_t>(1, ncols - c0 - (K - 1));
-  dim3 grid((unsigned)nwg);
+  // lead workgroup + persistent bulk workgroups: as many as run at once (one 1024-thread workgroup per CU), less the
+  // lead's place
+  const int64_t nbulk = (kold == 0) ? 0 : std::max<int64_t>(0, ncols - c0 - K);
 #define DHQR_RK(T_, E_)                                                                                  \
-  hipLaunchKernelGGL((k_rankk_fused<T_, E_, VEC, K>), grid, dim3(T_), 0, c->stream, P, ldp, rows, ncols, \
-                     c0, rtop, kold, vold, vnew, vlen, alpha)
+  hipLaunchKernelGGL((k_rankk_fused<T_, E_, VEC, K>),                                                    \
+                     dim3((unsigned)(1 + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs * (1024 / T_) - 1))),        \
+                     dim3(T_), 0, c->stream, P, ldp, rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha)
   if (cov <= 256 * 2) DHQR_RK(256, 2);
   else if (cov <= 256 * 4) DHQR_RK(256, 4);
   else if (cov <= 256 * 8) DHQR_RK(256, 8);
+  else if (cov <= 384 * 8) DHQR_RK(384, 8);
   else if (cov <= 512 * 8) DHQR_RK(512, 8);
+  else if (cov <= 640 * 8) DHQR_RK(640, 8);
+  else if (cov <= 768 * 8) DHQR_RK(768, 8);
+  else if (cov <= 896 * 8) DHQR_RK(896, 8);
   else DHQR_RK(1024, 8);
 #undef DHQR_RK
 }
@@ -1085,6 +1092,12 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
     if (const char *e = getenv("DHQR_SWIZZLE")) c->swizzle = atoi(e) != 0;
     if (const char *e = getenv("DHQR_NN_TR64")) c->nn_tr64 = atoi(e) != 0;
+    {
+      int ncu = 0;
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0)
+        c->rankk_wgs = ncu;
+    }
+    if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(4, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_TN_MODEL")) c->tn_model = atoi(e) != 0;
     if (const char *e = getenv("DHQR_TN_MODEL_MIN_TILES")) c->tn_model_min_tiles = atoi(e);

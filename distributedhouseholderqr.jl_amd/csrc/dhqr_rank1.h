@@ -150,14 +150,18 @@ __global__ __launch_bounds__(T) void k_rank1_fused(double *__restrict__ A, int64
   }
 }
 
-// K steps in ONE pass over the trailing columns.  The K reflectors v_jlo .. v_jlo+kold-1 already exist (`vold`, one
-// every `vlen` doubles); a workgroup loads its column once, applies them one after the other -- each with its own dot
-// product over the column as updated so far, i.e. exactly the arithmetic of `kold` consecutive k_rank1_fused launches
-// (src:208-209 per step) -- and stores the column once: 16/K bytes of HBM traffic per (element, reflector) instead of
-// 16.  The LEAD workgroup (blockIdx 0) owns the next K columns c0 .. c0+K-1 instead of one: column by column it also
-// applies the reflectors it has just built (re-read from `vnew`: each thread reads back only elements it wrote itself)
-// and builds the column's own reflector (src:129-140), so the launch hands v_c0 .. v_c0+K-1 to the next one and no
-// single-workgroup launch sits between two passes.  Workgroup b >= 1 owns column c0 + K-1 + b.
+// K steps in ONE pass over the trailing columns.  The reflectors v_jlo .. v_jlo+kold-1 already exist (`vold`, one every
+// `vlen` doubles) and stay in registers for the whole launch.  A workgroup loads a column once, applies them one after the
+// other -- each with its own dot product over the column as updated so far, i.e. exactly the arithmetic of `kold`
+// consecutive k_rank1_fused launches (src:208-209 per step) -- and stores it once: 16/K bytes of HBM traffic per
+// (element, reflector) instead of 16.
+//   * blockIdx 0, the LEAD workgroup, owns the next K columns c0 .. c0+K-1: column by column it also applies the
+//     reflectors it has just built (re-read from `vnew`: each thread reads back only elements it wrote itself) and builds
+//     the column's own reflector (src:129-140), so the launch hands v_c0 .. v_c0+K-1 to the next one and no
+//     single-workgroup launch sits between two passes.
+//   * blockIdx b >= 1, the BULK workgroups, are persistent: b owns columns c0+K + (b-1) + i (gridDim-1), and requests
+//     the next column's loads before it works on the current one (one workgroup per CU holds a column and the K
+//     reflectors in registers, so nothing else hides the load latency while it computes).
 // kold = 0 with a grid of ONE workgroup builds the first K reflectors of a matrix / panel from scratch; kold = 1
 // continues from the one-reflector kernels of the tall-column phase.  Rows covered: [rtop, rtop + T*EPT), rtop = jlo
 // (rounded down to even for VEC = 2); every reflector is zero above its diagonal.
@@ -169,22 +173,25 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
   __shared__ double red[2 * (T / 64) + 2];
   constexpr int HSLOT = 2 * (T / 64);
   const int t = threadIdx.x;
-  const bool lead = (blockIdx.x == 0);
   const int64_t mlast = m - VEC;
-  double a[EPT], w[EPT], v[K][EPT];
+  double a[EPT], an[EPT], v[K][EPT];
+  double ax[EPT];  // third column buffer of the bulk rotation
 
   auto row_of = [&](int e) -> int64_t {
     return (VEC == 2) ? rtop + 2 * ((int64_t)t + (int64_t)(e >> 1) * T) + (e & 1) : rtop + t + (int64_t)e * T;
   };
-  auto load = [&](const double *__restrict__ src, double *dst) {
+  // rows beyond m read a clamped address; a REFLECTOR is zeroed there (mask), a COLUMN is left as loaded: times the
+  // reflector's zero it adds nothing to a dot product, its update is a - 0 s, and it is never stored -- so a column's
+  // registers have no use between the load and the first dot product, and the bulk loop's early loads stay in flight
+  auto load = [&](const double *src, double *dst, bool mask) {
     if constexpr (VEC == 2) {
 #pragma unroll
       for (int i = 0; i < EPT / 2; ++i) {
         const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
         const bool ok = row < m;
         const double2 x = *reinterpret_cast<const double2 *>(src + (ok ? row : mlast));
-        dst[2 * i] = ok ? x.x : 0.0;
-        dst[2 * i + 1] = ok ? x.y : 0.0;
+        dst[2 * i] = (ok || !mask) ? x.x : 0.0;
+        dst[2 * i + 1] = (ok || !mask) ? x.y : 0.0;
       }
     } else {
 #pragma unroll
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
         const int64_t row = rtop + t + (int64_t)e * T;
         const bool ok = row < m;
         const double x = src[ok ? row : mlast];
-        dst[e] = ok ? x : 0.0;
+        dst[e] = (ok || !mask) ? x : 0.0;
       }
     }
   };
@@ -211,58 +218,96 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
       }
     }
   };
-  auto apply = [&](const double *x) {  // one step on the column in a[]: src:208 partialdot, src:209 hotloop!
+  auto apply = [&](double *y, const double *x) {  // one step on the column in y[]: src:208 partialdot, src:209 hotloop!
     double dot = 0.0;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) dot = fma(a[e], x[e], dot);
+    for (int e = 0; e < EPT; ++e) dot = fma(y[e], x[e], dot);
     const double s = block_sum<T>(dot, red);
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) a[e] = fma(-x[e], s, a[e]);
+    for (int e = 0; e < EPT; ++e) y[e] = fma(-x[e], s, y[e]);
   };
-
-  const int64_t cfirst = lead ? c0 : c0 + (K - 1) + blockIdx.x;
-  const int nown = lead ? (int)((ncols - c0 < K) ? (ncols - c0) : K) : 1;
-  load(A + cfirst * lda, a);  // the column first: its loads are in flight while the reflectors arrive
-#pragma unroll
-  for (int p = 0; p < K; ++p)
-    if (p < kold) load(vold + (int64_t)p * vlen, v[p]);
-
-  for (int q = 0; q < nown; ++q) {
-    const int64_t c = cfirst + q;
-    double *__restrict__ col = A + c * lda;
-    if (q > 0) load(col, a);
+  auto apply_old = [&](double *y) {
 #pragma unroll
     for (int p = 0; p < K; ++p)
-      if (p < kold) apply(v[p]);
-    if (lead) {
-      for (int p = 0; p < q; ++p) {  // the reflectors this workgroup built in this launch
-        load(vnew + (int64_t)p * vlen, w);
-        apply(w);
-      }
-      dhqr_dd acc = {0.0, 0.0};  // extended-precision column norm (src:129: dnrm2)
+      if (p < kold) apply(y, v[p]);
+  };
+
+  if (blockIdx.x != 0) {  // ---- bulk: persistent, the next column's loads in flight behind the current column's work
+    const int64_t stride = (int64_t)gridDim.x - 1;
+    int64_t c = c0 + K + ((int64_t)blockIdx.x - 1);
+    if (c >= ncols) return;
+    load(A + c * lda, a, false);
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const int64_t row = row_of(e);
-        if (row == c) red[HSLOT] = a[e];
-        if (row >= c && row < m) dd_add_sq(acc, a[e]);
-      }
-      const double sq = dd_block_sum<T>(acc, red);  // barriers inside also publish red[HSLOT]
-      const double h = red[HSLOT];
-      const double sn = sqrt(sq);                        // src:129
-      const double al = sn * dhqr_alphafactor(h);        // src:130
-      const double f = 1.0 / sqrt(sn * (sn + fabs(h)));  // src:131
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const int64_t row = row_of(e);
-        if (row == c) a[e] = (h - al) * f;  // src:132-135
-        else if (row > c) a[e] *= f;
-        w[e] = (row >= c) ? a[e] : 0.0;     // outgoing Hj (src:138-140)
-      }
-      if (t == 0) alpha[c] = al;
-      store(vnew + (int64_t)q * vlen, w);
-      __syncthreads();  // red[HSLOT] is rewritten for the next column
+    for (int p = 0; p < K; ++p)
+      if (p < kold) load(vold + (int64_t)p * vlen, v[p], true);
+    // THREE column buffers in rotation: a store holds its data registers until it completes, so the early load goes to
+    // the buffer stored one step earlier, not to the one stored a moment ago.  (The early load is unconditional -- past
+    // the last column it re-reads the current one -- so that the wait counters the compiler derives are those of
+    // straight-line code: a branch around the loads would make it wait for them at once.)
+#define DHQR_RK_STEP(CUR, NXT)                       \
+    {                                                  \
+      const int64_t cn = c + stride;                   \
+      const bool more = cn < ncols;                    \
+      load(A + (more ? cn : c) * lda, NXT, false);     \
+      apply_old(CUR);                                  \
+      store(A + c * lda, CUR);                         \
+      if (!more) break;                                \
+      c = cn;                                          \
     }
+    if constexpr (K <= 3) {
+      for (;;) {
+        DHQR_RK_STEP(a, an)
+        DHQR_RK_STEP(an, ax)
+        DHQR_RK_STEP(ax, a)
+      }
+    } else {  // K = 4: the registers hold two column buffers only
+      for (;;) {
+        DHQR_RK_STEP(a, an)
+        DHQR_RK_STEP(an, a)
+      }
+    }
+#undef DHQR_RK_STEP
+    return;
+  }
+
+  // ---- lead: the next K columns and their reflectors (an[] is the scratch for the reflectors built here)
+  const int nown = (int)((ncols - c0 < K) ? (ncols - c0) : K);
+  load(A + c0 * lda, a, false);
+#pragma unroll
+  for (int p = 0; p < K; ++p)
+    if (p < kold) load(vold + (int64_t)p * vlen, v[p], true);
+  for (int q = 0; q < nown; ++q) {
+    const int64_t c = c0 + q;
+    double *col = A + c * lda;
+    if (q > 0) load(col, a, false);
+    apply_old(a);
+    for (int p = 0; p < q; ++p) {  // the reflectors this workgroup built in this launch
+      load(vnew + (int64_t)p * vlen, an, true);
+      apply(a, an);
+    }
+    dhqr_dd acc = {0.0, 0.0};  // extended-precision column norm (src:129: dnrm2)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t row = row_of(e);
+      if (row == c) red[HSLOT] = a[e];
+      if (row >= c && row < m) dd_add_sq(acc, a[e]);
+    }
+    const double sq = dd_block_sum<T>(acc, red);  // barriers inside also publish red[HSLOT]
+    const double h = red[HSLOT];
+    const double sn = sqrt(sq);                        // src:129
+    const double al = sn * dhqr_alphafactor(h);        // src:130
+    const double f = 1.0 / sqrt(sn * (sn + fabs(h)));  // src:131
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t row = row_of(e);
+      if (row == c) a[e] = (h - al) * f;  // src:132-135
+      else if (row > c) a[e] *= f;
+      an[e] = (row >= c) ? a[e] : 0.0;    // outgoing Hj (src:138-140)
+    }
+    if (t == 0) alpha[c] = al;
+    store(vnew + (int64_t)q * vlen, an);
     store(col, a);
+    __syncthreads();  // red[HSLOT] is rewritten for the next column
   }
 }
 

@@ -418,8 +418,11 @@ inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind
 #define HIP_SYMBOL(x) (&(x))
 inline hipError_t hipMemcpyToSymbol(void *sym, const void *s, size_t n) { std::memmove(sym, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyFromSymbol(void *d, const void *sym, size_t n) { std::memmove(d, sym, n); return hipSuccess; }
-enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1 };
-inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 100000; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1, hipDeviceAttributeMultiprocessorCount = 2 };
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int) {
+  *v = (a == hipDeviceAttributeMultiprocessorCount) ? 4 : 100000;
+  return hipSuccess;
+}
 inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height,
                                    hipMemcpyKind, hipStream_t) {
   for (size_t r = 0; r < height; ++r) std::memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width);

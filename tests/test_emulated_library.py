@@ -93,7 +93,7 @@ def test_unblocked_k_reflectors_per_pass_is_the_same_arithmetic(emu, orc, m, n):
     A0 = orc.rand_matrix(m, n, 14)
     res = {}
     for K in (1, 2, 3, 4):
-        h = _ctx(emu, DHQR_RANKK=K)
+        h = _ctx(emu, DHQR_RANKK=K, DHQR_RANKK_WGS=2 + K % 2)  # 4 or 8 persistent bulk workgroups of 256 threads + the lead
         A, al = _factor(emu, h, A0, 0)
         _check(orc, A0, A, al)
         res[K] = (A, al)
