@@ -59,7 +59,7 @@ struct dhqr_ctx {
   int tn_model_min_tiles = 128;  // ... for launches of at least this many column tiles (below, the lane is the critical path and
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
   int rankk_wgs = 256;           // ... bulk workgroups of 1024 threads resident at once (CU count; DHQR_RANKK_WGS)
-  int rankk = 3;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..4)
+  int rankk = 5;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..5; beyond 3 the further ones are held in LDS)
   int nn_tr64 = 1;               // narrow C -= V W products on 64-row tiles (DHQR_NN_TR64=0: always 128)
   int swizzle = 1;               // XCD-aware tile order in k_gemm_nn_sub (+1.5 % at 32768^2; DHQR_SWIZZLE=0 disables)
   struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
@@ -204,7 +204,8 @@ static void launch_rankk(dhqr_ctx *c, bool vec, int K, double *P, int64_t ldp, i
        : launch_rankk<1, K_>(c, P, ldp, rows, ncols, c0, jlo, kold, vold, vnew, vlen, alpha))
   if (K == 2) DHQR_RKK(2);
   else if (K == 3) DHQR_RKK(3);
-  else DHQR_RKK(4);
+  else if (K == 4) DHQR_RKK(4);
+  else DHQR_RKK(5);
 #undef DHQR_RKK
 }
 
@@ -1098,7 +1099,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
         c->rankk_wgs = ncu;
     }
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
-    if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(4, std::max(1, atoi(e)));
+    if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_TN_MODEL")) c->tn_model = atoi(e) != 0;
     if (const char *e = getenv("DHQR_TN_MODEL_MIN_TILES")) c->tn_model_min_tiles = atoi(e);
     if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;

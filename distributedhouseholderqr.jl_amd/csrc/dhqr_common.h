@@ -66,6 +66,25 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
   return s;
 }
 
+// The same total with ONE barrier: consecutive calls alternate between two halves of `red` (>= 2 * THREADS/64 doubles;
+// `par` is the caller's call counter), so a wave that is already writing the next call's partial sums cannot overwrite
+// those a slower wave is still reading -- it cannot be two calls ahead, each call has its barrier.  Wave sums by DPP.
+// For kernels whose critical chain is dot product -> total -> update, several times per column (k_rankk_fused).
+template <int THREADS>
+__device__ __forceinline__ double block_sum_alt(double v, double *red, int &par) {
+  v = wave_sum_dpp(v);
+  constexpr int NW = THREADS / 64;
+  if constexpr (NW == 1) return v;
+  double *r = red + (par & 1) * NW;
+  ++par;
+  if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) s += r[i];
+  return s;
+}
+
 // ---- extended-precision sum of squares for the column norm.  The reference's norm (src:129) is BLAS
 // dnrm2 / dznrm2, which OpenBLAS accumulates in x87 extended precision on x86-64 (the CPU test oracle
 // restates that with long double).  The reflector of the dominant direction is what the reference's

@@ -170,11 +170,16 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
                                                    int64_t c0, int64_t rtop, int kold,
                                                    const double *__restrict__ vold, double *vnew, int64_t vlen,
                                                    double *__restrict__ alpha) {
-  __shared__ double red[2 * (T / 64) + 2];
+  constexpr int KR = K < 3 ? K : 3;  // reflectors held in registers ...
+  constexpr int KL = K - KR;         // ... and in LDS (one workgroup per CU: 64 KiB each at 8192 rows)
+  __shared__ double red[2 * (T / 64) + 2];   // the lead's double-double sums + the pivot slot
+  __shared__ double reda[2 * (T / 64)];      // block_sum_alt: two halves in alternation
+  int par = 0;
+  __shared__ __attribute__((aligned(16))) double vl[KL > 0 ? KL * T * EPT : 2];
   constexpr int HSLOT = 2 * (T / 64);
   const int t = threadIdx.x;
   const int64_t mlast = m - VEC;
-  double a[EPT], an[EPT], v[K][EPT];
+  double a[EPT], an[EPT], v[KR][EPT];
   double ax[EPT];  // third column buffer of the bulk rotation
 
   auto row_of = [&](int e) -> int64_t {
@@ -222,14 +227,42 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
     double dot = 0.0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) dot = fma(y[e], x[e], dot);
-    const double s = block_sum<T>(dot, red);
+    const double s = block_sum_alt<T>(dot, reda, par);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) y[e] = fma(-x[e], s, y[e]);
   };
+  // thread t keeps element e of an LDS-resident reflector at the position of its own 16-byte (8-byte) accesses
+  auto lds_at = [&](int q, int e) -> double * {
+    return (VEC == 2) ? vl + (size_t)q * T * EPT + 2 * ((size_t)t + (size_t)(e >> 1) * T) + (e & 1)
+                      : vl + (size_t)q * T * EPT + (size_t)t + (size_t)e * T;
+  };
+  auto apply_lds = [&](double *y, int q) {
+    double dot = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) dot = fma(y[e], *lds_at(q, e), dot);
+    const double s = block_sum_alt<T>(dot, reda, par);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) y[e] = fma(-*lds_at(q, e), s, y[e]);
+  };
+  auto load_old = [&]() {  // the launch's reflectors: registers, then LDS (staged through ax[])
+#pragma unroll
+    for (int p = 0; p < KR; ++p)
+      if (p < kold) load(vold + (int64_t)p * vlen, v[p], true);
+#pragma unroll
+    for (int q = 0; q < KL; ++q)
+      if (KR + q < kold) {
+        load(vold + (int64_t)(KR + q) * vlen, ax, true);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) *lds_at(q, e) = ax[e];  // read back by the same thread only
+      }
+  };
   auto apply_old = [&](double *y) {
 #pragma unroll
-    for (int p = 0; p < K; ++p)
+    for (int p = 0; p < KR; ++p)
       if (p < kold) apply(y, v[p]);
+#pragma unroll
+    for (int q = 0; q < KL; ++q)
+      if (KR + q < kold) apply_lds(y, q);
   };
 
   if (blockIdx.x != 0) {  // ---- bulk: persistent, the next column's loads in flight behind the current column's work
@@ -237,9 +270,7 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
     int64_t c = c0 + K + ((int64_t)blockIdx.x - 1);
     if (c >= ncols) return;
     load(A + c * lda, a, false);
-#pragma unroll
-    for (int p = 0; p < K; ++p)
-      if (p < kold) load(vold + (int64_t)p * vlen, v[p], true);
+    load_old();
     // THREE column buffers in rotation: a store holds its data registers until it completes, so the early load goes to
     // the buffer stored one step earlier, not to the one stored a moment ago.  (The early load is unconditional -- past
     // the last column it re-reads the current one -- so that the wait counters the compiler derives are those of
@@ -254,17 +285,10 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
       if (!more) break;                                \
       c = cn;                                          \
     }
-    if constexpr (K <= 3) {
-      for (;;) {
-        DHQR_RK_STEP(a, an)
-        DHQR_RK_STEP(an, ax)
-        DHQR_RK_STEP(ax, a)
-      }
-    } else {  // K = 4: the registers hold two column buffers only
-      for (;;) {
-        DHQR_RK_STEP(a, an)
-        DHQR_RK_STEP(an, a)
-      }
+    for (;;) {
+      DHQR_RK_STEP(a, an)
+      DHQR_RK_STEP(an, ax)
+      DHQR_RK_STEP(ax, a)
     }
 #undef DHQR_RK_STEP
     return;
@@ -273,9 +297,7 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
   // ---- lead: the next K columns and their reflectors (an[] is the scratch for the reflectors built here)
   const int nown = (int)((ncols - c0 < K) ? (ncols - c0) : K);
   load(A + c0 * lda, a, false);
-#pragma unroll
-  for (int p = 0; p < K; ++p)
-    if (p < kold) load(vold + (int64_t)p * vlen, v[p], true);
+  load_old();
   for (int q = 0; q < nown; ++q) {
     const int64_t c = c0 + q;
     double *col = A + c * lda;

@@ -92,14 +92,14 @@ def test_unblocked_k_reflectors_per_pass_is_the_same_arithmetic(emu, orc, m, n):
     (they are summed from the pass's first row, and the first column's norm by the lead workgroup instead of k_reflector)"""
     A0 = orc.rand_matrix(m, n, 14)
     res = {}
-    for K in (1, 2, 3, 4):
+    for K in (1, 2, 3, 4, 5):
         h = _ctx(emu, DHQR_RANKK=K, DHQR_RANKK_WGS=2 + K % 2)  # 4 or 8 persistent bulk workgroups of 256 threads + the lead
         A, al = _factor(emu, h, A0, 0)
         _check(orc, A0, A, al)
         res[K] = (A, al)
         emu.dhqr_destroy(h)
     scale = np.abs(res[1][0]).max()
-    for K in (2, 3, 4):
+    for K in (2, 3, 4, 5):
         assert np.abs(res[K][0] - res[1][0]).max() <= 1e-13 * scale and np.abs(res[K][1] - res[1][1]).max() <= 1e-13 * scale
 
 

@@ -60,10 +60,10 @@ def test_unblocked_vs_oracle(pkg, orc, m, n):
     assert pkg.residual(H, A0) < 1e-12
 
 
-@pytest.mark.parametrize("K", [1, 2, 3, 4])
-@pytest.mark.parametrize("m,n", [(2100, 300), (8203, 41), (517, 517)])
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("m,n", [(2100, 300), (8203, 41), (517, 517), (8192, 40), (5000, 64)])
 def test_unblocked_reflectors_per_pass(pkg, orc, m, n, K, monkeypatch):
-    """DHQR_RANKK = 1..4 reflectors per pass over the trailing columns: the same factorisation as the oracle's"""
+    """DHQR_RANKK = 1..5 reflectors per pass over the trailing columns: the same factorisation as the oracle's"""
     monkeypatch.setenv("DHQR_RANKK", str(K))  # read by dhqr_create
     api = pkg.api
     old = api._contexts.pop(0, None)

@@ -2,4 +2,4 @@
 # K reflectors per pass (k_rankk_fused, persistent bulk workgroups): parity + A/B at 8192^2 unblocked (BASELINE configs[1])
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 600 -k "unblocked" -p no:cacheprovider 2>&1 | tail -5 | tee gpurun_out/r3a_pytest.txt
-for F in "1 0" "2 0" "3 0" "4 0" "2 1" "3 1" "1 1"; do set -- $F; DHQR_RANKK=$1 DHQR_GRAPH=$2 timeout 300 python bench.py --config unblocked --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('rankk graph', '$F', 'ms', d['ms_per_step'], 'GFLOP/s', d['value'], 'resid', d.get('residual'), 'GB/s', d['roofline']['achieved'], d['roofline']['launches'])"; done | tee gpurun_out/r3a_ab.txt
+for F in 3 4 5 3 4 5; do DHQR_RANKK=$F timeout 300 python bench.py --config unblocked --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('rankk', '$F', 'ms', d['ms_per_step'], 'GFLOP/s', d['value'], 'resid', d.get('residual'), 'GB/s', d['roofline']['achieved'], d['roofline']['launches'])"; done | tee gpurun_out/r3a_ab.txt
