@@ -208,9 +208,10 @@ def pmc_traffic(kernel, m, n, nb, launches, work):
                ("k_gemm_tn2<2>" if kernel.startswith("k_gemm_tn") else None))
         e = pm.get("blocked32768_summary", {}).get(key) if key else None
         return e["bytes_per_launch"] if e else None
-    if not nb and kernel.startswith("k_rank1"):
-        # measured on the same kernel at 4096^2: HBM bytes = 1.0036 x the algorithmic 16 B / element / reflector
-        return pm["unblocked4096_k_rank1"]["ratio"] * work / max(1, launches)
+    if not nb and kernel.startswith("k_rankk"):
+        # measured on the same kernel and workload (8192^2): HBM bytes / the algorithmic bytes of the launches as implemented
+        e = pm.get("unblocked8192_k_rankk")
+        return e["ratio"] * work / max(1, launches) if e else None
     return None
 
 
@@ -229,8 +230,10 @@ def roofline_groups(st, steps, m=0, n=0, nb=0):
         groups.append(dict(kernel="panel lane: Gram/Cholesky/replay/narrow-update kernels (dhqr_recon.h)", bound="hbm", ms=st["ms_panel"],
                            launches=st["n_panel"], work=st["bytes_panel"]))
     if st["ms_rank1"] > 0:
-        groups.append(dict(kernel="k_rank1_fused (reflector apply)", bound="hbm", ms=st["ms_rank1"],
-                           launches=st["n_rank1"], work=st["bytes_rank1"]))
+        # work = algorithmic HBM bytes of the launches AS IMPLEMENTED: a pass applies K reflectors to every trailing column
+        # it loads and stores once (16 B per element and pass = 16/K B per element and reflector)
+        groups.append(dict(kernel="k_rankk_fused (reflector apply, K reflectors per pass over the trailing columns)",
+                           bound="hbm", ms=st["ms_rank1"], launches=st["n_rank1"], work=st["bytes_rank1"]))
     rl_all = []
     for gr in groups:
         if gr["bound"] == "mfma":
@@ -397,6 +400,15 @@ def main():
         "roofline": ({k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
                                           "launches", "avg_launch_ms")} if dom else None),
         "roofline_all": rl_all,
+        **({"reflector_apply": {
+            # SURVEY 8(d)'s per-unit figure (16 B per element and reflector: one read + one write) against what the
+            # launches move: the ratio is the number of reflectors a pass applies per load/store of a column
+            "bytes_one_reflector_per_pass": 16.0 * sum((m - j) * (n - j - 1) for j in range(n)) * args.steps,
+            "bytes_as_implemented": st["bytes_rank1"],
+            "reflectors_per_pass": 16.0 * sum((m - j) * (n - j - 1) for j in range(n)) * args.steps / st["bytes_rank1"],
+            "equivalent_GBps_at_16B_per_element_and_reflector":
+                16.0 * sum((m - j) * (n - j - 1) for j in range(n)) * args.steps / st["ms_rank1"] / 1e6}}
+           if (not nb and st["bytes_rank1"] > 0) else {}),
         "traffic_note": "HBM bytes per WIDE launch (read + write) from rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE, separate "
                         "passes over the torch-free driver with the end-of-round kernels (tools/gpu_pmc3.sh, profiles/r02_pmc_traffic.json); "
                         "algorithmic C bytes per wide two-panel launch: 5.78 GB (NN: read + write) / 2.89 GB (TN: read) -> measured "
