@@ -223,6 +223,28 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
       }
     }
   };
+  // the bulk's column stores are non-temporal: a column is not read again before the next launch, and dirty lines left in
+  // the L2s are written back at the kernel boundary, on the chain of dependent launches (8192^2: 154 -> 148 ms;
+  // non-temporal LOADS of the columns: no gain)
+  typedef double dhqr_d2 __attribute__((ext_vector_type(2)));
+  auto store_nt = [&](double *dst, const double *src) {
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
+        if (row < m) {
+          const dhqr_d2 x = {src[2 * i], src[2 * i + 1]};
+          __builtin_nontemporal_store(x, reinterpret_cast<dhqr_d2 *>(dst + row));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t row = rtop + t + (int64_t)e * T;
+        if (row < m) __builtin_nontemporal_store(src[e], dst + row);
+      }
+    }
+  };
   auto apply = [&](double *y, const double *x) {  // one step on the column in y[]: src:208 partialdot, src:209 hotloop!
     double dot = 0.0;
 #pragma unroll
@@ -281,7 +303,7 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
       const bool more = cn < ncols;                    \
       load(A + (more ? cn : c) * lda, NXT, false);     \
       apply_old(CUR);                                  \
-      store(A + c * lda, CUR);                         \
+      store_nt(A + c * lda, CUR);                      \
       if (!more) break;                                \
       c = cn;                                          \
     }
