@@ -184,7 +184,7 @@ static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
   const int64_t nbulk = (kold == 0) ? 0 : std::max<int64_t>(0, ncols - c0 - K);
 #define DHQR_RK(T_, E_)                                                                                  \
   hipLaunchKernelGGL((k_rankk_fused<T_, E_, VEC, K>),                                                    \
-                     dim3((unsigned)(1 + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs * (1024 / T_) - 1))),        \
+                     dim3((unsigned)(1 + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs * (rankk_lead_slots(T_, E_, K) > 0 ? 1 : 1024 / T_) - 1))), \
                      dim3(T_), 0, c->stream, P, ldp, rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha)
   if (cov <= 256 * 2) DHQR_RK(256, 2);
   else if (cov <= 256 * 4) DHQR_RK(256, 4);

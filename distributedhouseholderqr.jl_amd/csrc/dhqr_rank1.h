@@ -165,6 +165,20 @@ __global__ __launch_bounds__(T) void k_rank1_fused(double *__restrict__ A, int64
 // kold = 0 with a grid of ONE workgroup builds the first K reflectors of a matrix / panel from scratch; kold = 1
 // continues from the one-reflector kernels of the tall-column phase.  Rows covered: [rtop, rtop + T*EPT), rtop = jlo
 // (rounded down to even for VEC = 2); every reflector is zero above its diagonal.
+// LDS slots for the reflectors the lead workgroup of k_rankk_fused builds (beside the K - 3 reflectors of the pass that
+// live in LDS): as many of the K - 1 as fit 144 KiB, for columns of at most 6144 rows -- the launches whose duration is
+// the lead's chain.  Such launches run ONE workgroup per CU (launch_rankk).  Measured at 8192^2 (ms): none 147.7,
+// <= 3072 rows 147.0, <= 4096 144.3, <= 6144 143.7.
+#ifndef DHQR_RK_LEAD_ROWS
+#define DHQR_RK_LEAD_ROWS 6144
+#endif
+constexpr int rankk_lead_slots(int T, int EPT, int K) {
+  const int KL = K > 3 ? K - 3 : 0;
+  if (T * EPT > DHQR_RK_LEAD_ROWS) return 0;
+  const int avail = (144 * 1024) / (T * EPT * 8) - KL;
+  return avail < 0 ? 0 : (avail < K - 1 ? avail : K - 1);
+}
+
 template <int T, int EPT, int VEC, int K>
 __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
                                                    int64_t c0, int64_t rtop, int kold,
@@ -175,7 +189,11 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
   __shared__ double red[2 * (T / 64) + 2];   // the lead's double-double sums + the pivot slot
   __shared__ double reda[2 * (T / 64)];      // block_sum_alt: two halves in alternation
   int par = 0;
-  __shared__ __attribute__((aligned(16))) double vl[KL > 0 ? KL * T * EPT : 2];
+  // ... and, where a column is short enough to leave room (<= 6144 rows), the reflectors the LEAD builds in this launch:
+  // it re-reads each of them for every later column of its K, on the chain that bounds the launch once the trailing
+  // matrix is small (such launches run one workgroup per CU: launch_rankk)
+  constexpr int NN = rankk_lead_slots(T, EPT, K);
+  __shared__ __attribute__((aligned(16))) double vl[(KL + NN) > 0 ? (KL + NN) * T * EPT : 2];
   constexpr int HSLOT = 2 * (T / 64);
   const int t = threadIdx.x;
   const int64_t mlast = m - VEC;
@@ -326,8 +344,12 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
     if (q > 0) load(col, a, false);
     apply_old(a);
     for (int p = 0; p < q; ++p) {  // the reflectors this workgroup built in this launch
-      load(vnew + (int64_t)p * vlen, an, true);
-      apply(a, an);
+      if (p < NN) {
+        apply_lds(a, KL + p);
+      } else {
+        load(vnew + (int64_t)p * vlen, an, true);
+        apply(a, an);
+      }
     }
     dhqr_dd acc = {0.0, 0.0};  // extended-precision column norm (src:129: dnrm2)
 #pragma unroll
@@ -350,6 +372,10 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
     }
     if (t == 0) alpha[c] = al;
     store(vnew + (int64_t)q * vlen, an);
+    if (q < NN) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) *lds_at(KL + q, e) = (row_of(e) < m) ? an[e] : 0.0;  // zero beyond the column (the columns are loaded unmasked); read back by the same thread only
+    }
     store(col, a);
     __syncthreads();  // red[HSLOT] is rewritten for the next column
   }
