@@ -150,6 +150,163 @@ __global__ __launch_bounds__(T) void k_rank1_fused(double *__restrict__ A, int64
   }
 }
 
+// LDS slots for the reflectors the lead workgroup of k_rankk_fused builds (beside the K - 3 reflectors of the pass that
+// live in LDS): as many of the K - 1 as fit 144 KiB, for columns of at most 6144 rows -- the launches whose duration is
+// the lead's chain.  Such launches run ONE workgroup per CU (launch_rankk).  Measured at 8192^2 (ms): none 147.7,
+// <= 3072 rows 147.0, <= 4096 144.3, <= 6144 143.7.
+#ifndef DHQR_RK_LEAD_ROWS
+#define DHQR_RK_LEAD_ROWS 6144
+#endif
+constexpr int rankk_lead_slots(int T, int EPT, int K) {
+  const int KL = K > 3 ? K - 3 : 0;
+  if (T * EPT > DHQR_RK_LEAD_ROWS) return 0;
+  const int avail = (144 * 1024) / (T * EPT * 8) - KL;
+  return avail < 0 ? 0 : (avail < K - 1 ? avail : K - 1);
+}
+
+// The LEAD workgroup of k_rankk_fused (see there).  NOT inlined: inside the kernel the register allocation is shaped by the
+// bulk (three column buffers + three reflectors), and with the norm's temporaries on top the 1024-thread instantiations
+// kept the reflectors in scratch and re-read them for every apply (26 us per lead column at 8192 rows).  Here the old
+// reflectors are not held at all: the first three stream from `vold` (L2) through two buffers, one load ahead of the
+// apply that uses them; reflectors 4, 5 and -- where they fit -- the ones built here sit in LDS (`vl`, passed in
+// together with the reduction scratch; generic pointers, so LDS is reached by flat instructions).
+template <int T, int EPT, int VEC, int K>
+__device__ __attribute__((noinline)) void rankk_lead(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
+                                                     int64_t c0, int64_t rtop, int kold, const double *vold,
+                                                     double *vnew, int64_t vlen, double *__restrict__ alpha,
+                                                     double *red, double *reda, double *vl) {
+  constexpr int KR = K < 3 ? K : 3;
+  constexpr int KL = K - KR;
+  constexpr int NN = rankk_lead_slots(T, EPT, K);
+  constexpr int HSLOT = 2 * (T / 64);
+  const int t = threadIdx.x;
+  const int64_t mlast = m - VEC;
+  int par = 0;
+  double a[EPT], w0[EPT], w1[EPT];
+
+  auto row_of = [&](int e) -> int64_t {
+    return (VEC == 2) ? rtop + 2 * ((int64_t)t + (int64_t)(e >> 1) * T) + (e & 1) : rtop + t + (int64_t)e * T;
+  };
+  auto load = [&](const double *src, double *dst, bool mask) {  // as in the kernel: reflectors masked, columns not
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
+        const bool ok = row < m;
+        const double2 x = *reinterpret_cast<const double2 *>(src + (ok ? row : mlast));
+        dst[2 * i] = (ok || !mask) ? x.x : 0.0;
+        dst[2 * i + 1] = (ok || !mask) ? x.y : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t row = rtop + t + (int64_t)e * T;
+        const bool ok = row < m;
+        const double x = src[ok ? row : mlast];
+        dst[e] = (ok || !mask) ? x : 0.0;
+      }
+    }
+  };
+  auto store = [&](double *dst, const double *src) {
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
+        if (row < m) *reinterpret_cast<double2 *>(dst + row) = make_double2(src[2 * i], src[2 * i + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t row = rtop + t + (int64_t)e * T;
+        if (row < m) dst[row] = src[e];
+      }
+    }
+  };
+  auto lds_at = [&](int q, int e) -> double * {
+    return (VEC == 2) ? vl + (size_t)q * T * EPT + 2 * ((size_t)t + (size_t)(e >> 1) * T) + (e & 1)
+                      : vl + (size_t)q * T * EPT + (size_t)t + (size_t)e * T;
+  };
+  auto apply = [&](const double *x) {  // src:208 partialdot, src:209 hotloop! on the column in a[]
+    double dot = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) dot = fma(a[e], x[e], dot);
+    const double s = block_sum_alt<T>(dot, reda, par);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) a[e] = fma(-x[e], s, a[e]);
+  };
+  auto apply_lds = [&](int q) {
+    double dot = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) dot = fma(a[e], *lds_at(q, e), dot);
+    const double s = block_sum_alt<T>(dot, reda, par);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) a[e] = fma(-*lds_at(q, e), s, a[e]);
+  };
+
+  const int nown = (int)((ncols - c0 < K) ? (ncols - c0) : K);
+  load(A + c0 * lda, a, false);
+#pragma unroll
+  for (int q = 0; q < KL; ++q)
+    if (KR + q < kold) {
+      load(vold + (int64_t)(KR + q) * vlen, w0, true);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) *lds_at(q, e) = w0[e];  // read back by the same thread only
+    }
+  const int kreg = kold < KR ? kold : KR;  // old reflectors that are not in LDS
+  for (int q = 0; q < nown; ++q) {
+    const int64_t c = c0 + q;
+    double *col = A + c * lda;
+    if (q > 0) load(col, a, false);
+    if (kreg > 0) load(vold, w0, true);
+    for (int p = 0; p < kreg; p += 2) {
+      if (p + 1 < kreg) load(vold + (int64_t)(p + 1) * vlen, w1, true);
+      apply(w0);
+      if (p + 1 < kreg) {
+        if (p + 2 < kreg) load(vold + (int64_t)(p + 2) * vlen, w0, true);
+        apply(w1);
+      }
+    }
+#pragma unroll
+    for (int ql = 0; ql < KL; ++ql)
+      if (KR + ql < kold) apply_lds(ql);
+    for (int p = 0; p < q; ++p) {  // the reflectors built in this launch
+      if (p < NN) {
+        apply_lds(KL + p);
+      } else {
+        load(vnew + (int64_t)p * vlen, w0, true);
+        apply(w0);
+      }
+    }
+    dhqr_dd acc = {0.0, 0.0};  // extended-precision column norm (src:129: dnrm2)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t row = row_of(e);
+      if (row == c) red[HSLOT] = a[e];
+      if (row >= c && row < m) dd_add_sq(acc, a[e]);
+    }
+    const double sq = dd_block_sum<T>(acc, red);  // barriers inside also publish red[HSLOT]
+    const double h = red[HSLOT];
+    const double sn = sqrt(sq);                        // src:129
+    const double al = sn * dhqr_alphafactor(h);        // src:130
+    const double f = 1.0 / sqrt(sn * (sn + fabs(h)));  // src:131
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t row = row_of(e);
+      if (row == c) a[e] = (h - al) * f;  // src:132-135
+      else if (row > c) a[e] *= f;
+      w0[e] = (row >= c && row < m) ? a[e] : 0.0;  // outgoing Hj (src:138-140), zero beyond the column
+    }
+    if (t == 0) alpha[c] = al;
+    store(vnew + (int64_t)q * vlen, w0);
+    if (q < NN) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) *lds_at(KL + q, e) = w0[e];  // read back by the same thread only
+    }
+    store(col, a);
+    __syncthreads();  // red[HSLOT] is rewritten for the next column
+  }
+}
+
 // K steps in ONE pass over the trailing columns.  The reflectors v_jlo .. v_jlo+kold-1 already exist (`vold`, one every
 // `vlen` doubles) and stay in registers for the whole launch.  A workgroup loads a column once, applies them one after the
 // other -- each with its own dot product over the column as updated so far, i.e. exactly the arithmetic of `kold`
@@ -165,20 +322,6 @@ __global__ __launch_bounds__(T) void k_rank1_fused(double *__restrict__ A, int64
 // kold = 0 with a grid of ONE workgroup builds the first K reflectors of a matrix / panel from scratch; kold = 1
 // continues from the one-reflector kernels of the tall-column phase.  Rows covered: [rtop, rtop + T*EPT), rtop = jlo
 // (rounded down to even for VEC = 2); every reflector is zero above its diagonal.
-// LDS slots for the reflectors the lead workgroup of k_rankk_fused builds (beside the K - 3 reflectors of the pass that
-// live in LDS): as many of the K - 1 as fit 144 KiB, for columns of at most 6144 rows -- the launches whose duration is
-// the lead's chain.  Such launches run ONE workgroup per CU (launch_rankk).  Measured at 8192^2 (ms): none 147.7,
-// <= 3072 rows 147.0, <= 4096 144.3, <= 6144 143.7.
-#ifndef DHQR_RK_LEAD_ROWS
-#define DHQR_RK_LEAD_ROWS 6144
-#endif
-constexpr int rankk_lead_slots(int T, int EPT, int K) {
-  const int KL = K > 3 ? K - 3 : 0;
-  if (T * EPT > DHQR_RK_LEAD_ROWS) return 0;
-  const int avail = (144 * 1024) / (T * EPT * 8) - KL;
-  return avail < 0 ? 0 : (avail < K - 1 ? avail : K - 1);
-}
-
 template <int T, int EPT, int VEC, int K>
 __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
                                                    int64_t c0, int64_t rtop, int kold,
@@ -334,51 +477,8 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
     return;
   }
 
-  // ---- lead: the next K columns and their reflectors (an[] is the scratch for the reflectors built here)
-  const int nown = (int)((ncols - c0 < K) ? (ncols - c0) : K);
-  load(A + c0 * lda, a, false);
-  load_old();
-  for (int q = 0; q < nown; ++q) {
-    const int64_t c = c0 + q;
-    double *col = A + c * lda;
-    if (q > 0) load(col, a, false);
-    apply_old(a);
-    for (int p = 0; p < q; ++p) {  // the reflectors this workgroup built in this launch
-      if (p < NN) {
-        apply_lds(a, KL + p);
-      } else {
-        load(vnew + (int64_t)p * vlen, an, true);
-        apply(a, an);
-      }
-    }
-    dhqr_dd acc = {0.0, 0.0};  // extended-precision column norm (src:129: dnrm2)
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const int64_t row = row_of(e);
-      if (row == c) red[HSLOT] = a[e];
-      if (row >= c && row < m) dd_add_sq(acc, a[e]);
-    }
-    const double sq = dd_block_sum<T>(acc, red);  // barriers inside also publish red[HSLOT]
-    const double h = red[HSLOT];
-    const double sn = sqrt(sq);                        // src:129
-    const double al = sn * dhqr_alphafactor(h);        // src:130
-    const double f = 1.0 / sqrt(sn * (sn + fabs(h)));  // src:131
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const int64_t row = row_of(e);
-      if (row == c) a[e] = (h - al) * f;  // src:132-135
-      else if (row > c) a[e] *= f;
-      an[e] = (row >= c) ? a[e] : 0.0;    // outgoing Hj (src:138-140)
-    }
-    if (t == 0) alpha[c] = al;
-    store(vnew + (int64_t)q * vlen, an);
-    if (q < NN) {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) *lds_at(KL + q, e) = (row_of(e) < m) ? an[e] : 0.0;  // zero beyond the column (the columns are loaded unmasked); read back by the same thread only
-    }
-    store(col, a);
-    __syncthreads();  // red[HSLOT] is rewritten for the next column
-  }
+  // ---- lead: the next K columns and their reflectors -- a function of its own (own register allocation)
+  rankk_lead<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
 }
 
 // Fused step j for columns taller than 1024*8 rows: same contract, the column is streamed twice

@@ -51,8 +51,9 @@ if __name__ == "__main__":
     cfgs = [(2048, 0), (2048, 128), (8192, 0), (8192, 128), (16384, 128)]
     if len(sys.argv) > 1:
         cfgs = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
-    for n, nb in cfgs:
+    for cfg in cfgs:  # n,nb or n,nb,m
+        n, nb = cfg[0], cfg[1]
         try:
-            run(n, nb)
+            run(n, nb, m=cfg[2] if len(cfg) > 2 else None)
         except Exception as e:  # keep going: this is a diagnostic
             print("FAILED", n, nb, repr(e), flush=True)
