@@ -171,10 +171,10 @@ constexpr int rankk_lead_slots(int T, int EPT, int K) {
 // apply that uses them; reflectors 4, 5 and -- where they fit -- the ones built here sit in LDS (`vl`, passed in
 // together with the reduction scratch; generic pointers, so LDS is reached by flat instructions).
 template <int T, int EPT, int VEC, int K>
-__device__ __attribute__((noinline)) void rankk_lead(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
-                                                     int64_t c0, int64_t rtop, int kold, const double *vold,
-                                                     double *vnew, int64_t vlen, double *__restrict__ alpha,
-                                                     double *red, double *reda, double *vl) {
+__device__ __forceinline__ void rankk_lead_body(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
+                                                int64_t c0, int64_t rtop, int kold, const double *vold,
+                                                double *vnew, int64_t vlen, double *__restrict__ alpha,
+                                                double *red, double *reda, double *vl) {
   constexpr int KR = K < 3 ? K : 3;
   constexpr int KL = K - KR;
   constexpr int NN = rankk_lead_slots(T, EPT, K);
@@ -305,6 +305,16 @@ __device__ __attribute__((noinline)) void rankk_lead(double *__restrict__ A, int
     store(col, a);
     __syncthreads();  // red[HSLOT] is rewritten for the next column
   }
+}
+
+// (workgroups of at most 512 threads have 256 registers per thread and no such problem: they inline the body and save the
+// call's register saves -- 1024^2: 5.75 -> 5.4 ms)
+template <int T, int EPT, int VEC, int K>
+__device__ __attribute__((noinline)) void rankk_lead(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
+                                                     int64_t c0, int64_t rtop, int kold, const double *vold,
+                                                     double *vnew, int64_t vlen, double *__restrict__ alpha,
+                                                     double *red, double *reda, double *vl) {
+  rankk_lead_body<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
 }
 
 // K steps in ONE pass over the trailing columns.  The reflectors v_jlo .. v_jlo+kold-1 already exist (`vold`, one every
@@ -478,7 +488,8 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
   }
 
   // ---- lead: the next K columns and their reflectors -- a function of its own (own register allocation)
-  rankk_lead<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
+  if constexpr (T > 512) rankk_lead<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
+  else rankk_lead_body<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
 }
 
 // Fused step j for columns taller than 1024*8 rows: same contract, the column is streamed twice
