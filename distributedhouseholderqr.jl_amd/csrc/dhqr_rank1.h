@@ -318,17 +318,18 @@ __device__ __attribute__((noinline)) void rankk_lead(double *__restrict__ A, int
 }
 
 // K steps in ONE pass over the trailing columns.  The reflectors v_jlo .. v_jlo+kold-1 already exist (`vold`, one every
-// `vlen` doubles) and stay in registers for the whole launch.  A workgroup loads a column once, applies them one after the
+// `vlen` doubles) and stay on the CU for the whole launch (three in registers, the others in LDS).  A workgroup loads a
+// column once, applies them one after the
 // other -- each with its own dot product over the column as updated so far, i.e. exactly the arithmetic of `kold`
 // consecutive k_rank1_fused launches (src:208-209 per step) -- and stores it once: 16/K bytes of HBM traffic per
 // (element, reflector) instead of 16.
-//   * blockIdx 0, the LEAD workgroup, owns the next K columns c0 .. c0+K-1: column by column it also applies the
-//     reflectors it has just built (re-read from `vnew`: each thread reads back only elements it wrote itself) and builds
-//     the column's own reflector (src:129-140), so the launch hands v_c0 .. v_c0+K-1 to the next one and no
-//     single-workgroup launch sits between two passes.
+//   * blockIdx 0, the LEAD workgroup (rankk_lead_body above), owns the next K columns c0 .. c0+K-1: column by column
+//     it also applies the reflectors it has just built (from LDS where they fit, otherwise re-read from `vnew`: each
+//     thread reads back only elements it wrote itself) and builds the column's own reflector (src:129-140), so the
+//     launch hands v_c0 .. v_c0+K-1 to the next one and no single-workgroup launch sits between two passes.
 //   * blockIdx b >= 1, the BULK workgroups, are persistent: b owns columns c0+K + (b-1) + i (gridDim-1), and requests
-//     the next column's loads before it works on the current one (one workgroup per CU holds a column and the K
-//     reflectors in registers, so nothing else hides the load latency while it computes).
+//     the next column's loads before it works on the current one (one workgroup per CU holds three column buffers and
+//     three reflectors in registers, so nothing else hides the load latency while it computes).
 // kold = 0 with a grid of ONE workgroup builds the first K reflectors of a matrix / panel from scratch; kold = 1
 // continues from the one-reflector kernels of the tall-column phase.  Rows covered: [rtop, rtop + T*EPT), rtop = jlo
 // (rounded down to even for VEC = 2); every reflector is zero above its diagonal.
