@@ -348,15 +348,11 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
   // matrix is small (such launches run one workgroup per CU: launch_rankk)
   constexpr int NN = rankk_lead_slots(T, EPT, K);
   __shared__ __attribute__((aligned(16))) double vl[(KL + NN) > 0 ? (KL + NN) * T * EPT : 2];
-  constexpr int HSLOT = 2 * (T / 64);
   const int t = threadIdx.x;
   const int64_t mlast = m - VEC;
   double a[EPT], an[EPT], v[KR][EPT];
   double ax[EPT];  // third column buffer of the bulk rotation
 
-  auto row_of = [&](int e) -> int64_t {
-    return (VEC == 2) ? rtop + 2 * ((int64_t)t + (int64_t)(e >> 1) * T) + (e & 1) : rtop + t + (int64_t)e * T;
-  };
   // rows beyond m read a clamped address; a REFLECTOR is zeroed there (mask), a COLUMN is left as loaded: times the
   // reflector's zero it adds nothing to a dot product, its update is a - 0 s, and it is never stored -- so a column's
   // registers have no use between the load and the first dot product, and the bulk loop's early loads stay in flight
@@ -377,21 +373,6 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
         const bool ok = row < m;
         const double x = src[ok ? row : mlast];
         dst[e] = (ok || !mask) ? x : 0.0;
-      }
-    }
-  };
-  auto store = [&](double *dst, const double *src) {
-    if constexpr (VEC == 2) {
-#pragma unroll
-      for (int i = 0; i < EPT / 2; ++i) {
-        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
-        if (row < m) *reinterpret_cast<double2 *>(dst + row) = make_double2(src[2 * i], src[2 * i + 1]);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const int64_t row = rtop + t + (int64_t)e * T;
-        if (row < m) dst[row] = src[e];
       }
     }
   };
