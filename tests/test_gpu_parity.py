@@ -80,6 +80,26 @@ def test_unblocked_reflectors_per_pass(pkg, orc, m, n, K, monkeypatch):
             api._contexts[0] = old
 
 
+@pytest.mark.parametrize("m,n", [(2000, 512), (8190, 384), (9000, 256)])
+def test_blocked_with_panels_through_the_column_kernels(pkg, orc, m, n, monkeypatch):
+    """DHQR_PANEL=1: every 128-column panel is factored by the unblocked column kernels (k_rankk_fused passes for panels of
+    at most 8192 rows, the one-reflector kernels above) and packed into the block reflector -- same factorisation"""
+    monkeypatch.setenv("DHQR_PANEL", "1")  # read by dhqr_create
+    api = pkg.api
+    old = api._contexts.pop(0, None)
+    try:
+        H, A0 = _factor_dev(pkg, m, n, 6, 128)
+        Ho, ao = orc.householder(orc.rand_matrix(m, n, 6))
+        scale = np.abs(Ho).max()
+        assert np.abs(H.A.cpu().numpy() - Ho).max() <= 1e-11 * scale
+        assert np.abs(H.α.cpu().numpy() - ao).max() <= 1e-11 * scale
+        assert pkg.residual(H, A0) < 1e-12
+    finally:
+        api._contexts.pop(0, None)
+        if old is not None:
+            api._contexts[0] = old
+
+
 @pytest.mark.parametrize("m,n", [(128, 128), (129, 129), (300, 128), (300, 200), (1000, 999), (2050, 1030),
                                  (1153, 600), (9000, 300),
                                  # n % 128 == 0 with >= 4 panels: the two-panel (K = 256) wide-update driver,
