@@ -105,6 +105,7 @@ SIGNATURES = {
     "dhqr_comm_destroy": (_i32, [_p]),
     "dhqr_comm_info": (_i32, [_p, _pi32, _pi32, _pi32, _pi64]),
     "dhqr_comm_get_bcast_tuning": (_i32, [_p, _pi32, _pd, _pd]),
+    "dhqr_comm_rccl_nranks": (_i32, [_p, _pi32, _pi32]),
     "dhqr_cs_local_cols": (_i64, [_i64, _i32, _i32]),
     "dhqr_cs_contiguous_range": (None, [_i64, _i32, _i32, _pi64, _pi64]),
     "dhqr_cs_fill_uniform_f64": (_i32, [_p, _p, _i64, _i64, _i64, _u64]),

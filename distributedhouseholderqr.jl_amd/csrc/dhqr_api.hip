@@ -2027,6 +2027,8 @@ static int32_t comm_new(dhqr_comm **out, dhqr_ctx *c, int kind, int nranks, int 
   cm->kind = kind;
   cm->nranks = nranks;
   cm->rank = rank;
+  if (const char *e = getenv("DHQR_BCAST_SAG_MIN"))  // doubles; broadcasts below it stay single ncclBroadcast calls
+    if (atoll(e) > 0) cm->bcast_sag_min = atoll(e);
   *out = cm;
   return DHQR_OK;
 }
@@ -2052,34 +2054,49 @@ int32_t dhqr_comm_create_rank(dhqr_comm **out, dhqr_ctx *c, int32_t nranks, int3
   CHECK(rccl_load());
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
-  ncclComm_t nc = nullptr;
-  RCCLCHECK(g_rccl.CommInitRank(&nc, nranks, id, rank));
-  CHECK(comm_new(out, c, COMM_RCCL, nranks, rank));
-  (*out)->nccl = nc;
-  // second channel for the look-ahead lane of the row-split driver: rank 0 draws another unique id and ships it over
-  // the first communicator (no change for the host layer)
-  if (lane_channel_wanted()) {
-    ncclUniqueId id2;
-    memset(&id2, 0, sizeof(id2));
-    if (rank == 0) RCCLCHECK(g_rccl.GetUniqueId(&id2));
-    void *dbuf = nullptr;
-    HIPCHECK(hipMalloc(&dbuf, sizeof(id2)));
-    auto ship = [&]() -> int32_t {
+  // everything after the first ncclCommInitRank runs inside `build`: on any failure the communicators created so far
+  // are destroyed and *out stays null (a half-built handle never reaches the caller)
+  ncclComm_t nc = nullptr, nc2 = nullptr;
+  dhqr_comm *cm = nullptr;
+  void *dbuf = nullptr;
+  auto build = [&]() -> int32_t {
+    RCCLCHECK(g_rccl.CommInitRank(&nc, nranks, id, rank));
+    if (g_rccl.CommCount) {
+      int cnt = 0;
+      RCCLCHECK(g_rccl.CommCount(nc, &cnt));
+      if (cnt != nranks) return set_err(DHQR_ECOMM, "RCCL communicator has %d ranks, %d requested", cnt, nranks);
+    }
+    CHECK(comm_new(&cm, c, COMM_RCCL, nranks, rank));
+    cm->nccl = nc;
+    nc = nullptr;  // owned by cm from here
+    // second channel for the look-ahead lane of the row-split driver: rank 0 draws another unique id and ships it over
+    // the first communicator (no change for the host layer)
+    if (lane_channel_wanted()) {
+      ncclUniqueId id2;
+      memset(&id2, 0, sizeof(id2));
+      if (rank == 0) RCCLCHECK(g_rccl.GetUniqueId(&id2));
+      HIPCHECK(hipMalloc(&dbuf, sizeof(id2)));
       HIPCHECK(hipMemcpyAsync(dbuf, &id2, sizeof(id2), hipMemcpyHostToDevice, c->stream));
-      RCCLCHECK(g_rccl.Broadcast(dbuf, dbuf, sizeof(id2), ncclChar, 0, nc, c->stream));
+      RCCLCHECK(g_rccl.Broadcast(dbuf, dbuf, sizeof(id2), ncclChar, 0, cm->nccl, c->stream));
       HIPCHECK(hipMemcpyAsync(&id2, dbuf, sizeof(id2), hipMemcpyDeviceToHost, c->stream));
       HIPCHECK(hipStreamSynchronize(c->stream));
-      return DHQR_OK;
-    };
-    const int32_t rc = ship();
-    (void)hipFree(dbuf);
-    CHECK(rc);
-    ncclComm_t nc2 = nullptr;
-    RCCLCHECK(g_rccl.CommInitRank(&nc2, nranks, id2, rank));
-    CHECK(comm_new(&(*out)->lane, c, COMM_RCCL, nranks, rank));
-    (*out)->lane->nccl = nc2;
+      RCCLCHECK(g_rccl.CommInitRank(&nc2, nranks, id2, rank));
+      CHECK(comm_new(&cm->lane, c, COMM_RCCL, nranks, rank));
+      cm->lane->nccl = nc2;
+      nc2 = nullptr;
+    }
+    return comm_tune_bcast(cm, c->stream);  // ring broadcast vs scatter + all-gather, measured on this node
+  };
+  const int32_t rc = build();
+  if (dbuf) (void)hipFree(dbuf);
+  if (rc != DHQR_OK) {
+    if (nc) (void)g_rccl.CommDestroy(nc);
+    if (nc2) (void)g_rccl.CommDestroy(nc2);
+    if (cm) (void)comm_free(cm);  // destroys cm->nccl and the lane
+    return rc;
   }
-  return comm_tune_bcast(*out, c->stream);  // ring broadcast vs scatter + all-gather, measured on this node
+  *out = cm;
+  return DHQR_OK;
 }
 
 int32_t dhqr_comm_create_callbacks(dhqr_comm **out, dhqr_ctx *c, int32_t nranks, int32_t rank, dhqr_bcast_fn bcast,
@@ -2106,6 +2123,21 @@ int32_t dhqr_comm_info(dhqr_comm *cm, int32_t *kind, int32_t *nranks, int32_t *r
   if (rank) *rank = cm->rank;
   if (bytes_bcast) *bytes_bcast = cm->bytes_bcast;
   return DHQR_OK;
+}
+
+int32_t dhqr_comm_rccl_nranks(dhqr_comm *cm, int32_t *main_channel, int32_t *lane_channel) {
+  if (!cm) return set_err(DHQR_EINVAL, "null communicator");
+  auto count = [&](dhqr_comm *x, int32_t *o) -> int32_t {
+    if (!o) return DHQR_OK;
+    *o = 0;  // 0: not an RCCL channel (or no ncclCommCount in this RCCL build)
+    if (!x || x->kind != COMM_RCCL || !x->nccl || !g_rccl.CommCount) return DHQR_OK;
+    int n = 0;
+    RCCLCHECK(g_rccl.CommCount(x->nccl, &n));
+    *o = n;
+    return DHQR_OK;
+  };
+  CHECK(count(cm, main_channel));
+  return count(cm->lane, lane_channel);
 }
 
 int32_t dhqr_comm_get_bcast_tuning(dhqr_comm *cm, int32_t *algo, double *ms_ring, double *ms_sag) {

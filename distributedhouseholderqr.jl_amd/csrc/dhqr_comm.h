@@ -47,6 +47,7 @@ struct RcclApi {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;  // optional: the bench line reports the communicator's own size
   bool has_sag() const { return AllGather && Send && Recv && GroupStart && GroupEnd; }
 };
 static RcclApi g_rccl;
@@ -59,10 +60,11 @@ static int32_t rccl_load() {
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
   if (g_rccl_state.load() == 1) return DHQR_OK;
-  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // DHQR_RCCL_LIB: path of the RCCL build to use (a site's own librccl; the CPU tests point it at their stand-in)
+  const char *names[] = {getenv("DHQR_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void *h = nullptr;
   for (const char *nm : names)
-    if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (nm && *nm && (h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
   if (!h) {
     g_rccl_state.store(-1);
     return set_err(DHQR_ECOMM, "dlopen(librccl.so) failed: %s", dlerror());
@@ -89,6 +91,7 @@ static int32_t rccl_load() {
   g_rccl.Recv = (decltype(g_rccl.Recv))dlsym(h, "ncclRecv");
   g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(h, "ncclGroupStart");
   g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(h, "ncclGroupEnd");
+  g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
   g_rccl.handle = h;
   g_rccl_state.store(1, std::memory_order_release);
   return DHQR_OK;

@@ -279,6 +279,9 @@ int32_t dhqr_comm_info(dhqr_comm *comm, int32_t *kind, int32_t *nranks, int32_t 
  * communicator creation measured for a 16 MiB broadcast with each (ms; 0 when no trial ran: other transports, or
  * DHQR_BCAST=ring|sag set).  dhqr_mg_get_bcast_tuning: the same for rank 0 of a single-process handle. */
 int32_t dhqr_comm_get_bcast_tuning(dhqr_comm *comm, int32_t *algo, double *ms_ring, double *ms_scatter_allgather);
+/* Rank count RCCL itself reports (ncclCommCount) for the communicator's main channel and for the row-split lane's second
+ * channel; 0 = that channel is not an RCCL communicator (other transport, single rank, DHQR_LANE_CHANNEL=0). */
+int32_t dhqr_comm_rccl_nranks(dhqr_comm *comm, int32_t *main_channel, int32_t *lane_channel);
 
 /* ------------------------------------------------------------------ multi-GPU: 1-D column split (SPMD, collective)
  * householder!(A::DArray, alpha) (src:115-120).  Layout: BLOCK-CYCLIC columns, block = DHQR_CS_BLOCK (a pair of

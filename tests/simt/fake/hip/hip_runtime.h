@@ -393,9 +393,16 @@ struct hipDeviceProp_t { char gcnArchName[256]; };
 
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emulated HIP error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-inline hipError_t hipSetDevice(int) { return hipSuccess; }
-inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+// SIMT_DEVICES=N: N emulated "devices" (one address space); lets dhqr_mg_* put its ranks on distinct devices, which the
+// RCCL transport requires (tests/simt/fake/rccl/fake_rccl.cpp stands in for librccl there)
+inline hipError_t hipGetDeviceCount(int *n) {
+  const char *e = std::getenv("SIMT_DEVICES");
+  *n = (e && std::atoi(e) > 0) ? std::atoi(e) : 1;
+  return hipSuccess;
+}
+inline thread_local int simt_cur_device = 0;
+inline hipError_t hipSetDevice(int d) { simt_cur_device = d; return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = simt_cur_device; return hipSuccess; }
 inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
 inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
