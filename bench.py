@@ -15,13 +15,25 @@ value = F(m,n) / t with F = 2 m n^2 - 2/3 n^3 (the reference's flop count, SURVE
 The JSON line also carries ||A-QR||_F/||A||_F of the last factorisation, `roofline` for the
 dominant kernel group (hipEvent-timed on the launch stream inside the timed region) and, at
 N = 1, `cpu_baseline` = the oracle's restatement of the reference algorithm on the host cores.
+
+N > 1 runs under a SUPERVISOR (this file, no GPU work of its own): every rank's bench.py starts the real run as a child
+process and watches its progress lines.  A child that makes no progress for DHQR_BENCH_STALL_S seconds (a collective that
+never completes) or fails is killed on every rank and the run is repeated with a more conservative communication set-up:
+attempt 0 library defaults -> attempt 1 DHQR_LANE_CHANNEL=0 + DHQR_BCAST=ring (one RCCL communicator, plain ncclBroadcast) ->
+attempt 2 one process drives all GPUs with peer copies instead of RCCL (DHQR_TRANSPORT=local).  The JSON line says which
+attempt produced it (`attempt`, `attempt_env`, `attempts_failed`).  Nothing is measured by the supervisor.
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
+import signal
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -33,6 +45,199 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 PEAK_FP64_MFMA_TFLOPS = 78.6   # AMD MI355X datasheet FP64 matrix (== vector) peak; the local
                                # MI355X_MICROARCH.md guide lists no FP64 number
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+_T0 = time.time()
+
+
+def progress(label):
+    """one line per phase on stderr: what the supervisor of a multi-GPU run watches (a run that stops printing is hung)"""
+    print(f"[bench progress] +{time.time() - _T0:.1f}s rank {os.environ.get('RANK', '0')}: {label}", file=sys.stderr, flush=True)
+
+
+class GpuTelemetry(threading.Thread):
+    """Power and shader clock of ONE GPU sampled from the amdgpu hwmon files while the timed region runs (this process's
+    own measurement; no literal numbers).  Absent files -> {"error": ...}."""
+
+    def __init__(self, index=0, period_s=0.05):
+        super().__init__(daemon=True)
+        self.period, self.stop_flag, self.w, self.mhz, self.src = period_s, threading.Event(), [], [], None
+        cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
+                    continue
+            except OSError:
+                continue
+            hw = sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*")))
+            if hw:
+                cards.append(hw[0])
+        if index < len(cards):
+            hw = cards[index]
+            self.fp = next((f for f in (os.path.join(hw, "power1_average"), os.path.join(hw, "power1_input")) if os.path.exists(f)), None)
+            self.ff = os.path.join(hw, "freq1_input") if os.path.exists(os.path.join(hw, "freq1_input")) else None
+            self.src = hw
+        else:
+            self.fp = self.ff = None
+
+    def run(self):
+        while not self.stop_flag.is_set():
+            try:
+                if self.fp:
+                    self.w.append(int(open(self.fp).read()) / 1e6)
+                if self.ff:
+                    self.mhz.append(int(open(self.ff).read()) / 1e6)
+            except (OSError, ValueError):
+                pass
+            self.stop_flag.wait(self.period)
+
+    def result(self):
+        self.stop_flag.set()
+        if self.is_alive():
+            self.join(timeout=2)
+        if not self.w and not self.mhz:
+            return {"error": "no amdgpu hwmon power1_average / power1_input / freq1_input readable under /sys/class/drm"}
+        out = {"source": self.src, "samples": max(len(self.w), len(self.mhz)), "period_s": self.period,
+               "note": "sampled by this process during the timed region (whole factorisation steps, all kernels)"}
+        if self.w:
+            out.update(watts_avg=sum(self.w) / len(self.w), watts_max=max(self.w))
+        if self.mhz:
+            out.update(sclk_mhz_avg=sum(self.mhz) / len(self.mhz), sclk_mhz_min=min(self.mhz))
+        return out
+
+
+def git_blob_hash(path):
+    """git's blob id of a file (sha1 of "blob <len>\0" + content): ties committed counter data to the kernel source"""
+    try:
+        data = open(path, "rb").read()
+    except OSError:
+        return None
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Supervisor of the multi-GPU runs (see the module docstring).  No GPU work, no torch.distributed process group of its
+# own: the ranks agree on the fate of an attempt through a key-value store on MASTER_PORT (torchrun's rendezvous port
+# serves the launcher's own store on the agent, the per-rank MASTER_PORT is free for the job).
+ATTEMPTS = [
+    ("library defaults", {}),
+    ("one RCCL communicator, plain ncclBroadcast", {"DHQR_LANE_CHANNEL": "0", "DHQR_BCAST": "ring"}),
+    ("one process drives every GPU, peer copies instead of RCCL", {"DHQR_TRANSPORT": "local"}),
+]
+
+
+def _kill_tree(proc):
+    """end exactly the child we started (it is its own process-group leader) and whatever it spawned"""
+    try:
+        os.killpg(proc.pid, signal.SIGKILL)
+    except (ProcessLookupError, PermissionError):
+        pass
+    try:
+        proc.wait(timeout=30)
+    except Exception:
+        pass
+
+
+def supervise(argv):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    spmd = world > 1
+    stall_s = float(os.environ.get("DHQR_BENCH_STALL_S", "120"))
+    start_s = float(os.environ.get("DHQR_BENCH_START_S", "420"))   # first import of torch on a fresh box: minutes
+    total_s = float(os.environ.get("DHQR_BENCH_ATTEMPT_S", "700"))
+    worker = os.environ.get("DHQR_BENCH_WORKER")  # tests: a stand-in worker script
+    base_port = int(os.environ.get("MASTER_PORT", "29500"))
+    store = None
+    if spmd:
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        # torchrun's static rendezvous serves the agent's store on MASTER_PORT and tells the workers to join it as clients
+        # (TORCHELASTIC_USE_AGENT_STORE); launched any other way, rank 0 hosts the store
+        agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+        store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), base_port, None if agent_store else world,
+                         rank == 0 and not agent_store, timeout=timedelta(seconds=start_s))
+    failed = []
+    for k, (what, extra) in enumerate(ATTEMPTS):
+        single_process = "DHQR_TRANSPORT" in extra
+        env = dict(os.environ, **extra)
+        env["DHQR_BENCH_ATTEMPT"] = json.dumps({"attempt": k, "what": what, "env": extra, "failed": failed})
+        proc = None
+        if spmd and single_process:
+            # last resort: rank 0 alone starts ONE worker that drives all GPUs with its rank threads; the other ranks idle
+            for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID"):
+                env.pop(v, None)
+        elif spmd:
+            env["MASTER_PORT"] = str(base_port + 1 + k)  # the children's own rendezvous: a fresh store per attempt,
+            env["TORCHELASTIC_USE_AGENT_STORE"] = "False"  # hosted by the child of rank 0
+        if not (spmd and single_process and rank != 0):
+            cmd = ([sys.executable, worker] if worker else [sys.executable, os.path.abspath(__file__), "--worker"]) + argv
+            proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        state = {"last": time.time(), "seen": False, "out": []}
+
+        def pump(stream, is_out):
+            for line in stream:
+                state["last"] = time.time()
+                if is_out:
+                    state["out"].append(line)
+                else:
+                    if line.startswith("[bench progress]"):
+                        state["seen"] = True
+                    sys.stderr.write(line)
+                    sys.stderr.flush()
+
+        threads = []
+        if proc is not None:
+            threads = [threading.Thread(target=pump, args=(proc.stdout, True), daemon=True),
+                       threading.Thread(target=pump, args=(proc.stderr, False), daemon=True)]
+            [t.start() for t in threads]
+        t_begin = time.time()
+        verdict = "ok" if proc is None else None
+        abort_key = f"dhqr_bench/a{k}_abort"
+        while verdict is None:
+            rc = proc.poll()
+            now = time.time()
+            if rc is not None:
+                verdict = "ok" if rc == 0 else f"exit code {rc}"
+            elif now - state["last"] > (stall_s if state["seen"] else start_s):
+                verdict = f"no progress for {now - state['last']:.0f} s"
+            elif now - t_begin > total_s:
+                verdict = f"attempt longer than {total_s:.0f} s"
+            elif store is not None and store.check([abort_key]):
+                verdict = "a peer rank gave up"
+            else:
+                time.sleep(0.25)
+        if proc is not None and verdict != "ok":
+            print(f"[bench supervisor] rank {rank}: attempt {k} ({what}): {verdict}; ending the worker", file=sys.stderr, flush=True)
+            _kill_tree(proc)
+        [t.join(timeout=5) for t in threads]
+        all_ok = verdict == "ok"
+        if store is not None:
+            if not all_ok:
+                store.set(abort_key, "1")
+            store.set(f"dhqr_bench/a{k}_r{rank}", verdict)
+            try:
+                verdicts = [store.get(f"dhqr_bench/a{k}_r{r}").decode() for r in range(world)]  # blocks until every rank has reported
+            except Exception as e:
+                verdicts = [f"rank verdicts unavailable: {e!r}"]
+            all_ok = all(v == "ok" for v in verdicts)
+            if not all_ok:
+                verdict = "; ".join(f"rank {r}: {v}" for r, v in enumerate(verdicts) if v != "ok")
+        if all_ok:
+            if rank == 0:
+                lines = [ln for ln in state["out"] if ln.startswith("{")]
+                if not lines:
+                    verdict = "the worker printed no result line"
+                    all_ok = False
+                else:
+                    sys.stdout.write(lines[-1])
+                    sys.stdout.flush()
+            if all_ok:
+                return 0
+        failed.append({"attempt": k, "what": what, "env": extra, "why": verdict})
+        if rank == 0:
+            print(f"[bench supervisor] attempt {k} ({what}) failed: {verdict}", file=sys.stderr, flush=True)
+    if rank == 0:
+        print(json.dumps({"error": "every attempt failed", "attempts_failed": failed}), file=sys.stderr, flush=True)
+    return 3
 
 
 def flops_qr(m, n):
@@ -112,14 +317,20 @@ def cpu_baseline_distributed(procs=2, orders=(512, 2048, 4096), timeout_s=120):
         return {"error": repr(e)[:200]}
 
 
-def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd):
+def attempt_fields(attempt):
+    if not attempt:
+        return {}
+    return {"attempt": attempt["attempt"], "attempt_what": attempt["what"], "attempt_env": attempt["env"], "attempts_failed": attempt["failed"]}
+
+
+def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd, attempt=None):
     """BASELINE configs[4]: 262144 x 4096 Float64, rows split over the ranks (dhqr_rs_* / dhqr_mg_rs_*)."""
     m = args.m or 262144
     n = args.n or 4096
     mg = q = None
     if spmd:
         q = pkg.RowSplitQR(m, n, comm=pkg.Communicator.from_torch(pkg.get_context(local_rank)))
-        ctxs = [pkg.get_context(local_rank)]
+        progress("RCCL communicators up (row split)")
 
         def step():
             q.fill(0)
@@ -127,6 +338,7 @@ def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd):
     else:
         devices = list(range(world)) if (world > 1 or not args.logical_ranks) else [0] * args.logical_ranks
         mg = pkg.MultiGpuQR(devices=devices)
+        progress(f"multi-GPU handle up, transport {mg.transport}")
         mg.rs_alloc(m, n)
 
         def step():
@@ -140,8 +352,10 @@ def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd):
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        barrier()
+        progress(f"warm-up step {i + 1}/{args.warmup}")
     barrier()
     if mg is not None:
         mg.reset_stats()
@@ -151,12 +365,13 @@ def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    progress(f"{args.steps} timed steps done")
     st = None
     if mg is not None:
         st = mg.stats(0)
         mg.set_profiling(False)
     if spmd:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)  # host tensor: the control plane is gloo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     resid = None
@@ -173,6 +388,8 @@ def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd):
                    "nb": 128, "parallelism": f"rows split x{nranks} (128-row aligned slabs), all-reduce of Gram matrices and V'C "
                                              f"partial dots" + (f", transport {mg.transport}" if mg is not None else ", RCCL")},
         "residual": resid,
+        **attempt_fields(attempt),
+        **({"rccl_nranks": (q.comm.rccl_nranks() if spmd else mg.rccl_nranks())} if nranks > 1 else {}),
         "roofline": {"bound": "mfma", "achieved": value / 1e3 / max(world, 1), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": value / 1e3 / max(world, 1) / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
                      "kernel": "whole row-split factorisation per GPU (not a single kernel)"},
@@ -194,25 +411,28 @@ def emit(out, rank=0):
         print(json.dumps(out), flush=True)
 
 
-def pmc_traffic(kernel, m, n, nb, launches, work):
-    """HBM bytes per launch of a roofline group from the committed counter runs (profiles/r02_pmc_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/pmc_driver, gfx950 x2 FETCH correction,
-    calibrated on a streaming kernel).  Counters cannot be read from inside this process, so the figure is the one
-    measured for the SAME kernel on the SAME workload; None when no matching measurement is committed."""
+def pmc_traffic(symbol, m, n, nb, launches, work):
+    """(HBM bytes per launch, reason-if-None) of a roofline kernel from the committed counter run
+    profiles/pmc_traffic_current.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/pmc_driver,
+    gfx950 x2 FETCH correction, calibrated on a streaming kernel).  Counters cannot be read from inside this process, so the
+    figure is the one measured for the SAME kernel symbol on the SAME workload -- and only while the kernel's source files
+    still have the git blob ids the counter run was stamped with."""
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-    except Exception:
-        return None
-    if nb and (m, n) == (32768, 32768):
-        key = ("k_gemm_nn_sub<2,256>" if kernel.startswith("k_gemm_nn_sub") else
-               ("k_gemm_tn2<2>" if kernel.startswith("k_gemm_tn") else None))
-        e = pm.get("blocked32768_summary", {}).get(key) if key else None
-        return e["bytes_per_launch"] if e else None
-    if not nb and kernel.startswith("k_rankk"):
-        # measured on the same kernel and workload (8192^2): HBM bytes / the algorithmic bytes of the launches as implemented
-        e = pm.get("unblocked8192_k_rankk")
-        return e["ratio"] * work / max(1, launches) if e else None
-    return None
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")))
+    except Exception as e:
+        return None, f"profiles/pmc_traffic_current.json unreadable: {e!r}"
+    workload = (f"blocked {m}x{n} nb=128" if nb else f"unblocked {m}x{n}")
+    for e in pm.get("entries", []):
+        if e["kernel_symbol"] != symbol or not e["workload"].startswith(workload):
+            continue
+        for src in e["sources"]:
+            have, want = git_blob_hash(os.path.join(ROOT, src)), pm.get("source_hashes", {}).get(src)
+            if have != want:
+                return None, f"committed counters were taken with {src} at blob {str(want)[:12]}, this tree has {str(have)[:12]}: re-run tools/gpu_pmc_traffic.sh"
+        if "bytes_per_launch" in e:
+            return e["bytes_per_launch"], None
+        return e["ratio_to_algorithmic"] * work / max(1, launches), None  # measured bytes / algorithmic bytes of the same launches
+    return None, f"no counter run committed for {symbol} on {workload}"
 
 
 def roofline_groups(st, steps, m=0, n=0, nb=0):
@@ -221,27 +441,28 @@ def roofline_groups(st, steps, m=0, n=0, nb=0):
     if st["ms_gemm_avw"] > 0:
         # one timed group = ONE wide k_gemm_nn_sub launch on the caller's stream (rocprofv3 lists the narrow
         # look-ahead launches of the same template on the second stream as well: profiles/*_by_stream.csv)
-        groups.append(dict(kernel="k_gemm_nn_sub (A -= V*W, FP64 MFMA)", bound="mfma", ms=st["ms_gemm_avw"],
+        groups.append(dict(kernel="k_gemm_nn_sub (A -= V*W, FP64 MFMA)", symbol="k_gemm_nn_sub", bound="mfma", ms=st["ms_gemm_avw"],
                            launches=st["n_gemm_avw"], work=st["flops_gemm_avw"]))
         # one timed group = the TN launches of one wide update (two per two-panel update) + their split-K reductions
-        groups.append(dict(kernel="k_gemm_tn2 / k_gemm_tn (W = [V_a V_b]'*A, FP64 MFMA)", bound="mfma", ms=st["ms_gemm_vta"],
+        groups.append(dict(kernel="k_gemm_tn2 / k_gemm_tn (W = [V_a V_b]'*A, FP64 MFMA)", symbol="k_gemm_tn2", bound="mfma", ms=st["ms_gemm_vta"],
                            launches=st["n_gemm_vta"], work=st["flops_gemm_vta"]))
     if st["ms_panel"] > 0:
-        groups.append(dict(kernel="panel lane: Gram/Cholesky/replay/narrow-update kernels (dhqr_recon.h)", bound="hbm", ms=st["ms_panel"],
+        groups.append(dict(kernel="panel lane: Gram/Cholesky/replay/narrow-update kernels (dhqr_recon.h)", symbol="panel lane", bound="hbm", ms=st["ms_panel"],
                            launches=st["n_panel"], work=st["bytes_panel"]))
     if st["ms_rank1"] > 0:
         # work = algorithmic HBM bytes of the launches AS IMPLEMENTED: a pass applies K reflectors to every trailing column
         # it loads and stores once (16 B per element and pass = 16/K B per element and reflector)
         groups.append(dict(kernel="k_rankk_fused (reflector apply, K reflectors per pass over the trailing columns)",
-                           bound="hbm", ms=st["ms_rank1"], launches=st["n_rank1"], work=st["bytes_rank1"]))
+                           symbol="k_rankk_fused", bound="hbm", ms=st["ms_rank1"], launches=st["n_rank1"], work=st["bytes_rank1"]))
     rl_all = []
     for gr in groups:
         if gr["bound"] == "mfma":
             ach, peak, unit = gr["work"] / gr["ms"] / 1e9, PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"
         else:
             ach, peak, unit = gr["work"] / gr["ms"] / 1e6, PEAK_HBM_GBPS, "GB/s"
+        traffic, why = pmc_traffic(gr["symbol"], m, n, nb, gr["launches"], gr["work"])
         rl_all.append({"kernel": gr["kernel"], "bound": gr["bound"], "achieved": ach, "peak": peak, "unit": unit,
-                       "frac": ach / peak, "traffic": pmc_traffic(gr["kernel"], m, n, nb, gr["launches"], gr["work"]),
+                       "frac": ach / peak, "traffic": traffic, **({"traffic_null_because": why} if traffic is None else {}),
                        "launches": gr["launches"],
                        "avg_launch_ms": gr["ms"] / max(1, gr["launches"]), "total_ms": gr["ms"]})
     # the north star grades the trailing update: the DOMINANT (largest total time) MFMA group
@@ -264,32 +485,47 @@ def main():
     ap.add_argument("--no-residual", action="store_true")
     ap.add_argument("--logical-ranks", type=int, default=0,
                     help="development: run R ranks of the multi-GPU driver on ONE GPU (in-process peer-copy transport)")
+    ap.add_argument("--worker", action="store_true", help="internal: the measured run itself (started by the supervisor of N > 1)")
     args = ap.parse_args()
 
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if (args.gpus > 1 or env_world > 1) and not args.worker:
+        if env_world > 1 and env_world != args.gpus:
+            raise SystemExit(f"WORLD_SIZE={env_world} but --gpus {args.gpus}")
+        sys.exit(supervise([a for a in sys.argv[1:] if a != "--worker"]))
+
+    progress("start")
     import torch
     import torch.distributed as dist
     import __graft_entry__ as g
     pkg = g.import_package()
+    progress("torch and libdhqr loaded")
+    attempt = json.loads(os.environ.get("DHQR_BENCH_ATTEMPT", "null"))
+    if args.gpus > 1 and not args.logical_ranks:
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible to this process "
+                             f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r}, ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')!r})")
 
     # Launch modes (same C drivers underneath):
     #   python bench.py --gpus N                  ONE process drives N GPUs (dhqr_mg_*: a host thread per device, RCCL
     #                                             communicators from ncclCommInitAll)
     #   torchrun --nproc-per-node N bench.py ...  one process per GPU (dhqr_cs_* over ncclCommInitRank, the unique id
     #                                             shipped through torch.distributed)
-    env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     spmd = env_world > 1
-    if spmd and env_world != args.gpus:
-        raise SystemExit(f"WORLD_SIZE={env_world} but --gpus {args.gpus}")
     world = args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if spmd:
-        dist.init_process_group("nccl", device_id=dev)
+        # control plane only (unique id, barriers, max of the times): gloo, so that the job holds exactly the RCCL
+        # communicators libdhqr creates; the data path is RCCL inside the library
+        dist.init_process_group(os.environ.get("DHQR_BENCH_PG", "gloo"))
+        progress("process group up")
 
     if args.config == "tallskinny":
-        return tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd)
+        return tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd, attempt)
     nb = 128 if args.config == "blocked" else 0
     n = args.n or (32768 if nb else 8192)
     m = args.m or n
@@ -303,6 +539,7 @@ def main():
     if spmd:
         mode = "spmd"
         q = pkg.ColumnCyclicQR(m, n, comm=pkg.Communicator.from_torch(ctx))
+        progress("RCCL communicators up (column split)")
 
         def step():
             q.fill(seed)
@@ -311,6 +548,7 @@ def main():
         mode = "mg"
         devices = list(range(world)) if world > 1 else [0] * args.logical_ranks
         mg = pkg.MultiGpuQR(devices=devices)
+        progress(f"multi-GPU handle up, transport {mg.transport}")
         mg.alloc(m, n)
 
         def step():
@@ -335,8 +573,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        barrier()
+        progress(f"warm-up step {i + 1}/{args.warmup}")
     barrier()
     if mode == "mg":
         mg.reset_stats()
@@ -344,11 +584,15 @@ def main():
     else:
         ctx.reset_stats()
         ctx.set_profiling(True)
+    tele = GpuTelemetry(local_rank)
+    tele.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    telemetry = tele.result()
+    progress(f"{args.steps} timed steps done")
     per_rank = None
     if mode == "mg":
         per_rank = [mg.stats(r) for r in range(mg.ndev)]
@@ -360,7 +604,7 @@ def main():
         ctx.set_profiling(False)
         panel_counts = list(ctx.panel_counters())
     if spmd:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)  # host tensor: the control plane is gloo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
@@ -409,17 +653,21 @@ def main():
             "equivalent_GBps_at_16B_per_element_and_reflector":
                 16.0 * sum((m - j) * (n - j - 1) for j in range(n)) * args.steps / st["ms_rank1"] / 1e6}}
            if (not nb and st["bytes_rank1"] > 0) else {}),
-        "traffic_note": "HBM bytes per WIDE launch (read + write) from rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE, separate "
-                        "passes over the torch-free driver with the end-of-round kernels (tools/gpu_pmc3.sh, profiles/r02_pmc_traffic.json); "
-                        "algorithmic C bytes per wide two-panel launch: 5.78 GB (NN: read + write) / 2.89 GB (TN: read) -> measured "
-                        "8.97 / 3.64 GB",
+        "traffic_note": "roofline.traffic = HBM bytes per launch (read + write) of the same kernel symbol on the same workload from the "
+                        "committed rocprofv3 --pmc run (FETCH_SIZE x2 on gfx950, WRITE_SIZE; separate passes over the torch-free "
+                        "driver), used only while the kernel sources still have the git blob ids stamped into "
+                        "profiles/pmc_traffic_current.json; otherwise null with the reason",
+        "gpu_telemetry": telemetry,
+        **attempt_fields(attempt),
         "phase_ms_per_step": {k: st[k] / args.steps for k in st if k.startswith("ms_") and st[k] > 0},
         "panels_fast_fallback": panel_counts,
     }
     if mode == "mg" and mg.transport == "rccl":
         out["bcast_tuning"] = mg.bcast_tuning()
+        out["rccl_nranks"] = mg.rccl_nranks()
     elif mode == "spmd":
         out["bcast_tuning"] = q.comm.bcast_tuning()
+        out["rccl_nranks"] = q.comm.rccl_nranks()
     if mode != "single":
         out["roofline_note"] = "per-GPU figures of rank 0 (every rank runs the same kernels on 1/N of the columns)"
     if per_rank is not None:
@@ -444,8 +692,6 @@ def main():
                 pkg._lib.check(pkg._lib.lib().dhqr_bench_gemm_f64(ctx.handle, kind, 16384, 16384, 3, g4))
                 iso[name] = {"tflops": g4[1], "frac_of_peak": g4[1] / PEAK_FP64_MFMA_TFLOPS, "shader_mhz": g4[2]}
             out["gemm_kernels_in_isolation_16384"] = iso
-            out["power_note"] = ("rocm-smi while the kernels run (profiles/r02_power_telemetry.txt): MFMA-only loop 924 W, "
-                                 "k_gemm_tn2 1164 W, k_gemm_nn_sub 1245 W (peaks 1327 W) of the 1400 W cap at 2.38-2.39 GHz")
         except Exception as e:  # diagnostics only
             out["ubench_error"] = repr(e)
         if not args.no_cpu_baseline:

@@ -2401,6 +2401,10 @@ int32_t dhqr_mg_get_bcast_tuning(dhqr_mg *g, int32_t *algo, double *ms_ring, dou
   return dhqr_comm_get_bcast_tuning(g->rk[0].cm, algo, ms_ring, ms_sag);
 }
 
+int32_t dhqr_mg_rccl_nranks(dhqr_mg *g, int32_t *main_channel, int32_t *lane_channel) {
+  if (!g || g->rk.empty()) return set_err(DHQR_EINVAL, "null handle");
+  return dhqr_comm_rccl_nranks(g->rk[0].cm, main_channel, lane_channel);
+}
 int32_t dhqr_mg_info(dhqr_mg *g, int32_t *ndev, int32_t *transport, int64_t *m, int64_t *n) {
   if (!g) return set_err(DHQR_EINVAL, "null handle");
   if (ndev) *ndev = g->ndev;

@@ -156,6 +156,12 @@ class Communicator:
         return {"algorithm": {0: "ncclBroadcast", 1: "scatter + all-gather"}[a.value], "trial_ms_16MiB_ncclBroadcast": r.value,
                 "trial_ms_16MiB_scatter_allgather": g.value}
 
+    def rccl_nranks(self) -> dict:
+        """rank counts RCCL itself reports (ncclCommCount) for the main channel and the row-split lane's channel"""
+        a, b = ctypes.c_int32(), ctypes.c_int32()
+        check(self.L.dhqr_comm_rccl_nranks(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return {"main": a.value, "lane": b.value}
+
     def close(self):
         if self.handle:
             self.L.dhqr_comm_destroy(self.handle)
@@ -319,6 +325,11 @@ class MultiGpuQR:
         self._check(self.L.dhqr_mg_get_bcast_tuning(self._h, ctypes.byref(a), ctypes.byref(r), ctypes.byref(g)))
         return {"algorithm": {0: "ncclBroadcast", 1: "scatter + all-gather"}[a.value], "trial_ms_16MiB_ncclBroadcast": r.value,
                 "trial_ms_16MiB_scatter_allgather": g.value}
+
+    def rccl_nranks(self) -> dict:
+        a, b = ctypes.c_int32(), ctypes.c_int32()
+        self._check(self.L.dhqr_mg_rccl_nranks(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return {"main": a.value, "lane": b.value}
 
     # device-resident path (what bench.py times)
     def alloc(self, m, n):

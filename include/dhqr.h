@@ -326,6 +326,7 @@ int32_t dhqr_mg_create(dhqr_mg **mg, const int32_t *devices, int32_t ndev);
 int32_t dhqr_mg_destroy(dhqr_mg *mg);
 int32_t dhqr_mg_info(dhqr_mg *mg, int32_t *ndev, int32_t *transport, int64_t *m, int64_t *n);
 int32_t dhqr_mg_get_bcast_tuning(dhqr_mg *mg, int32_t *algo, double *ms_ring, double *ms_scatter_allgather);
+int32_t dhqr_mg_rccl_nranks(dhqr_mg *mg, int32_t *main_channel, int32_t *lane_channel); /* dhqr_comm_rccl_nranks of rank 0 */
 int32_t dhqr_mg_alloc_f64(dhqr_mg *mg, int64_t m, int64_t n);
 int32_t dhqr_mg_fill_uniform_f64(dhqr_mg *mg, uint64_t seed);
 int32_t dhqr_mg_factor_f64(dhqr_mg *mg);
