@@ -678,8 +678,9 @@ def main():
     if rank == 0 and mode == "single":
         try:
             import ctypes as _ct
+            B, bh = pkg.bench_context(local_rank)  # libdhqr_bench.so: the micro-benchmarks are not in the product library
             o4 = (_ct.c_double * 4)()   # 4 waves/SIMD, accumulators in VGPRs: the achievable issue rate
-            pkg._lib.check(pkg._lib.lib().dhqr_bench_issue2_f64(ctx.handle, 0, 1024, 256, o4))
+            pkg.bench_check(B, B.dhqr_bench_issue2_f64(bh, 0, 1024, 256, o4))
             out["fp64_mfma_ubench_tflops"] = o4[2]
             out["fp64_mfma_ubench_note"] = ("v_mfma_f64_16x16x4_f64 only, 4 waves/SIMD, VGPR accumulators "
                                             "(16 AGPR accumulators per wave issue at half rate: %.1f TFLOP/s)"
@@ -689,7 +690,7 @@ def main():
             g4 = (_ct.c_double * 4)()
             iso = {}
             for kind, name in ((0, "k_gemm_nn_sub K=256"), (1, "k_gemm_tn2")):
-                pkg._lib.check(pkg._lib.lib().dhqr_bench_gemm_f64(ctx.handle, kind, 16384, 16384, 3, g4))
+                pkg.bench_check(B, B.dhqr_bench_gemm_f64(bh, kind, 16384, 16384, 3, g4))
                 iso[name] = {"tflops": g4[1], "frac_of_peak": g4[1] / PEAK_FP64_MFMA_TFLOPS, "shader_mhz": g4[2]}
             out["gemm_kernels_in_isolation_16384"] = iso
         except Exception as e:  # diagnostics only

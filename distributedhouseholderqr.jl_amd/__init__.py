@@ -7,7 +7,7 @@ partition.py (index maps), distributed.py (front-ends of the multi-GPU C drivers
 """
 from . import _lib
 from ._lib import NB, DHQRError, build
-from .api import (Context, DistributedHouseholderQRStruct, apply_q_, bench_mfma_tflops,
+from .api import (Context, DistributedHouseholderQRStruct, apply_q_, bench_check, bench_context, bench_mfma_tflops,
                   bench_stream_gbps, empty_colmajor, get_context, get_q, get_r, householder_, ldiv, partialdot,
                   qr_, rand_colmajor, rand_colmajor_c, rand_vector_device, residual, solve_householder_)
 from .distributed import ColumnCyclicQR, Communicator, MultiGpuQR, qr_darray_, qr_multi_
@@ -16,7 +16,7 @@ from .partition import BlockCyclicColumns, LocalColumnBlock, contiguous_column_b
 
 __all__ = [
     "NB", "DHQRError", "build", "Context", "DistributedHouseholderQRStruct", "apply_q_",
-    "bench_mfma_tflops", "bench_stream_gbps", "empty_colmajor", "get_context", "get_q", "get_r", "householder_",
+    "bench_check", "bench_context", "bench_mfma_tflops", "bench_stream_gbps", "empty_colmajor", "get_context", "get_q", "get_r", "householder_",
     "ldiv", "partialdot", "qr_", "rand_colmajor", "rand_colmajor_c", "rand_vector_device", "residual",
     "solve_householder_", "ColumnCyclicQR", "Communicator", "MultiGpuQR", "qr_darray_", "qr_multi_", "RowSplitQR", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
 ]

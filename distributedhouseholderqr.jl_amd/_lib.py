@@ -8,6 +8,7 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libdhqr.so")
+BENCH_SO_PATH = os.path.join(_PKG, "libdhqr_bench.so")  # superset with the micro-benchmarks (include/dhqr_bench.h)
 CSRC = os.path.join(_PKG, "csrc")
 NB = 128  # DHQR_NB
 CS_BLOCK = 256  # DHQR_CS_BLOCK: cyclic block of the multi-GPU column split (a pair of panels)
@@ -42,7 +43,9 @@ def build(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(_PKG, "..", "include", "dhqr.h"))
     newest = max(os.path.getmtime(s) for s in srcs)
-    if force or not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < newest:
+    srcs.append(os.path.join(_PKG, "..", "include", "dhqr_bench.h"))
+    newest = max(newest, os.path.getmtime(srcs[-1]))
+    if force or any(not os.path.exists(so) or os.path.getmtime(so) < newest for so in (SO_PATH, BENCH_SO_PATH)):
         subprocess.check_call(["bash", os.path.join(CSRC, "build.sh")])
     return SO_PATH
 
@@ -143,6 +146,10 @@ SIGNATURES = {
     "dhqr_mg_rs_residual_f64": (_i32, [_p, _u64, _pd]),
     "dhqr_mg_rs_transfer_f64": (_i32, [_p, _p, _i64, _p, _i32]),
     "dhqr_mg_rs_solve_f64": (_i32, [_p, _p, _p]),
+}
+
+# include/dhqr_bench.h: exported by libdhqr_bench.so only
+BENCH_SIGNATURES = {
     "dhqr_bench_mfma_f64": (_i32, [_p, _pd]),
     "dhqr_bench_issue_f64": (_i32, [_p, _i32, _i32, _pd, _pd]),
     "dhqr_bench_issue2_f64": (_i32, [_p, _i32, _i32, _i32, _pd]),
@@ -170,6 +177,25 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+_bench = None
+
+
+def lib_bench() -> ctypes.CDLL:
+    """libdhqr_bench.so: the product source + the micro-benchmarks / the MFMA layout probe (include/dhqr_bench.h).
+    Its contexts are its own: pass handles created by ITS dhqr_create."""
+    global _bench
+    if _bench is None:
+        if not os.path.exists(BENCH_SO_PATH):
+            raise ImportError(f"{BENCH_SO_PATH} not found: build it with __graft_entry__.build()")
+        L = ctypes.CDLL(BENCH_SO_PATH)
+        for name, (res, args) in list(SIGNATURES.items()) + list(BENCH_SIGNATURES.items()):
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _bench = L
+    return _bench
 
 
 def check(rc: int) -> None:

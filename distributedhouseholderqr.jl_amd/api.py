@@ -414,15 +414,38 @@ def residual(H: DistributedHouseholderQRStruct, Aorig, work=None) -> float:
     return out.value
 
 
+_bench_ctx = {}
+
+
+def bench_context(device: Optional[int] = None):
+    """(libdhqr_bench.so, context handle created by it) for the micro-benchmarks of include/dhqr_bench.h -- they are not
+    in the product library, and contexts are per library."""
+    import torch as _t
+    dev = _t.cuda.current_device() if device is None else int(device)
+    if dev not in _bench_ctx:
+        B = _lib.lib_bench()
+        h = ctypes.c_void_p()
+        rc = B.dhqr_create(ctypes.byref(h), dev)
+        if rc != 0:
+            raise DHQRError(rc, B.dhqr_last_error().decode(errors="replace"))
+        _bench_ctx[dev] = (B, h)
+    return _bench_ctx[dev]
+
+
+def bench_check(B, rc):
+    if rc != 0:
+        raise DHQRError(rc, B.dhqr_last_error().decode(errors="replace"))
+
+
 def bench_mfma_tflops(device: Optional[int] = None) -> float:
-    ctx = get_context(device)
+    B, h = bench_context(device)
     out = ctypes.c_double()
-    check(_lib.lib().dhqr_bench_mfma_f64(ctx.handle, ctypes.byref(out)))
+    bench_check(B, B.dhqr_bench_mfma_f64(h, ctypes.byref(out)))
     return out.value
 
 
 def bench_stream_gbps(nbytes: int = 1 << 30, device: Optional[int] = None) -> float:
-    ctx = get_context(device)
+    B, h = bench_context(device)
     out = ctypes.c_double()
-    check(_lib.lib().dhqr_bench_stream_f64(ctx.handle, nbytes, ctypes.byref(out)))
+    bench_check(B, B.dhqr_bench_stream_f64(h, nbytes, ctypes.byref(out)))
     return out.value

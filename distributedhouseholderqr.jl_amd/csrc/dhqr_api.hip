@@ -1452,6 +1452,7 @@ int32_t dhqr_factor_c64_nb(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_
   ENTER(c);
   if (no_columns(m, n)) return DHQR_OK;
   if (nb != DHQR_ZNB) return set_err(DHQR_EINVAL, "ComplexF64: nb must be 0 (unblocked) or %d (blocked); got %d", DHQR_ZNB, nb);
+  CHECK(check_mat(dA, m, n, 2 * lda, false));  // the MFMA kernels see the interleaved storage as a real matrix with ld = 2 lda
   CHECK(check_mat(dA, m, n, lda, true));
   CHECK(check_zptr(dA, "matrix"));
   CHECK(check_zptr(dalpha, "alpha"));
@@ -1742,279 +1743,11 @@ int32_t dhqr_panel_apply_f64(dhqr_ctx *c, const double *dVT, int64_t rows, doubl
   return panel_apply(c, vt_view(dVT, rows), rows, dC, ncols, ldc, trans ? 1 : 0);
 }
 
-int32_t dhqr_bench_mfma_f64(dhqr_ctx *c, double *tflops) {
-  ENTER(c);
-  if (!tflops) return set_err(DHQR_EINVAL, "null output");
-  const int nblk = 256 * 8, iters = 4000;
-  CHECK(ensure(c, c->scratch, (size_t)nblk * 256 + 4096));
-  hipEvent_t a, b;
-  HIPCHECK(hipEventCreate(&a));
-  HIPCHECK(hipEventCreate(&b));
-  hipLaunchKernelGGL(k_mfma_bench, dim3(nblk), dim3(256), 0, c->stream, c->scratch.p, 100);
-  HIPCHECK(hipEventRecord(a, c->stream));
-  hipLaunchKernelGGL(k_mfma_bench, dim3(nblk), dim3(256), 0, c->stream, c->scratch.p, iters);
-  HIPCHECK(hipEventRecord(b, c->stream));
-  HIPCHECK(hipEventSynchronize(b));
-  float ms = 0.f;
-  HIPCHECK(hipEventElapsedTime(&ms, a, b));
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  const double flops = (double)nblk * 4.0 * (double)iters * 16.0 * 2048.0;
-  *tflops = flops / ((double)ms * 1e-3) / 1e12;
-  return DHQR_OK;
-}
-
-int32_t dhqr_bench_issue_f64(dhqr_ctx *c, int32_t kind, int32_t nblocks, double *cycles_per_instr,
-                             double *tflops) {
-  ENTER(c);
-  if (!cycles_per_instr || !tflops || nblocks <= 0 || nblocks > 4096 || (kind != 0 && kind != 1))
-    return set_err(DHQR_EINVAL, "bad arguments");
-  const int iters = 2000;
-  CHECK(ensure(c, c->scratch, (size_t)nblocks * 256 + 4096 + (size_t)nblocks * 4 + 16));
-  double *sink = c->scratch.p;
-  long long *cyc = (long long *)(c->scratch.p + (size_t)nblocks * 256 + 4096);
-  hipEvent_t a, b;
-  HIPCHECK(hipEventCreate(&a));
-  HIPCHECK(hipEventCreate(&b));
-  for (int rep = 0; rep < 2; ++rep) {  // first pass warms clocks / code
-    HIPCHECK(hipEventRecord(a, c->stream));
-    if (kind == 0) hipLaunchKernelGGL((k_issue_probe<0>), dim3(nblocks), dim3(256), 0, c->stream, sink, cyc, iters);
-    else hipLaunchKernelGGL((k_issue_probe<1>), dim3(nblocks), dim3(256), 0, c->stream, sink, cyc, iters);
-    HIPCHECK(hipEventRecord(b, c->stream));
-    HIPCHECK(hipEventSynchronize(b));
-  }
-  float ms = 0.f;
-  HIPCHECK(hipEventElapsedTime(&ms, a, b));
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  std::vector<long long> h((size_t)nblocks * 4);
-  HIPCHECK(hipMemcpy(h.data(), cyc, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-  double sum = 0;
-  for (long long v : h) sum += (double)v;
-  *cycles_per_instr = sum / (double)h.size() / ((double)iters * 16.0);
-  const double flop_per_instr = kind == 0 ? 2048.0 : 128.0;
-  *tflops = (double)nblocks * 4.0 * iters * 16.0 * flop_per_instr / ((double)ms * 1e-3) / 1e12;
-  return DHQR_OK;
-}
-
-int32_t dhqr_bench_issue2_f64(dhqr_ctx *c, int32_t mode, int32_t threads, int32_t nblocks, double *out4) {
-  ENTER(c);
-  if (!out4 || nblocks <= 0 || nblocks > 4096 || mode < 0 || mode > 2 || threads % 256 || threads > 1024)
-    return set_err(DHQR_EINVAL, "bad arguments");
-  const int iters = 1000, wpb = threads / 64;
-  CHECK(ensure(c, c->scratch, (size_t)nblocks * threads + 4096 + (size_t)nblocks * wpb + 16));
-  double *sink = c->scratch.p;
-  long long *cyc = (long long *)(c->scratch.p + (size_t)nblocks * threads + 4096);
-  hipEvent_t a, b;
-  HIPCHECK(hipEventCreate(&a));
-  HIPCHECK(hipEventCreate(&b));
-  for (int rep = 0; rep < 2; ++rep) {
-    HIPCHECK(hipEventRecord(a, c->stream));
-    hipLaunchKernelGGL(k_issue_probe2, dim3(nblocks), dim3(threads), 0, c->stream, sink, cyc, iters, (int)mode);
-    HIPCHECK(hipEventRecord(b, c->stream));
-    HIPCHECK(hipEventSynchronize(b));
-  }
-  float ms = 0.f;
-  HIPCHECK(hipEventElapsedTime(&ms, a, b));
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  std::vector<long long> h((size_t)nblocks * wpb);
-  HIPCHECK(hipMemcpy(h.data(), cyc, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-  double sm = 0, sv = 0;
-  int64_t nm = 0, nv = 0;
-  for (size_t i = 0; i < h.size(); ++i) {
-    const int wave = (int)(i % wpb);
-    const bool mf = (mode == 0) || (mode == 2 && wave < 4);
-    if (mf) { sm += (double)h[i]; nm++; } else { sv += (double)h[i]; nv++; }
-  }
-  out4[0] = nm ? sm / nm / (iters * 8.0) : 0.0;          // cycles per MFMA per wave
-  out4[1] = nv ? sv / nv / (iters * 8.0 * 16.0) : 0.0;   // cycles per v_fma_f64 per wave
-  out4[2] = (double)nm * iters * 8.0 * 2048.0 / (ms * 1e-3) / 1e12;
-  out4[3] = (double)nv * iters * 8.0 * 16.0 * 128.0 / (ms * 1e-3) / 1e12;
-  return DHQR_OK;
-}
-
-int32_t dhqr_bench_stream_f64(dhqr_ctx *c, int64_t bytes, double *gbps) {
-  ENTER(c);
-  if (!gbps || bytes < 4096) return set_err(DHQR_EINVAL, "bad arguments");
-  const int64_t n2 = bytes / 16;
-  double *x = nullptr, *y = nullptr;
-  if (hipMalloc((void **)&x, (size_t)n2 * 16) != hipSuccess || hipMalloc((void **)&y, (size_t)n2 * 16) != hipSuccess) {
-    if (x) (void)hipFree(x);
-    return set_err(DHQR_ENOMEM, "hipMalloc failed in dhqr_bench_stream_f64");
-  }
-  (void)hipMemsetAsync(x, 0, (size_t)n2 * 16, c->stream);
-  hipEvent_t a, b;
-  (void)hipEventCreate(&a);
-  (void)hipEventCreate(&b);
-  const unsigned grid = 256 * 16;
-  hipLaunchKernelGGL(k_stream_bench, dim3(grid), dim3(256), 0, c->stream, (const double2 *)x, (double2 *)y, n2);
-  (void)hipEventRecord(a, c->stream);
-  const int reps = 5;
-  for (int r = 0; r < reps; ++r)
-    hipLaunchKernelGGL(k_stream_bench, dim3(grid), dim3(256), 0, c->stream, (const double2 *)x, (double2 *)y, n2);
-  (void)hipEventRecord(b, c->stream);
-  (void)hipEventSynchronize(b);
-  float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, a, b);
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  (void)hipFree(x);
-  (void)hipFree(y);
-  *gbps = 2.0 * (double)n2 * 16.0 * reps / ((double)ms * 1e-3) / 1e9;
-  return DHQR_OK;
-}
-
-// GEMM micro-benchmark of the two wide trailing-update kernels on synthetic operands (not a product entry point):
-// kind 0: k_gemm_nn_sub<2,256> (C -= [V_a V_b] W, rows x ncols), kind 1: k_gemm_tn2 (Y = [V_a V_b]' C).
-// `reps` timed launches after one warm-up; a one-wave clock probe runs beside them on a second stream.
-// out = {ms per launch, TFLOP/s, shader MHz under the kernel, 0}.  The A/B switches of the context apply.
-int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t ncols, int32_t reps, double *out4) {
-  ENTER(c);
-  if (!out4 || rows < 256 || ncols < 128 || rows % 128 || ncols % 128 || reps < 1 || (kind != 0 && kind != 1))
-    return set_err(DHQR_EINVAL, "bad arguments");
-  const int64_t ldv = rows, ldc = rows, ld2 = 2 * DHQR_NBV;
-  double *V = nullptr, *W = nullptr, *C = nullptr, *Y = nullptr;
-  long long *clk = nullptr;
-  hipStream_t s2 = nullptr;
-  hipEvent_t a = nullptr, b = nullptr;
-  auto body = [&]() -> int32_t {
-    HIPCHECK(hipMalloc((void **)&V, (size_t)ldv * ld2 * 8));
-    HIPCHECK(hipMalloc((void **)&W, (size_t)ld2 * ncols * 8));
-    HIPCHECK(hipMalloc((void **)&C, (size_t)ldc * ncols * 8));
-    HIPCHECK(hipMalloc((void **)&clk, 64));
-    HIPCHECK(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, -1));
-    HIPCHECK(hipEventCreate(&a));
-    HIPCHECK(hipEventCreate(&b));
-    CHECK(dhqr_fill_uniform_f64(c, V, rows, ld2, ldv, 1, rows, 0, 128, 1, 0));
-    CHECK(dhqr_fill_uniform_f64(c, W, ld2, ncols, ld2, 2, ld2, 0, 128, 1, 0));
-    CHECK(dhqr_fill_uniform_f64(c, C, rows, ncols, ldc, 3, rows, 0, 128, 1, 0));
-    const int64_t ntiles = ncols / 128, gx = rows / 128;
-    int64_t nsplit = 1, rps = rows;
-    if (kind == 1) {
-      pick_split(rows, ntiles, 256, ntiles <= 2 ? 256 : 64, &nsplit, &rps, 256);
-      HIPCHECK(hipMalloc((void **)&Y, (size_t)nsplit * ld2 * ncols * 8));
-    }
-    bool timed_nn = false;
-    auto launch = [&]() {
-      if (kind == 0) {
-        const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
-        dim3 grid((unsigned)gx, (unsigned)ntiles);
-        if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
-        if (timed_nn)
-          hipLaunchKernelGGL((k_gemm_nn_sub<2, 256, false, true>), grid, dim3(256), 0, c->stream, (const double *)V, ldv,
-                             (const double *)W, ld2, C, ldc, rows, ncols, swz, (const int *)nullptr, 0);
-        else
-          launch_nn_sub<256>(c, true, grid, V, ldv, W, ld2, C, ldc, rows, ncols, swz, false);
-      } else {
-        hipLaunchKernelGGL((k_gemm_tn2<2>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(512), 0, c->stream, V, ldv,
-                           (const double *)C, ldc, rows, ncols, rps, Y, ld2 * ncols);
-      }
-    };
-    launch();
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    if (kind == 0 && getenv("DHQR_NN_TIME")) {  // phase clock of one launch (instrumented instantiation)
-      unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_nn_phase), z, sizeof(z)));
-      timed_nn = true;
-      launch();
-      timed_nn = false;
-      HIPCHECK(hipStreamSynchronize(c->stream));
-      HIPCHECK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_nn_phase), sizeof(z)));
-      const double nt = (double)std::max<unsigned long long>(1, z[4]);
-      fprintf(stderr, "k_gemm_nn_sub phase clock (wave 0, cycles per tile over %.0f tiles): prologue + C tile %.0f, K loop %.0f, "
-                      "store issue %.0f, store drain %.0f\n", nt, z[0] / nt, z[1] / nt, z[2] / nt, z[3] / nt);
-    }
-    HIPCHECK(hipEventRecord(a, c->stream));
-    launch();
-    HIPCHECK(hipEventRecord(b, c->stream));
-    HIPCHECK(hipEventSynchronize(b));
-    float ms1 = 0.f;
-    HIPCHECK(hipEventElapsedTime(&ms1, a, b));
-    // clock probe for about 60 % of the timed region, started right behind the first timed launch
-    int wall_khz = 100000;
-    (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, c->device);
-    const long long ticks = (long long)(0.6 * ms1 * reps * wall_khz);
-    HIPCHECK(hipEventRecord(a, c->stream));
-    for (int r = 0; r < reps; ++r) {
-      launch();
-      if (r == 0) hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s2, clk, ticks);
-    }
-    HIPCHECK(hipEventRecord(b, c->stream));
-    HIPCHECK(hipEventSynchronize(b));
-    HIPCHECK(hipStreamSynchronize(s2));
-    LAUNCHCHECK();
-    float ms = 0.f;
-    HIPCHECK(hipEventElapsedTime(&ms, a, b));
-    long long h[2] = {0, 0};
-    HIPCHECK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
-    out4[0] = ms / reps;
-    out4[1] = 2.0 * 256.0 * (double)rows * (double)ncols / (out4[0] * 1e-3) / 1e12;
-    out4[2] = h[1] > 0 ? (double)h[0] / (double)h[1] * (double)wall_khz * 1e-3 : 0.0;
-    out4[3] = 0.0;
-    return DHQR_OK;
-  };
-  const int32_t rc = body();
-  (void)hipStreamSynchronize(c->stream);
-  if (s2) (void)hipStreamDestroy(s2);
-  if (a) (void)hipEventDestroy(a);
-  if (b) (void)hipEventDestroy(b);
-  (void)hipFree(V); (void)hipFree(W); (void)hipFree(C); (void)hipFree(Y); (void)hipFree(clk);
-  return rc;
-}
-
-// MFMA cadence probe (k_mma_probe<mode>): 256 workgroups of `threads` (256 / 512) threads; out2 = {mean cycles per
-// MFMA per wave, wall TFLOP/s}.
-int32_t dhqr_bench_mma_probe_f64(dhqr_ctx *c, int32_t mode, int32_t threads, double *out2) {
-  ENTER(c);
-  if (!out2 || (threads != 256 && threads != 512) || mode < 0 || mode > 4) return set_err(DHQR_EINVAL, "bad arguments");
-  const int nblk = 256, iters = 400, nw = threads / 64;
-  double *sink = nullptr;
-  long long *cyc = nullptr;
-  HIPCHECK(hipMalloc((void **)&sink, (size_t)nblk * threads * 8));
-  HIPCHECK(hipMalloc((void **)&cyc, (size_t)nblk * nw * 8));
-  hipEvent_t a, b;
-  HIPCHECK(hipEventCreate(&a));
-  HIPCHECK(hipEventCreate(&b));
-  auto launch = [&](int it) {
-    switch (mode) {
-      case 0: hipLaunchKernelGGL(k_mma_probe<0>, dim3(nblk), dim3(threads), 0, c->stream, sink, cyc, it); break;
-      case 1: hipLaunchKernelGGL(k_mma_probe<1>, dim3(nblk), dim3(threads), 0, c->stream, sink, cyc, it); break;
-      case 2: hipLaunchKernelGGL(k_mma_probe<2>, dim3(nblk), dim3(threads), 0, c->stream, sink, cyc, it); break;
-      case 3: hipLaunchKernelGGL(k_mma_probe<3>, dim3(nblk), dim3(threads), 0, c->stream, sink, cyc, it); break;
-      default: hipLaunchKernelGGL(k_mma_probe<4>, dim3(nblk), dim3(threads), 0, c->stream, sink, cyc, it); break;
-    }
-  };
-  launch(20);
-  HIPCHECK(hipEventRecord(a, c->stream));
-  launch(iters);
-  HIPCHECK(hipEventRecord(b, c->stream));
-  HIPCHECK(hipEventSynchronize(b));
-  float ms = 0.f;
-  HIPCHECK(hipEventElapsedTime(&ms, a, b));
-  std::vector<long long> h((size_t)nblk * nw);
-  HIPCHECK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
-  double tot = 0.0;
-  for (long long v : h) tot += (double)v;
-  out2[0] = tot / (double)h.size() / ((double)iters * 64.0);
-  out2[1] = (double)nblk * nw * (double)iters * 64.0 * 2048.0 / ((double)ms * 1e-3) / 1e12;
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  (void)hipFree(sink);
-  (void)hipFree(cyc);
-  return DHQR_OK;
-}
-
-// test hook (not in dhqr.h's stable surface, declared in the test binding only):
-// raw MFMA D registers for the documented operand maps
-int32_t dhqr_debug_mfma_probe(dhqr_ctx *c, const double *da, const double *db, double *dout) {
-  ENTER(c);
-  hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, c->stream, da, db, dout);
-  LAUNCHCHECK();
-  HIPCHECK(hipStreamSynchronize(c->stream));
-  return DHQR_OK;
-}
-
+#ifdef DHQR_BENCH_BUILD
+}  // extern "C"
+#include "dhqr_bench.h"  // micro-benchmarks and the MFMA layout probe: libdhqr_bench.so only (include/dhqr_bench.h)
+extern "C" {
+#endif
 
 // ============================================================ multi-GPU: communicators (dhqr_comm.h)
 static bool lane_channel_wanted() {  // DHQR_LANE_CHANNEL=0: the row-split lane shares the wide stream's channel

@@ -291,7 +291,9 @@ static int32_t comm_wait_consumed(dhqr_comm *cm, int64_t ticket, hipStream_t str
     if (w->abort.load()) return set_err(DHQR_ECOMM, "a peer rank failed");
     comm_pause(spins);
   }
-  if (sl.seq.load(std::memory_order_acquire) != ticket) return DHQR_OK;
+  // Slot already recycled (seq != ticket): recycling only needs every receiver to have ENQUEUED its copy, so the copies
+  // may still be in flight -- wait on the receivers' events all the same (a re-recorded event completes after the
+  // earlier work of the stream it was recorded on, so waiting on it is at least as strong).
   for (int r = 0; r < w->nranks; ++r)
     if (r != cm->rank) HIPCHECK(hipStreamWaitEvent(stream, w->done[r][ticket % DHQR_COMM_RING], 0));
   return DHQR_OK;

@@ -335,7 +335,9 @@ __global__ __launch_bounds__(512) void k_gemm_tn2(const double *__restrict__ V, 
 // stat/epoch: device-side commit predicate of the asynchronous panel pipeline (dhqr_api.hip): the launch is a
 // no-op when a panel with index <= epoch failed its verification (stat[0] = index of the first failed panel).
 // Phase clock of the TIME instantiation (micro-benchmark only): summed shader cycles of wave 0 per phase.
+#ifdef DHQR_BENCH_BUILD
 __device__ unsigned long long g_nn_phase[8];
+#endif
 
 // TR = rows of the output tile: 128 (the trailing update: each wave 64 x 64) or 64 (four waves side by side, each 64 rows x
 // 32 columns).  A workgroup's time is its K loop on one CU (13.7 us for a 128 x 128 x 128 tile); the latency-critical
@@ -480,10 +482,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
       tph[3] = clock64();
       __builtin_amdgcn_s_waitcnt(0x0F70);  // the stores have left the wave
       tph[4] = clock64();
+#ifdef DHQR_BENCH_BUILD
       if (threadIdx.x == 0) {
         for (int q = 0; q < 4; ++q) atomicAdd(&g_nn_phase[q], (unsigned long long)(tph[q + 1] - tph[q]));
         atomicAdd(&g_nn_phase[4], 1ull);
       }
+#endif
     }
   };
 
@@ -705,201 +709,3 @@ __global__ __launch_bounds__(256) void k_tw_fused(const double *__restrict__ Y, 
 // This holds for ANY vectors v_j, so the reference's zero-pivot reflectors (||v||^2 != 2, src:8)
 // are reproduced exactly.  The trailing update is A <- A - V (T' (V' A)).
 
-// Raw MFMA layout probe (test hook): out[lane*4 + g] = D register g of lane, with
-// A[i][k] = a[i*4+k], B[k][j] = b[k*16+j] loaded per the operand maps documented above, C = 0.
-__global__ void k_mfma_probe(const double *__restrict__ a, const double *__restrict__ b,
-                             double *__restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int i16 = lane & 15, k4 = lane >> 4;
-  dhqr_d4 acc = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
-  acc = mfma_f64(a[i16 * 4 + k4], b[k4 * 16 + i16], acc);
-  for (int g = 0; g < 4; ++g) out[lane * 4 + g] = acc[g];
-}
-
-// FP64 MFMA issue-rate micro-benchmark: every wave runs `iters` x 16 independent accumulators.
-__global__ __launch_bounds__(256) void k_mfma_bench(double *__restrict__ out, int iters) {
-  dhqr_d4 acc[16];
-  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-#pragma unroll
-  for (int x = 0; x < 16; ++x) acc[x] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int x = 0; x < 16; ++x) acc[x] = mfma_f64(a, b, acc[x]);
-  }
-  double s = 0.0;
-#pragma unroll
-  for (int x = 0; x < 16; ++x) s += acc[x][0] + acc[x][1] + acc[x][2] + acc[x][3];
-  out[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
-// Issue-rate probes in SHADER cycles (s_memtime), independent of DVFS: per wave, `iters` x 16
-// independent v_mfma_f64_16x16x4_f64 (kind 0) or v_fma_f64 (kind 1) chains; cyc[wave] = cycles.
-template <int KIND>
-__global__ __launch_bounds__(256) void k_issue_probe(double *__restrict__ sink,
-                                                     long long *__restrict__ cyc, int iters) {
-  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-  long long t0, t1;
-  double s = 0.0;
-  if constexpr (KIND == 0) {
-    dhqr_d4 acc[16];
-#pragma unroll
-    for (int x = 0; x < 16; ++x) acc[x] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
-    t0 = clock64();
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-      for (int x = 0; x < 16; ++x) acc[x] = mfma_f64(a, b, acc[x]);
-    }
-    t1 = clock64();
-#pragma unroll
-    for (int x = 0; x < 16; ++x) s += acc[x][0] + acc[x][1] + acc[x][2] + acc[x][3];
-  } else {
-    double acc[16];
-#pragma unroll
-    for (int x = 0; x < 16; ++x) acc[x] = threadIdx.x * 1e-3 + x;
-    t0 = clock64();
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-      for (int x = 0; x < 16; ++x) acc[x] = fma(acc[x], a, b);
-    }
-    t1 = clock64();
-#pragma unroll
-    for (int x = 0; x < 16; ++x) s += acc[x];
-  }
-  sink[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
-  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
-}
-
-// Second probe: several waves per SIMD and MFMA/VALU co-issue.  mode 0: every wave MFMA; mode 1:
-// every wave v_fma_f64; mode 2: waves 0-3 of the workgroup MFMA, the others VALU (blockDim 512:
-// one MFMA wave + one VALU wave per SIMD).  8 independent chains per wave (low register use, so
-// blockDim up to 1024 = 4 waves per SIMD fits).
-__global__ __launch_bounds__(1024) void k_issue_probe2(double *__restrict__ sink,
-                                                       long long *__restrict__ cyc, int iters,
-                                                       int mode) {
-  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-  const int wave = threadIdx.x >> 6;
-  const bool do_mfma = (mode == 0) || (mode == 2 && wave < 4);
-  long long t0, t1;
-  double s = 0.0;
-  if (do_mfma) {
-    dhqr_d4 acc[8];
-#pragma unroll
-    for (int x = 0; x < 8; ++x) acc[x] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
-    t0 = clock64();
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-      for (int x = 0; x < 8; ++x) acc[x] = mfma_f64(a, b, acc[x]);
-    }
-    t1 = clock64();
-#pragma unroll
-    for (int x = 0; x < 8; ++x) s += acc[x][0] + acc[x][1] + acc[x][2] + acc[x][3];
-  } else {
-    double acc[16];
-#pragma unroll
-    for (int x = 0; x < 16; ++x) acc[x] = threadIdx.x * 1e-3 + x;
-    t0 = clock64();
-    for (int it = 0; it < iters * 8; ++it) {  // 16 FMA per trip: ~same duration as the MFMA waves
-#pragma unroll
-      for (int x = 0; x < 16; ++x) acc[x] = fma(acc[x], a, b);
-    }
-    t1 = clock64();
-#pragma unroll
-    for (int x = 0; x < 16; ++x) s += acc[x];
-  }
-  sink[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
-  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + wave] = t1 - t0;
-}
-
-// Shader-clock probe: one wave sleeps for `wall_ticks` ticks of the constant-rate counter (wall_clock64) and reports
-// how many shader cycles (s_memtime) passed: launched beside a GEMM on a second stream it gives the clock the chip
-// sustains under that kernel (the chip clocks to its power budget).  out = {shader cycles, wall ticks}.
-__global__ void k_clock_probe(long long *__restrict__ out, long long wall_ticks) {
-  const long long w0 = wall_clock64(), c0 = clock64();
-  while (wall_clock64() - w0 < wall_ticks) __builtin_amdgcn_s_sleep(64);
-  const long long c1 = clock64(), w1 = wall_clock64();
-  if (threadIdx.x == 0) {
-    out[0] = c1 - c0;
-    out[1] = w1 - w0;
-  }
-}
-
-// MFMA cadence probe: the inner loop of the GEMM kernels (4 x 4 MFMA tiles per wave, fragments from LDS) without
-// staging, barriers or global memory: cycles per MFMA per wave (s_memtime).  MODE 0: register operands only;
-// 1: fragments by ds_read from the k-contiguous layout, stride S = 18 doubles (what k_gemm_tn* use; the compiler
-// merges the kk / kk+1 reads into ds_read2_b64); 2: same layout, one opaque base per kk (plain ds_read_b64 only);
-// 3: stride 17 (odd: conflict-free for ds_read2_b64's 16-lane groups); 4: the NN kernel's operands (V tile
-// row-contiguous with stride 144, W tile stride 18).  blockDim 256 (one wave per SIMD) or 512 (two).
-template <int MODE>
-__global__ __launch_bounds__(512) void k_mma_probe(double *__restrict__ sink, long long *__restrict__ cyc, int iters) {
-  constexpr int S = (MODE == 3) ? 17 : G_LDK;
-  __shared__ double Vs[256 * 19];
-  __shared__ double Cs[128 * 19];
-  __shared__ double Vr[G_KT * G_LDR];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int i16 = lane & 15, k4 = lane >> 4;
-  for (int e = t; e < 256 * 19; e += blockDim.x) Vs[e] = 1.0 + 1e-6 * e;
-  for (int e = t; e < 128 * 19; e += blockDim.x) Cs[e] = 1.0 - 1e-6 * e;
-  for (int e = t; e < G_KT * G_LDR; e += blockDim.x) Vr[e] = 0.5 + 1e-6 * e;
-  __syncthreads();
-  const int wc = (w >> 2) & 1, wp = w & 3;
-  dhqr_d4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
-  const double *cs = &Cs[(wc * 64 + i16) * S + k4];
-  const double *vs = (MODE == 4) ? &Vr[k4 * G_LDR + (wp & 1) * 64 + i16] : &Vs[(wp * 64 + i16) * S + k4];
-  int offc[4], offv[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    offc[kk] = kk * 4;
-    offv[kk] = (MODE == 4) ? kk * 4 * G_LDR : kk * 4;
-    if (MODE == 2) {  // opaque offsets: the kk and kk+1 reads cannot be paired into ds_read2_b64
-      asm volatile("" : "+v"(offc[kk]));
-      asm volatile("" : "+v"(offv[kk]));
-    }
-  }
-  double ra[4] = {1.0 + lane * 1e-9, 1.1, 1.2, 1.3}, rb[4] = {1.0 - lane * 1e-9, 0.9, 0.8, 0.7};
-  const long long t0 = clock64();
-  for (int it = 0; it < iters; ++it) {
-    asm volatile("" ::: "memory");  // the fragments are re-read every iteration, as in the GEMM kernels
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      double a[4], b[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        if (MODE == 0) {
-          a[x] = ra[x];
-          b[x] = rb[x];
-        } else {
-          a[x] = cs[offc[kk] + x * 16 * S];
-          b[x] = (MODE == 4) ? vs[offv[kk] + x * 16] : vs[offv[kk] + x * 16 * S];
-        }
-      }
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int pi = 0; pi < 4; ++pi) acc[ci][pi] = mfma_f64(a[ci], b[pi], acc[ci][pi]);
-    }
-  }
-  const long long t1 = clock64();
-  double sum = 0.0;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) sum += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
-  sink[(int64_t)blockIdx.x * blockDim.x + t] = sum;
-  if (lane == 0) cyc[blockIdx.x * (blockDim.x >> 6) + w] = t1 - t0;
-}
-
-// streaming read+write micro-benchmark (y = x + 1 on double2)
-__global__ __launch_bounds__(256) void k_stream_bench(const double2 *__restrict__ x,
-                                                      double2 *__restrict__ y, int64_t n2) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += stride) {
-    double2 v = x[e];
-    v.x += 1.0;
-    v.y += 1.0;
-    y[e] = v;
-  }
-}

@@ -64,6 +64,28 @@ static void mg_worker(dhqr_mg *g, int r) {
 
 // Run job(rank) on every rank thread; returns the first failure (its message becomes the caller's last error).
 static int32_t mg_run(dhqr_mg *g, std::function<int32_t(int)> job) {
+  // A failed job leaves the abort flag of the in-process transport set (peers stop waiting) and the ranks' collective
+  // counters out of step.  Every rank thread is idle here: restart the mailbox from a clean state, otherwise one
+  // failure poisons the handle for ever.
+  for (auto &k : g->rk)
+    for (dhqr_comm *cm : {k.cm, k.cm ? k.cm->lane : nullptr})
+      if (cm && cm->world && cm->world->abort.load()) {
+        for (auto &k2 : g->rk) {
+          (void)hipSetDevice(k2.c->device);
+          (void)hipDeviceSynchronize();
+          for (dhqr_comm *c2 : {k2.cm, k2.cm ? k2.cm->lane : nullptr})
+            if (c2 && c2->world == cm->world) c2->seq = 0;
+        }
+        LocalWorld *w = cm->world;
+        for (int sidx = 0; sidx < DHQR_COMM_RING; ++sidx) {
+          w->slot[sidx].seq.store(-1);
+          w->slot[sidx].posted.store(0);
+          w->slot[sidx].pulled.store(0);
+          w->slot[sidx].need = 0;
+        }
+        w->bar_count.store(0);
+        w->abort.store(0);
+      }
   {
     std::lock_guard<std::mutex> lk(g->mu);
     g->job = std::move(job);

@@ -356,8 +356,15 @@ class MultiGpuQR:
         self._check(self.L.dhqr_mg_download_f64(self._h, H.ctypes.data_as(_P), self.m, al.ctypes.data_as(_P)))
         return H, al
 
+    def _host_vec(self, b, length, what):
+        """the C entry points take bare pointers: a short vector would be a host out-of-bounds read"""
+        b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1)
+        if b.size != length:
+            raise ValueError(f"{what} must have {length} elements, got {b.size}")
+        return b
+
     def solve(self, b):
-        b = np.ascontiguousarray(b, dtype=np.float64)
+        b = self._host_vec(b, self.m, "b")
         x = np.zeros(self.n)
         self._check(self.L.dhqr_mg_solve_f64(self._h, b.ctypes.data_as(_P), x.ctypes.data_as(_P)))
         return x
@@ -381,10 +388,11 @@ class MultiGpuQR:
         m, n = A.shape
         F = A if A.flags.f_contiguous else np.asfortranarray(A)
         x = np.zeros(n)
-        bb = np.ascontiguousarray(b, dtype=np.float64)
+        bb = self._host_vec(b, m, "b")
+        alpha = self._host_vec(alpha, n, "alpha")
         lda = F.strides[1] // 8 if n > 1 else max(m, 1)
         self._check(self.L.dhqr_mg_ldiv_f64(self._h, F.ctypes.data_as(_P), m, n, lda,
-                                            np.ascontiguousarray(alpha).ctypes.data_as(_P), bb.ctypes.data_as(_P),
+                                            alpha.ctypes.data_as(_P), bb.ctypes.data_as(_P),
                                             x.ctypes.data_as(_P)))
         self.m, self.n = m, n
         return x
@@ -410,6 +418,8 @@ class MultiGpuQR:
 
     def rs_upload(self, A):
         F = np.asfortranarray(A, dtype=np.float64)
+        if F.ndim != 2 or F.shape != (self.m, self.n):
+            raise ValueError(f"rs_upload: matrix must be {self.m} x {self.n} (rs_alloc), got {F.shape}")
         self._check(self.L.dhqr_mg_rs_transfer_f64(self._h, F.ctypes.data_as(_P), F.shape[0], None, 1))
         return self
 
@@ -420,7 +430,7 @@ class MultiGpuQR:
         return H, al
 
     def rs_solve(self, b):
-        b = np.ascontiguousarray(b, dtype=np.float64)
+        b = self._host_vec(b, self.m, "b")
         x = np.zeros(self.n)
         self._check(self.L.dhqr_mg_rs_solve_f64(self._h, b.ctypes.data_as(_P), x.ctypes.data_as(_P)))
         return x

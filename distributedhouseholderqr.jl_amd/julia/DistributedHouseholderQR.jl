@@ -219,6 +219,7 @@ end
 # test/runtests.jl:71-78).  Written against DistributedArrays' API (procs(A), localpart(A), size(A)); the package is
 # loaded by the caller exactly as with the reference.  `devices[i]` is the HIP device of the i-th worker of A.
 const _comm = Ref{Ptr{Cvoid}}(C_NULL)
+const _comm_key = Ref{Any}(nothing)   # (worker pids, devices) the cached communicator of this worker was built for
 
 "RCCL unique id (128 bytes): created on ONE worker, shipped to the others by the caller"
 function comm_unique_id()
@@ -227,13 +228,32 @@ function comm_unique_id()
   return id
 end
 
-"collective over the workers: bind this worker (rank `rank` of `nranks`, 0-based) to GPU `device`"
-function comm_init(id::Vector{UInt8}, nranks::Integer, rank::Integer, device::Integer)
+"does this worker already hold a communicator for `key` = (worker pids, devices)?  (qr! is called repeatedly, e.g. under
+@benchmark, test/runtests.jl:84: the RCCL bootstrap -- two ncclCommInitRank and the broadcast trial -- runs once per key)"
+comm_cached(key) = _comm[] != C_NULL && _comm_key[] == key
+
+"destroy this worker's communicator (also registered with atexit)"
+function comm_free()
+  if _comm[] != C_NULL
+    ccall((:dhqr_comm_destroy, libdhqr), Int32, (Ptr{Cvoid},), _comm[])
+    _comm[] = C_NULL
+    _comm_key[] = nothing
+  end
+  return nothing
+end
+
+"collective over the workers: bind this worker (rank `rank` of `nranks`, 0-based) to GPU `device`; replaces (and
+destroys) a communicator built for another set of workers / devices"
+function comm_init(id::Vector{UInt8}, nranks::Integer, rank::Integer, device::Integer, key=nothing)
+  first_time = _comm_key[] === nothing && _comm[] == C_NULL
+  comm_free()
   h = Ref{Ptr{Cvoid}}(C_NULL)
   check(ccall((:dhqr_comm_create_rank, libdhqr), Int32,
               (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}),
               h, context(device), Int32(nranks), Int32(rank), id))
   _comm[] = h[]
+  _comm_key[] = key
+  first_time && atexit(comm_free)
   return nothing
 end
 
@@ -253,10 +273,13 @@ function __init_darray_methods__(DistributedArrays)
       ws = vec(procs(A))
       np = length(ws)
       m, n = size(A)
-      devs = devices === nothing ? collect(0:np-1) : devices
-      id = remotecall_fetch(comm_unique_id, ws[1])                       # replaces the SharedArray bootstrap (src:301-304)
-      @sync for (i, p) in enumerate(ws)                                  # ncclCommInitRank is collective
-        @async remotecall_wait(comm_init, p, id, np, i - 1, devs[i])
+      devs = devices === nothing ? collect(0:np-1) : collect(devices)
+      key = (ws, devs)
+      if !all(remotecall_fetch(comm_cached, p, key) for p in ws)         # bootstrap once per (workers, devices), not per call
+        id = remotecall_fetch(comm_unique_id, ws[1])                     # replaces the SharedArray bootstrap (src:301-304)
+        @sync for (i, p) in enumerate(ws)                                # ncclCommInitRank is collective
+          @async remotecall_wait(comm_init, p, id, np, i - 1, devs[i], key)
+        end
       end
       futs = [remotecall(p) do                                           # ONE call per worker (src:115-120 visits owners
                 al = zeros(Float64, n)                                   #   sequentially and fans out every column)

@@ -63,8 +63,10 @@ typedef struct dhqr_stats {
   double ms_solve;      /* Q'b + back substitution                             (src:215-294)  */
   int64_t n_panel, n_tbuild, n_gemm_vta, n_gemm_tw, n_gemm_avw, n_rank1, n_solve; /* launches */
   double flops_gemm_vta, flops_gemm_avw; /* algorithmic flops issued by the two trailing GEMMs */
-  double bytes_rank1;                    /* algorithmic bytes (16 B / trailing element / reflector) */
-  double bytes_panel;                    /* same accounting for the in-panel rank-1 updates */
+  double bytes_rank1;                    /* HBM bytes of the nb = 0 launches AS IMPLEMENTED: 16 B per element of every column a
+                                          * pass loads and stores once; a pass applies K reflectors (K = 5 where a column
+                                          * fits 8192 rows), i.e. 16/K B per trailing element and reflector */
+  double bytes_panel;                    /* algorithmic bytes of the panel-lane launches (16 B per element touched) */
 } dhqr_stats;
 
 /* ------------------------------------------------------------------ library / context */
@@ -120,11 +122,15 @@ int32_t dhqr_fill_uniform_f64(dhqr_ctx *ctx, double *dA, int64_t rows, int64_t c
 /* ------------------------------------------------------------------ factorisation
  * dhqr_factor_f64: device-resident replacement of householder!(A, alpha) (src:113, src:122-148,
  * src:198-213) for one GPU.  In place on dA (m x n, m >= n), writes dalpha[0:n].
- *   nb == 0      : unblocked path -- per column one fused kernel (reflector build + rank-1
- *                  trailing update), the reference's algorithm verbatim (BASELINE config 2).
+ *   nb == 0      : unblocked path (BASELINE configs[1]) -- the reference's operations in the reference's order
+ *                  (src:129-143, 208-209: each dot product over the column as updated so far); a launch applies K
+ *                  consecutive reflectors to every trailing column it loads once (K = 5 where a column fits 8192
+ *                  rows, K = 2 above) and builds the next K reflectors in its lead workgroup.
  *   nb == DHQR_NB: blocked path -- panel factorisation + compact-WY trailing update
- *                  A -= V * (T' * (V' * A)) on FP64 MFMA (BASELINE config 3).
- * Async on the ctx stream. */
+ *                  A -= V * (T' * (V' * A)) on FP64 MFMA (BASELINE configs[2]).
+ * nb == 0 is asynchronous on the ctx stream.  nb == DHQR_NB enqueues the whole factorisation without host
+ * synchronisation and then waits ONCE for the device-side panel verification word (a rejected panel is redone by the
+ * robust ladder before returning): synchronous on return. */
 int32_t dhqr_factor_f64(dhqr_ctx *ctx, double *dA, int64_t m, int64_t n, int64_t lda,
                         double *dalpha, int32_t nb);
 
@@ -368,38 +374,7 @@ int32_t dhqr_mg_rs_residual_f64(dhqr_mg *mg, uint64_t seed, double *hrel);
 int32_t dhqr_mg_rs_transfer_f64(dhqr_mg *mg, double *hA, int64_t lda, double *halpha, int32_t upload);
 int32_t dhqr_mg_rs_solve_f64(dhqr_mg *mg, const double *hb, double *hx);
 
-/* ------------------------------------------------------------------ micro-benchmarks
- * Device ceilings measured on the box itself (bench.py reports them next to the spec peaks):
- * FP64 MFMA issue-bound TFLOP/s (v_mfma_f64_16x16x4_f64 only) and a read+write streaming
- * copy in GB/s over `bytes` bytes. Synchronous. */
-int32_t dhqr_bench_mfma_f64(dhqr_ctx *ctx, double *tflops);
-int32_t dhqr_bench_stream_f64(dhqr_ctx *ctx, int64_t bytes, double *gbps);
-/* Issue-rate probe in shader cycles (s_memtime, DVFS independent): kind 0 = v_mfma_f64_16x16x4_f64,
- * kind 1 = v_fma_f64; nblocks workgroups of 4 waves (one per SIMD), 16 independent chains per wave.
- * Returns mean cycles per instruction per wave and the wall-clock TFLOP/s of the launch. */
-int32_t dhqr_bench_issue_f64(dhqr_ctx *ctx, int32_t kind, int32_t nblocks, double *cycles_per_instr,
-                             double *tflops);
-
-/* ------------------------------------------------------------------ test hook
- * One v_mfma_f64_16x16x4_f64 with A[i][k] = da[i*4+k], B[k][j] = db[k*16+j], C = 0, operands
- * loaded with the lane maps documented in csrc/dhqr_gemm.h; dout[lane*4+g] = raw D register g.
- * tests/test_gpu_kernels.py uses it to pin the f64 C/D fragment layout on the device. Synchronous. */
-int32_t dhqr_debug_mfma_probe(dhqr_ctx *ctx, const double *da, const double *db, double *dout);
-
-/* Probe 2: `threads`/256 waves per SIMD; mode 0 all-MFMA, 1 all-v_fma_f64, 2 mixed (waves 0-3 MFMA,
- * rest VALU).  out4 = {cycles/MFMA/wave, cycles/v_fma_f64/wave, MFMA TFLOP/s, VALU TFLOP/s}. */
-int32_t dhqr_bench_issue2_f64(dhqr_ctx *ctx, int32_t mode, int32_t threads, int32_t nblocks, double *out4);
-
-/* GEMM micro-benchmark of the two wide trailing-update kernels on synthetic operands: kind 0 = C -= [V_a V_b] W
- * (k_gemm_nn_sub, K = 256), kind 1 = Y = [V_a V_b]' C (k_gemm_tn2); rows, ncols multiples of 128.
- * out4 = {ms per launch, TFLOP/s, shader clock in MHz sustained under the kernel (one-wave s_memtime probe on a
- * second stream), 0}.  Synchronous. */
-int32_t dhqr_bench_gemm_f64(dhqr_ctx *ctx, int32_t kind, int64_t rows, int64_t ncols, int32_t reps, double *out4);
-/* MFMA cadence probe: the GEMM kernels' inner loop (4 x 4 MFMA tiles per wave, fragments from LDS) alone; mode 0 register
- * operands, 1 k-contiguous LDS layout stride 18 (merged ds_read2_b64), 2 same with plain ds_read_b64, 3 stride 17,
- * 4 the NN kernel's operand layouts; threads = 256 / 512 (one / two waves per SIMD).
- * out2 = {cycles per MFMA per wave, TFLOP/s}.  Synchronous. */
-int32_t dhqr_bench_mma_probe_f64(dhqr_ctx *ctx, int32_t mode, int32_t threads, double *out2);
+/* Micro-benchmarks and the MFMA layout probe are NOT part of this library: include/dhqr_bench.h, libdhqr_bench.so. */
 
 #ifdef __cplusplus
 }

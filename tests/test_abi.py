@@ -25,6 +25,22 @@ def test_header_symbols_exported(pkg):
     assert sorted(pkg._lib.SIGNATURES) == names
 
 
+def test_micro_benchmarks_are_not_in_the_product_library(pkg):
+    """include/dhqr_bench.h is exported by libdhqr_bench.so (a superset build) and by it alone"""
+    pkg.build()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dhqr_bench.h")).read(), flags=re.S)
+    bench = sorted(set(re.findall(r"\b(dhqr_[a-z0-9_]+)\s*\(", src)))
+    assert sorted(pkg._lib.BENCH_SIGNATURES) == bench and len(bench) >= 7
+    L, B = ctypes.CDLL(pkg._lib.SO_PATH), ctypes.CDLL(pkg._lib.BENCH_SO_PATH)
+    import subprocess
+    exported = subprocess.run(["nm", "-D", "--defined-only", pkg._lib.SO_PATH], capture_output=True, text=True).stdout
+    assert "dhqr_bench_" not in exported and "dhqr_debug_" not in exported
+    for n in bench + _declared():
+        assert hasattr(B, n), f"libdhqr_bench.so does not export {n}"
+    for n in bench:
+        assert not hasattr(L, n)
+
+
 def test_layout_constants_match_the_header(pkg):
     hdr = open(os.path.join(ROOT, "include", "dhqr.h")).read()
     macro = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(DHQR_NB|DHQR_CS_BLOCK|DHQR_ZNB)\s+(\d+)", hdr)}

@@ -14,6 +14,13 @@ import pytest
 import scipy.linalg as sl
 
 pytestmark = pytest.mark.gpu
+
+
+def TOL(H):
+    """element-wise tolerance of a factorisation against the oracle's, relative to max|H|: 8 n eps (n = columns = number of
+    dependent reflector steps; summation order differs from the reference's @simd, never bitwise).  Measured agreement is
+    1e-15 ... 1e-14, so a wrong summation (a dropped term, a float accumulator) fails."""
+    return 8.0 * max(int(H.shape[1]), 8) * np.finfo(np.float64).eps
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 REF_SHAPES = [(110, 100), (220, 200), (440, 400), (880, 800), (1100, 1000), (2200, 2000), (4400, 4000)]
 
@@ -52,8 +59,8 @@ def test_golden_fixtures_complex_host_dropin(pkg, orc, path):
     H = pkg.qr_(A)
     assert H.A is A and H.α.dtype == np.complex128  # in place, complex alpha (src:306-309)
     scale = np.abs(g["H"]).max()
-    assert np.abs(A - g["H"]).max() <= 1e-11 * scale
-    assert np.abs(H.α - g["alpha"]).max() <= 1e-11 * scale
+    assert np.abs(A - g["H"]).max() <= TOL(g["H"]) * scale
+    assert np.abs(H.α - g["alpha"]).max() <= TOL(g["H"]) * scale
     b = orc.rand_vector_c(m, seed + 1)
     b0 = b.copy()
     x = pkg.ldiv(H, b)
@@ -75,8 +82,8 @@ def test_device_path_vs_oracle(pkg, orc, m, n):
     Ho, ao = orc.householder_c(A0)
     scale = np.abs(Ho).max()
     Hd, ad = H.A.cpu().numpy(), H.α.cpu().numpy()
-    assert np.abs(Hd - Ho).max() <= 1e-11 * scale
-    assert np.abs(ad - ao).max() <= 1e-11 * scale
+    assert np.abs(Hd - Ho).max() <= TOL(Ho) * scale
+    assert np.abs(ad - ao).max() <= TOL(Ho) * scale
     QR = orc.form_qr_c(np.asfortranarray(Hd), ad)
     assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-12
     # solve on the device, b untouched
@@ -86,6 +93,46 @@ def test_device_path_vs_oracle(pkg, orc, m, n):
     assert torch.equal(b, b0)
     xo = orc.solve_c(Ho, ao, b0.cpu().numpy())
     assert np.abs(x.cpu().numpy() - xo).max() <= 1e-11 * max(1.0, np.linalg.cond(A0)) * np.abs(xo).max()
+
+
+def _single_draw_ratio(pkg, orc, m, n, seed, nb):
+    """the reference's own statistic (test/runtests.jl:49-62), one draw, evaluated in double exactly as written there:
+    norm(A' * A * x2 .- A' * b) / norm(A' * A * x1 .- A' * b) with x1 from LAPACK's QR"""
+    A = orc.rand_matrix_c(m, n, seed)
+    b = orc.rand_vector_c(m, seed + 1)
+    q, r = np.linalg.qr(A)
+    x1 = sl.solve_triangular(r, q.conj().T @ b)
+    Ah = A.conj().T
+    stdliberr = np.linalg.norm(Ah @ (A @ x1) - Ah @ b)
+    H = pkg.qr_(A.copy(order="F"), nb=nb)
+    x2 = np.asarray(pkg.ldiv(H, b))
+    return np.linalg.norm(Ah @ (A @ x2) - Ah @ b) / stdliberr
+
+
+@pytest.mark.parametrize("m,n", REF_SHAPES)
+def test_reference_single_draw_seed0_default_path(pkg, orc, m, n):
+    """test/runtests.jl:62 LITERALLY: one draw (seed 0), residuals in double, `< 8 stdliberr`, for the path qr_(A) takes
+    by default (nb=None: blocked from n >= 256).  Shapes below 2000 columns pass with a wide margin and are asserted.  On
+    the two largest shapes the statistic is a ratio of two rounding-noise norms whose value moves between 4 and 17 with the
+    summation order of ANY step (the oracle's own restatement of the reference lands between 2.3 and 3.8 at 1100 x 1000 from
+    the order of one dot product): recorded as xfail(strict=False), so the report shows which draws
+    miss instead of hiding them behind a median."""
+    ratio = _single_draw_ratio(pkg, orc, m, n, 0, None)
+    print(f"single draw, seed 0, default path, {m}x{n}: ratio {ratio:.2f} (reference bound 8)")
+    if n >= 2000 and not ratio < 8:
+        pytest.xfail(f"single-draw ratio {ratio:.2f} >= 8 at {m}x{n} (noise-dominated statistic; median test below)")
+    assert ratio < 8, ratio
+
+
+@pytest.mark.parametrize("seed", [0, 2, 4, 6, 8])
+@pytest.mark.parametrize("nb", [0, 64])
+def test_reference_single_draws_largest_shape_recorded(pkg, orc, seed, nb):
+    """every draw of the multi-seed tests below as its own literal `< 8` check on the reference's largest shape: xfail
+    (strict=False) when a draw misses, so the record lists the misses per seed and path"""
+    ratio = _single_draw_ratio(pkg, orc, 4400, 4000, seed, nb)
+    print(f"single draw, seed {seed}, nb={nb}, 4400x4000: ratio {ratio:.2f}")
+    if not ratio < 8:
+        pytest.xfail(f"seed {seed} nb={nb}: ratio {ratio:.2f} >= 8")
 
 
 @pytest.mark.parametrize("m,n", REF_SHAPES)
@@ -121,7 +168,7 @@ def test_reference_acceptance_inequality_complex(pkg, orc, m, n):
 
 
 @pytest.mark.parametrize("m,n", [(300, 200), (1100, 1000), (2100, 2048), (5000, 130)])
-def test_blocked_complex_vs_oracle_and_unblocked(pkg, orc, m, n):
+def test_blocked_complex_vs_oracle(pkg, orc, m, n):
     """nb = 64: panels by the unblocked complex kernels, trailing update by the FP64 MFMA kernels on the real embedding of
     the 64 complex reflectors (dhqr_factor_c64_nb): the reference's factorisation, element by element"""
     import torch
@@ -130,19 +177,13 @@ def test_blocked_complex_vs_oracle_and_unblocked(pkg, orc, m, n):
     H = pkg.qr_(A, nb=64)
     torch.cuda.synchronize()
     Hd, ad = H.A.cpu().numpy(), H.α.cpu().numpy()
-    if n <= 1000:
-        Ho, ao = orc.householder_c(A0)
-    else:  # the device's own unblocked path (itself oracle-checked above) as the comparator at larger sizes
-        A2 = pkg.rand_colmajor_c(m, n, 3, "cuda:0")
-        H2 = pkg.qr_(A2, nb=0)
-        torch.cuda.synchronize()
-        Ho, ao = H2.A.cpu().numpy(), H2.α.cpu().numpy()
+    Ho, ao = orc.householder_c(A0)  # the reference restatement at every size (2100 x 2048: ~1 min on the host cores)
     scale = np.abs(Ho).max()
     # two backward-stable orderings of the same factorisation agree element-wise to ~ kappa(A) * eps, not to eps: the
     # nearly square 2100 x 2048 case has kappa = 5.8e3 and differs by 6e-12 (H) / 2.3e-11 (alpha) in its LAST columns
     # while ||A - QR|| / ||A|| and the solution are equally accurate for both (profiles/r02_c64_blocked_accuracy.txt)
     kappa = np.linalg.cond(A0) if n > 1000 else 1.0
-    tol = max(1e-11, 64 * kappa * np.finfo(float).eps)
+    tol = max(TOL(Ho), 64 * kappa * np.finfo(float).eps)
     assert np.abs(Hd - Ho).max() <= tol * scale, np.abs(Hd - Ho).max() / scale
     assert np.abs(ad - ao).max() <= tol * scale
     QR = orc.form_qr_c(np.asfortranarray(Hd), ad)

@@ -2,7 +2,7 @@
 
 Tolerances: the reference accumulates with @simd (order unspecified, src:45); the GPU uses
 wavefront trees / MFMA chains, so element-wise agreement is to rounding, not bitwise:
-  |dH|, |dalpha| <= 1e-11 * max|H|   (c*n*eps with n <= 4000),  ||A-QR||_F/||A||_F < 1e-12
+  |dH|, |dalpha| <= 8 n eps * max|H|  (TOL below: 1.8e-13 at n = 100, 7e-12 at n = 4000),  ||A-QR||_F/||A||_F < 1e-12
 (the north-star tolerance), and the reference's own acceptance inequality
   ||A'A x - A'b|| < 8 * (same for LAPACK QR)      (test/runtests.jl:61-63).
 """
@@ -14,6 +14,13 @@ import pytest
 import scipy.linalg as sl
 
 pytestmark = pytest.mark.gpu
+
+
+def TOL(H):
+    """element-wise tolerance of a factorisation against the oracle's, relative to max|H|: 8 n eps (n = columns = number of
+    dependent reflector steps; summation order differs from the reference's @simd, never bitwise).  Measured agreement is
+    1e-15 ... 1e-14, so a wrong summation (a dropped term, a float accumulator) fails."""
+    return 8.0 * max(int(H.shape[1]), 8) * np.finfo(np.float64).eps
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 REF_SHAPES = [(110, 100), (220, 200), (440, 400), (880, 800), (1100, 1000), (2200, 2000), (4400, 4000)]
 
@@ -34,8 +41,8 @@ def test_golden_fixtures(pkg, path, nb):
     m, n, seed = int(g["m"]), int(g["n"]), int(g["seed"])
     H, A0 = _factor_dev(pkg, m, n, seed, nb)
     scale = np.abs(g["H"]).max()
-    assert np.abs(H.A.cpu().numpy() - g["H"]).max() <= 1e-11 * scale
-    assert np.abs(H.α.cpu().numpy() - g["alpha"]).max() <= 1e-11 * scale
+    assert np.abs(H.A.cpu().numpy() - g["H"]).max() <= TOL(g["H"]) * scale
+    assert np.abs(H.α.cpu().numpy() - g["alpha"]).max() <= TOL(g["H"]) * scale
     b = pkg.rand_vector_device(m, seed + 1, "cuda:0")
     b0 = b.clone()
     x = pkg.ldiv(H, b)
@@ -55,8 +62,8 @@ def test_unblocked_vs_oracle(pkg, orc, m, n):
     H, A0 = _factor_dev(pkg, m, n, 3, 0)
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 3))
     scale = np.abs(Ho).max()
-    assert np.abs(H.A.cpu().numpy() - Ho).max() <= 1e-11 * scale
-    assert np.abs(H.α.cpu().numpy() - ao).max() <= 1e-11 * scale
+    assert np.abs(H.A.cpu().numpy() - Ho).max() <= TOL(Ho) * scale
+    assert np.abs(H.α.cpu().numpy() - ao).max() <= TOL(Ho) * scale
     assert pkg.residual(H, A0) < 1e-12
 
 
@@ -71,8 +78,8 @@ def test_unblocked_reflectors_per_pass(pkg, orc, m, n, K, monkeypatch):
         H, A0 = _factor_dev(pkg, m, n, 5, 0)
         Ho, ao = orc.householder(orc.rand_matrix(m, n, 5))
         scale = np.abs(Ho).max()
-        assert np.abs(H.A.cpu().numpy() - Ho).max() <= 1e-11 * scale
-        assert np.abs(H.α.cpu().numpy() - ao).max() <= 1e-11 * scale
+        assert np.abs(H.A.cpu().numpy() - Ho).max() <= TOL(Ho) * scale
+        assert np.abs(H.α.cpu().numpy() - ao).max() <= TOL(Ho) * scale
         assert pkg.residual(H, A0) < 1e-12
     finally:
         api._contexts.pop(0, None)
@@ -91,8 +98,8 @@ def test_blocked_with_panels_through_the_column_kernels(pkg, orc, m, n, monkeypa
         H, A0 = _factor_dev(pkg, m, n, 6, 128)
         Ho, ao = orc.householder(orc.rand_matrix(m, n, 6))
         scale = np.abs(Ho).max()
-        assert np.abs(H.A.cpu().numpy() - Ho).max() <= 1e-11 * scale
-        assert np.abs(H.α.cpu().numpy() - ao).max() <= 1e-11 * scale
+        assert np.abs(H.A.cpu().numpy() - Ho).max() <= TOL(Ho) * scale
+        assert np.abs(H.α.cpu().numpy() - ao).max() <= TOL(Ho) * scale
         assert pkg.residual(H, A0) < 1e-12
     finally:
         api._contexts.pop(0, None)
@@ -109,8 +116,8 @@ def test_blocked_vs_oracle(pkg, orc, m, n):
     H, A0 = _factor_dev(pkg, m, n, 4, 128)
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 4))
     scale = np.abs(Ho).max()
-    assert np.abs(H.A.cpu().numpy() - Ho).max() <= 1e-11 * scale
-    assert np.abs(H.α.cpu().numpy() - ao).max() <= 1e-11 * scale
+    assert np.abs(H.A.cpu().numpy() - Ho).max() <= TOL(Ho) * scale
+    assert np.abs(H.α.cpu().numpy() - ao).max() <= TOL(Ho) * scale
     assert pkg.residual(H, A0) < 1e-12
 
 
@@ -140,14 +147,14 @@ def test_host_in_host_out_drop_in(pkg, orc):
         Ah = A.copy(order="F")
         H = pkg.qr_(Ah, nb=nb)
         assert H.A is Ah  # in place like qr!
-        assert np.abs(Ah - Ho).max() <= 1e-11 * np.abs(Ho).max()
-        assert np.abs(H.α - ao).max() <= 1e-11 * np.abs(Ho).max()
+        assert np.abs(Ah - Ho).max() <= TOL(Ho) * np.abs(Ho).max()
+        assert np.abs(H.α - ao).max() <= TOL(Ho) * np.abs(Ho).max()
         x = pkg.ldiv(H, b)
         assert np.abs(x - orc.solve(Ho, ao, b)).max() <= 1e-9 * np.abs(x).max()
     # row-major caller: still factored "in place"
     Ac = np.ascontiguousarray(A)
     pkg.qr_(Ac, nb=128)
-    assert np.abs(Ac - Ho).max() <= 1e-11 * np.abs(Ho).max()
+    assert np.abs(Ac - Ho).max() <= TOL(Ho) * np.abs(Ho).max()
 
 
 def test_zero_pivot_matches_reference(pkg, orc):
@@ -171,14 +178,14 @@ def test_error_paths(pkg):
         pkg.qr_(torch.zeros((16, 8), dtype=torch.float64, device="cuda:0"))  # row-major tensor
 
 
-@pytest.mark.parametrize("n,nb", [(8192, 0), (8192, 128), (16384, 128)])
+@pytest.mark.parametrize("n,nb", [(8192, 0), (8192, 128), (16384, 128), (32768, 128)])
 def test_full_size_properties(pkg, n, nb):
-    """BASELINE-size checks through size-independent properties: ||A-QR||/||A|| < 1e-12,
-    ||v_j||^2 == 2 for every column, and Q'(Q b) == b."""
+    """BASELINE-size checks (32768 = configs[2], the headline configuration) through size-independent properties:
+    ||A-QR||/||A|| < 1e-12, ||v_j||^2 == 2 for every column, and Q'(Q b) == b."""
     import torch
     A = pkg.rand_colmajor(n, n, 0, "cuda:0")
     H = pkg.qr_(A, nb=nb)
-    v2 = torch.tril(H.A).pow(2).sum(dim=0)
+    v2 = torch.cat([torch.tril(H.A[:, c:c + 4096], diagonal=-c).pow(2).sum(dim=0) for c in range(0, n, 4096)])
     assert (v2 - 2.0).abs().max().item() < 1e-11
     A0 = pkg.rand_colmajor(n, n, 0, "cuda:0")
     assert pkg.residual(H, A0) < 1e-12
@@ -203,8 +210,8 @@ def test_column_cyclic_driver_single_rank(pkg, orc, m, n):
     H, alpha = q.local_numpy()
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 8))
     scale = np.abs(Ho).max()
-    assert np.abs(H - Ho).max() <= 1e-11 * scale
-    assert np.abs(alpha - ao).max() <= 1e-11 * scale
+    assert np.abs(H - Ho).max() <= TOL(Ho) * scale
+    assert np.abs(alpha - ao).max() <= TOL(Ho) * scale
     assert q.residual(8) < 1e-12
     b = orc.rand_vector(m, 9)
     x = q.solve(torch.tensor(b, device="cuda:0")).cpu().numpy()
@@ -225,7 +232,7 @@ def test_wide_tn_split_model_on_a_small_matrix(pkg, orc, monkeypatch):
         assert mg.residual(15) < 1e-12
         Ho, ao = orc.householder(orc.rand_matrix(m, n, 15))
         scale = np.abs(Ho).max()
-        assert np.abs(H - Ho).max() <= 1e-11 * scale and np.abs(alpha - ao).max() <= 1e-11 * scale
+        assert np.abs(H - Ho).max() <= TOL(Ho) * scale and np.abs(alpha - ao).max() <= TOL(Ho) * scale
     finally:
         mg.close()
 
@@ -249,8 +256,8 @@ def test_multi_device_handle_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
         if m <= 2304:
             Ho, ao = orc.householder(Ah)
             scale = np.abs(Ho).max()
-            assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
-            assert np.abs(alpha - ao).max() <= 1e-11 * scale
+            assert np.abs(H - Ho).max() <= TOL(Ho) * scale, np.abs(H - Ho).max()
+            assert np.abs(alpha - ao).max() <= TOL(Ho) * scale
             b = orc.rand_vector(m, 12)
             x = mg.solve(b)
             xo = orc.solve(Ho, ao, b)
@@ -285,7 +292,7 @@ def test_multi_device_host_drop_in_and_rejected_panel_gpu(pkg, orc, rung, monkey
         A1 = orc.rand_matrix(900, 520, 23)
         Ho, ao = orc.householder(A1)
         F, al = mg.qr_(A1.copy(order="F"))
-        assert np.abs(F - Ho).max() <= 1e-11 * np.abs(Ho).max()
+        assert np.abs(F - Ho).max() <= TOL(Ho) * np.abs(Ho).max()
         b = orc.rand_vector(900, 24)
         x = mg.ldiv(F, al, b)
         xo = orc.solve(Ho, ao, b)
@@ -313,7 +320,7 @@ def _rccl_one_rank(rank, P, m, n):
     q.fill(3).factor()
     H, alpha = q.local_numpy()
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 3))
-    assert np.abs(H - Ho).max() <= 1e-11 * np.abs(Ho).max()
+    assert np.abs(H - Ho).max() <= TOL(Ho) * np.abs(Ho).max()
     return True
 
 
@@ -329,8 +336,8 @@ def test_tall_skinny_single_gpu(pkg, orc):
     for nb in (0, 128):
         H, A0 = _factor_dev(pkg, m, n, 13, nb)
         scale = np.abs(Ho).max()
-        assert np.abs(H.A.cpu().numpy() - Ho).max() <= 1e-11 * scale
-        assert np.abs(H.α.cpu().numpy() - ao).max() <= 1e-11 * scale
+        assert np.abs(H.A.cpu().numpy() - Ho).max() <= TOL(Ho) * scale
+        assert np.abs(H.α.cpu().numpy() - ao).max() <= TOL(Ho) * scale
         assert pkg.residual(H, A0) < 1e-12
 
 
@@ -368,8 +375,8 @@ def test_tsqr_hr_as_the_source_of_every_panel_gpu(pkg, orc, m, n):
         assert fb == 0 and fast >= 1 and ctx.tsqr_count() == fast
         Ho, ao = orc.householder(orc.rand_matrix(m, n, 31))
         scale = np.abs(Ho).max()
-        assert np.abs(H.A.cpu().numpy() - Ho).max() <= 1e-11 * scale
-        assert np.abs(H.α.cpu().numpy() - ao).max() <= 1e-11 * scale
+        assert np.abs(H.A.cpu().numpy() - Ho).max() <= TOL(Ho) * scale
+        assert np.abs(H.α.cpu().numpy() - ao).max() <= TOL(Ho) * scale
         assert pkg.residual(H, A0) < 1e-12
     finally:
         ctx.set_r_source(1)
@@ -454,8 +461,8 @@ def test_row_split_driver_single_rank(pkg, orc, m, n):
     H, alpha = q.local_numpy()
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 41))
     scale = np.abs(Ho).max()
-    assert np.abs(H - Ho).max() <= 1e-11 * scale
-    assert np.abs(alpha - ao).max() <= 1e-11 * scale
+    assert np.abs(H - Ho).max() <= TOL(Ho) * scale
+    assert np.abs(alpha - ao).max() <= TOL(Ho) * scale
     assert q.residual(41) < 1e-12
     b = orc.rand_vector(m, 42)
     x = q.solve(torch.tensor(b, device="cuda:0")).cpu().numpy()
@@ -481,8 +488,8 @@ def test_row_split_logical_ranks_one_gpu(pkg, orc, ranks, m, n, tsqr, monkeypatc
         H, alpha = mg.rs_download()
         Ho, ao = orc.householder(Ah)
         scale = np.abs(Ho).max()
-        assert np.abs(H - Ho).max() <= 1e-11 * scale, np.abs(H - Ho).max()
-        assert np.abs(alpha - ao).max() <= 1e-11 * scale
+        assert np.abs(H - Ho).max() <= TOL(Ho) * scale, np.abs(H - Ho).max()
+        assert np.abs(alpha - ao).max() <= TOL(Ho) * scale
         assert mg.rs_residual(43) < 1e-12
         b = orc.rand_vector(m, 44)
         x = mg.rs_solve(b)
@@ -551,8 +558,8 @@ def test_panel_kernels_keep_every_panel_on_the_fast_path(pkg, orc):
             assert (f1 - f0, b1 - b0) == (n // 128, 0)
             Ho, ao = orc.householder(orc.rand_matrix(m, n, 4))
             scale = np.abs(Ho).max()
-            assert np.abs(A.cpu().numpy() - Ho).max() <= 1e-11 * scale
-            assert np.abs(alpha.cpu().numpy() - ao).max() <= 1e-11 * scale
+            assert np.abs(A.cpu().numpy() - Ho).max() <= TOL(Ho) * scale
+            assert np.abs(alpha.cpu().numpy() - ao).max() <= TOL(Ho) * scale
     finally:
         ctx.close()
 
@@ -584,8 +591,8 @@ def test_darray_front_end_single_gpu(pkg, orc):
     torch.cuda.synchronize()
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 61))
     scale = np.abs(Ho).max()
-    assert np.abs(A.cpu().numpy() - Ho).max() <= 1e-11 * scale
-    assert np.abs(alpha.cpu().numpy() - ao).max() <= 1e-11 * scale
+    assert np.abs(A.cpu().numpy() - Ho).max() <= TOL(Ho) * scale
+    assert np.abs(alpha.cpu().numpy() - ao).max() <= TOL(Ho) * scale
     b = orc.rand_vector(m, 62)
     x = q.solve(torch.tensor(b, device="cuda:0")).cpu().numpy()
     xo = orc.solve(Ho, ao, b)
@@ -598,8 +605,8 @@ def test_full_size_r_and_tau_pinned_against_lapack(pkg, n, nb):
     """R (strict upper part of H + alpha on the diagonal) and tau_j = v_jj^2 of a FULL-SIZE factorisation against
     LAPACK dgeqrf on the host cores (scipy): for real matrices the reference's factorisation equals LAPACK's with
     v_lapack = v / v_jj (for m == n LAPACK does not reflect the last column: tau_n = 0 and
-    R[n,n] has the opposite sign).  Tolerance: 1e-10 * max|R| element-wise -- the blocked MFMA path sums in a
-    different order from dgeqrf, n reaches 16384 and cond(A) ~ n for U[0,1) entries."""
+    R[n,n] has the opposite sign).  Tolerance: 8 n eps * max|R| element-wise (1.5e-11 at 8192; measured 4e-15) -- the
+    blocked MFMA path sums in a different order from dgeqrf and cond(A) ~ n for U[0,1) entries."""
     import scipy.linalg as sl
     import torch
     A = pkg.rand_colmajor(n, n, 0, "cuda:0")
@@ -616,7 +623,8 @@ def test_full_size_r_and_tau_pinned_against_lapack(pkg, n, nb):
     vjj = np.diag(Hh)
     dt = np.abs(vjj[:-1] ** 2 - tau[:-1]).max()
     print(f"n={n} nb={nb}: |dR|={dR / scale:.2e} |d diag|={dd / scale:.2e} |v_jj^2 - tau|={dt:.2e} (relative to max|R_jj|={scale:.1f})")
-    assert dR <= 1e-10 * scale and dd <= 1e-10 * scale and dt <= 1e-10
+    tol = 8.0 * n * np.finfo(np.float64).eps
+    assert dR <= tol * scale and dd <= tol * scale and dt <= tol
     assert abs(abs(al[-1]) - abs(qr_l[-1, -1])) <= 1e-8 * scale  # same magnitude, sign convention differs (see above)
     # v itself: v_lapack = v / v_jj on a sample of columns
     for j in (0, n // 3, n - 2):
@@ -627,7 +635,8 @@ def test_full_size_r_and_tau_pinned_against_lapack(pkg, n, nb):
 def test_unblocked_8192_elementwise_against_oracle(pkg, orc):
     """BASELINE configs[1] in full: every entry of H and alpha of the 8192 x 8192 unblocked factorisation against the
     oracle's restatement of src:122-148,198-213 run on the host cores (OpenMP over the trailing columns like @batch;
-    ~0.7 TFLOP, tens of seconds).  Tolerance 1e-10 * max|H| (8192 dependent reflectors, different summation order)."""
+    ~0.7 TFLOP, tens of seconds).  Tolerance 8 n eps * max|H| = 1.5e-11 (8192 dependent reflectors, different summation
+    order; measured 1e-14)."""
     import torch
     n = 8192
     A = pkg.rand_colmajor(n, n, 0, "cuda:0")
@@ -640,4 +649,4 @@ def test_unblocked_8192_elementwise_against_oracle(pkg, orc):
     scale = np.abs(Ho).max()
     eH, ea = np.abs(Hh - Ho).max() / scale, np.abs(al - ao).max() / scale
     print(f"8192^2 unblocked vs oracle: |dH|={eH:.2e} |dalpha|={ea:.2e}")
-    assert eH <= 1e-10 and ea <= 1e-10
+    assert eH <= TOL(Ho) and ea <= TOL(Ho)

@@ -12,15 +12,15 @@ import __graft_entry__ as g  # noqa: E402
 
 def main():
     pkg = g.import_package()
-    L = pkg._lib.lib()
-    ctx = pkg.get_context(0)
+    L, _bh = pkg.bench_context(0)  # libdhqr_bench.so
+    ctx = type("BenchCtx", (), {"handle": _bh})
     tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("DHQR_")) or "default"
     args = sys.argv[1:]
     while len(args) >= 4:
         kind, rows_, ncols, reps = (int(x) for x in args[:4])
         args = args[4:]
         out = (ctypes.c_double * 4)()
-        pkg._lib.check(L.dhqr_bench_gemm_f64(ctx.handle, kind, rows_, ncols, reps, out))
+        pkg.bench_check(L, L.dhqr_bench_gemm_f64(ctx.handle, kind, rows_, ncols, reps, out))
         print(f"[{tag}] kind={'NN256' if kind == 0 else 'TN2'} {rows_}x{ncols}: {out[0]:.3f} ms/launch, {out[1]:.2f} TFLOP/s "
               f"({out[1] / 78.6:.3f} of 78.6), shader clock {out[2]:.0f} MHz", flush=True)
 

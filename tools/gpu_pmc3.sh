@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM byte counters of the 32768^2 blocked factorisation, final kernels of the round (torch-free driver, one counter per pass)
 # build first (cross-compiles without a GPU):
-#   hipcc -O2 -std=c++17 tools/pmc_driver.cpp -o tools/pmc_driver -L distributedhouseholderqr.jl_amd -ldhqr -Wl,-rpath,'$ORIGIN/../distributedhouseholderqr.jl_amd'
+#   hipcc -O2 -std=c++17 tools/pmc_driver.cpp -o tools/pmc_driver -L distributedhouseholderqr.jl_amd -ldhqr_bench -Wl,-rpath,'$ORIGIN/../distributedhouseholderqr.jl_amd'
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc4; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 D=$R/tools/pmc_driver

@@ -13,12 +13,12 @@ NAMES = {0: "register operands", 1: "LDS stride 18, ds_read2_b64 (as shipped)", 
 
 def main():
     pkg = g.import_package()
-    L = pkg._lib.lib()
-    ctx = pkg.get_context(0)
+    L, _bh = pkg.bench_context(0)  # libdhqr_bench.so
+    ctx = type("BenchCtx", (), {"handle": _bh})
     for threads in (256, 512):
         for mode in range(5):
             out = (ctypes.c_double * 2)()
-            pkg._lib.check(L.dhqr_bench_mma_probe_f64(ctx.handle, mode, threads, out))
+            pkg.bench_check(L, L.dhqr_bench_mma_probe_f64(ctx.handle, mode, threads, out))
             print(f"waves/SIMD={threads // 256} mode {mode} ({NAMES[mode]}): {out[0]:.1f} cycles/MFMA/wave, {out[1]:.1f} TFLOP/s", flush=True)
 
 
