@@ -62,6 +62,10 @@ struct dhqr_ctx {
   int rankk = 5;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..5; beyond 3 the further ones are held in LDS)
   int nn_tr64 = 1;               // narrow C -= V W products on 64-row tiles (DHQR_NN_TR64=0: always 128)
   int swizzle = 1;               // XCD-aware tile order in k_gemm_nn_sub (+1.5 % at 32768^2; DHQR_SWIZZLE=0 disables)
+  int ncu = 256;                 // compute units of the device
+  int spare_cus = 0;             // CUs the persistent wide GEMMs (k_gemm_tn2, k_gemm_nn2) leave free for the look-ahead lane's
+                                 // single-workgroup kernels and for RCCL's kernels (DHQR_SPARE_CUS; multiple of 8: one per XCD)
+  int nn2 = 1;                   // wide C -= V W on the persistent 256 x 128-tile kernel k_gemm_nn2 (DHQR_NN2=0: k_gemm_nn_sub)
   struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
   int cur_ws = 0;
   bool lookahead = true;
@@ -338,6 +342,36 @@ static void launch_nn_sub(dhqr_ctx *c, bool vec, dim3 grid, const double *V, int
     hipLaunchKernelGGL((k_gemm_nn_sub<1, KW, INIT0>), grid, dim3(256), 0, c->stream, V, ldv, W, ldw, C, ldc, rows, ncols,
                        swz, st, c->epoch);
 }
+
+// Wide C -= V W on the persistent kernel k_gemm_nn2 (dhqr_gemm.h): 8 S workgroups, S per XCD, S * 8 <= #CU - spare.
+// Block shape of the XCD-aware tile order: br x bc tiles with br * bc == S where possible, so that the S workgroups of an
+// XCD work on ONE block at a time (br V row-tiles + bc W column-tiles in its L2).
+template <int KW>
+static void launch_nn2(dhqr_ctx *c, const double *V, int64_t ldv, const double *W, int64_t ldw, double *C,
+                       int64_t ldc, int64_t rows, int64_t ncols, bool predicated) {
+  const int *st = predicated ? pred_stat(c) : nullptr;
+  const int64_t gx = (rows + 255) / 256, gy = (ncols + 127) / 128;
+  int S = (int)std::max<int64_t>(1, ((int64_t)c->ncu - c->spare_cus) / 8);
+  S = (int)std::min<int64_t>(S, std::max<int64_t>(1, (gx * gy + 7) / 8));  // small launches: no idle workgroups
+  int br = 1, bc = S;
+  double best = 1e300;
+  for (int r = 1; r <= S; ++r) {
+    if (S % r) continue;
+    const double cost = 2.0 * r + (double)(S / r);  // a V row-tile (256 rows) is twice a W column-tile (128 columns)
+    if (cost < best) { best = cost; br = r; bc = S / r; }
+  }
+  if (best > 3.0 * std::sqrt(2.0 * S) + 1.0) {  // S prime or nearly: 4 x 8 blocks, the workgroups drift across two blocks
+    br = 4;
+    bc = 8;
+  }
+  br = (int)std::min<int64_t>(br, gx);
+  bc = (int)std::min<int64_t>(bc, gy);
+  const dim3 grid((unsigned)(8 * S));
+  hipLaunchKernelGGL((k_gemm_nn2<KW>), grid, dim3(512), 0, c->stream, V, ldv, W, ldw, C, ldc, rows, ncols, br, bc, st, c->epoch);
+}
+
+// Workgroups of a persistent wide launch: one per CU, minus the CUs kept free for the lane / RCCL (ctx->spare_cus).
+static inline int64_t wide_slots(const dhqr_ctx *c) { return std::max<int64_t>(8, (int64_t)c->ncu - c->spare_cus); }
 
 // Split-K factor for k_gemm_tn: `ntiles` column tiles x ns row slabs should fill the 512 resident
 // workgroup slots (256 CUs x 2) in whole waves -- 765 workgroups on 512 slots run at 75 %.
@@ -846,7 +880,8 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   const int64_t ntiles = (ncols + 127) / 128;
   int64_t nsplit, rps;
   // k_gemm_tn2 workgroups have 512 threads and 110 KB of LDS: one per CU, 256 resident
-  pick_split(rows, ntiles, 256, ntiles <= 2 ? 256 : 64, &nsplit, &rps, 256, ntiles <= 2 ? 64 : 128);
+  const int64_t slots = wide_slots(c);
+  pick_split(rows, ntiles, slots, ntiles <= 2 ? 256 : 64, &nsplit, &rps, slots, ntiles <= 2 ? 64 : 128);
   if (ntiles >= c->tn_model_min_tiles && c->tn_model) {
     // Wide launches: k_gemm_tn2 runs ONE workgroup per CU, all of the same size, so a launch takes
     // ceil(ntiles * ns / 256) rounds of rows / ns rows each -- 224 column tiles at ns = 1..4 idle an eighth of the chip,
@@ -861,7 +896,7 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
       if (ns > 1 && ntiles * ns > 3072) break;  // partial buffer: at most 12 rounds (cs_prepare / rs_prepare size it for that)
       int64_t r = (rows + ns - 1) / ns;
       r = (r + G_KT - 1) / G_KT * G_KT;
-      const int64_t rounds = (ntiles * ns + 255) / 256;
+      const int64_t rounds = (ntiles * ns + slots - 1) / slots;
       const double est = (double)rounds * (double)r + (double)ns * (double)ncols * 4.79e-3 + 40.0 * (double)rounds;
       if (est < best) { best = est; bns = ns; }
     }
@@ -877,7 +912,8 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   CHECK(ensure(c, ws.w2, (size_t)ld2 * (size_t)ncols));
   const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(Vp);
   const int64_t wstride = ld2 * ncols;
-  const dim3 gtn((unsigned)ntiles, (unsigned)nsplit), gred((unsigned)((wstride + 63) / 64));
+  // k_gemm_tn2 is persistent: its workgroups loop over the (column tile, row slab) units
+  const dim3 gtn((unsigned)std::min<int64_t>(ntiles * nsplit, slots)), gred((unsigned)((wstride + 63) / 64));
 
   // Y = [V_a V_b]' C: ONE pass over C for both panels (stacked 256 x ncols result), then the split-K reduction
   CHECK(prof_begin(c, CAT_VTA));
@@ -920,7 +956,10 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
   dim3 grid((unsigned)gx, (unsigned)ntiles);
   if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
-  launch_nn_sub<256>(c, vec, grid, Vp, ldv, (const double *)ws.w2.p, ld2, C, ldc, rows, ncols, swz, true);
+  if (c->nn2 && vec && ntiles > 2 && aligned16(ws.w2.p))
+    launch_nn2<256>(c, Vp, ldv, (const double *)ws.w2.p, ld2, C, ldc, rows, ncols, true);
+  else
+    launch_nn_sub<256>(c, vec, grid, Vp, ldv, (const double *)ws.w2.p, ld2, C, ldc, rows, ncols, swz, true);
   CHECK(prof_end(c));
   if (c->profiling) {
     c->st.flops_gemm_vta += 2.0 * DHQR_NBV * ((double)rows + (double)rows_b) * (double)ncols;
@@ -1095,9 +1134,13 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_NN_TR64")) c->nn_tr64 = atoi(e) != 0;
     {
       int ncu = 0;
-      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0)
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) {
         c->rankk_wgs = ncu;
+        c->ncu = ncu;
+      }
     }
+    if (const char *e = getenv("DHQR_SPARE_CUS")) c->spare_cus = std::max(0, std::min(c->ncu - 8, atoi(e)));
+    if (const char *e = getenv("DHQR_NN2")) c->nn2 = atoi(e) != 0;
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_TN_MODEL")) c->tn_model = atoi(e) != 0;

@@ -327,7 +327,7 @@ int32_t dhqr_bench_stream_f64(dhqr_ctx *c, int64_t bytes, double *gbps) {
 }
 
 // GEMM micro-benchmark of the two wide trailing-update kernels on synthetic operands (not a product entry point):
-// kind 0: k_gemm_nn_sub<2,256> (C -= [V_a V_b] W, rows x ncols), kind 1: k_gemm_tn2 (Y = [V_a V_b]' C).
+// kind 0: k_gemm_nn2<2,256> (DHQR_NN2=0: k_gemm_nn_sub<2,256>) (C -= [V_a V_b] W, rows x ncols), kind 1: k_gemm_tn2 (Y = [V_a V_b]' C).
 // `reps` timed launches after one warm-up; a one-wave clock probe runs beside them on a second stream.
 // out = {ms per launch, TFLOP/s, shader MHz under the kernel, 0}.  The A/B switches of the context apply.
 int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t ncols, int32_t reps, double *out4) {
@@ -353,7 +353,7 @@ int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t nco
     const int64_t ntiles = ncols / 128, gx = rows / 128;
     int64_t nsplit = 1, rps = rows;
     if (kind == 1) {
-      pick_split(rows, ntiles, 256, ntiles <= 2 ? 256 : 64, &nsplit, &rps, 256);
+      pick_split(rows, ntiles, wide_slots(c), ntiles <= 2 ? 256 : 64, &nsplit, &rps, wide_slots(c));
       HIPCHECK(hipMalloc((void **)&Y, (size_t)nsplit * ld2 * ncols * 8));
     }
     bool timed_nn = false;
@@ -365,10 +365,12 @@ int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t nco
         if (timed_nn)
           hipLaunchKernelGGL((k_gemm_nn_sub<2, 256, false, true>), grid, dim3(256), 0, c->stream, (const double *)V, ldv,
                              (const double *)W, ld2, C, ldc, rows, ncols, swz, (const int *)nullptr, 0);
+        else if (c->nn2)  // the kernel the wide updates use (persistent, 256 x 128 tiles)
+          launch_nn2<256>(c, V, ldv, W, ld2, C, ldc, rows, ncols, false);
         else
           launch_nn_sub<256>(c, true, grid, V, ldv, W, ld2, C, ldc, rows, ncols, swz, false);
       } else {
-        hipLaunchKernelGGL((k_gemm_tn2<2>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(512), 0, c->stream, V, ldv,
+        hipLaunchKernelGGL((k_gemm_tn2<2>), dim3((unsigned)std::min<int64_t>(ntiles * nsplit, wide_slots(c))), dim3(512), 0, c->stream, V, ldv,
                            (const double *)C, ldc, rows, ncols, rps, Y, ld2 * ncols);
       }
     };

@@ -3,6 +3,8 @@
 // wave-synchronously with the documented operand maps.  Workgroups are independent and run in sequence.
 //   emu_gemm tn <vec> <nbv> <rows> <ncols> <ldv> <ldc> <rps> V C out          out: nsplit x (nbv... ld 128) x ncols
 //   emu_gemm nn <vec> <kw>  <rows> <ncols> <ldv> <ldc> <swz> V W Cin Cout     W: ld = kw
+//   emu_gemm nn2 <vec> <kw> <rows> <ncols> <ldv> <ldc> <100 br + bc> V W Cin Cout <S>   persistent kernel, 8 S workgroups
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -58,9 +60,21 @@ int main(int argc, char **argv) {
     const int nsplit = (int)((rows + rps - 1) / rps), ntiles = (int)((ncols + 127) / 128);
     const int64_t ostride = 256 * ncols;
     std::vector<double> out((size_t)nsplit * ostride, -7.0);
-    if (vec == 2) grid2(ntiles, nsplit, 512, [&] { k_gemm_tn2<2>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride); });
-    else grid2(ntiles, nsplit, 512, [&] { k_gemm_tn2<1>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride); });
+    // persistent: fewer workgroups than units, so every workgroup loops (3 is coprime to most unit counts)
+    const int wgs = std::max(1, std::min(3, ntiles * nsplit - 1));
+    if (vec == 2) grid2(wgs, 1, 512, [&] { k_gemm_tn2<2>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride); });
+    else grid2(wgs, 1, 512, [&] { k_gemm_tn2<1>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride); });
     wr(argv[11], out);
+  } else if (op == "nn2") {  // persistent wide C -= V W (k_gemm_nn2): swz field = 100 * br + bc of the tile blocks, 8 * S workgroups
+    const int brbc = atoi(argv[8]);
+    auto V = rd(argv[9], (size_t)ldv * kparam);
+    auto W = rd(argv[10], (size_t)kparam * ncols);
+    auto C = rd(argv[11], (size_t)ldc * ncols);
+    const int br = brbc / 100, bc = brbc % 100, S = atoi(argv[13]);
+    if (vec == 2 && kparam == 256) grid2(8 * S, 1, 512, [&] { k_gemm_nn2<256>(V.data(), ldv, W.data(), (int64_t)256, C.data(), ldc, rows, ncols, br, bc, nullptr, 0); });
+    else if (vec == 2 && kparam == 128) grid2(8 * S, 1, 512, [&] { k_gemm_nn2<128>(V.data(), ldv, W.data(), (int64_t)128, C.data(), ldc, rows, ncols, br, bc, nullptr, 0); });
+    else return 2;
+    wr(argv[12], C);
   } else if (op == "nn") {
     const int swz = atoi(argv[8]);
     auto V = rd(argv[9], (size_t)ldv * kparam);

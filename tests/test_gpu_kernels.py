@@ -30,9 +30,9 @@ def test_mfma_layout_probe(pkg, torch_cuda):
     da = torch.tensor(A.reshape(-1), device="cuda:0")
     db = torch.tensor(B.reshape(-1), device="cuda:0")
     out = torch.zeros(256, dtype=torch.float64, device="cuda:0")
-    B, bh = pkg.bench_context(0)  # the probe lives in libdhqr_bench.so (same kernels source), not in the product library
+    BL, bh = pkg.bench_context(0)  # the probe lives in libdhqr_bench.so (same kernels source), not in the product library
     torch.cuda.synchronize()
-    pkg.bench_check(B, B.dhqr_debug_mfma_probe(bh, ctypes.c_void_p(da.data_ptr()), ctypes.c_void_p(db.data_ptr()),
+    pkg.bench_check(BL, BL.dhqr_debug_mfma_probe(bh, ctypes.c_void_p(da.data_ptr()), ctypes.c_void_p(db.data_ptr()),
                                                ctypes.c_void_p(out.data_ptr())))
     D = A @ B
     got = out.cpu().numpy().reshape(64, 4)

@@ -294,6 +294,32 @@ def test_gemm_nn_sub(emu_gemm, tmp_path, vec, kw, rows, ncols, swz):
     assert np.abs(Co - ref).max() < 1e-12   # the padding rows of C keep their value
 
 
+# (vec, kw, rows, ncols, br, bc, S): interior tiles only (streamed C); edge tiles both ways with a block grid that needs
+# padding; more workgroups than tiles; a two-row / one-column edge; one workgroup per XCD looping over many tiles; K = 128
+@pytest.mark.parametrize("vec,kw,rows,ncols,br,bc,S", [(2, 256, 512, 256, 2, 2, 1), (2, 256, 700, 300, 2, 2, 1),
+                                                       (2, 256, 300, 150, 4, 8, 2), (2, 256, 258, 129, 1, 1, 1),
+                                                       (2, 128, 520, 384, 3, 1, 1)])
+def test_gemm_nn2_persistent(emu_gemm, tmp_path, vec, kw, rows, ncols, br, bc, S):
+    """C -= V W on the persistent wide kernel (k_gemm_nn2: 512 threads, 256 x 128 tiles, 8 S workgroups looping over the
+    XCD-blocked tile list): every tile exactly once, padding rows of V / C never used or changed"""
+    rng = np.random.default_rng(2)
+    ldv, ldc = rows + rows % 2 + 2, rows + rows % 2 + 4
+    V = np.full((ldv, kw), 5.0)
+    V[:rows] = rng.standard_normal((rows, kw))
+    W = rng.standard_normal((kw, ncols))
+    C = np.full((ldc, ncols), 3.0)
+    C[:rows] = rng.standard_normal((rows, ncols))
+    f = {k: str(tmp_path / f"{k}.bin") for k in ("V", "W", "C", "Co")}
+    _put(f["V"], V)
+    _put(f["W"], W)
+    _put(f["C"], C)
+    _run(emu_gemm, "nn2", vec, kw, rows, ncols, ldv, ldc, 100 * br + bc, f["V"], f["W"], f["C"], f["Co"], S)
+    Co = _get(f["Co"], (ldc, ncols))
+    ref = C.copy()
+    ref[:rows] -= V[:rows] @ W
+    assert np.abs(Co - ref).max() < 1e-12
+
+
 # ------------------------------------------------------------------ memory safety of the new generations
 def test_new_panel_kernels_under_address_sanitizer(orc, tmp_path):
     """the panel kernels once more in an AddressSanitizer build of the emulator: no access outside

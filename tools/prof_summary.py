@@ -41,8 +41,31 @@ def by_stream(db, out, cmd=""):
     print("wrote", out, "rows:", len(rows))
 
 
+def per_launch(db, out, cmd=""):
+    """every launch of the wide stream's kernels in time order: start, duration, workgroups, gap to the previous kernel
+    of the same stream -- to see where a step's time goes launch by launch (tail effects, gaps between kernels)"""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute(
+        "select name, stream, start, end, grid_x*grid_y*grid_z/(workgroup_x*workgroup_y*workgroup_z), workgroup_x "
+        "from kernels order by start").fetchall()
+    last_end = {}
+    with open(out, "w", newline="") as f:
+        if cmd:
+            f.write(f"# rocprofv3 --kernel-trace -- {cmd}  (every launch)\n")
+        w = csv.writer(f)
+        w.writerow(["Name", "Stream", "StartNs", "DurationNs", "Workgroups", "Threads", "GapToPrevOnStreamNs"])
+        t0 = rows[0][2] if rows else 0
+        for name, stream, st, en, wgs, thr in rows:
+            gap = st - last_end[stream] if stream in last_end else 0
+            last_end[stream] = en
+            w.writerow([name.split("(")[0][:60], stream, st - t0, en - st, wgs, thr, gap])
+    print("wrote", out, "launches:", len(rows))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--by-stream":
+    if len(sys.argv) > 1 and sys.argv[1] == "--per-launch":
+        per_launch(*sys.argv[2:5])
+    elif len(sys.argv) > 1 and sys.argv[1] == "--by-stream":
         by_stream(*sys.argv[2:5])
     else:
         main(*sys.argv[1:4])
