@@ -61,11 +61,14 @@ struct dhqr_ctx {
   int rankk_wgs = 256;           // ... bulk workgroups of 1024 threads resident at once (CU count; DHQR_RANKK_WGS)
   int rankk = 5;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..5; beyond 3 the further ones are held in LDS)
   int nn_tr64 = 1;               // narrow C -= V W products on 64-row tiles (DHQR_NN_TR64=0: always 128)
+  int rankk_tall = 1;            // nb = 0, columns of 8192 < rows <= 16384: reflectors per pass (k_rankk_tall, <= 3; DHQR_RANKK_TALL=1: one per launch)
   int swizzle = 1;               // XCD-aware tile order in k_gemm_nn_sub (+1.5 % at 32768^2; DHQR_SWIZZLE=0 disables)
   int ncu = 256;                 // compute units of the device
   int spare_cus = 0;             // CUs the persistent wide GEMMs (k_gemm_tn2, k_gemm_nn2) leave free for the look-ahead lane's
                                  // single-workgroup kernels and for RCCL's kernels (DHQR_SPARE_CUS; multiple of 8: one per XCD)
-  int nn2 = 1;                   // wide C -= V W on the persistent 256 x 128-tile kernel k_gemm_nn2 (DHQR_NN2=0: k_gemm_nn_sub)
+  int quad = 1;                  // P == 1: two consecutive pairs applied in ONE K = 512 pass (quad_apply; DHQR_QUAD=0: pairs only)
+  int64_t quad_min_cols = 6144;  // ... while at least this many columns lie to the right of the quad (DHQR_QUAD_MIN_COLS)
+  int nn2 = 0;                   // wide C -= V W on the persistent 256 x 128-tile kernel k_gemm_nn2 (DHQR_NN2=0: k_gemm_nn_sub)
   struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
   int cur_ws = 0;
   bool lookahead = true;
@@ -190,6 +193,14 @@ static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
   hipLaunchKernelGGL((k_rankk_fused<T_, E_, VEC, K>),                                                    \
                      dim3((unsigned)(1 + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs * (rankk_lead_slots(T_, E_, K) > 0 ? 1 : 1024 / T_) - 1))), \
                      dim3(T_), 0, c->stream, P, ldp, rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha)
+#define DHQR_RKT(E_)                                                                                     \
+  hipLaunchKernelGGL((k_rankk_tall<1024, E_, VEC, K>),                                                    \
+                     dim3((unsigned)(1 + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs - 1))), dim3(1024), 0, c->stream, P, ldp, \
+                     rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha)
+  if constexpr (K <= 3) {  // columns of 8192 < rows <= 16384: factor_unblocked_cols passes K <= 3 there
+    if (cov > 1024 * 12) { DHQR_RKT(16); return; }
+    if (cov > 1024 * 8) { DHQR_RKT(12); return; }
+  }
   if (cov <= 256 * 2) DHQR_RK(256, 2);
   else if (cov <= 256 * 4) DHQR_RK(256, 4);
   else if (cov <= 256 * 8) DHQR_RK(256, 8);
@@ -200,6 +211,7 @@ static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
   else if (cov <= 896 * 8) DHQR_RK(896, 8);
   else DHQR_RK(1024, 8);
 #undef DHQR_RK
+#undef DHQR_RKT
 }
 static void launch_rankk(dhqr_ctx *c, bool vec, int K, double *P, int64_t ldp, int64_t rows, int64_t ncols, int64_t c0,
                          int64_t jlo, int kold, const double *vold, double *vnew, int64_t vlen, double *alpha) {
@@ -216,6 +228,7 @@ static void launch_rankk(dhqr_ctx *c, bool vec, int K, double *P, int64_t ldp, i
 static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64_t ncols,
                                      int64_t ldp, double *alpha, int cat) {
   const int K = c->rankk;  // reflectors per pass over the trailing columns (1: one launch per reflector)
+  const int Kt = std::min(K, c->rankk_tall);  // ... while a column has 8192 < rows <= 16384 (k_rankk_tall; < 2: one per launch)
   const size_t vlen = (size_t)((rows + 17) & ~(int64_t)15);
   CHECK(ensure(c, c->vbuf, 2 * (size_t)std::max(K, 1) * vlen));
   double *vset[2] = {c->vbuf.p, c->vbuf.p + (size_t)std::max(K, 1) * vlen};  // two sets of K reflectors
@@ -231,7 +244,8 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
   // reflector per launch, v_j / v_j+1 ping-pong between slot 0 of the two sets.
   int64_t j = 0;
   int cur = 0;
-  auto tall = [&](int64_t jj) { return K < 2 || rows - (vec ? (jj & ~(int64_t)1) : jj) > 1024 * 8; };
+  auto height = [&](int64_t jj) { return rows - (vec ? (jj & ~(int64_t)1) : jj); };
+  auto tall = [&](int64_t jj) { return K < 2 || height(jj) > (Kt >= 2 ? 1024 * 16 : 1024 * 8); };
   bool have_v = false;  // v_j built (in vset[cur][0])
   if (tall(0)) {
     CHECK(prof_begin(c, cat));
@@ -264,13 +278,14 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
     for (;;) {
       const int64_t c0 = jlo + kold;  // first column not yet final
       if (c0 >= ncols) break;
+      const int Kp = height(jlo) > 1024 * 8 ? Kt : K;  // reflectors this pass builds (and the next one applies)
       CHECK(prof_begin(c, cat));
-      launch_rankk(c, vec, K, P, ldp, rows, ncols, c0, jlo, kold, vset[cur], vset[cur ^ 1], (int64_t)vlen, alpha);
+      launch_rankk(c, vec, Kp, P, ldp, rows, ncols, c0, jlo, kold, vset[cur], vset[cur ^ 1], (int64_t)vlen, alpha);
       CHECK(prof_end(c));
-      account(jlo, kold == 0 ? std::min<int64_t>(K, ncols) : ncols - c0);
+      account(jlo, kold == 0 ? std::min<int64_t>(Kp, ncols) : ncols - c0);
       cur ^= 1;
       jlo = c0;
-      kold = K;
+      kold = Kp;
     }
   }
   LAUNCHCHECK();
@@ -483,7 +498,7 @@ static int32_t panel_apply(dhqr_ctx *c, const PanelBuf &pb, int64_t rows, double
     }                                                                                                \
     if (KW_ == DHQR_NBV && ntiles <= 2) /* the lane's narrow updates: k_tw_fused (dhqr_gemm.h) */    \
       hipLaunchKernelGGL((k_tw_fused<false>), dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, c->stream, w1sum, ncols, \
-                         TopT, (const double *)nullptr, (const double *)nullptr, ws.w2.p);              \
+                         TopT, (const double *)nullptr, (const double *)nullptr, ws.w2.p, (int64_t)DHQR_NBV); \
     else                                                                                             \
     hipLaunchKernelGGL((k_gemm_tn<2, 1, KW_>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top, \
                        (int64_t)DHQR_NBV, w1sum, (int64_t)DHQR_NBV, 1, (int64_t)0, (int64_t)KW_, ncols,  \
@@ -872,11 +887,11 @@ static int32_t factor_panel_sync(dhqr_ctx *c, double *P, int64_t rows, int64_t w
 // the cross-partition partial dots"), and V_b may start fewer than 128 rows below V_a on a rank that does not hold
 // the pair's diagonal blocks (statistics only).
 static int32_t comm_allreduce_sum(dhqr_comm *cm, double *dbuf, int64_t count, hipStream_t stream);
-static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows, const double *Ta,
-                          const double *Tb, const double *Sba, double *C, int64_t ncols, int64_t ldc,
-                          dhqr_comm *ar = nullptr, int64_t rows_b_in = -1) {
-  if (ncols <= 0) return DHQR_OK;
-  const int64_t rows_b = rows_b_in >= 0 ? rows_b_in : rows - DHQR_NBV;
+
+// Y (256 x ncols, ld 256) = [V_a V_b]' C: k_gemm_tn2 (ONE pass over C for both panels, split-K over row slabs into
+// ws.w1) + the deterministic split-K reduction.
+static int32_t pair_vtc(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows, const double *C, int64_t ldc,
+                        int64_t ncols, bool vec, double *Y) {
   const int64_t ntiles = (ncols + 127) / 128;
   int64_t nsplit, rps;
   // k_gemm_tn2 workgroups have 512 threads and 110 KB of LDS: one per CU, 256 resident
@@ -906,49 +921,66 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
     nsplit = std::max<int64_t>(1, (rows + r - 1) / r);
   }
   dhqr_ctx::WS &ws = c->ws[c->cur_ws];
-  const int64_t ld2 = 2 * DHQR_NBV;
-  CHECK(ensure(c, ws.w1, (size_t)nsplit * ld2 * (size_t)ncols));
-  CHECK(ensure(c, ws.w1r, (size_t)ld2 * (size_t)ncols));
-  CHECK(ensure(c, ws.w2, (size_t)ld2 * (size_t)ncols));
-  const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(Vp);
-  const int64_t wstride = ld2 * ncols;
+  const int64_t ld2 = 2 * DHQR_NBV, wstride = ld2 * ncols;
+  CHECK(ensure(c, ws.w1, (size_t)nsplit * (size_t)wstride));
   // k_gemm_tn2 is persistent: its workgroups loop over the (column tile, row slab) units
   const dim3 gtn((unsigned)std::min<int64_t>(ntiles * nsplit, slots)), gred((unsigned)((wstride + 63) / 64));
-
-  // Y = [V_a V_b]' C: ONE pass over C for both panels (stacked 256 x ncols result), then the split-K reduction
-  CHECK(prof_begin(c, CAT_VTA));
   if (vec)
-    hipLaunchKernelGGL((k_gemm_tn2<2>), gtn, dim3(512), 0, c->stream, Vp, ldv, (const double *)C, ldc, rows, ncols, rps,
-                       ws.w1.p, wstride);
+    hipLaunchKernelGGL((k_gemm_tn2<2>), gtn, dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, rps, ws.w1.p, wstride);
   else
-    hipLaunchKernelGGL((k_gemm_tn2<1>), gtn, dim3(512), 0, c->stream, Vp, ldv, (const double *)C, ldc, rows, ncols, rps,
-                       ws.w1.p, wstride);
-  hipLaunchKernelGGL(k_reduce_splits, gred, dim3(256), 0, c->stream, (const double *)ws.w1.p, (int)nsplit, wstride, wstride,
-                     ws.w1r.p);
-  CHECK(prof_end(c));
+    hipLaunchKernelGGL((k_gemm_tn2<1>), gtn, dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, rps, ws.w1.p, wstride);
+  hipLaunchKernelGGL(k_reduce_splits, gred, dim3(256), 0, c->stream, (const double *)ws.w1.p, (int)nsplit, wstride, wstride, Y);
+  return DHQR_OK;
+}
 
-  CHECK(prof_begin(c, CAT_TW));
-  if (ar) CHECK(comm_allreduce_sum(ar, ws.w1r.p, wstride, c->stream));
-  double *Ya = ws.w1r.p, *Yb = ws.w1r.p + DHQR_NBV;  // rows 0..127 / 128..255 of Y (ld 256)
+// The T products of a pair: W (rows 0..255 of a matrix with leading dimension ldw) from Y (256 x ncols, ld 256; its
+// lower half is overwritten):  W_a = T_a' Y_a,  Y_b -= (V_b' V_a) W_a,  W_b = T_b' Y_b.
+static int32_t pair_tw(dhqr_ctx *c, double *Y, const double *Ta, const double *Tb, const double *Sba, double *W,
+                       int64_t ldw, int64_t ncols) {
+  const int64_t ntiles = (ncols + 127) / 128, ld2 = 2 * DHQR_NBV;
+  double *Ya = Y, *Yb = Y + DHQR_NBV;  // rows 0..127 / 128..255 of Y
   if (ntiles <= 2) {
     // the lane's narrow update: all three T products in one launch (k_tw_fused, dhqr_gemm.h); T' of a panel sits right
     // behind its T in every operand buffer ([T | T' | alpha]: PanelBuf tails, row-split slots)
     const int64_t NN_ = (int64_t)DHQR_NBV * DHQR_NBV;
-    hipLaunchKernelGGL((k_tw_fused<true>), dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, c->stream, (const double *)ws.w1r.p, ncols,
-                       Ta + NN_, Tb + NN_, Sba, ws.w2.p);
-  } else {
-  // W_a = T_a' Y_a  -> rows 0..127 of W2 (ld 256)
-  hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Ta, (int64_t)DHQR_NBV,
-                     (const double *)Ya, ld2, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV, ws.w2.p, ld2,
-                     (int64_t)0);
-  // Y_b -= (V_b' V_a) W_a   (workspace: never predicated)
-  launch_nn_sub<128>(c, true, dim3(1, (unsigned)ntiles), Sba, (int64_t)DHQR_NBV, (const double *)ws.w2.p, ld2, Yb, ld2,
-                     (int64_t)DHQR_NBV, ncols, 0, false);
-  // W_b = T_b' Y_b  -> rows 128..255 of W2
-  hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Tb, (int64_t)DHQR_NBV,
-                     (const double *)Yb, ld2, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV,
-                     ws.w2.p + DHQR_NBV, ld2, (int64_t)0);
+    hipLaunchKernelGGL((k_tw_fused<true>), dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, c->stream, (const double *)Y, ncols,
+                       Ta + NN_, Tb + NN_, Sba, W, ldw);
+    return DHQR_OK;
   }
+  // W_a = T_a' Y_a  -> rows 0..127 of W
+  hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Ta, (int64_t)DHQR_NBV,
+                     (const double *)Ya, ld2, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV, W, ldw, (int64_t)0);
+  // Y_b -= (V_b' V_a) W_a   (workspace: never predicated)
+  launch_nn_sub<128>(c, true, dim3(1, (unsigned)ntiles), Sba, (int64_t)DHQR_NBV, (const double *)W, ldw, Yb, ld2,
+                     (int64_t)DHQR_NBV, ncols, 0, false);
+  // W_b = T_b' Y_b  -> rows 128..255 of W
+  hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Tb, (int64_t)DHQR_NBV,
+                     (const double *)Yb, ld2, 1, (int64_t)0, (int64_t)DHQR_NBV, ncols, (int64_t)DHQR_NBV, W + DHQR_NBV, ldw,
+                     (int64_t)0);
+  return DHQR_OK;
+}
+
+static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows, const double *Ta,
+                          const double *Tb, const double *Sba, double *C, int64_t ncols, int64_t ldc,
+                          dhqr_comm *ar = nullptr, int64_t rows_b_in = -1) {
+  if (ncols <= 0) return DHQR_OK;
+  const int64_t rows_b = rows_b_in >= 0 ? rows_b_in : rows - DHQR_NBV;
+  const int64_t ntiles = (ncols + 127) / 128;
+  dhqr_ctx::WS &ws = c->ws[c->cur_ws];
+  const int64_t ld2 = 2 * DHQR_NBV;
+  CHECK(ensure(c, ws.w1r, (size_t)ld2 * (size_t)ncols));
+  CHECK(ensure(c, ws.w2, (size_t)ld2 * (size_t)ncols));
+  const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(Vp);
+  const int64_t wstride = ld2 * ncols;
+
+  // Y = [V_a V_b]' C: ONE pass over C for both panels (stacked 256 x ncols result), then the split-K reduction
+  CHECK(prof_begin(c, CAT_VTA));
+  CHECK(pair_vtc(c, Vp, ldv, rows, C, ldc, ncols, vec, ws.w1r.p));
+  CHECK(prof_end(c));
+
+  CHECK(prof_begin(c, CAT_TW));
+  if (ar) CHECK(comm_allreduce_sum(ar, ws.w1r.p, wstride, c->stream));
+  CHECK(pair_tw(c, ws.w1r.p, Ta, Tb, Sba, ws.w2.p, ld2, ncols));
   CHECK(prof_end(c));
 
   CHECK(prof_begin(c, CAT_AVW));
@@ -965,6 +997,72 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
     c->st.flops_gemm_vta += 2.0 * DHQR_NBV * ((double)rows + (double)rows_b) * (double)ncols;
     c->st.flops_gemm_avw += 2.0 * DHQR_NBV * ((double)rows + (double)rows_b) * (double)ncols;
   }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+// ---- four-panel trailing update (K = 512): two consecutive pairs (a, b), (c, d) in ONE pass over C for the subtraction ----
+//   Y_1 = V_1' C,  Y_2 = V_2' C                     (V_1 = [V_a V_b], V_2 = [V_c V_d]: k_gemm_tn2 twice, C unchanged between)
+//   W_1 = pair_tw(Y_1),  Y_2 -= (V_2' V_1) W_1,  W_2 = pair_tw(Y_2)        (= V_2' (C - V_1 W_1): the first pair applied)
+//   C -= [V_1 V_2] [W_1; W_2]                       (k_gemm_nn_quad: C read and written once for 512 reflectors)
+// V_2 starts 256 rows below V_1 and has the SAME leading dimension (cs_run gives every group buffer of a factorisation
+// the ldv of the first panel when quads are on).  rows = rows of panel a.  Requires the 16-byte path (vec).
+static int32_t quad_apply(dhqr_ctx *c, const double *V1, const double *V2, int64_t ldv, int64_t rows, const double *Ta,
+                          const double *Tb, const double *Sba, const double *Tc, const double *Td, const double *Sdc,
+                          const double *S21, double *C, int64_t ncols, int64_t ldc) {
+  if (ncols <= 0) return DHQR_OK;
+  const int64_t NB = DHQR_NBV, ld2 = 2 * NB, ld4 = 4 * NB, rows2 = rows - 2 * NB;
+  const int64_t ntiles = (ncols + 127) / 128;
+  dhqr_ctx::WS &ws = c->ws[c->cur_ws];
+  CHECK(ensure(c, ws.w1r, (size_t)ld4 * (size_t)ncols));
+  CHECK(ensure(c, ws.w2, (size_t)ld4 * (size_t)ncols));
+  double *Y1 = ws.w1r.p, *Y2 = ws.w1r.p + ld2 * ncols, *W = ws.w2.p;
+
+  CHECK(prof_begin(c, CAT_VTA));
+  CHECK(pair_vtc(c, V1, ldv, rows, C, ldc, ncols, true, Y1));
+  CHECK(pair_vtc(c, V2, ldv, rows2, C + 2 * NB, ldc, ncols, true, Y2));
+  CHECK(prof_end(c));
+
+  CHECK(prof_begin(c, CAT_TW));
+  CHECK(pair_tw(c, Y1, Ta, Tb, Sba, W, ld4, ncols));
+  launch_nn_sub<256>(c, true, dim3(2, (unsigned)ntiles), S21, ld2, (const double *)W, ld4, Y2, ld2, ld2, ncols, 0, false);
+  CHECK(pair_tw(c, Y2, Tc, Td, Sdc, W + ld2, ld4, ncols));
+  CHECK(prof_end(c));
+
+  CHECK(prof_begin(c, CAT_AVW));
+  const int *st = pred_stat(c);
+  const int64_t gx = (rows + 127) / 128;
+  if (ntiles <= 2 && gx * ntiles < 512 && c->nn_tr64) {  // narrow (the lane / the head of a wide step): 64-row tiles
+    hipLaunchKernelGGL((k_gemm_nn_quad<2, 64>), dim3((unsigned)((rows + 63) / 64), (unsigned)ntiles), dim3(256), 0, c->stream, V1,
+                       V2 - 2 * NB, ldv, 2 * NB, (const double *)W, ld4, C, ldc, rows, ncols, 0, st, c->epoch);
+  } else {
+    const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
+    dim3 grid((unsigned)gx, (unsigned)ntiles);
+    if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
+    hipLaunchKernelGGL((k_gemm_nn_quad<2, 128>), grid, dim3(256), 0, c->stream, V1, V2 - 2 * NB, ldv, 2 * NB,
+                       (const double *)W, ld4, C, ldc, rows, ncols, swz, st, c->epoch);
+  }
+  CHECK(prof_end(c));
+  if (c->profiling) {
+    const double f = 2.0 * NB * ((double)rows + (double)(rows - NB) + (double)rows2 + (double)(rows2 - NB)) * (double)ncols;
+    c->st.flops_gemm_vta += f;
+    c->st.flops_gemm_avw += f;
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+// S_21 = V_2' V_1 (256 x 256, ld 256) of two consecutive pair operands (V_2 starts 256 rows below V_1, same ldv): the
+// cross term of quad_apply.  rows_a = rows of the first pair's first panel.
+static int32_t quad_cross_gram(dhqr_ctx *c, const double *V1, const double *V2, int64_t ldv, int64_t rows_a, double *S21) {
+  const int64_t NB = DHQR_NBV, rows2 = rows_a - 2 * NB, ld2 = 2 * NB;
+  int64_t nsplit, rps;
+  pick_split(rows2, 2, wide_slots(c), 128, &nsplit, &rps, wide_slots(c), 64);
+  CHECK(ensure(c, c->spart, (size_t)nsplit * (size_t)(ld2 * ld2)));
+  hipLaunchKernelGGL((k_gemm_tn2<2>), dim3((unsigned)std::min<int64_t>(2 * nsplit, wide_slots(c))), dim3(512), 0, c->stream, V2, ldv,
+                     V1 + 2 * NB, ldv, rows2, ld2, rps, c->spart.p, ld2 * ld2);
+  hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(ld2 * ld2 / 64)), dim3(256), 0, c->stream, (const double *)c->spart.p,
+                     (int)nsplit, ld2 * ld2, ld2 * ld2, S21);
   LAUNCHCHECK();
   return DHQR_OK;
 }
@@ -1141,8 +1239,11 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     }
     if (const char *e = getenv("DHQR_SPARE_CUS")) c->spare_cus = std::max(0, std::min(c->ncu - 8, atoi(e)));
     if (const char *e = getenv("DHQR_NN2")) c->nn2 = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_QUAD")) c->quad = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_QUAD_MIN_COLS")) c->quad_min_cols = std::max<int64_t>(0, atoll(e));
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
+    if (const char *e = getenv("DHQR_RANKK_TALL")) c->rankk_tall = std::min(3, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_TN_MODEL")) c->tn_model = atoi(e) != 0;
     if (const char *e = getenv("DHQR_TN_MODEL_MIN_TILES")) c->tn_model_min_tiles = atoi(e);
     if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;

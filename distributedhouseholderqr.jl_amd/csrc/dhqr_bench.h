@@ -332,9 +332,9 @@ int32_t dhqr_bench_stream_f64(dhqr_ctx *c, int64_t bytes, double *gbps) {
 // out = {ms per launch, TFLOP/s, shader MHz under the kernel, 0}.  The A/B switches of the context apply.
 int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t ncols, int32_t reps, double *out4) {
   ENTER(c);
-  if (!out4 || rows < 256 || ncols < 128 || rows % 128 || ncols % 128 || reps < 1 || (kind != 0 && kind != 1))
+  if (!out4 || rows < 256 || ncols < 128 || rows % 128 || ncols % 128 || reps < 1 || kind < 0 || kind > 2)
     return set_err(DHQR_EINVAL, "bad arguments");
-  const int64_t ldv = rows, ldc = rows, ld2 = 2 * DHQR_NBV;
+  const int64_t ldv = rows, ldc = rows, ld2 = (kind == 2 ? 4 : 2) * DHQR_NBV;  // kind 2: k_gemm_nn_quad (K = 512)
   double *V = nullptr, *W = nullptr, *C = nullptr, *Y = nullptr;
   long long *clk = nullptr;
   hipStream_t s2 = nullptr;
@@ -358,7 +358,13 @@ int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t nco
     }
     bool timed_nn = false;
     auto launch = [&]() {
-      if (kind == 0) {
+      if (kind == 2) {
+        const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
+        dim3 grid((unsigned)gx, (unsigned)ntiles);
+        if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
+        hipLaunchKernelGGL((k_gemm_nn_quad<2, 128>), grid, dim3(256), 0, c->stream, (const double *)V, (const double *)(V + 256 * ldv),
+                           ldv, (int64_t)0, (const double *)W, ld2, C, ldc, rows, ncols, swz, (const int *)nullptr, 0);
+      } else if (kind == 0) {
         const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
         dim3 grid((unsigned)gx, (unsigned)ntiles);
         if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
@@ -412,7 +418,7 @@ int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t nco
     long long h[2] = {0, 0};
     HIPCHECK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
     out4[0] = ms / reps;
-    out4[1] = 2.0 * 256.0 * (double)rows * (double)ncols / (out4[0] * 1e-3) / 1e12;
+    out4[1] = 2.0 * (double)ld2 * (double)rows * (double)ncols / (out4[0] * 1e-3) / 1e12;
     out4[2] = h[1] > 0 ? (double)h[0] / (double)h[1] * (double)wall_khz * 1e-3 : 0.0;
     out4[3] = 0.0;
     return DHQR_OK;

@@ -27,7 +27,7 @@
 // broadcast as the contiguous range [tail_a | V_a], panel b as [V_b | tail_b]: no repacking on any rank.
 #pragma once
 
-#define CS_NGB 4   // group buffers in flight
+#define CS_NGB 6   // group buffers in flight (a quad step keeps two of them until its wide update has finished)
 #define CS_EVR 8   // event ring length (groups); panels use 2 * CS_EVR
 
 struct CsState {
@@ -132,7 +132,7 @@ struct CsGroup {
 };
 
 struct CsGroupBuf {
-  double *tailA, *VA, *VB, *tailB, *Sba;
+  double *tailA, *VA, *VB, *tailB, *Sba, *S21;  // S21 (256 x 256): V_2' V_1 when this pair is the second of a quad step
   int64_t ldv, rows_a;
   PanelBuf pa() const { return tail_view(VA, ldv, tailA); }
   PanelBuf pb() const { return tail_view(VB + DHQR_NBV, ldv, tailB); }  // V_b proper starts 128 rows down
@@ -140,18 +140,58 @@ struct CsGroupBuf {
   int64_t region_elems() const { return ldv * DHQR_NBV + panel_tail_elems(); }
 };
 static inline size_t cs_gbuf_elems(int64_t m) {
-  return (size_t)(2 * panel_tail_elems() + 2 * panel_ldv(m) * DHQR_NBV + (int64_t)DHQR_NBV * DHQR_NBV);
+  return (size_t)(2 * panel_tail_elems() + 2 * panel_ldv(m) * DHQR_NBV + 5 * (int64_t)DHQR_NBV * DHQR_NBV);
 }
-static inline CsGroupBuf cs_gbuf_view(double *base, int64_t rows_a) {
+// ldv_fixed > 0: every group of the factorisation uses this leading dimension (quad steps: the K = 512 update reads the
+// reflectors of two group buffers with one stride)
+static inline CsGroupBuf cs_gbuf_view(double *base, int64_t rows_a, int64_t ldv_fixed = 0) {
   CsGroupBuf g;
   g.rows_a = rows_a;
-  g.ldv = panel_ldv(rows_a);
+  g.ldv = ldv_fixed > 0 ? ldv_fixed : panel_ldv(rows_a);
   g.tailA = base;
   g.VA = base + panel_tail_elems();
   g.VB = g.VA + g.ldv * DHQR_NBV;
   g.tailB = g.VB + g.ldv * DHQR_NBV;
   g.Sba = g.tailB + panel_tail_elems();
+  g.S21 = g.Sba + (int64_t)DHQR_NBV * DHQR_NBV;
   return g;
+}
+
+// A step of the wide stream: one group, or a QUAD = two consecutive pairs applied to the trailing matrix in one K = 512
+// pass (quad_apply: C is read three times and written once for four panels instead of four times and twice; the K loop
+// of the subtraction is twice as long per tile prologue / epilogue).  The group that follows a step receives the step
+// from the lane (narrow update), everything beyond from the wide stream.
+struct CsStep {
+  int g0, ng;  // first group, number of groups (1 or 2)
+};
+// Groups and steps of a pass that starts at panel kstart.  Quads: single rank, 16-byte path, and at least
+// c->quad_min_cols columns to the right of the quad (beyond that the panel chain, not the wide stream, bounds the
+// factorisation and pairs keep the chain shorter).
+static void cs_plan(const CsProblem &pr, int64_t kstart, std::vector<CsGroup> &groups, std::vector<CsStep> &steps) {
+  const dhqr_ctx *c = pr.c;
+  const int64_t NB = DHQR_NBV;
+  const bool pairing = c->pair && (pr.n >= c->pair_min_n || pr.P > 1);
+  groups.clear();
+  steps.clear();
+  for (int64_t k = kstart; k < pr.K;) {
+    CsGroup g;
+    g.a = k;
+    g.np = (pairing && k + 1 < pr.K && pr.width(k) == NB && pr.width(k + 1) == NB) ? 2 : 1;
+    groups.push_back(g);
+    k += g.np;
+  }
+  const bool quads = c->quad && pr.P == 1 && pr.m % 2 == 0 && pr.lda % 2 == 0 && aligned16(pr.A);
+  const int G = (int)groups.size();
+  for (int g = 0; g < G;) {
+    CsStep st;
+    st.g0 = g;
+    st.ng = 1;
+    if (quads && g + 1 < G && groups[g].np == 2 && groups[g + 1].np == 2 &&
+        pr.n - (groups[g + 1].last() + 1) * NB >= c->quad_min_cols)
+      st.ng = 2;
+    steps.push_back(st);
+    g += st.ng;
+  }
 }
 
 // One asynchronous pass over the panels [kstart, K).  `robust_first`: panel kstart is factored with the
@@ -163,22 +203,24 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
   CsState &S = *c->cs;
   const int64_t NB = DHQR_NBV, K = pr.K, m = pr.m, lda = pr.lda;
   const int P = pr.P;
-  const bool pairing = c->pair && (pr.n >= c->pair_min_n || P > 1);
-  // ---- groups
+  // ---- groups and steps
   std::vector<CsGroup> groups;
-  for (int64_t k = kstart; k < K;) {
-    CsGroup g;
-    g.a = k;
-    g.np = (pairing && k + 1 < K && pr.width(k) == NB && pr.width(k + 1) == NB) ? 2 : 1;
-    groups.push_back(g);
-    k += g.np;
-  }
-  const int G = (int)groups.size();
+  std::vector<CsStep> steps;
+  cs_plan(pr, kstart, groups, steps);
+  const int G = (int)groups.size(), NS = (int)steps.size();
   if (G == 0) {
     *failed = INT_MAX;
     return DHQR_OK;
   }
-  auto gview = [&](int g) { return cs_gbuf_view(S.gbuf[g % CS_NGB].p, m - groups[g].a * NB); };
+  std::vector<int> step_of((size_t)G);
+  bool any_quad = false;
+  for (int si = 0; si < NS; ++si)
+    for (int q = 0; q < steps[si].ng; ++q) {
+      step_of[(size_t)(steps[si].g0 + q)] = si;
+      any_quad = any_quad || steps[si].ng == 2;
+    }
+  const int64_t ldv_fixed = any_quad ? panel_ldv(m - groups[0].a * NB) : 0;
+  auto gview = [&](int g) { return cs_gbuf_view(S.gbuf[g % CS_NGB].p, m - groups[g].a * NB, ldv_fixed); };
 
   hipStream_t sW = c->stream, sL = c->hi, sC = S.comm;
   auto on = [&](hipStream_t s, int wsi) { c->stream = s; c->cur_ws = wsi; };
@@ -195,6 +237,15 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
     else
       rc = panel_apply(c, gb.pa(), gb.rows_a, C, ncols, lda, 1);
     return rc;
+  };
+  auto apply_step = [&](int si, int64_t lstart, int64_t ncols) -> int32_t {  // step si -> local columns [lstart, lstart+ncols)
+    const CsStep &st = steps[si];
+    if (st.ng == 1) return apply_group(st.g0, lstart, ncols);
+    if (ncols <= 0) return DHQR_OK;
+    const CsGroupBuf g1 = gview(st.g0), g2 = gview(st.g0 + 1);
+    c->epoch = (int)groups[st.g0 + 1].last();
+    return quad_apply(c, g1.VA, g2.VA, g1.ldv, g1.rows_a, g1.pa().T, g1.pb().T, g1.Sba, g2.pa().T, g2.pb().T, g2.Sba, g2.S21,
+                      pr.A + groups[st.g0].a * NB + lstart * lda, ncols, lda);
   };
   // lane work accounted to the panel group of the statistics
   auto lane_begin = [&](bool &was) -> int32_t {
@@ -214,10 +265,12 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
     const CsGroup &gr = groups[h];
     const CsGroupBuf gb = gview(h);
     const int prev = h - 1;
+    const int sh = step_of[(size_t)h];
+    const bool second_of_quad = steps[sh].ng == 2 && h == steps[sh].g0 + 1;
     // writers into this buffer slot must wait for the readers of group h - CS_NGB
     auto guard = [&](hipStream_t s) -> int32_t {
       if (h >= CS_NGB) {
-        HIPCHECK(hipStreamWaitEvent(s, S.ev_wide[(h - CS_NGB) % CS_EVR], 0));
+        HIPCHECK(hipStreamWaitEvent(s, S.ev_wide[step_of[(size_t)(h - CS_NGB)] % CS_EVR], 0));
         HIPCHECK(hipStreamWaitEvent(s, S.ev_lane[(h - CS_NGB + 1) % CS_EVR], 0));
         if (cm)
           for (int idx = 0; idx < groups[h - CS_NGB].np; ++idx) {
@@ -238,15 +291,21 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
         const int64_t lc = pr.lcol(x);
         bool was = false;
         if (prev >= 0 && !merged_update) {
-          // block x must carry every group before `prev`: done by the head (or whole) wide update of prev - 1
-          if (prev >= 1) HIPCHECK(hipStreamWaitEvent(sL, (P > 1 ? S.ev_head : S.ev_wide)[(prev - 1) % CS_EVR], 0));
+          // The block receives here what the wide stream leaves to the lane: the whole previous STEP when this group
+          // opens a step (the block must carry everything before that step: the wide update of step sh - 2), or the
+          // quad's first pair when this group is the quad's second (the block is the head of step sh - 1).
+          if (second_of_quad) {
+            if (sh >= 1) HIPCHECK(hipStreamWaitEvent(sL, S.ev_head[(sh - 1) % CS_EVR], 0));
+          } else if (sh >= 2) {
+            HIPCHECK(hipStreamWaitEvent(sL, (P > 1 ? S.ev_head : S.ev_wide)[(sh - 2) % CS_EVR], 0));
+          }
           int64_t ncols = w;
           if (gr.np == 2 && idx == 0 && pr.mine(x + 1) && pr.lcol(x + 1) == lc + w) {
             ncols += pr.width(x + 1);  // both panels are local and adjacent (a whole cyclic block): one 256-column update
             merged_update = true;
           }
           CHECK(lane_begin(was));
-          const int32_t rc = apply_group(prev, lc, ncols);
+          const int32_t rc = second_of_quad ? apply_group(prev, lc, ncols) : apply_step(sh - 1, lc, ncols);
           CHECK(lane_end(was));
           CHECK(rc);
         }
@@ -299,7 +358,11 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
     if (gr.np == 2 && gr.last() + 1 < K) {
       bool was = false;
       CHECK(lane_begin(was));
-      const int32_t rc = pair_cross_gram(c, gb.VA, gb.ldv, gb.rows_a, gb.Sba);
+      int32_t rc = pair_cross_gram(c, gb.VA, gb.ldv, gb.rows_a, gb.Sba);
+      if (rc == DHQR_OK && second_of_quad) {
+        const CsGroupBuf g1 = gview(h - 1);
+        rc = quad_cross_gram(c, g1.VA, gb.VA, gb.ldv, g1.rows_a, gb.S21);
+      }
       CHECK(lane_end(was));
       CHECK(rc);
     }
@@ -314,25 +377,28 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
     HIPCHECK(hipEventRecord(S.ev_start, sW));
     HIPCHECK(hipStreamWaitEvent(sL, S.ev_start, 0));
     HIPCHECK(hipStreamWaitEvent(sC, S.ev_start, 0));
-    CHECK(produce(0));
-    for (int g = 0; g < G; ++g) {
-      const CsGroup &gr = groups[g];
-      if (gr.last() + 1 >= K) break;  // nothing to the right of this group
-      // ---- wide stream: group g -> local blocks beyond group g+1
+    for (int q = 0; q < steps[0].ng; ++q) CHECK(produce(steps[0].g0 + q));
+    for (int si = 0; si < NS; ++si) {
+      const int glast = steps[si].g0 + steps[si].ng - 1;
+      if (groups[glast].last() + 1 >= K) break;  // nothing to the right of this step
+      // ---- wide stream: step si -> local blocks beyond the group that follows it (that group gets the step from the lane)
       on(sW, 0);
-      HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[g % CS_EVR], 0));
-      const int64_t after_next = groups[g + 1].last() + 1;
+      HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[glast % CS_EVR], 0));
+      const int64_t after_next = groups[glast + 1].last() + 1;
       int64_t lo = pr.local_from(after_next);
-      if (P > 1 && g + 2 < G) {  // head: the blocks of group g+2 this rank owns (needed by the lane next)
-        const int64_t hi = pr.local_from(groups[g + 2].last() + 1);
-        CHECK(apply_group(g, lo, hi - lo));
+      // head: the blocks of group glast + 2 -- what the lane needs first: at P > 1 always, at P == 1 when that group is the
+      // second pair of a quad (it waits for the head instead of the whole step, see produce)
+      if (glast + 2 < G && (P > 1 || (steps[step_of[(size_t)(glast + 2)]].ng == 2 && steps[step_of[(size_t)(glast + 2)]].g0 == glast + 1))) {
+        const int64_t hi = pr.local_from(groups[glast + 2].last() + 1);
+        CHECK(apply_step(si, lo, hi - lo));
         lo = hi;
       }
-      HIPCHECK(hipEventRecord(S.ev_head[g % CS_EVR], sW));
-      CHECK(apply_group(g, lo, pr.ncl - lo));
-      HIPCHECK(hipEventRecord(S.ev_wide[g % CS_EVR], sW));
-      // ---- lane + comm: group g+1
-      CHECK(produce(g + 1));
+      HIPCHECK(hipEventRecord(S.ev_head[si % CS_EVR], sW));
+      CHECK(apply_step(si, lo, pr.ncl - lo));
+      HIPCHECK(hipEventRecord(S.ev_wide[si % CS_EVR], sW));
+      // ---- lane + comm: the groups of step si + 1
+      if (si + 1 < NS)
+        for (int q = 0; q < steps[si + 1].ng; ++q) CHECK(produce(steps[si + 1].g0 + q));
     }
     // join: the caller's stream owns the result
     on(sW, 0);
@@ -363,10 +429,10 @@ static int32_t cs_prepare(const CsProblem &pr) {
   const size_t w1cap = NN * (6144 + 2 * ntmax + 128);  // split-K partials of k_gemm_tn (128 rows) / k_gemm_tn2 (256 rows)
   for (int s = 0; s < 2; ++s) {
     CHECK(ensure(c, c->ws[s].w1, s == 0 ? w1cap : NN * 2200));
-    CHECK(ensure(c, c->ws[s].w1r, (size_t)2 * NB * ncmax));
-    CHECK(ensure(c, c->ws[s].w2, (size_t)2 * NB * ncmax));
+    CHECK(ensure(c, c->ws[s].w1r, (size_t)4 * NB * ncmax));  // Y_1, Y_2 / [W_1; W_2] of a quad step
+    CHECK(ensure(c, c->ws[s].w2, (size_t)4 * NB * ncmax));
   }
-  CHECK(ensure(c, c->spart, (size_t)256 * NN));
+  CHECK(ensure(c, c->spart, (size_t)512 * NN));  // Gram partials; 128 slabs of the 256 x 256 cross term of a quad
   CHECK(ensure(c, c->sfull, NN));
   CHECK(ensure(c, c->rbuf, 6 * NN + 1024));
   if (c->cholqr_passes == 3) CHECK(ensure(c, c->tsq, TsqrLocal::elems(m)));  // TSQR-HR for every panel
@@ -397,20 +463,29 @@ static int32_t cs_factor(const CsProblem &pr) {
     if (failed == INT_MAX) break;
     // ---- resume: panels < failed are committed; matrix updates with epoch >= failed did not run
     CHECK(status_reset(c));
-    const bool pairing = c->pair && (pr.n >= c->pair_min_n || pr.P > 1);
-    bool is_b = false;
-    for (int64_t k = ks; k <= failed;) {  // replay the grouping of the failed pass
-      const int np = (pairing && k + 1 < pr.K && pr.width(k) == NB && pr.width(k + 1) == NB) ? 2 : 1;
-      if (np == 2 && k + 1 == failed) is_b = true;
-      k += np;
+    // Committed panels of the failed panel's group / step were only applied as far as the lane needed them: apply them
+    // to the rest before resuming.  Pair (a, b), b rejected: a reached block b only.  Quad (a, b)(c, d): c rejected ->
+    // a, b reached the blocks of c and d only; d rejected -> so did a, b, and c reached block d only.
+    std::vector<CsGroup> groups;
+    std::vector<CsStep> steps;
+    cs_plan(pr, ks, groups, steps);
+    std::vector<std::pair<int64_t, int64_t>> redo;  // (committed panel, first panel of the blocks it has not reached)
+    for (const CsStep &st : steps) {
+      const CsGroup &g1 = groups[(size_t)st.g0], &gl = groups[(size_t)(st.g0 + st.ng - 1)];
+      if (failed < g1.a || failed > gl.last()) continue;
+      if (st.ng == 1 || failed <= g1.last()) {
+        if (failed == g1.a + 1) redo.push_back({g1.a, failed + 1});
+      } else {
+        for (int64_t y = g1.a; y <= g1.last(); ++y) redo.push_back({y, gl.last() + 1});
+        if (failed == gl.last()) redo.push_back({gl.a, failed + 1});
+      }
     }
-    if (is_b) {
-      // the pair's first panel is committed and was applied to block `failed` only: apply it to the rest
-      const int64_t a = failed - 1, rows_a = pr.m - a * NB;
+    for (const auto &rd : redo) {
+      const int64_t a = rd.first, rows_a = pr.m - a * NB;
       const PanelBuf pb = vt_view(c->cs->vt.p, rows_a);
       if (pr.mine(a)) CHECK(panel_pack_and_t(c, pr.A + a * NB + pr.lcol(a) * pr.lda, rows_a, NB, pr.lda, pr.alpha + a * NB, pb));
       if (pr.cm && pr.P > 1) CHECK(comm_bcast(pr.cm, c->cs->vt.p, panel_elems(rows_a), pr.owner(a), c->stream, nullptr));
-      const int64_t lo = pr.local_from(failed + 1);
+      const int64_t lo = pr.local_from(rd.second);
       CHECK(panel_apply(c, pb, rows_a, pr.A + a * NB + lo * pr.lda, pr.ncl - lo, pr.lda, 1));
       if (pr.cm && pr.P > 1) HIPCHECK(hipStreamSynchronize(c->stream));  // vt is reused by the next resume
     }

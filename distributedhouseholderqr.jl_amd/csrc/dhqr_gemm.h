@@ -350,12 +350,15 @@ __device__ unsigned long long g_nn_phase[8];
 // 32 columns).  A workgroup's time is its K loop on one CU (13.7 us for a 128 x 128 x 128 tile); the latency-critical
 // products of the panel lane (V = P M^{-1}, the narrow look-ahead update) at a few thousand rows fill a fraction of the
 // chip with 128-row tiles, so they run with TR = 64: twice the workgroups, half the time each.
-template <int VEC, int KW, bool INIT0 = false, bool TIME = false, int TR = 128>
-__global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict__ V, int64_t ldv,
-                                                        const double *__restrict__ W, int64_t ldw,
-                                                        double *__restrict__ C, int64_t ldc,
-                                                        int64_t rows, int64_t ncols, int swz,
-                                                        const int *__restrict__ stat, int epoch) {
+// KW = 512 (k_gemm_nn_quad: FOUR panels = two pairs in one pass over C): reflectors 0..255 come from V, reflectors
+// 256..511 from V2 (same leading dimension), whose first `skip2` rows (the second pair starts 256 rows below the
+// first) are implicit zeros: row tiles above skip2 run half the K loop and never touch V2 (the host passes
+// V2 = first stored row - skip2).  Per flop the C traffic and the tile prologue / epilogue are half those of K = 256.
+template <int VEC, int KW, bool INIT0, bool TIME, int TR>
+__device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, int64_t ldv, const double *__restrict__ V2,
+                                                 int64_t skip2, const double *__restrict__ W, int64_t ldw,
+                                                 double *__restrict__ C, int64_t ldc, int64_t rows, int64_t ncols, int swz,
+                                                 const int *__restrict__ stat, int epoch) {
   static_assert(TR == 128 || TR == 64, "tile rows");
   constexpr int NCI = TR / 32;                     // 16-column MFMA tiles per wave: 4 (64 columns) or 2 (32 columns)
   constexpr int WCOLS = NCI * 16;                  // columns per wave
@@ -390,8 +393,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
   const int ncv = (int)((ncols - c0 < 128) ? ncols - c0 : 128);  // valid columns
 
   const double *Vb = V + r0;
+  const double *Vb2 = (KW == 512) ? V2 + r0 : V;  // only dereferenced by tiles at or below skip2
   const double *Wb = W + c0 * ldw;
   double *Cb = C + r0 + c0 * ldc;
+  const bool below2 = (KW != 512) || r0 >= skip2;  // uniform: the tile sees the second pair's reflectors
 
   // staging offsets (32-bit, from uniform bases); invalid rows/columns are clamped to element 0
   uint32_t offv[4], offw[4];
@@ -409,7 +414,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
   }
   double2 sv[4], sw[4];
   auto load_tile = [&](int kt) {  // issue only; masking / negation happen in store_tile
-    const double *Vt = Vb + (int64_t)kt * G_KT * ldv;
+    const double *Vt = (KW == 512 && kt >= KW / (2 * G_KT)) ? Vb2 + (int64_t)(kt - KW / (2 * G_KT)) * G_KT * ldv
+                                                            : Vb + (int64_t)kt * G_KT * ldv;
     const double *Wt = Wb + kt * G_KT;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -506,8 +512,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
   // idle matrix pipes; during the K loops the two waves of a SIMD saturate the pipe, 2 x 1024 x 64 cycles), and waiting
   // on a saturated memory re-forms the convoy after any perturbation (random start phases changed nothing).  Streaming
   // spreads the same reads evenly over the K loops.
-  constexpr bool STREAM = !INIT0 && VEC == 2 && (KW == 256 || KW == 128) && TR == 128;
-  if constexpr (STREAM) if (full) {  // uniform branch
+  constexpr bool STREAM = !INIT0 && VEC == 2 && (KW == 512 || KW == 256 || KW == 128) && TR == 128;
+  if constexpr (STREAM) if (full && below2) {  // uniform branch
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
@@ -515,29 +521,35 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
     store_tile(0);
     __syncthreads();
     if constexpr (TIME) tph[1] = clock64();
-    constexpr int UPT = STREAM ? 16 / NKT : 1;  // units per K-tile
+    constexpr int KTPU = NKT > 16 ? NKT / 16 : 1;     // K-tiles per unit (KW = 512: a unit every second K-tile)
+    constexpr int UPT = NKT > 16 ? 1 : 16 / NKT;      // units per K-tile that carries units
     const double *cin = cunit0;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
+      const bool carry = (kt % KTPU) == 0;  // compile-time after unrolling
       double2 cu[UPT][2];
+      if (carry) {
 #pragma unroll
-      for (int u = 0; u < UPT; ++u) {
-        cu[u][0] = *reinterpret_cast<const double2 *>(cin);
-        cu[u][1] = *reinterpret_cast<const double2 *>(cin + 2);
-        cin += cstep;
+        for (int u = 0; u < UPT; ++u) {
+          cu[u][0] = *reinterpret_cast<const double2 *>(cin);
+          cu[u][1] = *reinterpret_cast<const double2 *>(cin + 2);
+          cin += cstep;
+        }
       }
       if (kt + 1 < NKT) load_tile(kt + 1);
       __builtin_amdgcn_sched_barrier(0);
       mma_tile(kt & 1);
       __builtin_amdgcn_sched_barrier(0);
       if (kt + 1 < NKT) store_tile((kt & 1) ^ 1);
+      if (carry) {
 #pragma unroll
-      for (int u = 0; u < UPT; ++u) {
-        const int ci = (kt * UPT + u) >> 2, g = (kt * UPT + u) & 3;
-        acc[ci][0][g] += cu[u][0].x;
-        acc[ci][1][g] += cu[u][0].y;
-        acc[ci][2][g] += cu[u][1].x;
-        acc[ci][3][g] += cu[u][1].y;
+        for (int u = 0; u < UPT; ++u) {
+          const int ci = ((kt / KTPU) * UPT + u) >> 2, g = ((kt / KTPU) * UPT + u) & 3;
+          acc[ci][0][g] += cu[u][0].x;
+          acc[ci][1][g] += cu[u][0].y;
+          acc[ci][2][g] += cu[u][1].x;
+          acc[ci][3][g] += cu[u][1].y;
+        }
       }
       if (kt + 1 < NKT) __syncthreads();
     }
@@ -599,8 +611,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the C tile has arrived
     tph[1] = clock64();
   }
+  const int nkt_run = below2 ? NKT : NKT / 2;  // tiles above skip2: the second pair's reflectors are zero there
 #pragma unroll 1
-  for (int kt = 0; kt < NKT - 1; ++kt) {
+  for (int kt = 0; kt < nkt_run - 1; ++kt) {
     const int buf = kt & 1;
     load_tile(kt + 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -609,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
     store_tile(buf ^ 1);
     __syncthreads();
   }
-  mma_tile((NKT - 1) & 1);
+  mma_tile((nkt_run - 1) & 1);
   if constexpr (TIME) {
     __builtin_amdgcn_sched_barrier(0);
     tph[2] = clock64();
@@ -633,6 +646,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
       }
   }
   time_end();
+}
+
+template <int VEC, int KW, bool INIT0 = false, bool TIME = false, int TR = 128>
+__global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict__ V, int64_t ldv,
+                                                        const double *__restrict__ W, int64_t ldw,
+                                                        double *__restrict__ C, int64_t ldc,
+                                                        int64_t rows, int64_t ncols, int swz,
+                                                        const int *__restrict__ stat, int epoch) {
+  static_assert(KW != 512, "K = 512 takes two reflector operands: k_gemm_nn_quad");
+  gemm_nn_sub_body<VEC, KW, INIT0, TIME, TR>(V, ldv, nullptr, 0, W, ldw, C, ldc, rows, ncols, swz, stat, epoch);
+}
+
+// The four-panel update C -= [V | V2] W (W: 512 x ncols, rows 0..255 for V, 256..511 for V2), see gemm_nn_sub_body.
+template <int VEC, int TR = 128>
+__global__ __launch_bounds__(256, 2) void k_gemm_nn_quad(const double *__restrict__ V, const double *__restrict__ V2,
+                                                         int64_t ldv, int64_t skip2, const double *__restrict__ W,
+                                                         int64_t ldw, double *__restrict__ C, int64_t ldc, int64_t rows,
+                                                         int64_t ncols, int swz, const int *__restrict__ stat, int epoch) {
+  gemm_nn_sub_body<VEC, 512, false, false, TR>(V, ldv, V2, skip2, W, ldw, C, ldc, rows, ncols, swz, stat, epoch);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -897,8 +929,8 @@ __global__ __launch_bounds__(256) void k_reduce_splits(const double *__restrict_
 template <bool PAIR>
 __global__ __launch_bounds__(256) void k_tw_fused(const double *__restrict__ Y, int64_t ncols, const double *__restrict__ TaT,
                                                   const double *__restrict__ TbT, const double *__restrict__ Sba,
-                                                  double *__restrict__ W2) {
-  constexpr int LDY = PAIR ? 256 : 128, NC = 4;
+                                                  double *__restrict__ W2, int64_t ldw) {
+  constexpr int LDY = PAIR ? 256 : 128, NC = 4;  // ldw: leading dimension of W2 (LDY, or 512 inside a four-panel update)
   __shared__ double y[NC][LDY], wa[NC][128];
   const int t = threadIdx.x, p = t & 127, ch = t >> 7;  // this thread: output row p of columns 2 ch, 2 ch + 1
   const int64_t c0 = (int64_t)blockIdx.x * NC;
@@ -920,8 +952,8 @@ __global__ __launch_bounds__(256) void k_tw_fused(const double *__restrict__ Y, 
   };
   double a0, a1;
   tprod(TaT, y, 0, a0, a1);  // w_a = Top_a' y_a
-  if (c0 + 2 * ch < ncols) W2[p + (c0 + 2 * ch) * LDY] = a0;
-  if (c0 + 2 * ch + 1 < ncols) W2[p + (c0 + 2 * ch + 1) * LDY] = a1;
+  if (c0 + 2 * ch < ncols) W2[p + (c0 + 2 * ch) * ldw] = a0;
+  if (c0 + 2 * ch + 1 < ncols) W2[p + (c0 + 2 * ch + 1) * ldw] = a1;
   if constexpr (PAIR) {
     wa[2 * ch][p] = a0;
     wa[2 * ch + 1][p] = a1;
@@ -939,8 +971,8 @@ __global__ __launch_bounds__(256) void k_tw_fused(const double *__restrict__ Y, 
     __syncthreads();
     double b0, b1;
     tprod(TbT, y, 128, b0, b1);  // w_b = Top_b' y_b
-    if (c0 + 2 * ch < ncols) W2[128 + p + (c0 + 2 * ch) * LDY] = b0;
-    if (c0 + 2 * ch + 1 < ncols) W2[128 + p + (c0 + 2 * ch + 1) * LDY] = b1;
+    if (c0 + 2 * ch < ncols) W2[128 + p + (c0 + 2 * ch) * ldw] = b0;
+    if (c0 + 2 * ch + 1 < ncols) W2[128 + p + (c0 + 2 * ch + 1) * ldw] = b1;
   }
 }
 

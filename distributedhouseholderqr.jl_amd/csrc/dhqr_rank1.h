@@ -474,6 +474,94 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
   else rankk_lead_body<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
 }
 
+// k_rankk_fused for columns of 8192 < rows <= 16384 (EPT = 12 / 16 at 1024 threads): the same pass -- every trailing
+// column loaded once, K reflectors applied one after the other in the reference's order (src:208-209 per step), stored
+// once, the LEAD workgroup (the same rankk_lead) building the next K -- but a column of this height leaves no registers
+// or LDS to keep the pass's reflectors on the CU, so the bulk STREAMS each reflector from `vold` (L2: K x 128 KiB per
+// column against 256 KiB of HBM traffic) into one buffer, requested right behind its previous use, while the next
+// column's loads are in flight in a second column buffer.  K <= 3 (the lead holds no reflector in LDS at this height).
+// HBM traffic 16 / K bytes per element and reflector instead of the 16 of k_rank1_generic.
+template <int T, int EPT, int VEC, int K>
+__global__ __launch_bounds__(T) void k_rankk_tall(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
+                                                  int64_t c0, int64_t rtop, int kold, const double *__restrict__ vold,
+                                                  double *vnew, int64_t vlen, double *__restrict__ alpha) {
+  static_assert(K <= 3, "the lead keeps reflectors 4.. in LDS, which a tall column does not leave");
+  __shared__ double red[2 * (T / 64) + 2];
+  __shared__ double reda[2 * (T / 64)];
+  __shared__ double vl[2];  // never addressed (KL = NN = 0)
+  if (blockIdx.x == 0) {
+    rankk_lead<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
+    return;
+  }
+  int par = 0;
+  const int t = threadIdx.x;
+  const int64_t mlast = m - VEC;
+  double a[EPT], an[EPT], w[EPT];
+  auto load = [&](const double *src, double *dst, bool mask) {
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
+        const bool ok = row < m;
+        const double2 x = *reinterpret_cast<const double2 *>(src + (ok ? row : mlast));
+        dst[2 * i] = (ok || !mask) ? x.x : 0.0;
+        dst[2 * i + 1] = (ok || !mask) ? x.y : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t row = rtop + t + (int64_t)e * T;
+        const bool ok = row < m;
+        const double x = src[ok ? row : mlast];
+        dst[e] = (ok || !mask) ? x : 0.0;
+      }
+    }
+  };
+  typedef double dhqr_d2 __attribute__((ext_vector_type(2)));
+  auto store_nt = [&](double *dst, const double *src) {
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
+        if (row < m) {
+          const dhqr_d2 x = {src[2 * i], src[2 * i + 1]};
+          __builtin_nontemporal_store(x, reinterpret_cast<dhqr_d2 *>(dst + row));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t row = rtop + t + (int64_t)e * T;
+        if (row < m) __builtin_nontemporal_store(src[e], dst + row);
+      }
+    }
+  };
+  const int64_t stride = (int64_t)gridDim.x - 1;
+  int64_t c = c0 + K + ((int64_t)blockIdx.x - 1);
+  if (c >= ncols) return;
+  load(A + c * lda, a, false);
+  for (;;) {
+    const int64_t cn = c + stride;
+    const bool more = cn < ncols;
+    load(A + (more ? cn : c) * lda, an, false);  // unconditional early load (see k_rankk_fused)
+    load(vold, w, true);
+    for (int p = 0; p < kold; ++p) {
+      double dot = 0.0;  // src:208 partialdot
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) dot = fma(a[e], w[e], dot);
+      const double sdot = block_sum_alt<T>(dot, reda, par);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) a[e] = fma(-w[e], sdot, a[e]);  // src:209 hotloop!
+      if (p + 1 < kold) load(vold + (int64_t)(p + 1) * vlen, w, true);
+    }
+    store_nt(A + c * lda, a);
+    if (!more) break;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) a[e] = an[e];
+    c = cn;
+  }
+}
+
 // Fused step j for columns taller than 1024*8 rows: same contract, the column is streamed twice
 // (the second pass hits L2: a 32768-row column is 256 KiB).
 template <int T, int VEC>

@@ -258,7 +258,7 @@ static int32_t rs_apply_w(const RsProblem &pr, const double *V, int64_t ldv, con
   CHECK(ensure(c, ws.w2, (size_t)NB * (size_t)ncols));
   if (TopT && ntiles <= 2)
     hipLaunchKernelGGL((k_tw_fused<false>), dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, c->stream, (const double *)ws.w1r.p, ncols,
-                       TopT, (const double *)nullptr, (const double *)nullptr, ws.w2.p);
+                       TopT, (const double *)nullptr, (const double *)nullptr, ws.w2.p, NB);
   else
   hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top, NB,
                      (const double *)ws.w1r.p, NB, 1, (int64_t)0, NB, ncols, NB, ws.w2.p, NB, (int64_t)0);

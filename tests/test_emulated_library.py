@@ -117,6 +117,41 @@ def test_two_panel_driver_and_switches(emu, orc):
 
 
 
+def test_quad_steps_two_pairs_in_one_k512_update(emu, orc):
+    """1280 columns = 5 pairs with DHQR_QUAD_MIN_COLS=0: steps quad (0,1), quad (2,3), pair 4 -- the K = 512 update
+    (k_gemm_nn_quad: row tiles above the second pair run half the K loop; 64-row tiles in the lane's narrow update, the
+    streamed-C path for interior tiles), the 256 x 256 cross term, the head of a wide step for the quad's second pair --
+    against the oracle, and the same factorisation as pairs only (DHQR_QUAD=0) to rounding"""
+    A0 = orc.rand_matrix(1290, 1280, 8)
+    res = []
+    for env in ({"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD_MIN_COLS": 0}, {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD": 0}):
+        h = _ctx(emu, **env)
+        A, al = _factor(emu, h, A0, 128)
+        _check(orc, A0, A, al)
+        assert _counters(emu, h) == (9, 0)  # the last panel (138 rows) is below the fast path's height
+        emu.dhqr_destroy(h)
+        res.append((A, al))
+    scale = np.abs(res[1][0]).max()
+    assert np.abs(res[0][0] - res[1][0]).max() <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("bad", [200, 300, 400])
+def test_rejected_panel_inside_a_quad_step(emu, orc, bad):
+    """640 columns: quad (a, b)(c, d) + one panel to its right.  A nearly dependent column pair in panel b / c / d is
+    rejected on the device; the committed panels of the quad, which had only reached the blocks the lane needed, are
+    applied to the rest before the run resumes (cs_factor) -- backward stable, every other panel on the fast path"""
+    h = _ctx(emu, DHQR_PAIR_MIN_N=0, DHQR_QUAD_MIN_COLS=0)
+    m, n = 700, 640
+    A0 = orc.rand_matrix(m, n, 23)
+    A0[:, bad] = A0[:, bad - 1] * (1.0 + 1e-9)
+    A, al = _factor(emu, h, A0, 128)
+    fast, fb = _counters(emu, h)
+    assert fb >= 1 and fast + fb >= 4, (fast, fb)  # the last panel (188 rows) is below the fast path's height
+    QR = orc.form_qr(np.asfortranarray(A), al)
+    assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-13
+    emu.dhqr_destroy(h)
+
+
 @pytest.mark.parametrize("env", [{}, pytest.param({"DHQR_NN2": 0}, marks=_SLOW)])
 def test_wide_update_on_the_persistent_kernels(emu, orc, env):
     """1024 columns: the first pair's wide update covers 4 column tiles (> 2), i.e. it runs on the persistent kernels

@@ -21,7 +21,7 @@ def main():
         args = args[4:]
         out = (ctypes.c_double * 4)()
         pkg.bench_check(L, L.dhqr_bench_gemm_f64(ctx.handle, kind, rows_, ncols, reps, out))
-        print(f"[{tag}] kind={'NN256' if kind == 0 else 'TN2'} {rows_}x{ncols}: {out[0]:.3f} ms/launch, {out[1]:.2f} TFLOP/s "
+        print(f"[{tag}] kind={('NN256', 'TN2', 'NN512')[kind]} {rows_}x{ncols}: {out[0]:.3f} ms/launch, {out[1]:.2f} TFLOP/s "
               f"({out[1] / 78.6:.3f} of 78.6), shader clock {out[2]:.0f} MHz", flush=True)
 
 
