@@ -61,7 +61,7 @@ struct dhqr_ctx {
   int rankk_wgs = 256;           // ... bulk workgroups of 1024 threads resident at once (CU count; DHQR_RANKK_WGS)
   int rankk = 5;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..5; beyond 3 the further ones are held in LDS)
   int nn_tr64 = 1;               // narrow C -= V W products on 64-row tiles (DHQR_NN_TR64=0: always 128)
-  int rankk_tall = 1;            // nb = 0, columns of 8192 < rows <= 16384: reflectors per pass (k_rankk_tall, <= 3; DHQR_RANKK_TALL=1: one per launch)
+  int rankk_tall = 5;            // nb = 0, columns of 8192 < rows <= 16384: reflectors per pass (k_rankk_tall; DHQR_RANKK_TALL=1: one per launch)
   int swizzle = 1;               // XCD-aware tile order in k_gemm_nn_sub (+1.5 % at 32768^2; DHQR_SWIZZLE=0 disables)
   int ncu = 256;                 // compute units of the device
   int spare_cus = 0;             // CUs the persistent wide GEMMs (k_gemm_tn2, k_gemm_nn2) leave free for the look-ahead lane's
@@ -194,13 +194,12 @@ static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
                      dim3((unsigned)(1 + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs * (rankk_lead_slots(T_, E_, K) > 0 ? 1 : 1024 / T_) - 1))), \
                      dim3(T_), 0, c->stream, P, ldp, rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha)
 #define DHQR_RKT(E_)                                                                                     \
-  hipLaunchKernelGGL((k_rankk_tall<1024, E_, VEC, K>),                                                    \
-                     dim3((unsigned)(1 + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs - 1))), dim3(1024), 0, c->stream, P, ldp, \
+  hipLaunchKernelGGL((k_rankk_tall<512, E_, VEC, K>),                                                     \
+                     dim3((unsigned)(1 + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs - 1))), dim3(512), 0, c->stream, P, ldp, \
                      rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha)
-  if constexpr (K <= 3) {  // columns of 8192 < rows <= 16384: factor_unblocked_cols passes K <= 3 there
-    if (cov > 1024 * 12) { DHQR_RKT(16); return; }
-    if (cov > 1024 * 8) { DHQR_RKT(12); return; }
-  }
+  // columns of 8192 < rows <= 16384 (factor_unblocked_cols sends them here when DHQR_RANKK_TALL >= 2)
+  if (cov > 512 * 24) { DHQR_RKT(32); return; }
+  if (cov > 1024 * 8) { DHQR_RKT(24); return; }
   if (cov <= 256 * 2) DHQR_RK(256, 2);
   else if (cov <= 256 * 4) DHQR_RK(256, 4);
   else if (cov <= 256 * 8) DHQR_RK(256, 8);
@@ -229,8 +228,11 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
                                      int64_t ldp, double *alpha, int cat) {
   const int K = c->rankk;  // reflectors per pass over the trailing columns (1: one launch per reflector)
   const int Kt = std::min(K, c->rankk_tall);  // ... while a column has 8192 < rows <= 16384 (k_rankk_tall; < 2: one per launch)
-  const size_t vlen = (size_t)((rows + 17) & ~(int64_t)15);
+  // a reflector slot: the column's rows, zero-padded so that k_rankk_tall (512 threads x 32 elements from a row > rows -
+  // 16384) reads reflectors without clamping or masking -- the kernels never write beyond row `rows`
+  const size_t vlen = (size_t)((rows + (Kt >= 2 && rows > 1024 * 8 ? 1024 * 8 : 0) + 17) & ~(int64_t)15);
   CHECK(ensure(c, c->vbuf, 2 * (size_t)std::max(K, 1) * vlen));
+  if (Kt >= 2 && rows > 1024 * 8) HIPCHECK(hipMemsetAsync(c->vbuf.p, 0, 2 * (size_t)std::max(K, 1) * vlen * sizeof(double), c->stream));
   double *vset[2] = {c->vbuf.p, c->vbuf.p + (size_t)std::max(K, 1) * vlen};  // two sets of K reflectors
   const bool vec = (ldp % 2 == 0) && (rows % 2 == 0) && aligned16(P);
   auto account = [&](int64_t jlo, int64_t ncol_upd) {
@@ -1243,7 +1245,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_QUAD_MIN_COLS")) c->quad_min_cols = std::max<int64_t>(0, atoll(e));
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
-    if (const char *e = getenv("DHQR_RANKK_TALL")) c->rankk_tall = std::min(3, std::max(1, atoi(e)));
+    if (const char *e = getenv("DHQR_RANKK_TALL")) c->rankk_tall = std::min(5, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_TN_MODEL")) c->tn_model = atoi(e) != 0;
     if (const char *e = getenv("DHQR_TN_MODEL_MIN_TILES")) c->tn_model_min_tiles = atoi(e);
     if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;

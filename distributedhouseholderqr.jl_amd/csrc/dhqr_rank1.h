@@ -170,14 +170,16 @@ constexpr int rankk_lead_slots(int T, int EPT, int K) {
 // reflectors are not held at all: the first three stream from `vold` (L2) through two buffers, one load ahead of the
 // apply that uses them; reflectors 4, 5 and -- where they fit -- the ones built here sit in LDS (`vl`, passed in
 // together with the reduction scratch; generic pointers, so LDS is reached by flat instructions).
-template <int T, int EPT, int VEC, int K>
+// STREAM_ALL (k_rankk_tall: columns of more than 8192 rows leave no LDS for reflectors): every old reflector streams from
+// L2 through the two buffers, nothing is kept in LDS.
+template <int T, int EPT, int VEC, int K, bool STREAM_ALL = false>
 __device__ __forceinline__ void rankk_lead_body(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
                                                 int64_t c0, int64_t rtop, int kold, const double *vold,
                                                 double *vnew, int64_t vlen, double *__restrict__ alpha,
                                                 double *red, double *reda, double *vl) {
-  constexpr int KR = K < 3 ? K : 3;
+  constexpr int KR = STREAM_ALL ? K : (K < 3 ? K : 3);
   constexpr int KL = K - KR;
-  constexpr int NN = rankk_lead_slots(T, EPT, K);
+  constexpr int NN = STREAM_ALL ? 0 : rankk_lead_slots(T, EPT, K);
   constexpr int HSLOT = 2 * (T / 64);
   const int t = threadIdx.x;
   const int64_t mlast = m - VEC;
@@ -474,92 +476,134 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
   else rankk_lead_body<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
 }
 
-// k_rankk_fused for columns of 8192 < rows <= 16384 (EPT = 12 / 16 at 1024 threads): the same pass -- every trailing
-// column loaded once, K reflectors applied one after the other in the reference's order (src:208-209 per step), stored
-// once, the LEAD workgroup (the same rankk_lead) building the next K -- but a column of this height leaves no registers
-// or LDS to keep the pass's reflectors on the CU, so the bulk STREAMS each reflector from `vold` (L2: K x 128 KiB per
-// column against 256 KiB of HBM traffic) into one buffer, requested right behind its previous use, while the next
-// column's loads are in flight in a second column buffer.  K <= 3 (the lead holds no reflector in LDS at this height).
+__device__ __forceinline__ uint32_t rk_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+template <int T, int EPT, int VEC, int K>
+__device__ __attribute__((noinline)) void rankk_lead_tall(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
+                                                          int64_t c0, int64_t rtop, int kold, const double *vold,
+                                                          double *vnew, int64_t vlen, double *__restrict__ alpha,
+                                                          double *red, double *reda, double *vl) {
+  rankk_lead_body<T, EPT, VEC, K, true>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
+}
+
+// k_rankk_fused for columns of 8192 < rows <= 16384: the same pass -- every trailing column loaded once, K reflectors
+// applied one after the other in the reference's order (src:208-209 per step), stored once, the LEAD workgroup building
+// the next K -- but a column of this height leaves neither registers nor LDS to keep the pass's reflectors on the CU:
+//   * 512 threads x 24 / 32 elements (ONE workgroup per CU, 256 registers per thread; at 1024 threads the three buffers
+//     of 16 elements spilled 150 registers and the pass ran SLOWER than one reflector per launch);
+//   * the bulk STREAMS each reflector from `vold` (L2: K x 128 KiB per column beside 256 KiB of HBM traffic) into one
+//     buffer, requested right behind its previous use;
+//   * two column buffers in alternation: the next column's loads are issued after the FIRST reflector of the current
+//     one -- the buffer they go to was stored at the end of the previous column, and a load into registers a store is
+//     still reading from waits for that store; one reflector step later it has drained, and K - 1 steps remain to cover
+//     the HBM latency;
+//   * the lead (rankk_lead_body<..., STREAM_ALL>) streams all K old reflectors through its two buffers, nothing in LDS.
 // HBM traffic 16 / K bytes per element and reflector instead of the 16 of k_rank1_generic.
 template <int T, int EPT, int VEC, int K>
 __global__ __launch_bounds__(T) void k_rankk_tall(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
                                                   int64_t c0, int64_t rtop, int kold, const double *__restrict__ vold,
                                                   double *vnew, int64_t vlen, double *__restrict__ alpha) {
-  static_assert(K <= 3, "the lead keeps reflectors 4.. in LDS, which a tall column does not leave");
+  static_assert(T <= 512, "three buffers of a tall column need the 256 registers of a <= 512-thread workgroup");
   __shared__ double red[2 * (T / 64) + 2];
   __shared__ double reda[2 * (T / 64)];
-  __shared__ double vl[2];  // never addressed (KL = NN = 0)
+  __shared__ double vl[2];  // never addressed (STREAM_ALL)
   if (blockIdx.x == 0) {
-    rankk_lead<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
+    rankk_lead_tall<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
     return;
   }
   int par = 0;
-  const int t = threadIdx.x;
-  const int64_t mlast = m - VEC;
+  const uint32_t t = threadIdx.x;
+  // 32-bit element offsets from the (uniform) base `src + rtop`, clamped to the last valid access: the addresses are one
+  // scalar base plus a recomputed lane offset, no 64-bit address registers stay live beside the three buffers
+  const uint32_t span = (uint32_t)(m - rtop);          // valid rows from rtop
+  const uint32_t olast = span - VEC;                   // offset of the last valid (pair of) element(s)
   double a[EPT], an[EPT], w[EPT];
-  auto load = [&](const double *src, double *dst, bool mask) {
+  // columns: offsets clamped to the last valid access (never masked: see k_rankk_fused); reflectors: the host pads every
+  // reflector slot with zeros up to rtop + T * EPT (factor_unblocked_cols: vlen), so their loads need neither
+  auto load_col = [&](const double *src, double *dst) {
+    const double *base = src + rtop;
     if constexpr (VEC == 2) {
 #pragma unroll
       for (int i = 0; i < EPT / 2; ++i) {
-        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
-        const bool ok = row < m;
-        const double2 x = *reinterpret_cast<const double2 *>(src + (ok ? row : mlast));
-        dst[2 * i] = (ok || !mask) ? x.x : 0.0;
-        dst[2 * i + 1] = (ok || !mask) ? x.y : 0.0;
+        const uint32_t o = rk_umin(2u * (t + (uint32_t)i * T), olast);
+        const double2 x = *reinterpret_cast<const double2 *>(base + o);
+        dst[2 * i] = x.x;
+        dst[2 * i + 1] = x.y;
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const int64_t row = rtop + t + (int64_t)e * T;
-        const bool ok = row < m;
-        const double x = src[ok ? row : mlast];
-        dst[e] = (ok || !mask) ? x : 0.0;
+      for (int e = 0; e < EPT; ++e) dst[e] = base[rk_umin(t + (uint32_t)e * T, olast)];
+    }
+  };
+  auto load_refl = [&](const double *src, double *dst) {
+    const double *base = src + rtop;
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const double2 x = *reinterpret_cast<const double2 *>(base + 2u * (t + (uint32_t)i * T));
+        dst[2 * i] = x.x;
+        dst[2 * i + 1] = x.y;
       }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) dst[e] = base[t + (uint32_t)e * T];
     }
   };
   typedef double dhqr_d2 __attribute__((ext_vector_type(2)));
   auto store_nt = [&](double *dst, const double *src) {
+    double *base = dst + rtop;
     if constexpr (VEC == 2) {
 #pragma unroll
       for (int i = 0; i < EPT / 2; ++i) {
-        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
-        if (row < m) {
+        const uint32_t o = 2u * (t + (uint32_t)i * T);
+        if (o < span) {
           const dhqr_d2 x = {src[2 * i], src[2 * i + 1]};
-          __builtin_nontemporal_store(x, reinterpret_cast<dhqr_d2 *>(dst + row));
+          __builtin_nontemporal_store(x, reinterpret_cast<dhqr_d2 *>(base + o));
         }
       }
     } else {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
-        const int64_t row = rtop + t + (int64_t)e * T;
-        if (row < m) __builtin_nontemporal_store(src[e], dst + row);
+        const uint32_t o = t + (uint32_t)e * T;
+        if (o < span) __builtin_nontemporal_store(src[e], base + o);
       }
     }
   };
   const int64_t stride = (int64_t)gridDim.x - 1;
   int64_t c = c0 + K + ((int64_t)blockIdx.x - 1);
   if (c >= ncols) return;
-  load(A + c * lda, a, false);
-  for (;;) {
-    const int64_t cn = c + stride;
-    const bool more = cn < ncols;
-    load(A + (more ? cn : c) * lda, an, false);  // unconditional early load (see k_rankk_fused)
-    load(vold, w, true);
-    for (int p = 0; p < kold; ++p) {
-      double dot = 0.0;  // src:208 partialdot
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) dot = fma(a[e], w[e], dot);
-      const double sdot = block_sum_alt<T>(dot, reda, par);
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) a[e] = fma(-w[e], sdot, a[e]);  // src:209 hotloop!
-      if (p + 1 < kold) load(vold + (int64_t)(p + 1) * vlen, w, true);
-    }
-    store_nt(A + c * lda, a);
-    if (!more) break;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) a[e] = an[e];
-    c = cn;
+  load_col(A + c * lda, a);
+  // one column: CUR holds it, NXT receives the next one (unconditional early load, see k_rankk_fused), requested behind
+  // the first reflector's step
+#define DHQR_RKT_APPLY(CUR)                                                              \
+  {                                                                                      \
+    double dot = 0.0; /* src:208 partialdot */                                           \
+    _Pragma("unroll") for (int e = 0; e < EPT; ++e) dot = fma(CUR[e], w[e], dot);        \
+    const double sdot = block_sum_alt<T>(dot, reda, par);                                \
+    _Pragma("unroll") for (int e = 0; e < EPT; ++e) CUR[e] = fma(-w[e], sdot, CUR[e]); /* src:209 hotloop! */ \
   }
+#define DHQR_RKT_STEP(CUR, NXT)                                                          \
+  {                                                                                      \
+    const int64_t cn = c + stride;                                                       \
+    const bool more = cn < ncols;                                                        \
+    load_refl(vold, w);                                                                  \
+    DHQR_RKT_APPLY(CUR)                                                                  \
+    if (kold > 1) load_refl(vold + vlen, w);                                             \
+    load_col(A + (more ? cn : c) * lda, NXT);                                            \
+    for (int p = 1; p < kold; ++p) {                                                     \
+      DHQR_RKT_APPLY(CUR)                                                                \
+      if (p + 1 < kold) load_refl(vold + (int64_t)(p + 1) * vlen, w);                    \
+    }                                                                                    \
+    store_nt(A + c * lda, CUR);                                                          \
+    if (!more) break;                                                                    \
+    c = cn;                                                                              \
+  }
+  for (;;) {
+    DHQR_RKT_STEP(a, an)
+    DHQR_RKT_STEP(an, a)
+  }
+#undef DHQR_RKT_APPLY
+#undef DHQR_RKT_STEP
 }
 
 // Fused step j for columns taller than 1024*8 rows: same contract, the column is streamed twice

@@ -85,7 +85,8 @@ def test_factor_drivers_vs_oracle(emu, orc, m, n, nb):
     assert emu.dhqr_destroy(h) == 0
 
 
-@pytest.mark.parametrize("m,n,Ks", [(200, 64, (2, 5)), (131, 37, (3,)), (70, 70, (4,))])
+@pytest.mark.parametrize("m,n,Ks", [(200, 64, (2, 5)), (131, 37, (3,)), (70, 70, (4,)),
+                                    (8300, 9, (3,))])  # columns of more than 8192 rows: k_rankk_tall, then k_rankk_fused
 def test_unblocked_k_reflectors_per_pass_is_the_same_arithmetic(emu, orc, m, n, Ks):
     """nb = 0: k_rankk_fused applies K reflectors in one pass over every trailing column (1/K of the HBM traffic) --
     element by element the operations of K k_rank1_fused launches; only the summation order of the dot products differs
