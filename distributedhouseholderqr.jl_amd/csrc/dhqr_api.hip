@@ -77,6 +77,9 @@ struct dhqr_ctx {
   int64_t pair_min_n = 12288;    // below this the longer look-ahead lane of the pair driver costs more than it saves (profiles/r02_ab_pair_tail_and_threshold.txt)
   int panel_impl = 3;  // 3: R-first (CholeskyQR + reconstruction, dhqr_recon.h) with fallback to 2;
                        // 2: row-split sub-panel kernels (dhqr_panel.h); 1: one workgroup per column
+  int zpipe = 1;         // ComplexF64 panels of <= 128 columns and <= 8192 rows in one column-pipelined launch (k_zpanel_pipe; DHQR_ZPIPE=0: one launch per column)
+  int *zflags = nullptr; // its 128 ready flags (device), never reset: a flag holds the number of the launch that set it
+  int zepoch = 0;
   int *hflag = nullptr;  // pinned host copy of the device status block
   int *dstat = nullptr;  // device status block (ints): [0] first rejected panel of the running factorisation
                          // (INT_MAX: none), [1] Cholesky breakdown flag of the panel in flight
@@ -1252,6 +1255,9 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_PAIR_MIN_N")) c->pair_min_n = atoll(e);
     HIPCHECK(hipHostMalloc((void **)&c->hflag, 4 * sizeof(int), hipHostMallocDefault));
     HIPCHECK(hipMalloc((void **)&c->dstat, 16 * sizeof(int)));
+    HIPCHECK(hipMalloc((void **)&c->zflags, 128 * DHQR_ZFLAG_STRIDE * sizeof(int)));
+    HIPCHECK(hipMemsetAsync(c->zflags, 0, 128 * DHQR_ZFLAG_STRIDE * sizeof(int), c->stream));
+    if (const char *e = getenv("DHQR_ZPIPE")) c->zpipe = atoi(e) != 0;
     hipLaunchKernelGGL(k_set_status, dim3(1), dim3(64), 0, c->stream, c->dstat, INT_MAX);
     LAUNCHCHECK();
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -1297,6 +1303,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   }
   if (c->hflag) (void)hipHostFree(c->hflag);
   if (c->dstat) (void)hipFree(c->dstat);
+  if (c->zflags) (void)hipFree(c->zflags);
   if (c->hi) (void)hipStreamDestroy(c->hi);
   if (c->own) (void)hipStreamDestroy(c->own);
   delete c;
@@ -1563,9 +1570,27 @@ int32_t dhqr_factor_c64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t l
   CHECK(check_mat(dA, m, n, lda, true));
   CHECK(check_zptr(dA, "matrix"));
   CHECK(check_zptr(dalpha, "alpha"));
+  double2 *A = reinterpret_cast<double2 *>(dA), *al = reinterpret_cast<double2 *>(dalpha);
+  if (c->zpipe && n <= 128 && m <= 8192) {  // a panel: one column-pipelined launch (k_zpanel_pipe, dhqr_complex.h)
+    const int epoch = ++c->zepoch;
+    CHECK(prof_begin(c, CAT_RANK1));
+#define DHQR_ZPP(T_, E_, G_) hipLaunchKernelGGL((k_zpanel_pipe<T_, E_, G_>), dim3((unsigned)((n + G_ - 1) / G_)), dim3(T_), 0, c->stream, A, lda, m, (int)n, al, c->zflags, epoch)
+    // ONE column per workgroup: measured (profiles/r03_c64_panel_pipeline.txt), several columns per workgroup make the
+    // hand-overs rarer but serialise their dot / update rounds on one CU's FP64 pipes -- slower at every height
+    if (m <= 512) DHQR_ZPP(256, 2, 1);
+    else if (m <= 1024) DHQR_ZPP(256, 4, 1);
+    else if (m <= 2048) DHQR_ZPP(256, 8, 1);
+    else if (m <= 4096) DHQR_ZPP(512, 8, 1);
+    else DHQR_ZPP(1024, 8, 1);
+#undef DHQR_ZPP
+    CHECK(prof_end(c));
+    if (c->profiling)
+      for (int64_t j = 0; j + 1 < n; ++j) c->st.bytes_rank1 += 32.0 * (double)(m - j) * (double)(n - j - 1);
+    LAUNCHCHECK();
+    return DHQR_OK;
+  }
   const size_t vlen = (size_t)((m + 15) & ~(int64_t)15);  // complex elements per staging vector
   CHECK(ensure(c, c->vbuf, 4 * vlen));
-  double2 *A = reinterpret_cast<double2 *>(dA), *al = reinterpret_cast<double2 *>(dalpha);
   double2 *vb[2] = {reinterpret_cast<double2 *>(c->vbuf.p), reinterpret_cast<double2 *>(c->vbuf.p) + vlen};
   CHECK(prof_begin(c, CAT_RANK1));
   hipLaunchKernelGGL((k_zreflector<1024>), dim3(1), dim3(1024), 0, c->stream, A, m, (int64_t)0, vb[0], al);

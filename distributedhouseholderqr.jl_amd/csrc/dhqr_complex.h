@@ -16,6 +16,7 @@
 // Float64 unblocked path: 32 algorithmic bytes and 16 real flops per trailing element per reflector.
 #pragma once
 #include "dhqr_common.h"
+#include <utility>
 
 __device__ __forceinline__ double2 zmake(double re, double im) { return make_double2(re, im); }
 // conj(a) * b   (src:51-59: Complex(ar*br + ai*bi, ar*bi - ai*br))
@@ -137,6 +138,194 @@ __global__ __launch_bounds__(T) void k_zrank1(double2 *__restrict__ A, int64_t l
     vnext[row] = val;
   }
   if (t == 0) alpha[jp] = al;
+}
+
+// (re, im) block sums with ONE barrier (see block_sum_alt: two halves of `red`, >= 4 * T/64 doubles, in alternation)
+template <int THREADS>
+__device__ __forceinline__ double2 zblock_sum_alt(double sr, double si, double *red, int &par) {
+  sr = wave_sum_dpp(sr);
+  si = wave_sum_dpp(si);
+  constexpr int NW = THREADS / 64;
+  if constexpr (NW == 1) return zmake(sr, si);
+  double *r = red + (par & 1) * 2 * NW;
+  ++par;
+  if ((threadIdx.x & 63) == 0) {
+    r[2 * (threadIdx.x >> 6)] = sr;
+    r[2 * (threadIdx.x >> 6) + 1] = si;
+  }
+  __syncthreads();
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    a += r[2 * i];
+    b += r[2 * i + 1];
+  }
+  return zmake(a, b);
+}
+
+// NV block sums with ONE barrier (see block_sum_alt: two halves of `red`, >= 2 * NV * T/64 doubles, in alternation)
+template <int THREADS, int NV>
+__device__ __forceinline__ void block_sum_multi(double (&v)[NV], double *red, int &par) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum_dpp(v[i]);
+  constexpr int NW = THREADS / 64;
+  if constexpr (NW == 1) return;
+  double *r = red + (par & 1) * NV * NW;
+  ++par;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[(threadIdx.x >> 6) * NV + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) s += r[k * NV + i];
+    v[i] = s;
+  }
+}
+template <class F, int... I>
+__device__ __forceinline__ void zstatic_for(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+
+// ---- a whole panel (w <= 128 complex columns, rows <= T * EPT) in ONE launch: column-pipelined -------------------------
+// Workgroup g owns the G consecutive columns g G .. g G + G - 1 of the panel and keeps them in REGISTERS for the whole
+// kernel.  It applies the reflectors of the groups before it, in the reference's order and arithmetic (src:208-209 with
+// the complex partialdot / hotloop!, src:51-59,171-196), as their owners publish them; then, column by column, builds
+// its own reflectors (src:129-140) and applies each to its later columns -- locally, from registers; finally it stores
+// its columns (below the diagonal they ARE the reflectors) and raises flag g.  The one-launch-per-column loop (k_zrank1)
+// spends ~10 us per column, most of it launch latency and two passes over L2 per trailing column; here the chain is one
+// hand-over between workgroups per G columns (flag -> load G reflectors -> ... -> store -> flag: ~7 us with G = 1 on
+// the MI355X, profiles/r03_c64_panel_pipeline.txt) plus dot -> sum -> update rounds out of registers.  G grows as the
+// panel gets shorter (2 columns at 8192 rows ... 16 below 512), so late panels hand over only a few times.
+// Synchronisation: flag g = epoch (a per-launch number, so the flags are never reset) is stored with RELEASE at agent
+// scope once the owner's column stores have reached its L2 (the release writes the L2 back -- workgroups sit on
+// different XCDs, whose L2s are not coherent with each other); a reader polls it with ACQUIRE at agent scope, which
+// invalidates the non-coherent cache lines of its CU / XCD before the reflectors are loaded.  A workgroup waits only for
+// workgroups with a SMALLER index: they were dispatched earlier, so the wait cannot deadlock (and the CPU emulator,
+// which runs workgroups one after the other in index order, never spins).  All <= 64 workgroups fit the 256 CUs.
+#define DHQR_ZFLAG_STRIDE 32  // ints between two flags: one 128-byte line each
+template <int T, int EPT, int G>
+__global__ __launch_bounds__(T) void k_zpanel_pipe(double2 *__restrict__ P, int64_t ldp, int64_t rows, int w,
+                                                   double2 *__restrict__ alpha, int *flags, int epoch) {
+  constexpr int NW = T / 64;
+  __shared__ double red[2 * NW + 4];
+  __shared__ double reda[2 * (2 * G) * NW];
+  const int t = threadIdx.x, nrow = (int)rows;  // rows <= T * EPT <= 8192: 32-bit row arithmetic
+  const int g = blockIdx.x;
+  const int c0 = g * G;
+  if (c0 >= w) return;
+  const int nc = (w - c0 < G) ? w - c0 : G;  // columns of this group (only the last group may be short)
+  double2 a[G][EPT];
+#pragma unroll
+  for (int q = 0; q < G; ++q)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int row = t + e * T;
+      a[q][e] = (q < nc && row < nrow) ? P[(int64_t)(c0 + q) * ldp + row] : zmake(0.0, 0.0);
+    }
+  int par = 0;
+  // the reflectors of the groups before this one, on all G columns at once (a missing column is zero and stays zero)
+  for (int jg = 0; jg < g; ++jg) {
+    // ONE thread polls (a thousand waves spinning on one word slow the owner's flag store down), the barrier releases the
+    // others: the acquire's cache invalidation acts on the CU's L1 and the XCD's L2, not on the polling wave alone, and
+    // nobody on this CU has touched those columns before
+    if (t == 0)
+      while (__hip_atomic_load(flags + jg * DHQR_ZFLAG_STRIDE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(2);
+    __syncthreads();
+    for (int qj = 0; qj < G; ++qj) {
+      const int j = jg * G + qj;
+      const double2 *vj = P + (int64_t)j * ldp;  // v_j = column j from its diagonal down (R above it)
+      double2 v[EPT];
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int row = t + e * T;
+        v[e] = (row >= j && row < nrow) ? vj[row] : zmake(0.0, 0.0);
+      }
+      double s[2 * G];
+#pragma unroll
+      for (int q = 0; q < G; ++q) {
+        s[2 * q] = 0.0;
+        s[2 * q + 1] = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) zcdot_acc(v[e], a[q][e], s[2 * q], s[2 * q + 1]);  // src:208 partialdot: conj(Hj) . col
+      }
+      block_sum_multi<T, 2 * G>(s, reda, par);
+#pragma unroll
+      for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) a[q][e] = zsubmul(a[q][e], v[e], s[2 * q], s[2 * q + 1]);  // src:209 hotloop!
+    }
+  }
+  // this group's own columns: reflector of column Q (src:129-140; norm in double-double like dznrm2's extended
+  // accumulation), then onto the columns Q+1 .. G-1 out of registers
+  zstatic_for([&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    if (Q < nc) {  // uniform
+      const int c = c0 + Q;
+      dhqr_dd acc = {0.0, 0.0};
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int row = t + e * T;
+        if (row == c) {
+          red[2 * NW] = a[Q][e].x;
+          red[2 * NW + 1] = a[Q][e].y;
+        }
+        if (row >= c && row < nrow) {
+          dd_add_sq(acc, a[Q][e].x);
+          dd_add_sq(acc, a[Q][e].y);
+        }
+      }
+      const double s2 = dd_block_sum<T>(acc, red);  // barriers inside also publish the pivot slots
+      const double2 h = zmake(red[2 * NW], red[2 * NW + 1]);
+      const double sn = sqrt(s2);
+      double ah;
+      const double2 af = zalphafactor(h, &ah);
+      const double2 al = zmake(sn * af.x, sn * af.y);  // src:130
+      const double f = 1.0 / sqrt(sn * (sn + ah));     // src:131
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int row = t + e * T;
+        if (row == c) a[Q][e] = zmake((h.x - al.x) * f, (h.y - al.y) * f);  // src:132-135
+        else if (row > c) a[Q][e] = zmake(a[Q][e].x * f, a[Q][e].y * f);
+      }
+      if (t == 0) alpha[c] = al;
+      if constexpr (Q + 1 < G) {
+        constexpr int NR = G - Q - 1;  // later columns of the group
+        double s[2 * NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+          s[2 * q] = 0.0;
+          s[2 * q + 1] = 0.0;
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) {
+            const int row = t + e * T;
+            if (row >= c) zcdot_acc(a[Q][e], a[Q + 1 + q][e], s[2 * q], s[2 * q + 1]);  // rows above the diagonal hold R, not v
+          }
+        }
+        block_sum_multi<T, 2 * NR>(s, reda, par);
+#pragma unroll
+        for (int q = 0; q < NR; ++q)
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) {
+            const int row = t + e * T;
+            if (row >= c) a[Q + 1 + q][e] = zsubmul(a[Q + 1 + q][e], a[Q][e], s[2 * q], s[2 * q + 1]);
+          }
+      }
+      __syncthreads();  // the pivot slots are rewritten by the next column
+    }
+  }, std::make_integer_sequence<int, G>{});
+#pragma unroll
+  for (int q = 0; q < G; ++q)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int row = t + e * T;
+      if (q < nc && row < nrow) P[(int64_t)(c0 + q) * ldp + row] = a[q][e];
+    }
+  __syncthreads();  // every wave's column stores have reached the L2 (the barrier's workgroup-scope release waits for them)
+  if (t == 0) __hip_atomic_store(flags + g * DHQR_ZFLAG_STRIDE, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // L2 write-back, then the flag
 }
 
 // b[j:m] <- (I - v v^H) b[j:m] for the reflector stored in column j (v = &A[0 + j*lda]); one workgroup.

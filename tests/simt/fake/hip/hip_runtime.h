@@ -282,6 +282,11 @@ inline long long wall_clock64() {
   return t += 1000;  // every poll advances the fake constant-rate counter: bounded spins terminate
 }
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
+// inter-workgroup flags (k_zpanel_pipe): workgroups run one after the other here, the atomics are plain host atomics
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
   return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
