@@ -439,11 +439,12 @@ def roofline_groups(st, steps, m=0, n=0, nb=0):
     """per-kernel-group roofline entries from the hipEvent statistics of ONE rank"""
     groups = []
     if st["ms_gemm_avw"] > 0:
-        # one timed group = ONE wide k_gemm_nn_sub launch on the caller's stream (rocprofv3 lists the narrow
-        # look-ahead launches of the same template on the second stream as well: profiles/*_by_stream.csv)
-        groups.append(dict(kernel="k_gemm_nn_sub (A -= V*W, FP64 MFMA)", symbol="k_gemm_nn_sub", bound="mfma", ms=st["ms_gemm_avw"],
+        # one timed group = ONE wide subtraction launch on the caller's stream: k_gemm_nn_quad (four panels, K = 512) while
+        # quad steps run, k_gemm_nn_sub (K = 256 / 128) for the pairs / single panels of the tail (rocprofv3 lists the
+        # narrow look-ahead launches of the same templates on the second stream as well: profiles/*_by_stream.csv)
+        groups.append(dict(kernel="k_gemm_nn_quad / k_gemm_nn_sub (A -= V*W, K = 512 / 256, FP64 MFMA)", symbol="k_gemm_nn_quad", bound="mfma", ms=st["ms_gemm_avw"],
                            launches=st["n_gemm_avw"], work=st["flops_gemm_avw"]))
-        # one timed group = the TN launches of one wide update (two per two-panel update) + their split-K reductions
+        # one timed group = the TN launches of one wide update (one k_gemm_tn2 per pair of panels) + their split-K reductions
         groups.append(dict(kernel="k_gemm_tn2 / k_gemm_tn (W = [V_a V_b]'*A, FP64 MFMA)", symbol="k_gemm_tn2", bound="mfma", ms=st["ms_gemm_vta"],
                            launches=st["n_gemm_vta"], work=st["flops_gemm_vta"]))
     if st["ms_panel"] > 0:
@@ -689,7 +690,7 @@ def main():
             # the wide kernels alone on synthetic operands of the first (largest) update + the shader clock under them
             g4 = (_ct.c_double * 4)()
             iso = {}
-            for kind, name in ((0, "k_gemm_nn_sub K=256"), (1, "k_gemm_tn2")):
+            for kind, name in ((2, "k_gemm_nn_quad K=512"), (0, "k_gemm_nn_sub K=256"), (1, "k_gemm_tn2")):
                 pkg.bench_check(B, B.dhqr_bench_gemm_f64(bh, kind, 16384, 16384, 3, g4))
                 iso[name] = {"tflops": g4[1], "frac_of_peak": g4[1] / PEAK_FP64_MFMA_TFLOPS, "shader_mhz": g4[2]}
             out["gemm_kernels_in_isolation_16384"] = iso

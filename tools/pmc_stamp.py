@@ -1,0 +1,120 @@
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `tools/pmc_driver blocked 32768` (tools/gpu_r3_evidence.sh)
+-> profiles/pmc_traffic_current.json, the file bench.py reads for roofline.traffic, stamped with the git blob ids of the
+kernel sources.  Per kernel symbol: the WIDE launches (those that move at least 10 % of the symbol's largest launch; the
+narrow look-ahead launches of the same template are left out), their measured HBM bytes (gfx950: read = 2 x FETCH_SIZE
+KiB, written = WRITE_SIZE KiB, see pmc_summary.py) and the algorithmic bytes of the same launches from the driver's plan
+(cs_plan in csrc/dhqr_dist.h, restated below: C read + written once by the subtraction, read once by each k_gemm_tn2).
+usage: pmc_stamp.py <dir with blocked_FETCH_SIZE/ blocked_WRITE_SIZE/> [n=32768] [commit note]"""
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NB = 128
+
+
+def blob(path):
+    data = open(os.path.join(ROOT, path), "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def per_launch(root, ctr, scale):
+    f = glob.glob(os.path.join(root, f"blocked_{ctr}", "**", "*counter_collection.csv"), recursive=True)
+    out = {}
+    for r in csv.DictReader(open(f[0])):
+        k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
+        out.setdefault(k, []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"]) * scale))
+    return {k: [v for _, v in sorted(vs)] for k, vs in out.items()}
+
+
+def plan(n, pair_min_n=12288, quad_min_cols=6144):
+    """(rows, ncols) of the wide launches of the single-GPU blocked driver: NN launches, TN2 launches"""
+    m = n
+    K = n // NB
+    groups = []
+    k = 0
+    while k < K:
+        np_ = 2 if (n >= pair_min_n and k + 1 < K) else 1
+        groups.append((k, np_))
+        k += np_
+    last = lambda g: groups[g][0] + groups[g][1] - 1
+    G = len(groups)
+    steps = []
+    g = 0
+    while g < G:
+        ng = 2 if (g + 1 < G and groups[g][1] == 2 and groups[g + 1][1] == 2 and n - (last(g + 1) + 1) * NB >= quad_min_cols) else 1
+        steps.append((g, ng))
+        g += ng
+    step_of = {}
+    for si, (g0, ng) in enumerate(steps):
+        for q in range(ng):
+            step_of[g0 + q] = si
+    nn, tn = [], []
+    for si, (g0, ng) in enumerate(steps):
+        glast = g0 + ng - 1
+        if last(glast) + 1 >= K:
+            break
+        rows = m - groups[g0][0] * NB
+        lo = (last(glast + 1) + 1) * NB
+        pieces = []
+        if glast + 2 < G and steps[step_of[glast + 2]][1] == 2 and steps[step_of[glast + 2]][0] == glast + 1:
+            hi = (last(glast + 2) + 1) * NB
+            pieces.append(hi - lo)
+            lo = hi
+        pieces.append(n - lo)
+        for nc in pieces:
+            if nc <= 0:
+                continue
+            nn.append((rows, nc, 512 if ng == 2 else 128 * groups[g0][1]))
+            tn.append((rows, nc))
+            if ng == 2:
+                tn.append((rows - 2 * NB, nc))
+    return nn, tn
+
+
+def main():
+    root = sys.argv[1]
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+    note = sys.argv[3] if len(sys.argv) > 3 else ""
+    rd = per_launch(root, "FETCH_SIZE", 2.0 * 1024.0)
+    wr = per_launch(root, "WRITE_SIZE", 1024.0)
+    nn, tn = plan(n)
+    srcs = ["distributedhouseholderqr.jl_amd/csrc/dhqr_gemm.h", "distributedhouseholderqr.jl_amd/csrc/dhqr_rank1.h"]
+    entries = []
+
+    def entry(symbols, alg_list, alg_bytes):
+        r = [x for s in symbols for x in rd.get(s, [])]
+        w = [x for s in symbols for x in wr.get(s, [])]
+        if not r:
+            return
+        cut = 0.1 * max(r)
+        idx = [i for i, x in enumerate(r) if x >= cut]
+        rsum, wsum = sum(r[i] for i in idx), sum(w[i] for i in idx if i < len(w))
+        wide = [a for a in alg_list if alg_bytes(a) >= 0.1 * max(alg_bytes(b) for b in alg_list)]
+        alg = sum(alg_bytes(a) for a in wide)
+        entries.append({"kernel_symbol": symbols[0], "also_counted": symbols[1:], "sources": [srcs[0]],
+                        "workload": f"blocked {n}x{n} nb=128, wide launches", "launches": len(idx),
+                        "launches_in_plan": len(wide), "bytes_per_launch": (rsum + wsum) / len(idx),
+                        "ratio_to_algorithmic": (rsum + wsum) / alg, "read_GB": rsum / 1e9, "write_GB": wsum / 1e9,
+                        "algorithmic_GB": alg / 1e9})
+
+    entry(["k_gemm_nn_quad", "k_gemm_nn_sub"], nn, lambda a: 16.0 * a[0] * a[1])
+    entry(["k_gemm_tn2"], tn, lambda a: 8.0 * a[0] * a[1])
+    old = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")))
+    for e in old.get("entries", []):  # the unblocked entry stays while its source is unchanged
+        if e["kernel_symbol"] == "k_rankk_fused" and old.get("source_hashes", {}).get(srcs[1]) == blob(srcs[1]):
+            entries.append(e)
+    out = {"what": old["what"].replace("tools/gpu_pmc_traffic.sh + tools/pmc_stamp.py", "tools/gpu_r3_evidence.sh (pmc passes) + tools/pmc_stamp.py"),
+           "method": old["method"], "correction": old["correction"], "measured_at_commit": note,
+           "source_hashes": {s: blob(s) for s in srcs}, "entries": entries}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json"), "w"), indent=1)
+    for e in entries:
+        print(e["kernel_symbol"], "launches", e["launches"], "plan", e.get("launches_in_plan"), "GB/launch", round(e.get("bytes_per_launch", 0) / 1e9, 3),
+              "ratio", round(e["ratio_to_algorithmic"], 3))
+
+
+if __name__ == "__main__":
+    main()
