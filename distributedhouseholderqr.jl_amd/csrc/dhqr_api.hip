@@ -67,7 +67,7 @@ struct dhqr_ctx {
   int spare_cus = 0;             // CUs the persistent wide GEMMs (k_gemm_tn2, k_gemm_nn2) leave free for the look-ahead lane's
                                  // single-workgroup kernels and for RCCL's kernels (DHQR_SPARE_CUS; multiple of 8: one per XCD)
   int quad = 1;                  // P == 1: two consecutive pairs applied in ONE K = 512 pass (quad_apply; DHQR_QUAD=0: pairs only)
-  int64_t quad_min_cols = 6144;  // ... while at least this many columns lie to the right of the quad (DHQR_QUAD_MIN_COLS)
+  int64_t quad_min_cols = 10240;  // ... while at least this many columns lie to the right of the quad (DHQR_QUAD_MIN_COLS)
   int nn2 = 0;                   // wide C -= V W on the persistent 256 x 128-tile kernel k_gemm_nn2 (DHQR_NN2=0: k_gemm_nn_sub)
   struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
   int cur_ws = 0;
@@ -78,6 +78,7 @@ struct dhqr_ctx {
   int panel_impl = 3;  // 3: R-first (CholeskyQR + reconstruction, dhqr_recon.h) with fallback to 2;
                        // 2: row-split sub-panel kernels (dhqr_panel.h); 1: one workgroup per column
   int zpipe = 1;         // ComplexF64 panels of <= 128 columns and <= 8192 rows in one column-pipelined launch (k_zpanel_pipe; DHQR_ZPIPE=0: one launch per column)
+  hipEvent_t zev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // look-ahead of the blocked ComplexF64 driver
   int *zflags = nullptr; // its 128 ready flags (device), never reset: a flag holds the number of the launch that set it
   int zepoch = 0;
   int *hflag = nullptr;  // pinned host copy of the device status block
@@ -1304,6 +1305,8 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   if (c->hflag) (void)hipHostFree(c->hflag);
   if (c->dstat) (void)hipFree(c->dstat);
   if (c->zflags) (void)hipFree(c->zflags);
+  for (hipEvent_t e : c->zev)
+    if (e) (void)hipEventDestroy(e);
   if (c->hi) (void)hipStreamDestroy(c->hi);
   if (c->own) (void)hipStreamDestroy(c->own);
   delete c;
@@ -1628,16 +1631,14 @@ int32_t dhqr_factor_c64_nb(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_
   CHECK(check_zptr(dA, "matrix"));
   CHECK(check_zptr(dalpha, "alpha"));
   const int64_t ZB = DHQR_ZNB;
-  // No look-ahead lane here: measured (profiles/r02_ab_c64_blocked_lookahead.txt), the 1024-thread rank-1 launches of a
-  // lane wait for a CU behind the wide update's GEMM workgroups and the lane takes as long as the wide stream.
-  CHECK(ensure(c, c->vt, (size_t)panel_elems(2 * m)));
-  for (int64_t c0 = 0; c0 < n; c0 += ZB) {
+  CHECK(ensure(c, c->vt, 2 * (size_t)panel_elems(2 * m)));  // two panel operand buffers (look-ahead: panel k + 1 is built while k is applied)
+  double *vtb[2] = {c->vt.p, c->vt.p + panel_elems(2 * m)};
+  // one panel: factor (src:122-148,171-213 inside the panel), embed, T
+  auto make_panel = [&](int64_t c0, const PanelBuf &pb) -> int32_t {
     const int64_t w = std::min<int64_t>(ZB, n - c0), rows = m - c0;
     double *P = dA + 2 * (c0 + c0 * lda);
-    CHECK(dhqr_factor_c64(c, P, rows, w, lda, dalpha + 2 * c0));  // src:122-148,171-213 inside the panel
-    const int64_t ncols = n - c0 - w;
-    if (ncols <= 0) break;
-    const PanelBuf pb = vt_view(c->vt.p, 2 * rows);
+    CHECK(dhqr_factor_c64(c, P, rows, w, lda, dalpha + 2 * c0));
+    if (n - c0 - w <= 0) return DHQR_OK;  // the last panel is applied to nothing
     const int64_t npad = panel_ldv(2 * rows);
     CHECK(prof_begin(c, CAT_TBUILD));
     {
@@ -1647,8 +1648,82 @@ int32_t dhqr_factor_c64_nb(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_
     }
     CHECK(panel_build_t(c, 2 * rows, -2 * w, pb));  // negative: strict upper part at the 2 x 2 block level
     CHECK(prof_end(c));
-    CHECK(panel_apply(c, pb, 2 * rows, dA + 2 * (c0 + (c0 + w) * lda), ncols, 2 * lda, 1));
+    return DHQR_OK;
+  };
+  // Look-ahead (DHQR_LOOKAHEAD=0 or per-column panels: plain loop).  With one launch per COLUMN a lane was slower than
+  // no lane (profiles/r02_ab_c64_blocked_lookahead.txt: every launch waited for a CU behind the wide update's GEMM
+  // workgroups); the column-pipelined panel kernel is ONE launch per panel, waits once, and then holds its <= 64 CUs
+  // while the wide update runs on the others.
+  // Panels taller than the pipelined kernel's 8192 rows are factored one launch per column: no lane for them (plain loop);
+  // the lane takes over at the first panel whose SUCCESSOR fits.
+  const bool lane = c->lookahead && c->zpipe && n > 2 * ZB;
+  int64_t cstart = 0;  // first panel of the look-ahead phase
+  while (cstart < n && (!lane || m - cstart - ZB > 8192)) {
+    const int64_t w = std::min<int64_t>(ZB, n - cstart), rows = m - cstart;
+    const PanelBuf pb = vt_view(vtb[0], 2 * rows);
+    CHECK(make_panel(cstart, pb));
+    const int64_t ncols = n - cstart - w;
+    if (ncols > 0) CHECK(panel_apply(c, pb, 2 * rows, dA + 2 * (cstart + (cstart + w) * lda), ncols, 2 * lda, 1));
+    cstart += ZB;
   }
+  if (cstart < n && n - cstart <= ZB) {  // one panel left: applied to nothing
+    CHECK(make_panel(cstart, vt_view(vtb[0], 2 * (m - cstart))));
+    cstart = n;
+  }
+  if (cstart >= n) {
+    LAUNCHCHECK();
+    return DHQR_OK;
+  }
+  // lane (high priority): panel k -> the columns of panel k + 1, then panel k + 1;  caller's stream: panel k -> beyond
+  if (!c->zev[0])
+    for (int i = 0; i < 5; ++i) HIPCHECK(hipEventCreateWithFlags(&c->zev[i], hipEventDisableTiming));
+  hipEvent_t evP[2] = {c->zev[0], c->zev[1]}, evW[2] = {c->zev[2], c->zev[3]}, evS = c->zev[4];
+  hipStream_t sW = c->stream, sL = c->hi;
+  auto on = [&](hipStream_t st, int wsi) { c->stream = st; c->cur_ws = wsi; };
+  {  // the workspaces of both streams, sized up front: nothing is (re)allocated while the two streams run
+    const size_t NN = (size_t)DHQR_NBV * DHQR_NBV, ncmax = (size_t)std::max<int64_t>(n, 2 * DHQR_NBV);
+    for (int wsi = 0; wsi < 2; ++wsi) {
+      CHECK(ensure(c, c->ws[wsi].w1, NN * (wsi == 0 ? 2 * ((ncmax + 127) / 128) + 2600 : 520)));  // split-K partials: pick_split stops at 4 x 512 workgroups
+      CHECK(ensure(c, c->ws[wsi].w1r, (size_t)DHQR_NBV * ncmax));
+      CHECK(ensure(c, c->ws[wsi].w2, (size_t)DHQR_NBV * ncmax));
+    }
+    CHECK(ensure(c, c->spart, 256 * NN));
+    CHECK(ensure(c, c->sfull, NN));
+  }
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipEventRecord(evS, sW));
+    HIPCHECK(hipStreamWaitEvent(sL, evS, 0));
+    on(sL, 1);
+    CHECK(make_panel(cstart, vt_view(vtb[0], 2 * (m - cstart))));
+    HIPCHECK(hipEventRecord(evP[0], sL));
+    int64_t k = 0;
+    for (int64_t c0 = cstart; c0 < n; c0 += ZB, ++k) {
+      const int64_t w = std::min<int64_t>(ZB, n - c0), rows = m - c0;
+      const int64_t c1 = c0 + w;  // first column of panel k + 1
+      if (c1 >= n) break;
+      const int64_t w1 = std::min<int64_t>(ZB, n - c1);
+      const PanelBuf pb = vt_view(vtb[k & 1], 2 * rows);
+      // lane: the columns of panel k + 1 carry every panel before k once the wide update of k - 1 has finished
+      on(sL, 1);
+      if (k >= 1) HIPCHECK(hipStreamWaitEvent(sL, evW[(k - 1) & 1], 0));
+      CHECK(panel_apply(c, pb, 2 * rows, dA + 2 * (c0 + c1 * lda), w1, 2 * lda, 1));
+      CHECK(make_panel(c1, vt_view(vtb[(k + 1) & 1], 2 * (m - c1))));  // its buffer was last read by the wide update of k - 1
+      HIPCHECK(hipEventRecord(evP[(k + 1) & 1], sL));
+      // caller's stream: panel k -> everything beyond panel k + 1
+      on(sW, 0);
+      HIPCHECK(hipStreamWaitEvent(sW, evP[k & 1], 0));
+      const int64_t ncols = n - c1 - w1;
+      if (ncols > 0) CHECK(panel_apply(c, pb, 2 * rows, dA + 2 * (c0 + (c1 + w1) * lda), ncols, 2 * lda, 1));
+      HIPCHECK(hipEventRecord(evW[k & 1], sW));
+    }
+    on(sW, 0);
+    HIPCHECK(hipEventRecord(evS, sL));
+    HIPCHECK(hipStreamWaitEvent(sW, evS, 0));  // join: the caller's stream owns the result
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  on(sW, 0);
+  CHECK(rc);
   LAUNCHCHECK();
   return DHQR_OK;
 }
