@@ -58,10 +58,12 @@ class GpuTelemetry(threading.Thread):
     """Power and shader clock of ONE GPU sampled from the amdgpu hwmon files while the timed region runs (this process's
     own measurement; no literal numbers).  Absent files -> {"error": ...}."""
 
-    def __init__(self, index=0, period_s=0.05):
+    def __init__(self, index=0, period_s=0.05, pci=None):
+        """pci: "dddd:bb:dd.f" of the device under test (the box may expose more cards than this process may use: the
+        hwmon files of another, idle card read 95 MHz); without a match the index-th amdgpu card is taken"""
         super().__init__(daemon=True)
         self.period, self.stop_flag, self.w, self.mhz, self.src = period_s, threading.Event(), [], [], None
-        cards = []
+        cards, by_pci = [], {}
         for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
             try:
                 if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
@@ -71,8 +73,10 @@ class GpuTelemetry(threading.Thread):
             hw = sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*")))
             if hw:
                 cards.append(hw[0])
-        if index < len(cards):
-            hw = cards[index]
+                by_pci[os.path.basename(os.path.realpath(d)).lower()] = hw[0]
+        self.matched_pci = bool(pci and pci.lower() in by_pci)
+        if self.matched_pci or index < len(cards):
+            hw = by_pci[pci.lower()] if self.matched_pci else cards[index]
             self.fp = next((f for f in (os.path.join(hw, "power1_average"), os.path.join(hw, "power1_input")) if os.path.exists(f)), None)
             self.ff = os.path.join(hw, "freq1_input") if os.path.exists(os.path.join(hw, "freq1_input")) else None
             self.src = hw
@@ -96,7 +100,7 @@ class GpuTelemetry(threading.Thread):
             self.join(timeout=2)
         if not self.w and not self.mhz:
             return {"error": "no amdgpu hwmon power1_average / power1_input / freq1_input readable under /sys/class/drm"}
-        out = {"source": self.src, "samples": max(len(self.w), len(self.mhz)), "period_s": self.period,
+        out = {"source": self.src, "device_matched_by_pci_address": self.matched_pci, "samples": max(len(self.w), len(self.mhz)), "period_s": self.period,
                "note": "sampled by this process during the timed region (whole factorisation steps, all kernels)"}
         if self.w:
             out.update(watts_avg=sum(self.w) / len(self.w), watts_max=max(self.w))
@@ -428,7 +432,7 @@ def pmc_traffic(symbol, m, n, nb, launches, work):
         for src in e["sources"]:
             have, want = git_blob_hash(os.path.join(ROOT, src)), pm.get("source_hashes", {}).get(src)
             if have != want:
-                return None, f"committed counters were taken with {src} at blob {str(want)[:12]}, this tree has {str(have)[:12]}: re-run tools/gpu_pmc_traffic.sh"
+                return None, f"committed counters were taken with {src} at blob {str(want)[:12]}, this tree has {str(have)[:12]}: re-run the counter passes of tools/gpu_r3_evidence.sh and tools/pmc_stamp.py"
         if "bytes_per_launch" in e:
             return e["bytes_per_launch"], None
         return e["ratio_to_algorithmic"] * work / max(1, launches), None  # measured bytes / algorithmic bytes of the same launches
@@ -585,7 +589,12 @@ def main():
     else:
         ctx.reset_stats()
         ctx.set_profiling(True)
-    tele = GpuTelemetry(local_rank)
+    try:
+        _pr = torch.cuda.get_device_properties(local_rank)
+        _pci = "%04x:%02x:%02x.0" % (_pr.pci_domain_id, _pr.pci_bus_id, _pr.pci_device_id)
+    except Exception:
+        _pci = None
+    tele = GpuTelemetry(local_rank, pci=_pci)
     tele.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -55,20 +55,16 @@ struct dhqr_ctx {
   hipStream_t own = nullptr, stream = nullptr;
   bool profiling = false;
   hipStream_t hi = nullptr;      // high-priority stream: panel factorisation under look-ahead
-  int tn_model = 1;              // wide k_gemm_tn2 launches: split-K factor from the round / partial-traffic estimate (DHQR_TN_MODEL=0: round filling only)
-  int tn_model_min_tiles = 128;  // ... for launches of at least this many column tiles (below, the lane is the critical path and
+  int tn_model_min_tiles = 128;  // wide k_gemm_tn2 launches of at least this many column tiles: split-K factor from the round / partial-traffic estimate (below, the lane is the critical path and
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
   int rankk_wgs = 256;           // ... bulk workgroups of 1024 threads resident at once (CU count; DHQR_RANKK_WGS)
   int rankk = 5;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..5; beyond 3 the further ones are held in LDS)
-  int nn_tr64 = 1;               // narrow C -= V W products on 64-row tiles (DHQR_NN_TR64=0: always 128)
   int rankk_tall = 5;            // nb = 0, columns of 8192 < rows <= 16384: reflectors per pass (k_rankk_tall; DHQR_RANKK_TALL=1: one per launch)
-  int swizzle = 1;               // XCD-aware tile order in k_gemm_nn_sub (+1.5 % at 32768^2; DHQR_SWIZZLE=0 disables)
   int ncu = 256;                 // compute units of the device
-  int spare_cus = 0;             // CUs the persistent wide GEMMs (k_gemm_tn2, k_gemm_nn2) leave free for the look-ahead lane's
+  int spare_cus = 0;             // CUs the persistent wide k_gemm_tn2 launches leave free for the look-ahead lane's
                                  // single-workgroup kernels and for RCCL's kernels (DHQR_SPARE_CUS; multiple of 8: one per XCD)
   int quad = 1;                  // P == 1: two consecutive pairs applied in ONE K = 512 pass (quad_apply; DHQR_QUAD=0: pairs only)
   int64_t quad_min_cols = 10240;  // ... while at least this many columns lie to the right of the quad (DHQR_QUAD_MIN_COLS)
-  int nn2 = 0;                   // wide C -= V W on the persistent 256 x 128-tile kernel k_gemm_nn2 (DHQR_NN2=0: k_gemm_nn_sub)
   struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
   int cur_ws = 0;
   bool lookahead = true;
@@ -350,7 +346,7 @@ static void launch_nn_sub(dhqr_ctx *c, bool vec, dim3 grid, const double *V, int
                           double *C, int64_t ldc, int64_t rows, int64_t ncols, int swz, bool predicated) {
   const int *st = predicated ? pred_stat(c) : nullptr;
   const int64_t ntiles = (ncols + 127) / 128;
-  if (vec && !swz && ntiles <= 2 && ((rows + 127) / 128) * ntiles < 512 && c->nn_tr64) {
+  if (vec && !swz && ntiles <= 2 && ((rows + 127) / 128) * ntiles < 512) {
     const dim3 g64((unsigned)((rows + 63) / 64), (unsigned)ntiles);
     hipLaunchKernelGGL((k_gemm_nn_sub<2, KW, INIT0, false, 64>), g64, dim3(256), 0, c->stream, V, ldv, W, ldw, C, ldc, rows, ncols,
                        0, st, c->epoch);
@@ -362,33 +358,6 @@ static void launch_nn_sub(dhqr_ctx *c, bool vec, dim3 grid, const double *V, int
   else
     hipLaunchKernelGGL((k_gemm_nn_sub<1, KW, INIT0>), grid, dim3(256), 0, c->stream, V, ldv, W, ldw, C, ldc, rows, ncols,
                        swz, st, c->epoch);
-}
-
-// Wide C -= V W on the persistent kernel k_gemm_nn2 (dhqr_gemm.h): 8 S workgroups, S per XCD, S * 8 <= #CU - spare.
-// Block shape of the XCD-aware tile order: br x bc tiles with br * bc == S where possible, so that the S workgroups of an
-// XCD work on ONE block at a time (br V row-tiles + bc W column-tiles in its L2).
-template <int KW>
-static void launch_nn2(dhqr_ctx *c, const double *V, int64_t ldv, const double *W, int64_t ldw, double *C,
-                       int64_t ldc, int64_t rows, int64_t ncols, bool predicated) {
-  const int *st = predicated ? pred_stat(c) : nullptr;
-  const int64_t gx = (rows + 255) / 256, gy = (ncols + 127) / 128;
-  int S = (int)std::max<int64_t>(1, ((int64_t)c->ncu - c->spare_cus) / 8);
-  S = (int)std::min<int64_t>(S, std::max<int64_t>(1, (gx * gy + 7) / 8));  // small launches: no idle workgroups
-  int br = 1, bc = S;
-  double best = 1e300;
-  for (int r = 1; r <= S; ++r) {
-    if (S % r) continue;
-    const double cost = 2.0 * r + (double)(S / r);  // a V row-tile (256 rows) is twice a W column-tile (128 columns)
-    if (cost < best) { best = cost; br = r; bc = S / r; }
-  }
-  if (best > 3.0 * std::sqrt(2.0 * S) + 1.0) {  // S prime or nearly: 4 x 8 blocks, the workgroups drift across two blocks
-    br = 4;
-    bc = 8;
-  }
-  br = (int)std::min<int64_t>(br, gx);
-  bc = (int)std::min<int64_t>(bc, gy);
-  const dim3 grid((unsigned)(8 * S));
-  hipLaunchKernelGGL((k_gemm_nn2<KW>), grid, dim3(512), 0, c->stream, V, ldv, W, ldw, C, ldc, rows, ncols, br, bc, st, c->epoch);
 }
 
 // Workgroups of a persistent wide launch: one per CU, minus the CUs kept free for the lane / RCCL (ctx->spare_cus).
@@ -512,7 +481,7 @@ static int32_t panel_apply(dhqr_ctx *c, const PanelBuf &pb, int64_t rows, double
     CHECK(prof_end(c));                                                                              \
     CHECK(prof_begin(c, CAT_AVW));                                                                   \
     const int64_t gx_ = (rows + 127) / 128;                                                          \
-    const int swz_ = (c->swizzle && gx_ >= 16 && ntiles >= 16) ? 1 : 0;                              \
+    const int swz_ = (gx_ >= 16 && ntiles >= 16) ? 1 : 0;                              \
     dim3 grid((unsigned)gx_, (unsigned)ntiles);                                                      \
     if (swz_) grid = dim3((unsigned)((((gx_ + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);      \
     launch_nn_sub<KW_>(c, vec, grid, V, ldv, (const double *)ws.w2.p, (int64_t)DHQR_NBV, C, ldc, rows, ncols, swz_, \
@@ -903,7 +872,7 @@ static int32_t pair_vtc(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows
   // k_gemm_tn2 workgroups have 512 threads and 110 KB of LDS: one per CU, 256 resident
   const int64_t slots = wide_slots(c);
   pick_split(rows, ntiles, slots, ntiles <= 2 ? 256 : 64, &nsplit, &rps, slots, ntiles <= 2 ? 64 : 128);
-  if (ntiles >= c->tn_model_min_tiles && c->tn_model) {
+  if (ntiles >= c->tn_model_min_tiles) {
     // Wide launches: k_gemm_tn2 runs ONE workgroup per CU, all of the same size, so a launch takes
     // ceil(ntiles * ns / 256) rounds of rows / ns rows each -- 224 column tiles at ns = 1..4 idle an eighth of the chip,
     // at ns = 8 they are exactly seven full rounds.  Estimated time in "rows of one workgroup" (2.85e-7 s each at the
@@ -991,13 +960,10 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
 
   CHECK(prof_begin(c, CAT_AVW));
   const int64_t gx = (rows + 127) / 128;
-  const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
+  const int swz = (gx >= 16 && ntiles >= 16) ? 1 : 0;
   dim3 grid((unsigned)gx, (unsigned)ntiles);
   if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
-  if (c->nn2 && vec && ntiles > 2 && aligned16(ws.w2.p))
-    launch_nn2<256>(c, Vp, ldv, (const double *)ws.w2.p, ld2, C, ldc, rows, ncols, true);
-  else
-    launch_nn_sub<256>(c, vec, grid, Vp, ldv, (const double *)ws.w2.p, ld2, C, ldc, rows, ncols, swz, true);
+  launch_nn_sub<256>(c, vec, grid, Vp, ldv, (const double *)ws.w2.p, ld2, C, ldc, rows, ncols, swz, true);
   CHECK(prof_end(c));
   if (c->profiling) {
     c->st.flops_gemm_vta += 2.0 * DHQR_NBV * ((double)rows + (double)rows_b) * (double)ncols;
@@ -1038,11 +1004,11 @@ static int32_t quad_apply(dhqr_ctx *c, const double *V1, const double *V2, int64
   CHECK(prof_begin(c, CAT_AVW));
   const int *st = pred_stat(c);
   const int64_t gx = (rows + 127) / 128;
-  if (ntiles <= 2 && gx * ntiles < 512 && c->nn_tr64) {  // narrow (the lane / the head of a wide step): 64-row tiles
+  if (ntiles <= 2 && gx * ntiles < 512) {  // narrow (the lane / the head of a wide step): 64-row tiles
     hipLaunchKernelGGL((k_gemm_nn_quad<2, 64>), dim3((unsigned)((rows + 63) / 64), (unsigned)ntiles), dim3(256), 0, c->stream, V1,
                        V2 - 2 * NB, ldv, 2 * NB, (const double *)W, ld4, C, ldc, rows, ncols, 0, st, c->epoch);
   } else {
-    const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
+    const int swz = (gx >= 16 && ntiles >= 16) ? 1 : 0;
     dim3 grid((unsigned)gx, (unsigned)ntiles);
     if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
     hipLaunchKernelGGL((k_gemm_nn_quad<2, 128>), grid, dim3(256), 0, c->stream, V1, V2 - 2 * NB, ldv, 2 * NB,
@@ -1234,8 +1200,6 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
       HIPCHECK(hipStreamCreateWithPriority(&c->hi, hipStreamNonBlocking, hi));
     }
     if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
-    if (const char *e = getenv("DHQR_SWIZZLE")) c->swizzle = atoi(e) != 0;
-    if (const char *e = getenv("DHQR_NN_TR64")) c->nn_tr64 = atoi(e) != 0;
     {
       int ncu = 0;
       if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) {
@@ -1244,13 +1208,11 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
       }
     }
     if (const char *e = getenv("DHQR_SPARE_CUS")) c->spare_cus = std::max(0, std::min(c->ncu - 8, atoi(e)));
-    if (const char *e = getenv("DHQR_NN2")) c->nn2 = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QUAD")) c->quad = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QUAD_MIN_COLS")) c->quad_min_cols = std::max<int64_t>(0, atoll(e));
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_RANKK_TALL")) c->rankk_tall = std::min(5, std::max(1, atoi(e)));
-    if (const char *e = getenv("DHQR_TN_MODEL")) c->tn_model = atoi(e) != 0;
     if (const char *e = getenv("DHQR_TN_MODEL_MIN_TILES")) c->tn_model_min_tiles = atoi(e);
     if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;
     if (const char *e = getenv("DHQR_PAIR_MIN_N")) c->pair_min_n = atoll(e);
@@ -1278,10 +1240,6 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
   if (const char *e = getenv("DHQR_PANEL")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 3) c->panel_impl = v;
-  }
-  if (const char *e = getenv("DHQR_IB")) {
-    const int v = atoi(e);
-    if (v == 16 || v == 32 || v == 64 || v == 128) c->ib = v;
   }
   *out = c;
   return DHQR_OK;

@@ -327,7 +327,7 @@ int32_t dhqr_bench_stream_f64(dhqr_ctx *c, int64_t bytes, double *gbps) {
 }
 
 // GEMM micro-benchmark of the two wide trailing-update kernels on synthetic operands (not a product entry point):
-// kind 0: k_gemm_nn2<2,256> (DHQR_NN2=0: k_gemm_nn_sub<2,256>) (C -= [V_a V_b] W, rows x ncols), kind 1: k_gemm_tn2 (Y = [V_a V_b]' C).
+// kind 0: k_gemm_nn_sub<2,256> (C -= [V_a V_b] W, rows x ncols), kind 1: k_gemm_tn2 (Y = [V_a V_b]' C), kind 2: k_gemm_nn_quad (K = 512).
 // `reps` timed launches after one warm-up; a one-wave clock probe runs beside them on a second stream.
 // out = {ms per launch, TFLOP/s, shader MHz under the kernel, 0}.  The A/B switches of the context apply.
 int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t ncols, int32_t reps, double *out4) {
@@ -359,20 +359,18 @@ int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t nco
     bool timed_nn = false;
     auto launch = [&]() {
       if (kind == 2) {
-        const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
+        const int swz = (gx >= 16 && ntiles >= 16) ? 1 : 0;
         dim3 grid((unsigned)gx, (unsigned)ntiles);
         if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
         hipLaunchKernelGGL((k_gemm_nn_quad<2, 128>), grid, dim3(256), 0, c->stream, (const double *)V, (const double *)(V + 256 * ldv),
                            ldv, (int64_t)0, (const double *)W, ld2, C, ldc, rows, ncols, swz, (const int *)nullptr, 0);
       } else if (kind == 0) {
-        const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
+        const int swz = (gx >= 16 && ntiles >= 16) ? 1 : 0;
         dim3 grid((unsigned)gx, (unsigned)ntiles);
         if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
         if (timed_nn)
           hipLaunchKernelGGL((k_gemm_nn_sub<2, 256, false, true>), grid, dim3(256), 0, c->stream, (const double *)V, ldv,
                              (const double *)W, ld2, C, ldc, rows, ncols, swz, (const int *)nullptr, 0);
-        else if (c->nn2)  // the kernel the wide updates use (persistent, 256 x 128 tiles)
-          launch_nn2<256>(c, V, ldv, W, ld2, C, ldc, rows, ncols, false);
         else
           launch_nn_sub<256>(c, true, grid, V, ldv, W, ld2, C, ldc, rows, ncols, swz, false);
       } else {

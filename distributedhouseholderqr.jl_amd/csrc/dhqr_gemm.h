@@ -667,240 +667,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_quad(const double *__restric
   gemm_nn_sub_body<VEC, 512, false, false, TR>(V, ldv, V2, skip2, W, ldw, C, ldc, rows, ncols, swz, stat, epoch);
 }
 
-// -------------------------------------------------------------------------------------------
-// k_gemm_nn2:  the WIDE trailing update  C[r + c*ldc] -= sum_{p<KW} V[r + p*ldv] * W[p + c*ldw]  as a PERSISTENT kernel.
-//   512 threads = 8 waves as 4 (rows) x 2 (columns), each wave the same 64 x 64 block of 4 x 4 MFMA tiles and the same
-//   four-consecutive-rows accumulator map as k_gemm_nn_sub; output tile 256 rows x 128 columns; 103 KB of LDS, so ONE
-//   workgroup per CU -- like k_gemm_tn2.  Per K-tile the workgroup stages 48 KB for 512 MFMAs (96 B per MFMA against
-//   128 B with 128 x 128 tiles).
-//   The grid is gridDim.x = 8 * S workgroups that LOOP over the tiles (S per XCD: workgroup b runs on XCD b % 8, the
-//   observed dispatch rule, speed only): the host launches 8 * S <= #CU workgroups, so `#CU - 8 S` CUs stay FREE for the
-//   look-ahead lane's single-workgroup kernels and for RCCL's kernels, which otherwise wait for a CU behind a grid of
-//   tens of thousands of GEMM workgroups (profiles/r02: k_build_t 558 us average against 19 us alone).
-//   Tile order: XCD x owns the blocks x, x + 8, ... of br x bc tiles (row-tile fastest inside a block), its S workgroups
-//   walk that list together, so the V row-tiles and W column-tiles of a block (br x 512 KB + bc x 256 KB at KW = 256) are
-//   re-read from the XCD's own L2.
-//   Interior tiles stream their C tile in during the K loop (see k_gemm_nn_sub); edge tiles take the C-first path.
-//   stat/epoch: the device-side commit predicate (see k_gemm_nn_sub).
-#define G_LDV2 258  // LDS stride (doubles) of a 256-row V tile column: k rows 4 banks apart for ds_read_b128
-// SOFTWARE PIPELINE ACROSS TILES: the eight waves of the one workgroup on a CU run in lockstep (barriers), so nothing else
-// on the CU hides a tile's prologue (first operand tile) and epilogue (32 stores per lane) -- with two independent
-// 4-wave workgroups per CU (k_gemm_nn_sub) one's K loop covers the other's.  Here the LAST K-tile of a tile requests the
-// FIRST K-tile of the workgroup's next tile and parks it in the free LDS buffer, so the next tile's MFMAs start right
-// behind the barrier while this tile's stores drain.
-// Requirements (host: launch_nn2): 16-byte aligned operands, rows / ldv / ldc even (VEC = 2 addressing).
-template <int KW>
-__global__ __launch_bounds__(512) void k_gemm_nn2(const double *__restrict__ V, int64_t ldv, const double *__restrict__ W,
-                                                  int64_t ldw, double *__restrict__ C, int64_t ldc, int64_t rows,
-                                                  int64_t ncols, int br, int bc, const int *__restrict__ stat, int epoch) {
-  constexpr int NKT = KW / G_KT;
-  static_assert(NKT == 16 || NKT == 8, "KW = 256 or 128");
-  __shared__ __attribute__((aligned(16))) double Vs[2][G_KT * G_LDV2];
-  __shared__ __attribute__((aligned(16))) double Ws[2][128 * G_LDK];
-  if (stat != nullptr && stat[0] <= epoch) return;  // uniform
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int i16 = lane & 15, k4 = lane >> 4;
-  const int wr = w & 3, wc = w >> 2;
-  const int64_t gx = (rows + 255) / 256, gy = (ncols + 127) / 128;
-  const int64_t nbx = (gx + br - 1) / br, nby = (gy + bc - 1) / bc, nblk = nbx * nby;
-  const int xcd = blockIdx.x & 7, S = gridDim.x >> 3, bsz = br * bc;
-
-  // this workgroup's tile list: entries slot, slot + S, ... of its XCD's list (blocks xcd, xcd + 8, ...), padding skipped
-  int64_t idx = (int64_t)(blockIdx.x >> 3) - S;
-  int64_t r0 = 0, c0 = 0;  // the tile `next_tile` found
-  auto next_tile = [&]() -> bool {
-    for (;;) {
-      idx += S;
-      const int64_t bl = idx / bsz;
-      const int within = (int)(idx - bl * bsz);
-      const int64_t blk = bl * 8 + xcd;
-      if (blk >= nblk) return false;
-      const int64_t tr = (blk % nbx) * br + within % br, tc = (blk / nbx) * bc + within / br;
-      if (tr >= gx || tc >= gy) continue;
-      r0 = tr * 256;
-      c0 = tc * 128;
-      return true;
-    }
-  };
-
-  // staging state of the tile whose K-tiles are being requested
-  const double *Vb = V, *Wb = W;
-  uint32_t offv[4], offw[2];
-  bool okv[4], okw[2];
-  auto setup_staging = [&]() {  // for the tile (r0, c0)
-    const int nrv = (int)((rows - r0 < 256) ? rows - r0 : 256);
-    const int ncv = (int)((ncols - c0 < 128) ? ncols - c0 : 128);
-    Vb = V + r0;
-    Wb = W + c0 * ldw;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {  // V K-tile = 16 p-columns x 128 row pairs
-      const int q = t + i * 512;
-      const int p = q >> 7, rp = q & 127;
-      okv[i] = 2 * rp < nrv;  // rows even: a pair is all or nothing
-      offv[i] = (uint32_t)(p * ldv) + (okv[i] ? 2 * rp : 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {  // W K-tile = 128 columns x 8 p pairs
-      const int q = t + i * 512;
-      const int col = q >> 3, pp = q & 7;
-      okw[i] = col < ncv;
-      offw[i] = (uint32_t)((okw[i] ? col : 0) * ldw) + 2 * pp;
-    }
-  };
-  double2 sv[4], sw[2];
-  auto load_tile = [&](int kt) {  // issue only
-    const double *Vt = Vb + (int64_t)kt * G_KT * ldv;
-    const double *Wt = Wb + kt * G_KT;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sv[i] = *reinterpret_cast<const double2 *>(Vt + offv[i]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) sw[i] = *reinterpret_cast<const double2 *>(Wt + offw[i]);
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = t + i * 512;
-      double2 x = sv[i];
-      if (!okv[i]) x = make_double2(0.0, 0.0);
-      *reinterpret_cast<double2 *>(&Vs[buf][(q >> 7) * G_LDV2 + 2 * (q & 127)]) = x;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = t + i * 512;
-      double2 y = sw[i];
-      if (!okw[i]) y = make_double2(0.0, 0.0);
-      *reinterpret_cast<double2 *>(&Ws[buf][(q >> 3) * G_LDK + 2 * (q & 7)]) = make_double2(-y.x, -y.y);
-    }
-  };
-  dhqr_d4 acc[4][4];
-  auto mma_tile = [&](int buf) {
-    const double *ws = &Ws[buf][(wc * 64 + i16) * G_LDK + k4];
-    const double *vs = &Vs[buf][k4 * G_LDV2 + wr * 64 + 4 * i16];
-#pragma unroll
-    for (int kk = 0; kk < G_KT / 4; ++kk) {
-      double a[4], b[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) a[x] = ws[x * 16 * G_LDK + kk * 4];
-      const double2 b01 = *reinterpret_cast<const double2 *>(vs + kk * 4 * G_LDV2);
-      const double2 b23 = *reinterpret_cast<const double2 *>(vs + kk * 4 * G_LDV2 + 2);
-      b[0] = b01.x;
-      b[1] = b01.y;
-      b[2] = b23.x;
-      b[3] = b23.y;
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = mfma_f64(a[ci], b[ri], acc[ci][ri]);
-    }
-  };
-
-  if (!next_tile()) return;
-  setup_staging();
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (;;) {
-    // ---- the tile being computed: its C addressing outlives setup_staging() of the next tile
-    const int nrv = (int)((rows - r0 < 256) ? rows - r0 : 256);
-    const int ncv = (int)((ncols - c0 < 128) ? ncols - c0 : 128);
-    double *const Cb = C + r0 + c0 * ldc;
-    double *const cunit0 = Cb + ((uint32_t)((wc * 64 + k4) * ldc) + (uint32_t)(wr * 64 + 4 * i16));
-    const int64_t cstep = 4 * ldc;
-    const bool full = nrv == 256 && ncv == 128;  // uniform
-    const bool more = next_tile();                // (r0, c0) now name the NEXT tile
-    if (full) {
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
-    } else {  // edge tile: C first, clamped addresses, masks applied after all loads are issued
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
-          const uint32_t co = (uint32_t)((cl < ncv ? cl : 0) * ldc);
-#pragma unroll
-          for (int ri = 0; ri < 4; ++ri) {
-            const int rl = wr * 64 + 4 * i16 + ri;
-            acc[ci][ri][g] = Cb[co + (uint32_t)(rl < nrv ? rl : 0)];
-          }
-        }
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const bool cok = wc * 64 + ci * 16 + k4 + 4 * g < ncv;
-#pragma unroll
-          for (int ri = 0; ri < 4; ++ri)
-            if (!(cok && wr * 64 + 4 * i16 + ri < nrv)) acc[ci][ri][g] = 0.0;
-        }
-    }
-    // ---- K loop; interior tiles add 16 / NKT of the lane's sixteen (column, 4-row) units of C per K-tile
-    constexpr int UPT = (16 / NKT) > 0 ? 16 / NKT : 1;
-    const double *cin = cunit0;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      double2 cu[UPT][2];
-      if (full) {
-#pragma unroll
-        for (int u = 0; u < UPT; ++u) {
-          cu[u][0] = *reinterpret_cast<const double2 *>(cin);
-          cu[u][1] = *reinterpret_cast<const double2 *>(cin + 2);
-          cin += cstep;
-        }
-      }
-      if (kt + 1 < NKT) {
-        load_tile(kt + 1);
-      } else if (more) {  // the first K-tile of this workgroup's next tile
-        setup_staging();
-        load_tile(0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mma_tile(kt & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 1 < NKT || more) store_tile((kt & 1) ^ 1);
-      if (full) {
-#pragma unroll
-        for (int u = 0; u < UPT; ++u) {
-          const int ci = (kt * UPT + u) >> 2, g = (kt * UPT + u) & 3;
-          acc[ci][0][g] += cu[u][0].x;
-          acc[ci][1][g] += cu[u][0].y;
-          acc[ci][2][g] += cu[u][1].x;
-          acc[ci][3][g] += cu[u][1].y;
-        }
-      }
-      __syncthreads();
-    }
-    // ---- stores: they drain behind the next tile's first MFMAs
-    if (full) {
-      double *cp = cunit0;
-#pragma unroll
-      for (int n = 0; n < 16; ++n) {
-        *reinterpret_cast<double2 *>(cp) = make_double2(acc[n >> 2][0][n & 3], acc[n >> 2][1][n & 3]);
-        *reinterpret_cast<double2 *>(cp + 2) = make_double2(acc[n >> 2][2][n & 3], acc[n >> 2][3][n & 3]);
-        cp += cstep;
-      }
-    } else {
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
-          if (cl < ncv) {
-            const uint32_t co = (uint32_t)(cl * ldc);
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-              const int rl = wr * 64 + 4 * i16 + ri;
-              if (rl < nrv) Cb[co + (uint32_t)rl] = acc[ci][ri][g];
-            }
-          }
-        }
-    }
-    if (!more) break;
-  }
-}
-
 // out[e] = sum_{s<nsplit} in[s*stride + e], e < count  (split-K reduction, deterministic order).
 // A block of 256 threads owns 64 consecutive elements; its four 64-thread groups each sum a quarter
 // of the splits (interleaved) and the quarters are combined through LDS in a fixed order, so a

@@ -22,7 +22,7 @@
 #pragma once
 #include "dhqr_common.h"
 
-#define DHQR_IB 64   // sub-panel width (measured on MI355X at 32768^2: 64 > 32 > 16; DHQR_IB env overrides)
+#define DHQR_IB 64   // sub-panel width (measured on MI355X at 32768^2: 64 > 32 > 16)
 #define PS_CPW 4     // columns per workgroup in k_panel_step
 #define PS_RC 1024   // rows per workgroup chunk (256 threads x 4 rows)
 

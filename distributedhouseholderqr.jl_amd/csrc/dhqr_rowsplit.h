@@ -265,7 +265,7 @@ static int32_t rs_apply_w(const RsProblem &pr, const double *V, int64_t ldv, con
   if (rows > 0) {
     const bool vec = (ldc % 2 == 0) && (ldv % 2 == 0) && (rows % 2 == 0) && aligned16(C) && aligned16(V);
     const int64_t gx = (rows + 127) / 128;
-    const int swz = (c->swizzle && gx >= 16 && ntiles >= 16) ? 1 : 0;
+    const int swz = (gx >= 16 && ntiles >= 16) ? 1 : 0;
     dim3 grid((unsigned)gx, (unsigned)ntiles);
     if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
     launch_nn_sub<128>(c, vec, grid, V, ldv, (const double *)ws.w2.p, NB, C, ldc, rows, ncols, swz, pred);

@@ -153,13 +153,12 @@ def test_rejected_panel_inside_a_quad_step(emu, orc, bad):
     emu.dhqr_destroy(h)
 
 
-@pytest.mark.parametrize("env", [{}, pytest.param({"DHQR_NN2": 0}, marks=_SLOW)])
-def test_wide_update_on_the_persistent_kernels(emu, orc, env):
-    """1024 columns: the first pair's wide update covers 4 column tiles (> 2), i.e. it runs on the persistent kernels
-    k_gemm_tn2 / k_gemm_nn2 (workgroups looping over units / tiles, first K-tile of the next tile prefetched; 256-row
-    tiles: the last row tile is an edge tile) -- against the oracle.  DHQR_NN2=0: the 128 x 128-tile kernel."""
+def test_wide_update_on_the_persistent_tn_kernel(emu, orc):
+    """1024 columns: the first pair's wide update covers 4 column tiles (> 2), i.e. its V'C pass runs on the persistent
+    k_gemm_tn2 (workgroups looping over their (column tile, row slab) units) and its subtraction on the 128 x 128-tile
+    kernel with edge tiles in the last row tile -- against the oracle"""
     A0 = orc.rand_matrix(1030, 1024, 6)
-    h = _ctx(emu, **env)
+    h = _ctx(emu)
     A, al = _factor(emu, h, A0, 128)
     _check(orc, A0, A, al)
     emu.dhqr_destroy(h)
@@ -167,7 +166,6 @@ def test_wide_update_on_the_persistent_kernels(emu, orc, env):
 
 @pytest.mark.parametrize("m,env", [(301, {}),                          # odd m: scalar (VEC = 1) loads everywhere
                                    (300, {"DHQR_PANEL": 2}),           # row-split step kernels for every panel
-                                   pytest.param(300, {"DHQR_PANEL": 2, "DHQR_IB": 32}, marks=_SLOW),
                                    pytest.param(300, {"DHQR_PANEL": 1}, marks=_SLOW),  # one workgroup per column
                                    (300, {"DHQR_CHOLQR_PASSES": 2})])  # CholeskyQR2 in the fast path
 def test_panel_implementations_and_switches(emu, orc, m, env):

@@ -20,6 +20,8 @@ D=$R/tools/pmc_driver
 for ctr in FETCH_SIZE WRITE_SIZE; do
   ( timeout 500 rocprofv3 --pmc $ctr --kernel-trace -d $O/pmc/blocked_$ctr -o out --output-format csv -- $D blocked 32768 > $O/pmc_blocked_$ctr.log 2>&1; echo "rc=$?" >> $O/pmc_blocked_$ctr.log )
   tail -1 $O/pmc_blocked_$ctr.log
+  ( timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d $O/pmc/unblocked_$ctr -o out --output-format csv -- $D unblocked 8192 > $O/pmc_unblocked_$ctr.log 2>&1; echo "rc=$?" >> $O/pmc_unblocked_$ctr.log )
+  tail -1 $O/pmc_unblocked_$ctr.log
 done
 cd $R
 CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-residual"

@@ -21,9 +21,11 @@ def blob(path):
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
-def per_launch(root, ctr, scale):
-    f = glob.glob(os.path.join(root, f"blocked_{ctr}", "**", "*counter_collection.csv"), recursive=True)
+def per_launch(root, ctr, scale, cfg="blocked"):
+    f = glob.glob(os.path.join(root, f"{cfg}_{ctr}", "**", "*counter_collection.csv"), recursive=True)
     out = {}
+    if not f:
+        return out
     for r in csv.DictReader(open(f[0])):
         k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
         out.setdefault(k, []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"]) * scale))
@@ -104,9 +106,25 @@ def main():
     entry(["k_gemm_nn_quad", "k_gemm_nn_sub"], nn, lambda a: 16.0 * a[0] * a[1])
     entry(["k_gemm_tn2"], tn, lambda a: 8.0 * a[0] * a[1])
     old = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")))
-    for e in old.get("entries", []):  # the unblocked entry stays while its source is unchanged
-        if e["kernel_symbol"] == "k_rankk_fused" and old.get("source_hashes", {}).get(srcs[1]) == blob(srcs[1]):
-            entries.append(e)
+    # unblocked 8192^2 (tools/pmc_driver unblocked 8192): every k_rankk_fused launch; algorithmic bytes as implemented =
+    # factor_unblocked_cols' own account: a pass loads and stores every trailing column once (16 B per element and pass)
+    ur, uw = per_launch(root, "FETCH_SIZE", 2.0 * 1024.0, "unblocked"), per_launch(root, "WRITE_SIZE", 1024.0, "unblocked")
+    if ur.get("k_rankk_fused"):
+        nu, K = 8192, 5
+        alg, c0, kold, launches = 0.0, 0, 0, 0
+        while c0 < nu:
+            jlo = c0 - kold
+            alg += 16.0 * (nu - jlo) * (min(K, nu) if kold == 0 else nu - c0)
+            launches += 1
+            c0, kold = c0 + K, K
+        rsum, wsum = sum(ur["k_rankk_fused"]), sum(uw.get("k_rankk_fused", []))
+        entries.append({"kernel_symbol": "k_rankk_fused", "sources": [srcs[1]], "workload": f"unblocked {nu}x{nu}",
+                        "ratio_to_algorithmic": (rsum + wsum) / alg, "read_GB": rsum / 1e9, "write_GB": wsum / 1e9,
+                        "algorithmic_GB": alg / 1e9, "launches": len(ur["k_rankk_fused"]), "launches_in_plan": launches})
+    else:
+        for e in old.get("entries", []):  # the unblocked entry stays while its source is unchanged
+            if e["kernel_symbol"] == "k_rankk_fused" and old.get("source_hashes", {}).get(srcs[1]) == blob(srcs[1]):
+                entries.append(e)
     out = {"what": old["what"].replace("tools/gpu_pmc_traffic.sh + tools/pmc_stamp.py", "tools/gpu_r3_evidence.sh (pmc passes) + tools/pmc_stamp.py"),
            "method": old["method"], "correction": old["correction"], "measured_at_commit": note,
            "source_hashes": {s: blob(s) for s in srcs}, "entries": entries}
