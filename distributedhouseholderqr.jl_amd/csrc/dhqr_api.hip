@@ -195,8 +195,8 @@ static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
                      dim3(T_), 0, c->stream, P, ldp, rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha)
 #define DHQR_RKT(E_)                                                                                     \
   hipLaunchKernelGGL((k_rankk_tall<512, E_, VEC, K>),                                                     \
-                     dim3((unsigned)(1 + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs - 1))), dim3(512), 0, c->stream, P, ldp, \
-                     rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha)
+                     dim3((unsigned)(K + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs - K))), dim3(512), 0, c->stream, P, ldp, \
+                     rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, c->zflags, ++c->zepoch)
   // columns of 8192 < rows <= 16384 (factor_unblocked_cols sends them here when DHQR_RANKK_TALL >= 2)
   if (cov > 512 * 24) { DHQR_RKT(32); return; }
   if (cov > 1024 * 8) { DHQR_RKT(24); return; }

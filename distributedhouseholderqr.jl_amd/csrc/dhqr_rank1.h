@@ -170,16 +170,14 @@ constexpr int rankk_lead_slots(int T, int EPT, int K) {
 // reflectors are not held at all: the first three stream from `vold` (L2) through two buffers, one load ahead of the
 // apply that uses them; reflectors 4, 5 and -- where they fit -- the ones built here sit in LDS (`vl`, passed in
 // together with the reduction scratch; generic pointers, so LDS is reached by flat instructions).
-// STREAM_ALL (k_rankk_tall: columns of more than 8192 rows leave no LDS for reflectors): every old reflector streams from
-// L2 through the two buffers, nothing is kept in LDS.
-template <int T, int EPT, int VEC, int K, bool STREAM_ALL = false>
+template <int T, int EPT, int VEC, int K>
 __device__ __forceinline__ void rankk_lead_body(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
                                                 int64_t c0, int64_t rtop, int kold, const double *vold,
                                                 double *vnew, int64_t vlen, double *__restrict__ alpha,
                                                 double *red, double *reda, double *vl) {
-  constexpr int KR = STREAM_ALL ? K : (K < 3 ? K : 3);
+  constexpr int KR = K < 3 ? K : 3;
   constexpr int KL = K - KR;
-  constexpr int NN = STREAM_ALL ? 0 : rankk_lead_slots(T, EPT, K);
+  constexpr int NN = rankk_lead_slots(T, EPT, K);
   constexpr int HSLOT = 2 * (T / 64);
   const int t = threadIdx.x;
   const int64_t mlast = m - VEC;
@@ -478,12 +476,123 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
 
 __device__ __forceinline__ uint32_t rk_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
+// The lead of k_rankk_tall, PIPELINED over K workgroups: workgroup q owns column c0 + q.  All K apply the pass's old
+// reflectors at the same time (streamed from L2 through two buffers), then workgroup q waits for the reflectors
+// v_c0 .. v_c0+q-1 of its predecessors (flag p = epoch: stored with release at agent scope once the owner's stores have
+// reached its L2, polled with acquire by one thread -- the mechanism of k_zpanel_pipe, dhqr_complex.h; a workgroup only
+// waits for lower-indexed ones), applies them, builds its own and publishes it.  The arithmetic and its order are those of
+// the one-workgroup lead (rankk_lead_body): one workgroup needed K x (K + q) applies of 128 KiB each in sequence (~300 us
+// per launch at 16384 rows, three times the bulk's traffic time); here the chain is K old applies + K hand-overs.
+#define DHQR_RK_FLAG_STRIDE 32  // ints between two flags: one 128-byte line each
 template <int T, int EPT, int VEC, int K>
-__device__ __attribute__((noinline)) void rankk_lead_tall(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
-                                                          int64_t c0, int64_t rtop, int kold, const double *vold,
-                                                          double *vnew, int64_t vlen, double *__restrict__ alpha,
-                                                          double *red, double *reda, double *vl) {
-  rankk_lead_body<T, EPT, VEC, K, true>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
+__device__ __attribute__((noinline)) void rankk_lead_pipe(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols, int64_t c0,
+                                                int64_t rtop, int kold, const double *vold, double *vnew, int64_t vlen,
+                                                double *__restrict__ alpha, double *red, double *reda, int *flags,
+                                                int epoch, int q) {
+  constexpr int HSLOT = 2 * (T / 64);
+  const int64_t c = c0 + q;
+  if (c >= ncols) return;
+  const uint32_t t = threadIdx.x;
+  const uint32_t span = (uint32_t)(m - rtop), olast = span - VEC;
+  int par = 0;
+  double a[EPT], w0[EPT], w1[EPT];
+  auto row_of = [&](int e) -> int64_t {
+    return (VEC == 2) ? rtop + 2 * ((int64_t)t + (int64_t)(e >> 1) * T) + (e & 1) : rtop + t + (int64_t)e * T;
+  };
+  auto load_col = [&](const double *src, double *dst) {  // clamped, not masked (see k_rankk_fused)
+    const double *base = src + rtop;
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const double2 x = *reinterpret_cast<const double2 *>(base + rk_umin(2u * (t + (uint32_t)i * T), olast));
+        dst[2 * i] = x.x;
+        dst[2 * i + 1] = x.y;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) dst[e] = base[rk_umin(t + (uint32_t)e * T, olast)];
+    }
+  };
+  auto load_refl = [&](const double *src, double *dst) {  // zero-padded slots: no clamp, no mask
+    const double *base = src + rtop;
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const double2 x = *reinterpret_cast<const double2 *>(base + 2u * (t + (uint32_t)i * T));
+        dst[2 * i] = x.x;
+        dst[2 * i + 1] = x.y;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) dst[e] = base[t + (uint32_t)e * T];
+    }
+  };
+  auto store = [&](double *dst, const double *src) {
+    double *base = dst + rtop;
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const uint32_t o = 2u * (t + (uint32_t)i * T);
+        if (o < span) *reinterpret_cast<double2 *>(base + o) = make_double2(src[2 * i], src[2 * i + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const uint32_t o = t + (uint32_t)e * T;
+        if (o < span) base[o] = src[e];
+      }
+    }
+  };
+  auto apply = [&](const double *x) {  // src:208 partialdot, src:209 hotloop! on the column in a[]
+    double dot = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) dot = fma(a[e], x[e], dot);
+    const double s = block_sum_alt<T>(dot, reda, par);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) a[e] = fma(-x[e], s, a[e]);
+  };
+  double *col = A + c * lda;
+  load_col(col, a);
+  if (kold > 0) load_refl(vold, w0);
+  for (int p = 0; p < kold; p += 2) {  // the pass's reflectors, one load ahead of the apply that uses it
+    if (p + 1 < kold) load_refl(vold + (int64_t)(p + 1) * vlen, w1);
+    apply(w0);
+    if (p + 1 < kold) {
+      if (p + 2 < kold) load_refl(vold + (int64_t)(p + 2) * vlen, w0);
+      apply(w1);
+    }
+  }
+  for (int p = 0; p < q; ++p) {  // the reflectors of this launch's earlier columns, as their owners publish them
+    if (t == 0)
+      while (__hip_atomic_load(flags + p * DHQR_RK_FLAG_STRIDE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(2);
+    __syncthreads();
+    load_refl(vnew + (int64_t)p * vlen, w0);
+    apply(w0);
+  }
+  dhqr_dd acc = {0.0, 0.0};  // extended-precision column norm (src:129: dnrm2)
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t row = row_of(e);
+    if (row == c) red[HSLOT] = a[e];
+    if (row >= c && row < m) dd_add_sq(acc, a[e]);
+  }
+  const double sq = dd_block_sum<T>(acc, red);  // barriers inside also publish red[HSLOT]
+  const double h = red[HSLOT];
+  const double sn = sqrt(sq);                        // src:129
+  const double al = sn * dhqr_alphafactor(h);        // src:130
+  const double f = 1.0 / sqrt(sn * (sn + fabs(h)));  // src:131
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t row = row_of(e);
+    if (row == c) a[e] = (h - al) * f;  // src:132-135
+    else if (row > c) a[e] *= f;
+    w0[e] = (row >= c && row < m) ? a[e] : 0.0;  // outgoing Hj (src:138-140), zero beyond the column
+  }
+  if (t == 0) alpha[c] = al;
+  store(vnew + (int64_t)q * vlen, w0);
+  store(col, a);
+  __syncthreads();  // every wave's stores have reached the L2
+  if (t == 0) __hip_atomic_store(flags + q * DHQR_RK_FLAG_STRIDE, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // k_rankk_fused for columns of 8192 < rows <= 16384: the same pass -- every trailing column loaded once, K reflectors
@@ -497,18 +606,19 @@ __device__ __attribute__((noinline)) void rankk_lead_tall(double *__restrict__ A
 //     one -- the buffer they go to was stored at the end of the previous column, and a load into registers a store is
 //     still reading from waits for that store; one reflector step later it has drained, and K - 1 steps remain to cover
 //     the HBM latency;
-//   * the lead (rankk_lead_body<..., STREAM_ALL>) streams all K old reflectors through its two buffers, nothing in LDS.
+//   * the lead is K workgroups, one column each, handing their reflectors on through flags (rankk_lead_pipe above).
 // HBM traffic 16 / K bytes per element and reflector instead of the 16 of k_rank1_generic.
 template <int T, int EPT, int VEC, int K>
 __global__ __launch_bounds__(T) void k_rankk_tall(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
                                                   int64_t c0, int64_t rtop, int kold, const double *__restrict__ vold,
-                                                  double *vnew, int64_t vlen, double *__restrict__ alpha) {
+                                                  double *vnew, int64_t vlen, double *__restrict__ alpha, int *flags,
+                                                  int epoch) {
   static_assert(T <= 512, "three buffers of a tall column need the 256 registers of a <= 512-thread workgroup");
   __shared__ double red[2 * (T / 64) + 2];
   __shared__ double reda[2 * (T / 64)];
-  __shared__ double vl[2];  // never addressed (STREAM_ALL)
-  if (blockIdx.x == 0) {
-    rankk_lead_tall<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
+  if (blockIdx.x < K) {  // the K lead workgroups: one column each (rankk_lead_pipe)
+    rankk_lead_pipe<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, flags, epoch,
+                                    (int)blockIdx.x);
     return;
   }
   int par = 0;
@@ -569,8 +679,8 @@ __global__ __launch_bounds__(T) void k_rankk_tall(double *__restrict__ A, int64_
       }
     }
   };
-  const int64_t stride = (int64_t)gridDim.x - 1;
-  int64_t c = c0 + K + ((int64_t)blockIdx.x - 1);
+  const int64_t stride = (int64_t)gridDim.x - K;
+  int64_t c = c0 + K + ((int64_t)blockIdx.x - K);
   if (c >= ncols) return;
   load_col(A + c * lda, a);
   // one column: CUR holds it, NXT receives the next one (unconditional early load, see k_rankk_fused), requested behind

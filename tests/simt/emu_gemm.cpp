@@ -3,7 +3,7 @@
 // wave-synchronously with the documented operand maps.  Workgroups are independent and run in sequence.
 //   emu_gemm tn <vec> <nbv> <rows> <ncols> <ldv> <ldc> <rps> V C out          out: nsplit x (nbv... ld 128) x ncols
 //   emu_gemm nn <vec> <kw>  <rows> <ncols> <ldv> <ldc> <swz> V W Cin Cout     W: ld = kw
-//   emu_gemm nn2 <vec> <kw> <rows> <ncols> <ldv> <ldc> <100 br + bc> V W Cin Cout <S>   persistent kernel, 8 S workgroups
+//   emu_gemm quad <2> <512> <rows> <ncols> <ldv> <ldc> <swz> V1 V2 W Cin Cout <skip>   four-panel update (k_gemm_nn_quad)
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -65,16 +65,21 @@ int main(int argc, char **argv) {
     if (vec == 2) grid2(wgs, 1, 512, [&] { k_gemm_tn2<2>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride); });
     else grid2(wgs, 1, 512, [&] { k_gemm_tn2<1>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride); });
     wr(argv[11], out);
-  } else if (op == "nn2") {  // persistent wide C -= V W (k_gemm_nn2): swz field = 100 * br + bc of the tile blocks, 8 * S workgroups
-    const int brbc = atoi(argv[8]);
-    auto V = rd(argv[9], (size_t)ldv * kparam);
-    auto W = rd(argv[10], (size_t)kparam * ncols);
-    auto C = rd(argv[11], (size_t)ldc * ncols);
-    const int br = brbc / 100, bc = brbc % 100, S = atoi(argv[13]);
-    if (vec == 2 && kparam == 256) grid2(8 * S, 1, 512, [&] { k_gemm_nn2<256>(V.data(), ldv, W.data(), (int64_t)256, C.data(), ldc, rows, ncols, br, bc, nullptr, 0); });
-    else if (vec == 2 && kparam == 128) grid2(8 * S, 1, 512, [&] { k_gemm_nn2<128>(V.data(), ldv, W.data(), (int64_t)128, C.data(), ldc, rows, ncols, br, bc, nullptr, 0); });
-    else return 2;
-    wr(argv[12], C);
+  } else if (op == "quad") {  // four-panel C -= [V1 | V2] W (k_gemm_nn_quad): V2 starts `skip` rows below V1 (same ldv); swz 2 = 64-row tiles
+    const int swz = atoi(argv[8]);
+    auto V1 = rd(argv[9], (size_t)ldv * 256);
+    auto V2 = rd(argv[10], (size_t)ldv * 256);  // row r of V2's storage is row r + skip of the operand
+    auto W = rd(argv[11], (size_t)512 * ncols);
+    auto C = rd(argv[12], (size_t)ldc * ncols);
+    const int64_t skip = atoll(argv[14]);
+    const int gx = (int)((rows + 127) / 128), gy = (int)((ncols + 127) / 128);
+    int lx = gx, ly = gy;
+    if (swz == 1) { lx = (((gx + 7) / 8) * ((gy + 7) / 8) + 7) / 8 * 512; ly = 1; }
+    if (swz == 2)
+      grid2((int)((rows + 63) / 64), gy, 256, [&] { k_gemm_nn_quad<2, 64>(V1.data(), V2.data() - skip, ldv, skip, W.data(), (int64_t)512, C.data(), ldc, rows, ncols, 0, nullptr, 0); });
+    else
+      grid2(lx, ly, 256, [&] { k_gemm_nn_quad<2, 128>(V1.data(), V2.data() - skip, ldv, skip, W.data(), (int64_t)512, C.data(), ldc, rows, ncols, swz, nullptr, 0); });
+    wr(argv[13], C);
   } else if (op == "nn") {
     const int swz = atoi(argv[8]);
     auto V = rd(argv[9], (size_t)ldv * kparam);

@@ -294,30 +294,32 @@ def test_gemm_nn_sub(emu_gemm, tmp_path, vec, kw, rows, ncols, swz):
     assert np.abs(Co - ref).max() < 1e-12   # the padding rows of C keep their value
 
 
-# (vec, kw, rows, ncols, br, bc, S): interior tiles only (streamed C); edge tiles both ways with a block grid that needs
-# padding; more workgroups than tiles; a two-row / one-column edge; one workgroup per XCD looping over many tiles; K = 128
-@pytest.mark.parametrize("vec,kw,rows,ncols,br,bc,S", [(2, 256, 512, 256, 2, 2, 1), (2, 256, 700, 300, 2, 2, 1),
-                                                       (2, 256, 300, 150, 4, 8, 2), (2, 256, 258, 129, 1, 1, 1),
-                                                       (2, 128, 520, 384, 3, 1, 1)])
-def test_gemm_nn2_persistent(emu_gemm, tmp_path, vec, kw, rows, ncols, br, bc, S):
-    """C -= V W on the persistent wide kernel (k_gemm_nn2: 512 threads, 256 x 128 tiles, 8 S workgroups looping over the
-    XCD-blocked tile list): every tile exactly once, padding rows of V / C never used or changed"""
-    rng = np.random.default_rng(2)
-    ldv, ldc = rows + rows % 2 + 2, rows + rows % 2 + 4
-    V = np.full((ldv, kw), 5.0)
-    V[:rows] = rng.standard_normal((rows, kw))
-    W = rng.standard_normal((kw, ncols))
+# (rows, ncols, swz): interior tiles below the second pair (streamed C, K = 512), the two row tiles above it (half the K
+# loop, V2 never touched), edge tiles both ways, the XCD-aware 1-D launch, 64-row tiles (the lane's narrow quad update)
+@pytest.mark.parametrize("rows,ncols,swz", [(512, 256, 0), (700, 300, 0), (2100, 2100, 1), (450, 256, 2)])
+def test_gemm_nn_quad(emu_gemm, tmp_path, rows, ncols, swz):
+    """C -= [V1 | V2] [W1; W2] (k_gemm_nn_quad): V2 starts 256 rows below V1; padding rows of V / C never used or changed"""
+    rng = np.random.default_rng(4)
+    skip = 256
+    ldv, ldc = rows + 2, rows + 4
+    V1 = np.full((ldv, 256), 5.0)
+    V1[:rows] = rng.standard_normal((rows, 256))
+    V2 = np.full((ldv, 256), 6.0)  # storage row r = operand row r + skip
+    V2[:rows - skip] = rng.standard_normal((rows - skip, 256))
+    W = rng.standard_normal((512, ncols))
     C = np.full((ldc, ncols), 3.0)
     C[:rows] = rng.standard_normal((rows, ncols))
-    f = {k: str(tmp_path / f"{k}.bin") for k in ("V", "W", "C", "Co")}
-    _put(f["V"], V)
+    f = {k: str(tmp_path / f"{k}.bin") for k in ("V1", "V2", "W", "C", "Co")}
+    _put(f["V1"], V1)
+    _put(f["V2"], V2)
     _put(f["W"], W)
     _put(f["C"], C)
-    _run(emu_gemm, "nn2", vec, kw, rows, ncols, ldv, ldc, 100 * br + bc, f["V"], f["W"], f["C"], f["Co"], S)
+    _run(emu_gemm, "quad", 2, 512, rows, ncols, ldv, ldc, swz, f["V1"], f["V2"], f["W"], f["C"], f["Co"], skip)
     Co = _get(f["Co"], (ldc, ncols))
     ref = C.copy()
-    ref[:rows] -= V[:rows] @ W
-    assert np.abs(Co - ref).max() < 1e-12
+    ref[:rows] -= V1[:rows] @ W[:256]
+    ref[skip:rows] -= V2[:rows - skip] @ W[256:]
+    assert np.abs(Co - ref).max() < 1e-11
 
 
 # ------------------------------------------------------------------ memory safety of the new generations

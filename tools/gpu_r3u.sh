@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 3, call u: k_rankk_tall with the pipelined lead (K workgroups, noinline): parity vs oracle, sizes
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3u; mkdir -p $O; cd $R
+timeout 600 python tools/tall_check.py 2>&1 | grep -v amdgpu.ids > $O/tall_parity.txt 2>&1
+timeout 900 python tools/quick_bench.py 12288,0 4096,0,16384 2048,0,12288 16384,0 8192,0 1024,0,16384 2>/dev/null | grep '^{' | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print(' ', d['m'],'x',d['n'],'ms', round(d['t1']*1e3,2), 'GFLOP/s', round(d['gflops'],1), 'resid', d.get('resid'))" > $O/tall_sizes.txt 2>&1
+cat $O/tall_parity.txt $O/tall_sizes.txt
