@@ -232,8 +232,12 @@ __global__ __launch_bounds__(T) void k_zpanel_pipe(double2 *__restrict__ P, int6
     // ONE thread polls (a thousand waves spinning on one word slow the owner's flag store down), the barrier releases the
     // others: the acquire's cache invalidation acts on the CU's L1 and the XCD's L2, not on the polling wave alone, and
     // nobody on this CU has touched those columns before
-    if (t == 0)
-      while (__hip_atomic_load(flags + jg * DHQR_ZFLAG_STRIDE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(2);
+    // The polls are RELAXED loads and ONE acquire fence follows: an acquire load at agent scope invalidates the L2 on every
+    // iteration, for every CU of the XCD (dhqr_recon.h, k_panel_server: measured on the wide GEMMs).
+    if (t == 0) {
+      while (__hip_atomic_load(flags + jg * DHQR_ZFLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     __syncthreads();
     for (int qj = 0; qj < G; ++qj) {
       const int j = jg * G + qj;

@@ -563,8 +563,10 @@ __device__ __attribute__((noinline)) void rankk_lead_pipe(double *__restrict__ A
     }
   }
   for (int p = 0; p < q; ++p) {  // the reflectors of this launch's earlier columns, as their owners publish them
-    if (t == 0)
-      while (__hip_atomic_load(flags + p * DHQR_RK_FLAG_STRIDE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(2);
+    if (t == 0) {  // relaxed polls, one acquire fence (an acquire load would invalidate the XCD's L2 on every iteration)
+      while (__hip_atomic_load(flags + p * DHQR_RK_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     __syncthreads();
     load_refl(vnew + (int64_t)p * vlen, w0);
     apply(w0);
