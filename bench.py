@@ -364,12 +364,14 @@ def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd, attem
     if mg is not None:
         mg.reset_stats()
         mg.set_profiling(True)
+    cc0 = mg.comm_counters(0) if mg is not None else q.comm.counters()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
     progress(f"{args.steps} timed steps done")
+    cc1 = mg.comm_counters(0) if mg is not None else q.comm.counters()
     st = None
     if mg is not None:
         st = mg.stats(0)
@@ -392,6 +394,10 @@ def tallskinny(args, pkg, torch, dist, world, rank, local_rank, dev, spmd, attem
                    "nb": 128, "parallelism": f"rows split x{nranks} (128-row aligned slabs), all-reduce of Gram matrices and V'C "
                                              f"partial dots" + (f", transport {mg.transport}" if mg is not None else ", RCCL")},
         "residual": resid,
+        # count and volume of the all-reduces of cross-partition partial dots, per factorisation and
+        # rank, as the driver issued them (at one rank they move nothing; the count and the sizes do not depend on N)
+        "allreduce_per_step": {"count": (cc1["n_allreduce"] - cc0["n_allreduce"]) / args.steps,
+                               "bytes": (cc1["bytes_allreduce"] - cc0["bytes_allreduce"]) / args.steps},
         **attempt_fields(attempt),
         **({"rccl_nranks": (q.comm.rccl_nranks() if spmd else mg.rccl_nranks())} if nranks > 1 else {}),
         "roofline": {"bound": "mfma", "achieved": value / 1e3 / max(world, 1), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -107,6 +107,7 @@ SIGNATURES = {
     "dhqr_comm_create_callbacks": (_i32, [_pp, _p, _i32, _i32, BCAST_FN, ALLREDUCE_FN, _p]),
     "dhqr_comm_destroy": (_i32, [_p]),
     "dhqr_comm_info": (_i32, [_p, _pi32, _pi32, _pi32, _pi64]),
+    "dhqr_comm_counters": (_i32, [_p, _pi64]),
     "dhqr_comm_get_bcast_tuning": (_i32, [_p, _pi32, _pd, _pd]),
     "dhqr_comm_rccl_nranks": (_i32, [_p, _pi32, _pi32]),
     "dhqr_cs_local_cols": (_i64, [_i64, _i32, _i32]),
@@ -123,6 +124,7 @@ SIGNATURES = {
     "dhqr_mg_info": (_i32, [_p, _pi32, _pi32, _pi64, _pi64]),
     "dhqr_mg_get_bcast_tuning": (_i32, [_p, _pi32, _pd, _pd]),
     "dhqr_mg_rccl_nranks": (_i32, [_p, _pi32, _pi32]),
+    "dhqr_mg_comm_counters": (_i32, [_p, _i32, _pi64]),
     "dhqr_mg_alloc_f64": (_i32, [_p, _i64, _i64]),
     "dhqr_mg_fill_uniform_f64": (_i32, [_p, _u64]),
     "dhqr_mg_factor_f64": (_i32, [_p]),

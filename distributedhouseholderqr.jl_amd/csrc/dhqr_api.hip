@@ -2062,6 +2062,15 @@ int32_t dhqr_comm_info(dhqr_comm *cm, int32_t *kind, int32_t *nranks, int32_t *r
   return DHQR_OK;
 }
 
+int32_t dhqr_comm_counters(dhqr_comm *cm, int64_t *out4) {
+  if (!cm || !out4) return set_err(DHQR_EINVAL, "null pointer argument");
+  out4[0] = cm->n_bcast;
+  out4[1] = cm->bytes_bcast;
+  out4[2] = cm->n_allreduce + (cm->lane ? cm->lane->n_allreduce : 0);
+  out4[3] = cm->bytes_allreduce + (cm->lane ? cm->lane->bytes_allreduce : 0);
+  return DHQR_OK;
+}
+
 int32_t dhqr_comm_rccl_nranks(dhqr_comm *cm, int32_t *main_channel, int32_t *lane_channel) {
   if (!cm) return set_err(DHQR_EINVAL, "null communicator");
   auto count = [&](dhqr_comm *x, int32_t *o) -> int32_t {
@@ -2338,6 +2347,10 @@ int32_t dhqr_mg_get_bcast_tuning(dhqr_mg *g, int32_t *algo, double *ms_ring, dou
   return dhqr_comm_get_bcast_tuning(g->rk[0].cm, algo, ms_ring, ms_sag);
 }
 
+int32_t dhqr_mg_comm_counters(dhqr_mg *g, int32_t rank, int64_t *out4) {
+  if (!g || rank < 0 || rank >= g->ndev) return set_err(DHQR_EINVAL, "bad arguments");
+  return dhqr_comm_counters(g->rk[rank].cm, out4);
+}
 int32_t dhqr_mg_rccl_nranks(dhqr_mg *g, int32_t *main_channel, int32_t *lane_channel) {
   if (!g || g->rk.empty()) return set_err(DHQR_EINVAL, "null handle");
   return dhqr_comm_rccl_nranks(g->rk[0].cm, main_channel, lane_channel);

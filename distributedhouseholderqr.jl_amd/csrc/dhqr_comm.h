@@ -141,6 +141,7 @@ struct dhqr_comm {
   dhqr_allreduce_fn cb_allreduce = nullptr;
   void *cb_user = nullptr;
   int64_t bytes_bcast = 0, n_bcast = 0;  // statistics
+  int64_t bytes_allreduce = 0, n_allreduce = 0;  // all-reduces the drivers ISSUED (counted at one rank too, where they move nothing)
   // Second channel over the same ranks (own RCCL communicator / own mailbox): the row-split driver's look-ahead lane
   // issues its small latency-bound collectives here so they do not queue behind the wide stream's all-reduces (the
   // operations of ONE channel are ordered).  nullptr: CALLBACK transport (host synchronous anyway) or a single rank.
@@ -302,6 +303,10 @@ static int32_t comm_wait_consumed(dhqr_comm *cm, int64_t ticket, hipStream_t str
 // In-place sum over the ranks of `count` doubles at dbuf (small buffers: partial dots, norms).  The result is
 // bitwise identical on every rank (fixed summation order).
 static int32_t comm_allreduce_sum(dhqr_comm *cm, double *dbuf, int64_t count, hipStream_t stream) {
+  if (count > 0) {
+    cm->bytes_allreduce += count * 8;
+    cm->n_allreduce++;
+  }
   if (cm->nranks == 1 || count <= 0) return DHQR_OK;
   if (cm->kind == COMM_RCCL) {
     RCCLCHECK(g_rccl.AllReduce(dbuf, dbuf, (size_t)count, ncclFloat64, ncclSum, cm->nccl, stream));

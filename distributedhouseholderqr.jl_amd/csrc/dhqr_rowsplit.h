@@ -245,7 +245,7 @@ static int32_t rs_vtc_allreduce(const RsProblem &pr, dhqr_comm *cmx, const doubl
                        (const double *)ws.w1.p, (int)nsplit, wstride, wstride, ws.w1r.p);
   }
   LAUNCHCHECK();
-  if (cmx && cmx->nranks > 1) CHECK(comm_allreduce_sum(cmx, ws.w1r.p, wstride, c->stream));
+  if (cmx) CHECK(comm_allreduce_sum(cmx, ws.w1r.p, wstride, c->stream));
   return DHQR_OK;
 }
 // C (rows x ncols) -= V (op(T)' Y): W = Top' Y, then the NN GEMM (predicated when `pred`)
@@ -280,7 +280,7 @@ static int32_t rs_gram_allreduce(const RsProblem &pr, dhqr_comm *cmx, const doub
   if (rows <= 0) HIPCHECK(hipMemsetAsync(out, 0, NN * sizeof(double), c->stream));
   else CHECK(gram128(c, X, ldx, rows, out));
   LAUNCHCHECK();
-  if (cmx && cmx->nranks > 1) CHECK(comm_allreduce_sum(cmx, out, (int64_t)NN, c->stream));
+  if (cmx) CHECK(comm_allreduce_sum(cmx, out, (int64_t)NN, c->stream));
   return DHQR_OK;
 }
 // out2 (128 x 256, ld 128) = sum over the ranks of Vb' [Va | Vb]: the pair's cross term V_b'V_a and S_b = V_b'V_b from ONE
@@ -308,7 +308,7 @@ static int32_t rs_gram_cross_allreduce(const RsProblem &pr, dhqr_comm *cmx, cons
                        (int)nsplit, (int64_t)(2 * NN), (int64_t)(2 * NN), out2);
   }
   LAUNCHCHECK();
-  if (cmx && cmx->nranks > 1) CHECK(comm_allreduce_sum(cmx, out2, (int64_t)(2 * NN), c->stream));
+  if (cmx) CHECK(comm_allreduce_sum(cmx, out2, (int64_t)(2 * NN), c->stream));
   return DHQR_OK;
 }
 // Vdst <- the V operand of an already factored panel (diag owner: R part zeroed; others: plain copy of their rows)

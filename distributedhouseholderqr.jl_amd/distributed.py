@@ -156,6 +156,12 @@ class Communicator:
         return {"algorithm": {0: "ncclBroadcast", 1: "scatter + all-gather"}[a.value], "trial_ms_16MiB_ncclBroadcast": r.value,
                 "trial_ms_16MiB_scatter_allgather": g.value}
 
+    def counters(self) -> dict:
+        """collectives carried so far (dhqr_comm_counters): all-reduces are counted as issued, also at one rank"""
+        o = (ctypes.c_int64 * 4)()
+        check(self.L.dhqr_comm_counters(self.handle, o))
+        return {"n_bcast": o[0], "bytes_bcast": o[1], "n_allreduce": o[2], "bytes_allreduce": o[3]}
+
     def rccl_nranks(self) -> dict:
         """rank counts RCCL itself reports (ncclCommCount) for the main channel and the row-split lane's channel"""
         a, b = ctypes.c_int32(), ctypes.c_int32()
@@ -325,6 +331,12 @@ class MultiGpuQR:
         self._check(self.L.dhqr_mg_get_bcast_tuning(self._h, ctypes.byref(a), ctypes.byref(r), ctypes.byref(g)))
         return {"algorithm": {0: "ncclBroadcast", 1: "scatter + all-gather"}[a.value], "trial_ms_16MiB_ncclBroadcast": r.value,
                 "trial_ms_16MiB_scatter_allgather": g.value}
+
+    def comm_counters(self, rank: int = 0) -> dict:
+        """collectives one rank's communicator has carried (dhqr_mg_comm_counters)"""
+        o = (ctypes.c_int64 * 4)()
+        self._check(self.L.dhqr_mg_comm_counters(self._h, rank, o))
+        return {"n_bcast": o[0], "bytes_bcast": o[1], "n_allreduce": o[2], "bytes_allreduce": o[3]}
 
     def rccl_nranks(self) -> dict:
         a, b = ctypes.c_int32(), ctypes.c_int32()
