@@ -475,6 +475,17 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
 }
 
 __device__ __forceinline__ uint32_t rk_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// The thread index as a value the optimiser cannot hoist: in k_rankk_tall every load address is loop invariant, LICM formed
+// 16 + 16 full 64-bit addresses in front of the column loop, the register allocator spilled them, and every global load
+// then waited (s_waitcnt vmcnt(0)) for the scratch reload of ITS address -- one load in flight at a time (ISA of the
+// 512 x 32 instantiation: 152 scratch loads in the loop; 16384-row columns ran at 1.8 - 3.1 TB/s against 4.5 at 12288 rows).
+// With an opaque copy per step the offsets are recomputed where they are used: two VALU instructions per 16-byte load.
+__device__ __forceinline__ uint32_t rk_opaque(uint32_t t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(t));
+#endif
+  return t;
+}
 
 // The lead of k_rankk_tall, PIPELINED over K workgroups: workgroup q owns column c0 + q.  All K apply the pass's old
 // reflectors at the same time (streamed from L2 through two buffers), then workgroup q waits for the reflectors
@@ -501,44 +512,47 @@ __device__ __attribute__((noinline)) void rankk_lead_pipe(double *__restrict__ A
   };
   auto load_col = [&](const double *src, double *dst) {  // clamped, not masked (see k_rankk_fused)
     const double *base = src + rtop;
+    const uint32_t tt = rk_opaque(t);  // offsets recomputed per call, not hoisted and spilled (rk_opaque)
     if constexpr (VEC == 2) {
 #pragma unroll
       for (int i = 0; i < EPT / 2; ++i) {
-        const double2 x = *reinterpret_cast<const double2 *>(base + rk_umin(2u * (t + (uint32_t)i * T), olast));
+        const double2 x = *reinterpret_cast<const double2 *>(base + rk_umin(2u * (tt + (uint32_t)i * T), olast));
         dst[2 * i] = x.x;
         dst[2 * i + 1] = x.y;
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) dst[e] = base[rk_umin(t + (uint32_t)e * T, olast)];
+      for (int e = 0; e < EPT; ++e) dst[e] = base[rk_umin(tt + (uint32_t)e * T, olast)];
     }
   };
   auto load_refl = [&](const double *src, double *dst) {  // zero-padded slots: no clamp, no mask
     const double *base = src + rtop;
+    const uint32_t tt = rk_opaque(t);
     if constexpr (VEC == 2) {
 #pragma unroll
       for (int i = 0; i < EPT / 2; ++i) {
-        const double2 x = *reinterpret_cast<const double2 *>(base + 2u * (t + (uint32_t)i * T));
+        const double2 x = *reinterpret_cast<const double2 *>(base + 2u * (tt + (uint32_t)i * T));
         dst[2 * i] = x.x;
         dst[2 * i + 1] = x.y;
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) dst[e] = base[t + (uint32_t)e * T];
+      for (int e = 0; e < EPT; ++e) dst[e] = base[tt + (uint32_t)e * T];
     }
   };
   auto store = [&](double *dst, const double *src) {
     double *base = dst + rtop;
+    const uint32_t tt = rk_opaque(t);
     if constexpr (VEC == 2) {
 #pragma unroll
       for (int i = 0; i < EPT / 2; ++i) {
-        const uint32_t o = 2u * (t + (uint32_t)i * T);
+        const uint32_t o = 2u * (tt + (uint32_t)i * T);
         if (o < span) *reinterpret_cast<double2 *>(base + o) = make_double2(src[2 * i], src[2 * i + 1]);
       }
     } else {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
-        const uint32_t o = t + (uint32_t)e * T;
+        const uint32_t o = tt + (uint32_t)e * T;
         if (o < span) base[o] = src[e];
       }
     }
@@ -632,42 +646,42 @@ __global__ __launch_bounds__(T) void k_rankk_tall(double *__restrict__ A, int64_
   double a[EPT], an[EPT], w[EPT];
   // columns: offsets clamped to the last valid access (never masked: see k_rankk_fused); reflectors: the host pads every
   // reflector slot with zeros up to rtop + T * EPT (factor_unblocked_cols: vlen), so their loads need neither
-  auto load_col = [&](const double *src, double *dst) {
+  auto load_col = [&](const double *src, double *dst, uint32_t tt) {
     const double *base = src + rtop;
     if constexpr (VEC == 2) {
 #pragma unroll
       for (int i = 0; i < EPT / 2; ++i) {
-        const uint32_t o = rk_umin(2u * (t + (uint32_t)i * T), olast);
+        const uint32_t o = rk_umin(2u * (tt + (uint32_t)i * T), olast);
         const double2 x = *reinterpret_cast<const double2 *>(base + o);
         dst[2 * i] = x.x;
         dst[2 * i + 1] = x.y;
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) dst[e] = base[rk_umin(t + (uint32_t)e * T, olast)];
+      for (int e = 0; e < EPT; ++e) dst[e] = base[rk_umin(tt + (uint32_t)e * T, olast)];
     }
   };
-  auto load_refl = [&](const double *src, double *dst) {
+  auto load_refl = [&](const double *src, double *dst, uint32_t tt) {
     const double *base = src + rtop;
     if constexpr (VEC == 2) {
 #pragma unroll
       for (int i = 0; i < EPT / 2; ++i) {
-        const double2 x = *reinterpret_cast<const double2 *>(base + 2u * (t + (uint32_t)i * T));
+        const double2 x = *reinterpret_cast<const double2 *>(base + 2u * (tt + (uint32_t)i * T));
         dst[2 * i] = x.x;
         dst[2 * i + 1] = x.y;
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) dst[e] = base[t + (uint32_t)e * T];
+      for (int e = 0; e < EPT; ++e) dst[e] = base[tt + (uint32_t)e * T];
     }
   };
   typedef double dhqr_d2 __attribute__((ext_vector_type(2)));
-  auto store_nt = [&](double *dst, const double *src) {
+  auto store_nt = [&](double *dst, const double *src, uint32_t tt) {
     double *base = dst + rtop;
     if constexpr (VEC == 2) {
 #pragma unroll
       for (int i = 0; i < EPT / 2; ++i) {
-        const uint32_t o = 2u * (t + (uint32_t)i * T);
+        const uint32_t o = 2u * (tt + (uint32_t)i * T);
         if (o < span) {
           const dhqr_d2 x = {src[2 * i], src[2 * i + 1]};
           __builtin_nontemporal_store(x, reinterpret_cast<dhqr_d2 *>(base + o));
@@ -676,7 +690,7 @@ __global__ __launch_bounds__(T) void k_rankk_tall(double *__restrict__ A, int64_
     } else {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
-        const uint32_t o = t + (uint32_t)e * T;
+        const uint32_t o = tt + (uint32_t)e * T;
         if (o < span) __builtin_nontemporal_store(src[e], base + o);
       }
     }
@@ -684,7 +698,7 @@ __global__ __launch_bounds__(T) void k_rankk_tall(double *__restrict__ A, int64_
   const int64_t stride = (int64_t)gridDim.x - K;
   int64_t c = c0 + K + ((int64_t)blockIdx.x - K);
   if (c >= ncols) return;
-  load_col(A + c * lda, a);
+  load_col(A + c * lda, a, t);
   // one column: CUR holds it, NXT receives the next one (unconditional early load, see k_rankk_fused), requested behind
   // the first reflector's step
 #define DHQR_RKT_APPLY(CUR)                                                              \
@@ -698,15 +712,16 @@ __global__ __launch_bounds__(T) void k_rankk_tall(double *__restrict__ A, int64_
   {                                                                                      \
     const int64_t cn = c + stride;                                                       \
     const bool more = cn < ncols;                                                        \
-    load_refl(vold, w);                                                                  \
+    const uint32_t tt = rk_opaque(t); /* offsets recomputed per step, never hoisted */   \
+    load_refl(vold, w, tt);                                                              \
     DHQR_RKT_APPLY(CUR)                                                                  \
-    if (kold > 1) load_refl(vold + vlen, w);                                             \
-    load_col(A + (more ? cn : c) * lda, NXT);                                            \
+    if (kold > 1) load_refl(vold + vlen, w, tt);                                         \
+    load_col(A + (more ? cn : c) * lda, NXT, tt);                                        \
     for (int p = 1; p < kold; ++p) {                                                     \
       DHQR_RKT_APPLY(CUR)                                                                \
-      if (p + 1 < kold) load_refl(vold + (int64_t)(p + 1) * vlen, w);                    \
+      if (p + 1 < kold) load_refl(vold + (int64_t)(p + 1) * vlen, w, rk_opaque(t));      \
     }                                                                                    \
-    store_nt(A + c * lda, CUR);                                                          \
+    store_nt(A + c * lda, CUR, rk_opaque(t));                                            \
     if (!more) break;                                                                    \
     c = cn;                                                                              \
   }

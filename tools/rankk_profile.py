@@ -7,7 +7,7 @@ import sys
 db, n, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 nfact = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 cur = sqlite3.connect(db).cursor()
-rows = cur.execute("select start, end - start from kernels where name like '%k_rankk_fused%' order by start").fetchall()
+rows = cur.execute("select start, end - start from kernels where name like '%k_rankk_%' order by start").fetchall()
 per = len(rows) // nfact
 rows = rows[-per:]  # last factorisation
 print(f"# {len(rows)} k_rankk_fused launches of the last factorisation, n = {n}, K = {K}")
