@@ -59,6 +59,7 @@ struct dhqr_ctx {
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
   int rankk_wgs = 256;           // ... bulk workgroups of 1024 threads resident at once (CU count; DHQR_RANKK_WGS)
   int rankk = 5;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..5; beyond 3 the further ones are held in LDS)
+  int rankk_pipe = 1;            // k_rankk_fused: the lead as K pipelined workgroups where the lead bounds the launch (launch_rankk; DHQR_RANKK_PIPE=0 never, 2 always)
   int rankk_tall = 5;            // nb = 0, columns of 8192 < rows <= 16384: reflectors per pass (k_rankk_tall; DHQR_RANKK_TALL=1: one per launch)
   int ncu = 256;                 // compute units of the device
   int spare_cus = 0;             // CUs the persistent wide k_gemm_tn2 launches leave free for the look-ahead lane's
@@ -189,10 +190,18 @@ static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
   // lead workgroup + persistent bulk workgroups: as many as run at once (one 1024-thread workgroup per CU), less the
   // lead's place
   const int64_t nbulk = (kold == 0) ? 0 : std::max<int64_t>(0, ncols - c0 - K);
+  // The lead as K pipelined workgroups (rankk_lead_pipe) where the LEAD bounds the launch: few columns left for the bulk
+  // (its traffic takes less than the one-workgroup lead's ~105 us x cov / 8192 below ~3000 columns, whatever cov) and
+  // columns long enough for K - 1 hand-overs (~8 us each) to cost less than the one workgroup's K (K + 1) / 2 extra applies.
+  // 8192 x 2048: 43 -> 25 ms; on squares K - 1 fewer bulk workgroups cost 1.6 % while the bulk bounds the launch, hence
+  // not everywhere (profiles/r03_unblocked_pipelined_lead.txt).  DHQR_RANKK_PIPE=0: never, 2: always.
+  const bool pipe = c->rankk_pipe == 2 || (c->rankk_pipe == 1 && nbulk <= 3072 && cov >= 2048);
+  const int nlead = pipe ? K : 1;
 #define DHQR_RK(T_, E_)                                                                                  \
   hipLaunchKernelGGL((k_rankk_fused<T_, E_, VEC, K>),                                                    \
-                     dim3((unsigned)(1 + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs * (rankk_lead_slots(T_, E_, K) > 0 ? 1 : 1024 / T_) - 1))), \
-                     dim3(T_), 0, c->stream, P, ldp, rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha)
+                     dim3((unsigned)(nlead + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs * (rankk_lead_slots(T_, E_, K) > 0 ? 1 : 1024 / T_) - nlead))), \
+                     dim3(T_), 0, c->stream, P, ldp, rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha,  \
+                     pipe ? c->zflags : (int *)nullptr, pipe ? ++c->zepoch : 0)
 #define DHQR_RKT(E_)                                                                                     \
   hipLaunchKernelGGL((k_rankk_tall<512, E_, VEC, K>),                                                     \
                      dim3((unsigned)(K + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs - K))), dim3(512), 0, c->stream, P, ldp, \
@@ -230,9 +239,10 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
   const int Kt = std::min(K, c->rankk_tall);  // ... while a column has 8192 < rows <= 16384 (k_rankk_tall; < 2: one per launch)
   // a reflector slot: the column's rows, zero-padded so that k_rankk_tall (512 threads x 32 elements from a row > rows -
   // 16384) reads reflectors without clamping or masking -- the kernels never write beyond row `rows`
-  const size_t vlen = (size_t)((rows + (Kt >= 2 && rows > 1024 * 8 ? 1024 * 8 : 0) + 17) & ~(int64_t)15);
+  const bool padded = (Kt >= 2 && rows > 1024 * 8) || c->rankk_pipe;
+  const size_t vlen = (size_t)((rows + (padded ? 1024 * 8 : 0) + 17) & ~(int64_t)15);
   CHECK(ensure(c, c->vbuf, 2 * (size_t)std::max(K, 1) * vlen));
-  if (Kt >= 2 && rows > 1024 * 8) HIPCHECK(hipMemsetAsync(c->vbuf.p, 0, 2 * (size_t)std::max(K, 1) * vlen * sizeof(double), c->stream));
+  if (padded) HIPCHECK(hipMemsetAsync(c->vbuf.p, 0, 2 * (size_t)std::max(K, 1) * vlen * sizeof(double), c->stream));
   double *vset[2] = {c->vbuf.p, c->vbuf.p + (size_t)std::max(K, 1) * vlen};  // two sets of K reflectors
   const bool vec = (ldp % 2 == 0) && (rows % 2 == 0) && aligned16(P);
   auto account = [&](int64_t jlo, int64_t ncol_upd) {
@@ -1213,6 +1223,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_RANKK_TALL")) c->rankk_tall = std::min(5, std::max(1, atoi(e)));
+    if (const char *e = getenv("DHQR_RANKK_PIPE")) c->rankk_pipe = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("DHQR_TN_MODEL_MIN_TILES")) c->tn_model_min_tiles = atoi(e);
     if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;
     if (const char *e = getenv("DHQR_PAIR_MIN_N")) c->pair_min_n = atoll(e);

@@ -317,163 +317,6 @@ __device__ __attribute__((noinline)) void rankk_lead(double *__restrict__ A, int
   rankk_lead_body<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
 }
 
-// K steps in ONE pass over the trailing columns.  The reflectors v_jlo .. v_jlo+kold-1 already exist (`vold`, one every
-// `vlen` doubles) and stay on the CU for the whole launch (three in registers, the others in LDS).  A workgroup loads a
-// column once, applies them one after the
-// other -- each with its own dot product over the column as updated so far, i.e. exactly the arithmetic of `kold`
-// consecutive k_rank1_fused launches (src:208-209 per step) -- and stores it once: 16/K bytes of HBM traffic per
-// (element, reflector) instead of 16.
-//   * blockIdx 0, the LEAD workgroup (rankk_lead_body above), owns the next K columns c0 .. c0+K-1: column by column
-//     it also applies the reflectors it has just built (from LDS where they fit, otherwise re-read from `vnew`: each
-//     thread reads back only elements it wrote itself) and builds the column's own reflector (src:129-140), so the
-//     launch hands v_c0 .. v_c0+K-1 to the next one and no single-workgroup launch sits between two passes.
-//   * blockIdx b >= 1, the BULK workgroups, are persistent: b owns columns c0+K + (b-1) + i (gridDim-1), and requests
-//     the next column's loads before it works on the current one (one workgroup per CU holds three column buffers and
-//     three reflectors in registers, so nothing else hides the load latency while it computes).
-// kold = 0 with a grid of ONE workgroup builds the first K reflectors of a matrix / panel from scratch; kold = 1
-// continues from the one-reflector kernels of the tall-column phase.  Rows covered: [rtop, rtop + T*EPT), rtop = jlo
-// (rounded down to even for VEC = 2); every reflector is zero above its diagonal.
-template <int T, int EPT, int VEC, int K>
-__global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
-                                                   int64_t c0, int64_t rtop, int kold,
-                                                   const double *__restrict__ vold, double *vnew, int64_t vlen,
-                                                   double *__restrict__ alpha) {
-  constexpr int KR = K < 3 ? K : 3;  // reflectors held in registers ...
-  constexpr int KL = K - KR;         // ... and in LDS (one workgroup per CU: 64 KiB each at 8192 rows)
-  __shared__ double red[2 * (T / 64) + 2];   // the lead's double-double sums + the pivot slot
-  __shared__ double reda[2 * (T / 64)];      // block_sum_alt: two halves in alternation
-  int par = 0;
-  // ... and, where a column is short enough to leave room (<= 6144 rows), the reflectors the LEAD builds in this launch:
-  // it re-reads each of them for every later column of its K, on the chain that bounds the launch once the trailing
-  // matrix is small (such launches run one workgroup per CU: launch_rankk)
-  constexpr int NN = rankk_lead_slots(T, EPT, K);
-  __shared__ __attribute__((aligned(16))) double vl[(KL + NN) > 0 ? (KL + NN) * T * EPT : 2];
-  const int t = threadIdx.x;
-  const int64_t mlast = m - VEC;
-  double a[EPT], an[EPT], v[KR][EPT];
-  double ax[EPT];  // third column buffer of the bulk rotation
-
-  // rows beyond m read a clamped address; a REFLECTOR is zeroed there (mask), a COLUMN is left as loaded: times the
-  // reflector's zero it adds nothing to a dot product, its update is a - 0 s, and it is never stored -- so a column's
-  // registers have no use between the load and the first dot product, and the bulk loop's early loads stay in flight
-  auto load = [&](const double *src, double *dst, bool mask) {
-    if constexpr (VEC == 2) {
-#pragma unroll
-      for (int i = 0; i < EPT / 2; ++i) {
-        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
-        const bool ok = row < m;
-        const double2 x = *reinterpret_cast<const double2 *>(src + (ok ? row : mlast));
-        dst[2 * i] = (ok || !mask) ? x.x : 0.0;
-        dst[2 * i + 1] = (ok || !mask) ? x.y : 0.0;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const int64_t row = rtop + t + (int64_t)e * T;
-        const bool ok = row < m;
-        const double x = src[ok ? row : mlast];
-        dst[e] = (ok || !mask) ? x : 0.0;
-      }
-    }
-  };
-  // the bulk's column stores are non-temporal: a column is not read again before the next launch, and dirty lines left in
-  // the L2s are written back at the kernel boundary, on the chain of dependent launches (8192^2: 154 -> 148 ms;
-  // non-temporal LOADS of the columns: no gain)
-  typedef double dhqr_d2 __attribute__((ext_vector_type(2)));
-  auto store_nt = [&](double *dst, const double *src) {
-    if constexpr (VEC == 2) {
-#pragma unroll
-      for (int i = 0; i < EPT / 2; ++i) {
-        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
-        if (row < m) {
-          const dhqr_d2 x = {src[2 * i], src[2 * i + 1]};
-          __builtin_nontemporal_store(x, reinterpret_cast<dhqr_d2 *>(dst + row));
-        }
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const int64_t row = rtop + t + (int64_t)e * T;
-        if (row < m) __builtin_nontemporal_store(src[e], dst + row);
-      }
-    }
-  };
-  auto apply = [&](double *y, const double *x) {  // one step on the column in y[]: src:208 partialdot, src:209 hotloop!
-    double dot = 0.0;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) dot = fma(y[e], x[e], dot);
-    const double s = block_sum_alt<T>(dot, reda, par);
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) y[e] = fma(-x[e], s, y[e]);
-  };
-  // thread t keeps element e of an LDS-resident reflector at the position of its own 16-byte (8-byte) accesses
-  auto lds_at = [&](int q, int e) -> double * {
-    return (VEC == 2) ? vl + (size_t)q * T * EPT + 2 * ((size_t)t + (size_t)(e >> 1) * T) + (e & 1)
-                      : vl + (size_t)q * T * EPT + (size_t)t + (size_t)e * T;
-  };
-  auto apply_lds = [&](double *y, int q) {
-    double dot = 0.0;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) dot = fma(y[e], *lds_at(q, e), dot);
-    const double s = block_sum_alt<T>(dot, reda, par);
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) y[e] = fma(-*lds_at(q, e), s, y[e]);
-  };
-  auto load_old = [&]() {  // the launch's reflectors: registers, then LDS (staged through ax[])
-#pragma unroll
-    for (int p = 0; p < KR; ++p)
-      if (p < kold) load(vold + (int64_t)p * vlen, v[p], true);
-#pragma unroll
-    for (int q = 0; q < KL; ++q)
-      if (KR + q < kold) {
-        load(vold + (int64_t)(KR + q) * vlen, ax, true);
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) *lds_at(q, e) = ax[e];  // read back by the same thread only
-      }
-  };
-  auto apply_old = [&](double *y) {
-#pragma unroll
-    for (int p = 0; p < KR; ++p)
-      if (p < kold) apply(y, v[p]);
-#pragma unroll
-    for (int q = 0; q < KL; ++q)
-      if (KR + q < kold) apply_lds(y, q);
-  };
-
-  if (blockIdx.x != 0) {  // ---- bulk: persistent, the next column's loads in flight behind the current column's work
-    const int64_t stride = (int64_t)gridDim.x - 1;
-    int64_t c = c0 + K + ((int64_t)blockIdx.x - 1);
-    if (c >= ncols) return;
-    load(A + c * lda, a, false);
-    load_old();
-    // THREE column buffers in rotation: a store holds its data registers until it completes, so the early load goes to
-    // the buffer stored one step earlier, not to the one stored a moment ago.  (The early load is unconditional -- past
-    // the last column it re-reads the current one -- so that the wait counters the compiler derives are those of
-    // straight-line code: a branch around the loads would make it wait for them at once.)
-#define DHQR_RK_STEP(CUR, NXT)                       \
-    {                                                  \
-      const int64_t cn = c + stride;                   \
-      const bool more = cn < ncols;                    \
-      load(A + (more ? cn : c) * lda, NXT, false);     \
-      apply_old(CUR);                                  \
-      store_nt(A + c * lda, CUR);                      \
-      if (!more) break;                                \
-      c = cn;                                          \
-    }
-    for (;;) {
-      DHQR_RK_STEP(a, an)
-      DHQR_RK_STEP(an, ax)
-      DHQR_RK_STEP(ax, a)
-    }
-#undef DHQR_RK_STEP
-    return;
-  }
-
-  // ---- lead: the next K columns and their reflectors -- a function of its own (own register allocation)
-  if constexpr (T > 512) rankk_lead<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
-  else rankk_lead_body<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
-}
-
 __device__ __forceinline__ uint32_t rk_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 // The thread index as a value the optimiser cannot hoist: in k_rankk_tall every load address is loop invariant, LICM formed
 // 16 + 16 full 64-bit addresses in front of the column loop, the register allocator spilled them, and every global load
@@ -609,6 +452,171 @@ __device__ __attribute__((noinline)) void rankk_lead_pipe(double *__restrict__ A
   store(col, a);
   __syncthreads();  // every wave's stores have reached the L2
   if (t == 0) __hip_atomic_store(flags + q * DHQR_RK_FLAG_STRIDE, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// K steps in ONE pass over the trailing columns.  The reflectors v_jlo .. v_jlo+kold-1 already exist (`vold`, one every
+// `vlen` doubles) and stay on the CU for the whole launch (three in registers, the others in LDS).  A workgroup loads a
+// column once, applies them one after the
+// other -- each with its own dot product over the column as updated so far, i.e. exactly the arithmetic of `kold`
+// consecutive k_rank1_fused launches (src:208-209 per step) -- and stores it once: 16/K bytes of HBM traffic per
+// (element, reflector) instead of 16.
+//   * blockIdx 0, the LEAD workgroup (rankk_lead_body above), owns the next K columns c0 .. c0+K-1: column by column
+//     it also applies the reflectors it has just built (from LDS where they fit, otherwise re-read from `vnew`: each
+//     thread reads back only elements it wrote itself) and builds the column's own reflector (src:129-140), so the
+//     launch hands v_c0 .. v_c0+K-1 to the next one and no single-workgroup launch sits between two passes.
+//   * blockIdx b >= 1, the BULK workgroups, are persistent: b owns columns c0+K + (b-1) + i (gridDim-1), and requests
+//     the next column's loads before it works on the current one (one workgroup per CU holds three column buffers and
+//     three reflectors in registers, so nothing else hides the load latency while it computes).
+// kold = 0 with a grid of ONE workgroup builds the first K reflectors of a matrix / panel from scratch; kold = 1
+// continues from the one-reflector kernels of the tall-column phase.  Rows covered: [rtop, rtop + T*EPT), rtop = jlo
+// (rounded down to even for VEC = 2); every reflector is zero above its diagonal.
+template <int T, int EPT, int VEC, int K>
+__global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
+                                                   int64_t c0, int64_t rtop, int kold,
+                                                   const double *__restrict__ vold, double *vnew, int64_t vlen,
+                                                   double *__restrict__ alpha, int *flags, int epoch) {
+  constexpr int KR = K < 3 ? K : 3;  // reflectors held in registers ...
+  constexpr int KL = K - KR;         // ... and in LDS (one workgroup per CU: 64 KiB each at 8192 rows)
+  __shared__ double red[2 * (T / 64) + 2];   // the lead's double-double sums + the pivot slot
+  __shared__ double reda[2 * (T / 64)];      // block_sum_alt: two halves in alternation
+  int par = 0;
+  // ... and, where a column is short enough to leave room (<= 6144 rows), the reflectors the LEAD builds in this launch:
+  // it re-reads each of them for every later column of its K, on the chain that bounds the launch once the trailing
+  // matrix is small (such launches run one workgroup per CU: launch_rankk)
+  constexpr int NN = rankk_lead_slots(T, EPT, K);
+  __shared__ __attribute__((aligned(16))) double vl[(KL + NN) > 0 ? (KL + NN) * T * EPT : 2];
+  const int t = threadIdx.x;
+  const int64_t mlast = m - VEC;
+  double a[EPT], an[EPT], v[KR][EPT];
+  double ax[EPT];  // third column buffer of the bulk rotation
+
+  // rows beyond m read a clamped address; a REFLECTOR is zeroed there (mask), a COLUMN is left as loaded: times the
+  // reflector's zero it adds nothing to a dot product, its update is a - 0 s, and it is never stored -- so a column's
+  // registers have no use between the load and the first dot product, and the bulk loop's early loads stay in flight
+  auto load = [&](const double *src, double *dst, bool mask) {
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
+        const bool ok = row < m;
+        const double2 x = *reinterpret_cast<const double2 *>(src + (ok ? row : mlast));
+        dst[2 * i] = (ok || !mask) ? x.x : 0.0;
+        dst[2 * i + 1] = (ok || !mask) ? x.y : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t row = rtop + t + (int64_t)e * T;
+        const bool ok = row < m;
+        const double x = src[ok ? row : mlast];
+        dst[e] = (ok || !mask) ? x : 0.0;
+      }
+    }
+  };
+  // the bulk's column stores are non-temporal: a column is not read again before the next launch, and dirty lines left in
+  // the L2s are written back at the kernel boundary, on the chain of dependent launches (8192^2: 154 -> 148 ms;
+  // non-temporal LOADS of the columns: no gain)
+  typedef double dhqr_d2 __attribute__((ext_vector_type(2)));
+  auto store_nt = [&](double *dst, const double *src) {
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const int64_t row = rtop + 2 * ((int64_t)t + (int64_t)i * T);
+        if (row < m) {
+          const dhqr_d2 x = {src[2 * i], src[2 * i + 1]};
+          __builtin_nontemporal_store(x, reinterpret_cast<dhqr_d2 *>(dst + row));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int64_t row = rtop + t + (int64_t)e * T;
+        if (row < m) __builtin_nontemporal_store(src[e], dst + row);
+      }
+    }
+  };
+  auto apply = [&](double *y, const double *x) {  // one step on the column in y[]: src:208 partialdot, src:209 hotloop!
+    double dot = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) dot = fma(y[e], x[e], dot);
+    const double s = block_sum_alt<T>(dot, reda, par);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) y[e] = fma(-x[e], s, y[e]);
+  };
+  // thread t keeps element e of an LDS-resident reflector at the position of its own 16-byte (8-byte) accesses
+  auto lds_at = [&](int q, int e) -> double * {
+    return (VEC == 2) ? vl + (size_t)q * T * EPT + 2 * ((size_t)t + (size_t)(e >> 1) * T) + (e & 1)
+                      : vl + (size_t)q * T * EPT + (size_t)t + (size_t)e * T;
+  };
+  auto apply_lds = [&](double *y, int q) {
+    double dot = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) dot = fma(y[e], *lds_at(q, e), dot);
+    const double s = block_sum_alt<T>(dot, reda, par);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) y[e] = fma(-*lds_at(q, e), s, y[e]);
+  };
+  auto load_old = [&]() {  // the launch's reflectors: registers, then LDS (staged through ax[])
+#pragma unroll
+    for (int p = 0; p < KR; ++p)
+      if (p < kold) load(vold + (int64_t)p * vlen, v[p], true);
+#pragma unroll
+    for (int q = 0; q < KL; ++q)
+      if (KR + q < kold) {
+        load(vold + (int64_t)(KR + q) * vlen, ax, true);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) *lds_at(q, e) = ax[e];  // read back by the same thread only
+      }
+  };
+  auto apply_old = [&](double *y) {
+#pragma unroll
+    for (int p = 0; p < KR; ++p)
+      if (p < kold) apply(y, v[p]);
+#pragma unroll
+    for (int q = 0; q < KL; ++q)
+      if (KR + q < kold) apply_lds(y, q);
+  };
+
+  // flags != nullptr: the lead is K workgroups, one column each, handing their reflectors on (rankk_lead_pipe: built for
+  // k_rankk_tall, where it took 16384 x 4096 from 312 to 257 ms); flags == nullptr: one lead workgroup (rankk_lead_body)
+  const int nlead = flags ? K : 1;
+  if (flags && (int)blockIdx.x < K) {
+    rankk_lead_pipe<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, flags, epoch,
+                                    (int)blockIdx.x);
+    return;
+  }
+  if ((int)blockIdx.x >= nlead) {  // ---- bulk: persistent, the next column's loads in flight behind the current column's work
+    const int64_t stride = (int64_t)gridDim.x - nlead;
+    int64_t c = c0 + K + ((int64_t)blockIdx.x - nlead);
+    if (c >= ncols) return;
+    load(A + c * lda, a, false);
+    load_old();
+    // THREE column buffers in rotation: a store holds its data registers until it completes, so the early load goes to
+    // the buffer stored one step earlier, not to the one stored a moment ago.  (The early load is unconditional -- past
+    // the last column it re-reads the current one -- so that the wait counters the compiler derives are those of
+    // straight-line code: a branch around the loads would make it wait for them at once.)
+#define DHQR_RK_STEP(CUR, NXT)                       \
+    {                                                  \
+      const int64_t cn = c + stride;                   \
+      const bool more = cn < ncols;                    \
+      load(A + (more ? cn : c) * lda, NXT, false);     \
+      apply_old(CUR);                                  \
+      store_nt(A + c * lda, CUR);                      \
+      if (!more) break;                                \
+      c = cn;                                          \
+    }
+    for (;;) {
+      DHQR_RK_STEP(a, an)
+      DHQR_RK_STEP(an, ax)
+      DHQR_RK_STEP(ax, a)
+    }
+#undef DHQR_RK_STEP
+    return;
+  }
+
+  // ---- lead: the next K columns and their reflectors -- a function of its own (own register allocation)
+  if constexpr (T > 512) rankk_lead<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
+  else rankk_lead_body<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, vl);
 }
 
 // k_rankk_fused for columns of 8192 < rows <= 16384: the same pass -- every trailing column loaded once, K reflectors
