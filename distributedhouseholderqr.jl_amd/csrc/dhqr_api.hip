@@ -59,6 +59,7 @@ struct dhqr_ctx {
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
   int rankk_wgs = 256;           // ... bulk workgroups of 1024 threads resident at once (CU count; DHQR_RANKK_WGS)
   int rankk = 5;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..5; beyond 3 the further ones are held in LDS)
+  int nn_split = 4;              // wide subtraction launches in up to this many chunks of columns (or rows) (nn_chunks; DHQR_NN_SPLIT=1: one launch)
   int rankk_pipe = 1;            // k_rankk_fused: the lead as K pipelined workgroups where the lead bounds the launch (launch_rankk; DHQR_RANKK_PIPE=0 never, 2 always)
   int rankk_tall = 5;            // nb = 0, columns of 8192 < rows <= 16384: reflectors per pass (k_rankk_tall; DHQR_RANKK_TALL=1: one per launch)
   int ncu = 256;                 // compute units of the device
@@ -873,6 +874,19 @@ static int32_t factor_panel_sync(dhqr_ctx *c, double *P, int64_t rows, int64_t w
 // the pair's diagonal blocks (statistics only).
 static int32_t comm_allreduce_sum(dhqr_comm *cm, double *dbuf, int64_t count, hipStream_t stream);
 
+// Column chunks of a WIDE subtraction launch.  The look-ahead lane's single-workgroup kernels (k_panel_top, k_build_t: 1024
+// threads, 135-141 KB of LDS) need an EMPTY CU; while a subtraction launch runs every CU holds two of its workgroups and a
+// retiring one is replaced at once, so the lane stands still at its first such kernel until the launch has drained and
+// finishes its chain afterwards, with the wide stream waiting (profiles/r03_panel_server.txt: ~1 ms per quad step at
+// 32768^2, ~2 ms per pair step of the 262144 x 4096 row split).  Between two CHUNKS the CUs drain and the waiting kernel
+// gets one: each boundary lets the lane past one more of its whole-CU kernels, for the price of one launch tail.
+// Measured (profiles/r03_nn_chunks.txt): 32768^2 847.3 -> 841.5 ms, 16384^2 140.1 -> 138.5 ms, 262144 x 4096 row split
+// 178.9 -> 174.0 ms (row chunks: 30 column tiles, 2048 row tiles).  At most nn_split chunks of at least 48 tiles each.
+static inline int64_t nn_chunks(const dhqr_ctx *c, int64_t tiles) {
+  if (c->nn_split <= 1 || c->cur_ws != 0) return 1;
+  return std::max<int64_t>(1, std::min<int64_t>(c->nn_split, tiles / 48));
+}
+
 // Y (256 x ncols, ld 256) = [V_a V_b]' C: k_gemm_tn2 (ONE pass over C for both panels, split-K over row slabs into
 // ws.w1) + the deterministic split-K reduction.
 static int32_t pair_vtc(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows, const double *C, int64_t ldc,
@@ -970,10 +984,28 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
 
   CHECK(prof_begin(c, CAT_AVW));
   const int64_t gx = (rows + 127) / 128;
-  const int swz = (gx >= 16 && ntiles >= 16) ? 1 : 0;
-  dim3 grid((unsigned)gx, (unsigned)ntiles);
-  if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
-  launch_nn_sub<256>(c, vec, grid, Vp, ldv, (const double *)ws.w2.p, ld2, C, ldc, rows, ncols, swz, true);
+  // wide launches in nn_chunks(...) column chunks: see nn_chunks
+  const int64_t nch = nn_chunks(c, ntiles);
+  if (nch == 1 && nn_chunks(c, gx) > 1) {
+    // few column tiles but many row tiles (the row split's tall slabs): chunks of ROWS (same W, V and C from the chunk's row)
+    const int64_t nrc = nn_chunks(c, gx), rpc = (gx + nrc - 1) / nrc * 128;
+    for (int64_t r0 = 0; r0 < rows; r0 += rpc) {
+      const int64_t nr = std::min(rpc, rows - r0), gxr = (nr + 127) / 128;
+      const int swz = (gxr >= 16 && ntiles >= 16) ? 1 : 0;
+      dim3 grid((unsigned)gxr, (unsigned)ntiles);
+      if (swz) grid = dim3((unsigned)((((gxr + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
+      launch_nn_sub<256>(c, vec, grid, Vp + r0, ldv, (const double *)ws.w2.p, ld2, C + r0, ldc, nr, ncols, swz, true);
+    }
+  } else {
+    const int64_t tpc = (ntiles + nch - 1) / nch;
+    for (int64_t t0 = 0; t0 < ntiles; t0 += tpc) {
+      const int64_t nt = std::min(tpc, ntiles - t0), cc0 = t0 * 128, nc = std::min<int64_t>(nt * 128, ncols - cc0);
+      const int swz = (gx >= 16 && nt >= 16) ? 1 : 0;
+      dim3 grid((unsigned)gx, (unsigned)nt);
+      if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((nt + 7) / 8) + 7) / 8 * 512), 1);
+      launch_nn_sub<256>(c, vec, grid, Vp, ldv, (const double *)ws.w2.p + cc0 * ld2, ld2, C + cc0 * ldc, ldc, rows, nc, swz, true);
+    }
+  }
   CHECK(prof_end(c));
   if (c->profiling) {
     c->st.flops_gemm_vta += 2.0 * DHQR_NBV * ((double)rows + (double)rows_b) * (double)ncols;
@@ -1018,11 +1050,15 @@ static int32_t quad_apply(dhqr_ctx *c, const double *V1, const double *V2, int64
     hipLaunchKernelGGL((k_gemm_nn_quad<2, 64>), dim3((unsigned)((rows + 63) / 64), (unsigned)ntiles), dim3(256), 0, c->stream, V1,
                        V2 - 2 * NB, ldv, 2 * NB, (const double *)W, ld4, C, ldc, rows, ncols, 0, st, c->epoch);
   } else {
-    const int swz = (gx >= 16 && ntiles >= 16) ? 1 : 0;
-    dim3 grid((unsigned)gx, (unsigned)ntiles);
-    if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((ntiles + 7) / 8) + 7) / 8 * 512), 1);
-    hipLaunchKernelGGL((k_gemm_nn_quad<2, 128>), grid, dim3(256), 0, c->stream, V1, V2 - 2 * NB, ldv, 2 * NB,
-                       (const double *)W, ld4, C, ldc, rows, ncols, swz, st, c->epoch);
+    const int64_t nch = nn_chunks(c, ntiles), tpc = (ntiles + nch - 1) / nch;
+    for (int64_t t0 = 0; t0 < ntiles; t0 += tpc) {
+      const int64_t nt = std::min(tpc, ntiles - t0), cc0 = t0 * 128, nc = std::min<int64_t>(nt * 128, ncols - cc0);
+      const int swz = (gx >= 16 && nt >= 16) ? 1 : 0;
+      dim3 grid((unsigned)gx, (unsigned)nt);
+      if (swz) grid = dim3((unsigned)((((gx + 7) / 8) * ((nt + 7) / 8) + 7) / 8 * 512), 1);
+      hipLaunchKernelGGL((k_gemm_nn_quad<2, 128>), grid, dim3(256), 0, c->stream, V1, V2 - 2 * NB, ldv, 2 * NB,
+                         (const double *)W + cc0 * ld4, ld4, C + cc0 * ldc, ldc, rows, nc, swz, st, c->epoch);
+    }
   }
   CHECK(prof_end(c));
   if (c->profiling) {
@@ -1223,6 +1259,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_RANKK_TALL")) c->rankk_tall = std::min(5, std::max(1, atoi(e)));
+    if (const char *e = getenv("DHQR_NN_SPLIT")) c->nn_split = std::min(16, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_RANKK_PIPE")) c->rankk_pipe = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("DHQR_TN_MODEL_MIN_TILES")) c->tn_model_min_tiles = atoi(e);
     if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;
