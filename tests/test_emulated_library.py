@@ -125,7 +125,10 @@ def test_quad_steps_two_pairs_in_one_k512_update(emu, orc):
     against the oracle, and the same factorisation as pairs only (DHQR_QUAD=0) to rounding"""
     A0 = orc.rand_matrix(1290, 1280, 8)
     res = []
-    for env in ({"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD_MIN_COLS": 0}, {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD": 0}):
+    for env in ({"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD_MIN_COLS": 0}, {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD": 0},
+                # wide subtraction launches in up to 4 column chunks (nn_chunks; one tile per chunk is enough here)
+                {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD_MIN_COLS": 0, "DHQR_NN_CHUNK_TILES": 1},
+                {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD": 0, "DHQR_NN_CHUNK_TILES": 1, "DHQR_NN_SPLIT": 3}):
         h = _ctx(emu, **env)
         A, al = _factor(emu, h, A0, 128)
         _check(orc, A0, A, al)
@@ -134,6 +137,8 @@ def test_quad_steps_two_pairs_in_one_k512_update(emu, orc):
         res.append((A, al))
     scale = np.abs(res[1][0]).max()
     assert np.abs(res[0][0] - res[1][0]).max() <= 1e-12 * scale
+    # chunks only regroup the same tiles into several launches: the same bits
+    assert np.array_equal(res[2][0], res[0][0]) and np.array_equal(res[3][0], res[1][0])
 
 
 @pytest.mark.parametrize("bad", [200, 300, 400])

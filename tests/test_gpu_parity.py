@@ -92,6 +92,27 @@ def test_unblocked_reflectors_per_pass(pkg, orc, m, n, K, monkeypatch):
             api._contexts[0] = old
 
 
+@pytest.mark.parametrize("pipe", [0, 2])
+@pytest.mark.parametrize("m,n", [(2100, 300), (8192, 40), (5000, 64), (300, 40), (4097, 33)])
+def test_unblocked_lead_one_workgroup_or_pipelined(pkg, orc, m, n, pipe, monkeypatch):
+    """DHQR_RANKK_PIPE = 0 (the lead of a pass is ONE workgroup) / 2 (always K workgroups handing their reflectors on through
+    flags; the default, 1, picks per launch): the same factorisation as the oracle's either way"""
+    monkeypatch.setenv("DHQR_RANKK_PIPE", str(pipe))  # read by dhqr_create
+    api = pkg.api
+    old = api._contexts.pop(0, None)
+    try:
+        H, A0 = _factor_dev(pkg, m, n, 7, 0)
+        Ho, ao = orc.householder(orc.rand_matrix(m, n, 7))
+        scale = np.abs(Ho).max()
+        assert np.abs(H.A.cpu().numpy() - Ho).max() <= TOL(Ho) * scale
+        assert np.abs(H.α.cpu().numpy() - ao).max() <= TOL(Ho) * scale
+        assert pkg.residual(H, A0) < 1e-12
+    finally:
+        api._contexts.pop(0, None)
+        if old is not None:
+            api._contexts[0] = old
+
+
 @pytest.mark.parametrize("m,n", [(2000, 512), (8190, 384), (9000, 256)])
 def test_blocked_with_panels_through_the_column_kernels(pkg, orc, m, n, monkeypatch):
     """DHQR_PANEL=1: every 128-column panel is factored by the unblocked column kernels (k_rankk_fused passes for panels of
