@@ -59,6 +59,7 @@ struct dhqr_ctx {
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
   int rankk_wgs = 256;           // ... bulk workgroups of 1024 threads resident at once (CU count; DHQR_RANKK_WGS)
   int rankk = 5;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..5; beyond 3 the further ones are held in LDS)
+  int nn_split_cols = 0;         // column chunks too (DHQR_NN_SPLIT_COLS=1): +0.4 % at 32768^2, see nn_chunks
   int nn_chunk_tiles = 48;       // ... of at least this many 128-wide tiles each (DHQR_NN_CHUNK_TILES: the CPU emulator's tests set 1)
   int nn_split = 4;              // wide subtraction launches in up to this many chunks of columns (or rows) (nn_chunks; DHQR_NN_SPLIT=1: one launch)
   int rankk_pipe = 1;            // k_rankk_fused: the lead as K pipelined workgroups where the lead bounds the launch (launch_rankk; DHQR_RANKK_PIPE=0 never, 2 always)
@@ -202,12 +203,12 @@ static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
   const int epoch = ++c->zepoch;  // the launch's number in the flags (a value, not an expression in the launch's argument list)
 #define DHQR_RK(T_, E_)                                                                                  \
   hipLaunchKernelGGL((k_rankk_fused<T_, E_, VEC, K>),                                                    \
-                     dim3((unsigned)(nlead + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs * (rankk_lead_slots(T_, E_, K) > 0 ? 1 : 1024 / T_) - nlead))), \
+                     dim3((unsigned)(nlead + std::min<int64_t>(nbulk, std::max<int64_t>(1, (int64_t)c->rankk_wgs * (rankk_lead_slots(T_, E_, K) > 0 ? 1 : 1024 / T_) - nlead)))), \
                      dim3(T_), 0, c->stream, P, ldp, rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha,  \
                      pipe ? c->zflags : (int *)nullptr, epoch)
 #define DHQR_RKT(E_)                                                                                     \
   hipLaunchKernelGGL((k_rankk_tall<512, E_, VEC, K>),                                                     \
-                     dim3((unsigned)(K + std::min<int64_t>(nbulk, (int64_t)c->rankk_wgs - K))), dim3(512), 0, c->stream, P, ldp, \
+                     dim3((unsigned)(K + std::min<int64_t>(nbulk, std::max<int64_t>(1, (int64_t)c->rankk_wgs - K)))), dim3(512), 0, c->stream, P, ldp, \
                      rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, c->zflags, epoch)
   // columns of 8192 < rows <= 16384 (factor_unblocked_cols sends them here when DHQR_RANKK_TALL >= 2)
   if (cov > 512 * 24) { DHQR_RKT(32); return; }
@@ -884,8 +885,11 @@ static int32_t comm_allreduce_sum(dhqr_comm *cm, double *dbuf, int64_t count, hi
 // gets one: each boundary lets the lane past one more of its whole-CU kernels, for the price of one launch tail.
 // Measured (profiles/r03_nn_chunks.txt): 32768^2 847.3 -> 841.5 ms, 16384^2 140.1 -> 138.5 ms, 262144 x 4096 row split
 // 178.9 -> 174.0 ms (row chunks: 30 column tiles, 2048 row tiles).  At most nn_split chunks of at least nn_chunk_tiles (48) tiles each.
-static inline int64_t nn_chunks(const dhqr_ctx *c, int64_t tiles) {
-  if (c->nn_split <= 1 || c->cur_ws != 0) return 1;
+// Column chunks of the square single-GPU case gain 0.4 % (within the box-to-box spread) and move the lane's work into the
+// subtraction's timed window (its hipEvent group 380 -> 398 ms for the same total): off unless DHQR_NN_SPLIT_COLS=1.  Row
+// chunks (launches of few column tiles and many row tiles: the row split, a rank's local block at P > 1) stay on.
+static inline int64_t nn_chunks(const dhqr_ctx *c, int64_t tiles, bool columns = true) {
+  if (c->nn_split <= 1 || c->cur_ws != 0 || (columns && !c->nn_split_cols)) return 1;
   return std::max<int64_t>(1, std::min<int64_t>(c->nn_split, tiles / c->nn_chunk_tiles));
 }
 
@@ -988,9 +992,9 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   const int64_t gx = (rows + 127) / 128;
   // wide launches in nn_chunks(...) column chunks: see nn_chunks
   const int64_t nch = nn_chunks(c, ntiles);
-  if (nch == 1 && nn_chunks(c, gx) > 1) {
+  if (nch == 1 && ntiles < c->nn_chunk_tiles && nn_chunks(c, gx, false) > 1) {
     // few column tiles but many row tiles (the row split's tall slabs): chunks of ROWS (same W, V and C from the chunk's row)
-    const int64_t nrc = nn_chunks(c, gx), rpc = (gx + nrc - 1) / nrc * 128;
+    const int64_t nrc = nn_chunks(c, gx, false), rpc = (gx + nrc - 1) / nrc * 128;
     for (int64_t r0 = 0; r0 < rows; r0 += rpc) {
       const int64_t nr = std::min(rpc, rows - r0), gxr = (nr + 127) / 128;
       const int swz = (gxr >= 16 && ntiles >= 16) ? 1 : 0;
@@ -1261,6 +1265,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_RANKK_TALL")) c->rankk_tall = std::min(5, std::max(1, atoi(e)));
+    if (const char *e = getenv("DHQR_NN_SPLIT_COLS")) c->nn_split_cols = atoi(e) != 0;
     if (const char *e = getenv("DHQR_NN_CHUNK_TILES")) c->nn_chunk_tiles = std::max(1, atoi(e));
     if (const char *e = getenv("DHQR_NN_SPLIT")) c->nn_split = std::min(16, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_RANKK_PIPE")) c->rankk_pipe = std::min(2, std::max(0, atoi(e)));

@@ -252,7 +252,12 @@ def test_row_split_rank_threads_vs_oracle(emu, orc, ndev, m, n, tsqr):
     G = np.zeros((m, n), order="F")
     assert emu.dhqr_mg_rs_transfer_f64(h, _ptr(G), m, None, 0) == 0
     assert np.array_equal(G, A0)  # the device generator with the row offset of every slab
+    cnt0, cnt1 = (ctypes.c_int64 * 4)(), (ctypes.c_int64 * 4)()
+    assert emu.dhqr_mg_comm_counters(h, 0, cnt0) == 0
     assert emu.dhqr_mg_rs_factor_f64(h) == 0, emu.dhqr_last_error()
+    assert emu.dhqr_mg_comm_counters(h, 0, cnt1) == 0
+    # the row split's data path: all-reduces of partial dots (at least a Gram matrix per panel) + the small top-block broadcasts
+    assert cnt1[2] - cnt0[2] >= (n + 127) // 128 and cnt1[3] - cnt0[3] >= 8 * 128 * 128 * ((n + 127) // 128)
     H, al = np.zeros((m, n), order="F"), np.zeros(n)
     assert emu.dhqr_mg_rs_transfer_f64(h, _ptr(H), m, _ptr(al), 0) == 0
     Ho, ao = orc.householder(A0)

@@ -127,8 +127,8 @@ def test_quad_steps_two_pairs_in_one_k512_update(emu, orc):
     res = []
     for env in ({"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD_MIN_COLS": 0}, {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD": 0},
                 # wide subtraction launches in up to 4 column chunks (nn_chunks; one tile per chunk is enough here)
-                {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD_MIN_COLS": 0, "DHQR_NN_CHUNK_TILES": 1},
-                {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD": 0, "DHQR_NN_CHUNK_TILES": 1, "DHQR_NN_SPLIT": 3}):
+                {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD_MIN_COLS": 0, "DHQR_NN_CHUNK_TILES": 1, "DHQR_NN_SPLIT_COLS": 1},
+                {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD": 0, "DHQR_NN_CHUNK_TILES": 1, "DHQR_NN_SPLIT": 3, "DHQR_NN_SPLIT_COLS": 1}):
         h = _ctx(emu, **env)
         A, al = _factor(emu, h, A0, 128)
         _check(orc, A0, A, al)

@@ -107,7 +107,7 @@ def main():
                         "ratio_to_algorithmic": (rsum + wsum) / alg, "read_GB": rsum / 1e9, "write_GB": wsum / 1e9,
                         "algorithmic_GB": alg / 1e9})
 
-    entry(["k_gemm_nn_quad", "k_gemm_nn_sub"], nn, lambda a: 16.0 * a[0] * a[1], lambda a: max(1, min(4, ((a[1] + 127) // 128) // 48)))
+    entry(["k_gemm_nn_quad", "k_gemm_nn_sub"], nn, lambda a: 16.0 * a[0] * a[1], lambda a: 1)  # column chunks are off by default (DHQR_NN_SPLIT_COLS)
     entry(["k_gemm_tn2"], tn, lambda a: 8.0 * a[0] * a[1], lambda a: 1)
     old = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")))
     # unblocked 8192^2 (tools/pmc_driver unblocked 8192): every k_rankk_fused launch; algorithmic bytes as implemented =
