@@ -137,8 +137,9 @@ def test_quad_steps_two_pairs_in_one_k512_update(emu, orc):
         res.append((A, al))
     scale = np.abs(res[1][0]).max()
     assert np.abs(res[0][0] - res[1][0]).max() <= 1e-12 * scale
-    # chunks only regroup the same tiles into several launches: the same bits
-    assert np.array_equal(res[2][0], res[0][0]) and np.array_equal(res[3][0], res[1][0])
+    # chunks regroup the same tiles into several launches; a chunk's last tile takes the edge path (C tile loaded up front
+    # instead of streamed in during the K loop: the same sum in another order), so equal to rounding, not to the bit
+    assert np.abs(res[2][0] - res[0][0]).max() <= 1e-13 * scale and np.abs(res[3][0] - res[1][0]).max() <= 1e-13 * scale
 
 
 @pytest.mark.parametrize("bad", [200, 300, 400])
