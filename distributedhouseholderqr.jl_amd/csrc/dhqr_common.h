@@ -85,6 +85,29 @@ __device__ __forceinline__ double block_sum_alt(double v, double *red, int &par)
   return s;
 }
 
+// block_sum_alt with a RAW barrier: `__syncthreads()` makes the compiler drain every outstanding vector-memory operation
+// first when a direct global -> LDS load is in flight (it writes LDS), i.e. also the next column's prefetch from HBM.  The
+// only data this barrier hands from wave to wave are the partial sums written just above (LDS: lgkmcnt); the direct loads
+// in flight go to thread-private slots (k_rankk_tall).
+template <int THREADS>
+__device__ __forceinline__ double block_sum_alt_raw(double v, double *red, int &par) {
+  v = wave_sum_dpp(v);
+  constexpr int NW = THREADS / 64;
+  if constexpr (NW == 1) return v;
+  double *r = red + (par & 1) * NW;
+  ++par;
+  if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+  __syncthreads();
+#endif
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) s += r[i];
+  return s;
+}
+
 // ---- extended-precision sum of squares for the column norm.  The reference's norm (src:129) is BLAS
 // dnrm2 / dznrm2, which OpenBLAS accumulates in x87 extended precision on x86-64 (the CPU test oracle
 // restates that with long double).  The reflector of the dominant direction is what the reference's

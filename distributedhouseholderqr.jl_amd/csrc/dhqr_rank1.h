@@ -640,6 +640,7 @@ __global__ __launch_bounds__(T) void k_rankk_tall(double *__restrict__ A, int64_
   static_assert(T <= 512, "three buffers of a tall column need the 256 registers of a <= 512-thread workgroup");
   __shared__ double red[2 * (T / 64) + 2];
   __shared__ double reda[2 * (T / 64)];
+  __shared__ __attribute__((aligned(16))) double wl[VEC == 2 ? T * EPT : 2];  // the next reflector (bulk, 16-byte path)
   if (blockIdx.x < K) {  // the K lead workgroups: one column each (rankk_lead_pipe)
     rankk_lead_pipe<T, EPT, VEC, K>(A, lda, m, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, red, reda, flags, epoch,
                                     (int)blockIdx.x);
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(T) void k_rankk_tall(double *__restrict__ A, int64_
   {                                                                                      \
     double dot = 0.0; /* src:208 partialdot */                                           \
     _Pragma("unroll") for (int e = 0; e < EPT; ++e) dot = fma(CUR[e], w[e], dot);        \
-    const double sdot = block_sum_alt<T>(dot, reda, par);                                \
+    const double sdot = (VEC == 2) ? block_sum_alt_raw<T>(dot, reda, par) : block_sum_alt<T>(dot, reda, par); \
     _Pragma("unroll") for (int e = 0; e < EPT; ++e) CUR[e] = fma(-w[e], sdot, CUR[e]); /* src:209 hotloop! */ \
   }
 #define DHQR_RKT_STEP(CUR, NXT)                                                          \
@@ -733,9 +734,71 @@ __global__ __launch_bounds__(T) void k_rankk_tall(double *__restrict__ A, int64_
     if (!more) break;                                                                    \
     c = cn;                                                                              \
   }
-  for (;;) {
-    DHQR_RKT_STEP(a, an)
-    DHQR_RKT_STEP(an, a)
+  if constexpr (VEC == 2) {
+    // 16-byte path: the NEXT reflector streams from L2 into LDS (direct global -> LDS loads: no registers, 16 x 16 B per
+    // thread into thread-private slots wl[i][t]) while the current one, in registers, is applied; a reflector is then 16
+    // ds_read_b128 away instead of an exposed L2 round trip of 128 KiB per CU (with one register buffer each of a column's
+    // K reflector loads was exposed: 3.1 TB/s of the bytes as implemented at 16384 rows against 3.9-4.5 below).  Every thread
+    // reads back only the slots its own lanes wrote: no barrier.
+    auto issue_lds = [&](const double *src, uint32_t tt) {
+      const double *base = src + rtop;
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + 2u * (tt + (uint32_t)i * T)),
+                                         (__attribute__((address_space(3))) void *)(wl + 2 * (i * T + (int)(t & ~63u))), 16, 0, 0);
+#else
+        wl[2 * (i * T + (int)t)] = base[2u * (tt + (uint32_t)i * T)];
+        wl[2 * (i * T + (int)t) + 1] = base[2u * (tt + (uint32_t)i * T) + 1];
+#endif
+      }
+    };
+    auto lds_to_regs = [&](double *dst) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const double2 x = *reinterpret_cast<const double2 *>(wl + 2 * (i * T + (int)t));
+        dst[2 * i] = x.x;
+        dst[2 * i + 1] = x.y;
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+      // the reads have RETURNED before the next direct load is issued into the same slots: it is not ordered with the LDS
+      // queue, and 128 KiB of ds_read_b128 take ~0.45 us to drain -- an L2 hit came back sooner and overwrote slots not yet
+      // read (wrong factorisations once a workgroup owned more than one column; the dot product needs the data here anyway)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    };
+#define DHQR_RKT_STEP_LDS(CUR, NXT)                                                      \
+  {                                                                                      \
+    const int64_t cn = c + stride;                                                       \
+    const bool more = cn < ncols;                                                        \
+    const uint32_t tt = rk_opaque(t);                                                    \
+    lds_to_regs(w); /* reflector 0, requested during the previous column's last apply */ \
+    issue_lds(vold + (kold > 1 ? vlen : 0), tt);                                         \
+    DHQR_RKT_APPLY(CUR)                                                                  \
+    load_col(A + (more ? cn : c) * lda, NXT, tt);                                        \
+    for (int p = 1; p < kold; ++p) {                                                     \
+      lds_to_regs(w);                                                                    \
+      issue_lds(vold + (int64_t)(p + 1 < kold ? p + 1 : 0) * vlen, rk_opaque(t)); /* the next one, or reflector 0 for the next column */ \
+      DHQR_RKT_APPLY(CUR)                                                                \
+    }                                                                                    \
+    store_nt(A + c * lda, CUR, rk_opaque(t));                                            \
+    if (!more) break;                                                                    \
+    c = cn;                                                                              \
+  }
+    issue_lds(vold, t);
+    for (;;) {
+      DHQR_RKT_STEP_LDS(a, an)
+      DHQR_RKT_STEP_LDS(an, a)
+    }
+#undef DHQR_RKT_STEP_LDS
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_waitcnt(0);  // the last request (never read) has landed before the workgroup's LDS is released
+#endif
+  } else {
+    for (;;) {
+      DHQR_RKT_STEP(a, an)
+      DHQR_RKT_STEP(an, a)
+    }
   }
 #undef DHQR_RKT_APPLY
 #undef DHQR_RKT_STEP

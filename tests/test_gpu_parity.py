@@ -92,6 +92,27 @@ def test_unblocked_reflectors_per_pass(pkg, orc, m, n, K, monkeypatch):
             api._contexts[0] = old
 
 
+@pytest.mark.parametrize("m,n", [(12288, 64), (16390, 48), (9000, 40), (8192, 40)])
+def test_unblocked_few_workgroups_own_many_columns(pkg, orc, m, n, monkeypatch):
+    """DHQR_RANKK_WGS=8: three bulk workgroups walk through all trailing columns of a pass (on 256 CUs the shapes above give
+    every workgroup ONE column) -- the column-to-column pipeline of k_rankk_tall (next reflector streaming into LDS while the
+    current one is applied, next column prefetched) and of k_rankk_fused against the oracle"""
+    monkeypatch.setenv("DHQR_RANKK_WGS", "8")  # read by dhqr_create
+    api = pkg.api
+    old = api._contexts.pop(0, None)
+    try:
+        H, A0 = _factor_dev(pkg, m, n, 9, 0)
+        Ho, ao = orc.householder(orc.rand_matrix(m, n, 9))
+        scale = np.abs(Ho).max()
+        assert np.abs(H.A.cpu().numpy() - Ho).max() <= TOL(Ho) * scale
+        assert np.abs(H.α.cpu().numpy() - ao).max() <= TOL(Ho) * scale
+        assert pkg.residual(H, A0) < 1e-12
+    finally:
+        api._contexts.pop(0, None)
+        if old is not None:
+            api._contexts[0] = old
+
+
 @pytest.mark.parametrize("pipe", [0, 2])
 @pytest.mark.parametrize("m,n", [(2100, 300), (8192, 40), (5000, 64), (300, 40), (4097, 33)])
 def test_unblocked_lead_one_workgroup_or_pipelined(pkg, orc, m, n, pipe, monkeypatch):
