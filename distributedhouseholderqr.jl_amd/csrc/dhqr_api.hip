@@ -992,7 +992,7 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   const int64_t gx = (rows + 127) / 128;
   // wide launches in nn_chunks(...) column chunks: see nn_chunks
   const int64_t nch = nn_chunks(c, ntiles);
-  if (nch == 1 && ntiles < c->nn_chunk_tiles && nn_chunks(c, gx, false) > 1) {
+  if (nch == 1 && ntiles < 48 && nn_chunks(c, gx, false) > 1) {
     // few column tiles but many row tiles (the row split's tall slabs): chunks of ROWS (same W, V and C from the chunk's row)
     const int64_t nrc = nn_chunks(c, gx, false), rpc = (gx + nrc - 1) / nrc * 128;
     for (int64_t r0 = 0; r0 < rows; r0 += rpc) {

@@ -125,10 +125,7 @@ def test_quad_steps_two_pairs_in_one_k512_update(emu, orc):
     against the oracle, and the same factorisation as pairs only (DHQR_QUAD=0) to rounding"""
     A0 = orc.rand_matrix(1290, 1280, 8)
     res = []
-    for env in ({"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD_MIN_COLS": 0}, {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD": 0},
-                # wide subtraction launches in up to 4 column chunks (nn_chunks; one tile per chunk is enough here)
-                {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD_MIN_COLS": 0, "DHQR_NN_CHUNK_TILES": 1, "DHQR_NN_SPLIT_COLS": 1},
-                {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD": 0, "DHQR_NN_CHUNK_TILES": 1, "DHQR_NN_SPLIT": 3, "DHQR_NN_SPLIT_COLS": 1}):
+    for env in ({"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD_MIN_COLS": 0}, {"DHQR_PAIR_MIN_N": 512, "DHQR_QUAD": 0}):
         h = _ctx(emu, **env)
         A, al = _factor(emu, h, A0, 128)
         _check(orc, A0, A, al)
@@ -137,9 +134,25 @@ def test_quad_steps_two_pairs_in_one_k512_update(emu, orc):
         res.append((A, al))
     scale = np.abs(res[1][0]).max()
     assert np.abs(res[0][0] - res[1][0]).max() <= 1e-12 * scale
-    # chunks regroup the same tiles into several launches; a chunk's last tile takes the edge path (C tile loaded up front
-    # instead of streamed in during the K loop: the same sum in another order), so equal to rounding, not to the bit
-    assert np.abs(res[2][0] - res[0][0]).max() <= 1e-13 * scale and np.abs(res[3][0] - res[1][0]).max() <= 1e-13 * scale
+
+
+def test_wide_subtraction_launches_in_chunks(emu, orc):
+    """nn_chunks: a wide subtraction launch issued as several launches (one tile per chunk is enough here) -- the quad's in up
+    to 4 COLUMN chunks (DHQR_NN_SPLIT_COLS), the pairs' in up to 3 ROW chunks (the default path of launches with few column
+    tiles: the row split, a rank's local block).  Chunks regroup the same tiles; a chunk's last tile takes the edge path (C tile
+    loaded up front instead of streamed in during the K loop: the same sum in another order), so equal to rounding"""
+    A0 = orc.rand_matrix(780, 768, 12)
+    res = []
+    for env in ({"DHQR_PAIR_MIN_N": 0, "DHQR_QUAD_MIN_COLS": 0},
+                {"DHQR_PAIR_MIN_N": 0, "DHQR_QUAD_MIN_COLS": 0, "DHQR_NN_CHUNK_TILES": 1, "DHQR_NN_SPLIT_COLS": 1},
+                {"DHQR_PAIR_MIN_N": 0, "DHQR_QUAD": 0, "DHQR_NN_CHUNK_TILES": 1, "DHQR_NN_SPLIT": 3}):
+        h = _ctx(emu, **env)
+        A, al = _factor(emu, h, A0, 128)
+        _check(orc, A0, A, al)
+        emu.dhqr_destroy(h)
+        res.append(A)
+    scale = np.abs(res[0]).max()
+    assert np.abs(res[1] - res[0]).max() <= 1e-13 * scale and np.abs(res[2] - res[0]).max() <= 1e-12 * scale
 
 
 @pytest.mark.parametrize("bad", [200, 300, 400])

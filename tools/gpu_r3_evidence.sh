@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3 evidence on the GPU box: gpu tests, smoke, the contract bench line + the other configurations, rocprofv3
 # kernel-trace summaries of the same commands, HBM counter passes (one counter per pass) -> gpurun_out/r3e/
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3e3; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3e4; mkdir -p $O; cd $R
 ( timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -rfEs -p no:cacheprovider 2>&1 | tail -15 ) > $O/pytest_gpu.txt; tail -3 $O/pytest_gpu.txt
 ( timeout 300 python __graft_entry__.py smoke 2>&1 | grep -v amdgpu | tail -4 ) > $O/smoke.txt; cat $O/smoke.txt
 timeout 900 python bench.py > $O/bench_blocked32768.json 2> $O/bench_blocked32768.err; tail -c 600 $O/bench_blocked32768.json
