@@ -499,7 +499,7 @@ static int32_t rs_group_apply(const RsProblem &pr, const RsWork &w, const RsSlot
   dhqr_ctx *c = pr.c;
   if (ncols <= 0) return DHQR_OK;
   const int64_t NB = DHQR_NBV;
-  dhqr_comm *cm = (cmx && cmx->nranks > 1) ? cmx : nullptr;
+  dhqr_comm *cm = cmx;  // also at one rank: the all-reduces of V'C are then counted as issued (dhqr_comm_counters) and move nothing
   int64_t off, rows;
   pr.active(gr.a * NB, &off, &rows);
   double *C = pr.A + off + col0 * pr.lda;
