@@ -141,7 +141,7 @@ def test_wide_subtraction_launches_in_chunks(emu, orc):
     to 4 COLUMN chunks (DHQR_NN_SPLIT_COLS), the pairs' in up to 3 ROW chunks (the default path of launches with few column
     tiles: the row split, a rank's local block).  Chunks regroup the same tiles; a chunk's last tile takes the edge path (C tile
     loaded up front instead of streamed in during the K loop: the same sum in another order), so equal to rounding"""
-    A0 = orc.rand_matrix(780, 768, 12)
+    A0 = orc.rand_matrix(650, 640, 12)
     res = []
     for env in ({"DHQR_PAIR_MIN_N": 0, "DHQR_QUAD_MIN_COLS": 0},
                 {"DHQR_PAIR_MIN_N": 0, "DHQR_QUAD_MIN_COLS": 0, "DHQR_NN_CHUNK_TILES": 1, "DHQR_NN_SPLIT_COLS": 1},

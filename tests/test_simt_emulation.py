@@ -295,8 +295,11 @@ def test_gemm_nn_sub(emu_gemm, tmp_path, vec, kw, rows, ncols, swz):
 
 
 # (rows, ncols, swz): interior tiles below the second pair (streamed C, K = 512), the two row tiles above it (half the K
-# loop, V2 never touched), edge tiles both ways, the XCD-aware 1-D launch, 64-row tiles (the lane's narrow quad update)
-@pytest.mark.parametrize("rows,ncols,swz", [(512, 256, 0), (700, 300, 0), (2100, 2100, 1), (450, 256, 2)])
+# loop, V2 never touched), edge tiles both ways, the XCD-aware 1-D launch (9 x 4 tiles: two 8 x 8 blocks; the size at which
+# the driver switches it on, 2100 x 2100, behind DHQR_SLOW=1), 64-row tiles (the lane's narrow quad update)
+@pytest.mark.parametrize("rows,ncols,swz", [(512, 256, 0), (700, 300, 0), (1100, 400, 1), (450, 256, 2),
+                                            pytest.param(2100, 2100, 1, marks=pytest.mark.skipif(
+                                                os.environ.get("DHQR_SLOW") != "1", reason="5 min; DHQR_SLOW=1"))])
 def test_gemm_nn_quad(emu_gemm, tmp_path, rows, ncols, swz):
     """C -= [V1 | V2] [W1; W2] (k_gemm_nn_quad): V2 starts 256 rows below V1; padding rows of V / C never used or changed"""
     rng = np.random.default_rng(4)
