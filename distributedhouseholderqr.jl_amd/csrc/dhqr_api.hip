@@ -1632,6 +1632,23 @@ int32_t dhqr_factor_c64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t l
   return DHQR_OK;
 }
 
+// One ComplexF64 panel: factor (src:122-148,171-213 inside the panel) and, when `build` is set, embed its reflectors as a
+// real 2 rows x 128 operand and build T (the last panel is applied to nothing: build = false).
+static int32_t zpanel_make(dhqr_ctx *c, double *P, int64_t rows, int64_t w, int64_t lda, double *al, const PanelBuf &pb, bool build) {
+  CHECK(dhqr_factor_c64(c, P, rows, w, lda, al));
+  if (!build) return DHQR_OK;
+  const int64_t npad = panel_ldv(2 * rows);
+  CHECK(prof_begin(c, CAT_TBUILD));
+  {
+    dim3 grid((unsigned)std::min<int64_t>((npad / 2 + 255) / 256, 64), (unsigned)DHQR_ZNB);
+    hipLaunchKernelGGL(k_zpack_emb, grid, dim3(256), 0, c->stream, reinterpret_cast<const double2 *>(P), lda, rows, (int)w,
+                       pb.V, pb.ldv, npad);
+  }
+  CHECK(panel_build_t(c, 2 * rows, -2 * w, pb));  // negative: strict upper part at the 2 x 2 block level
+  CHECK(prof_end(c));
+  return DHQR_OK;
+}
+
 // Blocked ComplexF64 factorisation: panels of DHQR_ZNB = 64 complex columns are factored by the unblocked complex
 // kernels, their block reflector is applied to the trailing matrix by the Float64 MFMA kernels through the real
 // embedding (dhqr_complex.h).  nb = 0: unblocked (dhqr_factor_c64), nb = 64: blocked.
@@ -1647,22 +1664,9 @@ int32_t dhqr_factor_c64_nb(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_
   const int64_t ZB = DHQR_ZNB;
   CHECK(ensure(c, c->vt, 2 * (size_t)panel_elems(2 * m)));  // two panel operand buffers (look-ahead: panel k + 1 is built while k is applied)
   double *vtb[2] = {c->vt.p, c->vt.p + panel_elems(2 * m)};
-  // one panel: factor (src:122-148,171-213 inside the panel), embed, T
   auto make_panel = [&](int64_t c0, const PanelBuf &pb) -> int32_t {
-    const int64_t w = std::min<int64_t>(ZB, n - c0), rows = m - c0;
-    double *P = dA + 2 * (c0 + c0 * lda);
-    CHECK(dhqr_factor_c64(c, P, rows, w, lda, dalpha + 2 * c0));
-    if (n - c0 - w <= 0) return DHQR_OK;  // the last panel is applied to nothing
-    const int64_t npad = panel_ldv(2 * rows);
-    CHECK(prof_begin(c, CAT_TBUILD));
-    {
-      dim3 grid((unsigned)std::min<int64_t>((npad / 2 + 255) / 256, 64), (unsigned)ZB);
-      hipLaunchKernelGGL(k_zpack_emb, grid, dim3(256), 0, c->stream, reinterpret_cast<const double2 *>(P), lda, rows, (int)w,
-                         pb.V, pb.ldv, npad);
-    }
-    CHECK(panel_build_t(c, 2 * rows, -2 * w, pb));  // negative: strict upper part at the 2 x 2 block level
-    CHECK(prof_end(c));
-    return DHQR_OK;
+    const int64_t w = std::min<int64_t>(ZB, n - c0);
+    return zpanel_make(c, dA + 2 * (c0 + c0 * lda), m - c0, w, lda, dalpha + 2 * c0, pb, n - c0 - w > 0);
   };
   // Look-ahead (DHQR_LOOKAHEAD=0 or per-column panels: plain loop).  With one launch per COLUMN a lane was slower than
   // no lane (profiles/r02_ab_c64_blocked_lookahead.txt: every launch waited for a CU behind the wide update's GEMM
@@ -2554,6 +2558,71 @@ int32_t dhqr_mg_ldiv_f64(dhqr_mg *g, const double *hA, int64_t m, int64_t n, int
   if (g->m != m || g->n != n) CHECK(dhqr_mg_alloc_f64(g, m, n));
   CHECK(mg_transfer(g, const_cast<double *>(hA), lda, const_cast<double *>(halpha), true));
   return dhqr_mg_solve_f64(g, hb, hx);
+}
+
+// ---- ComplexF64 column split (dhqr_zdist.h): cyclic blocks of DHQR_ZNB = 64 complex columns
+#include "dhqr_zdist.h"
+int64_t dhqr_cs_local_cols_c64(int64_t n, int32_t nranks, int32_t rank) {
+  if (n < 0 || nranks < 1 || rank < 0 || rank >= nranks) return -1;
+  return zcs_local_cols(n, nranks, rank);
+}
+
+// householder!(A, alpha) (src:215-294) for ComplexF64 columns distributed over the communicator's ranks.
+int32_t dhqr_cs_factor_c64(dhqr_comm *cm, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha) {
+  if (!cm) return set_err(DHQR_EINVAL, "null communicator");
+  if (no_columns(m, n)) return DHQR_OK;
+  if (m <= 0 || n <= 0 || m < n) return set_err(DHQR_EINVAL, "m >= n >= 1 required (m=%lld n=%lld)", (long long)m, (long long)n);
+  ENTER(cm->ctx);
+  const int64_t ncl = zcs_local_cols(n, cm->nranks, cm->rank);
+  if (ncl > 0) {
+    CHECK(check_mat(dA, m, ncl, 2 * lda, false));  // the MFMA kernels see the interleaved storage as a real matrix with ld = 2 lda
+    CHECK(check_mat(dA, m, ncl, lda, false));
+    CHECK(check_zptr(dA, "matrix"));
+  }
+  CHECK(check_zptr(dalpha, "alpha"));
+  return zcs_factor(cm->ctx, cm, dA, m, n, lda, dalpha);
+}
+
+// qr!(A; ndev) (src:311-315) for a ComplexF64 host matrix over all devices of the handle: host in / host out (H in
+// place of A, alpha), the format dhqr_ldiv_c64 solves with.  The device blocks live for the duration of the call.
+int32_t dhqr_mg_qr_c64(dhqr_mg *g, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha) {
+  if (!g) return set_err(DHQR_EINVAL, "null handle");
+  if (no_columns(m, n)) return DHQR_OK;
+  CHECK(check_mat(hA, m, n, lda, true));
+  if (!halpha) return set_err(DHQR_EINVAL, "null alpha pointer");
+  return mg_run(g, [g, hA, m, n, lda, halpha](int r) -> int32_t {
+    MgRank &k = g->rk[r];
+    dhqr_ctx *c = k.c;
+    const int P = g->ndev;
+    const int64_t ZB = DHQR_ZNB, K = zcs_npanels(n), ncl = zcs_local_cols(n, P, r);
+    const size_t esz = 2 * sizeof(double);
+    double *dA = nullptr, *dal = nullptr;
+    auto body = [&]() -> int32_t {
+      if (hipMalloc((void **)&dA, (size_t)m * (size_t)std::max<int64_t>(ncl, 1) * esz) != hipSuccess)
+        return set_err(DHQR_ENOMEM, "hipMalloc of the %lld x %lld complex block failed", (long long)m, (long long)ncl);
+      if (hipMalloc((void **)&dal, (size_t)n * esz) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc of alpha failed");
+      HIPCHECK(hipMemsetAsync(dal, 0, (size_t)n * esz, c->stream));
+      for (int64_t b = r; b < K; b += P) {
+        const int64_t w = std::min<int64_t>(ZB, n - b * ZB);
+        HIPCHECK(hipMemcpy2DAsync(dA + 2 * (b / P) * ZB * m, m * esz, hA + 2 * b * ZB * lda, lda * esz, m * esz, w,
+                                  hipMemcpyHostToDevice, c->stream));
+      }
+      CHECK(zcs_factor(c, P > 1 ? k.cm : nullptr, dA, m, n, m, dal));
+      for (int64_t b = r; b < K; b += P) {
+        const int64_t w = std::min<int64_t>(ZB, n - b * ZB);
+        HIPCHECK(hipMemcpy2DAsync(hA + 2 * b * ZB * lda, lda * esz, dA + 2 * (b / P) * ZB * m, m * esz, m * esz, w,
+                                  hipMemcpyDeviceToHost, c->stream));
+      }
+      if (r == 0) HIPCHECK(hipMemcpyAsync(halpha, dal, (size_t)n * esz, hipMemcpyDeviceToHost, c->stream));
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      return DHQR_OK;
+    };
+    const int32_t rc = body();
+    if (rc != DHQR_OK) (void)hipDeviceSynchronize();
+    if (dA) (void)hipFree(dA);
+    if (dal) (void)hipFree(dal);
+    return rc;
+  });
 }
 
 int32_t dhqr_mg_set_profiling(dhqr_mg *g, int32_t on) {

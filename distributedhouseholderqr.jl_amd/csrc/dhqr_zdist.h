@@ -1,0 +1,121 @@
+// dhqr_zdist.h -- ComplexF64 column split: `householder!` for a matrix whose columns are distributed over P ranks
+// (reference: src:122-148 for the owner's reflectors, src:141-143 for their fan-out, src:171-213 for the update of
+// the columns a rank holds; the reference is generic over the element type, test/runtests.jl:42-63 runs ComplexF64).
+//
+// Map: cyclic blocks of DHQR_ZNB = 64 complex columns (one panel): panel k lives on rank k % P at local column
+// (k / P) * 64.  Per panel ONE broadcast of [alpha (64 complex) | embedded reflectors V (2 rows x 128) | T | T'] --
+// the operand the Float64 MFMA kernels apply through the real 2 x 2 embedding (dhqr_complex.h) -- and every rank
+// updates the columns it holds with panel_apply.  Look-ahead: the owner of panel k + 1 updates that panel's 64 columns
+// first, factors it and broadcasts it on the high-priority stream while the caller's stream applies panel k to
+// everything beyond (the single-GPU schedule of dhqr_factor_c64_nb with a broadcast between "factored" and "applied").
+// Every broadcast of a factorisation is issued on the high-priority stream, in panel order, on every rank.
+#pragma once
+
+static inline int64_t zcs_npanels(int64_t n) { return (n + DHQR_ZNB - 1) / DHQR_ZNB; }
+// complex columns rank r holds
+static inline int64_t zcs_local_cols(int64_t n, int P, int r) {
+  const int64_t K = zcs_npanels(n);
+  int64_t cols = 0;
+  for (int64_t k = r; k < K; k += P) cols += std::min<int64_t>(DHQR_ZNB, n - k * DHQR_ZNB);
+  return cols;
+}
+// local column of the first panel >= k that rank r holds (clamped to the rank's column count)
+static inline int64_t zcs_local_from(int64_t k, int64_t n, int P, int r) {
+  const int64_t owned_before = k / P + ((k % P) > r ? 1 : 0);
+  return std::min<int64_t>(owned_before * DHQR_ZNB, zcs_local_cols(n, P, r));
+}
+
+// A: the rank's columns (m x zcs_local_cols complex, interleaved re/im, leading dimension lda complex elements);
+// alpha: n complex, replicated (every rank ends with all of it).  cm == nullptr: one rank.
+static int32_t zcs_factor(dhqr_ctx *c, dhqr_comm *cm, double *A, int64_t m, int64_t n, int64_t lda, double *alpha) {
+  const int P = cm ? cm->nranks : 1, r = cm ? cm->rank : 0;
+  const int64_t ZB = DHQR_ZNB, K = zcs_npanels(n), ncl = zcs_local_cols(n, P, r);
+  // broadcast unit of a panel: [alpha: 2 ZB doubles | panel operand of 2 (m - c0) real rows]; two of them (ring)
+  const size_t unit = (size_t)(2 * ZB + panel_elems(2 * m));
+  CHECK(ensure(c, c->vt, 2 * unit));
+  double *buf[2] = {c->vt.p, c->vt.p + unit};
+  int64_t tick[2] = {-1, -1};
+  if (!c->zev[0])
+    for (int i = 0; i < 5; ++i) HIPCHECK(hipEventCreateWithFlags(&c->zev[i], hipEventDisableTiming));
+  hipEvent_t evP[2] = {c->zev[0], c->zev[1]}, evW[2] = {c->zev[2], c->zev[3]}, evS = c->zev[4];
+  hipStream_t sW = c->stream, sL = c->hi;
+  auto on = [&](hipStream_t st, int wsi) { c->stream = st; c->cur_ws = wsi; };
+  {  // the workspaces of both streams, sized up front: nothing is (re)allocated while the two streams run
+    const size_t NN = (size_t)DHQR_NBV * DHQR_NBV, ncmax = (size_t)std::max<int64_t>(ncl, 2 * DHQR_NBV);
+    for (int wsi = 0; wsi < 2; ++wsi) {
+      CHECK(ensure(c, c->ws[wsi].w1, NN * (wsi == 0 ? 2 * ((ncmax + 127) / 128) + 2600 : 520)));
+      CHECK(ensure(c, c->ws[wsi].w1r, (size_t)DHQR_NBV * ncmax));
+      CHECK(ensure(c, c->ws[wsi].w2, (size_t)DHQR_NBV * ncmax));
+    }
+    CHECK(ensure(c, c->spart, 256 * NN));
+    CHECK(ensure(c, c->sfull, NN));
+  }
+  auto width = [&](int64_t k) { return std::min<int64_t>(ZB, n - k * ZB); };
+  auto mine = [&](int64_t k) { return (int)(k % P) == r; };
+  auto has_right = [&](int64_t k) { return n - k * ZB - width(k) > 0; };
+  // the owner factors panel k into buf[k & 1] on the lane, everybody takes part in its broadcast there
+  auto produce = [&](int64_t k) -> int32_t {
+    const int64_t c0 = k * ZB, w = width(k), rows = m - c0;
+    double *b = buf[k & 1];
+    on(sL, 1);
+    // the readers of the broadcast that last LEFT this buffer (panel k - 2, if this rank was its root) must have copied it
+    // out before anything -- this rank's next panel or a peer's incoming one -- overwrites it
+    if (cm) CHECK(comm_wait_consumed(cm, tick[k & 1], sL));
+    if (mine(k)) {
+      double *Pk = A + 2 * (c0 + (k / P) * ZB * lda);
+      CHECK(zpanel_make(c, Pk, rows, w, lda, alpha + 2 * c0, vt_view(b + 2 * ZB, 2 * rows), has_right(k)));
+      HIPCHECK(hipMemcpyAsync(b, alpha + 2 * c0, (size_t)(2 * w) * sizeof(double), hipMemcpyDeviceToDevice, sL));
+    }
+    if (cm && P > 1) {
+      const int64_t count = 2 * ZB + (has_right(k) ? panel_elems(2 * rows) : 0);
+      CHECK(comm_bcast(cm, b, count, (int)(k % P), sL, &tick[k & 1]));
+      if (!mine(k))
+        HIPCHECK(hipMemcpyAsync(alpha + 2 * c0, b, (size_t)(2 * w) * sizeof(double), hipMemcpyDeviceToDevice, sL));
+    }
+    HIPCHECK(hipEventRecord(evP[k & 1], sL));
+    return DHQR_OK;
+  };
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipEventRecord(evS, sW));
+    HIPCHECK(hipStreamWaitEvent(sL, evS, 0));
+    bool produced = false;  // panel k already factored and broadcast by the look-ahead of step k - 1
+    for (int64_t k = 0; k < K; ++k) {
+      const int64_t c0 = k * ZB, rows = m - c0;
+      on(sL, 1);
+      if (k >= 1) HIPCHECK(hipStreamWaitEvent(sL, evW[(k - 1) & 1], 0));  // update k - 1 done; its buffer is free
+      if (!produced) CHECK(produce(k));
+      produced = false;
+      if (!has_right(k)) break;  // the last panel is applied to nothing
+      const PanelBuf pb = vt_view(buf[k & 1] + 2 * ZB, 2 * rows);
+      // look-ahead: panels the pipelined kernel takes in one launch (<= 8192 rows); taller ones are one launch per
+      // column and stay in line (a lane of single-column launches is slower than none, profiles/r02_ab_c64_blocked_lookahead.txt)
+      const bool ahead = c->lookahead && c->zpipe && rows - ZB <= 8192 && k + 1 < K;
+      if (ahead) {
+        on(sL, 1);
+        if (mine(k + 1)) {
+          const int64_t lc = ((k + 1) / P) * ZB;
+          CHECK(panel_apply(c, pb, 2 * rows, A + 2 * (c0 + lc * lda), width(k + 1), 2 * lda, 1));
+        }
+        CHECK(produce(k + 1));
+        produced = true;
+      }
+      // caller's stream: panel k -> every column this rank holds beyond it (beyond panel k + 1 after a look-ahead)
+      on(sW, 0);
+      HIPCHECK(hipStreamWaitEvent(sW, evP[k & 1], 0));
+      const int64_t lo = zcs_local_from(ahead ? k + 2 : k + 1, n, P, r);
+      if (ncl - lo > 0) CHECK(panel_apply(c, pb, 2 * rows, A + 2 * (c0 + lo * lda), ncl - lo, 2 * lda, 1));
+      HIPCHECK(hipEventRecord(evW[k & 1], sW));
+    }
+    on(sW, 0);
+    HIPCHECK(hipEventRecord(evS, sL));
+    HIPCHECK(hipStreamWaitEvent(sW, evS, 0));  // join: the caller's stream owns the result
+    if (cm)
+      for (int i = 0; i < 2; ++i) CHECK(comm_wait_consumed(cm, tick[i], sW));  // c->vt may be reused once this returns
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  on(sW, 0);
+  CHECK(rc);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}

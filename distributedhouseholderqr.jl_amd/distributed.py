@@ -383,10 +383,22 @@ class MultiGpuQR:
 
     # host-in / host-out drop-ins
     def qr_(self, A):
-        """qr!(A) over all devices: A (float64 numpy, m x n) is factored in place; returns (A, α)."""
-        if not isinstance(A, np.ndarray) or A.dtype != np.float64 or A.ndim != 2:
-            raise TypeError("float64 numpy matrix expected")
+        """qr!(A) over all devices: A (float64 or complex128 numpy, m x n) is factored in place; returns (A, α).
+        complex128: cyclic blocks of 64 columns over the devices (dhqr_mg_qr_c64); `ldiv` of the single-GPU API
+        (dhqr_ldiv_c64) solves with the result."""
+        if not isinstance(A, np.ndarray) or A.dtype not in (np.float64, np.complex128) or A.ndim != 2:
+            raise TypeError("float64 or complex128 numpy matrix expected")
         m, n = A.shape
+        if m < n:
+            raise ValueError("m >= n required")
+        if A.dtype == np.complex128:
+            F = A if A.flags.f_contiguous else np.asfortranarray(A)
+            al = np.zeros(n, dtype=np.complex128)
+            lda = F.strides[1] // 16 if n > 1 else max(m, 1)
+            self._check(self.L.dhqr_mg_qr_c64(self._h, F.ctypes.data_as(_P), m, n, lda, al.ctypes.data_as(_P)))
+            if F is not A:
+                A[...] = F
+            return A, al
         F = A if A.flags.f_contiguous else np.asfortranarray(A)
         al = np.zeros(n)
         lda = F.strides[1] // 8 if n > 1 else max(m, 1)

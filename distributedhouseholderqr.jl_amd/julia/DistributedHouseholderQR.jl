@@ -169,6 +169,23 @@ function householder!(A::StridedMatrix{Float64}, α::Vector{Float64}, ndev::Inte
   return (A, α)
 end
 
+# ComplexF64 over `ndev` GPUs: cyclic blocks of 64 columns (dhqr_mg_qr_c64); `\` of the result is the single-GPU
+# ComplexF64 solve (the factored matrix is back on the host in the reference's format).
+function householder!(A::StridedMatrix{ComplexF64}, α::Vector{ComplexF64}, ndev::Integer)
+  m, n = size(A)
+  stride(A, 1) == 1 || throw(ArgumentError("column-major storage required"))
+  check(ccall((:dhqr_mg_qr_c64, libdhqr), Int32,
+              (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Int64, Int64, Ptr{ComplexF64}),
+              multigpu(ndev), A, m, n, stride(A, 2), α))
+  return (A, α)
+end
+
+function qr!(A::StridedMatrix{ComplexF64}, ndev::Integer)
+  H = DistributedHouseholderQRStruct(A)
+  householder!(H.A, H.α, ndev)
+  return H
+end
+
 function qr!(A::StridedMatrix{Float64}, ndev::Integer)   # qr!(A, 8): the 8 GPUs of the node
   H = DistributedHouseholderQRStruct(A)
   householder!(H.A, H.α, ndev)

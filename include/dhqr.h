@@ -323,6 +323,17 @@ int32_t dhqr_cs_store_contiguous_f64(dhqr_comm *comm, const double *dA, int64_t 
                                      double *dBlock, int64_t ldb, double *dstage);
 int32_t dhqr_cs_qr_darray_f64(dhqr_comm *comm, double *hBlock, int64_t m, int64_t n, int64_t ldb, double *halpha);
 
+/* ------------------------------------------------------------------ multi-GPU: ComplexF64 column split
+ * The reference's householder! is generic over the element type (src:215-294; test/runtests.jl:42-63 runs ComplexF64).
+ * Layout: cyclic blocks of 64 complex columns (one panel): rank r holds the global panels r, r+P, r+2P, ...
+ * contiguously (dA: m x dhqr_cs_local_cols_c64(n,P,r) complex, interleaved re/im, leading dimension lda complex
+ * elements); dalpha (n complex) is replicated.  Per panel ONE broadcast of (alpha, embedded V, T, T') replaces the
+ * per-column fan-out (src:141-143); the owner of the next panel looks ahead on a high-priority stream.
+ * Every rank of the communicator must make the call.  Asynchronous on the context's stream like dhqr_factor_c64_nb.
+ *   dhqr_mg_qr_c64   qr!(A; ndev) for a ComplexF64 host matrix (host in / host out; dhqr_ldiv_c64 solves with it). */
+int64_t dhqr_cs_local_cols_c64(int64_t n, int32_t nranks, int32_t rank);
+int32_t dhqr_cs_factor_c64(dhqr_comm *comm, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha);
+
 /* ------------------------------------------------------------------ multi-GPU: single-process handle
  * One host process drives `ndev` GPUs (devices[i] = HIP device of rank i; NULL = 0..ndev-1): one context, one
  * communicator rank and one host thread per device run the SPMD drivers above.  Transport: RCCL
@@ -345,6 +356,7 @@ int32_t dhqr_mg_residual_f64(dhqr_mg *mg, uint64_t seed, double *hrel);
 int32_t dhqr_mg_upload_f64(dhqr_mg *mg, const double *hA, int64_t lda, const double *halpha);
 int32_t dhqr_mg_download_f64(dhqr_mg *mg, double *hA, int64_t lda, double *halpha);
 int32_t dhqr_mg_qr_f64(dhqr_mg *mg, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha);
+int32_t dhqr_mg_qr_c64(dhqr_mg *mg, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha);
 int32_t dhqr_mg_solve_f64(dhqr_mg *mg, const double *hb, double *hx);
 int32_t dhqr_mg_ldiv_f64(dhqr_mg *mg, const double *hA, int64_t m, int64_t n, int64_t lda, const double *halpha,
                          const double *hb, double *hx);

@@ -150,6 +150,34 @@ def test_column_split_over_rccl(rk, orc, ndev, m, n, env):
     assert _stats(F)["live"] == 0  # every communicator destroyed
 
 
+# ComplexF64 column split (dhqr_zdist.h): cyclic blocks of 64 complex columns, one ncclBroadcast per panel issued on the
+# look-ahead stream of every rank; 3 ranks / 5 panels with a partial last one, 8 ranks with 3 panels (five ranks own nothing)
+@pytest.mark.parametrize("ndev,m,n", [(2, 260, 200), (3, 330, 300), (8, 200, 130)])
+def test_complex_column_split_over_rccl(rk, orc, ndev, m, n):
+    L, F = rk
+    with _env(DHQR_BCAST="ring"):
+        h = _mg(L, ndev)
+    A0 = orc.rand_matrix_c(m, n, 21)
+    A, al = A0.copy(order="F"), np.zeros(n, dtype=complex)
+    _stats(F)
+    assert L.dhqr_mg_qr_c64(h, _ptr(A), m, n, m, _ptr(al)) == 0, L.dhqr_last_error()
+    s1 = _stats(F)
+    assert s1["bcast"] == ndev * ((n + 63) // 64), s1  # one broadcast per panel on every rank
+    assert s1["timeouts"] == 0 and s1["mismatches"] == 0
+    Ho, ao = orc.householder_c(A0)
+    scale = np.abs(Ho).max()
+    assert np.abs(A - Ho).max() <= 1e-12 * scale and np.abs(al - ao).max() <= 1e-12 * scale
+    # the same bits as one rank (every column sees the same panel operands in the same order)
+    h1 = P_()
+    assert L.dhqr_create(ctypes.byref(h1), 0) == 0
+    A1, al1 = A0.copy(order="F"), np.zeros(n, dtype=complex)
+    assert L.dhqr_qr_c64_nb(h1, _ptr(A1), m, n, m, _ptr(al1), 64) == 0, L.dhqr_last_error()
+    assert np.abs(A1 - A).max() <= 1e-13 * scale
+    L.dhqr_destroy(h1)
+    assert L.dhqr_mg_destroy(h) == 0
+    assert _stats(F)["live"] == 0
+
+
 # row split: lane collectives on the second communicator while the wide stream uses the first; DHQR_LANE_CHANNEL=0
 # shares one; tsqr: every panel through the cross-rank tree (gather of the R factors by one all-reduce)
 @pytest.mark.parametrize("ndev,m,n,env", [

@@ -194,6 +194,42 @@ def test_blocked_complex_vs_oracle(pkg, orc, m, n):
     assert np.abs(x - xr).max() <= 1e-8 * np.abs(xr).max()
 
 
+@pytest.mark.parametrize("ranks,m,n", [(1, 300, 200), (2, 300, 200), (3, 700, 650), (2, 1100, 1000), (8, 1500, 1030),
+                                        (3, 9000, 200), (4, 64, 64), (5, 70, 3)])
+def test_complex_column_split_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
+    """qr!(A; ndev) for ComplexF64 (dhqr_mg_qr_c64 -> zcs_factor, dhqr_zdist.h): cyclic blocks of 64 complex columns over
+    `ranks` rank threads on cuda:0 (peer-copy transport), one broadcast per panel, look-ahead by the owner of the next
+    panel; against the oracle element by element, then the reference's solve on the host-format result.  Shapes: fewer
+    panels than ranks, a partial last panel, panels taller than the pipelined kernel's 8192 rows (no look-ahead there)."""
+    mg = pkg.MultiGpuQR(devices=[0] * ranks)
+    try:
+        A0 = orc.rand_matrix_c(m, n, 3)
+        A = np.asfortranarray(A0.copy())
+        H, alpha = mg.qr_(A)
+        assert H is A
+        Ho, ao = orc.householder_c(A0)
+        scale = np.abs(Ho).max()
+        kappa = np.linalg.cond(A0) if n >= 1000 else 1.0
+        tol = max(TOL(Ho), 64 * kappa * np.finfo(float).eps)
+        assert np.abs(H - Ho).max() <= tol * scale, np.abs(H - Ho).max() / scale
+        assert np.abs(alpha - ao).max() <= tol * scale
+        QR = orc.form_qr_c(np.asfortranarray(H), alpha)
+        assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-12
+        b = orc.rand_vector_c(m, 4)
+        x = pkg.ldiv(pkg.DistributedHouseholderQRStruct(H, alpha), b)
+        xr = np.linalg.lstsq(A0, b, rcond=None)[0]
+        assert np.abs(np.asarray(x) - xr).max() <= 1e-8 * np.abs(xr).max()
+        if ranks > 1 and n > 64:
+            cnt = mg.comm_counters(0)
+            assert cnt["n_bcast"] == (n + 63) // 64, cnt  # ONE broadcast per panel (src:141-143 fans out per column)
+        # a second factorisation on the same handle gives the same bits (buffers, events, mailboxes reused)
+        A2 = np.asfortranarray(A0.copy())
+        H2, alpha2 = mg.qr_(A2)
+        assert np.array_equal(H2, H) and np.array_equal(alpha2, alpha)
+    finally:
+        mg.close()
+
+
 @pytest.mark.parametrize("m,n", REF_SHAPES)
 def test_reference_acceptance_inequality_complex_blocked(pkg, orc, m, n):
     """test/runtests.jl:42-63 with T = ComplexF64 through the BLOCKED path (host drop-in, nb = 64).  The reference's
