@@ -2583,6 +2583,45 @@ int32_t dhqr_cs_factor_c64(dhqr_comm *cm, double *dA, int64_t m, int64_t n, int6
   return zcs_factor(cm->ctx, cm, dA, m, n, lda, dalpha);
 }
 
+// qr!(A::DArray{ComplexF64}) (src:115-120, 311-315) for one process: its contiguous host column block in, the factored
+// block + the replicated alpha out (the ComplexF64 method of dhqr_cs_qr_darray_f64).
+int32_t dhqr_cs_qr_darray_c64(dhqr_comm *cm, double *hBlock, int64_t m, int64_t n, int64_t ldb, double *halpha) {
+  if (!cm) return set_err(DHQR_EINVAL, "null communicator");
+  if (no_columns(m, n)) return DHQR_OK;
+  if (m <= 0 || n <= 0 || m < n) return set_err(DHQR_EINVAL, "m >= n >= 1 required (m=%lld n=%lld)", (long long)m, (long long)n);
+  dhqr_ctx *c = cm->ctx;
+  ENTER(c);
+  if (!halpha) return set_err(DHQR_EINVAL, "null alpha pointer");
+  const int P = cm->nranks, r = cm->rank;
+  int64_t lo, hi;
+  cs_contig_range(n, P, r, &lo, &hi);
+  const int64_t wr = hi - lo, wmax = std::max<int64_t>(n / P + 1, DHQR_ZNB), ncl = zcs_local_cols(n, P, r);
+  if (wr > 0 && (!hBlock || ldb < m)) return set_err(DHQR_EINVAL, "bad local block");
+  const size_t esz = 2 * sizeof(double);
+  double *dA = nullptr, *dBlk = nullptr, *dStage = nullptr, *dal = nullptr;
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMalloc((void **)&dA, (size_t)m * std::max<int64_t>(ncl, 1) * esz));
+    HIPCHECK(hipMalloc((void **)&dBlk, (size_t)m * std::max<int64_t>(wr, 1) * esz));
+    HIPCHECK(hipMalloc((void **)&dStage, (size_t)m * wmax * esz));
+    HIPCHECK(hipMalloc((void **)&dal, (size_t)n * esz));
+    HIPCHECK(hipMemsetAsync(dal, 0, (size_t)n * esz, c->stream));
+    if (wr > 0) HIPCHECK(hipMemcpy2DAsync(dBlk, m * esz, hBlock, ldb * esz, m * esz, wr, hipMemcpyHostToDevice, c->stream));
+    CHECK(zcs_convert(c, cm, dA, m, n, m, dBlk, m, dStage, true));
+    CHECK(zcs_factor(c, cm, dA, m, n, m, dal));
+    CHECK(zcs_convert(c, cm, dA, m, n, m, dBlk, m, dStage, false));
+    if (wr > 0) HIPCHECK(hipMemcpy2DAsync(hBlock, ldb * esz, dBlk, m * esz, m * esz, wr, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(halpha, dal, (size_t)n * esz, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  (void)hipDeviceSynchronize();
+  double *ps[] = {dA, dBlk, dStage, dal};
+  for (double *p : ps)
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
 // qr!(A; ndev) (src:311-315) for a ComplexF64 host matrix over all devices of the handle: host in / host out (H in
 // place of A, alpha), the format dhqr_ldiv_c64 solves with.  The device blocks live for the duration of the call.
 int32_t dhqr_mg_qr_c64(dhqr_mg *g, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha) {

@@ -119,3 +119,55 @@ static int32_t zcs_factor(dhqr_ctx *c, dhqr_comm *cm, double *A, int64_t m, int6
   LAUNCHCHECK();
   return DHQR_OK;
 }
+
+// ---- the reference's DArray layout for ComplexF64 (src:115-120, test/runtests.jl:71): ONE contiguous column block per
+// process (cs_contig_range) <-> the cyclic 64-column blocks above.  One broadcast of every rank's block on the way in, one
+// per panel on the way out.  dBlk: m x w_r complex (leading dimension ldb complex); dStage: m x max(n/P + 1, 64) complex.
+static int32_t zcs_convert(dhqr_ctx *c, dhqr_comm *cm_, double *A, int64_t m, int64_t n, int64_t lda, double *dBlk, int64_t ldb,
+                           double *dStage, bool load) {
+  const int P = cm_ ? cm_->nranks : 1, r = cm_ ? cm_->rank : 0;
+  dhqr_comm *cm = P > 1 ? cm_ : nullptr;
+  const int64_t ZB = DHQR_ZNB, K = zcs_npanels(n);
+  const size_t esz = 2 * sizeof(double);
+  auto stage_reusable = [&]() -> int32_t {  // LOCAL: peers read the root's stage directly
+    if (cm && cm->kind == COMM_LOCAL) {
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      CHECK(comm_host_barrier(cm));
+    }
+    return DHQR_OK;
+  };
+  if (load) {
+    for (int s = 0; s < P; ++s) {
+      int64_t lo, hi;
+      cs_contig_range(n, P, s, &lo, &hi);
+      const int64_t wblk = hi - lo;
+      if (wblk == 0) continue;
+      if (s == r)
+        HIPCHECK(hipMemcpy2DAsync(dStage, m * esz, dBlk, ldb * esz, m * esz, wblk, hipMemcpyDeviceToDevice, c->stream));
+      if (cm) CHECK(comm_bcast(cm, dStage, 2 * m * wblk, s, c->stream, nullptr));
+      for (int64_t k = lo / ZB; k <= (hi - 1) / ZB; ++k) {  // the pieces of [lo, hi) this rank holds, panel by panel
+        if ((int)(k % P) != r) continue;
+        const int64_t g0 = std::max<int64_t>(k * ZB, lo), g1 = std::min<int64_t>(std::min<int64_t>((k + 1) * ZB, hi), n);
+        if (g1 <= g0) continue;
+        HIPCHECK(hipMemcpy2DAsync(A + 2 * ((k / P) * ZB + g0 - k * ZB) * lda, lda * esz, dStage + 2 * (g0 - lo) * m, m * esz,
+                                  m * esz, g1 - g0, hipMemcpyDeviceToDevice, c->stream));
+      }
+      CHECK(stage_reusable());
+    }
+    return DHQR_OK;
+  }
+  int64_t lo, hi;
+  cs_contig_range(n, P, r, &lo, &hi);
+  for (int64_t k = 0; k < K; ++k) {
+    const int64_t w = std::min<int64_t>(ZB, n - k * ZB), g0 = k * ZB;
+    if ((int)(k % P) == r)
+      HIPCHECK(hipMemcpy2DAsync(dStage, m * esz, A + 2 * (k / P) * ZB * lda, lda * esz, m * esz, w, hipMemcpyDeviceToDevice, c->stream));
+    if (cm) CHECK(comm_bcast(cm, dStage, 2 * m * w, (int)(k % P), c->stream, nullptr));
+    const int64_t i0 = std::max<int64_t>(g0, lo), i1 = std::min<int64_t>(g0 + w, hi);
+    if (i1 > i0)
+      HIPCHECK(hipMemcpy2DAsync(dBlk + 2 * (i0 - lo) * ldb, ldb * esz, dStage + 2 * (i0 - g0) * m, m * esz, m * esz, i1 - i0,
+                                hipMemcpyDeviceToDevice, c->stream));
+    CHECK(stage_reusable());
+  }
+  return DHQR_OK;
+}

@@ -293,6 +293,28 @@ def qr_darray_(local_block, n: int, comm: Optional[Communicator] = None, mem=Non
     return q, q.alpha
 
 
+def qr_darray_c64_(local_block, m: int, n: int, comm: Communicator):
+    """qr!(A::DArray{ComplexF64}) (src:115-120, 311-315) for one process: `local_block` is this rank's CONTIGUOUS column
+    block (complex128 numpy, column-major, m x w_r -- the reference's DistributedArrays layout) and is overwritten with the
+    factored columns; returns the replicated α (dhqr_cs_qr_darray_c64: cyclic 64-column blocks inside)."""
+    if not isinstance(local_block, np.ndarray) or local_block.dtype != np.complex128 or local_block.ndim != 2:
+        raise TypeError("complex128 numpy block expected")
+    if local_block.shape[1] and not local_block.flags.f_contiguous:
+        raise ValueError("column-major block expected")
+    if local_block.shape[0] != m:
+        raise ValueError(f"the block must have {m} rows, got {local_block.shape[0]}")
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    comm.L.dhqr_cs_contiguous_range(n, comm.nranks, comm.rank, ctypes.byref(lo), ctypes.byref(hi))
+    if local_block.shape[1] != hi.value - lo.value:
+        raise ValueError(f"rank {comm.rank} must pass columns [{lo.value}, {hi.value}), got {local_block.shape[1]} columns")
+    al = np.zeros(n, dtype=np.complex128)
+    ptr = local_block.ctypes.data_as(_P) if local_block.shape[1] else None
+    rc = comm.L.dhqr_cs_qr_darray_c64(comm.handle, ptr, m, n, m, al.ctypes.data_as(_P))
+    if rc != 0:
+        raise _lib.DHQRError(rc, comm.L.dhqr_last_error().decode(errors="replace"))
+    return al
+
+
 class MultiGpuQR:
     """Single-process multi-GPU handle (dhqr_mg_*): one host thread per device inside the library.
     `qr!(A; ndev)` of the Julia module binds the same entry points."""

@@ -281,12 +281,18 @@ function householder_local!(Al::StridedMatrix{Float64}, m::Integer, n::Integer, 
               _comm[], Al, m, n, max(stride(Al, 2), m), α))
   return α
 end
+function householder_local!(Al::StridedMatrix{ComplexF64}, m::Integer, n::Integer, α::Vector{ComplexF64})
+  check(ccall((:dhqr_cs_qr_darray_c64, libdhqr), Int32,
+              (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Int64, Int64, Ptr{ComplexF64}),
+              _comm[], Al, m, n, max(stride(Al, 2), m), α))
+  return α
+end
 
 # The DArray method itself needs DistributedArrays (not a dependency of this file: the method is defined when the
 # caller has loaded it, the way the reference's src:115-120 is written against it).
 function __init_darray_methods__(DistributedArrays)
   @eval begin
-    function householder!(A::$(DistributedArrays).DArray{Float64, 2}, α::Vector{Float64}; devices=nothing)
+    function householder!(A::$(DistributedArrays).DArray{T, 2}, α::Vector{T}; devices=nothing) where {T<:Union{Float64, ComplexF64}}
       ws = vec(procs(A))
       np = length(ws)
       m, n = size(A)
@@ -299,15 +305,15 @@ function __init_darray_methods__(DistributedArrays)
         end
       end
       futs = [remotecall(p) do                                           # ONE call per worker (src:115-120 visits owners
-                al = zeros(Float64, n)                                   #   sequentially and fans out every column)
+                al = zeros(T, n)                                         #   sequentially and fans out every column)
                 householder_local!($(DistributedArrays).localpart(A), m, n, al)
               end for p in ws]
       α .= fetch(futs[1])                                                # α is replicated (SharedArray in the reference)
       foreach(wait, futs)
       return (A, α)
     end
-    function qr!(A::$(DistributedArrays).DArray{Float64, 2}; devices=nothing)   # src:311-315
-      H = DistributedHouseholderQRStruct(A, zeros(Float64, size(A, 2)))
+    function qr!(A::$(DistributedArrays).DArray{T, 2}; devices=nothing) where {T<:Union{Float64, ComplexF64}}   # src:311-315
+      H = DistributedHouseholderQRStruct(A, zeros(T, size(A, 2)))
       householder!(H.A, H.α; devices=devices)
       return H
     end

@@ -330,9 +330,12 @@ int32_t dhqr_cs_qr_darray_f64(dhqr_comm *comm, double *hBlock, int64_t m, int64_
  * elements); dalpha (n complex) is replicated.  Per panel ONE broadcast of (alpha, embedded V, T, T') replaces the
  * per-column fan-out (src:141-143); the owner of the next panel looks ahead on a high-priority stream.
  * Every rank of the communicator must make the call.  Asynchronous on the context's stream like dhqr_factor_c64_nb.
+ *   dhqr_cs_qr_darray_c64  qr!(A::DArray{ComplexF64}) for one process: its CONTIGUOUS host column block
+ *                          (dhqr_cs_contiguous_range) in, factored block + alpha out; synchronous.
  *   dhqr_mg_qr_c64   qr!(A; ndev) for a ComplexF64 host matrix (host in / host out; dhqr_ldiv_c64 solves with it). */
 int64_t dhqr_cs_local_cols_c64(int64_t n, int32_t nranks, int32_t rank);
 int32_t dhqr_cs_factor_c64(dhqr_comm *comm, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha);
+int32_t dhqr_cs_qr_darray_c64(dhqr_comm *comm, double *hBlock, int64_t m, int64_t n, int64_t ldb, double *halpha);
 
 /* ------------------------------------------------------------------ multi-GPU: single-process handle
  * One host process drives `ndev` GPUs (devices[i] = HIP device of rank i; NULL = 0..ndev-1): one context, one

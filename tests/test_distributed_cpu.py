@@ -237,6 +237,44 @@ def test_darray_layout_front_end(emulated_so, m, n, P):
     run_ranks(_darray, P, m, n, emulated_so)
 
 
+def _darray_c64(rank, P, m, n, so):
+    """qr!(A::DArray{ComplexF64}): every PROCESS passes its contiguous block of complex columns and gets it back factored
+    (dhqr_cs_qr_darray_c64: cyclic 64-column blocks, one broadcast per panel over the callback transport = gloo here),
+    then the SPMD entry point dhqr_cs_factor_c64 on the cyclic layout directly"""
+    from dist_helpers import emulated_rank
+    from oracle import dhqr_oracle as orc
+    L, h, comm, D = emulated_rank(so, P, rank)
+    A = orc.rand_matrix_c(m, n, 61)
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    L.dhqr_cs_contiguous_range(n, P, rank, ctypes.byref(lo), ctypes.byref(hi))
+    blk = np.array(A[:, lo.value: hi.value], order="F")
+    alpha = D.qr_darray_c64_(blk, m, n, comm)
+    Ho, ao = orc.householder_c(A)
+    scale = np.abs(Ho).max()
+    if hi.value > lo.value:
+        assert np.abs(blk - Ho[:, lo.value: hi.value]).max() <= 1e-12 * scale
+    assert np.abs(alpha - ao).max() <= 1e-12 * scale
+    with pytest.raises(ValueError):
+        D.qr_darray_c64_(np.zeros((m, hi.value - lo.value + 1), dtype=complex, order="F"), m, n, comm)
+    # cyclic layout, caller-managed memory (the emulated device's memory is host memory)
+    ncl = L.dhqr_cs_local_cols_c64(n, P, rank)
+    gcols = [((jl // 64) * P + rank) * 64 + jl % 64 for jl in range(ncl)]
+    loc = np.array(A[:, gcols], order="F") if ncl else np.zeros((m, 1), dtype=complex, order="F")
+    al = np.zeros(n, dtype=complex)
+    rc = L.dhqr_cs_factor_c64(comm.handle, loc.ctypes.data_as(ctypes.c_void_p), m, n, m, al.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0, L.dhqr_last_error()
+    assert L.dhqr_synchronize(h) == 0
+    if ncl:
+        assert np.abs(loc - Ho[:, gcols]).max() <= 1e-12 * scale
+    assert np.abs(al - ao).max() <= 1e-12 * scale
+    return True
+
+
+@pytest.mark.parametrize("m,n,P", [(260, 200, 3), (150, 70, 2)])
+def test_complex_darray_front_end_and_spmd_column_split(emulated_so, m, n, P):
+    run_ranks(_darray_c64, P, m, n, emulated_so)
+
+
 # ---------------------------------------------------------------- 3: row split (BASELINE configs[4]), emulated library
 # (ndev, m, n): diagonal blocks on several ranks (n > rows of rank 0); partial last panel; more ranks than row blocks
 # tsqr = 1: every panel through TSQR-HR (local trees, gather of the rank R factors, the cross-rank tree, explicit Q)

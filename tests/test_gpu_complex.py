@@ -230,6 +230,27 @@ def test_complex_column_split_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
         mg.close()
 
 
+def test_complex_darray_front_end_single_gpu(pkg, orc):
+    """qr!(A::DArray{ComplexF64}) at world size 1 (dhqr_cs_qr_darray_c64: contiguous host block in / out, the cyclic layout
+    and the SPMD driver inside) = the single-GPU blocked factorisation, bit for bit; several processes: tests/test_distributed_cpu.py"""
+    import importlib
+    D = importlib.import_module("dhqr_amd.distributed")
+    api = importlib.import_module("dhqr_amd.api")
+    comm = D.Communicator.from_torch(api.get_context(0))
+    m, n = 700, 650
+    A0 = orc.rand_matrix_c(m, n, 9)
+    blk = A0.copy(order="F")
+    alpha = pkg.qr_darray_c64_(blk, m, n, comm)
+    H1 = A0.copy(order="F")
+    H = pkg.qr_(H1, nb=64)
+    assert np.array_equal(blk, np.asarray(H.A)) and np.array_equal(alpha, np.asarray(H.α))
+    Ho, ao = orc.householder_c(A0)
+    assert np.abs(blk - Ho).max() <= TOL(Ho) * np.abs(Ho).max()
+    with pytest.raises(ValueError):
+        pkg.qr_darray_c64_(np.zeros((m, n - 1), dtype=complex, order="F"), m, n, comm)
+    comm.close()
+
+
 @pytest.mark.parametrize("m,n", REF_SHAPES)
 def test_reference_acceptance_inequality_complex_blocked(pkg, orc, m, n):
     """test/runtests.jl:42-63 with T = ComplexF64 through the BLOCKED path (host drop-in, nb = 64).  The reference's
