@@ -3,9 +3,9 @@
 // the columns a rank holds; the reference is generic over the element type, test/runtests.jl:42-63 runs ComplexF64).
 //
 // Map: cyclic blocks of DHQR_ZNB = 64 complex columns (one panel): panel k lives on rank k % P at local column
-// (k / P) * 64.  Per panel ONE broadcast of [alpha (64 complex) | embedded reflectors V (2 rows x 128) | T | T'] --
-// the operand the Float64 MFMA kernels apply through the real 2 x 2 embedding (dhqr_complex.h) -- and every rank
-// updates the columns it holds with panel_apply.  Look-ahead: the owner of panel k + 1 updates that panel's 64 columns
+// (k / P) * 64.  Per panel ONE broadcast of [alpha (64 complex) | T | T' | the factored panel, rows x 64 complex]; every
+// rank embeds the 64 reflectors itself (k_zpack_emb: the real 2 x 2 embedding of dhqr_complex.h, 2 rows x 128 -- twice
+// the bytes, which therefore do not travel) and updates the columns it holds with the Float64 MFMA kernels (panel_apply).  Look-ahead: the owner of panel k + 1 updates that panel's 64 columns
 // first, factors it and broadcasts it on the high-priority stream while the caller's stream applies panel k to
 // everything beyond (the single-GPU schedule of dhqr_factor_c64_nb with a broadcast between "factored" and "applied").
 // Every broadcast of a factorisation is issued on the high-priority stream, in panel order, on every rank.
@@ -30,10 +30,15 @@ static inline int64_t zcs_local_from(int64_t k, int64_t n, int P, int r) {
 static int32_t zcs_factor(dhqr_ctx *c, dhqr_comm *cm, double *A, int64_t m, int64_t n, int64_t lda, double *alpha) {
   const int P = cm ? cm->nranks : 1, r = cm ? cm->rank : 0;
   const int64_t ZB = DHQR_ZNB, K = zcs_npanels(n), ncl = zcs_local_cols(n, P, r);
-  // broadcast unit of a panel: [alpha: 2 ZB doubles | panel operand of 2 (m - c0) real rows]; two of them (ring)
-  const size_t unit = (size_t)(2 * ZB + panel_elems(2 * m));
-  CHECK(ensure(c, c->vt, 2 * unit));
+  // broadcast unit of a panel: [alpha: 2 ZB doubles | T, T' (panel tail) | the factored panel itself, (m - c0) x 64 complex,
+  // compact] -- HALF the bytes of the embedded operand: every rank embeds the reflectors itself (k_zpack_emb) into one
+  // of two local operand buffers.  Two units rotate.
+  const size_t unit = (size_t)((2 * ZB + panel_tail_elems() + 2 * m * ZB + 15) & ~(int64_t)15);
+  const size_t vloc = (size_t)(panel_ldv(2 * m) * DHQR_NBV);
+  CHECK(ensure(c, c->vt, 2 * unit + 2 * vloc));
   double *buf[2] = {c->vt.p, c->vt.p + unit};
+  double *Vl[2] = {c->vt.p + 2 * unit, c->vt.p + 2 * unit + vloc};
+  auto operand = [&](int64_t k) { return tail_view(Vl[k & 1], panel_ldv(2 * (m - k * ZB)), buf[k & 1] + 2 * ZB); };
   int64_t tick[2] = {-1, -1};
   if (!c->zev[0])
     for (int i = 0; i < 5; ++i) HIPCHECK(hipEventCreateWithFlags(&c->zev[i], hipEventDisableTiming));
@@ -61,16 +66,29 @@ static int32_t zcs_factor(dhqr_ctx *c, dhqr_comm *cm, double *A, int64_t m, int6
     // the readers of the broadcast that last LEFT this buffer (panel k - 2, if this rank was its root) must have copied it
     // out before anything -- this rank's next panel or a peer's incoming one -- overwrites it
     if (cm) CHECK(comm_wait_consumed(cm, tick[k & 1], sL));
+    const size_t esz = 2 * sizeof(double);
+    double *Pc = b + 2 * ZB + panel_tail_elems();  // the panel as it travels: rows x w complex, leading dimension rows
+    const bool spread = cm && P > 1;
     if (mine(k)) {
       double *Pk = A + 2 * (c0 + (k / P) * ZB * lda);
-      CHECK(zpanel_make(c, Pk, rows, w, lda, alpha + 2 * c0, vt_view(b + 2 * ZB, 2 * rows), has_right(k)));
+      CHECK(zpanel_make(c, Pk, rows, w, lda, alpha + 2 * c0, operand(k), has_right(k)));
       HIPCHECK(hipMemcpyAsync(b, alpha + 2 * c0, (size_t)(2 * w) * sizeof(double), hipMemcpyDeviceToDevice, sL));
+      if (spread && has_right(k))
+        HIPCHECK(hipMemcpy2DAsync(Pc, rows * esz, Pk, lda * esz, rows * esz, w, hipMemcpyDeviceToDevice, sL));
     }
-    if (cm && P > 1) {
-      const int64_t count = 2 * ZB + (has_right(k) ? panel_elems(2 * rows) : 0);
+    if (spread) {
+      const int64_t count = 2 * ZB + (has_right(k) ? panel_tail_elems() + 2 * rows * ZB : 0);
       CHECK(comm_bcast(cm, b, count, (int)(k % P), sL, &tick[k & 1]));
-      if (!mine(k))
+      if (!mine(k)) {
         HIPCHECK(hipMemcpyAsync(alpha + 2 * c0, b, (size_t)(2 * w) * sizeof(double), hipMemcpyDeviceToDevice, sL));
+        if (has_right(k)) {  // the receiver's own embedding of the 64 reflectors (the owner's is made by zpanel_make)
+          const PanelBuf pb = operand(k);
+          const int64_t npad = panel_ldv(2 * rows);
+          dim3 grid((unsigned)std::min<int64_t>((npad / 2 + 255) / 256, 64), (unsigned)ZB);
+          hipLaunchKernelGGL(k_zpack_emb, grid, dim3(256), 0, sL, reinterpret_cast<const double2 *>(Pc), rows, rows, (int)w, pb.V,
+                             pb.ldv, npad);
+        }
+      }
     }
     HIPCHECK(hipEventRecord(evP[k & 1], sL));
     return DHQR_OK;
@@ -86,7 +104,7 @@ static int32_t zcs_factor(dhqr_ctx *c, dhqr_comm *cm, double *A, int64_t m, int6
       if (!produced) CHECK(produce(k));
       produced = false;
       if (!has_right(k)) break;  // the last panel is applied to nothing
-      const PanelBuf pb = vt_view(buf[k & 1] + 2 * ZB, 2 * rows);
+      const PanelBuf pb = operand(k);
       // look-ahead: panels the pipelined kernel takes in one launch (<= 8192 rows); taller ones are one launch per
       // column and stay in line (a lane of single-column launches is slower than none, profiles/r02_ab_c64_blocked_lookahead.txt)
       const bool ahead = c->lookahead && c->zpipe && rows - ZB <= 8192 && k + 1 < K;

@@ -431,7 +431,13 @@ class MultiGpuQR:
         return A, al
 
     def ldiv(self, A, alpha, b):
+        """`H \\ b` (src:317-321) for a factored HOST matrix.  complex128: the host-format result of qr_ is solved by the
+        single-GPU ComplexF64 method (dhqr_ldiv_c64; the solve is O(mn) next to the O(mn^2) factorisation)."""
         m, n = A.shape
+        if isinstance(A, np.ndarray) and A.dtype == np.complex128:
+            from .api import DistributedHouseholderQRStruct, ldiv as _ldiv1
+            return np.asarray(_ldiv1(DistributedHouseholderQRStruct(A, np.asarray(alpha, dtype=np.complex128)),
+                                     np.asarray(b, dtype=np.complex128)))
         F = A if A.flags.f_contiguous else np.asfortranarray(A)
         x = np.zeros(n)
         bb = self._host_vec(b, m, "b")

@@ -219,9 +219,16 @@ def test_complex_column_split_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
         x = pkg.ldiv(pkg.DistributedHouseholderQRStruct(H, alpha), b)
         xr = np.linalg.lstsq(A0, b, rcond=None)[0]
         assert np.abs(np.asarray(x) - xr).max() <= 1e-8 * np.abs(xr).max()
+        assert np.array_equal(mg.ldiv(H, alpha, b), np.asarray(x))  # the handle's `\` for complex128 = the same solve
         if ranks > 1 and n > 64:
             cnt = mg.comm_counters(0)
             assert cnt["n_bcast"] == (n + 63) // 64, cnt  # ONE broadcast per panel (src:141-143 fans out per column)
+            # what travels: alpha (64 complex) + T, T' and status (2 * 128^2 + 128 + 16 doubles) + the factored panel as
+            # rows x 64 COMPLEX -- not its real embedding (2 rows x 128), which every rank forms itself; the last panel
+            # (applied to nothing) sends its alpha only
+            tail = 2 * 128 * 128 + 128 + 16
+            want = sum(8 * (128 + ((tail + 2 * (m - 64 * k) * 64) if 64 * (k + 1) < n else 0)) for k in range((n + 63) // 64))
+            assert cnt["bytes_bcast"] == want, (cnt, want)
         # a second factorisation on the same handle gives the same bits (buffers, events, mailboxes reused)
         A2 = np.asfortranarray(A0.copy())
         H2, alpha2 = mg.qr_(A2)
