@@ -270,7 +270,7 @@ def _darray_c64(rank, P, m, n, so):
     return True
 
 
-@pytest.mark.parametrize("m,n,P", [(260, 200, 3), (150, 70, 2)])
+@pytest.mark.parametrize("m,n,P", [(200, 150, 3), pytest.param(150, 70, 2, marks=_SLOW)])
 def test_complex_darray_front_end_and_spmd_column_split(emulated_so, m, n, P):
     run_ranks(_darray_c64, P, m, n, emulated_so)
 

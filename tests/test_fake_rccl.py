@@ -151,8 +151,8 @@ def test_column_split_over_rccl(rk, orc, ndev, m, n, env):
 
 
 # ComplexF64 column split (dhqr_zdist.h): cyclic blocks of 64 complex columns, one ncclBroadcast per panel issued on the
-# look-ahead stream of every rank; 3 ranks / 5 panels with a partial last one, 8 ranks with 3 panels (five ranks own nothing)
-@pytest.mark.parametrize("ndev,m,n", [(2, 260, 200), (3, 330, 300), (8, 200, 130)])
+# look-ahead stream of every rank; 3 ranks / 3 panels with a partial last one; DHQR_SLOW=1: 2 ranks / 4 panels, 8 ranks with 3 panels (five ranks own nothing)
+@pytest.mark.parametrize("ndev,m,n", [(3, 200, 150), pytest.param(2, 260, 200, marks=_SLOW), pytest.param(8, 200, 130, marks=_SLOW)])
 def test_complex_column_split_over_rccl(rk, orc, ndev, m, n):
     L, F = rk
     with _env(DHQR_BCAST="ring"):
