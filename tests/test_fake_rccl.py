@@ -152,17 +152,21 @@ def test_column_split_over_rccl(rk, orc, ndev, m, n, env):
 
 # ComplexF64 column split (dhqr_zdist.h): cyclic blocks of 64 complex columns, one ncclBroadcast per panel issued on the
 # look-ahead stream of every rank; 3 ranks / 3 panels with a partial last one; DHQR_SLOW=1: 2 ranks / 4 panels, 8 ranks with 3 panels (five ranks own nothing)
-@pytest.mark.parametrize("ndev,m,n", [(3, 200, 150), pytest.param(2, 260, 200, marks=_SLOW), pytest.param(8, 200, 130, marks=_SLOW)])
-def test_complex_column_split_over_rccl(rk, orc, ndev, m, n):
+@pytest.mark.parametrize("ndev,m,n,algo", [(3, 200, 150, "ring"), pytest.param(2, 260, 200, "ring", marks=_SLOW),
+                                           pytest.param(8, 200, 130, "ring", marks=_SLOW), pytest.param(2, 200, 150, "sag", marks=_SLOW)])
+def test_complex_column_split_over_rccl(rk, orc, ndev, m, n, algo):
     L, F = rk
-    with _env(DHQR_BCAST="ring"):
+    with _env(DHQR_BCAST=algo, DHQR_BCAST_SAG_MIN=1):
         h = _mg(L, ndev)
     A0 = orc.rand_matrix_c(m, n, 21)
     A, al = A0.copy(order="F"), np.zeros(n, dtype=complex)
     _stats(F)
     assert L.dhqr_mg_qr_c64(h, _ptr(A), m, n, m, _ptr(al)) == 0, L.dhqr_last_error()
     s1 = _stats(F)
-    assert s1["bcast"] == ndev * ((n + 63) // 64), s1  # one broadcast per panel on every rank
+    if algo == "ring":
+        assert s1["bcast"] == ndev * ((n + 63) // 64), s1  # one broadcast per panel on every rank
+    else:  # scatter + all-gather where the unit divides by the rank count, ncclBroadcast otherwise
+        assert s1["allgather"] > 0 and s1["bcast"] + s1["allgather"] == ndev * ((n + 63) // 64), s1
     assert s1["timeouts"] == 0 and s1["mismatches"] == 0
     Ho, ao = orc.householder_c(A0)
     scale = np.abs(Ho).max()
