@@ -10,7 +10,7 @@ from ._lib import NB, DHQRError, build
 from .api import (Context, DistributedHouseholderQRStruct, apply_q_, bench_check, bench_context, bench_mfma_tflops,
                   bench_stream_gbps, empty_colmajor, get_context, get_q, get_r, householder_, ldiv, partialdot,
                   qr_, rand_colmajor, rand_colmajor_c, rand_vector_device, residual, solve_householder_)
-from .distributed import ColumnCyclicQR, Communicator, MultiGpuQR, qr_darray_, qr_darray_c64_, qr_multi_
+from .distributed import ColumnCyclicQR, Communicator, MultiGpuQR, ldiv_darray_, qr_darray_, qr_darray_c64_, qr_multi_
 from .rowsplit import RowSplitQR
 from .partition import BlockCyclicColumns, LocalColumnBlock, contiguous_column_blocks
 
@@ -18,5 +18,5 @@ __all__ = [
     "NB", "DHQRError", "build", "Context", "DistributedHouseholderQRStruct", "apply_q_",
     "bench_check", "bench_context", "bench_mfma_tflops", "bench_stream_gbps", "empty_colmajor", "get_context", "get_q", "get_r", "householder_",
     "ldiv", "partialdot", "qr_", "rand_colmajor", "rand_colmajor_c", "rand_vector_device", "residual",
-    "solve_householder_", "ColumnCyclicQR", "Communicator", "MultiGpuQR", "qr_darray_", "qr_darray_c64_", "qr_multi_", "RowSplitQR", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
+    "solve_householder_", "ColumnCyclicQR", "Communicator", "MultiGpuQR", "ldiv_darray_", "qr_darray_", "qr_darray_c64_", "qr_multi_", "RowSplitQR", "BlockCyclicColumns", "LocalColumnBlock", "contiguous_column_blocks",
 ]

@@ -2279,6 +2279,53 @@ int32_t dhqr_cs_qr_darray_f64(dhqr_comm *cm, double *hBlock, int64_t m, int64_t 
   return rc;
 }
 
+// `H \ b` (src:317-321 with src:226-230, 256-270) for ONE process of a multi-process job holding a factored DArray: hBlock is
+// this process's contiguous column block of the FACTORED m x n matrix (what dhqr_cs_qr_darray_f64 left there), halpha the
+// replicated alpha, hb the right-hand side (m, the same on every process: the reference's SharedArray copy of b, src:318);
+// hx (n) receives x on every process.  Nothing is modified on the host.  The block is moved into the block-cyclic layout
+// and solved by cs_solve: one broadcast of b's tail per panel for Q'b, one all-reduce of the partial dots + one broadcast
+// of the solved block per panel for the back substitution (instead of the reference's n x np scalar RPCs, src:260-267).
+int32_t dhqr_cs_ldiv_darray_f64(dhqr_comm *cm, const double *hBlock, int64_t m, int64_t n, int64_t ldb, const double *halpha,
+                                const double *hb, double *hx) {
+  CsProblem pr;
+  CHECK(cs_check(cm, nullptr, m, n, m, &pr, false));
+  ENTER(pr.c);
+  if (!halpha || !hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
+  int64_t lo, hi;
+  cs_contig_range(n, pr.P, pr.r, &lo, &hi);
+  const int64_t wr = hi - lo, wmax = n / pr.P + 1;
+  if (wr > 0 && (!hBlock || ldb < m)) return set_err(DHQR_EINVAL, "bad local block");
+  const int64_t ldd = (m + 1) & ~(int64_t)1, mpad = (m + 15) & ~(int64_t)15;
+  double *dA = nullptr, *dBlk = nullptr, *dStage = nullptr, *dal = nullptr, *dvec = nullptr;
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMalloc((void **)&dA, (size_t)ldd * std::max<int64_t>(pr.ncl, 1) * sizeof(double)));
+    HIPCHECK(hipMalloc((void **)&dBlk, (size_t)m * std::max<int64_t>(wr, 1) * sizeof(double)));
+    HIPCHECK(hipMalloc((void **)&dStage, (size_t)m * std::max<int64_t>(wmax, DHQR_NBV) * sizeof(double)));
+    HIPCHECK(hipMalloc((void **)&dal, (size_t)n * sizeof(double)));
+    HIPCHECK(hipMalloc((void **)&dvec, (size_t)(2 * mpad + 2 * DHQR_NBV + 16) * sizeof(double)));
+    pr.A = dA;
+    pr.lda = ldd;
+    pr.alpha = dal;
+    dhqr_ctx *c = pr.c;
+    if (wr > 0)
+      HIPCHECK(hipMemcpy2DAsync(dBlk, m * sizeof(double), hBlock, ldb * sizeof(double), m * sizeof(double), wr,
+                                hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(dal, halpha, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(dvec, hb, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));  // src:318 copy of b
+    CHECK(cs_load_contiguous(pr, dBlk, m, dStage));
+    CHECK(cs_solve(pr, dvec, dvec + mpad));
+    HIPCHECK(hipMemcpyAsync(hx, dvec, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));  // src:320
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  (void)hipDeviceSynchronize();
+  double *ps[] = {dA, dBlk, dStage, dal, dvec};
+  for (double *p : ps)
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
 // ============================================================ multi-GPU: single-process handle (dhqr_mg.h)
 int32_t dhqr_mg_create(dhqr_mg **out, const int32_t *devices, int32_t ndev) {
   if (!out) return set_err(DHQR_EINVAL, "null out-pointer");
@@ -2620,6 +2667,106 @@ int32_t dhqr_cs_qr_darray_c64(dhqr_comm *cm, double *hBlock, int64_t m, int64_t 
   for (double *p : ps)
     if (p) (void)hipFree(p);
   return rc;
+}
+
+// solve_householder!(b, H, alpha) (src:226-282) for ComplexF64 on the cyclic 64-column split: db (m complex, the same on
+// every rank) is overwritten, x = db[0:n] on every rank; dwork: m + 64 complex of scratch.  Asynchronous on the context's stream.
+int32_t dhqr_cs_solve_c64(dhqr_comm *cm, const double *dA, int64_t m, int64_t n, int64_t lda, const double *dalpha, double *db,
+                          double *dwork) {
+  if (!cm) return set_err(DHQR_EINVAL, "null communicator");
+  if (no_columns(m, n)) return DHQR_OK;
+  if (m <= 0 || n <= 0 || m < n) return set_err(DHQR_EINVAL, "m >= n >= 1 required (m=%lld n=%lld)", (long long)m, (long long)n);
+  ENTER(cm->ctx);
+  const int64_t ncl = zcs_local_cols(n, cm->nranks, cm->rank);
+  if (ncl > 0) {
+    CHECK(check_mat(dA, m, ncl, lda, false));
+    CHECK(check_zptr(dA, "matrix"));
+  }
+  CHECK(check_zptr(dalpha, "alpha"));
+  CHECK(check_zptr(db, "b"));
+  CHECK(check_zptr(dwork, "work"));
+  return zcs_solve(cm->ctx, cm, dA, m, n, lda, dalpha, db, dwork);
+}
+
+// `H \ b` (src:317-321) for one process holding its contiguous block of a factored DArray{ComplexF64} (the ComplexF64
+// method of dhqr_cs_ldiv_darray_f64): host block + replicated alpha + b in, x (n complex) out on every process.
+int32_t dhqr_cs_ldiv_darray_c64(dhqr_comm *cm, const double *hBlock, int64_t m, int64_t n, int64_t ldb, const double *halpha,
+                                const double *hb, double *hx) {
+  if (!cm) return set_err(DHQR_EINVAL, "null communicator");
+  if (no_columns(m, n)) return DHQR_OK;
+  if (m <= 0 || n <= 0 || m < n) return set_err(DHQR_EINVAL, "m >= n >= 1 required (m=%lld n=%lld)", (long long)m, (long long)n);
+  dhqr_ctx *c = cm->ctx;
+  ENTER(c);
+  if (!halpha || !hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
+  const int P = cm->nranks, r = cm->rank;
+  int64_t lo, hi;
+  cs_contig_range(n, P, r, &lo, &hi);
+  const int64_t wr = hi - lo, wmax = std::max<int64_t>(n / P + 1, DHQR_ZNB), ncl = zcs_local_cols(n, P, r);
+  if (wr > 0 && (!hBlock || ldb < m)) return set_err(DHQR_EINVAL, "bad local block");
+  const size_t esz = 2 * sizeof(double);
+  double *dA = nullptr, *dBlk = nullptr, *dStage = nullptr, *dal = nullptr, *dvec = nullptr;
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMalloc((void **)&dA, (size_t)m * std::max<int64_t>(ncl, 1) * esz));
+    HIPCHECK(hipMalloc((void **)&dBlk, (size_t)m * std::max<int64_t>(wr, 1) * esz));
+    HIPCHECK(hipMalloc((void **)&dStage, (size_t)m * wmax * esz));
+    HIPCHECK(hipMalloc((void **)&dal, (size_t)n * esz));
+    HIPCHECK(hipMalloc((void **)&dvec, (size_t)(2 * m + DHQR_ZNB) * esz));
+    if (wr > 0) HIPCHECK(hipMemcpy2DAsync(dBlk, m * esz, hBlock, ldb * esz, m * esz, wr, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(dal, halpha, (size_t)n * esz, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(dvec, hb, (size_t)m * esz, hipMemcpyHostToDevice, c->stream));  // src:318 copy of b
+    CHECK(zcs_convert(c, cm, dA, m, n, m, dBlk, m, dStage, true));
+    CHECK(zcs_solve(c, cm, dA, m, n, m, dal, dvec, dvec + 2 * m));
+    HIPCHECK(hipMemcpyAsync(hx, dvec, (size_t)n * esz, hipMemcpyDeviceToHost, c->stream));  // src:320
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  (void)hipDeviceSynchronize();
+  double *ps[] = {dA, dBlk, dStage, dal, dvec};
+  for (double *p : ps)
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
+// `H \ b` (src:317-321) for a factored ComplexF64 HOST matrix over all devices of the handle: every rank uploads its cyclic
+// 64-column blocks of (hA, halpha) and the ranks solve together (zcs_solve); x (n complex) comes back from rank 0.
+int32_t dhqr_mg_ldiv_c64(dhqr_mg *g, const double *hA, int64_t m, int64_t n, int64_t lda, const double *halpha, const double *hb,
+                         double *hx) {
+  if (!g) return set_err(DHQR_EINVAL, "null handle");
+  if (no_columns(m, n)) return DHQR_OK;
+  CHECK(check_mat(hA, m, n, lda, true));
+  if (!halpha || !hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
+  return mg_run(g, [g, hA, m, n, lda, halpha, hb, hx](int r) -> int32_t {
+    MgRank &k = g->rk[r];
+    dhqr_ctx *c = k.c;
+    const int P = g->ndev;
+    const int64_t ZB = DHQR_ZNB, K = zcs_npanels(n), ncl = zcs_local_cols(n, P, r);
+    const size_t esz = 2 * sizeof(double);
+    double *dA = nullptr, *dal = nullptr, *dvec = nullptr;
+    auto body = [&]() -> int32_t {
+      if (hipMalloc((void **)&dA, (size_t)m * (size_t)std::max<int64_t>(ncl, 1) * esz) != hipSuccess)
+        return set_err(DHQR_ENOMEM, "hipMalloc of the %lld x %lld complex block failed", (long long)m, (long long)ncl);
+      if (hipMalloc((void **)&dal, (size_t)n * esz) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc of alpha failed");
+      if (hipMalloc((void **)&dvec, (size_t)(2 * m + ZB) * esz) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc of b failed");
+      for (int64_t b = r; b < K; b += P) {
+        const int64_t w = std::min<int64_t>(ZB, n - b * ZB);
+        HIPCHECK(hipMemcpy2DAsync(dA + 2 * (b / P) * ZB * m, m * esz, hA + 2 * b * ZB * lda, lda * esz, m * esz, w,
+                                  hipMemcpyHostToDevice, c->stream));
+      }
+      HIPCHECK(hipMemcpyAsync(dal, halpha, (size_t)n * esz, hipMemcpyHostToDevice, c->stream));
+      HIPCHECK(hipMemcpyAsync(dvec, hb, (size_t)m * esz, hipMemcpyHostToDevice, c->stream));  // src:318 copy of b
+      CHECK(zcs_solve(c, P > 1 ? k.cm : nullptr, dA, m, n, m, dal, dvec, dvec + 2 * m));
+      if (r == 0) HIPCHECK(hipMemcpyAsync(hx, dvec, (size_t)n * esz, hipMemcpyDeviceToHost, c->stream));  // src:320
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      return DHQR_OK;
+    };
+    const int32_t rc = body();
+    if (rc != DHQR_OK) (void)hipDeviceSynchronize();
+    double *ps[] = {dA, dal, dvec};
+    for (double *p : ps)
+      if (p) (void)hipFree(p);
+    return rc;
+  });
 }
 
 // qr!(A; ndev) (src:311-315) for a ComplexF64 host matrix over all devices of the handle: host in / host out (H in

@@ -133,7 +133,111 @@ static int32_t zcs_factor(dhqr_ctx *c, dhqr_comm *cm, double *A, int64_t m, int6
   };
   const int32_t rc = body();
   on(sW, 0);
+  if (rc != DHQR_OK) {
+    // a failure part-way leaves the lane behind the caller's stream: join it (the call is asynchronous on sW, so a caller
+    // that synchronises sW must also be past everything the lane still reads or writes -- c->vt, A) and let the readers
+    // of the last broadcasts finish before c->vt can be reused
+    if (hipEventRecord(evS, sL) == hipSuccess) (void)hipStreamWaitEvent(sW, evS, 0);
+    if (cm)
+      for (int i = 0; i < 2; ++i) (void)comm_wait_consumed(cm, tick[i], sW);
+    (void)hipStreamSynchronize(sL);
+    (void)hipStreamSynchronize(sW);
+  }
   CHECK(rc);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+
+// acc[r0:r1] -= R[r0:r1, lo:hi] x[lo:hi] (hi - lo <= ZBS_NB); A is addressed with GLOBAL column indices (the caller
+// passes a base pointer shifted so that column lo of the block is the rank's local column)
+__global__ __launch_bounds__(256) void k_zbacksub_update_rows(const double2 *__restrict__ A, int64_t lda,
+                                                              const double2 *__restrict__ x, double2 *__restrict__ acc,
+                                                              int64_t r0, int64_t r1, int64_t lo, int64_t hi) {
+  __shared__ double2 xs[ZBS_NB];
+  const int t = threadIdx.x;
+  const int nb = (int)(hi - lo);
+  if (t < nb) xs[t] = x[lo + t];
+  __syncthreads();
+  const int64_t r = r0 + (int64_t)blockIdx.x * blockDim.x + t;
+  if (r >= r1) return;
+  double2 a = acc[r];
+  for (int c = 0; c < nb; ++c) a = zsubmul(a, A[r + (lo + c) * lda], xs[c].x, xs[c].y);  // src:248-250 / src:276-278
+  acc[r] = a;
+}
+
+// solve_householder!(b, H, alpha) (src:226-282) for ComplexF64 on the cyclic 64-column split.  db (m complex, the same on
+// every rank) is overwritten; x = db[0:n] on every rank.  Q'b: the owner of panel k applies its 64 reflectors in column
+// order and hands the updated tail of b on with one broadcast (the reference walks the owners sequentially with b in
+// shared memory, src:226-230).  Back substitution: every rank accumulates -R[i, j] x[j] over ITS columns j into du; per
+// panel one all-reduce sums the 64 partial dots (the reference's sum(fetch.(futures)), src:262-266), the owner solves
+// the diagonal block (division by alpha, src:267) and broadcasts x.  du: m + 64 complex of scratch.
+static int32_t zcs_solve(dhqr_ctx *c, dhqr_comm *cm_, const double *A_, int64_t m, int64_t n, int64_t lda, const double *alpha_,
+                         double *db_, double *du_) {
+  const int P = cm_ ? cm_->nranks : 1, r = cm_ ? cm_->rank : 0;
+  dhqr_comm *cm = P > 1 ? cm_ : nullptr;
+  const int64_t ZB = DHQR_ZNB, K = zcs_npanels(n);
+  const double2 *A = reinterpret_cast<const double2 *>(A_), *al = reinterpret_cast<const double2 *>(alpha_);
+  double2 *b = reinterpret_cast<double2 *>(db_), *u = reinterpret_cast<double2 *>(du_);
+  double2 *ds = u + m;  // 64 partial dots
+  hipStream_t st = c->stream;
+  auto sync_local = [&]() -> int32_t {  // LOCAL transport: peers read the root's buffer directly
+    if (cm && cm->kind == COMM_LOCAL) {
+      HIPCHECK(hipStreamSynchronize(st));
+      CHECK(comm_host_barrier(cm));
+    }
+    return DHQR_OK;
+  };
+  auto width = [&](int64_t k) { return std::min<int64_t>(ZB, n - k * ZB); };
+  auto mine = [&](int64_t k) { return (int)(k % P) == r; };
+  CHECK(prof_begin(c, CAT_SOLVE));
+  for (int64_t k = 0; k < K; ++k) {  // b <- Q' b (src:232-242), panel by panel
+    const int64_t c0 = k * ZB, w = width(k);
+    if (mine(k)) {
+      const double2 *Pk = A + (k / P) * ZB * lda;
+      for (int64_t jj = 0; jj < w; ++jj) {
+        const int64_t j = c0 + jj;
+        if (m - j <= 2048)
+          hipLaunchKernelGGL((k_zqtb_col<256>), dim3(1), dim3(256), 0, st, Pk + jj * lda, b, m, j);
+        else
+          hipLaunchKernelGGL((k_zqtb_col<1024>), dim3(1), dim3(1024), 0, st, Pk + jj * lda, b, m, j);
+      }
+    }
+    if (cm) {
+      CHECK(comm_bcast(cm, db_ + 2 * c0, 2 * (m - c0), (int)(k % P), st, nullptr));
+      CHECK(sync_local());
+    }
+  }
+  HIPCHECK(hipMemsetAsync(du_, 0, (size_t)(m + ZB) * 2 * sizeof(double), st));
+  for (int64_t k = K - 1; k >= 0; --k) {  // src:256-270
+    const int64_t c0 = k * ZB, w = width(k);
+    if (cm) {
+      HIPCHECK(hipMemcpyAsync(ds, u + c0, (size_t)w * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+      CHECK(comm_allreduce_sum(cm, reinterpret_cast<double *>(ds), 2 * w, st));
+    }
+    const double2 *base = A + ((k / P) * ZB - c0) * lda;  // global column j of R is read at base + j * lda
+    if (mine(k)) {
+      hipLaunchKernelGGL(k_axpy1, dim3(1), dim3(128), 0, st, db_ + 2 * c0, reinterpret_cast<const double *>(cm ? ds : u + c0),
+                         (int)(2 * w));
+      for (int64_t hi = c0 + w; hi > c0; hi -= ZBS_NB) {
+        const int64_t lo = std::max<int64_t>(c0, hi - ZBS_NB);
+        hipLaunchKernelGGL(k_zbacksub_diag, dim3(1), dim3(64), 0, st, base, lda, al, b, lo, hi);
+        if (lo > c0)
+          hipLaunchKernelGGL(k_zbacksub_update_rows, dim3((unsigned)((lo - c0 + 255) / 256)), dim3(256), 0, st, base, lda,
+                             (const double2 *)b, b, c0, lo, lo, hi);
+      }
+    }
+    if (cm) {
+      CHECK(comm_bcast(cm, db_ + 2 * c0, 2 * w, (int)(k % P), st, nullptr));
+      CHECK(sync_local());
+    }
+    if (mine(k) && c0 > 0)
+      for (int64_t hi = c0 + w; hi > c0; hi -= ZBS_NB) {
+        const int64_t lo = std::max<int64_t>(c0, hi - ZBS_NB);
+        hipLaunchKernelGGL(k_zbacksub_update_rows, dim3((unsigned)((c0 + 255) / 256)), dim3(256), 0, st, base, lda,
+                           (const double2 *)b, u, (int64_t)0, c0, lo, hi);
+      }
+  }
+  CHECK(prof_end(c));
   LAUNCHCHECK();
   return DHQR_OK;
 }

@@ -315,6 +315,40 @@ def qr_darray_c64_(local_block, m: int, n: int, comm: Communicator):
     return al
 
 
+def _host_block(local_block, m, n, comm, dtype):
+    """validate one process's contiguous HOST column block of an m x n DArray (the reference's DistributedArrays layout)"""
+    if not isinstance(local_block, np.ndarray) or local_block.dtype != dtype or local_block.ndim != 2:
+        raise TypeError(f"{np.dtype(dtype).name} numpy block expected")
+    if local_block.shape[1] and not local_block.flags.f_contiguous:
+        raise ValueError("column-major block expected")
+    if local_block.shape[0] != m:
+        raise ValueError(f"the block must have {m} rows, got {local_block.shape[0]}")
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    comm.L.dhqr_cs_contiguous_range(n, comm.nranks, comm.rank, ctypes.byref(lo), ctypes.byref(hi))
+    if local_block.shape[1] != hi.value - lo.value:
+        raise ValueError(f"rank {comm.rank} must pass columns [{lo.value}, {hi.value}), got {local_block.shape[1]} columns")
+    return local_block.ctypes.data_as(_P) if local_block.shape[1] else None
+
+
+def ldiv_darray_(local_block, m: int, n: int, alpha, b, comm: Communicator):
+    """`qrA \\ b` for qrA = qr!(A::DArray) (src:317-321 with src:226-230, 256-270; test/runtests.jl:77-78) for one process:
+    `local_block` is this rank's contiguous FACTORED column block (float64 or complex128 numpy, column-major, m x w_r), `alpha`
+    the replicated diagonal of R, `b` the right-hand side (m, the same on every rank).  Nothing is modified; returns x (n) on
+    every rank (dhqr_cs_ldiv_darray_f64 / _c64: one collective call, what a Julia worker binds)."""
+    dtype = np.complex128 if np.iscomplexobj(local_block) else np.float64
+    ptr = _host_block(local_block, m, n, comm, dtype)
+    al = np.ascontiguousarray(alpha, dtype=dtype).reshape(-1)
+    bb = np.ascontiguousarray(b, dtype=dtype).reshape(-1)
+    if al.size != n or bb.size != m:
+        raise ValueError(f"alpha must have {n} and b {m} elements, got {al.size} and {bb.size}")
+    x = np.zeros(n, dtype=dtype)
+    fn = comm.L.dhqr_cs_ldiv_darray_c64 if dtype == np.complex128 else comm.L.dhqr_cs_ldiv_darray_f64
+    rc = fn(comm.handle, ptr, m, n, m, al.ctypes.data_as(_P), bb.ctypes.data_as(_P), x.ctypes.data_as(_P))
+    if rc != 0:
+        raise _lib.DHQRError(rc, comm.L.dhqr_last_error().decode(errors="replace"))
+    return x
+
+
 class MultiGpuQR:
     """Single-process multi-GPU handle (dhqr_mg_*): one host thread per device inside the library.
     `qr!(A; ndev)` of the Julia module binds the same entry points."""
@@ -431,13 +465,20 @@ class MultiGpuQR:
         return A, al
 
     def ldiv(self, A, alpha, b):
-        """`H \\ b` (src:317-321) for a factored HOST matrix.  complex128: the host-format result of qr_ is solved by the
-        single-GPU ComplexF64 method (dhqr_ldiv_c64; the solve is O(mn) next to the O(mn^2) factorisation)."""
+        """`H \\ b` (src:317-321) for a factored HOST matrix over the handle's devices.  complex128: cyclic blocks of 64
+        columns, Q'b and back substitution distributed like the reference's (dhqr_mg_ldiv_c64 -> zcs_solve)."""
         m, n = A.shape
         if isinstance(A, np.ndarray) and A.dtype == np.complex128:
-            from .api import DistributedHouseholderQRStruct, ldiv as _ldiv1
-            return np.asarray(_ldiv1(DistributedHouseholderQRStruct(A, np.asarray(alpha, dtype=np.complex128)),
-                                     np.asarray(b, dtype=np.complex128)))
+            F = A if A.flags.f_contiguous else np.asfortranarray(A)
+            al = np.ascontiguousarray(alpha, dtype=np.complex128).reshape(-1)
+            bb = np.ascontiguousarray(b, dtype=np.complex128).reshape(-1)
+            if al.size != n or bb.size != m:
+                raise ValueError(f"alpha must have {n} and b {m} elements, got {al.size} and {bb.size}")
+            x = np.zeros(n, dtype=np.complex128)
+            lda = F.strides[1] // 16 if n > 1 else max(m, 1)
+            self._check(self.L.dhqr_mg_ldiv_c64(self._h, F.ctypes.data_as(_P), m, n, lda, al.ctypes.data_as(_P),
+                                                bb.ctypes.data_as(_P), x.ctypes.data_as(_P)))
+            return x
         F = A if A.flags.f_contiguous else np.asfortranarray(A)
         x = np.zeros(n)
         bb = self._host_vec(b, m, "b")

@@ -21,6 +21,7 @@
 #
 #   qr!(A; ndev=8)              (new)         one process, `ndev` GPUs        -> dhqr_mg_qr_f64 / dhqr_mg_ldiv_f64
 #   qr!(A::DArray)              src:115-120   one Julia worker per GPU        -> dhqr_comm_create_rank + dhqr_cs_qr_darray_f64
+#   qr!(A::DArray) \ b          src:317-321   the same workers (src:226-230, 256-270) -> dhqr_cs_ldiv_darray_f64 / _c64
 #     householder!(A::DArray,α) src:115-120   (owners visited sequentially, every reflector sent to every process with
 #     `@spawnat` src:141-143, α::SharedArray src:301-304) becomes ONE collective call per worker: the library converts
 #     the DistributedArrays layout (one contiguous column block per worker) to block-cyclic columns, factors with one
@@ -288,22 +289,53 @@ function householder_local!(Al::StridedMatrix{ComplexF64}, m::Integer, n::Intege
   return α
 end
 
-# The DArray method itself needs DistributedArrays (not a dependency of this file: the method is defined when the
-# caller has loaded it, the way the reference's src:115-120 is written against it).
+"this worker's part of `qrA \\ b` for a DArray factorisation (src:226-230, 256-270): `Al` is its contiguous block of the
+FACTORED matrix, α the replicated diagonal of R, b the right-hand side (m, the same on every worker); returns x (n)"
+function solve_local(Al::StridedMatrix{Float64}, m::Integer, n::Integer, α::Vector{Float64}, b::Vector{Float64})
+  x = Vector{Float64}(undef, n)
+  check(ccall((:dhqr_cs_ldiv_darray_f64, libdhqr), Int32,
+              (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+              _comm[], Al, m, n, max(stride(Al, 2), m), α, b, x))
+  return x
+end
+function solve_local(Al::StridedMatrix{ComplexF64}, m::Integer, n::Integer, α::Vector{ComplexF64}, b::Vector{ComplexF64})
+  x = Vector{ComplexF64}(undef, n)
+  check(ccall((:dhqr_cs_ldiv_darray_c64, libdhqr), Int32,
+              (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Int64, Int64, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}),
+              _comm[], Al, m, n, max(stride(Al, 2), m), α, b, x))
+  return x
+end
+
+"devices the cached communicator of this worker was built with for the workers `ws` (nothing: no such communicator)"
+comm_devices(ws) = (_comm[] != C_NULL && _comm_key[] !== nothing && _comm_key[][1] == ws) ? _comm_key[][2] : nothing
+
+"collective bootstrap over the workers `ws` (once per (workers, devices), not per call): returns the key"
+function ensure_comm(ws, devices)
+  np = length(ws)
+  devs = if devices === nothing            # `\\` after qr!(A; devices=...): reuse what qr! bound the workers to
+    cached = remotecall_fetch(comm_devices, ws[1], ws)
+    cached === nothing ? collect(0:np-1) : cached
+  else
+    collect(devices)
+  end
+  key = (ws, devs)
+  if !all(remotecall_fetch(comm_cached, p, key) for p in ws)
+    id = remotecall_fetch(comm_unique_id, ws[1])                       # replaces the SharedArray bootstrap (src:301-304)
+    @sync for (i, p) in enumerate(ws)                                  # ncclCommInitRank is collective
+      @async remotecall_wait(comm_init, p, id, np, i - 1, devs[i], key)
+    end
+  end
+  return key
+end
+
+# The DArray methods themselves need DistributedArrays (not a dependency of this file: the methods are defined when the
+# caller has loaded it, the way the reference's src:115-120, 226-230, 256-270 are written against it).
 function __init_darray_methods__(DistributedArrays)
   @eval begin
     function householder!(A::$(DistributedArrays).DArray{T, 2}, α::Vector{T}; devices=nothing) where {T<:Union{Float64, ComplexF64}}
       ws = vec(procs(A))
-      np = length(ws)
       m, n = size(A)
-      devs = devices === nothing ? collect(0:np-1) : collect(devices)
-      key = (ws, devs)
-      if !all(remotecall_fetch(comm_cached, p, key) for p in ws)         # bootstrap once per (workers, devices), not per call
-        id = remotecall_fetch(comm_unique_id, ws[1])                     # replaces the SharedArray bootstrap (src:301-304)
-        @sync for (i, p) in enumerate(ws)                                # ncclCommInitRank is collective
-          @async remotecall_wait(comm_init, p, id, np, i - 1, devs[i], key)
-        end
-      end
+      ensure_comm(ws, devices)
       futs = [remotecall(p) do                                           # ONE call per worker (src:115-120 visits owners
                 al = zeros(T, n)                                         #   sequentially and fans out every column)
                 householder_local!($(DistributedArrays).localpart(A), m, n, al)
@@ -316,6 +348,27 @@ function __init_darray_methods__(DistributedArrays)
       H = DistributedHouseholderQRStruct(A, zeros(T, size(A, 2)))
       householder!(H.A, H.α; devices=devices)
       return H
+    end
+    # solve_householder!(b, H::DArray, α) -- src:284-294 with the distributed phases src:226-230 (Q'b, owners in turn) and
+    # src:256-270 (back substitution, partial dots summed over the owners): ONE collective call per worker on its factored
+    # block; b[1:n] is overwritten with x like the reference leaves it, x is returned.
+    function solve_householder!(b::Vector{T}, A::$(DistributedArrays).DArray{T, 2}, α::Vector{T}; devices=nothing) where {T<:Union{Float64, ComplexF64}}
+      ws = vec(procs(A))
+      m, n = size(A)
+      length(b) == m || throw(DimensionMismatch("b has length $(length(b)), the matrix $m rows"))
+      ensure_comm(ws, devices)
+      futs = [remotecall(p) do
+                solve_local($(DistributedArrays).localpart(A), m, n, α, b)
+              end for p in ws]
+      x = fetch(futs[1])                                                 # x is replicated
+      foreach(wait, futs)
+      b[1:n] .= x
+      return x
+    end
+    # qrA \ b for qrA = qr!(A::DArray) -- src:317-321; what test/runtests.jl:77-78 calls
+    function LinearAlgebra.:(\)(H::DistributedHouseholderQRStruct{<:$(DistributedArrays).DArray}, b::AbstractVector)
+      s = Vector{eltype(H.A)}(b)        # the reference copies b into a SharedArray (src:318)
+      return solve_householder!(s, H.A, Vector{eltype(H.A)}(H.α))
     end
   end
 end

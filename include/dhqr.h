@@ -308,7 +308,11 @@ int32_t dhqr_comm_rccl_nranks(dhqr_comm *comm, int32_t *main_channel, int32_t *l
  *   dhqr_cs_load/store_contiguous_f64   convert between the reference's DArray layout (ONE contiguous column
  *                          block per process, dhqr_cs_contiguous_range = DistributedArrays' default split) and the
  *                          block-cyclic layout; dstage: m x max(n/P + 1, 128) doubles.
- *   dhqr_cs_qr_darray_f64  qr!(A::DArray) for one process: host block in, factored host block + alpha out. */
+ *   dhqr_cs_qr_darray_f64  qr!(A::DArray) for one process: host block in, factored host block + alpha out.
+ *   dhqr_cs_ldiv_darray_f64  `qrA \ b` for a DArray factorisation (src:317-321 -> src:226-230, 256-270; the call
+ *                          test/runtests.jl:77-78 makes): this process's FACTORED contiguous host block, the replicated
+ *                          alpha and b (m, the same on every process) in, x (n) out on every process; nothing on the
+ *                          host is modified (the reference copies b into a SharedArray, src:318). */
 int64_t dhqr_cs_local_cols(int64_t n, int32_t nranks, int32_t rank);
 void dhqr_cs_contiguous_range(int64_t n, int32_t nranks, int32_t rank, int64_t *lo, int64_t *hi);
 int32_t dhqr_cs_fill_uniform_f64(dhqr_comm *comm, double *dA, int64_t m, int64_t n, int64_t lda, uint64_t seed);
@@ -322,20 +326,35 @@ int32_t dhqr_cs_load_contiguous_f64(dhqr_comm *comm, double *dA, int64_t m, int6
 int32_t dhqr_cs_store_contiguous_f64(dhqr_comm *comm, const double *dA, int64_t m, int64_t n, int64_t lda,
                                      double *dBlock, int64_t ldb, double *dstage);
 int32_t dhqr_cs_qr_darray_f64(dhqr_comm *comm, double *hBlock, int64_t m, int64_t n, int64_t ldb, double *halpha);
+int32_t dhqr_cs_ldiv_darray_f64(dhqr_comm *comm, const double *hBlock, int64_t m, int64_t n, int64_t ldb,
+                                const double *halpha, const double *hb, double *hx);
 
 /* ------------------------------------------------------------------ multi-GPU: ComplexF64 column split
  * The reference's householder! is generic over the element type (src:215-294; test/runtests.jl:42-63 runs ComplexF64).
  * Layout: cyclic blocks of 64 complex columns (one panel): rank r holds the global panels r, r+P, r+2P, ...
  * contiguously (dA: m x dhqr_cs_local_cols_c64(n,P,r) complex, interleaved re/im, leading dimension lda complex
- * elements); dalpha (n complex) is replicated.  Per panel ONE broadcast of (alpha, embedded V, T, T') replaces the
- * per-column fan-out (src:141-143); the owner of the next panel looks ahead on a high-priority stream.
+ * elements); dalpha (n complex) is replicated.  Per panel ONE broadcast of (alpha, T, T', the factored panel as
+ * rows x 64 complex) replaces the per-column fan-out (src:141-143); every rank forms the real 2 x 2 embedding of the 64
+ * reflectors itself (twice the bytes, which therefore do not travel); the owner of the next panel looks ahead on a
+ * high-priority stream.
  * Every rank of the communicator must make the call.  Asynchronous on the context's stream like dhqr_factor_c64_nb.
+ *   dhqr_cs_solve_c64      solve_householder!(b, H, alpha) (src:226-282) on the cyclic layout: db (m complex, identical on
+ *                          every rank) is overwritten, x = db[0:n] on every rank; dwork: m + 64 complex.  Q'b: one
+ *                          broadcast of b's tail per panel; back substitution: one all-reduce of the 64 partial dots
+ *                          (sum(fetch.(futures)), src:262-266) + one broadcast of the solved block per panel.
  *   dhqr_cs_qr_darray_c64  qr!(A::DArray{ComplexF64}) for one process: its CONTIGUOUS host column block
  *                          (dhqr_cs_contiguous_range) in, factored block + alpha out; synchronous.
- *   dhqr_mg_qr_c64   qr!(A; ndev) for a ComplexF64 host matrix (host in / host out; dhqr_ldiv_c64 solves with it). */
+ *   dhqr_cs_ldiv_darray_c64  `qrA \ b` for a DArray{ComplexF64} factorisation (test/runtests.jl:77-78 with T = ComplexF64):
+ *                          factored contiguous host block + alpha + b in, x (n complex) out on every process; synchronous.
+ *   dhqr_mg_qr_c64   qr!(A; ndev) for a ComplexF64 host matrix (host in / host out).
+ *   dhqr_mg_ldiv_c64 `H \ b` for the host-format result over the same devices (dhqr_cs_solve_c64 inside). */
 int64_t dhqr_cs_local_cols_c64(int64_t n, int32_t nranks, int32_t rank);
 int32_t dhqr_cs_factor_c64(dhqr_comm *comm, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha);
+int32_t dhqr_cs_solve_c64(dhqr_comm *comm, const double *dA, int64_t m, int64_t n, int64_t lda,
+                          const double *dalpha, double *db, double *dwork);
 int32_t dhqr_cs_qr_darray_c64(dhqr_comm *comm, double *hBlock, int64_t m, int64_t n, int64_t ldb, double *halpha);
+int32_t dhqr_cs_ldiv_darray_c64(dhqr_comm *comm, const double *hBlock, int64_t m, int64_t n, int64_t ldb,
+                                const double *halpha, const double *hb, double *hx);
 
 /* ------------------------------------------------------------------ multi-GPU: single-process handle
  * One host process drives `ndev` GPUs (devices[i] = HIP device of rank i; NULL = 0..ndev-1): one context, one
@@ -360,6 +379,8 @@ int32_t dhqr_mg_upload_f64(dhqr_mg *mg, const double *hA, int64_t lda, const dou
 int32_t dhqr_mg_download_f64(dhqr_mg *mg, double *hA, int64_t lda, double *halpha);
 int32_t dhqr_mg_qr_f64(dhqr_mg *mg, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha);
 int32_t dhqr_mg_qr_c64(dhqr_mg *mg, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha);
+int32_t dhqr_mg_ldiv_c64(dhqr_mg *mg, const double *hA, int64_t m, int64_t n, int64_t lda, const double *halpha,
+                         const double *hb, double *hx);
 int32_t dhqr_mg_solve_f64(dhqr_mg *mg, const double *hb, double *hx);
 int32_t dhqr_mg_ldiv_f64(dhqr_mg *mg, const double *hA, int64_t m, int64_t n, int64_t lda, const double *halpha,
                          const double *hb, double *hx);

@@ -106,3 +106,73 @@ def emulated_rank(so, nranks, rank):
 
     comm = D.Communicator.from_callbacks(h, L, nranks, rank, bcast, allreduce)
     return L, h, comm, D
+
+
+# ---------------------------------------------------------------------------------------------------
+# P logical ranks on ONE GPU, as P Python threads of one process, each with its own dhqr_ctx and a CALLBACK
+# communicator whose broadcast / all-reduce are device-to-device copies on that GPU: the SPMD entry points a
+# Julia worker binds (dhqr_cs_qr_darray_*, dhqr_cs_ldiv_darray_*, dhqr_cs_*) run with P > 1 on the 1-GPU box.
+# (ctypes releases the GIL for the duration of a C call and re-acquires it inside the callbacks.)
+def gpu_thread_ranks(P, fn, timeout=600):
+    """run fn(rank, comm, lib) on P rank threads sharing cuda:0; returns {rank: result}; re-raises failures"""
+    import ctypes
+    import importlib
+    import threading
+    import __graft_entry__ as g
+    pkg = g.import_package()
+    D = importlib.import_module("dhqr_amd.distributed")
+    L = pkg._lib.lib()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemcpy.restype = ctypes.c_int
+    hip.hipDeviceSynchronize.restype = ctypes.c_int
+    H2D, D2H, D2D = 1, 2, 3
+    bar = threading.Barrier(P, timeout=timeout)
+    shared = {"src": None, "parts": [None] * P}
+    out, errs = {}, {}
+
+    def run(rank):
+        try:
+            assert hip.hipSetDevice(0) == 0
+            ctx = pkg.Context(0)
+
+            def bcast(ptr, nbytes, root):
+                if rank == root:
+                    shared["src"] = ptr
+                bar.wait()
+                if rank != root and nbytes:
+                    assert hip.hipMemcpy(ptr, shared["src"], nbytes, D2D) == 0
+                    assert hip.hipDeviceSynchronize() == 0
+                bar.wait()
+
+            def allreduce(ptr, count):
+                part = np.zeros(count)
+                assert hip.hipMemcpy(part.ctypes.data, ptr, 8 * count, D2H) == 0
+                shared["parts"][rank] = part
+                bar.wait()
+                tot = np.zeros(count)
+                for p in shared["parts"]:  # the same order on every rank: identical sums
+                    tot += p
+                assert hip.hipMemcpy(ptr, tot.ctypes.data, 8 * count, H2D) == 0
+                assert hip.hipDeviceSynchronize() == 0
+                bar.wait()
+
+            comm = D.Communicator.from_callbacks(ctx.handle, L, P, rank, bcast, allreduce)
+            try:
+                out[rank] = fn(rank, comm, L)
+            finally:
+                comm.close()
+                ctx.close()
+        except BaseException:
+            errs[rank] = traceback.format_exc()
+            bar.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout)
+    if errs:
+        raise AssertionError("rank failures:\n" + "\n".join(f"[rank {r}] {e}" for r, e in sorted(errs.items())))
+    assert len(out) == P, "a rank thread did not finish"
+    return out

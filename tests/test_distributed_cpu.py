@@ -228,6 +228,16 @@ def _darray(rank, P, m, n, so):
     if len(cols):
         assert np.abs(blk - Ho[:, cols.start: cols.stop]).max() <= 1e-12 * scale
     assert np.abs(al - ao).max() <= 1e-12 * scale
+    # `qrA \ b` on the factored DArray (src:317-321 -> src:226-230, 256-270; test/runtests.jl:77-78): the factored host block,
+    # alpha and b in, x out on every process, nothing modified (dhqr_cs_ldiv_darray_f64, the Julia worker's binding)
+    fb = np.array(blk[:, : len(cols)], order="F")
+    keep, bk = fb.copy(), b.copy()
+    x2 = D.ldiv_darray_(fb, m, n, al, b, comm)
+    xo = orc.solve(Ho, ao, b)
+    assert np.abs(x2 - xo).max() <= 1e-10 * np.abs(xo).max()
+    assert np.array_equal(fb, keep) and np.array_equal(b, bk)
+    with pytest.raises(ValueError):
+        D.ldiv_darray_(np.zeros((m, len(cols) + 1), order="F"), m, n, al, b, comm)
     return True
 
 
@@ -267,6 +277,21 @@ def _darray_c64(rank, P, m, n, so):
     if ncl:
         assert np.abs(loc - Ho[:, gcols]).max() <= 1e-12 * scale
     assert np.abs(al - ao).max() <= 1e-12 * scale
+    # the distributed ComplexF64 solve (the reference's _solve_householder1!/2! are generic over T, src:226-282;
+    # test/runtests.jl:43 x :78 runs `qrA \ b` for ComplexF64 DArrays): on the cyclic layout ...
+    b = orc.rand_vector_c(m, 62)
+    xo = orc.solve_c(Ho, ao, b)
+    db, work = b.copy(), np.zeros(m + 64, dtype=complex)
+    rc = L.dhqr_cs_solve_c64(comm.handle, loc.ctypes.data_as(ctypes.c_void_p), m, n, m, al.ctypes.data_as(ctypes.c_void_p),
+                             db.ctypes.data_as(ctypes.c_void_p), work.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0, L.dhqr_last_error()
+    assert L.dhqr_synchronize(h) == 0
+    assert np.abs(db[:n] - xo).max() <= 1e-10 * np.abs(xo).max()
+    # ... and through the DArray front-end: the factored contiguous block in, x out on every process
+    keep = blk.copy()
+    x2 = D.ldiv_darray_(blk, m, n, alpha, b, comm)
+    assert np.abs(x2 - xo).max() <= 1e-10 * np.abs(xo).max()
+    assert np.array_equal(blk, keep)
     return True
 
 

@@ -95,68 +95,91 @@ def test_device_path_vs_oracle(pkg, orc, m, n):
     assert np.abs(x.cpu().numpy() - xo).max() <= 1e-11 * max(1.0, np.linalg.cond(A0)) * np.abs(xo).max()
 
 
-def _single_draw_ratio(pkg, orc, m, n, seed, nb):
-    """the reference's own statistic (test/runtests.jl:49-62), one draw, evaluated in double exactly as written there:
-    norm(A' * A * x2 .- A' * b) / norm(A' * A * x1 .- A' * b) with x1 from LAPACK's QR"""
+_ORACLE_STAT = {}  # (m, n, seed) -> (stdliberr, oracle_err): one O(m n^2) oracle run per draw, shared by the tests below
+
+
+def _normal_residual(A, x, b):
+    """the reference's statistic as written, in double: norm(A' * A * x .- A' * b) (test/runtests.jl:51,62)"""
+    Ah = A.conj().T
+    return float(np.linalg.norm(Ah @ (A @ x) - Ah @ b))
+
+
+def _draw(orc, m, n, seed, with_oracle):
+    """(A, b, stdliberr, oracle_err): x1 from LAPACK's QR as in test/runtests.jl:49; oracle_err = the same statistic for
+    the ORACLE's x (the reference's algorithm restated on the CPU) -- what the reference itself would score on this draw"""
     A = orc.rand_matrix_c(m, n, seed)
     b = orc.rand_vector_c(m, seed + 1)
-    q, r = np.linalg.qr(A)
-    x1 = sl.solve_triangular(r, q.conj().T @ b)
-    Ah = A.conj().T
-    stdliberr = np.linalg.norm(Ah @ (A @ x1) - Ah @ b)
+    key = (m, n, seed)
+    if key not in _ORACLE_STAT or (with_oracle and _ORACLE_STAT[key][1] is None):
+        q, r = np.linalg.qr(A)
+        x1 = sl.solve_triangular(r, q.conj().T @ b)
+        stdliberr = _normal_residual(A, x1, b)
+        oerr = None
+        if with_oracle:
+            Ho, ao = orc.householder_c(A.copy(order="F"))
+            oerr = _normal_residual(A, orc.solve_c(Ho, ao, b), b)
+        _ORACLE_STAT[key] = (stdliberr, oerr)
+    return (A, b) + _ORACLE_STAT[key]
+
+
+def _gpu_statistic(pkg, A, b, nb):
     H = pkg.qr_(A.copy(order="F"), nb=nb)
-    x2 = np.asarray(pkg.ldiv(H, b))
-    return np.linalg.norm(Ah @ (A @ x2) - Ah @ b) / stdliberr
+    return _normal_residual(A, np.asarray(pkg.ldiv(H, b)), b)
+
+
+def _check_against_reference_bound(pkg, orc, m, n, seed, nb):
+    """test/runtests.jl:62 for one draw, residuals in double as written there.  The bound `< 8 stdliberr` divides by LAPACK's
+    residual, which on the two largest shapes moves by 10 x from draw to draw (5.5e-11 ... 5.6e-10 at 4400 x 4000) while
+    the reference's own residual -- the ORACLE's, the algorithm restated on the CPU -- stays at 4e-10 ... 9e-10: the
+    restated reference itself scores 8.8 (seed 0) and 15.6 (seed 8) on the draws used here
+    (profiles/r04_c64_oracle_ratio_cpu_container.json).  So: the literal bound wherever the restated reference meets it
+    with a margin of 2, and never more than 2 x the reference's own statistic on the same draw."""
+    big = n >= 2000
+    A, b, stdliberr, oerr = _draw(orc, m, n, seed, with_oracle=big)
+    ratio = _gpu_statistic(pkg, A, b, nb) / stdliberr
+    if not big:
+        print(f"{m}x{n} seed {seed} nb={nb}: ratio {ratio:.2f} (reference bound 8)")
+        assert ratio < 8, ratio
+        return ratio, None
+    oratio = oerr / stdliberr
+    print(f"{m}x{n} seed {seed} nb={nb}: GPU ratio {ratio:.2f}, restated reference (oracle) ratio {oratio:.2f} (bound 8)")
+    assert ratio < max(8.0, 2.0 * oratio), (ratio, oratio)
+    if oratio < 4.0:
+        assert ratio < 8, (ratio, oratio)
+    return ratio, oratio
 
 
 @pytest.mark.parametrize("m,n", REF_SHAPES)
 def test_reference_single_draw_seed0_default_path(pkg, orc, m, n):
     """test/runtests.jl:62 LITERALLY: one draw (seed 0), residuals in double, `< 8 stdliberr`, for the path qr_(A) takes
-    by default (nb=None: blocked from n >= 256).  Shapes below 2000 columns pass with a wide margin and are asserted.  On
-    the two largest shapes the statistic is a ratio of two rounding-noise norms whose value moves between 4 and 17 with the
-    summation order of ANY step (the oracle's own restatement of the reference lands between 2.3 and 3.8 at 1100 x 1000 from
-    the order of one dot product): recorded as xfail(strict=False), so the report shows which draws
-    miss instead of hiding them behind a median."""
-    ratio = _single_draw_ratio(pkg, orc, m, n, 0, None)
-    print(f"single draw, seed 0, default path, {m}x{n}: ratio {ratio:.2f} (reference bound 8)")
-    if n >= 2000 and not ratio < 8:
-        pytest.xfail(f"single-draw ratio {ratio:.2f} >= 8 at {m}x{n} (noise-dominated statistic; median test below)")
-    assert ratio < 8, ratio
+    by default (nb=None: blocked from n >= 256); on the two largest shapes with the restated reference's own score beside
+    it (see _check_against_reference_bound)."""
+    _check_against_reference_bound(pkg, orc, m, n, 0, None)
 
 
 @pytest.mark.parametrize("seed", [0, 2, 4, 6, 8])
 @pytest.mark.parametrize("nb", [0, 64])
 def test_reference_single_draws_largest_shape_recorded(pkg, orc, seed, nb):
-    """every draw of the multi-seed tests below as its own literal `< 8` check on the reference's largest shape: xfail
-    (strict=False) when a draw misses, so the record lists the misses per seed and path"""
-    ratio = _single_draw_ratio(pkg, orc, 4400, 4000, seed, nb)
-    print(f"single draw, seed {seed}, nb={nb}, 4400x4000: ratio {ratio:.2f}")
+    """every draw of the reference's largest shape as its own check, both paths (nb = 0: the reference's operation order;
+    nb = 64: blocked).  A draw on which the GPU path misses the literal `< 8` is recorded as xfail(strict=False) WITH the
+    restated reference's score on the same draw -- the record shows whether the miss is the reference's own."""
+    ratio, oratio = _check_against_reference_bound(pkg, orc, 4400, 4000, seed, nb)
     if not ratio < 8:
-        pytest.xfail(f"seed {seed} nb={nb}: ratio {ratio:.2f} >= 8")
+        pytest.xfail(f"seed {seed} nb={nb}: GPU ratio {ratio:.2f} >= 8; the restated reference scores {oratio:.2f} on this draw")
 
 
 @pytest.mark.parametrize("m,n", REF_SHAPES)
 def test_reference_acceptance_inequality_complex(pkg, orc, m, n):
     """test/runtests.jl:42-63 with T = ComplexF64 and x from the GPU path in the reference's operation order (nb = 0;
-    the blocked default has its own test below).  The metric is one draw of a noisy ratio -- on the largest shape it
-    sits at 7-9 x the LAPACK value for seed 0 depending on nothing but the summation order of the column reductions
-    (7.25 with the xor butterfly, above 8 with the DPP reduction; x itself is accurate to 3e-14 either way) -- so
-    shapes with n >= 2000 take the median over three seeds, every seed below 2 x the reference's bound."""
-    ratios = []
+    the blocked default has its own test below), residuals in double as the reference evaluates them.  Shapes with
+    n >= 2000: three draws, each against the literal bound / the restated reference's own score."""
     for seed in ((0, 2, 4) if n >= 2000 else (0,)):
-        A = orc.rand_matrix_c(m, n, seed)
-        b = orc.rand_vector_c(m, seed + 1)
-        q, r = np.linalg.qr(A)
-        x1 = sl.solve_triangular(r, q.conj().T @ b)
-        Ah = A.conj().T
-        stdliberr = np.linalg.norm(Ah @ (A @ x1) - Ah @ b)
-        H = pkg.qr_(A.copy(order="F"), nb=0)
-        x2 = pkg.ldiv(H, b)
-        ratios.append(np.linalg.norm(Ah @ (A @ x2) - Ah @ b) / stdliberr)
-    assert np.median(ratios) < 8 and max(ratios) < 16, ratios
+        _check_against_reference_bound(pkg, orc, m, n, seed, 0)
     if n >= 2000:
         # largest shapes: pin the GPU factor (last seed) against LAPACK zgeqrf directly (rows of R equal up to the
-        # unit phase of alpha_j, see tests/test_oracle_complex.py) -- no O(m n^2) CPU oracle run here
+        # unit phase of alpha_j, see tests/test_oracle_complex.py)
+        A = orc.rand_matrix_c(m, n, 4)
+        H = pkg.qr_(A.copy(order="F"), nb=0)
         (qr_raw, _tau), _ = sl.qr(A, mode="raw")
         R = np.triu(H.A, 1)[:n] + np.diag(H.α)
         Rl = np.triu(qr_raw)[:n]
@@ -219,7 +242,19 @@ def test_complex_column_split_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
         x = pkg.ldiv(pkg.DistributedHouseholderQRStruct(H, alpha), b)
         xr = np.linalg.lstsq(A0, b, rcond=None)[0]
         assert np.abs(np.asarray(x) - xr).max() <= 1e-8 * np.abs(xr).max()
-        assert np.array_equal(mg.ldiv(H, alpha, b), np.asarray(x))  # the handle's `\` for complex128 = the same solve
+        # the handle's `\` for complex128: Q'b and the back substitution distributed over the same ranks (dhqr_mg_ldiv_c64
+        # -> zcs_solve, src:226-282), against the oracle's solve; the host inputs are not modified
+        Hk, bk = H.copy(), b.copy()
+        xd = mg.ldiv(H, alpha, b)
+        xo = orc.solve_c(Ho, ao, b)
+        assert np.abs(xd - xo).max() <= 1e-9 * np.abs(xo).max(), np.abs(xd - xo).max() / np.abs(xo).max()
+        assert np.array_equal(H, Hk) and np.array_equal(b, bk)
+        if ranks > 1 and n > 64:
+            c0 = mg.comm_counters(0)
+            mg.ldiv(H, alpha, b)
+            c1 = mg.comm_counters(0)
+            npan = (n + 63) // 64
+            assert c1["n_bcast"] - c0["n_bcast"] == 2 * npan and c1["n_allreduce"] - c0["n_allreduce"] == npan, (c0, c1)
         if ranks > 1 and n > 64:
             cnt = mg.comm_counters(0)
             assert cnt["n_bcast"] == (n + 63) // 64, cnt  # ONE broadcast per panel (src:141-143 fans out per column)
@@ -255,40 +290,56 @@ def test_complex_darray_front_end_single_gpu(pkg, orc):
     assert np.abs(blk - Ho).max() <= TOL(Ho) * np.abs(Ho).max()
     with pytest.raises(ValueError):
         pkg.qr_darray_c64_(np.zeros((m, n - 1), dtype=complex, order="F"), m, n, comm)
+    # `qrA \ b` through dhqr_cs_ldiv_darray_c64 (world size 1) against the oracle
+    b = orc.rand_vector_c(m, 10)
+    x = pkg.ldiv_darray_(blk, m, n, alpha, b, comm)
+    xo = orc.solve_c(Ho, ao, b)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     comm.close()
+
+
+@pytest.mark.parametrize("ranks,m,n", [(2, 300, 200), (3, 700, 650), (8, 1500, 1030), (3, 200, 3)])
+def test_complex_darray_qr_and_ldiv_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
+    """test/runtests.jl:71-82 with T = ComplexF64: `qrA = qr!(A::DArray); x = qrA \\ b` through dhqr_cs_qr_darray_c64 and
+    dhqr_cs_ldiv_darray_c64 with `ranks` rank threads sharing cuda:0 (callback transport), every rank holding its contiguous
+    column block; factor and x against the complex oracle on every rank"""
+    import ctypes
+    from dist_helpers import gpu_thread_ranks
+    A0 = orc.rand_matrix_c(m, n, 83)
+    b = orc.rand_vector_c(m, 84)
+    Ho, ao = orc.householder_c(A0)
+    xo = orc.solve_c(Ho, ao, b)
+    scale = np.abs(Ho).max()
+    kappa = np.linalg.cond(A0) if n >= 1000 else 1.0
+    tol = max(TOL(Ho), 64 * kappa * np.finfo(float).eps)
+
+    def rank_fn(rank, comm, L):
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        L.dhqr_cs_contiguous_range(n, ranks, rank, ctypes.byref(lo), ctypes.byref(hi))
+        lo, hi = lo.value, hi.value
+        blk = np.array(A0[:, lo:hi], order="F")
+        al = pkg.qr_darray_c64_(blk, m, n, comm)
+        if hi > lo:
+            assert np.abs(blk - Ho[:, lo:hi]).max() <= tol * scale
+        assert np.abs(al - ao).max() <= tol * scale
+        keep = blk.copy()
+        x = pkg.ldiv_darray_(blk, m, n, al, b, comm)
+        assert np.array_equal(blk, keep)
+        assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+        return x
+
+    xs = gpu_thread_ranks(ranks, rank_fn)
+    for r in range(1, ranks):
+        assert np.array_equal(xs[r], xs[0])
 
 
 @pytest.mark.parametrize("m,n", REF_SHAPES)
 def test_reference_acceptance_inequality_complex_blocked(pkg, orc, m, n):
-    """test/runtests.jl:42-63 with T = ComplexF64 through the BLOCKED path (host drop-in, nb = 64).  The reference's
-    metric is one draw of a noisy ratio: the normal-equation residual amplifies the rounding of x by ||A||^2, and evaluating
-    it in double adds noise of the same size (the same x gave 8.7 and 17.3 x the LAPACK value on two boxes whose host BLAS
-    used different thread counts, while x itself is accurate to 3e-14 relative).  The residuals are therefore evaluated
-    in extended precision, and shapes with n >= 2000 take the median over five seeds (bound: the reference's 8); no
-    single seed may exceed 4 x that bound."""
-    def normal_residuals(A, xs, b):
-        # r = A x - b is where the cancellation happens: extended precision; A' r (no cancellation) in double
-        Ar, Ai = A.real.astype(np.longdouble), A.imag.astype(np.longdouble)
-        out = []
-        for x in xs:
-            xr, xi = x.real.astype(np.longdouble), x.imag.astype(np.longdouble)
-            rr = Ar @ xr - Ai @ xi - b.real
-            ri = Ar @ xi + Ai @ xr - b.imag
-            out.append(float(np.linalg.norm(A.conj().T @ (rr.astype(float) + 1j * ri.astype(float)))))
-        return out
-
-    ratios = []
+    """test/runtests.jl:42-63 with T = ComplexF64 through the BLOCKED path (host drop-in, nb = 64), residuals in DOUBLE as
+    the reference evaluates them (round 3 needed an extended-precision evaluator and a median here; with the restated
+    reference's score on the same draw as the yardstick neither is needed).  Shapes with n >= 2000: five draws."""
     for seed in ((0, 2, 4, 6, 8) if n >= 2000 else (0,)):
-        A = orc.rand_matrix_c(m, n, seed)
-        b = orc.rand_vector_c(m, seed + 1)
-        q, r = np.linalg.qr(A)
-        x1 = sl.solve_triangular(r, q.conj().T @ b)
-        H = pkg.qr_(A.copy(order="F"), nb=64)
-        x2 = np.asarray(pkg.ldiv(H, b))
-        stdliberr, err = normal_residuals(A, [x1, x2], b)
-        ratios.append(err / stdliberr)
-    assert np.median(ratios) < 8, ratios
-    assert max(ratios) < 32, ratios
+        _check_against_reference_bound(pkg, orc, m, n, seed, 64)
 
 
 def test_zero_pivot_complex(pkg, orc):
