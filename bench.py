@@ -213,6 +213,15 @@ def supervise(argv):
             print(f"[bench supervisor] rank {rank}: attempt {k} ({what}): {verdict}; ending the worker", file=sys.stderr, flush=True)
             _kill_tree(proc)
         [t.join(timeout=5) for t in threads]
+        # rank 0 owns the result line: a worker that exits 0 without printing one is a FAILED attempt for every rank (checked
+        # before the verdict is published, so the ranks cannot diverge on whether the attempt counts)
+        result_line = None
+        if verdict == "ok" and rank == 0:
+            lines = [ln for ln in state["out"] if ln.startswith("{")]
+            if lines:
+                result_line = lines[-1]
+            else:
+                verdict = "the worker printed no result line"
         all_ok = verdict == "ok"
         if store is not None:
             if not all_ok:
@@ -227,15 +236,9 @@ def supervise(argv):
                 verdict = "; ".join(f"rank {r}: {v}" for r, v in enumerate(verdicts) if v != "ok")
         if all_ok:
             if rank == 0:
-                lines = [ln for ln in state["out"] if ln.startswith("{")]
-                if not lines:
-                    verdict = "the worker printed no result line"
-                    all_ok = False
-                else:
-                    sys.stdout.write(lines[-1])
-                    sys.stdout.flush()
-            if all_ok:
-                return 0
+                sys.stdout.write(result_line)
+                sys.stdout.flush()
+            return 0
         failed.append({"attempt": k, "what": what, "env": extra, "why": verdict})
         if rank == 0:
             print(f"[bench supervisor] attempt {k} ({what}) failed: {verdict}", file=sys.stderr, flush=True)
@@ -422,7 +425,7 @@ def emit(out, rank=0):
 
 
 def pmc_traffic(symbol, m, n, nb, launches, work):
-    """(HBM bytes per launch, reason-if-None) of a roofline kernel from the committed counter run
+    """(HBM traffic of one factorisation step, reason-if-None) of a roofline kernel from the committed counter run
     profiles/pmc_traffic_current.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/pmc_driver,
     gfx950 x2 FETCH correction, calibrated on a streaming kernel).  Counters cannot be read from inside this process, so the
     figure is the one measured for the SAME kernel symbol on the SAME workload -- and only while the kernel's source files
@@ -439,9 +442,11 @@ def pmc_traffic(symbol, m, n, nb, launches, work):
             have, want = git_blob_hash(os.path.join(ROOT, src)), pm.get("source_hashes", {}).get(src)
             if have != want:
                 return None, f"committed counters were taken with {src} at blob {str(want)[:12]}, this tree has {str(have)[:12]}: re-run the counter passes of tools/gpu_r3_evidence.sh and tools/pmc_stamp.py"
-        if "bytes_per_launch" in e:
-            return e["bytes_per_launch"], None
-        return e["ratio_to_algorithmic"] * work / max(1, launches), None  # measured bytes / algorithmic bytes of the same launches
+        # bytes of ONE factorisation step as the counters measured them: read + written by the launches the counter passes
+        # cover (`counted`: the wide launches of the symbol; the narrow look-ahead launches of the same template are left out)
+        info = {"bytes_per_step": (e["read_GB"] + e["write_GB"]) * 1e9, "counted_launches_per_step": e["launches"],
+                "algorithmic_bytes_per_step_of_those": e["algorithmic_GB"] * 1e9, "ratio_to_algorithmic": e["ratio_to_algorithmic"]}
+        return info, None
     return None, f"no counter run committed for {symbol} on {workload}"
 
 
@@ -471,15 +476,99 @@ def roofline_groups(st, steps, m=0, n=0, nb=0):
             ach, peak, unit = gr["work"] / gr["ms"] / 1e9, PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"
         else:
             ach, peak, unit = gr["work"] / gr["ms"] / 1e6, PEAK_HBM_GBPS, "GB/s"
-        traffic, why = pmc_traffic(gr["symbol"], m, n, nb, gr["launches"], gr["work"])
-        rl_all.append({"kernel": gr["kernel"], "bound": gr["bound"], "achieved": ach, "peak": peak, "unit": unit,
-                       "frac": ach / peak, "traffic": traffic, **({"traffic_null_because": why} if traffic is None else {}),
-                       "launches": gr["launches"],
-                       "avg_launch_ms": gr["ms"] / max(1, gr["launches"]), "total_ms": gr["ms"]})
+        tinfo, why = pmc_traffic(gr["symbol"], m, n, nb, gr["launches"], gr["work"])
+        # ONE definition of "launch" for every per-launch field: the hipEvent groups this run timed (`launches` of them in
+        # `steps` steps, `avg_launch_ms` each).  traffic = counter bytes of a step / timed groups of a step, so that
+        # traffic / avg_launch_ms = traffic_bytes_per_step / (total_ms / steps) = the HBM rate the group sustained.
+        per_step = gr["launches"] / max(1, steps)
+        entry = {"kernel": gr["kernel"], "bound": gr["bound"], "achieved": ach, "peak": peak, "unit": unit,
+                 "frac": ach / peak, "traffic": (tinfo["bytes_per_step"] / per_step if tinfo else None),
+                 **({"traffic_null_because": why} if tinfo is None else {}),
+                 "launches": gr["launches"], "launches_per_step": per_step,
+                 "avg_launch_ms": gr["ms"] / max(1, gr["launches"]), "total_ms": gr["ms"], "ms_per_step": gr["ms"] / max(1, steps)}
+        if tinfo:
+            entry.update(traffic_bytes_per_step=tinfo["bytes_per_step"],
+                         traffic_counted_launches_per_step=tinfo["counted_launches_per_step"],
+                         traffic_ratio_to_algorithmic=tinfo["ratio_to_algorithmic"],
+                         traffic_GBps=tinfo["bytes_per_step"] / (gr["ms"] / max(1, steps)) / 1e6)
+        rl_all.append(entry)
     # the north star grades the trailing update: the DOMINANT (largest total time) MFMA group
     mf = [r for r in rl_all if r["bound"] == "mfma"]
     dom = max(mf, key=lambda r: r["total_ms"]) if mf else (max(rl_all, key=lambda r: r["total_ms"]) if rl_all else None)
     return dom, rl_all
+
+
+def also_unblocked(pkg, torch, ctx, dev, steps=3, warmup=1, n=8192):
+    """BASELINE configs[1] beside the headline line: n x n Float64, unblocked (the reference's operation order, K reflectors
+    per pass over the trailing columns), device-resident, same timing discipline (refill inside the timed region)"""
+    import ctypes
+    m = n
+    L = pkg._lib.lib()
+    A = pkg.empty_colmajor(m, n, dev)
+    alpha = torch.zeros(n, dtype=torch.float64, device=dev)
+
+    def step():
+        ctx.use_torch_stream()
+        pkg._lib.check(L.dhqr_fill_uniform_f64(ctx.handle, ctypes.c_void_p(A.data_ptr()), m, n, m, 0, m, 0, pkg.NB, 1, 0))
+        pkg.householder_(A, alpha, nb=0)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.reset_stats()
+    ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    ctx.set_profiling(False)
+    A0 = pkg.rand_colmajor(m, n, 0, dev)
+    resid = pkg.residual(pkg.DistributedHouseholderQRStruct(A, alpha), A0)
+    dom, _ = roofline_groups(st, steps, m, n, 0)
+    ms = dt / steps * 1e3
+    return {"config": {"workload": f"{m}x{n} Float64 dense QR, unblocked rank-1 (BASELINE configs[1])", "m": m, "n": n, "nb": 0},
+            "value": flops_qr(m, n) / (dt / steps) / 1e9, "unit": "GFLOP/s", "ms_per_step": ms, "steps": steps, "warmup": warmup,
+            "residual": resid, "roofline": dom,
+            "reflectors_per_pass": 16.0 * sum((m - j) * (n - j - 1) for j in range(n)) * steps / st["bytes_rank1"] if st["bytes_rank1"] > 0 else None}
+
+
+def also_tallskinny(pkg, torch, steps=3, warmup=1, m=262144, n=4096):
+    """BASELINE configs[4] at world size 1 beside the headline line: the row-split driver (all-reduces issued and counted,
+    moving nothing at one rank) on the full 262144 x 4096 shape"""
+    mg = pkg.MultiGpuQR(devices=[0])
+    try:
+        mg.rs_alloc(m, n)
+        for _ in range(warmup):
+            mg.rs_fill(0)
+            mg.rs_factor()
+        torch.cuda.synchronize()
+        mg.reset_stats()
+        mg.set_profiling(True)
+        cc0 = mg.comm_counters(0)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            mg.rs_fill(0)
+            mg.rs_factor()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        cc1 = mg.comm_counters(0)
+        st = mg.stats(0)
+        mg.set_profiling(False)
+        resid = mg.rs_residual(0)
+    finally:
+        mg.close()
+    value = flops_qr(m, n) / (dt / steps) / 1e9
+    _, rl_all = roofline_groups(st, steps)
+    return {"config": {"workload": f"{m}x{n} Float64 tall-skinny QR, row split at world size 1 (BASELINE configs[4])", "m": m, "n": n, "nb": 128},
+            "value": value, "unit": "GFLOP/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "residual": resid,
+            "allreduce_per_step": {"count": (cc1["n_allreduce"] - cc0["n_allreduce"]) / steps,
+                                   "bytes": (cc1["bytes_allreduce"] - cc0["bytes_allreduce"]) / steps},
+            "roofline": {"bound": "mfma", "achieved": value / 1e3, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": value / 1e3 / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "whole row-split factorisation (not a single kernel)"},
+            "roofline_all": [{k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches_per_step", "ms_per_step")} for r in rl_all]}
 
 
 def main():
@@ -494,6 +583,9 @@ def main():
     ap.add_argument("--m", type=int, default=0, help="rows (default = n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-residual", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the other single-GPU configurations (unblocked 8192^2, row split 262144x4096 at world size 1) "
+                         "that the default 1-GPU run appends to its line as `also`")
     ap.add_argument("--logical-ranks", type=int, default=0,
                     help="development: run R ranks of the multi-GPU driver on ONE GPU (in-process peer-copy transport)")
     ap.add_argument("--worker", action="store_true", help="internal: the measured run itself (started by the supervisor of N > 1)")
@@ -592,9 +684,13 @@ def main():
     if mode == "mg":
         mg.reset_stats()
         mg.set_profiling(True)
+        for r in range(mg.ndev):
+            mg.comm_timing(r, on=1)
     else:
         ctx.reset_stats()
         ctx.set_profiling(True)
+        if mode == "spmd":
+            q.comm.timing(on=1)
     try:
         _pr = torch.cuda.get_device_properties(local_rank)
         _pci = "%04x:%02x:%02x.0" % (_pr.pci_domain_id, _pr.pci_bus_id, _pr.pci_device_id)
@@ -609,9 +705,10 @@ def main():
     dt = time.perf_counter() - t0
     telemetry = tele.result()
     progress(f"{args.steps} timed steps done")
-    per_rank = None
+    per_rank = comm_t = None
     if mode == "mg":
         per_rank = [mg.stats(r) for r in range(mg.ndev)]
+        comm_t = [mg.comm_timing(r, on=0) for r in range(mg.ndev)]
         mg.set_profiling(False)
         st = per_rank[0]
         panel_counts = [sum(s_["panels_fast"] for s_ in per_rank), sum(s_["panels_fallback"] for s_ in per_rank)]
@@ -619,6 +716,8 @@ def main():
         st = ctx.stats()
         ctx.set_profiling(False)
         panel_counts = list(ctx.panel_counters())
+        if mode == "spmd":
+            comm_t = q.comm.timing(on=0)
     if spmd:
         t = torch.tensor([dt], dtype=torch.float64)  # host tensor: the control plane is gloo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -657,8 +756,10 @@ def main():
                                 "unblocked rank-1 (BASELINE configs[1])"),
                    "m": m, "n": n, "nb": nb, "parallelism": par},
         "residual": resid,
-        "roofline": ({k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
-                                          "launches", "avg_launch_ms")} if dom else None),
+        "roofline": ({k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches",
+                                          "launches_per_step", "avg_launch_ms", "ms_per_step", "traffic_bytes_per_step",
+                                          "traffic_counted_launches_per_step", "traffic_ratio_to_algorithmic", "traffic_GBps",
+                                          "traffic_null_because") if k in dom} if dom else None),
         "roofline_all": rl_all,
         **({"reflector_apply": {
             # SURVEY 8(d)'s per-unit figure (16 B per element and reflector: one read + one write) against what the
@@ -669,10 +770,14 @@ def main():
             "equivalent_GBps_at_16B_per_element_and_reflector":
                 16.0 * sum((m - j) * (n - j - 1) for j in range(n)) * args.steps / st["ms_rank1"] / 1e6}}
            if (not nb and st["bytes_rank1"] > 0) else {}),
-        "traffic_note": "roofline.traffic = HBM bytes per launch (read + write) of the same kernel symbol on the same workload from the "
-                        "committed rocprofv3 --pmc run (FETCH_SIZE x2 on gfx950, WRITE_SIZE; separate passes over the torch-free "
-                        "driver), used only while the kernel sources still have the git blob ids stamped into "
-                        "profiles/pmc_traffic_current.json; otherwise null with the reason",
+        "traffic_note": "roofline.traffic = HBM bytes (read + write) per timed launch group -- the SAME launches `launches` and "
+                        "`avg_launch_ms` count -- = traffic_bytes_per_step / launches_per_step; traffic_bytes_per_step = the bytes of "
+                        "one factorisation from the committed rocprofv3 --pmc run of the same kernel symbol on the same workload "
+                        "(FETCH_SIZE x2 on gfx950, WRITE_SIZE; separate passes over the torch-free driver; its "
+                        "traffic_counted_launches_per_step wide launches carry the group's bytes, the narrow look-ahead launches "
+                        "of the template are not counted), traffic_GBps = traffic_bytes_per_step / ms_per_step; used only while "
+                        "the kernel sources still have the git blob ids stamped into profiles/pmc_traffic_current.json, "
+                        "otherwise null with the reason",
         "gpu_telemetry": telemetry,
         **attempt_fields(attempt),
         "phase_ms_per_step": {k: st[k] / args.steps for k in st if k.startswith("ms_") and st[k] > 0},
@@ -686,6 +791,22 @@ def main():
         out["rccl_nranks"] = q.comm.rccl_nranks()
     if mode != "single":
         out["roofline_note"] = "per-GPU figures of rank 0 (every rank runs the same kernels on 1/N of the columns)"
+    # per-rank diagnosis of a multi-GPU run: where each rank's step went (ms per step) -- the wide stream's GEMMs, the panel
+    # chain (lane busy time), the collectives (device time incl. the wait for the peers), and what is left of the step
+    # beside the wide stream's kernels (waiting for the lane or a broadcast)
+    def _diag(s_, t_):
+        wide = (s_["ms_gemm_avw"] + s_["ms_gemm_vta"] + s_["ms_gemm_tw"]) / args.steps
+        return {"wide_gemm_ms": round(wide, 2), "panel_chain_ms": round(s_["ms_panel"] / args.steps, 2),
+                "bcast_ms": round(t_["bcast_ms"] / args.steps, 2), "n_bcast": t_["n_bcast"] / args.steps,
+                "allreduce_ms": round(t_["allreduce_ms"] / args.steps, 2),
+                "wide_stream_not_in_gemms_ms": round(ms_step - wide, 2)}
+    if mode == "mg" and mg.ndev > 1:
+        out["per_rank_ms_per_step"] = [_diag(per_rank[r], comm_t[r]) for r in range(mg.ndev)]
+    elif mode == "spmd":
+        mine = _diag(st, comm_t)
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        out["per_rank_ms_per_step"] = allr
     if per_rank is not None:
         out["bcast_bytes_per_step_per_rank"] = per_rank[0]["bytes_bcast"] / args.steps
         out["per_rank_gemm_ms_per_step"] = [round((s_["ms_gemm_avw"] + s_["ms_gemm_vta"] + s_["ms_gemm_tw"]) / args.steps, 2)
@@ -711,9 +832,20 @@ def main():
             out["gemm_kernels_in_isolation_16384"] = iso
         except Exception as e:  # diagnostics only
             out["ubench_error"] = repr(e)
+        del A
+        torch.cuda.empty_cache()
+        if not args.no_also and args.config == "blocked" and not args.n and not args.m:
+            # the other single-GPU configurations of BASELINE.json, driver-timed in the same run (a few seconds each)
+            out["also"] = []
+            for what, fn in (("unblocked 8192^2", lambda: also_unblocked(pkg, torch, ctx, dev)),
+                             ("row split 262144x4096", lambda: also_tallskinny(pkg, torch))):
+                try:
+                    progress(f"also: {what}")
+                    out["also"].append(fn())
+                except Exception as e:  # never takes the headline line down
+                    out["also"].append({"config": {"workload": what}, "error": repr(e)[:300]})
+                torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
-            del A
-            torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(m, n)
             out["cpu_baseline"]["distributed_structure"] = cpu_baseline_distributed()
             out["cpu_baseline"]["lapack_dgeqrf"] = cpu_baseline_lapack()

@@ -136,6 +136,8 @@ SIGNATURES = {
     "dhqr_cs_local_cols_c64": (_i64, [_i64, _i32, _i32]),
     "dhqr_cs_factor_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
     "dhqr_cs_qr_darray_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
+    "dhqr_comm_timing": (_i32, [_p, _i32, _p]),
+    "dhqr_mg_comm_timing": (_i32, [_p, _i32, _i32, _p]),
     "dhqr_cs_ldiv_darray_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "dhqr_cs_ldiv_darray_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "dhqr_cs_solve_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),

@@ -73,6 +73,7 @@ struct dhqr_ctx {
   int cur_ws = 0;
   bool lookahead = true;
   Buf vbuf, vt, vts, spart, sfull, scratch, pbuf;
+  Buf zsolve_lo;         // low parts of the double-double right-hand side of the ComplexF64 solve
   int pair = 1;                  // 1: wide updates apply two panels per pass (DHQR_PAIR=0 disables)
   int64_t pair_min_n = 12288;    // below this the longer look-ahead lane of the pair driver costs more than it saves (profiles/r02_ab_pair_tail_and_threshold.txt)
   int panel_impl = 3;  // 3: R-first (CholeskyQR + reconstruction, dhqr_recon.h) with fallback to 2;
@@ -1274,8 +1275,8 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_PAIR_MIN_N")) c->pair_min_n = atoll(e);
     HIPCHECK(hipHostMalloc((void **)&c->hflag, 4 * sizeof(int), hipHostMallocDefault));
     HIPCHECK(hipMalloc((void **)&c->dstat, 16 * sizeof(int)));
-    HIPCHECK(hipMalloc((void **)&c->zflags, 128 * DHQR_ZFLAG_STRIDE * sizeof(int)));
-    HIPCHECK(hipMemsetAsync(c->zflags, 0, 128 * DHQR_ZFLAG_STRIDE * sizeof(int), c->stream));
+    HIPCHECK(hipMalloc((void **)&c->zflags, DHQR_PIPE_INTS * sizeof(int)));  // 128 flags + the error word (dhqr_common.h)
+    HIPCHECK(hipMemsetAsync(c->zflags, 0, DHQR_PIPE_INTS * sizeof(int), c->stream));
     if (const char *e = getenv("DHQR_ZPIPE")) c->zpipe = atoi(e) != 0;
     hipLaunchKernelGGL(k_set_status, dim3(1), dim3(64), 0, c->stream, c->dstat, INT_MAX);
     LAUNCHCHECK();
@@ -1309,7 +1310,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   cs_state_free(c);
   rs_state_free(c);
   Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
-                 &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq};
+                 &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {
@@ -1337,10 +1338,23 @@ int32_t dhqr_use_own_stream(dhqr_ctx *c) {
   c->stream = c->own;
   return DHQR_OK;
 }
+// A column pipeline whose bounded hand-over wait expired (dhqr_common.h) has produced wrong numbers instead of hanging
+// the GPU: reported here, by the entry points that synchronise anyway.  c->stream must be idle.
+static int32_t pipe_error_check(dhqr_ctx *c) {
+  if (!c->zflags) return DHQR_OK;
+  int e = 0;
+  HIPCHECK(hipMemcpy(&e, c->zflags + DHQR_PIPE_ERR_OFFSET, sizeof(int), hipMemcpyDeviceToHost));
+  if (e == 0) return DHQR_OK;
+  HIPCHECK(hipMemset(c->zflags + DHQR_PIPE_ERR_OFFSET, 0, sizeof(int)));
+  return set_err(DHQR_EHIP, "a column pipeline (k_zpanel_pipe / rankk_lead_pipe, launch %d) gave up waiting for a lower-indexed "
+                 "workgroup: the results of that factorisation are invalid; DHQR_ZPIPE=0 / DHQR_RANKK_PIPE=0 select the "
+                 "one-launch-per-column kernels", e);
+}
+
 int32_t dhqr_synchronize(dhqr_ctx *c) {
   ENTER(c);
   HIPCHECK(hipStreamSynchronize(c->stream));
-  return DHQR_OK;
+  return pipe_error_check(c);
 }
 int32_t dhqr_set_profiling(dhqr_ctx *c, int32_t on) {
   ENTER(c);
@@ -1451,7 +1465,7 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
                               n, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipMemcpyAsync(halpha, dal, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
-    return DHQR_OK;
+    return pipe_error_check(c);
   };
   rc = body();
   (void)hipStreamSynchronize(c->stream);
@@ -1765,7 +1779,7 @@ int32_t dhqr_qr_c64_nb(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t ld
     HIPCHECK(hipMemcpy2DAsync(hA, lda * esz, dA, m * esz, m * esz, n, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipMemcpyAsync(halpha, dal, n * esz, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
-    return DHQR_OK;
+    return pipe_error_check(c);
   };
   const int32_t rc = body();
   (void)hipStreamSynchronize(c->stream);
@@ -1793,7 +1807,7 @@ int32_t dhqr_qr_c64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
     HIPCHECK(hipMemcpy2DAsync(hA, lda * esz, dA, m * esz, m * esz, n, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipMemcpyAsync(halpha, dal, n * esz, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
-    return DHQR_OK;
+    return pipe_error_check(c);
   };
   const int32_t rc = body();
   (void)hipStreamSynchronize(c->stream);
@@ -1812,6 +1826,28 @@ int32_t dhqr_solve_c64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int6
   CHECK(check_zptr(db, "b"));
   const double2 *A = reinterpret_cast<const double2 *>(dA), *al = reinterpret_cast<const double2 *>(dalpha);
   double2 *b = reinterpret_cast<double2 *>(db);
+  static const bool dd = [] { const char *e = getenv("DHQR_ZSOLVE_DD"); return !(e && atoi(e) == 0); }();
+  if (dd) {  // b carried in double-double (dhqr_complex.h, "the solve with b carried in double-double")
+    CHECK(ensure(c, c->zsolve_lo, (size_t)(2 * m + 16)));
+    double2 *bl = reinterpret_cast<double2 *>(c->zsolve_lo.p);
+    HIPCHECK(hipMemsetAsync(bl, 0, (size_t)m * sizeof(double2), c->stream));
+    CHECK(prof_begin(c, CAT_SOLVE));
+    for (int64_t j = 0; j < n; ++j) {  // src:215-224: reflectors in column order
+      if (m - j <= 2048)
+        hipLaunchKernelGGL((k_zqtb_col_dd<256>), dim3(1), dim3(256), 0, c->stream, A + j * lda, b, bl, m, j);
+      else
+        hipLaunchKernelGGL((k_zqtb_col_dd<1024>), dim3(1), dim3(1024), 0, c->stream, A + j * lda, b, bl, m, j);
+    }
+    for (int64_t hi = n; hi > 0; hi -= ZBS_NB) {  // src:244-254
+      const int64_t lo = std::max<int64_t>(0, hi - ZBS_NB);
+      hipLaunchKernelGGL(k_zbacksub_diag_dd, dim3(1), dim3(64), 0, c->stream, A, lda, al, b, bl, lo, hi);
+      if (lo > 0)
+        hipLaunchKernelGGL(k_zbacksub_update_dd, dim3((unsigned)((lo + 255) / 256)), dim3(256), 0, c->stream, A, lda, b, bl, lo, hi);
+    }
+    CHECK(prof_end(c));
+    LAUNCHCHECK();
+    return DHQR_OK;
+  }
   CHECK(prof_begin(c, CAT_SOLVE));
   for (int64_t j = 0; j < n; ++j) {  // src:215-224: reflectors in column order
     const int64_t cov = m - j;
@@ -2014,9 +2050,14 @@ extern "C" {
 #endif
 
 // ============================================================ multi-GPU: communicators (dhqr_comm.h)
-static bool lane_channel_wanted() {  // DHQR_LANE_CHANNEL=0: the row-split lane shares the wide stream's channel
-  const char *e = getenv("DHQR_LANE_CHANNEL");
-  return !(e && atoi(e) == 0);
+// Second channel for the row-split look-ahead lane (its small latency-bound collectives overtake the wide stream's large
+// all-reduce).  Default: ON for the LOCAL transport (a second mailbox; measured), OFF for RCCL -- two communicators whose
+// kernels compete for CUs the persistent GEMMs hold have never run on hardware with more than one rank, so the first
+// multi-GPU run uses ONE ordered channel; DHQR_LANE_CHANNEL=1 turns the second RCCL communicator on, =0 forces it off
+// for every transport.
+static bool lane_channel_wanted(int kind) {
+  if (const char *e = getenv("DHQR_LANE_CHANNEL")) return atoi(e) != 0;
+  return kind != COMM_RCCL;
 }
 static int32_t comm_new(dhqr_comm **out, dhqr_ctx *c, int kind, int nranks, int rank) {
   dhqr_comm *cm = new dhqr_comm();
@@ -2068,7 +2109,7 @@ int32_t dhqr_comm_create_rank(dhqr_comm **out, dhqr_ctx *c, int32_t nranks, int3
     nc = nullptr;  // owned by cm from here
     // second channel for the look-ahead lane of the row-split driver: rank 0 draws another unique id and ships it over
     // the first communicator (no change for the host layer)
-    if (lane_channel_wanted()) {
+    if (lane_channel_wanted(COMM_RCCL)) {
       ncclUniqueId id2;
       memset(&id2, 0, sizeof(id2));
       if (rank == 0) RCCLCHECK(g_rccl.GetUniqueId(&id2));
@@ -2128,6 +2169,32 @@ int32_t dhqr_comm_counters(dhqr_comm *cm, int64_t *out4) {
   out4[1] = cm->bytes_bcast;
   out4[2] = cm->n_allreduce + (cm->lane ? cm->lane->n_allreduce : 0);
   out4[3] = cm->bytes_allreduce + (cm->lane ? cm->lane->bytes_allreduce : 0);
+  return DHQR_OK;
+}
+
+// Device time this rank spent in its collectives (hipEvent pairs around every broadcast / all-reduce, the wait for the
+// peers included) since the last call or since timing was switched on: out4 = {broadcast ms, broadcasts timed,
+// all-reduce ms, all-reduces timed}, the row-split lane's channel included.  on = 1 / 0 starts / stops collecting, -1
+// leaves it as it is.  Synchronises the device.
+int32_t dhqr_comm_timing(dhqr_comm *cm, int32_t on, double *out4) {
+  if (!cm) return set_err(DHQR_EINVAL, "null communicator");
+  if (cm->ctx) HIPCHECK(hipSetDevice(cm->ctx->device));
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  dhqr_comm *chs[2] = {cm, cm->lane};
+  for (dhqr_comm *ch : chs) {
+    if (!ch) continue;
+    if (ch->tev_used > 0) HIPCHECK(hipDeviceSynchronize());
+    for (size_t i = 0; i < ch->tev_used; ++i) {
+      float t = 0.f;
+      HIPCHECK(hipEventElapsedTime(&t, ch->tev[i].a, ch->tev[i].b));
+      acc[2 * ch->tev[i].kind] += (double)t;
+      acc[2 * ch->tev[i].kind + 1] += 1.0;
+    }
+    ch->tev_used = 0;
+    if (on >= 0) ch->timing = on != 0;
+  }
+  if (out4)
+    for (int i = 0; i < 4; ++i) out4[i] = acc[i];
   return DHQR_OK;
 }
 
@@ -2387,7 +2454,7 @@ int32_t dhqr_mg_create(dhqr_mg **out, const int32_t *devices, int32_t ndev) {
       g->rk[r].cm->nccl = nc[r];
       g->rk[r].cm->world = w;
     }
-    if (ndev > 1 && lane_channel_wanted()) {  // second channel (look-ahead lane of the row-split driver)
+    if (ndev > 1 && lane_channel_wanted(want)) {  // second channel (look-ahead lane of the row-split driver)
       std::vector<ncclComm_t> nc2(ndev, nullptr);
       LocalWorld *w2 = nullptr;
       bool ok = true;
@@ -2457,6 +2524,10 @@ int32_t dhqr_mg_get_bcast_tuning(dhqr_mg *g, int32_t *algo, double *ms_ring, dou
 int32_t dhqr_mg_comm_counters(dhqr_mg *g, int32_t rank, int64_t *out4) {
   if (!g || rank < 0 || rank >= g->ndev) return set_err(DHQR_EINVAL, "bad arguments");
   return dhqr_comm_counters(g->rk[rank].cm, out4);
+}
+int32_t dhqr_mg_comm_timing(dhqr_mg *g, int32_t rank, int32_t on, double *out4) {
+  if (!g || rank < 0 || rank >= g->ndev) return set_err(DHQR_EINVAL, "bad arguments");
+  return dhqr_comm_timing(g->rk[rank].cm, on, out4);
 }
 int32_t dhqr_mg_rccl_nranks(dhqr_mg *g, int32_t *main_channel, int32_t *lane_channel) {
   if (!g || g->rk.empty()) return set_err(DHQR_EINVAL, "null handle");
@@ -2659,7 +2730,7 @@ int32_t dhqr_cs_qr_darray_c64(dhqr_comm *cm, double *hBlock, int64_t m, int64_t 
     if (wr > 0) HIPCHECK(hipMemcpy2DAsync(hBlock, ldb * esz, dBlk, m * esz, m * esz, wr, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipMemcpyAsync(halpha, dal, (size_t)n * esz, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
-    return DHQR_OK;
+    return pipe_error_check(c);
   };
   const int32_t rc = body();
   (void)hipDeviceSynchronize();
@@ -2801,7 +2872,7 @@ int32_t dhqr_mg_qr_c64(dhqr_mg *g, double *hA, int64_t m, int64_t n, int64_t lda
       }
       if (r == 0) HIPCHECK(hipMemcpyAsync(halpha, dal, (size_t)n * esz, hipMemcpyDeviceToHost, c->stream));
       HIPCHECK(hipStreamSynchronize(c->stream));
-      return DHQR_OK;
+      return pipe_error_check(c);
     };
     const int32_t rc = body();
     if (rc != DHQR_OK) (void)hipDeviceSynchronize();

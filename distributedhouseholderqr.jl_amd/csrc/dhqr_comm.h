@@ -153,6 +153,13 @@ struct dhqr_comm {
   int bcast_algo = 0;
   int64_t bcast_sag_min = (int64_t)1 << 17;  // doubles (1 MiB): below this a single ncclBroadcast
   double tune_ms[2] = {0.0, 0.0};            // what the trial measured (ring, scatter + all-gather), 16 MiB
+  // Device time of this rank's collectives while the context profiles (dhqr_set_profiling): one hipEvent pair per
+  // operation on the stream that carries it -- the wait for the peers included, which is what a multi-GPU run needs to
+  // tell "the broadcast is slow" from "the panel chain is slow" (dhqr_comm_timing).  kind 0 broadcast, 1 all-reduce.
+  struct TimedOp { hipEvent_t a, b; int kind; };
+  std::vector<TimedOp> tev;
+  size_t tev_used = 0;
+  bool timing = false;
 };
 
 __global__ __launch_bounds__(256) void k_sum_ranks(const double *__restrict__ part, int nranks, int64_t stride,
@@ -235,7 +242,32 @@ static int32_t comm_tune_bcast(dhqr_comm *cm, hipStream_t stream) {
 
 // Broadcast `count` doubles at dbuf from rank `root`, ordered on `stream`.  *ticket (optional) identifies the
 // operation for comm_wait_consumed.
+static int32_t comm_time_begin(dhqr_comm *cm, int kind, hipStream_t stream) {
+  if (cm->tev_used == cm->tev.size()) {
+    dhqr_comm::TimedOp e;
+    HIPCHECK(hipEventCreate(&e.a));
+    HIPCHECK(hipEventCreate(&e.b));
+    e.kind = kind;
+    cm->tev.push_back(e);
+  }
+  cm->tev[cm->tev_used].kind = kind;
+  HIPCHECK(hipEventRecord(cm->tev[cm->tev_used].a, stream));
+  return DHQR_OK;
+}
+static int32_t comm_time_end(dhqr_comm *cm, hipStream_t stream) {
+  HIPCHECK(hipEventRecord(cm->tev[cm->tev_used].b, stream));
+  cm->tev_used++;
+  return DHQR_OK;
+}
+static int32_t comm_bcast_impl(dhqr_comm *cm, double *dbuf, int64_t count, int root, hipStream_t stream, int64_t *ticket);
 static int32_t comm_bcast(dhqr_comm *cm, double *dbuf, int64_t count, int root, hipStream_t stream, int64_t *ticket) {
+  const bool timed = cm->timing && cm->nranks > 1 && count > 0;
+  if (timed) CHECK(comm_time_begin(cm, 0, stream));
+  const int32_t rc = comm_bcast_impl(cm, dbuf, count, root, stream, ticket);
+  if (timed) CHECK(comm_time_end(cm, stream));
+  return rc;
+}
+static int32_t comm_bcast_impl(dhqr_comm *cm, double *dbuf, int64_t count, int root, hipStream_t stream, int64_t *ticket) {
   if (ticket) *ticket = -1;
   if (cm->nranks == 1 || count <= 0) return DHQR_OK;
   cm->bytes_bcast += count * 8;
@@ -302,7 +334,15 @@ static int32_t comm_wait_consumed(dhqr_comm *cm, int64_t ticket, hipStream_t str
 
 // In-place sum over the ranks of `count` doubles at dbuf (small buffers: partial dots, norms).  The result is
 // bitwise identical on every rank (fixed summation order).
+static int32_t comm_allreduce_sum_impl(dhqr_comm *cm, double *dbuf, int64_t count, hipStream_t stream);
 static int32_t comm_allreduce_sum(dhqr_comm *cm, double *dbuf, int64_t count, hipStream_t stream) {
+  const bool timed = cm->timing && cm->nranks > 1 && count > 0;
+  if (timed) CHECK(comm_time_begin(cm, 1, stream));
+  const int32_t rc = comm_allreduce_sum_impl(cm, dbuf, count, stream);
+  if (timed) CHECK(comm_time_end(cm, stream));
+  return rc;
+}
+static int32_t comm_allreduce_sum_impl(dhqr_comm *cm, double *dbuf, int64_t count, hipStream_t stream) {
   if (count > 0) {
     cm->bytes_allreduce += count * 8;
     cm->n_allreduce++;
@@ -406,6 +446,10 @@ static int32_t comm_free(dhqr_comm *cm) {
   if (cm->ctx) (void)hipSetDevice(cm->ctx->device);
   if (cm->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(cm->nccl);
   if (cm->scratch) (void)hipFree(cm->scratch);
+  for (auto &e : cm->tev) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
   if (cm->world && cm->world->refs.fetch_sub(1) == 1) {
     for (int r = 0; r < cm->world->nranks; ++r)
       for (int s = 0; s < DHQR_COMM_RING; ++s) {

@@ -131,6 +131,21 @@ __device__ __forceinline__ void dd_add_sq(dhqr_dd &acc, double x) {  // acc += x
   acc.hi = s;
   acc.lo += e + pe;
 }
+__device__ __forceinline__ void dd_add_prod(dhqr_dd &acc, double a, double b) {  // acc += a*b
+#pragma clang fp contract(off)
+  const double p = a * b;
+  const double pe = fma(a, b, -p);  // exact: a*b == p + pe
+  double s, e;
+  dd_two_sum(acc.hi, p, s, e);
+  acc.hi = s;
+  acc.lo += e + pe;
+}
+__device__ __forceinline__ void dd_renorm(dhqr_dd &a) {  // hi <- fl(hi + lo), lo <- the rest
+#pragma clang fp contract(off)
+  const double s = a.hi + a.lo;
+  a.lo = a.lo - (s - a.hi);
+  a.hi = s;
+}
 __device__ __forceinline__ dhqr_dd dd_add(const dhqr_dd a, const dhqr_dd b) {  // symmetric in (a, b)
 #pragma clang fp contract(off)
   double s, e;
@@ -211,4 +226,40 @@ __device__ __forceinline__ double dhqr_rcp(double x) {
 // src:8  alphafactor(x::Real) = -sign(x)  (sign(0) == 0 in Julia: a zero pivot gives alpha = -0*s)
 __device__ __forceinline__ double dhqr_alphafactor(double x) {
   return x > 0.0 ? -1.0 : (x < 0.0 ? 1.0 : -x);
+}
+
+// ---- inter-workgroup hand-over flags of the column pipelines (k_zpanel_pipe, rankk_lead_pipe) ----------------------
+// One array of 128 flags (one 128-byte line each) + one error word per context.  A flag holds the number (epoch) of the
+// launch that last raised it, so the flags are never reset.  INVARIANTS the drivers keep and the kernels rely on:
+//   * the flag-using launches of a context never overlap (they are all issued on ONE stream at a time: the look-ahead
+//     lane for ComplexF64 panels, the caller's stream for the unblocked path) -- and should two ever overlap, a flag is
+//     raised with an atomic MAX, so a late store of epoch e cannot take e + 1 back and strand a waiter;
+//   * a workgroup only waits for LOWER-indexed workgroups of its own launch, which the hardware dispatches first (observed,
+//     not promised by HIP).  Should that ever fail -- or a predecessor die -- the wait is BOUNDED: after
+//     DHQR_PIPE_SPIN_LIMIT polls the waiter records the epoch in the error word and goes on (wrong numbers instead of a
+//     hung GPU); the host reports it at its next synchronising entry point (pipe_error_check in dhqr_api.hip) and names
+//     the kill switches DHQR_ZPIPE=0 / DHQR_RANKK_PIPE=0 (one launch per column, no inter-workgroup waits).
+#define DHQR_PIPE_FLAG_STRIDE 32
+#define DHQR_PIPE_NFLAGS 128
+#define DHQR_PIPE_ERR_OFFSET (DHQR_PIPE_NFLAGS * DHQR_PIPE_FLAG_STRIDE)
+#define DHQR_PIPE_INTS (DHQR_PIPE_ERR_OFFSET + DHQR_PIPE_FLAG_STRIDE)
+#ifndef DHQR_PIPE_SPIN_LIMIT
+#define DHQR_PIPE_SPIN_LIMIT (1 << 24)  // x (one L2 poll + s_sleep 1) ~ several seconds; a hand-over takes microseconds
+#endif
+// called by ONE thread of the waiting workgroup: relaxed polls, then one acquire fence (an acquire LOAD at agent scope
+// would invalidate the XCD's L2 on every iteration)
+__device__ __forceinline__ void dhqr_pipe_wait(int *flags, int idx, int epoch) {
+  int spins = 0;
+  while (__hip_atomic_load(flags + idx * DHQR_PIPE_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > DHQR_PIPE_SPIN_LIMIT) {
+      __hip_atomic_store(flags + DHQR_PIPE_ERR_OFFSET, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// called by ONE thread after the workgroup's stores (and a barrier): L2 write-back, then the flag
+__device__ __forceinline__ void dhqr_pipe_raise(int *flags, int idx, int epoch) {
+  __hip_atomic_fetch_max(flags + idx * DHQR_PIPE_FLAG_STRIDE, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -109,6 +109,7 @@ struct CsProblem {
   double *alpha;   // n doubles, replicated on every rank
   int P, r;
   int64_t K, ncl;
+  int quads_ok = -1;  // P > 1: do ALL ranks meet the quad steps' alignment conditions (cs_agree_quads; -1: not asked yet)
   int64_t width(int64_t k) const { return std::min<int64_t>(DHQR_NBV, n - k * DHQR_NBV); }
   int owner(int64_t k) const { return (int)((k / 2) % P); }      // panel k belongs to the pair k / 2
   bool mine(int64_t k) const { return owner(k) == r; }
@@ -164,9 +165,9 @@ static inline CsGroupBuf cs_gbuf_view(double *base, int64_t rows_a, int64_t ldv_
 struct CsStep {
   int g0, ng;  // first group, number of groups (1 or 2)
 };
-// Groups and steps of a pass that starts at panel kstart.  Quads: single rank, 16-byte path, and at least
-// c->quad_min_cols columns to the right of the quad (beyond that the panel chain, not the wide stream, bounds the
-// factorisation and pairs keep the chain shorter).
+// Groups and steps of a pass that starts at panel kstart.  Quads: 16-byte path (on EVERY rank: the plan is part of the SPMD
+// program, cs_agree_quads), and at least c->quad_min_cols columns PER RANK to the right of the quad (beyond that the panel
+// chain, not the wide stream, bounds the factorisation and pairs keep the chain shorter).
 static void cs_plan(const CsProblem &pr, int64_t kstart, std::vector<CsGroup> &groups, std::vector<CsStep> &steps) {
   const dhqr_ctx *c = pr.c;
   const int64_t NB = DHQR_NBV;
@@ -180,14 +181,14 @@ static void cs_plan(const CsProblem &pr, int64_t kstart, std::vector<CsGroup> &g
     groups.push_back(g);
     k += g.np;
   }
-  const bool quads = c->quad && pr.P == 1 && pr.m % 2 == 0 && pr.lda % 2 == 0 && aligned16(pr.A);
+  const bool quads = c->quad && (pr.P == 1 ? (pr.m % 2 == 0 && pr.lda % 2 == 0 && aligned16(pr.A)) : pr.quads_ok == 1);
   const int G = (int)groups.size();
   for (int g = 0; g < G;) {
     CsStep st;
     st.g0 = g;
     st.ng = 1;
     if (quads && g + 1 < G && groups[g].np == 2 && groups[g + 1].np == 2 &&
-        pr.n - (groups[g + 1].last() + 1) * NB >= c->quad_min_cols)
+        (pr.n - (groups[g + 1].last() + 1) * NB) / pr.P >= c->quad_min_cols)
       st.ng = 2;
     steps.push_back(st);
     g += st.ng;
@@ -297,7 +298,10 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
           if (second_of_quad) {
             if (sh >= 1) HIPCHECK(hipStreamWaitEvent(sL, S.ev_head[(sh - 1) % CS_EVR], 0));
           } else if (sh >= 2) {
-            HIPCHECK(hipStreamWaitEvent(sL, (P > 1 ? S.ev_head : S.ev_wide)[(sh - 2) % CS_EVR], 0));
+            // the head of wide step sh - 2 is the group two behind that step's last one: this group when step sh - 1 is a
+            // single group, the SECOND pair of step sh - 1 when that is a quad (then this block is in the rest)
+            const bool in_head = P > 1 && h == steps[sh - 2].g0 + steps[sh - 2].ng + 1;
+            HIPCHECK(hipStreamWaitEvent(sL, (in_head ? S.ev_head : S.ev_wide)[(sh - 2) % CS_EVR], 0));
           }
           int64_t ncols = w;
           if (gr.np == 2 && idx == 0 && pr.mine(x + 1) && pr.lcol(x + 1) == lc + w) {
@@ -440,12 +444,34 @@ static int32_t cs_prepare(const CsProblem &pr) {
   return DHQR_OK;
 }
 
+// Quad steps at P > 1: the schedule (cs_plan) is part of the SPMD program, so the ranks must take the SAME decision, while
+// the conditions of the 16-byte path (even m, even lda, 16-byte aligned block) are local: one tiny all-reduce per
+// factorisation counts the ranks that do not meet them.
+static int32_t cs_agree_quads(CsProblem &pr) {
+  dhqr_ctx *c = pr.c;
+  if (pr.P == 1 || !pr.cm || !c->quad) {
+    pr.quads_ok = 0;
+    return DHQR_OK;
+  }
+  const double bad = (pr.ncl == 0 || (pr.m % 2 == 0 && pr.lda % 2 == 0 && aligned16(pr.A))) ? 0.0 : 1.0;
+  CHECK(ensure(c, c->scratch, 4096));
+  double h = bad;
+  HIPCHECK(hipMemcpyAsync(c->scratch.p, &h, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  CHECK(comm_allreduce_sum(pr.cm, c->scratch.p, 1, c->stream));
+  HIPCHECK(hipMemcpyAsync(&h, c->scratch.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  pr.quads_ok = (h == 0.0) ? 1 : 0;
+  return DHQR_OK;
+}
+
 // householder!(A, alpha) / householder!(A::DArray, alpha) (src:113-120) on this rank's block-cyclic columns.
 // Collective over pr.cm; synchronous on return (one status read per pass; a second pass only after a rejected panel).
-static int32_t cs_factor(const CsProblem &pr) {
+static int32_t cs_factor(const CsProblem &pr_in) {
+  CsProblem pr = pr_in;
   dhqr_ctx *c = pr.c;
   const int64_t NB = DHQR_NBV;
   CHECK(cs_prepare(pr));
+  if (pr.quads_ok < 0) CHECK(cs_agree_quads(pr));
   CHECK(status_reset(c));
   int64_t ks = 0;
   bool robust = false;

@@ -337,7 +337,7 @@ __device__ __forceinline__ uint32_t rk_opaque(uint32_t t) {
 // waits for lower-indexed ones), applies them, builds its own and publishes it.  The arithmetic and its order are those of
 // the one-workgroup lead (rankk_lead_body): one workgroup needed K x (K + q) applies of 128 KiB each in sequence (~300 us
 // per launch at 16384 rows, three times the bulk's traffic time); here the chain is K old applies + K hand-overs.
-#define DHQR_RK_FLAG_STRIDE 32  // ints between two flags: one 128-byte line each
+#define DHQR_RK_FLAG_STRIDE DHQR_PIPE_FLAG_STRIDE  // ints between two flags: one 128-byte line each
 template <int T, int EPT, int VEC, int K>
 __device__ __attribute__((noinline)) void rankk_lead_pipe(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols, int64_t c0,
                                                 int64_t rtop, int kold, const double *vold, double *vnew, int64_t vlen,
@@ -420,10 +420,7 @@ __device__ __attribute__((noinline)) void rankk_lead_pipe(double *__restrict__ A
     }
   }
   for (int p = 0; p < q; ++p) {  // the reflectors of this launch's earlier columns, as their owners publish them
-    if (t == 0) {  // relaxed polls, one acquire fence (an acquire load would invalidate the XCD's L2 on every iteration)
-      while (__hip_atomic_load(flags + p * DHQR_RK_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
+    if (t == 0) dhqr_pipe_wait(flags, p, epoch);  // relaxed polls, one acquire fence, bounded (dhqr_common.h)
     __syncthreads();
     load_refl(vnew + (int64_t)p * vlen, w0);
     apply(w0);
@@ -451,7 +448,7 @@ __device__ __attribute__((noinline)) void rankk_lead_pipe(double *__restrict__ A
   store(vnew + (int64_t)q * vlen, w0);
   store(col, a);
   __syncthreads();  // every wave's stores have reached the L2
-  if (t == 0) __hip_atomic_store(flags + q * DHQR_RK_FLAG_STRIDE, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (t == 0) dhqr_pipe_raise(flags, q, epoch);
 }
 
 // K steps in ONE pass over the trailing columns.  The reflectors v_jlo .. v_jlo+kold-1 already exist (`vold`, one every

@@ -162,6 +162,13 @@ class Communicator:
         check(self.L.dhqr_comm_counters(self.handle, o))
         return {"n_bcast": o[0], "bytes_bcast": o[1], "n_allreduce": o[2], "bytes_allreduce": o[3]}
 
+    def timing(self, on: int = -1) -> dict:
+        """device time of this rank's collectives since the last call (dhqr_comm_timing): hipEvent pairs around every
+        broadcast / all-reduce, the wait for the peers included; on = 1 / 0 starts / stops collecting"""
+        o = (ctypes.c_double * 4)()
+        check(self.L.dhqr_comm_timing(self.handle, on, o))
+        return {"bcast_ms": o[0], "n_bcast": int(o[1]), "allreduce_ms": o[2], "n_allreduce": int(o[3])}
+
     def rccl_nranks(self) -> dict:
         """rank counts RCCL itself reports (ncclCommCount) for the main channel and the row-split lane's channel"""
         a, b = ctypes.c_int32(), ctypes.c_int32()
@@ -393,6 +400,12 @@ class MultiGpuQR:
         o = (ctypes.c_int64 * 4)()
         self._check(self.L.dhqr_mg_comm_counters(self._h, rank, o))
         return {"n_bcast": o[0], "bytes_bcast": o[1], "n_allreduce": o[2], "bytes_allreduce": o[3]}
+
+    def comm_timing(self, rank: int = 0, on: int = -1) -> dict:
+        """device time of one rank's collectives since the last call (dhqr_mg_comm_timing)"""
+        o = (ctypes.c_double * 4)()
+        self._check(self.L.dhqr_mg_comm_timing(self._h, rank, on, o))
+        return {"bcast_ms": o[0], "n_bcast": int(o[1]), "allreduce_ms": o[2], "n_allreduce": int(o[3])}
 
     def rccl_nranks(self) -> dict:
         a, b = ctypes.c_int32(), ctypes.c_int32()

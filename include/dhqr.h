@@ -284,6 +284,11 @@ int32_t dhqr_comm_info(dhqr_comm *comm, int32_t *kind, int32_t *nranks, int32_t 
  * bytes} (the row-split lane's channel included).  All-reduces are counted as the drivers ISSUE them -- also at one rank,
  * where they move nothing -- so a single-GPU run reports the count and volume BASELINE.md section 2 asks for. */
 int32_t dhqr_comm_counters(dhqr_comm *comm, int64_t *out4);
+/* Device time this rank spent in its collectives (one hipEvent pair around every broadcast / all-reduce on the stream that
+ * carries it, the wait for the peers included): out4 = {broadcast ms, broadcasts timed, all-reduce ms, all-reduces timed}
+ * since the last call; on = 1 / 0 starts / stops collecting, -1 leaves it.  Synchronises the device.  What tells "the
+ * broadcast is slow" from "the panel chain is slow" in a multi-GPU run (bench.py prints it per rank). */
+int32_t dhqr_comm_timing(dhqr_comm *comm, int32_t on, double *out4);
 /* RCCL transport: which algorithm large panel broadcasts use -- 0 ncclBroadcast (rings), 1 scatter + all-gather (the root
  * sends 1/P of the panel to each peer over its own xGMI link, then ncclAllGather) -- and what the timed trial at
  * communicator creation measured for a 16 MiB broadcast with each (ms; 0 when no trial ran: other transports, or
@@ -371,6 +376,7 @@ int32_t dhqr_mg_info(dhqr_mg *mg, int32_t *ndev, int32_t *transport, int64_t *m,
 int32_t dhqr_mg_get_bcast_tuning(dhqr_mg *mg, int32_t *algo, double *ms_ring, double *ms_scatter_allgather);
 int32_t dhqr_mg_rccl_nranks(dhqr_mg *mg, int32_t *main_channel, int32_t *lane_channel); /* dhqr_comm_rccl_nranks of rank 0 */
 int32_t dhqr_mg_comm_counters(dhqr_mg *mg, int32_t rank, int64_t *out4);                 /* dhqr_comm_counters of one rank */
+int32_t dhqr_mg_comm_timing(dhqr_mg *mg, int32_t rank, int32_t on, double *out4);          /* dhqr_comm_timing of one rank */
 int32_t dhqr_mg_alloc_f64(dhqr_mg *mg, int64_t m, int64_t n);
 int32_t dhqr_mg_fill_uniform_f64(dhqr_mg *mg, uint64_t seed);
 int32_t dhqr_mg_factor_f64(dhqr_mg *mg);

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE: stand-in for `bench.py --worker` (DHQR_BENCH_WORKER) so the supervisor of the multi-GPU bench runs
 can be exercised without GPUs.  FAKE_WORKER_PLAN = comma-separated behaviour per attempt:
   ok | hang (progress once, then silence on every rank) | hang1 (only rank 1 goes silent; rank 0 keeps waiting for it)
-  | crash1 (rank 1 exits 7; the others wait)"""
+  | crash1 (rank 1 exits 7; the others wait) | mute (every rank exits 0, nobody prints a result line)"""
 import json
 import os
 import sys
@@ -19,6 +19,9 @@ if what == "ok":
                           "attempts_failed": att["failed"], "saw_rank_env": "RANK" in os.environ,
                           "master_port": os.environ.get("MASTER_PORT"), "transport": os.environ.get("DHQR_TRANSPORT"),
                           "agent_store": os.environ.get("TORCHELASTIC_USE_AGENT_STORE")}), flush=True)
+    sys.exit(0)
+if what == "mute":
+    time.sleep(0.3)
     sys.exit(0)
 if what == "crash1" and rank == 1:
     sys.exit(7)

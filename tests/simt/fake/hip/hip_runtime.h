@@ -287,6 +287,7 @@ inline long long wall_clock64() {
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+#define __hip_atomic_fetch_max(p, v, order, scope) __atomic_fetch_max((p), (v), (order))
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {

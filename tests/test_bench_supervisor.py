@@ -66,3 +66,13 @@ def test_single_process_form_is_supervised_too():
     r, lines, _ = _run("hang,ok", 2, torchrun=False)
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1 and json.loads(lines[0])["attempt"] == 1
+
+
+def test_worker_without_a_result_line_is_a_failed_attempt_on_every_rank():
+    """every rank exits 0 but rank 0 finds no JSON line: the attempt fails for ALL ranks (rank 0 checks before it publishes its
+    verdict), so the ranks enter the next attempt together instead of rank 0 alone waiting at a rendezvous"""
+    r, lines, _ = _run("mute,ok", 2, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["attempt"] == 1 and "no result line" in out["attempts_failed"][0]["why"]

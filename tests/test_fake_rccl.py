@@ -108,7 +108,7 @@ def test_column_split_over_rccl(rk, orc, ndev, m, n, env):
     with _env(**env):
         h = _mg(L, ndev)
     s0 = _stats(F, reset=False)
-    assert s0["comms"] == 2 * ndev and s0["live"] == 2 * ndev  # main channel + lane channel per rank
+    assert s0["comms"] == ndev and s0["live"] == ndev  # ONE communicator per rank: the RCCL default (DHQR_LANE_CHANNEL=1 adds the lane's)
     algo, t0, t1 = ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
     assert L.dhqr_mg_get_bcast_tuning(h, ctypes.byref(algo), ctypes.byref(t0), ctypes.byref(t1)) == 0
     if "DHQR_BCAST" in env:
@@ -148,6 +148,41 @@ def test_column_split_over_rccl(rk, orc, ndev, m, n, env):
     assert s2["allreduce"] > 0 and s2["timeouts"] == 0 and s2["mismatches"] == 0  # residual + back-substitution sums
     assert L.dhqr_mg_destroy(h) == 0
     assert _stats(F)["live"] == 0  # every communicator destroyed
+
+
+# Quad steps at P > 1 (cs_plan: two consecutive pairs -- owned by DIFFERENT ranks -- applied in one K = 512 pass): every rank
+# builds the 256 x 256 cross term from the broadcast panels itself; the group after a quad gets the quad from its owner's lane,
+# the quad's second pair is factored from the head of the previous wide step.  The ranks agree on the plan through one
+# all-reduce per factorisation (cs_agree_quads).  bad > 0: a nearly dependent column pair inside the quad is rejected on the
+# device and the run resumes (the committed panels of the quad are broadcast again and applied to the rest).
+@pytest.mark.parametrize("ndev,m,n,bad", [(2, 1290, 1280, 0), (2, 700, 640, 300), pytest.param(3, 1560, 1536, 0, marks=_SLOW),
+                                          pytest.param(3, 700, 640, 400, marks=_SLOW)])
+def test_column_split_quad_steps_over_rccl(rk, orc, ndev, m, n, bad):
+    L, F = rk
+    A0 = orc.rand_matrix(m, n, 8)
+    if bad:
+        A0[:, bad] = A0[:, bad - 1] * (1.0 + 1e-9)
+    res = []
+    for env in ({"DHQR_QUAD_MIN_COLS": 0, "DHQR_BCAST": "ring"}, {"DHQR_QUAD": 0, "DHQR_BCAST": "ring"}):
+        with _env(**env):
+            h = _mg(L, ndev)
+        A, al = A0.copy(order="F"), np.zeros(n)
+        _stats(F)
+        assert L.dhqr_mg_qr_f64(h, _ptr(A), m, n, m, _ptr(al)) == 0, L.dhqr_last_error()
+        s1 = _stats(F)
+        assert s1["timeouts"] == 0 and s1["mismatches"] == 0
+        assert s1["allreduce"] == (ndev if "DHQR_QUAD_MIN_COLS" in env else 0)  # the plan agreement, once per factorisation
+        if bad:
+            QR = orc.form_qr(np.asfortranarray(A), al)
+            assert np.linalg.norm(A0 - QR) / np.linalg.norm(A0) < 1e-13
+        else:
+            Ho, ao = orc.householder(A0)
+            scale = np.abs(Ho).max()
+            assert np.abs(A - Ho).max() <= 1e-12 * scale and np.abs(al - ao).max() <= 1e-12 * scale
+        res.append(A)
+        assert L.dhqr_mg_destroy(h) == 0
+    if not bad:  # quads and pairs: the same factorisation to rounding
+        assert np.abs(res[0] - res[1]).max() <= 1e-12 * np.abs(res[1]).max()
 
 
 # ComplexF64 column split (dhqr_zdist.h): cyclic blocks of 64 complex columns, one ncclBroadcast per panel issued on the
@@ -194,22 +229,25 @@ def test_complex_column_split_over_rccl(rk, orc, ndev, m, n, algo):
     assert _stats(F)["live"] == 0
 
 
-# row split: lane collectives on the second communicator while the wide stream uses the first; DHQR_LANE_CHANNEL=0
-# shares one; tsqr: every panel through the cross-rank tree (gather of the R factors by one all-reduce)
+# row split: by default ONE RCCL communicator carries the lane's and the wide stream's collectives (issued in the same host
+# order on every rank); DHQR_LANE_CHANNEL=1: the lane's collectives on a second communicator while the wide stream uses the
+# first; tsqr: every panel through the cross-rank tree (gather of the R factors by one all-reduce)
 @pytest.mark.parametrize("ndev,m,n,env", [
     (2, 1024, 384, {}),
-    pytest.param(2, 1024, 384, {"DHQR_LANE_CHANNEL": 0}, marks=_SLOW),
-    (3, 900, 300, {}),
+    (2, 1024, 384, {"DHQR_LANE_CHANNEL": 1}),
+    (3, 900, 300, {"DHQR_LANE_CHANNEL": 1}),
+    pytest.param(3, 900, 300, {}, marks=_SLOW),
     (8, 1100, 256, {}),
+    pytest.param(8, 1100, 256, {"DHQR_LANE_CHANNEL": 1}, marks=_SLOW),
     pytest.param(2, 384, 128, {"DHQR_TSQR": 1}, marks=_SLOW),
-    pytest.param(8, 2304, 640, {}, marks=_SLOW),
+    pytest.param(8, 2304, 640, {"DHQR_LANE_CHANNEL": 1}, marks=_SLOW),
 ])
 def test_row_split_over_rccl_two_communicators(rk, orc, ndev, m, n, env):
     L, F = rk
     _stats(F)
     with _env(**env):
         h = _mg(L, ndev)
-    lane = env.get("DHQR_LANE_CHANNEL", 1) != 0
+    lane = env.get("DHQR_LANE_CHANNEL", 0) != 0
     assert _stats(F, reset=False)["comms"] == (2 if lane else 1) * ndev
     assert L.dhqr_mg_rs_alloc_f64(h, m, n) == 0, L.dhqr_last_error()
     assert L.dhqr_mg_rs_fill_uniform_f64(h, 31) == 0
@@ -257,7 +295,7 @@ def test_row_split_rejected_panel_over_rccl(rk, orc):
     assert s["timeouts"] == 0 and s["mismatches"] == 0 and s["live"] == 0
 
 
-def _spmd_rank(L, P, r, idbuf, m, n, split, out, errs):
+def _spmd_rank(L, P, r, idbuf, m, n, split, out, errs, lane=False):
     """one rank of the multi-PROCESS form (a torchrun rank / a Julia worker), here a thread: its own context on its own
     device, dhqr_comm_create_rank from the shared unique id, then the SPMD entry points"""
     try:
@@ -266,7 +304,7 @@ def _spmd_rank(L, P, r, idbuf, m, n, split, out, errs):
         assert L.dhqr_comm_create_rank(ctypes.byref(cm), h, P, r, idbuf) == 0, L.dhqr_last_error()
         a, b = ctypes.c_int32(), ctypes.c_int32()
         assert L.dhqr_comm_rccl_nranks(cm, ctypes.byref(a), ctypes.byref(b)) == 0
-        assert (a.value, b.value) == (P, P)  # what RCCL itself reports for the two channels
+        assert (a.value, b.value) == (P, P if lane else 0)  # what RCCL itself reports for the main and the lane channel
         al = np.zeros(n)
         rel = ctypes.c_double()
         if split == "cs":
@@ -294,21 +332,22 @@ def _spmd_rank(L, P, r, idbuf, m, n, split, out, errs):
         errs.append(f"rank {r}: {traceback.format_exc()}")
 
 
-@pytest.mark.parametrize("P,m,n,split", [(2, 520, 384, "cs"), pytest.param(3, 900, 384, "cs", marks=_SLOW), (3, 600, 256, "rs"),
-                                           pytest.param(2, 1024, 256, "rs", marks=_SLOW)])
-def test_spmd_ranks_bootstrap_from_unique_id(rk, orc, P, m, n, split):
-    """dhqr_comm_unique_id -> dhqr_comm_create_rank on every rank (ncclCommInitRank twice: the lane's id travels over the
-    first communicator), then the dhqr_cs_* / dhqr_rs_* entry points a torchrun rank / Julia worker calls."""
+@pytest.mark.parametrize("P,m,n,split,lane", [(2, 520, 384, "cs", 0), pytest.param(3, 900, 384, "cs", 0, marks=_SLOW), (3, 600, 256, "rs", 1),
+                                                pytest.param(3, 600, 256, "rs", 0, marks=_SLOW), pytest.param(2, 1024, 256, "rs", 1, marks=_SLOW)])
+def test_spmd_ranks_bootstrap_from_unique_id(rk, orc, P, m, n, split, lane):
+    """dhqr_comm_unique_id -> dhqr_comm_create_rank on every rank (lane = 1, DHQR_LANE_CHANNEL=1: ncclCommInitRank twice, the
+    lane's id travels over the first communicator), then the dhqr_cs_* / dhqr_rs_* entry points a torchrun rank / Julia worker calls."""
     L, F = rk
     _stats(F)
     idbuf = (ctypes.c_char * 128)()
     assert L.dhqr_comm_unique_id(idbuf) == 0, L.dhqr_last_error()
     out, errs = {}, []
-    th = [threading.Thread(target=_spmd_rank, args=(L, P, r, idbuf, m, n, split, out, errs)) for r in range(P)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
+    th = [threading.Thread(target=_spmd_rank, args=(L, P, r, idbuf, m, n, split, out, errs, bool(lane))) for r in range(P)]
+    with _env(**({"DHQR_LANE_CHANNEL": 1} if lane else {})):  # read when the communicators are created
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
     assert not errs, "\n".join(errs)
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 5))
     scale = np.abs(Ho).max()
@@ -320,7 +359,7 @@ def test_spmd_ranks_bootstrap_from_unique_id(rk, orc, P, m, n, split):
             if cols:  # a rank beyond the last cyclic block owns nothing and still takes part in every collective
                 assert np.abs(A[:, :len(cols)] - Ho[:, cols]).max() <= 1e-12 * scale
     s = _stats(F)
-    assert s["comms"] == 2 * P and s["live"] == 0 and s["timeouts"] == 0 and s["mismatches"] == 0
+    assert s["comms"] == (2 if lane else 1) * P and s["live"] == 0 and s["timeouts"] == 0 and s["mismatches"] == 0
 
 
 def test_stand_in_reports_mismatch_and_different_order_instead_of_hanging(rk):
