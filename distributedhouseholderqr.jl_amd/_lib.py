@@ -140,6 +140,7 @@ SIGNATURES = {
     "dhqr_mg_comm_timing": (_i32, [_p, _i32, _i32, _p]),
     "dhqr_cs_ldiv_darray_f64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "dhqr_cs_ldiv_darray_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "dhqr_cs_solve_work_c64": (_i64, [_i64, _i32]),
     "dhqr_cs_solve_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "dhqr_mg_ldiv_c64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "dhqr_mg_solve_f64": (_i32, [_p, _p, _p]),

@@ -99,6 +99,12 @@ struct dhqr_ctx {
   int ib = DHQR_IB;
   struct CsState *cs = nullptr;  // streams / events / group buffers of the blocked driver (dhqr_dist.h)
   struct RsState *rs = nullptr;  // events / group ring of the row-split driver (dhqr_rowsplit.h)
+  // host-in / host-out drop-in (dhqr_hostio.h): the blocked driver reports every committed panel (index, event) to this
+  // hook so that the finished column block can travel to the host while later panels are factored
+  int32_t (*panel_hook)(void *, int64_t, hipEvent_t) = nullptr;
+  void *panel_hook_arg = nullptr;
+  struct HostIo *hio = nullptr;
+  int64_t n_resume = 0;  // passes of the blocked driver that resumed after a rejected panel
   // profiling
   struct Ev { hipEvent_t a, b; int cat; };
   std::vector<Ev> evs;
@@ -1129,6 +1135,7 @@ static int32_t factor_blocked_simple(dhqr_ctx *c, double *dA, int64_t m, int64_t
 }
 
 #include "dhqr_comm.h"
+#include "dhqr_hostio.h"
 #include "dhqr_dist.h"
 #include "dhqr_rowsplit.h"
 #include "dhqr_mg.h"
@@ -1309,6 +1316,11 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   (void)hipDeviceSynchronize();
   cs_state_free(c);
   rs_state_free(c);
+  if (c->hio) {
+    hio_free(*c->hio);
+    delete c->hio;
+    c->hio = nullptr;
+  }
   Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
                  &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo};
   for (Buf *b : bufs)
@@ -1345,7 +1357,8 @@ static int32_t pipe_error_check(dhqr_ctx *c) {
   int e = 0;
   HIPCHECK(hipMemcpy(&e, c->zflags + DHQR_PIPE_ERR_OFFSET, sizeof(int), hipMemcpyDeviceToHost));
   if (e == 0) return DHQR_OK;
-  HIPCHECK(hipMemset(c->zflags + DHQR_PIPE_ERR_OFFSET, 0, sizeof(int)));
+  HIPCHECK(hipMemsetAsync(c->zflags + DHQR_PIPE_ERR_OFFSET, 0, sizeof(int), c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
   return set_err(DHQR_EHIP, "a column pipeline (k_zpanel_pipe / rankk_lead_pipe, launch %d) gave up waiting for a lower-indexed "
                  "workgroup: the results of that factorisation are invalid; DHQR_ZPIPE=0 / DHQR_RANKK_PIPE=0 select the "
                  "one-launch-per-column kernels", e);
@@ -1455,8 +1468,10 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
     (void)hipFree(dA);
     return set_err(DHQR_ENOMEM, "hipMalloc of alpha failed");
   }
+  // DHQR_HOSTIO=0: the plain three-phase form (one hipMemcpy2D up, factorisation, one down)
+  static const bool overlap = [] { const char *e = getenv("DHQR_HOSTIO"); return !(e && atoi(e) == 0); }();
   int32_t rc = DHQR_OK;
-  auto body = [&]() -> int32_t {
+  auto plain = [&]() -> int32_t {
     HIPCHECK(hipMemcpy2DAsync(dA, ldd * sizeof(double), hA, lda * sizeof(double), m * sizeof(double),
                               n, hipMemcpyHostToDevice, c->stream));
     // the reference factors whatever m x n block it is given; m odd is handled by the scalar path
@@ -1467,8 +1482,47 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
     HIPCHECK(hipStreamSynchronize(c->stream));
     return pipe_error_check(c);
   };
-  rc = body();
+  // dhqr_hostio.h: staged upload on two copy streams, every column block downloaded behind its panel's commit
+  auto overlapped = [&]() -> int32_t {
+    if (!c->hio) c->hio = new HostIo();
+    HostIo &h = *c->hio;
+    const int64_t K = (n + DHQR_NBV - 1) / DHQR_NBV;
+    CHECK(hio_upload(h, hA, m, n, lda, dA, ldd, c->stream));
+    h.hA = hA;
+    h.dA = dA;
+    h.m = m;
+    h.n = n;
+    h.lda = lda;
+    h.ldd = ldd;
+    h.use = 0;
+    h.done.assign((size_t)K, 0);
+    const int64_t resumes = c->n_resume, fallbacks = c->n_fallback;
+    c->panel_hook = hio_panel_hook;
+    c->panel_hook_arg = &h;
+    const int32_t rf = dhqr_factor_f64(c, dA, m, n, ldd, dal, nb);
+    c->panel_hook = nullptr;
+    c->panel_hook_arg = nullptr;
+    if (rf != DHQR_OK) {
+      (void)hio_drain(h);
+      return rf;
+    }
+    // a block that left while a rejected panel was being redone may be stale: take everything again (rare)
+    if (c->n_resume != resumes || c->n_fallback != fallbacks) {
+      CHECK(hio_drain(h));
+      h.done.assign((size_t)K, 0);
+    }
+    HIPCHECK(hipEventRecord(h.ev[0], c->stream));  // what the hook did not cover waits for the whole factorisation
+    for (int i = 0; i < 2; ++i) HIPCHECK(hipStreamWaitEvent(h.s[i], h.ev[0], 0));
+    for (int64_t k = 0; k < K; ++k)
+      if (!h.done[(size_t)k]) CHECK(hio_download_block(h, k * DHQR_NBV, std::min<int64_t>(DHQR_NBV, n - k * DHQR_NBV), nullptr));
+    HIPCHECK(hipMemcpyAsync(halpha, dal, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    CHECK(hio_drain(h));
+    return pipe_error_check(c);
+  };
+  rc = overlap ? overlapped() : plain();
   (void)hipStreamSynchronize(c->stream);
+  if (c->hio) (void)hio_drain(*c->hio);
   (void)hipFree(dA);
   (void)hipFree(dal);
   return rc;
@@ -2741,7 +2795,9 @@ int32_t dhqr_cs_qr_darray_c64(dhqr_comm *cm, double *hBlock, int64_t m, int64_t 
 }
 
 // solve_householder!(b, H, alpha) (src:226-282) for ComplexF64 on the cyclic 64-column split: db (m complex, the same on
-// every rank) is overwritten, x = db[0:n] on every rank; dwork: m + 64 complex of scratch.  Asynchronous on the context's stream.
+// every rank) is overwritten, x = db[0:n] on every rank; dwork: dhqr_cs_solve_work_c64(m, nranks) complex of scratch (b is
+// carried in double-double).  Asynchronous on the context's stream.
+int64_t dhqr_cs_solve_work_c64(int64_t m, int32_t nranks) { return (m < 0 || nranks < 1) ? -1 : zcs_solve_work(m, nranks); }
 int32_t dhqr_cs_solve_c64(dhqr_comm *cm, const double *dA, int64_t m, int64_t n, int64_t lda, const double *dalpha, double *db,
                           double *dwork) {
   if (!cm) return set_err(DHQR_EINVAL, "null communicator");
@@ -2781,7 +2837,7 @@ int32_t dhqr_cs_ldiv_darray_c64(dhqr_comm *cm, const double *hBlock, int64_t m, 
     HIPCHECK(hipMalloc((void **)&dBlk, (size_t)m * std::max<int64_t>(wr, 1) * esz));
     HIPCHECK(hipMalloc((void **)&dStage, (size_t)m * wmax * esz));
     HIPCHECK(hipMalloc((void **)&dal, (size_t)n * esz));
-    HIPCHECK(hipMalloc((void **)&dvec, (size_t)(2 * m + DHQR_ZNB) * esz));
+    HIPCHECK(hipMalloc((void **)&dvec, (size_t)(m + zcs_solve_work(m, P)) * esz));
     if (wr > 0) HIPCHECK(hipMemcpy2DAsync(dBlk, m * esz, hBlock, ldb * esz, m * esz, wr, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(dal, halpha, (size_t)n * esz, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(dvec, hb, (size_t)m * esz, hipMemcpyHostToDevice, c->stream));  // src:318 copy of b
@@ -2818,7 +2874,7 @@ int32_t dhqr_mg_ldiv_c64(dhqr_mg *g, const double *hA, int64_t m, int64_t n, int
       if (hipMalloc((void **)&dA, (size_t)m * (size_t)std::max<int64_t>(ncl, 1) * esz) != hipSuccess)
         return set_err(DHQR_ENOMEM, "hipMalloc of the %lld x %lld complex block failed", (long long)m, (long long)ncl);
       if (hipMalloc((void **)&dal, (size_t)n * esz) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc of alpha failed");
-      if (hipMalloc((void **)&dvec, (size_t)(2 * m + ZB) * esz) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc of b failed");
+      if (hipMalloc((void **)&dvec, (size_t)(m + zcs_solve_work(m, P)) * esz) != hipSuccess) return set_err(DHQR_ENOMEM, "hipMalloc of b failed");
       for (int64_t b = r; b < K; b += P) {
         const int64_t w = std::min<int64_t>(ZB, n - b * ZB);
         HIPCHECK(hipMemcpy2DAsync(dA + 2 * (b / P) * ZB * m, m * esz, hA + 2 * b * ZB * lda, lda * esz, m * esz, w,

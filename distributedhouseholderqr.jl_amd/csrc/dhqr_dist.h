@@ -341,6 +341,8 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
           hipLaunchKernelGGL(k_set_statword, dim3(1), dim3(64), 0, sL, (const int *)c->dstat, pbx.alpha + DHQR_NBV);
         }
         HIPCHECK(hipEventRecord(S.ev_ready[pe], sL));
+        // host-in / host-out drop-in: the column block of a committed panel is final and may leave for the host
+        if (c->panel_hook && P == 1) CHECK(c->panel_hook(c->panel_hook_arg, x, S.ev_ready[pe]));
         if (cm && P > 1) {
           HIPCHECK(hipStreamWaitEvent(sC, S.ev_ready[pe], 0));
           CHECK(comm_bcast(cm, gb.region(idx), gb.region_elems(), pr.r, sC, &S.ticket[pe]));
@@ -487,6 +489,7 @@ static int32_t cs_factor(const CsProblem &pr_in) {
         if (c->cholqr_passes == 3) c->n_tsqr++;
       }
     if (failed == INT_MAX) break;
+    c->n_resume++;
     // ---- resume: panels < failed are committed; matrix updates with epoch >= failed did not run
     CHECK(status_reset(c));
     // Committed panels of the failed panel's group / step were only applied as far as the lane needed them: apply them

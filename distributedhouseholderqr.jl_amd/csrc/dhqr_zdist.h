@@ -148,11 +148,12 @@ static int32_t zcs_factor(dhqr_ctx *c, dhqr_comm *cm, double *A, int64_t m, int6
   return DHQR_OK;
 }
 
-// acc[r0:r1] -= R[r0:r1, lo:hi] x[lo:hi] (hi - lo <= ZBS_NB); A is addressed with GLOBAL column indices (the caller
-// passes a base pointer shifted so that column lo of the block is the rank's local column)
-__global__ __launch_bounds__(256) void k_zbacksub_update_rows(const double2 *__restrict__ A, int64_t lda,
-                                                              const double2 *__restrict__ x, double2 *__restrict__ acc,
-                                                              int64_t r0, int64_t r1, int64_t lo, int64_t hi) {
+// (acc_hi, acc_lo)[r0:r1] -= R[r0:r1, lo:hi] x[lo:hi] in double-double (hi - lo <= ZBS_NB); A is addressed with GLOBAL column
+// indices (the caller passes a base pointer shifted so that column lo of the block is the rank's local column)
+__global__ __launch_bounds__(256) void k_zbacksub_update_rows_dd(const double2 *__restrict__ A, int64_t lda,
+                                                                 const double2 *__restrict__ x, double2 *__restrict__ acc_hi,
+                                                                 double2 *__restrict__ acc_lo, int64_t r0, int64_t r1,
+                                                                 int64_t lo, int64_t hi) {
   __shared__ double2 xs[ZBS_NB];
   const int t = threadIdx.x;
   const int nb = (int)(hi - lo);
@@ -160,25 +161,55 @@ __global__ __launch_bounds__(256) void k_zbacksub_update_rows(const double2 *__r
   __syncthreads();
   const int64_t r = r0 + (int64_t)blockIdx.x * blockDim.x + t;
   if (r >= r1) return;
-  double2 a = acc[r];
-  for (int c = 0; c < nb; ++c) a = zsubmul(a, A[r + (lo + c) * lda], xs[c].x, xs[c].y);  // src:248-250 / src:276-278
-  acc[r] = a;
+  dhqr_dd br = {acc_hi[r].x, acc_lo[r].x}, bi = {acc_hi[r].y, acc_lo[r].y};
+  for (int c = 0; c < nb; ++c) {  // src:248-250 / src:276-278
+    const double2 a = A[r + (lo + c) * lda], xc = xs[c];
+    dd_add_prod(br, -a.x, xc.x);
+    dd_add_prod(br, a.y, xc.y);
+    dd_add_prod(bi, -a.x, xc.y);
+    dd_add_prod(bi, -a.y, xc.x);
+  }
+  dd_renorm(br);
+  dd_renorm(bi);
+  acc_hi[r] = zmake(br.hi, bi.hi);
+  acc_lo[r] = zmake(br.lo, bi.lo);
+}
+// (bh, bl)[i] += sum over the P slots of (slot_hi, slot_lo)[i], i < w, exactly (double-double adds): the partial dots of
+// the ranks, gathered by an all-reduce of a buffer in which every rank filled only its own slot.  slot p: 2 w complex
+// (hi parts, then lo parts) at gath + p * 4 w doubles.  One workgroup of 64 threads.
+__global__ __launch_bounds__(64) void k_zdd_accumulate(double2 *__restrict__ bh, double2 *__restrict__ bl,
+                                                       const double2 *__restrict__ gath, int P, int w) {
+  const int i = threadIdx.x;
+  if (i >= w) return;
+  dhqr_dd sr = {bh[i].x, bl[i].x}, si = {bh[i].y, bl[i].y};
+  for (int p = 0; p < P; ++p) {
+    const double2 h = gath[(int64_t)p * 2 * w + i], l = gath[(int64_t)p * 2 * w + w + i];
+    sr = dd_add(sr, dhqr_dd{h.x, l.x});
+    si = dd_add(si, dhqr_dd{h.y, l.y});
+  }
+  bh[i] = zmake(sr.hi, si.hi);
+  bl[i] = zmake(sr.lo, si.lo);
 }
 
 // solve_householder!(b, H, alpha) (src:226-282) for ComplexF64 on the cyclic 64-column split.  db (m complex, the same on
-// every rank) is overwritten; x = db[0:n] on every rank.  Q'b: the owner of panel k applies its 64 reflectors in column
-// order and hands the updated tail of b on with one broadcast (the reference walks the owners sequentially with b in
-// shared memory, src:226-230).  Back substitution: every rank accumulates -R[i, j] x[j] over ITS columns j into du; per
-// panel one all-reduce sums the 64 partial dots (the reference's sum(fetch.(futures)), src:262-266), the owner solves
-// the diagonal block (division by alpha, src:267) and broadcasts x.  du: m + 64 complex of scratch.
+// every rank) is overwritten; x = db[0:n] on every rank.  b is carried in DOUBLE-DOUBLE like the single-GPU solve
+// (dhqr_complex.h: the reference's acceptance statistic, which test/runtests.jl:80-82 asserts for exactly this
+// distributed call, sees the rounding of the O(mn) solve).  Q'b: the owner of panel k applies its 64 reflectors in column
+// order and hands the updated tail of b -- high and low parts -- on with two broadcasts (the reference walks the owners
+// sequentially with b in shared memory, src:226-230).  Back substitution: every rank accumulates -R[i, j] x[j] over ITS
+// columns j into a double-double vector u; per panel one all-reduce GATHERS the ranks' 64 partial dots (every rank fills
+// its own slot of a P-slot buffer, so the sum is exact) -- the reference's sum(fetch.(futures)), src:262-266 -- the
+// owner adds them in double-double, solves the diagonal block (division by alpha, src:267) and broadcasts x.
+// du: 3 m + 192 + 128 P complex of scratch.
+static inline int64_t zcs_solve_work(int64_t m, int P) { return 3 * m + 192 + 128 * (int64_t)P; }
 static int32_t zcs_solve(dhqr_ctx *c, dhqr_comm *cm_, const double *A_, int64_t m, int64_t n, int64_t lda, const double *alpha_,
                          double *db_, double *du_) {
   const int P = cm_ ? cm_->nranks : 1, r = cm_ ? cm_->rank : 0;
   dhqr_comm *cm = P > 1 ? cm_ : nullptr;
   const int64_t ZB = DHQR_ZNB, K = zcs_npanels(n);
   const double2 *A = reinterpret_cast<const double2 *>(A_), *al = reinterpret_cast<const double2 *>(alpha_);
-  double2 *b = reinterpret_cast<double2 *>(db_), *u = reinterpret_cast<double2 *>(du_);
-  double2 *ds = u + m;  // 64 partial dots
+  double2 *bh = reinterpret_cast<double2 *>(db_);
+  double2 *uh = reinterpret_cast<double2 *>(du_), *ul = uh + (m + ZB), *bl = ul + (m + ZB), *gath = bl + (m + ZB);
   hipStream_t st = c->stream;
   auto sync_local = [&]() -> int32_t {  // LOCAL transport: peers read the root's buffer directly
     if (cm && cm->kind == COMM_LOCAL) {
@@ -190,6 +221,7 @@ static int32_t zcs_solve(dhqr_ctx *c, dhqr_comm *cm_, const double *A_, int64_t 
   auto width = [&](int64_t k) { return std::min<int64_t>(ZB, n - k * ZB); };
   auto mine = [&](int64_t k) { return (int)(k % P) == r; };
   CHECK(prof_begin(c, CAT_SOLVE));
+  HIPCHECK(hipMemsetAsync(du_, 0, (size_t)zcs_solve_work(m, P) * 2 * sizeof(double), st));  // u = 0, bl = 0
   for (int64_t k = 0; k < K; ++k) {  // b <- Q' b (src:232-242), panel by panel
     const int64_t c0 = k * ZB, w = width(k);
     if (mine(k)) {
@@ -197,44 +229,52 @@ static int32_t zcs_solve(dhqr_ctx *c, dhqr_comm *cm_, const double *A_, int64_t 
       for (int64_t jj = 0; jj < w; ++jj) {
         const int64_t j = c0 + jj;
         if (m - j <= 2048)
-          hipLaunchKernelGGL((k_zqtb_col<256>), dim3(1), dim3(256), 0, st, Pk + jj * lda, b, m, j);
+          hipLaunchKernelGGL((k_zqtb_col_dd<256>), dim3(1), dim3(256), 0, st, Pk + jj * lda, bh, bl, m, j);
         else
-          hipLaunchKernelGGL((k_zqtb_col<1024>), dim3(1), dim3(1024), 0, st, Pk + jj * lda, b, m, j);
+          hipLaunchKernelGGL((k_zqtb_col_dd<1024>), dim3(1), dim3(1024), 0, st, Pk + jj * lda, bh, bl, m, j);
       }
     }
     if (cm) {
       CHECK(comm_bcast(cm, db_ + 2 * c0, 2 * (m - c0), (int)(k % P), st, nullptr));
       CHECK(sync_local());
+      CHECK(comm_bcast(cm, reinterpret_cast<double *>(bl + c0), 2 * (m - c0), (int)(k % P), st, nullptr));
+      CHECK(sync_local());
     }
   }
-  HIPCHECK(hipMemsetAsync(du_, 0, (size_t)(m + ZB) * 2 * sizeof(double), st));
   for (int64_t k = K - 1; k >= 0; --k) {  // src:256-270
     const int64_t c0 = k * ZB, w = width(k);
-    if (cm) {
-      HIPCHECK(hipMemcpyAsync(ds, u + c0, (size_t)w * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
-      CHECK(comm_allreduce_sum(cm, reinterpret_cast<double *>(ds), 2 * w, st));
+    if (cm) {  // gather the ranks' partial dots of rows [c0, c0 + w): slot r = (hi parts | lo parts), zeros elsewhere
+      HIPCHECK(hipMemsetAsync(gath, 0, (size_t)P * 2 * w * sizeof(double2), st));
+      HIPCHECK(hipMemcpyAsync(gath + (int64_t)r * 2 * w, uh + c0, (size_t)w * sizeof(double2), hipMemcpyDeviceToDevice, st));
+      HIPCHECK(hipMemcpyAsync(gath + (int64_t)r * 2 * w + w, ul + c0, (size_t)w * sizeof(double2), hipMemcpyDeviceToDevice, st));
+      CHECK(comm_allreduce_sum(cm, reinterpret_cast<double *>(gath), (int64_t)P * 4 * w, st));
     }
     const double2 *base = A + ((k / P) * ZB - c0) * lda;  // global column j of R is read at base + j * lda
     if (mine(k)) {
-      hipLaunchKernelGGL(k_axpy1, dim3(1), dim3(128), 0, st, db_ + 2 * c0, reinterpret_cast<const double *>(cm ? ds : u + c0),
-                         (int)(2 * w));
+      if (cm) {
+        hipLaunchKernelGGL(k_zdd_accumulate, dim3(1), dim3(64), 0, st, bh + c0, bl + c0, (const double2 *)gath, P, (int)w);
+      } else {  // one rank: its own partial dots, straight from u (slot layout: hi parts at uh, lo parts at ul)
+        HIPCHECK(hipMemcpyAsync(gath, uh + c0, (size_t)w * sizeof(double2), hipMemcpyDeviceToDevice, st));
+        HIPCHECK(hipMemcpyAsync(gath + w, ul + c0, (size_t)w * sizeof(double2), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_zdd_accumulate, dim3(1), dim3(64), 0, st, bh + c0, bl + c0, (const double2 *)gath, 1, (int)w);
+      }
       for (int64_t hi = c0 + w; hi > c0; hi -= ZBS_NB) {
         const int64_t lo = std::max<int64_t>(c0, hi - ZBS_NB);
-        hipLaunchKernelGGL(k_zbacksub_diag, dim3(1), dim3(64), 0, st, base, lda, al, b, lo, hi);
+        hipLaunchKernelGGL(k_zbacksub_diag_dd, dim3(1), dim3(64), 0, st, base, lda, al, bh, bl, lo, hi);
         if (lo > c0)
-          hipLaunchKernelGGL(k_zbacksub_update_rows, dim3((unsigned)((lo - c0 + 255) / 256)), dim3(256), 0, st, base, lda,
-                             (const double2 *)b, b, c0, lo, lo, hi);
+          hipLaunchKernelGGL(k_zbacksub_update_rows_dd, dim3((unsigned)((lo - c0 + 255) / 256)), dim3(256), 0, st, base, lda,
+                             (const double2 *)bh, bh, bl, c0, lo, lo, hi);
       }
     }
     if (cm) {
-      CHECK(comm_bcast(cm, db_ + 2 * c0, 2 * w, (int)(k % P), st, nullptr));
+      CHECK(comm_bcast(cm, db_ + 2 * c0, 2 * w, (int)(k % P), st, nullptr));  // x (its low part is zero)
       CHECK(sync_local());
     }
     if (mine(k) && c0 > 0)
       for (int64_t hi = c0 + w; hi > c0; hi -= ZBS_NB) {
         const int64_t lo = std::max<int64_t>(c0, hi - ZBS_NB);
-        hipLaunchKernelGGL(k_zbacksub_update_rows, dim3((unsigned)((c0 + 255) / 256)), dim3(256), 0, st, base, lda,
-                           (const double2 *)b, u, (int64_t)0, c0, lo, hi);
+        hipLaunchKernelGGL(k_zbacksub_update_rows_dd, dim3((unsigned)((c0 + 255) / 256)), dim3(256), 0, st, base, lda,
+                           (const double2 *)bh, uh, ul, (int64_t)0, c0, lo, hi);
       }
   }
   CHECK(prof_end(c));

@@ -344,8 +344,10 @@ int32_t dhqr_cs_ldiv_darray_f64(dhqr_comm *comm, const double *hBlock, int64_t m
  * high-priority stream.
  * Every rank of the communicator must make the call.  Asynchronous on the context's stream like dhqr_factor_c64_nb.
  *   dhqr_cs_solve_c64      solve_householder!(b, H, alpha) (src:226-282) on the cyclic layout: db (m complex, identical on
- *                          every rank) is overwritten, x = db[0:n] on every rank; dwork: m + 64 complex.  Q'b: one
- *                          broadcast of b's tail per panel; back substitution: one all-reduce of the 64 partial dots
+ *                          every rank) is overwritten, x = db[0:n] on every rank; dwork: dhqr_cs_solve_work_c64(m, P)
+ *                          complex.  b is carried in double-double (the reference's acceptance statistic sees the
+ *                          solve's rounding).  Q'b: two broadcasts of b's tail (high / low parts) per panel; back
+ *                          substitution: one all-reduce that gathers the ranks' 64 partial dots
  *                          (sum(fetch.(futures)), src:262-266) + one broadcast of the solved block per panel.
  *   dhqr_cs_qr_darray_c64  qr!(A::DArray{ComplexF64}) for one process: its CONTIGUOUS host column block
  *                          (dhqr_cs_contiguous_range) in, factored block + alpha out; synchronous.
@@ -355,6 +357,7 @@ int32_t dhqr_cs_ldiv_darray_f64(dhqr_comm *comm, const double *hBlock, int64_t m
  *   dhqr_mg_ldiv_c64 `H \ b` for the host-format result over the same devices (dhqr_cs_solve_c64 inside). */
 int64_t dhqr_cs_local_cols_c64(int64_t n, int32_t nranks, int32_t rank);
 int32_t dhqr_cs_factor_c64(dhqr_comm *comm, double *dA, int64_t m, int64_t n, int64_t lda, double *dalpha);
+int64_t dhqr_cs_solve_work_c64(int64_t m, int32_t nranks);
 int32_t dhqr_cs_solve_c64(dhqr_comm *comm, const double *dA, int64_t m, int64_t n, int64_t lda,
                           const double *dalpha, double *db, double *dwork);
 int32_t dhqr_cs_qr_darray_c64(dhqr_comm *comm, double *hBlock, int64_t m, int64_t n, int64_t ldb, double *halpha);

@@ -423,6 +423,8 @@ inline hipError_t hipMalloc(void **p, size_t bytes) {
 }
 inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+typedef void (*hipHostFn_t)(void *);
+inline hipError_t hipLaunchHostFunc(hipStream_t, hipHostFn_t fn, void *arg) { fn(arg); return hipSuccess; }  // streams run synchronously here
 inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) {

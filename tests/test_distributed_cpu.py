@@ -281,7 +281,7 @@ def _darray_c64(rank, P, m, n, so):
     # test/runtests.jl:43 x :78 runs `qrA \ b` for ComplexF64 DArrays): on the cyclic layout ...
     b = orc.rand_vector_c(m, 62)
     xo = orc.solve_c(Ho, ao, b)
-    db, work = b.copy(), np.zeros(m + 64, dtype=complex)
+    db, work = b.copy(), np.zeros(L.dhqr_cs_solve_work_c64(m, P), dtype=complex)
     rc = L.dhqr_cs_solve_c64(comm.handle, loc.ctypes.data_as(ctypes.c_void_p), m, n, m, al.ctypes.data_as(ctypes.c_void_p),
                              db.ctypes.data_as(ctypes.c_void_p), work.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0, L.dhqr_last_error()

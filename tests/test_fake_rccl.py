@@ -213,15 +213,15 @@ def test_complex_column_split_over_rccl(rk, orc, ndev, m, n, algo):
     assert L.dhqr_qr_c64_nb(h1, _ptr(A1), m, n, m, _ptr(al1), 64) == 0, L.dhqr_last_error()
     assert np.abs(A1 - A).max() <= 1e-13 * scale
     L.dhqr_destroy(h1)
-    # `H \ b` over the same ranks (dhqr_mg_ldiv_c64 -> zcs_solve): per panel one broadcast of b's tail (Q'b), one all-reduce
-    # of the partial dots and one broadcast of the solved block (back substitution), src:226-282
+    # `H \ b` over the same ranks (dhqr_mg_ldiv_c64 -> zcs_solve, b in double-double): per panel two broadcasts of b's tail
+    # (high / low parts, Q'b), one all-reduce gathering the partial dots and one broadcast of the solved block, src:226-282
     b, x = orc.rand_vector_c(m, 22), np.zeros(n, dtype=complex)
     bk = b.copy()
     _stats(F)
     assert L.dhqr_mg_ldiv_c64(h, _ptr(A), m, n, m, _ptr(al), _ptr(b), _ptr(x)) == 0, L.dhqr_last_error()
     s2 = _stats(F)
     np_ = (n + 63) // 64
-    assert s2["allreduce"] == ndev * np_ and s2["bcast"] + s2["allgather"] == ndev * 2 * np_, s2
+    assert s2["allreduce"] == ndev * np_ and s2["bcast"] + s2["allgather"] == ndev * 3 * np_, s2
     assert s2["timeouts"] == 0 and s2["mismatches"] == 0
     xo = orc.solve_c(Ho, ao, bk)
     assert np.array_equal(b, bk) and np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()

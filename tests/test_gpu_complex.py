@@ -128,39 +128,31 @@ def _gpu_statistic(pkg, A, b, nb):
 
 
 def _check_against_reference_bound(pkg, orc, m, n, seed, nb):
-    """test/runtests.jl:62 for one draw, residuals in double as written there.  Measured (profiles/r04_c64_ratio_table.json, the
-    five draws of 4400 x 4000 on the GPU box; extended-precision evaluation changes the numbers by a few per cent, so the
-    statistic is a property of x, not evaluation noise): the statistic of the restated reference (the ORACLE) is 4.0e-10 ...
-    9.1e-10, of the GPU paths 1.1e-10 ... 12e-10 (means 6.2 / 4.3 (nb 0) / 5.5 (nb 64) e-10), of LAPACK 0.6e-10 ... 5.0e-10:
-    the bound `< 8 stdliberr` divides by a number that moves 9 x between draws (and with the host BLAS' thread count: 12 x
-    between this container and the GPU box on the same draw), and the restated reference itself scores up to 7.8 there
-    and 8.8 / 15.6 on another host.  So: shapes below 2000 columns assert the literal bound; the two largest assert that
-    the GPU path is never more than 4 x the restated reference's own statistic on the same draw (the yardstick that does not
-    depend on LAPACK's luck) and return the literal ratios for the record."""
+    """test/runtests.jl:62 LITERALLY for one draw: norm(A' * A * x2 .- A' * b) < 8 stdliberr, residuals in double as written
+    there -- asserted for every shape and draw since round 4.  Round 3 needed medians and an extended-precision evaluator
+    here; what the measurements of this round showed (profiles/r04_c64_ratio_table_*.txt, the five draws of 4400 x 4000):
+      * the statistic is a property of x, not evaluation noise (extended-precision evaluation moves it by a few per cent);
+      * the bound divides by LAPACK's own statistic, which moves 9 x between draws, and the ORACLE -- the reference's algorithm
+        restated on the CPU -- itself scores 1.8 ... 7.8 x LAPACK on the GPU box's host and 8.8 / 15.6 on another host
+        (profiles/r04_c64_oracle_ratio_cpu_container.json): the reference does not meet its own bound on every draw;
+      * with a plain-double solve the GPU paths scored like the oracle (0.2 ... 14 x LAPACK), and the ORACLE'S solve on the
+        GPU's factor scored half of that: the O(mn) solve, not the O(mn^2) factorisation, dominated.  With b carried in
+        double-double through Q'b and the back substitution (k_zqtb_col_dd, k_zbacksub_*_dd) the GPU paths score 0.09 ...
+        1.2 x LAPACK on the same draws.
+    For the two largest shapes the restated reference's score on the same draw is printed beside the GPU's, and the GPU's
+    statistic must not exceed it."""
     big = n >= 2000
     A, b, stdliberr, oerr = _draw(orc, m, n, seed, with_oracle=big)
     gerr = _gpu_statistic(pkg, A, b, nb)
     ratio = gerr / stdliberr
-    if not big:
+    if big:
+        print(f"{m}x{n} seed {seed} nb={nb}: GPU {gerr:.2e} = {ratio:.2f} x LAPACK, restated reference (oracle) {oerr:.2e} = "
+              f"{oerr / stdliberr:.2f} x LAPACK (bound 8)")
+        assert gerr < oerr, (gerr, oerr)
+    else:
         print(f"{m}x{n} seed {seed} nb={nb}: ratio {ratio:.2f} (reference bound 8)")
-        assert ratio < 8, ratio
-        return ratio, None, gerr, None
-    oratio = oerr / stdliberr
-    print(f"{m}x{n} seed {seed} nb={nb}: GPU {gerr:.2e} = {ratio:.2f} x LAPACK, restated reference (oracle) {oerr:.2e} = {oratio:.2f} x LAPACK (bound 8)")
-    assert gerr < 4.0 * oerr, (gerr, oerr)
-    return ratio, oratio, gerr, oerr
-
-
-def _check_draws(pkg, orc, m, n, seeds, nb):
-    """several draws of one shape: every draw as above, and over the draws the GPU path's statistic must not exceed the
-    restated reference's by more than 1.5 x in the sum (single draws scatter by 3 x either way)"""
-    res = [_check_against_reference_bound(pkg, orc, m, n, seed, nb) for seed in seeds]
-    if n >= 2000:
-        gs, os_ = sum(r[2] for r in res), sum(r[3] for r in res)
-        print(f"{m}x{n} nb={nb}: sum over {len(res)} draws GPU {gs:.2e}, restated reference {os_:.2e}; literal ratios "
-              f"{[round(r[0], 2) for r in res]} (oracle {[round(r[1], 2) for r in res]})")
-        assert gs < 1.5 * os_, (gs, os_)
-    return res
+    assert ratio < 8, ratio
+    return ratio
 
 
 @pytest.mark.parametrize("m,n", REF_SHAPES)
@@ -173,21 +165,19 @@ def test_reference_single_draw_seed0_default_path(pkg, orc, m, n):
 
 @pytest.mark.parametrize("seed", [0, 2, 4, 6, 8])
 @pytest.mark.parametrize("nb", [0, 64])
-def test_reference_single_draws_largest_shape_recorded(pkg, orc, seed, nb):
-    """every draw of the reference's largest shape as its own check, both paths (nb = 0: the reference's operation order;
-    nb = 64: blocked).  A draw on which the GPU path misses the literal `< 8` is recorded as xfail(strict=False) WITH the
-    restated reference's score on the same draw -- the record shows whether the miss is the reference's own."""
-    ratio, oratio, _, _ = _check_against_reference_bound(pkg, orc, 4400, 4000, seed, nb)
-    if not ratio < 8:
-        pytest.xfail(f"seed {seed} nb={nb}: GPU ratio {ratio:.2f} >= 8; the restated reference scores {oratio:.2f} on this draw")
+def test_reference_single_draws_largest_shape(pkg, orc, seed, nb):
+    """every draw of the reference's largest shape as its own literal `< 8` check, both paths (nb = 0: the reference's
+    operation order; nb = 64: blocked).  Round 3 recorded two of these ten as xfail; none is left."""
+    _check_against_reference_bound(pkg, orc, 4400, 4000, seed, nb)
 
 
 @pytest.mark.parametrize("m,n", REF_SHAPES)
 def test_reference_acceptance_inequality_complex(pkg, orc, m, n):
     """test/runtests.jl:42-63 with T = ComplexF64 and x from the GPU path in the reference's operation order (nb = 0;
     the blocked default has its own test below), residuals in double as the reference evaluates them.  Shapes with
-    n >= 2000: five draws against the restated reference's own statistic (see _check_against_reference_bound)."""
-    _check_draws(pkg, orc, m, n, (0, 2, 4, 6, 8) if n >= 2000 else (0,), 0)
+    n >= 2000: three draws, each against the literal bound."""
+    for seed in ((0, 2, 4) if n >= 2000 else (0,)):
+        _check_against_reference_bound(pkg, orc, m, n, seed, 0)
     if n >= 2000:
         # largest shapes: pin the GPU factor (last seed) against LAPACK zgeqrf directly (rows of R equal up to the
         # unit phase of alpha_j, see tests/test_oracle_complex.py)
@@ -276,7 +266,7 @@ def test_complex_column_split_logical_ranks_one_gpu(pkg, orc, ranks, m, n):
             mg.ldiv(H, alpha, b)
             c1 = mg.comm_counters(0)
             npan = (n + 63) // 64
-            assert c1["n_bcast"] - c0["n_bcast"] == 2 * npan and c1["n_allreduce"] - c0["n_allreduce"] == npan, (c0, c1)
+            assert c1["n_bcast"] - c0["n_bcast"] == 3 * npan and c1["n_allreduce"] - c0["n_allreduce"] == npan, (c0, c1)
         # a second factorisation on the same handle gives the same bits (buffers, events, mailboxes reused)
         A2 = np.asfortranarray(A0.copy())
         H2, alpha2 = mg.qr_(A2)
@@ -346,12 +336,47 @@ def test_complex_darray_qr_and_ldiv_logical_ranks_one_gpu(pkg, orc, ranks, m, n)
         assert np.array_equal(xs[r], xs[0])
 
 
+@pytest.mark.parametrize("dtype", ["complex128", "float64"])
+@pytest.mark.parametrize("ranks,m,n,seed", [(2, 440, 400, 0), (3, 1100, 1000, 0), (2, 4400, 4000, 0), (3, 4400, 4000, 8)])
+def test_reference_distributed_acceptance(pkg, orc, dtype, ranks, m, n, seed):
+    """test/runtests.jl:71-82, the reference's "distributed + threaded" check, LITERALLY: A3 = DArray of A over the workers
+    (contiguous column blocks), qrA = qr!(A3), x3 = qrA \\ b, norm(A' * A * x3 .- A' * b) < 8 stdliberr -- for T in (Float64,
+    ComplexF64) through the entry points a Julia worker binds (dhqr_cs_qr_darray_*, dhqr_cs_ldiv_darray_*), `ranks` rank
+    threads sharing cuda:0 (callback transport)"""
+    import ctypes
+    from dist_helpers import gpu_thread_ranks
+    cplx = dtype == "complex128"
+    A = orc.rand_matrix_c(m, n, seed) if cplx else orc.rand_matrix(m, n, seed)
+    b = orc.rand_vector_c(m, seed + 1) if cplx else orc.rand_vector(m, seed + 1)
+    q, r = np.linalg.qr(A)
+    x1 = sl.solve_triangular(r, q.conj().T @ b)
+    stdliberr = _normal_residual(A, x1, b)
+
+    def rank_fn(rank, comm, L):
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        L.dhqr_cs_contiguous_range(n, ranks, rank, ctypes.byref(lo), ctypes.byref(hi))
+        blk = np.array(A[:, lo.value:hi.value], order="F")
+        if cplx:
+            al = pkg.qr_darray_c64_(blk, m, n, comm)
+        else:
+            al = np.zeros(n)
+            rc = L.dhqr_cs_qr_darray_f64(comm.handle, blk.ctypes.data_as(ctypes.c_void_p), m, n, m, al.ctypes.data_as(ctypes.c_void_p))
+            assert rc == 0, L.dhqr_last_error()
+        return pkg.ldiv_darray_(blk, m, n, al, b, comm)
+
+    xs = gpu_thread_ranks(ranks, rank_fn)
+    ratio = _normal_residual(A, xs[0], b) / stdliberr
+    print(f"distributed {dtype} {m}x{n} over {ranks} ranks, seed {seed}: ratio {ratio:.2f} (reference bound 8)")
+    assert ratio < 8, ratio
+
+
 @pytest.mark.parametrize("m,n", REF_SHAPES)
 def test_reference_acceptance_inequality_complex_blocked(pkg, orc, m, n):
-    """test/runtests.jl:42-63 with T = ComplexF64 through the BLOCKED path (host drop-in, nb = 64), residuals in DOUBLE as
-    the reference evaluates them (round 3 needed an extended-precision evaluator and a median here; with the restated
-    reference's score on the same draw as the yardstick neither is needed).  Shapes with n >= 2000: five draws."""
-    _check_draws(pkg, orc, m, n, (0, 2, 4, 6, 8) if n >= 2000 else (0,), 64)
+    """test/runtests.jl:42-63 with T = ComplexF64 through the BLOCKED path (host drop-in, nb = 64): the literal bound,
+    residuals in DOUBLE as the reference evaluates them (round 3 needed an extended-precision evaluator and a median here).
+    Shapes with n >= 2000: five draws."""
+    for seed in ((0, 2, 4, 6, 8) if n >= 2000 else (0,)):
+        _check_against_reference_bound(pkg, orc, m, n, seed, 64)
 
 
 def test_zero_pivot_complex(pkg, orc):

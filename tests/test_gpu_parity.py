@@ -519,6 +519,42 @@ def test_row_split_driver_single_rank(pkg, orc, m, n):
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
 
 
+def test_row_split_full_size_properties(pkg):
+    """BASELINE configs[4] at its FULL shape, 262144 x 4096, through the row-split driver at world size 1 (every all-reduce
+    issued, moving nothing): size-independent properties -- ||A-QR||/||A|| < 1e-12 and ||v_j||^2 == 2 for every column"""
+    import torch
+    m, n = 262144, 4096
+    q = pkg.RowSplitQR(m, n)
+    q.fill(0)
+    q.factor()
+    torch.cuda.synchronize()
+    v2 = torch.cat([torch.tril(q.A[:, c:c + 512], diagonal=-c).pow(2).sum(dim=0) for c in range(0, n, 512)])
+    assert (v2 - 2.0).abs().max().item() < 1e-11
+    assert q.residual(0) < 1e-12
+    cnt = q.comm.counters()
+    assert cnt["n_allreduce"] >= n // 128  # the cross-partition partial dots: at least a Gram matrix per panel
+
+
+def test_column_split_full_size_eight_logical_ranks(pkg):
+    """BASELINE configs[3] at its FULL size, 32768 x 32768 over 8 ranks -- here 8 rank threads sharing cuda:0 (peer-copy
+    transport; every stream, event and mailbox of the 8-GPU program live): ||A-QR||/||A|| < 1e-12, every panel on the
+    device-verified fast path, one broadcast per panel"""
+    n = 32768
+    mg = pkg.MultiGpuQR(devices=[0] * 8)
+    try:
+        mg.alloc(n, n).fill(0)
+        c0 = mg.comm_counters(0)
+        mg.factor()
+        c1 = mg.comm_counters(0)
+        assert n // 128 - 1 <= c1["n_bcast"] - c0["n_bcast"] <= n // 128  # ONE broadcast per panel (src:141-143: one per column and process)
+        assert mg.residual(0) < 1e-12
+        fast = sum(mg.stats(r)["panels_fast"] for r in range(8))
+        fb = sum(mg.stats(r)["panels_fallback"] for r in range(8))
+        assert fb == 0 and fast >= n // 128 - 2, (fast, fb)
+    finally:
+        mg.close()
+
+
 @pytest.mark.parametrize("ranks,m,n,tsqr", [(2, 6000, 512, 0), (2, 16384, 1024, 0), (8, 16384, 2048, 0), (3, 3000, 1100, 0),
                                             (2, 6000, 512, 1), (8, 16384, 1024, 1), (3, 3000, 1100, 1)])
 def test_row_split_logical_ranks_one_gpu(pkg, orc, ranks, m, n, tsqr, monkeypatch):
@@ -572,8 +608,10 @@ def test_row_split_rejected_panel_gpu(pkg, orc, rung, monkeypatch):
 
 
 @pytest.mark.parametrize("m,n", [(300, 128), (1000, 333)])
-def test_explicit_q_and_r(pkg, m, n):
-    """get_r / get_q: R upper triangular with diag == alpha, Q'Q == I, Q R == A"""
+def test_explicit_q_and_r(pkg, orc, m, n):
+    """get_r / get_q / apply_q_: R upper triangular with diag == alpha, Q'Q == I, Q R == A -- and
+    element by element against the oracle: Q = the reference's reflectors applied to [I; 0] (orc.form_qr of the reflectors
+    with R = I), apply_q_ on [R; 0] = the oracle's Q R"""
     import torch
     A = pkg.rand_colmajor(m, n, 9, "cuda:0")
     A0 = A.clone()
@@ -586,6 +624,20 @@ def test_explicit_q_and_r(pkg, m, n):
     eye = torch.eye(n, dtype=torch.float64, device="cuda:0")
     assert (Q.t() @ Q - eye).abs().max().item() < 1e-12
     assert ((Q @ R - A0).norm() / A0.norm()).item() < 1e-12
+    Ho, ao = orc.householder(A0.cpu().numpy())
+    Ro = np.triu(Ho, 1)[:n] + np.diag(ao)
+    assert np.abs(R.cpu().numpy() - Ro).max() <= TOL(Ho) * np.abs(Ro).max()
+    Qo = orc.form_qr(np.asfortranarray(np.tril(Ho)), np.ones(n))  # H_1 ... H_n [I; 0] in the reference's order
+    assert np.abs(Q.cpu().numpy() - Qo).max() <= TOL(Ho)
+    B = pkg.empty_colmajor(m, n, "cuda:0")
+    B.zero_()
+    B[:n] = R
+    pkg.apply_q_(H, B, trans=False)  # Q [R; 0]
+    QRo = orc.form_qr(Ho, ao)
+    assert np.abs(B.cpu().numpy() - QRo).max() <= TOL(Ho) * np.abs(QRo).max()
+    pkg.apply_q_(H, B, trans=True)   # Q' (Q [R; 0]) = [R; 0]
+    Bn = B.cpu().numpy()
+    assert np.abs(Bn[:n] - Ro).max() <= TOL(Ho) * np.abs(Ro).max() and np.abs(Bn[n:]).max() <= TOL(Ho) * np.abs(Ro).max()
 
 
 def test_panel_kernels_keep_every_panel_on_the_fast_path(pkg, orc):

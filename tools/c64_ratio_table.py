@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--seeds", type=int, nargs="+", default=[0, 2, 4, 6, 8])
     ap.add_argument("--shape", type=int, nargs=2, default=[4400, 4000])
     ap.add_argument("--out", default=None)
+    ap.add_argument("--real", action="store_true", help="Float64 instead of ComplexF64 (nb = 0 / 128)")
     a = ap.parse_args()
     pkg = g.import_package()
     orc.build()
@@ -45,14 +46,24 @@ def main():
     rows = []
     for s in a.seeds:
         t0 = time.time()
-        A = orc.rand_matrix_c(m, n, s)
-        b = orc.rand_vector_c(m, s + 1)
+        A = orc.rand_matrix(m, n, s).astype(complex) if a.real else orc.rand_matrix_c(m, n, s)
+        b = orc.rand_vector(m, s + 1).astype(complex) if a.real else orc.rand_vector_c(m, s + 1)
         Ar, Ai = A.real.astype(np.longdouble), A.imag.astype(np.longdouble)
         q, r = np.linalg.qr(A)
         xs = {"lapack": sl.solve_triangular(r, q.conj().T @ b)}
-        Ho, ao = orc.householder_c(A.copy(order="F"))
-        xs["oracle"] = orc.solve_c(Ho, ao, b)
-        for nb in (0, 64):
+        if a.real:
+            Ar_ = np.asfortranarray(A.real)
+            Ho, ao = orc.householder(Ar_.copy(order="F"))
+            xs["oracle"] = orc.solve(Ho, ao, b.real.copy()).astype(complex)
+        else:
+            Ho, ao = orc.householder_c(A.copy(order="F"))
+            xs["oracle"] = orc.solve_c(Ho, ao, b)
+        for nb in ((0, 128) if a.real else (0, 64)):
+            if a.real:
+                H = pkg.qr_(Ar_.copy(order="F"), nb=nb)
+                xs[f"gpu_nb{nb}"] = np.asarray(pkg.ldiv(H, b.real.copy())).astype(complex)
+                xs[f"gpu_nb{nb}_factor_oracle_solve"] = orc.solve(np.asfortranarray(np.asarray(H.A)), np.asarray(H.α), b.real.copy()).astype(complex)
+                continue
             H = pkg.qr_(A.copy(order="F"), nb=nb)
             xs[f"gpu_nb{nb}"] = np.asarray(pkg.ldiv(H, b))
             # the oracle's solve on the GPU's factor: separates the factorisation's share from the solve's
