@@ -534,6 +534,28 @@ def also_unblocked(pkg, torch, ctx, dev, steps=3, warmup=1, n=8192):
             "reflectors_per_pass": 16.0 * sum((m - j) * (n - j - 1) for j in range(n)) * steps / st["bytes_rank1"] if st["bytes_rank1"] > 0 else None}
 
 
+def host_in_out(pkg, torch, dev, m, n, reps=2):
+    """the PCIe-inclusive drop-in call `qr!(A::Matrix)` = dhqr_qr_f64 on a HOST matrix (pageable numpy memory, as a Julia
+    Matrix would be): staged upload, factorisation, every column block downloaded behind its panel's commit
+    (csrc/dhqr_hostio.h).  Reported beside the device-resident time; never the headline `value`."""
+    import numpy as np
+    Ad = pkg.rand_colmajor(m, n, 0, dev)
+    A0 = Ad.cpu().numpy()           # column-major view of the same synthetic input, on the host
+    del Ad
+    torch.cuda.empty_cache()
+    if not A0.flags.f_contiguous:
+        A0 = np.asfortranarray(A0)
+    ts = []
+    for _ in range(reps + 1):       # the first call also allocates the pinned staging buffers
+        A = A0.copy(order="F")
+        t0 = time.perf_counter()
+        H = pkg.qr_(A, nb=128)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    v2 = float((H.A[n // 2:, n // 2] ** 2).sum())
+    return {"ms": min(ts[1:]), "first_call_ms": ts[0], "calls": reps, "gflops": flops_qr(m, n) / (min(ts[1:]) / 1e3) / 1e9,
+            "check_v_norm2": v2, "note": "wall time of dhqr_qr_f64 on pageable host memory (upload + factorisation + download overlapped)"}
+
+
 def also_tallskinny(pkg, torch, steps=3, warmup=1, m=262144, n=4096):
     """BASELINE configs[4] at world size 1 beside the headline line: the row-split driver (all-reduces issued and counted,
     moving nothing at one rank) on the full 262144 x 4096 shape"""
@@ -845,6 +867,13 @@ def main():
                 except Exception as e:  # never takes the headline line down
                     out["also"].append({"config": {"workload": what}, "error": repr(e)[:300]})
                 torch.cuda.empty_cache()
+            try:
+                progress("host-in / host-out call")
+                out["host_in_out"] = host_in_out(pkg, torch, dev, m, n)
+                out["host_in_out_ms"] = out["host_in_out"]["ms"]
+            except Exception as e:
+                out["host_in_out"] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, n)
             out["cpu_baseline"]["distributed_structure"] = cpu_baseline_distributed()

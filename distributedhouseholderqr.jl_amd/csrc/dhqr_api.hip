@@ -1,6 +1,7 @@
 // dhqr_api.hip -- host side of libdhqr.so: context, workspaces, panel/trailing-update drivers and
 // the extern "C" entry points declared in include/dhqr.h.  gfx950 only; no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <climits>
@@ -55,6 +56,7 @@ struct dhqr_ctx {
   hipStream_t own = nullptr, stream = nullptr;
   bool profiling = false;
   hipStream_t hi = nullptr;      // high-priority stream: panel factorisation under look-ahead
+  int tn_streamk = 1;            // wide k_gemm_tn2 launches: stream-K decomposition (DHQR_TN_STREAMK=0: column-tile x row-slab units + the round model)
   int tn_model_min_tiles = 128;  // wide k_gemm_tn2 launches of at least this many column tiles: split-K factor from the round / partial-traffic estimate (below, the lane is the critical path and
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
   int rankk_wgs = 256;           // ... bulk workgroups of 1024 threads resident at once (CU count; DHQR_RANKK_WGS)
@@ -74,6 +76,7 @@ struct dhqr_ctx {
   bool lookahead = true;
   Buf vbuf, vt, vts, spart, sfull, scratch, pbuf;
   Buf zsolve_lo;         // low parts of the double-double right-hand side of the ComplexF64 solve
+  Buf host_mat;          // device copy of the caller's HOST matrix (+ alpha) of dhqr_qr_f64, kept between calls
   int pair = 1;                  // 1: wide updates apply two panels per pass (DHQR_PAIR=0 disables)
   int64_t pair_min_n = 12288;    // below this the longer look-ahead lane of the pair driver costs more than it saves (profiles/r02_ab_pair_tail_and_threshold.txt)
   int panel_impl = 3;  // 3: R-first (CholeskyQR + reconstruction, dhqr_recon.h) with fallback to 2;
@@ -934,13 +937,27 @@ static int32_t pair_vtc(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows
   }
   dhqr_ctx::WS &ws = c->ws[c->cur_ws];
   const int64_t ld2 = 2 * DHQR_NBV, wstride = ld2 * ncols;
+  if (c->tn_streamk && ntiles >= c->tn_model_min_tiles && ntiles <= 1024 && rows >= 1024) {
+    // stream-K (k_gemm_tn2<.., true>): 128-row fine units numbered tile-major, a contiguous range per workgroup
+    const int64_t FU = 128, S = (rows + FU - 1) / FU, U = ntiles * S;
+    const int64_t G = std::min<int64_t>(U, slots), q = (U + G - 1) / G, Gq = (U + q - 1) / q;
+    const int64_t pieces = (q >= S) ? 2 : (S + q - 1) / q + 1;
+    CHECK(ensure(c, ws.w1, (size_t)pieces * (size_t)wstride));
+    if (vec)
+      hipLaunchKernelGGL((k_gemm_tn2<2, true>), dim3((unsigned)Gq), dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, FU, ws.w1.p, wstride, q);
+    else
+      hipLaunchKernelGGL((k_gemm_tn2<1, true>), dim3((unsigned)Gq), dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, FU, ws.w1.p, wstride, q);
+    hipLaunchKernelGGL(k_reduce_pieces, dim3((unsigned)((wstride + 255) / 256)), dim3(256), 0, c->stream, (const double *)ws.w1.p, S, q,
+                       wstride, wstride, Y);
+    return DHQR_OK;
+  }
   CHECK(ensure(c, ws.w1, (size_t)nsplit * (size_t)wstride));
   // k_gemm_tn2 is persistent: its workgroups loop over the (column tile, row slab) units
   const dim3 gtn((unsigned)std::min<int64_t>(ntiles * nsplit, slots)), gred((unsigned)((wstride + 63) / 64));
   if (vec)
-    hipLaunchKernelGGL((k_gemm_tn2<2>), gtn, dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, rps, ws.w1.p, wstride);
+    hipLaunchKernelGGL((k_gemm_tn2<2>), gtn, dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, rps, ws.w1.p, wstride, (int64_t)0);
   else
-    hipLaunchKernelGGL((k_gemm_tn2<1>), gtn, dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, rps, ws.w1.p, wstride);
+    hipLaunchKernelGGL((k_gemm_tn2<1>), gtn, dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, rps, ws.w1.p, wstride, (int64_t)0);
   hipLaunchKernelGGL(k_reduce_splits, gred, dim3(256), 0, c->stream, (const double *)ws.w1.p, (int)nsplit, wstride, wstride, Y);
   return DHQR_OK;
 }
@@ -1091,7 +1108,7 @@ static int32_t quad_cross_gram(dhqr_ctx *c, const double *V1, const double *V2, 
   pick_split(rows2, 2, wide_slots(c), 128, &nsplit, &rps, wide_slots(c), 64);
   CHECK(ensure(c, c->spart, (size_t)nsplit * (size_t)(ld2 * ld2)));
   hipLaunchKernelGGL((k_gemm_tn2<2>), dim3((unsigned)std::min<int64_t>(2 * nsplit, wide_slots(c))), dim3(512), 0, c->stream, V2, ldv,
-                     V1 + 2 * NB, ldv, rows2, ld2, rps, c->spart.p, ld2 * ld2);
+                     V1 + 2 * NB, ldv, rows2, ld2, rps, c->spart.p, ld2 * ld2, (int64_t)0);
   hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(ld2 * ld2 / 64)), dim3(256), 0, c->stream, (const double *)c->spart.p,
                      (int)nsplit, ld2 * ld2, ld2 * ld2, S21);
   LAUNCHCHECK();
@@ -1269,6 +1286,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     }
     if (const char *e = getenv("DHQR_SPARE_CUS")) c->spare_cus = std::max(0, std::min(c->ncu - 8, atoi(e)));
     if (const char *e = getenv("DHQR_QUAD")) c->quad = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_TN_STREAMK")) c->tn_streamk = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QUAD_MIN_COLS")) c->quad_min_cols = std::max<int64_t>(0, atoll(e));
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
@@ -1322,7 +1340,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
     c->hio = nullptr;
   }
   Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
-                 &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo};
+                 &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo, &c->host_mat};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {
@@ -1460,14 +1478,11 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
   if (no_columns(m, n)) return DHQR_OK;
   CHECK(check_mat(hA, m, n, lda, true));
   if (!halpha) return set_err(DHQR_EINVAL, "null alpha pointer");
-  double *dA = nullptr, *dal = nullptr;
+  // The device copy of the matrix lives in the context between calls (hipMalloc + hipFree of 8 GiB cost ~0.3 s per call at
+  // 32768^2, a third of the factorisation; `qr!` is typically called in a loop, test/runtests.jl:84); freed by dhqr_destroy.
   const int64_t ldd = (m + 1) & ~(int64_t)1;
-  if (hipMalloc((void **)&dA, (size_t)ldd * n * sizeof(double)) != hipSuccess)
-    return set_err(DHQR_ENOMEM, "hipMalloc of the %lld x %lld matrix failed", (long long)m, (long long)n);
-  if (hipMalloc((void **)&dal, (size_t)n * sizeof(double)) != hipSuccess) {
-    (void)hipFree(dA);
-    return set_err(DHQR_ENOMEM, "hipMalloc of alpha failed");
-  }
+  CHECK(ensure(c, c->host_mat, (size_t)ldd * (size_t)n + (size_t)n + 16));
+  double *dA = c->host_mat.p, *dal = dA + (((size_t)ldd * (size_t)n + 1) & ~(size_t)1);
   // DHQR_HOSTIO=0: the plain three-phase form (one hipMemcpy2D up, factorisation, one down)
   static const bool overlap = [] { const char *e = getenv("DHQR_HOSTIO"); return !(e && atoi(e) == 0); }();
   int32_t rc = DHQR_OK;
@@ -1487,7 +1502,14 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
     if (!c->hio) c->hio = new HostIo();
     HostIo &h = *c->hio;
     const int64_t K = (n + DHQR_NBV - 1) / DHQR_NBV;
+    static const bool trace = getenv("DHQR_HOSTIO_TRACE") != nullptr;  // phase times on stderr (tools/hostio_bench.py)
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count(); };
     CHECK(hio_upload(h, hA, m, n, lda, dA, ldd, c->stream));
+    if (trace) {
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      fprintf(stderr, "[hostio] upload done at %.1f ms\n", since());
+    }
     h.hA = hA;
     h.dA = dA;
     h.m = m;
@@ -1502,6 +1524,7 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
     const int32_t rf = dhqr_factor_f64(c, dA, m, n, ldd, dal, nb);
     c->panel_hook = nullptr;
     c->panel_hook_arg = nullptr;
+    if (trace) fprintf(stderr, "[hostio] factorisation returned at %.1f ms\n", since());
     if (rf != DHQR_OK) {
       (void)hio_drain(h);
       return rf;
@@ -1518,13 +1541,12 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
     HIPCHECK(hipMemcpyAsync(halpha, dal, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
     CHECK(hio_drain(h));
+    if (trace) fprintf(stderr, "[hostio] last block on the host at %.1f ms\n", since());
     return pipe_error_check(c);
   };
   rc = overlap ? overlapped() : plain();
   (void)hipStreamSynchronize(c->stream);
   if (c->hio) (void)hio_drain(*c->hio);
-  (void)hipFree(dA);
-  (void)hipFree(dal);
   return rc;
 }
 

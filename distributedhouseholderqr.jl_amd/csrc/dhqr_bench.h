@@ -375,7 +375,7 @@ int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t nco
           launch_nn_sub<256>(c, true, grid, V, ldv, W, ld2, C, ldc, rows, ncols, swz, false);
       } else {
         hipLaunchKernelGGL((k_gemm_tn2<2>), dim3((unsigned)std::min<int64_t>(ntiles * nsplit, wide_slots(c))), dim3(512), 0, c->stream, V, ldv,
-                           (const double *)C, ldc, rows, ncols, rps, Y, ld2 * ncols);
+                           (const double *)C, ldc, rows, ncols, rps, Y, ld2 * ncols, (int64_t)0);
       }
     };
     launch();

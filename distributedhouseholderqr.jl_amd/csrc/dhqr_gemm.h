@@ -199,11 +199,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
 // k_gemm_tn; output tile 128 columns x 256 reflectors.  Per K-tile the workgroup stages 48 KB for 1.05 MFLOP
 // (21.8 flop/B through the CU memory pipe, against 16 for two 128-reflector passes).  One workgroup per CU
 // (110 KB of LDS), i.e. the same 2 waves per SIMD as two k_gemm_tn workgroups.
-template <int VEC>
+// SK ("stream-K", wide launches): the fine units (column tile, rps-row slab) are numbered TILE-major and workgroup b takes
+// the CONTIGUOUS range [b q, (b + 1) q): at most a few (tile, row range) segments, each ONE K loop whose accumulators run
+// over the whole row range -- every workgroup does the same number of K-tiles whatever ntiles is (no rounds, no idle
+// eighth of the chip at 224 column tiles), and a tile's partial sums are as many as workgroups share it (2-3) instead of
+// one per row slab (up to 12): the split-K partials written and re-read by the reduction shrink accordingly.  Segment of
+// workgroup b in tile t goes to partial slot (b - floor(t S / q), t) with S = slabs per tile; k_reduce_pieces sums a
+// tile's floor(((t + 1) S - 1) / q) - floor(t S / q) + 1 slots.
+template <int VEC, bool SK = false>
 __global__ __launch_bounds__(512) void k_gemm_tn2(const double *__restrict__ V, int64_t ldv,
                                                   const double *__restrict__ C, int64_t ldc, int64_t rows,
                                                   int64_t ncols, int64_t rps, double *__restrict__ out,
-                                                  int64_t osplit_stride) {
+                                                  int64_t osplit_stride, int64_t skq) {
   constexpr int NP = 256;
   __shared__ __attribute__((aligned(16))) double Vs[2][NP * G_LDK];
   __shared__ __attribute__((aligned(16))) double Cs[2][128 * G_LDK];
@@ -213,11 +220,26 @@ __global__ __launch_bounds__(512) void k_gemm_tn2(const double *__restrict__ V, 
   // PERSISTENT: gridDim.x workgroups (one per CU, the host leaves CUs free for the look-ahead lane / RCCL by launching
   // fewer) loop over the units u = (column tile, row slab), column tile fastest -- the order of the former 2-D grid.
   const int64_t ntiles = (ncols + 127) / 128, nslab = (rows + rps - 1) / rps;
-  for (int64_t u = blockIdx.x; u < ntiles * nslab; u += gridDim.x) {
-  const int64_t ux = u % ntiles, uy = u / ntiles;
+  const int64_t ufirst = SK ? (int64_t)blockIdx.x * skq : (int64_t)blockIdx.x;
+  const int64_t ulast = SK ? (ufirst + skq < ntiles * nslab ? ufirst + skq : ntiles * nslab) : ntiles * nslab;
+  for (int64_t u = ufirst; u < ulast;) {
+  int64_t ux, uy, rbeg, rend;
+  if constexpr (SK) {
+    ux = u / nslab;
+    const int64_t s0 = u - ux * nslab;
+    const int64_t s1 = (s0 + (ulast - u) < nslab) ? s0 + (ulast - u) : nslab;
+    rbeg = s0 * rps;
+    rend = (s1 * rps < rows) ? s1 * rps : rows;
+    uy = (int64_t)blockIdx.x - (ux * nslab) / skq;  // this workgroup's piece of tile ux
+    u += s1 - s0;
+  } else {
+    ux = u % ntiles;
+    uy = u / ntiles;
+    rbeg = uy * rps;
+    rend = (rbeg + rps < rows) ? rbeg + rps : rows;
+    u += gridDim.x;
+  }
   const int64_t c0 = ux * 128;
-  const int64_t rbeg = uy * rps;
-  const int64_t rend = (rbeg + rps < rows) ? rbeg + rps : rows;
   const int nkt = (int)((rend - rbeg + G_KT - 1) / G_KT);
   const int ncv = (int)((ncols - c0 < 128) ? ncols - c0 : 128);
 
@@ -671,6 +693,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_quad(const double *__restric
 // A block of 256 threads owns 64 consecutive elements; its four 64-thread groups each sum a quarter
 // of the splits (interleaved) and the quarters are combined through LDS in a fixed order, so a
 // 128 x 128 Gram matrix with 256 partials is reduced by 256 blocks instead of 64.
+// The reduction of a stream-K k_gemm_tn2 launch: element e of Y (256 x ncols, ld 256) belongs to column tile
+// t = e / (256 * 128) and is the sum of that tile's pieces (slots 0 .. npieces(t) - 1, see k_gemm_tn2).
+__global__ __launch_bounds__(256) void k_reduce_pieces(const double *__restrict__ in, int64_t nslab, int64_t skq,
+                                                       int64_t stride, int64_t count, double *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  const int64_t tile = e / (256 * 128);
+  const int np = (int)((((tile + 1) * nslab - 1) / skq) - ((tile * nslab) / skq) + 1);
+  double s = in[e];
+  for (int q = 1; q < np; ++q) s += in[(int64_t)q * stride + e];
+  out[e] = s;
+}
+
 __global__ __launch_bounds__(256) void k_reduce_splits(const double *__restrict__ in, int nsplit,
                                                        int64_t stride, int64_t count,
                                                        double *__restrict__ out) {

@@ -62,8 +62,8 @@ int main(int argc, char **argv) {
     std::vector<double> out((size_t)nsplit * ostride, -7.0);
     // persistent: fewer workgroups than units, so every workgroup loops (3 is coprime to most unit counts)
     const int wgs = std::max(1, std::min(3, ntiles * nsplit - 1));
-    if (vec == 2) grid2(wgs, 1, 512, [&] { k_gemm_tn2<2>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride); });
-    else grid2(wgs, 1, 512, [&] { k_gemm_tn2<1>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride); });
+    if (vec == 2) grid2(wgs, 1, 512, [&] { k_gemm_tn2<2>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride, (int64_t)0); });
+    else grid2(wgs, 1, 512, [&] { k_gemm_tn2<1>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride, (int64_t)0); });
     wr(argv[11], out);
   } else if (op == "quad") {  // four-panel C -= [V1 | V2] W (k_gemm_nn_quad): V2 starts `skip` rows below V1 (same ldv); swz 2 = 64-row tiles
     const int swz = atoi(argv[8]);

@@ -183,6 +183,23 @@ def test_wide_update_on_the_persistent_tn_kernel(emu, orc):
     emu.dhqr_destroy(h)
 
 
+@pytest.mark.parametrize("m,n", [(1290, 1280), (1161, 1152)])
+def test_wide_tn_stream_k(emu, orc, m, n):
+    """stream-K decomposition of the wide k_gemm_tn2 launches (normally from 128 column tiles on; DHQR_TN_MODEL_MIN_TILES=3
+    brings it to a small matrix): 128-row fine units numbered tile-major, a contiguous range per workgroup, a tile's
+    partial sums = the workgroups that share it (k_reduce_pieces) -- against the oracle, even and odd m (16-byte / scalar
+    loads), and against the column-tile x row-slab units (DHQR_TN_STREAMK=0) to rounding"""
+    A0 = orc.rand_matrix(m, n, 16)
+    res = []
+    for env in ({"DHQR_TN_MODEL_MIN_TILES": 3}, {"DHQR_TN_MODEL_MIN_TILES": 3, "DHQR_TN_STREAMK": 0}):
+        h = _ctx(emu, **env)
+        A, al = _factor(emu, h, A0, 128)
+        _check(orc, A0, A, al)
+        emu.dhqr_destroy(h)
+        res.append(A)
+    assert np.abs(res[0] - res[1]).max() <= 1e-12 * np.abs(res[1]).max()
+
+
 @pytest.mark.parametrize("m,env", [(301, {}),                          # odd m: scalar (VEC = 1) loads everywhere
                                    (300, {"DHQR_PANEL": 2}),           # row-split step kernels for every panel
                                    pytest.param(300, {"DHQR_PANEL": 1}, marks=_SLOW),  # one workgroup per column

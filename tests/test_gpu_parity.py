@@ -268,10 +268,14 @@ def test_column_cyclic_driver_single_rank(pkg, orc, m, n):
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
 
 
-def test_wide_tn_split_model_on_a_small_matrix(pkg, orc, monkeypatch):
-    """the split-K choice of the wide k_gemm_tn2 launches (round / partial-traffic estimate, normally for >= 128 column
-    tiles = matrices beyond 16384 columns) forced onto a 2304^2 matrix: same factorisation as the oracle's"""
+@pytest.mark.parametrize("streamk", [1, 0])
+def test_wide_tn_split_model_on_a_small_matrix(pkg, orc, monkeypatch, streamk):
+    """the decomposition of the wide k_gemm_tn2 launches (normally for >= 128 column tiles = matrices beyond 16384
+    columns) forced onto a 2304^2 matrix -- stream-K (default: tile-major fine units, a contiguous range per workgroup,
+    k_reduce_pieces) and the column-tile x row-slab units with the round / partial-traffic estimate (DHQR_TN_STREAMK=0):
+    same factorisation as the oracle's"""
     monkeypatch.setenv("DHQR_TN_MODEL_MIN_TILES", "3")  # read by dhqr_create of the rank context
+    monkeypatch.setenv("DHQR_TN_STREAMK", str(streamk))
     m = n = 2304
     mg = pkg.MultiGpuQR(devices=[0])
     try:

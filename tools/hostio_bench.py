@@ -1,0 +1,46 @@
+"""Host-in / host-out drop-in dhqr_qr_f64 (`qr!(A::Matrix)`): wall time of the call with the staged, overlapped PCIe path
+(default) and with the plain three-phase form (DHQR_HOSTIO=0), next to the device-resident factorisation.
+  python tools/hostio_bench.py [n=32768] [reps=3]"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(n, reps):
+    import numpy as np
+    import torch
+    import __graft_entry__ as g
+    pkg = g.import_package()
+    from oracle import dhqr_oracle as orc
+    A0 = np.empty((n, n), order="F")
+    orc.lib().dhqr_oracle_fill(orc._ptr(A0), n, n, n, 0)
+    ts = []
+    for r in range(reps + 1):
+        A = A0.copy(order="F")
+        t0 = time.perf_counter()
+        H = pkg.qr_(A, nb=128)
+        ts.append(time.perf_counter() - t0)
+    # the factor that came back is the device's: spot-check ||v_j||^2 = 2 on a few columns and compare with a device-resident run
+    cols = [0, 1, n // 2, n - 129, n - 2]
+    v2 = [float((H.A[c:, c] ** 2).sum()) for c in cols]
+    Ad = pkg.rand_colmajor(n, n, 0, "cuda:0")
+    Hd = pkg.qr_(Ad, nb=128)
+    torch.cuda.synchronize()
+    same = all(np.array_equal(H.A[:, c], Hd.A[:, c].cpu().numpy()) for c in cols) and np.array_equal(H.α, Hd.α.cpu().numpy())
+    print(json.dumps({"n": n, "hostio": os.environ.get("DHQR_HOSTIO", "1"), "first_call_s": ts[0], "best_s": min(ts[1:]),
+                      "calls_s": [round(t, 3) for t in ts], "v2": v2, "bitwise_equal_to_device_resident_run": bool(same)}), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--inner":
+        run(int(sys.argv[2]), int(sys.argv[3]))
+    else:
+        n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+        reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+        for mode in ("1", "0"):
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--inner", str(n), str(reps)], env=dict(os.environ, DHQR_HOSTIO=mode))
