@@ -445,7 +445,8 @@ def pmc_traffic(symbol, m, n, nb, launches, work):
         # bytes of ONE factorisation step as the counters measured them: read + written by the launches the counter passes
         # cover (`counted`: the wide launches of the symbol; the narrow look-ahead launches of the same template are left out)
         info = {"bytes_per_step": (e["read_GB"] + e["write_GB"]) * 1e9, "counted_launches_per_step": e["launches"],
-                "algorithmic_bytes_per_step_of_those": e["algorithmic_GB"] * 1e9, "ratio_to_algorithmic": e["ratio_to_algorithmic"]}
+                "algorithmic_bytes_per_step_of_those": (e["algorithmic_GB"] * 1e9 if e.get("algorithmic_GB") is not None else None),
+                "ratio_to_algorithmic": e.get("ratio_to_algorithmic")}
         return info, None
     return None, f"no counter run committed for {symbol} on {workload}"
 

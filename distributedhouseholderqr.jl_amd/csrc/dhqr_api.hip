@@ -56,6 +56,9 @@ struct dhqr_ctx {
   hipStream_t own = nullptr, stream = nullptr;
   bool profiling = false;
   hipStream_t hi = nullptr;      // high-priority stream: panel factorisation under look-ahead
+  hipStream_t hi2 = nullptr;     // its side stream: products that need a panel's V but not its T (V_a' C_b of the pair's second
+                                 // panel, the pair / quad cross terms) run here beside the panel's verification and commit
+  int lane_side = 1;             // ... DHQR_LANE_SIDE=0: everything on the one lane stream
   int tn_streamk = 1;            // wide k_gemm_tn2 launches: stream-K decomposition (DHQR_TN_STREAMK=0: column-tile x row-slab units + the round model)
   int tn_model_min_tiles = 128;  // wide k_gemm_tn2 launches of at least this many column tiles: split-K factor from the round / partial-traffic estimate (below, the lane is the critical path and
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
@@ -68,13 +71,18 @@ struct dhqr_ctx {
   int rankk_tall = 5;            // nb = 0, columns of 8192 < rows <= 16384: reflectors per pass (k_rankk_tall; DHQR_RANKK_TALL=1: one per launch)
   int ncu = 256;                 // compute units of the device
   int spare_cus = 0;             // CUs the persistent wide k_gemm_tn2 launches leave free for the look-ahead lane's
-                                 // single-workgroup kernels and for RCCL's kernels (DHQR_SPARE_CUS; multiple of 8: one per XCD)
+                                 // single-workgroup kernels and for RCCL's kernels (DHQR_SPARE_CUS; multiple of 8: one per XCD).
+                                 // Default 0 on one GPU (measured: 8 spare CUs cost the wide kernels more than the lane gains);
+                                 // 8 when the context is bound to an RCCL communicator of more than one rank: the panel
+                                 // broadcast sits on the critical chain there and RCCL's kernels need CUs of their own while a
+                                 // persistent launch holds every CU it was given (comm_bind_rccl)
+  bool spare_cus_set = false;    // DHQR_SPARE_CUS given: never overridden
   int quad = 1;                  // P == 1: two consecutive pairs applied in ONE K = 512 pass (quad_apply; DHQR_QUAD=0: pairs only)
   int64_t quad_min_cols = 10240;  // ... while at least this many columns lie to the right of the quad (DHQR_QUAD_MIN_COLS)
-  struct WS { Buf w1, w1r, w2; } ws[2];  // [0] wide trailing update, [1] panel / narrow updates
+  struct WS { Buf w1, w1r, w2; } ws[3];  // [0] wide trailing update, [1] panel / narrow updates, [2] the lane's side stream (hi2)
   int cur_ws = 0;
   bool lookahead = true;
-  Buf vbuf, vt, vts, spart, sfull, scratch, pbuf;
+  Buf vbuf, vt, vts, spart, spart2, sfull, scratch, pbuf;  // spart2: split-K partials of the cross terms on the side stream
   Buf zsolve_lo;         // low parts of the double-double right-hand side of the ComplexF64 solve
   Buf host_mat;          // device copy of the caller's HOST matrix (+ alpha) of dhqr_qr_f64, kept between calls
   int pair = 1;                  // 1: wide updates apply two panels per pass (DHQR_PAIR=0 disables)
@@ -457,8 +465,10 @@ static int32_t panel_pack_and_t(dhqr_ctx *c, const double *P, int64_t rows, int6
 }
 
 // C (rows x ncols) <- (I - V op(T) V') C with op(T) = T' (trans=1) or T (trans=0).
+// phase 0: everything; 1: only Y = V' C and its split-K reduction (needs V, not T: the lane's side stream runs it while the
+// panel is still being verified); 2: the rest (T product + subtraction) on the Y a phase-1 call left in the SAME workspace.
 static int32_t panel_apply(dhqr_ctx *c, const PanelBuf &pb, int64_t rows, double *C, int64_t ncols,
-                           int64_t ldc, int trans, int kw = DHQR_NBV) {
+                           int64_t ldc, int trans, int kw = DHQR_NBV, int phase = 0) {
   if (ncols <= 0 || rows <= 0) return DHQR_OK;
   const int64_t ldv = pb.ldv;
   const double *V = pb.V;
@@ -479,6 +489,7 @@ static int32_t panel_apply(dhqr_ctx *c, const PanelBuf &pb, int64_t rows, double
 #define DHQR_APPLY(KW_)                                                                              \
   do {                                                                                               \
     CHECK(prof_begin(c, CAT_VTA));                                                                   \
+    if (phase != 2) {                                                                                \
     if (vec)                                                                                         \
       hipLaunchKernelGGL((k_gemm_tn<2, 1, KW_>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(256), 0, \
                          c->stream, V, ldv, (const double *)C, ldc, 1, (int64_t)0, rows, ncols, rps,    \
@@ -487,14 +498,17 @@ static int32_t panel_apply(dhqr_ctx *c, const PanelBuf &pb, int64_t rows, double
       hipLaunchKernelGGL((k_gemm_tn<1, 1, KW_>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(256), 0, \
                          c->stream, V, ldv, (const double *)C, ldc, 1, (int64_t)0, rows, ncols, rps,    \
                          ws.w1.p, (int64_t)DHQR_NBV, wstride);                                           \
+    }                                                                                                \
     CHECK(prof_end(c));                                                                              \
     CHECK(prof_begin(c, CAT_TW));                                                                    \
     const double *w1sum = ws.w1.p;                                                                   \
     if (nsplit > 1) { /* bandwidth-friendly, deterministic split-K reduction */                      \
+      if (phase != 2)                                                                                \
       hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)((wstride + 63) / 64)), dim3(256), 0,       \
                          c->stream, (const double *)ws.w1.p, (int)nsplit, wstride, wstride, ws.w1r.p); \
       w1sum = ws.w1r.p;                                                                              \
     }                                                                                                \
+    if (phase == 1) { CHECK(prof_end(c)); break; }                                                   \
     if (KW_ == DHQR_NBV && ntiles <= 2) /* the lane's narrow updates: k_tw_fused (dhqr_gemm.h) */    \
       hipLaunchKernelGGL((k_tw_fused<false>), dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, c->stream, w1sum, ncols, \
                          TopT, (const double *)nullptr, (const double *)nullptr, ws.w2.p, (int64_t)DHQR_NBV); \
@@ -780,7 +794,7 @@ static int32_t tsqr_local_r(dhqr_ctx *c, const double *P, int64_t ldp, int64_t r
 // (k_build_t); once a panel has failed every later commit / trailing update with epoch >= its index is a
 // no-op, and the driver resumes from it with factor_panel_sync after its single final synchronisation.
 static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t ldp, double *alpha, const PanelBuf &pb,
-                                  int passes, int panel_idx) {
+                                  int passes, int panel_idx, hipEvent_t ev_v = nullptr) {
   const int64_t ldv = pb.ldv;
   const size_t NN = (size_t)DHQR_NBV * DHQR_NBV;
   CHECK(ensure(c, c->rbuf, 6 * NN + 1024));
@@ -823,6 +837,8 @@ static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t 
     CHECK(mul128(c, X, ldx, rows, negMinv, pb.V, ldv));                            // Vw = X M^{-1}
     hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, pb.V, ldv,
                        (const double *)(passes == 3 ? G : altmp), (const double *)negMinv);  // Vw = tril((X - aE) M^{-1})
+    // pb.V holds the reflectors from here on (T, the verdict and the commit follow): what needs V alone may start
+    if (ev_v) HIPCHECK(hipEventRecord(ev_v, c->stream));
     if (passes == 3)  // R = D R_t, alpha = diag(R)
       hipLaunchKernelGGL(k_tsqr_final_r, dim3(NN / 256), dim3(256), 0, c->stream, (const double *)Rf, (const double *)G, Rref,
                          altmp);
@@ -1102,37 +1118,40 @@ static int32_t quad_apply(dhqr_ctx *c, const double *V1, const double *V2, int64
 
 // S_21 = V_2' V_1 (256 x 256, ld 256) of two consecutive pair operands (V_2 starts 256 rows below V_1, same ldv): the
 // cross term of quad_apply.  rows_a = rows of the first pair's first panel.
-static int32_t quad_cross_gram(dhqr_ctx *c, const double *V1, const double *V2, int64_t ldv, int64_t rows_a, double *S21) {
+static int32_t quad_cross_gram(dhqr_ctx *c, const double *V1, const double *V2, int64_t ldv, int64_t rows_a, double *S21,
+                               Buf *part = nullptr) {
   const int64_t NB = DHQR_NBV, rows2 = rows_a - 2 * NB, ld2 = 2 * NB;
   int64_t nsplit, rps;
   pick_split(rows2, 2, wide_slots(c), 128, &nsplit, &rps, wide_slots(c), 64);
-  CHECK(ensure(c, c->spart, (size_t)nsplit * (size_t)(ld2 * ld2)));
+  Buf &sp = part ? *part : c->spart;
+  CHECK(ensure(c, sp, (size_t)nsplit * (size_t)(ld2 * ld2)));
   hipLaunchKernelGGL((k_gemm_tn2<2>), dim3((unsigned)std::min<int64_t>(2 * nsplit, wide_slots(c))), dim3(512), 0, c->stream, V2, ldv,
-                     V1 + 2 * NB, ldv, rows2, ld2, rps, c->spart.p, ld2 * ld2, (int64_t)0);
-  hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(ld2 * ld2 / 64)), dim3(256), 0, c->stream, (const double *)c->spart.p,
+                     V1 + 2 * NB, ldv, rows2, ld2, rps, sp.p, ld2 * ld2, (int64_t)0);
+  hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(ld2 * ld2 / 64)), dim3(256), 0, c->stream, (const double *)sp.p,
                      (int)nsplit, ld2 * ld2, ld2 * ld2, S21);
   LAUNCHCHECK();
   return DHQR_OK;
 }
 
 // S_ba = V_b' V_a (128 x 128) of a pair operand Vp = [V_a | V_b]: the cross term of pair_apply
-static int32_t pair_cross_gram(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows_a, double *Sba) {
+static int32_t pair_cross_gram(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows_a, double *Sba, Buf *part = nullptr) {
   const int64_t NB = DHQR_NBV, rows_b = rows_a - NB;
   const size_t NN = (size_t)NB * NB;
   int64_t nsplit, rps;
   pick_split(rows_b, 1, 512, 256, &nsplit, &rps, 512, 64);
-  CHECK(ensure(c, c->spart, (size_t)nsplit * NN));
+  Buf &sp = part ? *part : c->spart;
+  CHECK(ensure(c, sp, (size_t)nsplit * NN));
   const double *Vb = Vp + NB + NB * ldv;
   const bool vec = (ldv % 2 == 0) && (rows_b % 2 == 0) && aligned16(Vp);
   if (vec)
     hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, Vb, ldv,
-                       (const double *)(Vp + NB), ldv, 1, (int64_t)0, rows_b, (int64_t)NB, rps, c->spart.p, (int64_t)NB,
+                       (const double *)(Vp + NB), ldv, 1, (int64_t)0, rows_b, (int64_t)NB, rps, sp.p, (int64_t)NB,
                        (int64_t)NN);
   else
     hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, Vb, ldv,
-                       (const double *)(Vp + NB), ldv, 1, (int64_t)0, rows_b, (int64_t)NB, rps, c->spart.p, (int64_t)NB,
+                       (const double *)(Vp + NB), ldv, 1, (int64_t)0, rows_b, (int64_t)NB, rps, sp.p, (int64_t)NB,
                        (int64_t)NN);
-  hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(NN / 64)), dim3(256), 0, c->stream, (const double *)c->spart.p,
+  hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(NN / 64)), dim3(256), 0, c->stream, (const double *)sp.p,
                      (int)nsplit, (int64_t)NN, (int64_t)NN, Sba);
   LAUNCHCHECK();
   return DHQR_OK;
@@ -1275,6 +1294,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
       int lo = 0, hi = 0;
       HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
       HIPCHECK(hipStreamCreateWithPriority(&c->hi, hipStreamNonBlocking, hi));
+      HIPCHECK(hipStreamCreateWithPriority(&c->hi2, hipStreamNonBlocking, hi));
     }
     if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
     {
@@ -1284,9 +1304,13 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
         c->ncu = ncu;
       }
     }
-    if (const char *e = getenv("DHQR_SPARE_CUS")) c->spare_cus = std::max(0, std::min(c->ncu - 8, atoi(e)));
+    if (const char *e = getenv("DHQR_SPARE_CUS")) {
+      c->spare_cus = std::max(0, std::min(c->ncu - 8, atoi(e)));
+      c->spare_cus_set = true;
+    }
     if (const char *e = getenv("DHQR_QUAD")) c->quad = atoi(e) != 0;
     if (const char *e = getenv("DHQR_TN_STREAMK")) c->tn_streamk = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_LANE_SIDE")) c->lane_side = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QUAD_MIN_COLS")) c->quad_min_cols = std::max<int64_t>(0, atoll(e));
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
@@ -1340,7 +1364,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
     c->hio = nullptr;
   }
   Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
-                 &c->ws[1].w1r, &c->ws[1].w2, &c->spart, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo, &c->host_mat};
+                 &c->ws[1].w1r, &c->ws[1].w2, &c->ws[2].w1, &c->ws[2].w1r, &c->ws[2].w2, &c->spart, &c->spart2, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo, &c->host_mat};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {
@@ -1353,6 +1377,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
   for (hipEvent_t e : c->zev)
     if (e) (void)hipEventDestroy(e);
   if (c->hi) (void)hipStreamDestroy(c->hi);
+  if (c->hi2) (void)hipStreamDestroy(c->hi2);
   if (c->own) (void)hipStreamDestroy(c->own);
   delete c;
   return DHQR_OK;
@@ -2135,7 +2160,12 @@ static bool lane_channel_wanted(int kind) {
   if (const char *e = getenv("DHQR_LANE_CHANNEL")) return atoi(e) != 0;
   return kind != COMM_RCCL;
 }
+// a context that drives a rank of a multi-GPU RCCL job keeps one CU per XCD out of its persistent launches (see spare_cus)
+static void comm_bind_rccl(dhqr_ctx *c, int kind, int nranks) {
+  if (kind == COMM_RCCL && nranks > 1 && !c->spare_cus_set) c->spare_cus = std::min(8, std::max(0, c->ncu - 8));
+}
 static int32_t comm_new(dhqr_comm **out, dhqr_ctx *c, int kind, int nranks, int rank) {
+  comm_bind_rccl(c, kind, nranks);
   dhqr_comm *cm = new dhqr_comm();
   cm->ctx = c;
   cm->kind = kind;

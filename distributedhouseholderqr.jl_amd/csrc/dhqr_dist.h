@@ -35,6 +35,7 @@ struct CsState {
   hipStream_t comm = nullptr;
   hipEvent_t ev_group[CS_EVR], ev_wide[CS_EVR], ev_head[CS_EVR], ev_lane[CS_EVR];
   hipEvent_t ev_ready[2 * CS_EVR], ev_recv[2 * CS_EVR];
+  hipEvent_t ev_v[2 * CS_EVR], ev_y[2 * CS_EVR], ev_x[CS_EVR];  // lane side stream: V of a panel final / Y = V_a' C_b done / a group's cross terms done
   hipEvent_t ev_start = nullptr, ev_end = nullptr;
   int64_t ticket[2 * CS_EVR];
   Buf gbuf[CS_NGB];
@@ -53,10 +54,13 @@ static int32_t cs_state_init(dhqr_ctx *c) {
     HIPCHECK(hipEventCreateWithFlags(&s.ev_wide[i], hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&s.ev_head[i], hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&s.ev_lane[i], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&s.ev_x[i], hipEventDisableTiming));
   }
   for (int i = 0; i < 2 * CS_EVR; ++i) {
     HIPCHECK(hipEventCreateWithFlags(&s.ev_ready[i], hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&s.ev_recv[i], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&s.ev_v[i], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&s.ev_y[i], hipEventDisableTiming));
     s.ticket[i] = -1;
   }
   HIPCHECK(hipEventCreateWithFlags(&s.ev_start, hipEventDisableTiming));
@@ -73,10 +77,13 @@ static void cs_state_free(dhqr_ctx *c) {
       (void)hipEventDestroy(s.ev_wide[i]);
       (void)hipEventDestroy(s.ev_head[i]);
       (void)hipEventDestroy(s.ev_lane[i]);
+      (void)hipEventDestroy(s.ev_x[i]);
     }
     for (int i = 0; i < 2 * CS_EVR; ++i) {
       (void)hipEventDestroy(s.ev_ready[i]);
       (void)hipEventDestroy(s.ev_recv[i]);
+      (void)hipEventDestroy(s.ev_v[i]);
+      (void)hipEventDestroy(s.ev_y[i]);
     }
     (void)hipEventDestroy(s.ev_start);
     (void)hipEventDestroy(s.ev_end);
@@ -223,7 +230,11 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
   const int64_t ldv_fixed = any_quad ? panel_ldv(m - groups[0].a * NB) : 0;
   auto gview = [&](int g) { return cs_gbuf_view(S.gbuf[g % CS_NGB].p, m - groups[g].a * NB, ldv_fixed); };
 
-  hipStream_t sW = c->stream, sL = c->hi, sC = S.comm;
+  hipStream_t sW = c->stream, sL = c->hi, sC = S.comm, sX = c->hi2;
+  // Lane side stream (r4): what needs a panel's V but not its T runs on sX beside the panel's second Gram product, k_build_t
+  // and the commit -- Y = V_a' C_b for the pair's second panel, the pair's cross term V_b' V_a, the quad's V_2' V_1.  Only
+  // for panels this rank factors itself on the asynchronous fast path (a received panel has no "V final" event).
+  const bool side = c->lane_side && sX != nullptr;
   auto on = [&](hipStream_t s, int wsi) { c->stream = s; c->cur_ws = wsi; };
   const int saved_epoch = c->epoch;
   auto apply_group = [&](int g, int64_t lstart, int64_t ncols) -> int32_t {  // group g -> local columns [lstart, lstart+ncols)
@@ -282,6 +293,7 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
       return DHQR_OK;
     };
     bool merged_update = false;
+    bool v_event[2] = {false, false};  // ev_v recorded for panel idx of this group (this rank, fast path)
     for (int idx = 0; idx < gr.np; ++idx) {
       const int64_t x = gr.a + idx, w = pr.width(x), rows = m - x * NB;
       const PanelBuf pbx = idx == 0 ? gb.pa() : gb.pb();
@@ -315,9 +327,26 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
         }
         if (idx == 1) {  // panel a of this group -> block b
           if (!pr.mine(gr.a)) HIPCHECK(hipStreamWaitEvent(sL, S.ev_recv[(int)(gr.a % (2 * CS_EVR))], 0));
+          double *Cb = pr.A + gr.a * NB + lc * lda;
+          const int pa_ = (int)(gr.a % (2 * CS_EVR));
           CHECK(lane_begin(was));
           c->epoch = (int)gr.a;
-          const int32_t rc = panel_apply(c, gb.pa(), gb.rows_a, pr.A + gr.a * NB + lc * lda, w, lda, 1);
+          int32_t rc = DHQR_OK;
+          if (side && v_event[0] && (merged_update || prev < 0)) {
+            // Y = V_a' C_b on the side stream as soon as V_a is final (block b was brought up to date together with block a,
+            // before panel a was factored -- merged_update -- so ev_v is recorded behind that on the lane); T_a' Y and the
+            // subtraction follow on the lane once panel a is verified and committed.  Both calls see workspace 2.
+            on(sX, 2);
+            HIPCHECK(hipStreamWaitEvent(sX, S.ev_v[pa_], 0));
+            rc = panel_apply(c, gb.pa(), gb.rows_a, Cb, w, lda, 1, DHQR_NBV, 1);
+            HIPCHECK(hipEventRecord(S.ev_y[pa_], sX));
+            on(sL, 2);
+            HIPCHECK(hipStreamWaitEvent(sL, S.ev_y[pa_], 0));
+            if (rc == DHQR_OK) rc = panel_apply(c, gb.pa(), gb.rows_a, Cb, w, lda, 1, DHQR_NBV, 2);
+            on(sL, 1);
+          } else {
+            rc = panel_apply(c, gb.pa(), gb.rows_a, Cb, w, lda, 1);
+          }
           CHECK(lane_end(was));
           CHECK(rc);
           hipLaunchKernelGGL(k_zero_rows, dim3(DHQR_NBV), dim3(128), 0, sL, gb.VB, gb.ldv, (int)NB);
@@ -325,7 +354,8 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
         double *Pp = pr.A + x * NB + lc * lda;
         c->epoch = saved_epoch;
         if (panel_fast_eligible(c, rows, w) && !(robust_first && x == kstart)) {
-          CHECK(panel_fast_enqueue(c, Pp, rows, lda, pr.alpha + x * NB, pbx, c->cholqr_passes, (int)x));
+          CHECK(panel_fast_enqueue(c, Pp, rows, lda, pr.alpha + x * NB, pbx, c->cholqr_passes, (int)x, side ? S.ev_v[pe] : nullptr));
+          v_event[idx] = side;
           fast_idx.push_back(x);
         } else {
           // Short / partial panels (the last one or two of a factorisation) and the panel a resumed run starts
@@ -364,10 +394,29 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
     if (gr.np == 2 && gr.last() + 1 < K) {
       bool was = false;
       CHECK(lane_begin(was));
-      int32_t rc = pair_cross_gram(c, gb.VA, gb.ldv, gb.rows_a, gb.Sba);
-      if (rc == DHQR_OK && second_of_quad) {
-        const CsGroupBuf g1 = gview(h - 1);
-        rc = quad_cross_gram(c, g1.VA, gb.VA, gb.ldv, g1.rows_a, gb.S21);
+      int32_t rc = DHQR_OK;
+      if (side && v_event[1]) {
+        // the cross terms need the reflectors of this pair (and of the quad's first pair, complete long ago), not their T:
+        // on the side stream behind "V_b final", beside panel b's verification and commit; the lane waits for them here
+        const int pb_ = (int)(gr.last() % (2 * CS_EVR));
+        on(sX, 2);
+        HIPCHECK(hipStreamWaitEvent(sX, S.ev_v[pb_], 0));
+        if (!pr.mine(gr.a)) HIPCHECK(hipStreamWaitEvent(sX, S.ev_recv[(int)(gr.a % (2 * CS_EVR))], 0));
+        if (second_of_quad) HIPCHECK(hipStreamWaitEvent(sX, S.ev_lane[(h - 1) % CS_EVR], 0));  // the first pair assembled
+        rc = pair_cross_gram(c, gb.VA, gb.ldv, gb.rows_a, gb.Sba, &c->spart2);
+        if (rc == DHQR_OK && second_of_quad) {
+          const CsGroupBuf g1 = gview(h - 1);
+          rc = quad_cross_gram(c, g1.VA, gb.VA, gb.ldv, g1.rows_a, gb.S21, &c->spart2);
+        }
+        HIPCHECK(hipEventRecord(S.ev_x[h % CS_EVR], sX));
+        on(sL, 1);
+        HIPCHECK(hipStreamWaitEvent(sL, S.ev_x[h % CS_EVR], 0));
+      } else {
+        rc = pair_cross_gram(c, gb.VA, gb.ldv, gb.rows_a, gb.Sba);
+        if (rc == DHQR_OK && second_of_quad) {
+          const CsGroupBuf g1 = gview(h - 1);
+          rc = quad_cross_gram(c, g1.VA, gb.VA, gb.ldv, g1.rows_a, gb.S21);
+        }
       }
       CHECK(lane_end(was));
       CHECK(rc);
@@ -383,6 +432,7 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
     HIPCHECK(hipEventRecord(S.ev_start, sW));
     HIPCHECK(hipStreamWaitEvent(sL, S.ev_start, 0));
     HIPCHECK(hipStreamWaitEvent(sC, S.ev_start, 0));
+    if (sX) HIPCHECK(hipStreamWaitEvent(sX, S.ev_start, 0));
     for (int q = 0; q < steps[0].ng; ++q) CHECK(produce(steps[0].g0 + q));
     for (int si = 0; si < NS; ++si) {
       const int glast = steps[si].g0 + steps[si].ng - 1;
@@ -412,6 +462,10 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
     HIPCHECK(hipStreamWaitEvent(sW, S.ev_end, 0));
     HIPCHECK(hipEventRecord(S.ev_end, sC));
     HIPCHECK(hipStreamWaitEvent(sW, S.ev_end, 0));
+    if (sX) {
+      HIPCHECK(hipEventRecord(S.ev_end, sX));
+      HIPCHECK(hipStreamWaitEvent(sW, S.ev_end, 0));
+    }
     return DHQR_OK;
   };
   int32_t rc = body();
@@ -433,12 +487,13 @@ static int32_t cs_prepare(const CsProblem &pr) {
   const size_t ncmax = (size_t)std::max<int64_t>(pr.ncl, 2 * NB);
   const size_t ntmax = (ncmax + 127) / 128;
   const size_t w1cap = NN * (6144 + 2 * ntmax + 128);  // split-K partials of k_gemm_tn (128 rows) / k_gemm_tn2 (256 rows)
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < 3; ++s) {
     CHECK(ensure(c, c->ws[s].w1, s == 0 ? w1cap : NN * 2200));
-    CHECK(ensure(c, c->ws[s].w1r, (size_t)4 * NB * ncmax));  // Y_1, Y_2 / [W_1; W_2] of a quad step
-    CHECK(ensure(c, c->ws[s].w2, (size_t)4 * NB * ncmax));
+    CHECK(ensure(c, c->ws[s].w1r, s == 2 ? (size_t)4 * NB * 2 * NB : (size_t)4 * NB * ncmax));  // Y_1, Y_2 / [W_1; W_2] of a quad step
+    CHECK(ensure(c, c->ws[s].w2, s == 2 ? (size_t)4 * NB * 2 * NB : (size_t)4 * NB * ncmax));   // ([2]: the side stream's narrow products)
   }
   CHECK(ensure(c, c->spart, (size_t)512 * NN));  // Gram partials; 128 slabs of the 256 x 256 cross term of a quad
+  CHECK(ensure(c, c->spart2, (size_t)512 * NN));  // the same for the cross terms built on the lane's side stream
   CHECK(ensure(c, c->sfull, NN));
   CHECK(ensure(c, c->rbuf, 6 * NN + 1024));
   if (c->cholqr_passes == 3) CHECK(ensure(c, c->tsq, TsqrLocal::elems(m)));  // TSQR-HR for every panel
