@@ -58,7 +58,13 @@ struct dhqr_ctx {
   hipStream_t hi = nullptr;      // high-priority stream: panel factorisation under look-ahead
   hipStream_t hi2 = nullptr;     // its side stream: products that need a panel's V but not its T (V_a' C_b of the pair's second
                                  // panel, the pair / quad cross terms) run here beside the panel's verification and commit
-  int lane_side = 1;             // ... DHQR_LANE_SIDE=0: everything on the one lane stream
+  int lane_side = 1;             // ... DHQR_LANE_SIDE=0: everything on the one lane stream.  Single rank only: a device has
+                                 // GPU_MAX_HW_QUEUES = 4 hardware queues and streams beyond them share one -- with the
+                                 // communication stream of P > 1 (and RCCL's own) a fifth stream serialises something
+                                 // (measured with rank threads sharing one GPU: 32768^2 at 2 ranks 904 -> 971 ms)
+  int hi_priority = 0;
+  int quad_head = 1;             // P == 1: the blocks of a quad's second pair as a separate HEAD of the previous wide step
+                                 // (default) or inside its launches (DHQR_QUAD_HEAD=0: measured, slower -- see cs_run)
   int tn_streamk = 1;            // wide k_gemm_tn2 launches: stream-K decomposition (DHQR_TN_STREAMK=0: column-tile x row-slab units + the round model)
   int tn_model_min_tiles = 128;  // wide k_gemm_tn2 launches of at least this many column tiles: split-K factor from the round / partial-traffic estimate (below, the lane is the critical path and
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
@@ -1294,7 +1300,8 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
       int lo = 0, hi = 0;
       HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
       HIPCHECK(hipStreamCreateWithPriority(&c->hi, hipStreamNonBlocking, hi));
-      HIPCHECK(hipStreamCreateWithPriority(&c->hi2, hipStreamNonBlocking, hi));
+      if (const char *e = getenv("DHQR_LANE_SIDE")) c->lane_side = atoi(e) != 0;
+      c->hi_priority = hi;  // c->hi2 is created by the single-rank driver on first use (cs_run)
     }
     if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
     {
@@ -1310,7 +1317,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     }
     if (const char *e = getenv("DHQR_QUAD")) c->quad = atoi(e) != 0;
     if (const char *e = getenv("DHQR_TN_STREAMK")) c->tn_streamk = atoi(e) != 0;
-    if (const char *e = getenv("DHQR_LANE_SIDE")) c->lane_side = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_QUAD_HEAD")) c->quad_head = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QUAD_MIN_COLS")) c->quad_min_cols = std::max<int64_t>(0, atoll(e));
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
@@ -1506,7 +1513,7 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
   // The device copy of the matrix lives in the context between calls (hipMalloc + hipFree of 8 GiB cost ~0.3 s per call at
   // 32768^2, a third of the factorisation; `qr!` is typically called in a loop, test/runtests.jl:84); freed by dhqr_destroy.
   const int64_t ldd = (m + 1) & ~(int64_t)1;
-  CHECK(ensure(c, c->host_mat, (size_t)ldd * (size_t)n + (size_t)n + 16));
+  CHECK(ensure(c, c->host_mat, (size_t)ldd * (size_t)n + (size_t)n + (size_t)m + 32));  // (dhqr_ldiv_f64 keeps b behind alpha)
   double *dA = c->host_mat.p, *dal = dA + (((size_t)ldd * (size_t)n + 1) & ~(size_t)1);
   // DHQR_HOSTIO=0: the plain three-phase form (one hipMemcpy2D up, factorisation, one down)
   static const bool overlap = [] { const char *e = getenv("DHQR_HOSTIO"); return !(e && atoi(e) == 0); }();
@@ -1628,15 +1635,21 @@ int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64
   if (no_columns(m, n)) return DHQR_OK;
   CHECK(check_mat(hA, m, n, lda, true));
   if (!halpha || !hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
-  double *dA = nullptr, *dal = nullptr, *db = nullptr;
+  // the device copy of the context (shared with dhqr_qr_f64: no 8 GiB hipMalloc / hipFree per call) and the staged upload
+  // of dhqr_hostio.h; the factor is uploaded again -- the caller may have changed it since qr! (H.A is the caller's memory)
   const int64_t ldd = (m + 1) & ~(int64_t)1;
-  if (hipMalloc((void **)&dA, (size_t)ldd * n * sizeof(double)) != hipSuccess)
-    return set_err(DHQR_ENOMEM, "hipMalloc failed");
-  if (hipMalloc((void **)&dal, (size_t)n * sizeof(double)) != hipSuccess) { (void)hipFree(dA); return set_err(DHQR_ENOMEM, "hipMalloc failed"); }
-  if (hipMalloc((void **)&db, (size_t)(m + 2) * sizeof(double)) != hipSuccess) { (void)hipFree(dA); (void)hipFree(dal); return set_err(DHQR_ENOMEM, "hipMalloc failed"); }
+  const size_t mat = ((size_t)ldd * (size_t)n + 1) & ~(size_t)1;
+  CHECK(ensure(c, c->host_mat, mat + (size_t)n + (size_t)m + 32));
+  double *dA = c->host_mat.p, *dal = dA + mat, *db = dal + ((n + 1) & ~(int64_t)1);
+  static const bool overlap = [] { const char *e = getenv("DHQR_HOSTIO"); return !(e && atoi(e) == 0); }();
   auto body = [&]() -> int32_t {
-    HIPCHECK(hipMemcpy2DAsync(dA, ldd * sizeof(double), hA, lda * sizeof(double), m * sizeof(double),
-                              n, hipMemcpyHostToDevice, c->stream));
+    if (overlap) {
+      if (!c->hio) c->hio = new HostIo();
+      CHECK(hio_upload(*c->hio, hA, m, n, lda, dA, ldd, c->stream));
+    } else {
+      HIPCHECK(hipMemcpy2DAsync(dA, ldd * sizeof(double), hA, lda * sizeof(double), m * sizeof(double),
+                                n, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHECK(hipMemcpyAsync(dal, halpha, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(db, hb, m * sizeof(double), hipMemcpyHostToDevice, c->stream));  // src:318 copy of b
     CHECK(dhqr_solve_f64(c, dA, m, n, ldd, dal, db));
@@ -1646,9 +1659,7 @@ int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64
   };
   int32_t rc = body();
   (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(dA);
-  (void)hipFree(dal);
-  (void)hipFree(db);
+  if (c->hio) (void)hio_drain(*c->hio);
   return rc;
 }
 

@@ -230,7 +230,8 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
   const int64_t ldv_fixed = any_quad ? panel_ldv(m - groups[0].a * NB) : 0;
   auto gview = [&](int g) { return cs_gbuf_view(S.gbuf[g % CS_NGB].p, m - groups[g].a * NB, ldv_fixed); };
 
-  hipStream_t sW = c->stream, sL = c->hi, sC = S.comm, sX = c->hi2;
+  if (c->lane_side && P == 1 && !c->hi2) HIPCHECK(hipStreamCreateWithPriority(&c->hi2, hipStreamNonBlocking, c->hi_priority));
+  hipStream_t sW = c->stream, sL = c->hi, sC = S.comm, sX = (P == 1) ? c->hi2 : nullptr;
   // Lane side stream (r4): what needs a panel's V but not its T runs on sX beside the panel's second Gram product, k_build_t
   // and the commit -- Y = V_a' C_b for the pair's second panel, the pair's cross term V_b' V_a, the quad's V_2' V_1.  Only
   // for panels this rank factors itself on the asynchronous fast path (a received panel has no "V final" event).
@@ -258,6 +259,20 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
     c->epoch = (int)groups[st.g0 + 1].last();
     return quad_apply(c, g1.VA, g2.VA, g1.ldv, g1.rows_a, g1.pa().T, g1.pb().T, g1.Sba, g2.pa().T, g2.pb().T, g2.Sba, g2.S21,
                       pr.A + groups[st.g0].a * NB + lstart * lda, ncols, lda);
+  };
+  // Does wide step si apply itself to the blocks of group glast + 2 FIRST, as a separate head with its own event?  At P > 1
+  // always (that group's owner needs its block early: its wide launches are short and its lane is not shut out for long).
+  // At P == 1 the only candidate is the second pair of a quad.  A head is six latency-bound launches on 256 columns (two
+  // k_gemm_tn2, the T products, the cross term, a narrow K = 512 subtraction: ~0.55 ms, 45 times per 32768^2) where the
+  // same columns would be two column tiles more of the wide launches, and the lane gets only a few kernels of the second
+  // pair's chain placed before k_gemm_nn_quad shuts it out -- yet folding the head into the wide launches
+  // (DHQR_QUAD_HEAD=0) was SLOWER on the same box (r4, profiles/r04_ab_quad_head.txt: the wide kernels gain 8 ms, the total
+  // loses 3 ms at 32768^2, 3 ms at 16384^2, 4 ms at 24576^2): what the lane gets done early is worth more than the head costs.
+  auto has_head = [&](int si) -> bool {
+    const int gl = steps[si].g0 + steps[si].ng - 1;
+    if (gl + 2 >= G) return false;
+    if (P > 1) return true;
+    return c->quad_head && steps[step_of[(size_t)(gl + 2)]].ng == 2 && steps[step_of[(size_t)(gl + 2)]].g0 == gl + 1;
   };
   // lane work accounted to the panel group of the statistics
   auto lane_begin = [&](bool &was) -> int32_t {
@@ -308,11 +323,11 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
           // opens a step (the block must carry everything before that step: the wide update of step sh - 2), or the
           // quad's first pair when this group is the quad's second (the block is the head of step sh - 1).
           if (second_of_quad) {
-            if (sh >= 1) HIPCHECK(hipStreamWaitEvent(sL, S.ev_head[(sh - 1) % CS_EVR], 0));
+            if (sh >= 1) HIPCHECK(hipStreamWaitEvent(sL, (has_head(sh - 1) ? S.ev_head : S.ev_wide)[(sh - 1) % CS_EVR], 0));
           } else if (sh >= 2) {
             // the head of wide step sh - 2 is the group two behind that step's last one: this group when step sh - 1 is a
             // single group, the SECOND pair of step sh - 1 when that is a quad (then this block is in the rest)
-            const bool in_head = P > 1 && h == steps[sh - 2].g0 + steps[sh - 2].ng + 1;
+            const bool in_head = P > 1 && has_head(sh - 2) && h == steps[sh - 2].g0 + steps[sh - 2].ng + 1;
             HIPCHECK(hipStreamWaitEvent(sL, (in_head ? S.ev_head : S.ev_wide)[(sh - 2) % CS_EVR], 0));
           }
           int64_t ncols = w;
@@ -442,9 +457,8 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
       HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[glast % CS_EVR], 0));
       const int64_t after_next = groups[glast + 1].last() + 1;
       int64_t lo = pr.local_from(after_next);
-      // head: the blocks of group glast + 2 -- what the lane needs first: at P > 1 always, at P == 1 when that group is the
-      // second pair of a quad (it waits for the head instead of the whole step, see produce)
-      if (glast + 2 < G && (P > 1 || (steps[step_of[(size_t)(glast + 2)]].ng == 2 && steps[step_of[(size_t)(glast + 2)]].g0 == glast + 1))) {
+      // head: the blocks of group glast + 2 -- what the lane needs first (has_head above)
+      if (has_head(si)) {
         const int64_t hi = pr.local_from(groups[glast + 2].last() + 1);
         CHECK(apply_step(si, lo, hi - lo));
         lo = hi;

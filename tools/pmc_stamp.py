@@ -32,7 +32,7 @@ def per_launch(root, ctr, scale, cfg="blocked"):
     return {k: [v for _, v in sorted(vs)] for k, vs in out.items()}
 
 
-def plan(n, pair_min_n=12288, quad_min_cols=10240):
+def plan(n, pair_min_n=12288, quad_min_cols=10240, quad_head=False):
     """(rows, ncols) of the wide launches of the single-GPU blocked driver: NN launches, TN2 launches"""
     m = n
     K = n // NB
@@ -62,7 +62,7 @@ def plan(n, pair_min_n=12288, quad_min_cols=10240):
         rows = m - groups[g0][0] * NB
         lo = (last(glast + 1) + 1) * NB
         pieces = []
-        if glast + 2 < G and steps[step_of[glast + 2]][1] == 2 and steps[step_of[glast + 2]][0] == glast + 1:
+        if quad_head and glast + 2 < G and steps[step_of[glast + 2]][1] == 2 and steps[step_of[glast + 2]][0] == glast + 1:  # DHQR_QUAD_HEAD=1 (the default folds the head into the wide launches)
             hi = (last(glast + 2) + 1) * NB
             pieces.append(hi - lo)
             lo = hi
