@@ -851,7 +851,7 @@ def main():
             # the wide kernels alone on synthetic operands of the first (largest) update + the shader clock under them
             g4 = (_ct.c_double * 4)()
             iso = {}
-            for kind, name in ((2, "k_gemm_nn_quad K=512"), (0, "k_gemm_nn_sub K=256"), (1, "k_gemm_tn2")):
+            for kind, name in ((2, "k_gemm_nn_quad K=512"), (0, "k_gemm_nn_sub K=256"), (1, "k_gemm_tn2 + its split-K reduction")):
                 pkg.bench_check(B, B.dhqr_bench_gemm_f64(bh, kind, 16384, 16384, 3, g4))
                 iso[name] = {"tflops": g4[1], "frac_of_peak": g4[1] / PEAK_FP64_MFMA_TFLOPS, "shader_mhz": g4[2]}
             out["gemm_kernels_in_isolation_16384"] = iso

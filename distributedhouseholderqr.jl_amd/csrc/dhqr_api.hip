@@ -1300,7 +1300,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
       int lo = 0, hi = 0;
       HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
       HIPCHECK(hipStreamCreateWithPriority(&c->hi, hipStreamNonBlocking, hi));
-      if (const char *e = getenv("DHQR_LANE_SIDE")) c->lane_side = atoi(e) != 0;
+      if (const char *e = getenv("DHQR_LANE_SIDE")) c->lane_side = std::max(0, std::min(2, atoi(e)));
       c->hi_priority = hi;  // c->hi2 is created by the single-rank driver on first use (cs_run)
     }
     if (const char *e = getenv("DHQR_LOOKAHEAD")) c->lookahead = atoi(e) != 0;

@@ -327,7 +327,7 @@ int32_t dhqr_bench_stream_f64(dhqr_ctx *c, int64_t bytes, double *gbps) {
 }
 
 // GEMM micro-benchmark of the two wide trailing-update kernels on synthetic operands (not a product entry point):
-// kind 0: k_gemm_nn_sub<2,256> (C -= [V_a V_b] W, rows x ncols), kind 1: k_gemm_tn2 (Y = [V_a V_b]' C), kind 2: k_gemm_nn_quad (K = 512).
+// kind 0: k_gemm_nn_sub<2,256> (C -= [V_a V_b] W, rows x ncols), kind 1: k_gemm_tn2 + its split-K reduction as the driver launches them (pair_vtc: Y = [V_a V_b]' C), kind 2: k_gemm_nn_quad (K = 512).
 // `reps` timed launches after one warm-up; a one-wave clock probe runs beside them on a second stream.
 // out = {ms per launch, TFLOP/s, shader MHz under the kernel, 0}.  The A/B switches of the context apply.
 int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t ncols, int32_t reps, double *out4) {
@@ -352,9 +352,11 @@ int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t nco
     CHECK(dhqr_fill_uniform_f64(c, C, rows, ncols, ldc, 3, rows, 0, 128, 1, 0));
     const int64_t ntiles = ncols / 128, gx = rows / 128;
     int64_t nsplit = 1, rps = rows;
-    if (kind == 1) {
-      pick_split(rows, ntiles, wide_slots(c), ntiles <= 2 ? 256 : 64, &nsplit, &rps, wide_slots(c));
-      HIPCHECK(hipMalloc((void **)&Y, (size_t)nsplit * ld2 * ncols * 8));
+    if (kind == 1) {  // through pair_vtc: the decomposition the driver ships (stream-K for wide launches) + its reduction
+      (void)nsplit;
+      (void)rps;
+      HIPCHECK(hipMalloc((void **)&Y, (size_t)ld2 * ncols * 8));
+      CHECK(ensure(c, c->ws[c->cur_ws].w1, (size_t)16 * ld2 * ncols));
     }
     bool timed_nn = false;
     auto launch = [&]() {
@@ -374,8 +376,7 @@ int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t nco
         else
           launch_nn_sub<256>(c, true, grid, V, ldv, W, ld2, C, ldc, rows, ncols, swz, false);
       } else {
-        hipLaunchKernelGGL((k_gemm_tn2<2>), dim3((unsigned)std::min<int64_t>(ntiles * nsplit, wide_slots(c))), dim3(512), 0, c->stream, V, ldv,
-                           (const double *)C, ldc, rows, ncols, rps, Y, ld2 * ncols, (int64_t)0);
+        (void)pair_vtc(c, V, ldv, rows, C, ldc, ncols, true, Y);
       }
     };
     launch();

@@ -230,8 +230,11 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
   const int64_t ldv_fixed = any_quad ? panel_ldv(m - groups[0].a * NB) : 0;
   auto gview = [&](int g) { return cs_gbuf_view(S.gbuf[g % CS_NGB].p, m - groups[g].a * NB, ldv_fixed); };
 
-  if (c->lane_side && P == 1 && !c->hi2) HIPCHECK(hipStreamCreateWithPriority(&c->hi2, hipStreamNonBlocking, c->hi_priority));
-  hipStream_t sW = c->stream, sL = c->hi, sC = S.comm, sX = (P == 1) ? c->hi2 : nullptr;
+  // (DHQR_LANE_SIDE=2 turns the side stream on at P > 1 too: for the first runs on a real multi-GPU node, where each rank has
+  // its GPU's four hardware queues to itself and the chain it shortens is the critical path)
+  const bool want_side = c->lane_side == 2 || (c->lane_side == 1 && P == 1);
+  if (want_side && !c->hi2) HIPCHECK(hipStreamCreateWithPriority(&c->hi2, hipStreamNonBlocking, c->hi_priority));
+  hipStream_t sW = c->stream, sL = c->hi, sC = S.comm, sX = want_side ? c->hi2 : nullptr;
   // Lane side stream (r4): what needs a panel's V but not its T runs on sX beside the panel's second Gram product, k_build_t
   // and the commit -- Y = V_a' C_b for the pair's second panel, the pair's cross term V_b' V_a, the quad's V_2' V_1.  Only
   // for panels this rank factors itself on the asynchronous fast path (a received panel has no "V final" event).

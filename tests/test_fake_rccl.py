@@ -96,6 +96,7 @@ def _mg(L, ndev):
 # divide by 3 -> ring fallback inside the scatter+all-gather algorithm; 8 ranks with 2 cyclic blocks: six ranks own nothing
 @pytest.mark.parametrize("ndev,m,n,env", [
     (2, 520, 384, {"DHQR_BCAST": "ring"}),
+    (2, 520, 384, {"DHQR_BCAST": "ring", "DHQR_LANE_SIDE": 2}),  # the lane's side stream at P > 1 (off by default there)
     pytest.param(2, 700, 512, {"DHQR_BCAST": "sag", "DHQR_BCAST_SAG_MIN": 1}, marks=_SLOW),
     (2, 520, 384, {"DHQR_BCAST_SAG_MIN": 1}),
     (3, 640, 522, {"DHQR_BCAST": "sag", "DHQR_BCAST_SAG_MIN": 1}),
