@@ -7,8 +7,9 @@ the blocks of pair g+2 first); a panel is available to the other ranks one broad
 = a pair of panels (--own 2, the shipped layout: the second panel of a pair never waits for a broadcast) or one panel
 (--own 1, the layout until mid round 2).
 
-Inputs measured on one MI355X this round (profiles/r02_*):
-  trailing GEMMs in situ                          54 TFLOP/s per GPU (K = 256 pair update, both passes)
+Inputs measured on one MI355X (profiles/r02_*; round 4 re-checked the chain against the per-launch trace
+profiles/r04_blocked32768_per_launch.csv.gz: 290 us per 32768-row panel incl. ~40 us of event bubbles, unchanged kernels):
+  trailing GEMMs in situ                          54 TFLOP/s per GPU (K = 256 pair update, both passes; 60 with quad steps at one GPU)
   panel chain, uncontended                        0.215 ms single-workgroup kernels + small GEMMs + launch gaps (fixed)
                                                 + 0.035 ms * rows/32768 (Gram / product GEMMs, commit)
                                                   [fit to the per-panel time of the no-look-ahead driver at 8192^2 /
@@ -23,7 +24,7 @@ Assumed (NOT measured): broadcast of one panel = latency + bytes / bandwidth.
 import argparse
 
 
-def simulate(P, n=32768, nb=128, gemm_tflops=54.0, small_ms=0.215, var_ms=0.035, bw_gbps=100.0, lat_us=40.0, own=2):
+def simulate(P, n=32768, nb=128, gemm_tflops=54.0, small_ms=0.215, var_ms=0.035, bw_gbps=100.0, lat_us=40.0, own=2, side=False):
     # own = panels per cyclic block: 2 (DHQR_CS_BLOCK = 256: the shipped layout) or 1 (the earlier 128-column blocks)
     K = n // nb
     G = K // 2
@@ -31,6 +32,11 @@ def simulate(P, n=32768, nb=128, gemm_tflops=54.0, small_ms=0.215, var_ms=0.035,
     t_panel = lambda k: (small_ms + var_ms * rows(k) / n) * 1e-3
     t_narrow = lambda k, pair: (0.03 + 0.10 * rows(k) / n) * 1e-3 * (1.6 if pair else 1.0)
     t_cross = lambda k: (0.02 + 0.04 * rows(k) / n) * 1e-3
+    # side stream (round 4, DHQR_LANE_SIDE): Y = V_a' C_b and the pair's cross term run beside panel a's / b's verification
+    # and commit -- the split-K product + reduction of the narrow update (45 of 87 us at 32768 rows) and the cross term leave
+    # the chain (per-launch trace profiles/r04_blocked32768_per_launch.csv.gz); the events cost ~10 us
+    if side:
+        t_cross = lambda k: 0.010e-3
     t_bcast = lambda k: 0.0 if P == 1 else lat_us * 1e-6 + rows(k) * nb * 8 / (bw_gbps * 1e9)
     t_wide = lambda g, ncols: 2 * 4.0 * nb * (rows(2 * g) - nb / 2) * ncols / (gemm_tflops * 1e12)
     lane = [0.0] * P
@@ -56,7 +62,7 @@ def simulate(P, n=32768, nb=128, gemm_tflops=54.0, small_ms=0.215, var_ms=0.035,
                 t += t_narrow(2 * (h - 1), True) if (own == 1 or idx == 0) else 0.0
             if idx == 1:
                 # panel a -> block b: local when the pair lives on one rank, else after a's broadcast has arrived
-                t = (t if own == 2 else max(t, avail[a])) + t_narrow(a, False)
+                t = (t if own == 2 else max(t, avail[a])) + t_narrow(a, False) * (0.5 if (side and own == 2) else 1.0)
             t += t_panel(x)
             lane[o] = t
             avail[x] = t + t_bcast(x)
@@ -86,13 +92,16 @@ def main():
     ap.add_argument("--bw-gbps", type=float, default=100.0)
     ap.add_argument("--lat-us", type=float, default=40.0)
     ap.add_argument("--own", type=int, default=2, help="panels per cyclic block: 2 (shipped) or 1 (128-column blocks)")
+    ap.add_argument("--t1", type=float, default=0.843, help="measured 1-GPU time in seconds (round 4: 0.843)")
     a = ap.parse_args()
     t1 = simulate(1, small_ms=a.small_ms, var_ms=a.var_ms)
     print(f"fixed part of the panel chain {a.small_ms:.2f} ms, broadcast {a.bw_gbps:.0f} GB/s + {a.lat_us:.0f} us (assumed)")
-    print("  P   model time [ms]   vs model P=1   (measured 1 GPU: 0.90 s; the model's P=1 has no contention between lane and wide)")
+    print(f"  P   model time [ms]   vs model P=1   (measured 1 GPU: {a.t1:.3f} s; the model's P=1 has no contention between lane and wide)")
     for P in (1, 2, 4, 8):
         t = simulate(P, small_ms=a.small_ms, var_ms=a.var_ms, bw_gbps=a.bw_gbps, lat_us=a.lat_us, own=a.own)
-        print(f"  {P}   {t * 1e3:8.1f}        {t1 / t:5.2f}x        vs measured 0.90 s: {0.90 / t:5.2f}x")
+        ts = simulate(P, small_ms=a.small_ms, var_ms=a.var_ms, bw_gbps=a.bw_gbps, lat_us=a.lat_us, own=a.own, side=True)
+        print(f"  {P}   {t * 1e3:8.1f}        {t1 / t:5.2f}x        vs measured {a.t1:.3f} s: {a.t1 / t:5.2f}x"
+              f"     with the lane's side stream (DHQR_LANE_SIDE=2 at P > 1): {ts * 1e3:7.1f} ms = {a.t1 / ts:5.2f}x")
 
 
 if __name__ == "__main__":
