@@ -63,6 +63,7 @@ struct dhqr_ctx {
                                  // communication stream of P > 1 (and RCCL's own) a fifth stream serialises something
                                  // (measured with rank threads sharing one GPU: 32768^2 at 2 ranks 904 -> 971 ms)
   int hi_priority = 0;
+  int profile_lane = 0;          // DHQR_PROFILE_LANE=1: the lane's narrow updates / cross terms are timed too (cs_run)
   int quad_head = 1;             // P == 1: the blocks of a quad's second pair as a separate HEAD of the previous wide step
                                  // (default) or inside its launches (DHQR_QUAD_HEAD=0: measured, slower -- see cs_run)
   int tn_streamk = 1;            // wide k_gemm_tn2 launches: stream-K decomposition (DHQR_TN_STREAMK=0: column-tile x row-slab units + the round model)
@@ -123,7 +124,7 @@ struct dhqr_ctx {
   struct HostIo *hio = nullptr;
   int64_t n_resume = 0;  // passes of the blocked driver that resumed after a rejected panel
   // profiling
-  struct Ev { hipEvent_t a, b; int cat; };
+  struct Ev { hipEvent_t a, b; int cat; int start_from = -1; };  // start_from >= 0: the section starts at the END event of that entry (prof_switch)
   std::vector<Ev> evs;
   size_t ev_used = 0;
   dhqr_stats st;
@@ -159,6 +160,7 @@ static int32_t prof_begin(dhqr_ctx *c, int cat) {
     c->evs.push_back(e);
   }
   c->evs[c->ev_used].cat = cat;
+  c->evs[c->ev_used].start_from = -1;
   HIPCHECK(hipEventRecord(c->evs[c->ev_used].a, c->stream));
   return DHQR_OK;
 }
@@ -166,6 +168,23 @@ static int32_t prof_end(dhqr_ctx *c) {
   if (!c->profiling) return DHQR_OK;
   HIPCHECK(hipEventRecord(c->evs[c->ev_used].b, c->stream));
   c->ev_used++;
+  return DHQR_OK;
+}
+// End the running section and begin the next one (category `cat`) at the SAME point of the same stream with ONE event
+// record instead of two: every record is a bubble on the stream, and the wide stream carries three back-to-back sections
+// per update (V'C | T products | subtraction).
+static int32_t prof_switch(dhqr_ctx *c, int cat) {
+  if (!c->profiling) return DHQR_OK;
+  CHECK(prof_end(c));
+  if (c->ev_used == c->evs.size()) {
+    dhqr_ctx::Ev e;
+    HIPCHECK(hipEventCreate(&e.a));
+    HIPCHECK(hipEventCreate(&e.b));
+    e.cat = cat;
+    c->evs.push_back(e);
+  }
+  c->evs[c->ev_used].cat = cat;
+  c->evs[c->ev_used].start_from = (int)c->ev_used - 1;
   return DHQR_OK;
 }
 static int32_t prof_resolve(dhqr_ctx *c) {
@@ -176,7 +195,8 @@ static int32_t prof_resolve(dhqr_ctx *c) {
                          &c->st.n_gemm_avw, &c->st.n_rank1, &c->st.n_solve};
   for (size_t i = 0; i < c->ev_used; ++i) {
     float t = 0.f;
-    HIPCHECK(hipEventElapsedTime(&t, c->evs[i].a, c->evs[i].b));
+    const int sf = c->evs[i].start_from;
+    HIPCHECK(hipEventElapsedTime(&t, sf >= 0 ? c->evs[(size_t)sf].b : c->evs[i].a, c->evs[i].b));
     *ms[c->evs[i].cat] += (double)t;
     *cnt[c->evs[i].cat] += 1;
   }
@@ -505,8 +525,8 @@ static int32_t panel_apply(dhqr_ctx *c, const PanelBuf &pb, int64_t rows, double
                          c->stream, V, ldv, (const double *)C, ldc, 1, (int64_t)0, rows, ncols, rps,    \
                          ws.w1.p, (int64_t)DHQR_NBV, wstride);                                           \
     }                                                                                                \
-    CHECK(prof_end(c));                                                                              \
-    CHECK(prof_begin(c, CAT_TW));                                                                    \
+    CHECK(prof_switch(c, CAT_TW));                                                                              \
+    /* (one event ends the previous section and starts this one) */                                                                    \
     const double *w1sum = ws.w1.p;                                                                   \
     if (nsplit > 1) { /* bandwidth-friendly, deterministic split-K reduction */                      \
       if (phase != 2)                                                                                \
@@ -522,8 +542,8 @@ static int32_t panel_apply(dhqr_ctx *c, const PanelBuf &pb, int64_t rows, double
     hipLaunchKernelGGL((k_gemm_tn<2, 1, KW_>), dim3((unsigned)ntiles, 1), dim3(256), 0, c->stream, Top, \
                        (int64_t)DHQR_NBV, w1sum, (int64_t)DHQR_NBV, 1, (int64_t)0, (int64_t)KW_, ncols,  \
                        (int64_t)KW_, ws.w2.p, (int64_t)DHQR_NBV, (int64_t)0);                            \
-    CHECK(prof_end(c));                                                                              \
-    CHECK(prof_begin(c, CAT_AVW));                                                                   \
+    CHECK(prof_switch(c, CAT_AVW));                                                                              \
+    /* (one event ends the previous section and starts this one) */                                                                   \
     const int64_t gx_ = (rows + 127) / 128;                                                          \
     const int swz_ = (gx_ >= 16 && ntiles >= 16) ? 1 : 0;                              \
     dim3 grid((unsigned)gx_, (unsigned)ntiles);                                                      \
@@ -1027,14 +1047,14 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
   // Y = [V_a V_b]' C: ONE pass over C for both panels (stacked 256 x ncols result), then the split-K reduction
   CHECK(prof_begin(c, CAT_VTA));
   CHECK(pair_vtc(c, Vp, ldv, rows, C, ldc, ncols, vec, ws.w1r.p));
-  CHECK(prof_end(c));
+  CHECK(prof_switch(c, CAT_TW));
 
-  CHECK(prof_begin(c, CAT_TW));
+  /* (one event ends the previous section and starts this one) */
   if (ar) CHECK(comm_allreduce_sum(ar, ws.w1r.p, wstride, c->stream));
   CHECK(pair_tw(c, ws.w1r.p, Ta, Tb, Sba, ws.w2.p, ld2, ncols));
-  CHECK(prof_end(c));
+  CHECK(prof_switch(c, CAT_AVW));
 
-  CHECK(prof_begin(c, CAT_AVW));
+  /* (one event ends the previous section and starts this one) */
   const int64_t gx = (rows + 127) / 128;
   // wide launches in nn_chunks(...) column chunks: see nn_chunks
   const int64_t nch = nn_chunks(c, ntiles);
@@ -1087,15 +1107,15 @@ static int32_t quad_apply(dhqr_ctx *c, const double *V1, const double *V2, int64
   CHECK(prof_begin(c, CAT_VTA));
   CHECK(pair_vtc(c, V1, ldv, rows, C, ldc, ncols, true, Y1));
   CHECK(pair_vtc(c, V2, ldv, rows2, C + 2 * NB, ldc, ncols, true, Y2));
-  CHECK(prof_end(c));
+  CHECK(prof_switch(c, CAT_TW));
 
-  CHECK(prof_begin(c, CAT_TW));
+  /* (one event ends the previous section and starts this one) */
   CHECK(pair_tw(c, Y1, Ta, Tb, Sba, W, ld4, ncols));
   launch_nn_sub<256>(c, true, dim3(2, (unsigned)ntiles), S21, ld2, (const double *)W, ld4, Y2, ld2, ld2, ncols, 0, false);
   CHECK(pair_tw(c, Y2, Tc, Td, Sdc, W + ld2, ld4, ncols));
-  CHECK(prof_end(c));
+  CHECK(prof_switch(c, CAT_AVW));
 
-  CHECK(prof_begin(c, CAT_AVW));
+  /* (one event ends the previous section and starts this one) */
   const int *st = pred_stat(c);
   const int64_t gx = (rows + 127) / 128;
   if (ntiles <= 2 && gx * ntiles < 512) {  // narrow (the lane / the head of a wide step): 64-row tiles
@@ -1318,6 +1338,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_QUAD")) c->quad = atoi(e) != 0;
     if (const char *e = getenv("DHQR_TN_STREAMK")) c->tn_streamk = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QUAD_HEAD")) c->quad_head = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_PROFILE_LANE")) c->profile_lane = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QUAD_MIN_COLS")) c->quad_min_cols = std::max<int64_t>(0, atoll(e));
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));

@@ -277,16 +277,19 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
     if (P > 1) return true;
     return c->quad_head && steps[step_of[(size_t)(gl + 2)]].ng == 2 && steps[step_of[(size_t)(gl + 2)]].g0 == gl + 1;
   };
-  // lane work accounted to the panel group of the statistics
+  // Lane sections outside the panel factorisations (narrow updates, cross terms): timed as part of the panel group only on
+  // request (DHQR_PROFILE_LANE=1).  Every timed section is two event records on the lane -- the critical chain -- and a
+  // profiled 32768^2 run had ~2000 of them per factorisation (~4 ms of bubbles inside bench.py's timed region, r4:
+  // 832-833 ms unprofiled against 836-838 ms profiled on one box); the panel factorisations keep their own pair.
   auto lane_begin = [&](bool &was) -> int32_t {
-    CHECK(prof_begin(c, CAT_PANEL));
+    if (c->profile_lane) CHECK(prof_begin(c, CAT_PANEL));
     was = c->profiling;
     c->profiling = false;
     return DHQR_OK;
   };
   auto lane_end = [&](bool was) -> int32_t {
     c->profiling = was;
-    return prof_end(c);
+    return c->profile_lane ? prof_end(c) : DHQR_OK;
   };
 
   // produce group h: owners update + factor their panels (lane), everybody takes part in the broadcasts (comm),
