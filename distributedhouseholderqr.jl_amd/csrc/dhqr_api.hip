@@ -2316,7 +2316,7 @@ int32_t dhqr_comm_counters(dhqr_comm *cm, int64_t *out4) {
 // leaves it as it is.  Synchronises the device.
 int32_t dhqr_comm_timing(dhqr_comm *cm, int32_t on, double *out4) {
   if (!cm) return set_err(DHQR_EINVAL, "null communicator");
-  if (cm->ctx) HIPCHECK(hipSetDevice(cm->ctx->device));
+  ENTER(cm->ctx);  // the rank's device for the duration of the call; the caller's current device is restored on return
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   dhqr_comm *chs[2] = {cm, cm->lane};
   for (dhqr_comm *ch : chs) {

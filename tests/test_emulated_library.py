@@ -183,7 +183,7 @@ def test_wide_update_on_the_persistent_tn_kernel(emu, orc):
     emu.dhqr_destroy(h)
 
 
-@pytest.mark.parametrize("m,n", [(1290, 1280), (1161, 1152)])
+@pytest.mark.parametrize("m,n", [(1040, 896), pytest.param(1161, 1152, marks=_SLOW)])
 def test_wide_tn_stream_k(emu, orc, m, n):
     """stream-K decomposition of the wide k_gemm_tn2 launches (normally from 128 column tiles on; DHQR_TN_MODEL_MIN_TILES=3
     brings it to a small matrix): 128-row fine units numbered tile-major, a contiguous range per workgroup, a tile's
