@@ -464,8 +464,12 @@ def roofline_groups(st, steps, m=0, n=0, nb=0):
         groups.append(dict(kernel="k_gemm_tn2 / k_gemm_tn (W = [V_a V_b]'*A, FP64 MFMA)", symbol="k_gemm_tn2", bound="mfma", ms=st["ms_gemm_vta"],
                            launches=st["n_gemm_vta"], work=st["flops_gemm_vta"]))
     if st["ms_panel"] > 0:
-        groups.append(dict(kernel="panel lane: Gram/Cholesky/replay/narrow-update kernels (dhqr_recon.h)", symbol="panel lane", bound="hbm", ms=st["ms_panel"],
-                           launches=st["n_panel"], work=st["bytes_panel"]))
+        # a LATENCY chain (two single-workgroup kernels per panel), not a bandwidth kernel: `ms` is the elapsed time of the panel
+        # factorisations on the lane INCLUDING their wait for CUs behind the wide launches (DESIGN.md section 3 "The chain
+        # budget": ~0.29 ms per panel on an idle chip), priced against the reference's in-panel HBM traffic (16 B per element
+        # touched per reflector); the narrow updates / cross terms of the lane are timed only under DHQR_PROFILE_LANE=1
+        groups.append(dict(kernel="panel lane: the panel factorisations (Gram / Cholesky + replay / reconstruction kernels, dhqr_recon.h); elapsed incl. waits for CUs",
+                           symbol="panel lane", bound="hbm", ms=st["ms_panel"], launches=st["n_panel"], work=st["bytes_panel"]))
     if st["ms_rank1"] > 0:
         # work = algorithmic HBM bytes of the launches AS IMPLEMENTED: a pass applies K reflectors to every trailing column
         # it loads and stores once (16 B per element and pass = 16/K B per element and reflector)

@@ -170,6 +170,7 @@ BENCH_SIGNATURES = {
     "dhqr_debug_mfma_probe": (_i32, [_p, _p, _p, _p]),
     "dhqr_bench_gemm_f64": (_i32, [_p, _i32, _i64, _i64, _i32, _pd]),
     "dhqr_bench_mma_probe_f64": (_i32, [_p, _i32, _i32, _pd]),
+    "dhqr_bench_lane_probe_f64": (_i32, [_p, _i64, _i32, _i32, _i32, _pd]),
 }
 
 _lib = None

@@ -21,6 +21,7 @@ streams); every FLOP runs in the HIP library.  No CPU fallback exists.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -47,7 +48,11 @@ class Context:
         return self._h
 
     def use_torch_stream(self):
-        """run on torch's current stream of this device (so torch ops and dhqr kernels order)"""
+        """run on torch's current stream of this device (so torch ops and dhqr kernels order).  DHQR_OWN_STREAM=1
+        (experiments): keep the context's own stream; the caller then orders with torch by synchronising."""
+        if os.environ.get("DHQR_OWN_STREAM") == "1":
+            check(_lib.lib().dhqr_use_own_stream(self._h))
+            return
         s = torch.cuda.current_stream(self.device).cuda_stream
         check(_lib.lib().dhqr_set_stream(self._h, ctypes.c_void_p(s)))
 

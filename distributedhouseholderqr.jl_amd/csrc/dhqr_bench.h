@@ -473,6 +473,109 @@ int32_t dhqr_bench_mma_probe_f64(dhqr_ctx *c, int32_t mode, int32_t threads, dou
   return DHQR_OK;
 }
 
+// ---- feasibility probe for a look-ahead lane that CO-RESIDES with the wide subtraction (tools/thin_lane_probe.py) --------
+// Two k_gemm_nn_quad workgroups fill the register file of every SIMD (2 x 4 waves x 256 VGPRs) and 140 of the CU's 160 KB of
+// LDS; a slot frees when one of them retires: 4 waves x 256 registers (or 16 waves x 64) and ~90 KB of LDS.  Could the lane's
+// kernels be placed in such slots while the wide launch runs, and at what price?  This entry point runs, on the context's
+// HIGH-PRIORITY stream, `reps` times: (1) a Gram product of a rows x 128 panel by k_gemm_tn with `nsplit` workgroups (the
+// footprint of one subtraction workgroup: 256 threads, 72 KB of LDS) + its reduction; (2) a stand-in for the single-workgroup
+// panel kernels: ONE workgroup of 1024 threads, few registers, `lds_kb` KB of dynamic LDS, 128 dependent barrier steps
+// (LDS write -> barrier -> LDS read -> a few FMAs).  out4 = {ms per Gram + reduction, ms per stand-in, total ms per repetition,
+// 0}.  The caller runs it alone and beside dhqr_bench_gemm_f64 on ANOTHER context.
+// NR live doubles per thread: 8 (~30 VGPRs: 16 waves fit the 256 registers per SIMD one retiring subtraction workgroup frees)
+// or 40 (~90 VGPRs: 16 waves need 360 per SIMD, i.e. BOTH subtraction workgroups of a CU gone -- k_panel_top / k_build_t today)
+extern "C++" {
+template <int NR>
+__global__ __launch_bounds__(1024) void k_lane_standin(double *__restrict__ out, int steps) {
+  extern __shared__ double lsm[];
+  const int t = threadIdx.x;
+  double acc[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) acc[i] = 1.0 + 1e-9 * (t + i);
+  for (int s = 0; s < steps; ++s) {
+    double *row = lsm + (s & 1) * 1024;
+    double w = 0.0;
+#pragma unroll
+    for (int i = 0; i < NR; i += 8) w += acc[i];
+    row[t] = w;
+    __syncthreads();
+    const double x = row[(t + 1 + s) & 1023], y = row[(t * 7 + s) & 1023];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) acc[i] = fma(acc[i], 0.999999, x * 1e-9 + y * 1e-10 * (i + 1));
+  }
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) r += acc[i];
+  if (r == 12345.678) out[t] = r;  // keep the chain alive
+}
+}  // extern "C++"
+int32_t dhqr_bench_lane_probe_f64(dhqr_ctx *c, int64_t rows, int32_t nsplit, int32_t lds_kb_in, int32_t reps, double *out4) {
+  ENTER(c);
+  const bool real = lds_kb_in == 0;  // 0: the REAL single-workgroup kernels, k_panel_top (on the Gram matrix just formed) + k_build_t
+  const bool heavy = lds_kb_in < 0;  // negative: the register-heavy stand-in (~90 VGPRs) with |lds_kb| KB of LDS
+  const int32_t lds_kb = real ? 64 : (heavy ? -lds_kb_in : lds_kb_in);
+  if (!out4 || rows < 1024 || rows % 16 || nsplit < 1 || nsplit > 1024 || lds_kb < 16 || lds_kb > 160 || reps < 1)
+    return set_err(DHQR_EINVAL, "bad arguments");
+  const int64_t NB = DHQR_NBV, ldp = rows;
+  double *P = nullptr, *part = nullptr, *G = nullptr, *sink = nullptr, *scr = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipStream_t st = c->hi;
+  auto body = [&]() -> int32_t {
+    HIPCHECK(hipMalloc((void **)&P, (size_t)ldp * NB * 8));
+    HIPCHECK(hipMalloc((void **)&part, (size_t)nsplit * NB * NB * 8));
+    HIPCHECK(hipMalloc((void **)&G, (size_t)NB * NB * 8));
+    HIPCHECK(hipMalloc((void **)&sink, 1024 * 8));
+    HIPCHECK(hipMalloc((void **)&scr, (size_t)(4096 + 4 * NB * NB) * 8));
+    for (auto &e : ev) HIPCHECK(hipEventCreate(&e));
+    CHECK(dhqr_fill_uniform_f64(c, P, rows, NB, ldp, 5, rows, 0, 128, 1, 0));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lane_standin<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lane_standin<40>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024));
+    int64_t rps = (rows + nsplit - 1) / nsplit;
+    rps = (rps + G_KT - 1) / G_KT * G_KT;
+    const int64_t ns = (rows + rps - 1) / rps;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int r = 0; r <= reps; ++r) {  // r == 0: warm-up
+      HIPCHECK(hipEventRecord(ev[0], st));
+      hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3(1, (unsigned)ns), dim3(256), 0, st, (const double *)P, ldp, (const double *)P, ldp, 1,
+                         (int64_t)0, rows, NB, rps, part, NB, NB * NB);
+      hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)(NB * NB / 64)), dim3(256), 0, st, (const double *)part, (int)ns, NB * NB, NB * NB, G);
+      HIPCHECK(hipEventRecord(ev[1], st));
+      if (real) {
+        hipLaunchKernelGGL((k_panel_top<false>), dim3(1), dim3(1024), 0, st, (const double *)G, (const double *)P, ldp, scr, scr + 1024,
+                           scr + 1024 + NB * NB, (int *)(scr + 1024 + 2 * NB * NB));
+        hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, st, (const double *)G, (int)NB, scr + 2048 + 2 * NB * NB, scr + 2048 + 3 * NB * NB,
+                           0.0, (int *)nullptr, 0, (double *)nullptr);
+      } else if (heavy)
+        hipLaunchKernelGGL(k_lane_standin<40>, dim3(1), dim3(1024), (size_t)lds_kb * 1024, st, sink, 128);
+      else
+        hipLaunchKernelGGL(k_lane_standin<8>, dim3(1), dim3(1024), (size_t)lds_kb * 1024, st, sink, 128);
+      HIPCHECK(hipEventRecord(ev[2], st));
+      HIPCHECK(hipEventSynchronize(ev[2]));
+      float a = 0.f, b = 0.f;
+      HIPCHECK(hipEventElapsedTime(&a, ev[0], ev[1]));
+      HIPCHECK(hipEventElapsedTime(&b, ev[1], ev[2]));
+      if (r > 0) {
+        acc[0] += a;
+        acc[1] += b;
+        acc[2] += a + b;
+      }
+    }
+    LAUNCHCHECK();
+    for (int i = 0; i < 3; ++i) out4[i] = acc[i] / reps;
+    out4[3] = 0.0;
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  (void)hipStreamSynchronize(st);
+  for (auto &e : ev)
+    if (e) (void)hipEventDestroy(e);
+  double *ps[] = {P, part, G, sink, scr};
+  for (double *p_ : ps)
+    if (p_) (void)hipFree(p_);
+  return rc;
+}
+
 // test hook (not in dhqr.h's stable surface, declared in the test binding only):
 // raw MFMA D registers for the documented operand maps
 int32_t dhqr_debug_mfma_probe(dhqr_ctx *c, const double *da, const double *db, double *dout) {

@@ -43,6 +43,11 @@ int32_t dhqr_bench_gemm_f64(dhqr_ctx *ctx, int32_t kind, int64_t rows, int64_t n
  * 4 the NN kernel's operand layouts; threads = 256 / 512 (one / two waves per SIMD).
  * out2 = {cycles per MFMA per wave, TFLOP/s}.  Synchronous. */
 int32_t dhqr_bench_mma_probe_f64(dhqr_ctx *ctx, int32_t mode, int32_t threads, double *out2);
+/* Feasibility probe for lane kernels that co-reside with the wide subtraction (csrc/dhqr_bench.h, tools/thin_lane_probe.py):
+ * on the context's high-priority stream, `reps` times a Gram product of a rows x 128 panel in `nsplit` workgroups of the
+ * subtraction's footprint + its reduction, then a one-workgroup stand-in for the panel kernels (1024 threads, lds_kb KB of
+ * LDS, 128 barrier steps).  out4 = {ms Gram + reduction, ms stand-in, ms total, 0} per repetition.  Synchronous. */
+int32_t dhqr_bench_lane_probe_f64(dhqr_ctx *ctx, int64_t rows, int32_t nsplit, int32_t lds_kb, int32_t reps, double *out4);
 
 #ifdef __cplusplus
 }
