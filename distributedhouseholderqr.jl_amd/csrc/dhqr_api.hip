@@ -66,6 +66,8 @@ struct dhqr_ctx {
   int profile_lane = 0;          // DHQR_PROFILE_LANE=1: the lane's narrow updates / cross terms are timed too (cs_run)
   int quad_head = 1;             // P == 1: the blocks of a quad's second pair as a separate HEAD of the previous wide step
                                  // (default) or inside its launches (DHQR_QUAD_HEAD=0: measured, slower -- see cs_run)
+  int narrow_tn = 1;             // V'C of one or two column tiles (the look-ahead lane's updates, the heads, the cross term of a quad) through
+                                 // k_gemm_tn in slot-sized workgroups (DHQR_NARROW_TN=0: k_gemm_tn2, one whole CU per workgroup)
   int tn_streamk = 1;            // wide k_gemm_tn2 launches: stream-K decomposition (DHQR_TN_STREAMK=0: column-tile x row-slab units + the round model)
   int tn_model_min_tiles = 128;  // wide k_gemm_tn2 launches of at least this many column tiles: split-K factor from the round / partial-traffic estimate (below, the lane is the critical path and
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
@@ -945,11 +947,39 @@ static inline int64_t nn_chunks(const dhqr_ctx *c, int64_t tiles, bool columns =
   return std::max<int64_t>(1, std::min<int64_t>(c->nn_split, tiles / c->nn_chunk_tiles));
 }
 
+// Y (256 x ncols, ld 256) = [V_a V_b]' C for ONE or TWO column tiles, in workgroups that fit beside a running wide
+// subtraction.  k_gemm_tn2 needs a whole CU per workgroup (8 waves x 256 VGPRs, 110 KB of LDS): beside k_gemm_nn_quad,
+// whose 256-thread workgroups sit two to a CU and are replaced one at a time, a launch of ~250 of them on the look-ahead
+// lane found no CU until the subtraction had drained -- the r4 per-launch trace shows the lane's narrow V'C "running"
+// 12.2 ms beside a 12.7 ms subtraction, and the ~0.9 ms of panel chain behind it running after the subtraction with the
+// wide stream idle (45 x ~0.9 ms of 840 ms at 32768^2).  k_gemm_tn (256 threads, 220 VGPRs, 72 KB: the size of ONE
+// subtraction workgroup) takes the slots as they free up and runs at idle speed there (profiles/r04_thin_lane_probe.txt:
+// a 234-workgroup Gram launch 42 us beside the subtraction, 39 us alone).  Here: blockIdx.z = 0 / 1 = V_a / V_b, i.e. twice
+// the workgroups of half the size, C read once more (a narrow update's C is a few MB).  part: nsplit x 256 x ncols.
+static int32_t narrow_vtc(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows, const double *C, int64_t ldc,
+                          int64_t ncols, bool vec, Buf &part, double *Y) {
+  const int64_t ntiles = (ncols + 127) / 128, ld2 = 2 * DHQR_NBV, wstride = ld2 * ncols;
+  int64_t nsplit, rps;
+  pick_split(rows, 2 * ntiles, 512, 256 / ntiles, &nsplit, &rps, 512, 64);
+  CHECK(ensure(c, part, (size_t)nsplit * (size_t)wstride));
+  const dim3 grid((unsigned)ntiles, (unsigned)nsplit, 2);
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), grid, dim3(256), 0, c->stream, Vp, ldv, C, ldc, 1, (int64_t)0, rows, ncols, rps, part.p,
+                       ld2, wstride);
+  else
+    hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), grid, dim3(256), 0, c->stream, Vp, ldv, C, ldc, 1, (int64_t)0, rows, ncols, rps, part.p,
+                       ld2, wstride);
+  hipLaunchKernelGGL(k_reduce_splits, dim3((unsigned)((wstride + 63) / 64)), dim3(256), 0, c->stream, (const double *)part.p, (int)nsplit,
+                     wstride, wstride, Y);
+  return DHQR_OK;
+}
+
 // Y (256 x ncols, ld 256) = [V_a V_b]' C: k_gemm_tn2 (ONE pass over C for both panels, split-K over row slabs into
 // ws.w1) + the deterministic split-K reduction.
 static int32_t pair_vtc(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows, const double *C, int64_t ldc,
                         int64_t ncols, bool vec, double *Y) {
   const int64_t ntiles = (ncols + 127) / 128;
+  if (ntiles <= 2 && c->narrow_tn) return narrow_vtc(c, Vp, ldv, rows, C, ldc, ncols, vec, c->ws[c->cur_ws].w1, Y);
   int64_t nsplit, rps;
   // k_gemm_tn2 workgroups have 512 threads and 110 KB of LDS: one per CU, 256 resident
   const int64_t slots = wide_slots(c);
@@ -1147,9 +1177,14 @@ static int32_t quad_apply(dhqr_ctx *c, const double *V1, const double *V2, int64
 static int32_t quad_cross_gram(dhqr_ctx *c, const double *V1, const double *V2, int64_t ldv, int64_t rows_a, double *S21,
                                Buf *part = nullptr) {
   const int64_t NB = DHQR_NBV, rows2 = rows_a - 2 * NB, ld2 = 2 * NB;
+  Buf &sp = part ? *part : c->spart;
+  if (c->narrow_tn) {
+    CHECK(narrow_vtc(c, V2, ldv, rows2, V1 + 2 * NB, ldv, ld2, true, sp, S21));
+    LAUNCHCHECK();
+    return DHQR_OK;
+  }
   int64_t nsplit, rps;
   pick_split(rows2, 2, wide_slots(c), 128, &nsplit, &rps, wide_slots(c), 64);
-  Buf &sp = part ? *part : c->spart;
   CHECK(ensure(c, sp, (size_t)nsplit * (size_t)(ld2 * ld2)));
   hipLaunchKernelGGL((k_gemm_tn2<2>), dim3((unsigned)std::min<int64_t>(2 * nsplit, wide_slots(c))), dim3(512), 0, c->stream, V2, ldv,
                      V1 + 2 * NB, ldv, rows2, ld2, rps, sp.p, ld2 * ld2, (int64_t)0);
@@ -1337,6 +1372,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     }
     if (const char *e = getenv("DHQR_QUAD")) c->quad = atoi(e) != 0;
     if (const char *e = getenv("DHQR_TN_STREAMK")) c->tn_streamk = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_NARROW_TN")) c->narrow_tn = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QUAD_HEAD")) c->quad_head = atoi(e) != 0;
     if (const char *e = getenv("DHQR_PROFILE_LANE")) c->profile_lane = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QUAD_MIN_COLS")) c->quad_min_cols = std::max<int64_t>(0, atoll(e));

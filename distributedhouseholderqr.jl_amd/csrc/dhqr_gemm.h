@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
 
   // staging: tile = 128 columns x 16 rows; chunk q = t + i*256 -> column q/8, row pair q%8.
   // 32-bit element offsets from the (uniform) tile base.
-  const double *Vb = V + rbeg;
+  // blockIdx.z (0 in every launch but the narrow two-panel product, narrow_vtc in dhqr_api.hip): the z-th block of NBV
+  // reflectors of V, whose products go NBV rows further down in `out`.
+  const double *Vb = V + rbeg + (int64_t)blockIdx.z * NBV * ldv;
   const double *Cb = C + rbeg + c0 * ldc;
   uint32_t offv[4], offc[4];
   bool okc[4];
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
     __syncthreads();
   }
 
-  double *o = out + (int64_t)blockIdx.y * osplit_stride + c0 * ldo;
+  double *o = out + (int64_t)blockIdx.y * osplit_stride + c0 * ldo + (int64_t)blockIdx.z * NBV;
 #pragma unroll
   for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll

@@ -300,27 +300,28 @@ namespace simt {
 // The OS threads are created once and walk the grid in lockstep: [fixed barrier] thread 0 re-arms the
 // dynamic barriers [fixed barrier] kernel body, leave() -> next workgroup.  The fixed barriers also keep a
 // fast thread from touching the (static) LDS arrays of workgroup n+1 while a slow one still reads n.
-inline void launch_grid(int gx, int gy, int nthreads, const std::function<void()> &body) {
+inline void launch_grid(int gx, int gy, int nthreads, const std::function<void()> &body, int gz = 1) {
   Block blk;
   blk.waves = std::vector<Wave>((nthreads + 63) / 64);
   Barrier fence;  // fixed participant count, nobody leaves
   fence.reset(nthreads);
   cur_block() = &blk;
   blockDim = dim3(nthreads);
-  gridDim = dim3(gx, gy);
+  gridDim = dim3(gx, gy, gz);
   std::vector<std::thread> th;
   th.reserve(nthreads);
   for (int t = 0; t < nthreads; ++t)
     th.emplace_back([&, t] {
       tl_tid = t;
       threadIdx = simt_uint3{(unsigned)t, 0, 0};
-      for (int y = 0; y < gy; ++y)
+      for (int yz = 0; yz < gy * gz; ++yz)
         for (int x = 0; x < gx; ++x) {
+          const int y = yz % gy, z = yz / gy;
           fence.wait();
           if (t == 0) {
             blk.bar.reset(nthreads);
             for (int w = 0; w < (int)blk.waves.size(); ++w) blk.waves[w].bar.reset(std::min(64, nthreads - 64 * w));
-            blockIdx = simt_uint3{(unsigned)x, (unsigned)y, 0};
+            blockIdx = simt_uint3{(unsigned)x, (unsigned)y, (unsigned)z};
           }
           tl_xchg = 0;
           fence.wait();
@@ -343,7 +344,7 @@ inline void fiber_entry() {
   if (!yield_to_next()) swapcontext(&f.ctx, &s.main_ctx);  // last one out returns to the launcher
   std::abort();                                             // a finished fiber is never resumed
 }
-inline void launch_grid(int gx, int gy, int nthreads, const std::function<void()> &body) {
+inline void launch_grid(int gx, int gy, int nthreads, const std::function<void()> &body, int gz = 1) {
   constexpr size_t STACK = 256 * 1024;
   Sched &s = sched();
   Block blk;
@@ -353,12 +354,13 @@ inline void launch_grid(int gx, int gy, int nthreads, const std::function<void()
   s.body = &body;
   s.blk = &blk;
   blockDim = dim3(nthreads);
-  gridDim = dim3(gx, gy);
-  for (int y = 0; y < gy; ++y)
+  gridDim = dim3(gx, gy, gz);
+  for (int yz = 0; yz < gy * gz; ++yz)
     for (int x = 0; x < gx; ++x) {
+      const int y = yz % gy, z = yz / gy;
       blk.bar.reset(nthreads);
       for (int w = 0; w < (int)blk.waves.size(); ++w) blk.waves[w].bar.reset(std::min(64, nthreads - 64 * w));
-      blockIdx = simt_uint3{(unsigned)x, (unsigned)y, 0};
+      blockIdx = simt_uint3{(unsigned)x, (unsigned)y, (unsigned)z};
       for (int t = 0; t < nthreads; ++t) {
         Fiber &f = s.fb[t];
         if (!f.stack) f.stack.reset(new char[STACK]);
@@ -471,5 +473,5 @@ inline std::mutex &simt_launch_mutex() { static std::mutex m; return m; }
     const dim3 simt_g_ = (grid), simt_b_ = (block);                                                    \
     (void)(stream);                                                                                    \
     std::lock_guard<std::mutex> simt_lk_(simt_launch_mutex());                                         \
-    simt::launch_grid((int)simt_g_.x, (int)simt_g_.y, (int)simt_b_.x, [&] { kernel(__VA_ARGS__); });   \
+    simt::launch_grid((int)simt_g_.x, (int)simt_g_.y, (int)simt_b_.x, [&] { kernel(__VA_ARGS__); }, (int)simt_g_.z);   \
   } while (0)
