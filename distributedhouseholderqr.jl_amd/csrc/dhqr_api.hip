@@ -77,6 +77,7 @@ struct dhqr_ctx {
   int nn_chunk_tiles = 48;       // ... of at least this many 128-wide tiles each (DHQR_NN_CHUNK_TILES: the CPU emulator's tests set 1)
   int nn_split = 4;              // wide subtraction launches in up to this many chunks of columns (or rows) (nn_chunks; DHQR_NN_SPLIT=1: one launch)
   int rankk_pipe = 1;            // k_rankk_fused: the lead as K pipelined workgroups where the lead bounds the launch (launch_rankk; DHQR_RANKK_PIPE=0 never, 2 always)
+  int rankk_xtall = 5;           // nb = 0, columns of 16384 < rows <= 32768: reflectors per pass (k_rankk_xtall; DHQR_RANKK_XTALL=1: one per launch)
   int rankk_tall = 5;            // nb = 0, columns of 8192 < rows <= 16384: reflectors per pass (k_rankk_tall; DHQR_RANKK_TALL=1: one per launch)
   int ncu = 256;                 // compute units of the device
   int spare_cus = 0;             // CUs the persistent wide k_gemm_tn2 launches leave free for the look-ahead lane's
@@ -256,6 +257,13 @@ static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
   hipLaunchKernelGGL((k_rankk_tall<512, E_, VEC, K>),                                                     \
                      dim3((unsigned)(K + std::min<int64_t>(nbulk, std::max<int64_t>(1, (int64_t)c->rankk_wgs - K)))), dim3(512), 0, c->stream, P, ldp, \
                      rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, c->zflags, epoch)
+#define DHQR_RKX(E_)                                                                                     \
+  hipLaunchKernelGGL((k_rankk_xtall<512, E_, VEC, K>),                                                    \
+                     dim3((unsigned)(K + std::min<int64_t>(nbulk, std::max<int64_t>(1, (int64_t)c->rankk_wgs - K)))), dim3(512), 0, c->stream, P, ldp, \
+                     rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, c->zflags, epoch)
+  // columns of 16384 < rows <= 32768 (DHQR_RANKK_XTALL >= 2): one column per workgroup in registers, reflectors streamed
+  if (cov > 512 * 48) { DHQR_RKX(64); return; }
+  if (cov > 512 * 32) { DHQR_RKX(48); return; }
   // columns of 8192 < rows <= 16384 (factor_unblocked_cols sends them here when DHQR_RANKK_TALL >= 2)
   if (cov > 512 * 24) { DHQR_RKT(32); return; }
   if (cov > 1024 * 8) { DHQR_RKT(24); return; }
@@ -270,6 +278,7 @@ static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
   else DHQR_RK(1024, 8);
 #undef DHQR_RK
 #undef DHQR_RKT
+#undef DHQR_RKX
 }
 static void launch_rankk(dhqr_ctx *c, bool vec, int K, double *P, int64_t ldp, int64_t rows, int64_t ncols, int64_t c0,
                          int64_t jlo, int kold, const double *vold, double *vnew, int64_t vlen, double *alpha) {
@@ -287,12 +296,15 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
                                      int64_t ldp, double *alpha, int cat) {
   const int K = c->rankk;  // reflectors per pass over the trailing columns (1: one launch per reflector)
   const int Kt = std::min(K, c->rankk_tall);  // ... while a column has 8192 < rows <= 16384 (k_rankk_tall; < 2: one per launch)
+  const int Kx = Kt >= 2 ? std::min(Kt, c->rankk_xtall) : 1;  // ... 16384 < rows <= 32768 (k_rankk_xtall; < 2: one per launch)
   // a reflector slot: the column's rows, zero-padded so that k_rankk_tall (512 threads x 32 elements from a row > rows -
-  // 16384) reads reflectors without clamping or masking -- the kernels never write beyond row `rows`
+  // 16384) and k_rankk_xtall (512 x 64 from a row > rows - 32768) read reflectors without clamping or masking -- the
+  // kernels never write beyond row `rows`
   const bool padded = (Kt >= 2 && rows > 1024 * 8) || c->rankk_pipe;
-  const size_t vlen = (size_t)((rows + (padded ? 1024 * 8 : 0) + 17) & ~(int64_t)15);
+  const bool xpadded = Kx >= 2 && rows > 1024 * 16;
+  const size_t vlen = (size_t)((rows + (xpadded ? 1024 * 16 : (padded ? 1024 * 8 : 0)) + 17) & ~(int64_t)15);
   CHECK(ensure(c, c->vbuf, 2 * (size_t)std::max(K, 1) * vlen));
-  if (padded) HIPCHECK(hipMemsetAsync(c->vbuf.p, 0, 2 * (size_t)std::max(K, 1) * vlen * sizeof(double), c->stream));
+  if (padded || xpadded) HIPCHECK(hipMemsetAsync(c->vbuf.p, 0, 2 * (size_t)std::max(K, 1) * vlen * sizeof(double), c->stream));
   double *vset[2] = {c->vbuf.p, c->vbuf.p + (size_t)std::max(K, 1) * vlen};  // two sets of K reflectors
   const bool vec = (ldp % 2 == 0) && (rows % 2 == 0) && aligned16(P);
   auto account = [&](int64_t jlo, int64_t ncol_upd) {
@@ -307,7 +319,7 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
   int64_t j = 0;
   int cur = 0;
   auto height = [&](int64_t jj) { return rows - (vec ? (jj & ~(int64_t)1) : jj); };
-  auto tall = [&](int64_t jj) { return K < 2 || height(jj) > (Kt >= 2 ? 1024 * 16 : 1024 * 8); };
+  auto tall = [&](int64_t jj) { return K < 2 || height(jj) > (Kx >= 2 ? 1024 * 32 : (Kt >= 2 ? 1024 * 16 : 1024 * 8)); };
   bool have_v = false;  // v_j built (in vset[cur][0])
   if (tall(0)) {
     CHECK(prof_begin(c, cat));
@@ -340,7 +352,7 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
     for (;;) {
       const int64_t c0 = jlo + kold;  // first column not yet final
       if (c0 >= ncols) break;
-      const int Kp = height(jlo) > 1024 * 8 ? Kt : K;  // reflectors this pass builds (and the next one applies)
+      const int Kp = height(jlo) > 1024 * 16 ? Kx : (height(jlo) > 1024 * 8 ? Kt : K);  // reflectors this pass builds (and the next one applies)
       CHECK(prof_begin(c, cat));
       launch_rankk(c, vec, Kp, P, ldp, rows, ncols, c0, jlo, kold, vset[cur], vset[cur ^ 1], (int64_t)vlen, alpha);
       CHECK(prof_end(c));
@@ -1379,6 +1391,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_RANKK_WGS")) c->rankk_wgs = std::max(2, atoi(e));
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_RANKK_TALL")) c->rankk_tall = std::min(5, std::max(1, atoi(e)));
+    if (const char *e = getenv("DHQR_RANKK_XTALL")) c->rankk_xtall = std::min(5, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_NN_SPLIT_COLS")) c->nn_split_cols = atoi(e) != 0;
     if (const char *e = getenv("DHQR_NN_CHUNK_TILES")) c->nn_chunk_tiles = std::max(1, atoi(e));
     if (const char *e = getenv("DHQR_NN_SPLIT")) c->nn_split = std::min(16, std::max(1, atoi(e)));

@@ -801,6 +801,200 @@ __global__ __launch_bounds__(T) void k_rankk_tall(double *__restrict__ A, int64_
 #undef DHQR_RKT_STEP
 }
 
+// The K-reflector pass for columns of 16384 < rows <= 32768 (a column = up to 256 KiB: what ONE workgroup's registers hold,
+// 512 threads x 48 / 64 elements = 96 / 128 VGPRs, and nothing else).  Neither a second column buffer nor a whole
+// reflector fits beside it (k_rankk_tall keeps two columns and a reflector in registers and the next reflector in LDS), so
+// a reflector is STREAMED from `vold` (L2: K x 256 KiB per launch, shared by every CU) in chunks of 8 elements per thread,
+// twice per step -- once for the dot product (src:208 partialdot), once for the update (src:209 hotloop!) -- two chunks in
+// flight.  Per column and CU: 512 KiB of HBM traffic and 2 K x 256 KiB from L2; 16 / K bytes of HBM traffic per element
+// and reflector instead of the 16 of one k_rank1_generic launch per reflector, which is what columns of this height took
+// until round 4.  The arithmetic per thread (element order of the dot product, one fma per element of the update) is that
+// of k_rankk_fused / k_rankk_tall with the same row map.  The lead is K pipelined workgroups, one column each (the scheme
+// of rankk_lead_pipe), with the same streamed apply.
+template <int T, int EPT, int VEC, int K>
+__global__ __launch_bounds__(T) void k_rankk_xtall(double *__restrict__ A, int64_t lda, int64_t m, int64_t ncols,
+                                                   int64_t c0, int64_t rtop, int kold, const double *__restrict__ vold,
+                                                   double *vnew, int64_t vlen, double *__restrict__ alpha, int *flags,
+                                                   int epoch) {
+  static_assert(T <= 512 && EPT % 8 == 0, "one column in the 256 registers of a <= 512-thread workgroup, chunks of 8 elements");
+  constexpr int CH = 8, NCH = EPT / CH, HSLOT = 2 * (T / 64);
+  __shared__ double red[2 * (T / 64) + 2];
+  __shared__ double reda[2 * (T / 64)];
+  int par = 0;
+  const uint32_t t = threadIdx.x;
+  const uint32_t span = (uint32_t)(m - rtop);  // valid rows from rtop
+  const uint32_t olast = span - VEC;           // offset of the last valid (pair of) element(s)
+  double a[EPT];
+  auto row_of = [&](int e) -> int64_t {
+    return (VEC == 2) ? rtop + 2 * ((int64_t)t + (int64_t)(e >> 1) * T) + (e & 1) : rtop + t + (int64_t)e * T;
+  };
+  auto load_col = [&](const double *src) {  // clamped, never masked (see k_rankk_fused)
+    const double *base = src + rtop;
+    const uint32_t tt = rk_opaque(t);
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const double2 x = *reinterpret_cast<const double2 *>(base + rk_umin(2u * (tt + (uint32_t)i * T), olast));
+        a[2 * i] = x.x;
+        a[2 * i + 1] = x.y;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) a[e] = base[rk_umin(tt + (uint32_t)e * T, olast)];
+    }
+  };
+  typedef double dhqr_d2 __attribute__((ext_vector_type(2)));
+  auto store_col = [&](double *dst, bool nt) {
+    double *base = dst + rtop;
+    const uint32_t tt = rk_opaque(t);
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < EPT / 2; ++i) {
+        const uint32_t o = 2u * (tt + (uint32_t)i * T);
+        if (o < span) {
+          const dhqr_d2 x = {a[2 * i], a[2 * i + 1]};
+          if (nt) __builtin_nontemporal_store(x, reinterpret_cast<dhqr_d2 *>(base + o));
+          else *reinterpret_cast<dhqr_d2 *>(base + o) = x;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const uint32_t o = tt + (uint32_t)e * T;
+        if (o < span) {
+          if (nt) __builtin_nontemporal_store(a[e], base + o);
+          else base[o] = a[e];
+        }
+      }
+    }
+  };
+  // chunk j of a reflector slot (zero-padded up to rtop + T * EPT by the host: neither clamp nor mask)
+  auto load_chunk = [&](const double *base, int j, double (&w)[CH], uint32_t tt) {
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int i = 0; i < CH / 2; ++i) {
+        const double2 x = *reinterpret_cast<const double2 *>(base + 2u * (tt + (uint32_t)((CH / 2) * j + i) * T));
+        w[2 * i] = x.x;
+        w[2 * i + 1] = x.y;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) w[e] = base[tt + (uint32_t)(CH * j + e) * T];
+    }
+  };
+  // D chunks of a reflector in flight (the one being consumed included).  The order is pinned by scheduling barriers: left
+  // alone the scheduler hoists every chunk load of the unrolled loop to the front.
+  // Every CU streams the SAME reflectors at about the same time, so the pass is bound by what an XCD's L2 delivers to its 32
+  // CUs (2 x 256 KiB per step and CU: 9.6 us per step at 32768 rows, ~53 GB/s per CU), not by HBM.  The otherwise unused LDS
+  // takes a part of that: the first NL chunks of the dot-product pass are parked there (128 KiB, thread-private 16-byte
+  // slots: no barrier) and the update pass reads them back instead of asking the L2 again.
+  constexpr int D = (EPT >= 64) ? 5 : 6;
+  constexpr int NL = (VEC == 2) ? (NCH < 4 ? NCH : 4) : 0;
+  __shared__ __attribute__((aligned(16))) double wl[NL > 0 ? NL * CH * T : 2];
+  auto pin = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  };
+  auto park = [&](int j, const double (&w)[CH]) {
+#pragma unroll
+    for (int i = 0; i < CH / 2; ++i)
+      *reinterpret_cast<double2 *>(wl + 2 * (((CH / 2) * j + i) * T + (int)t)) = make_double2(w[2 * i], w[2 * i + 1]);
+  };
+  auto unpark = [&](int j, double (&w)[CH]) {
+#pragma unroll
+    for (int i = 0; i < CH / 2; ++i) {
+      const double2 x = *reinterpret_cast<const double2 *>(wl + 2 * (((CH / 2) * j + i) * T + (int)t));
+      w[2 * i] = x.x;
+      w[2 * i + 1] = x.y;
+    }
+  };
+  auto apply_stream = [&](const double *src) {  // one step on the column in a[]: src:208 partialdot, src:209 hotloop!
+    const double *base = src + rtop;
+    double w[D][CH];
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < D - 1 && j < NCH; ++j) load_chunk(base, j, w[j % D], rk_opaque(t));
+    pin();
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      if (j + D - 1 < NCH) load_chunk(base, j + D - 1, w[(j + D - 1) % D], rk_opaque(t));
+#pragma unroll
+      for (int e = 0; e < CH; ++e) dot = fma(a[CH * j + e], w[j % D][e], dot);
+      if (j < NL) park(j, w[j % D]);
+      pin();
+    }
+    // the update's chunks from the L2 (NL .. NCH - 1) travel during the reduction
+#pragma unroll
+    for (int j = NL; j < NL + D - 1 && j < NCH; ++j) load_chunk(base, j, w[j % D], rk_opaque(t));
+    pin();
+    const double sdot = block_sum_alt<T>(dot, reda, par);
+#pragma unroll
+    for (int j = NL; j < NCH; ++j) {
+      if (j + D - 1 < NCH) load_chunk(base, j + D - 1, w[(j + D - 1) % D], rk_opaque(t));
+#pragma unroll
+      for (int e = 0; e < CH; ++e) a[CH * j + e] = fma(-w[j % D][e], sdot, a[CH * j + e]);
+      pin();
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {  // the parked chunks: every thread reads back what it wrote itself
+      double u[CH];
+      unpark(j, u);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) a[CH * j + e] = fma(-u[e], sdot, a[CH * j + e]);
+    }
+  };
+
+  if ((int)blockIdx.x < K) {  // ---- the K lead workgroups: column c0 + q each, reflectors handed on through flags
+    const int q = (int)blockIdx.x;
+    const int64_t c = c0 + q;
+    if (c >= ncols) return;
+    double *col = A + c * lda;
+    load_col(col);
+    for (int p = 0; p < kold; ++p) apply_stream(vold + (int64_t)p * vlen);
+    for (int p = 0; p < q; ++p) {  // the reflectors of this launch's earlier columns, as their owners publish them
+      if (t == 0) dhqr_pipe_wait(flags, p, epoch);
+      __syncthreads();
+      apply_stream(vnew + (int64_t)p * vlen);
+    }
+    dhqr_dd acc = {0.0, 0.0};  // extended-precision column norm (src:129: dnrm2)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t row = row_of(e);
+      if (row == c) red[HSLOT] = a[e];
+      if (row >= c && row < m) dd_add_sq(acc, a[e]);
+    }
+    const double sq = dd_block_sum<T>(acc, red);  // barriers inside also publish red[HSLOT]
+    const double h = red[HSLOT];
+    const double sn = sqrt(sq);                        // src:129
+    const double al = sn * dhqr_alphafactor(h);        // src:130
+    const double f = 1.0 / sqrt(sn * (sn + fabs(h)));  // src:131
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t row = row_of(e);
+      if (row == c) a[e] = (h - al) * f;  // src:132-135
+      else if (row > c) a[e] *= f;
+    }
+    if (t == 0) alpha[c] = al;
+    store_col(col, false);
+    // outgoing Hj (src:138-140): the column from its diagonal down, zero above (rows rtop .. c - 1: at most K + 1 of them)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+      if (row_of(e) < c) a[e] = 0.0;
+    store_col(vnew + (int64_t)q * vlen, false);
+    __syncthreads();  // every wave's stores have reached the L2
+    if (t == 0) dhqr_pipe_raise(flags, q, epoch);
+    return;
+  }
+  // ---- bulk: persistent, one column at a time
+  const int64_t stride = (int64_t)gridDim.x - K;
+  for (int64_t c = c0 + K + ((int64_t)blockIdx.x - K); c < ncols; c += stride) {
+    load_col(A + c * lda);
+    for (int p = 0; p < kold; ++p) apply_stream(vold + (int64_t)p * vlen);
+    store_col(A + c * lda, true);
+  }
+}
+
 // Fused step j for columns taller than 1024*8 rows: same contract, the column is streamed twice
 // (the second pass hits L2: a 32768-row column is 256 KiB).
 template <int T, int VEC>

@@ -86,7 +86,9 @@ def test_factor_drivers_vs_oracle(emu, orc, m, n, nb):
 
 
 @pytest.mark.parametrize("m,n,Ks", [(200, 64, (2, 5)), (131, 37, (3,)), (70, 70, (4,)),
-                                    (8300, 9, (3,))])  # columns of more than 8192 rows: k_rankk_tall, then k_rankk_fused
+                                    (8300, 9, (3,)),  # columns of more than 8192 rows: k_rankk_tall, then k_rankk_fused
+                                    (16420, 7, (3,)),  # more than 16384 rows: k_rankk_xtall (48 elements per thread), then k_rankk_tall
+                                    (24590, 6, (2, 5))])  # k_rankk_xtall with 64 elements per thread
 def test_unblocked_k_reflectors_per_pass_is_the_same_arithmetic(emu, orc, m, n, Ks):
     """nb = 0: k_rankk_fused applies K reflectors in one pass over every trailing column (1/K of the HBM traffic) --
     element by element the operations of K k_rank1_fused launches; only the summation order of the dot products differs

@@ -63,7 +63,11 @@ def test_golden_fixtures(pkg, path, nb):
                                  # columns of 8192 < rows <= 16384 (k_rankk_tall: 512 threads x 24 / 32 elements, every
                                  # reflector streamed), the hand-over from the one-reflector kernels above 16384 rows
                                  # and to k_rankk_fused at 8192, even / odd m
-                                 (12288, 64), (16390, 48), (16384, 33), (12001, 37), (9000, 40)])
+                                 (12288, 64), (16390, 48), (16384, 33), (12001, 37), (9000, 40),
+                                 # columns of 16384 < rows <= 32768 (k_rankk_xtall: one column in a workgroup's registers,
+                                 # 512 threads x 48 / 64 elements, reflectors streamed twice per step), even / odd m, the
+                                 # hand-over from the one-reflector kernels above 32768 rows and to k_rankk_tall at 16384
+                                 (32768, 24), (20000, 64), (24577, 21), (32790, 40), (16400, 36)])
 def test_unblocked_vs_oracle(pkg, orc, m, n):
     H, A0 = _factor_dev(pkg, m, n, 3, 0)
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 3))
@@ -74,11 +78,12 @@ def test_unblocked_vs_oracle(pkg, orc, m, n):
 
 
 @pytest.mark.parametrize("K", [1, 2, 3, 4, 5])
-@pytest.mark.parametrize("m,n", [(2100, 300), (8203, 41), (517, 517), (8192, 40), (5000, 64), (12290, 23)])
+@pytest.mark.parametrize("m,n", [(2100, 300), (8203, 41), (517, 517), (8192, 40), (5000, 64), (12290, 23), (20010, 19)])
 def test_unblocked_reflectors_per_pass(pkg, orc, m, n, K, monkeypatch):
     """DHQR_RANKK = 1..5 reflectors per pass over the trailing columns: the same factorisation as the oracle's"""
     monkeypatch.setenv("DHQR_RANKK", str(K))  # read by dhqr_create
     monkeypatch.setenv("DHQR_RANKK_TALL", str(K))
+    monkeypatch.setenv("DHQR_RANKK_XTALL", str(K))
     api = pkg.api
     old = api._contexts.pop(0, None)
     try:
