@@ -68,6 +68,7 @@ struct dhqr_ctx {
                                  // (default) or inside its launches (DHQR_QUAD_HEAD=0: measured, slower -- see cs_run)
   int narrow_tn = 1;             // V'C of one or two column tiles (the look-ahead lane's updates, the heads, the cross term of a quad) through
                                  // k_gemm_tn in slot-sized workgroups (DHQR_NARROW_TN=0: k_gemm_tn2, one whole CU per workgroup)
+XX
   int tn_streamk = 1;            // wide k_gemm_tn2 launches: stream-K decomposition (DHQR_TN_STREAMK=0: column-tile x row-slab units + the round model)
   int tn_model_min_tiles = 128;  // wide k_gemm_tn2 launches of at least this many column tiles: split-K factor from the round / partial-traffic estimate (below, the lane is the critical path and
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
@@ -1137,7 +1138,9 @@ static int32_t pair_apply(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t ro
 // the ldv of the first panel when quads are on).  rows = rows of panel a.  Requires the 16-byte path (vec).
 static int32_t quad_apply(dhqr_ctx *c, const double *V1, const double *V2, int64_t ldv, int64_t rows, const double *Ta,
                           const double *Tb, const double *Sba, const double *Tc, const double *Td, const double *Sdc,
-                          const double *S21, double *C, int64_t ncols, int64_t ldc) {
+                          const double *S21, double *C, int64_t ncols, int64_t ldc, int phase = 0) {
+  // phase 1: the two Y products only (they need the reflectors, not T or the cross terms: the head of a wide step starts them
+  // as soon as the last panel's V is final, cs_run); phase 2: the rest, on the Y of an earlier phase-1 call; 0: everything
   if (ncols <= 0) return DHQR_OK;
   const int64_t NB = DHQR_NBV, ld2 = 2 * NB, ld4 = 4 * NB, rows2 = rows - 2 * NB;
   const int64_t ntiles = (ncols + 127) / 128;
@@ -1146,10 +1149,19 @@ static int32_t quad_apply(dhqr_ctx *c, const double *V1, const double *V2, int64
   CHECK(ensure(c, ws.w2, (size_t)ld4 * (size_t)ncols));
   double *Y1 = ws.w1r.p, *Y2 = ws.w1r.p + ld2 * ncols, *W = ws.w2.p;
 
-  CHECK(prof_begin(c, CAT_VTA));
-  CHECK(pair_vtc(c, V1, ldv, rows, C, ldc, ncols, true, Y1));
-  CHECK(pair_vtc(c, V2, ldv, rows2, C + 2 * NB, ldc, ncols, true, Y2));
-  CHECK(prof_switch(c, CAT_TW));
+  if (phase != 2) {
+    CHECK(prof_begin(c, CAT_VTA));
+    CHECK(pair_vtc(c, V1, ldv, rows, C, ldc, ncols, true, Y1));
+    CHECK(pair_vtc(c, V2, ldv, rows2, C + 2 * NB, ldc, ncols, true, Y2));
+    if (phase == 1) {
+      CHECK(prof_end(c));
+      LAUNCHCHECK();
+      return DHQR_OK;
+    }
+    CHECK(prof_switch(c, CAT_TW));
+  } else {
+    CHECK(prof_begin(c, CAT_TW));
+  }
 
   /* (one event ends the previous section and starts this one) */
   CHECK(pair_tw(c, Y1, Ta, Tb, Sba, W, ld4, ncols));
@@ -1385,6 +1397,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_QUAD")) c->quad = atoi(e) != 0;
     if (const char *e = getenv("DHQR_TN_STREAMK")) c->tn_streamk = atoi(e) != 0;
     if (const char *e = getenv("DHQR_NARROW_TN")) c->narrow_tn = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_HEAD_EARLY")) c->head_early = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QUAD_HEAD")) c->quad_head = atoi(e) != 0;
     if (const char *e = getenv("DHQR_PROFILE_LANE")) c->profile_lane = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QUAD_MIN_COLS")) c->quad_min_cols = std::max<int64_t>(0, atoll(e));

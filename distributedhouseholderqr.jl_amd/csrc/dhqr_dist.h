@@ -254,15 +254,17 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
       rc = panel_apply(c, gb.pa(), gb.rows_a, C, ncols, lda, 1);
     return rc;
   };
-  auto apply_step = [&](int si, int64_t lstart, int64_t ncols) -> int32_t {  // step si -> local columns [lstart, lstart+ncols)
+  auto apply_step = [&](int si, int64_t lstart, int64_t ncols, int phase = 0) -> int32_t {  // step si -> local columns [lstart, lstart+ncols)
     const CsStep &st = steps[si];
-    if (st.ng == 1) return apply_group(st.g0, lstart, ncols);
+    if (st.ng == 1) return apply_group(st.g0, lstart, ncols);  // (phases: quads only)
     if (ncols <= 0) return DHQR_OK;
     const CsGroupBuf g1 = gview(st.g0), g2 = gview(st.g0 + 1);
     c->epoch = (int)groups[st.g0 + 1].last();
     return quad_apply(c, g1.VA, g2.VA, g1.ldv, g1.rows_a, g1.pa().T, g1.pb().T, g1.Sba, g2.pa().T, g2.pb().T, g2.Sba, g2.S21,
-                      pr.A + groups[st.g0].a * NB + lstart * lda, ncols, lda);
+                      pr.A + groups[st.g0].a * NB + lstart * lda, ncols, lda, phase);
   };
+  // group h's last panel went through the asynchronous fast path on this rank with a "V final" event (ev_v) recorded
+  std::vector<char> v_final((size_t)G, 0);
   // Does wide step si apply itself to the blocks of group glast + 2 FIRST, as a separate head with its own event?  At P > 1
   // always (that group's owner needs its block early: its wide launches are short and its lane is not shut out for long).
   // At P == 1 the only candidate is the second pair of a quad.  A head is six latency-bound launches on 256 columns (two
@@ -444,6 +446,7 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
     }
     HIPCHECK(hipEventRecord(S.ev_group[h % CS_EVR], sL));
     HIPCHECK(hipEventRecord(S.ev_lane[h % CS_EVR], sL));
+    v_final[(size_t)h] = v_event[gr.np - 1] ? 1 : 0;
     LAUNCHCHECK();
     return DHQR_OK;
   };
@@ -460,14 +463,26 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
       if (groups[glast].last() + 1 >= K) break;  // nothing to the right of this step
       // ---- wide stream: step si -> local blocks beyond the group that follows it (that group gets the step from the lane)
       on(sW, 0);
-      HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[glast % CS_EVR], 0));
       const int64_t after_next = groups[glast + 1].last() + 1;
       int64_t lo = pr.local_from(after_next);
-      // head: the blocks of group glast + 2 -- what the lane needs first (has_head above)
+      // head: the blocks of group glast + 2 -- what the lane needs first (has_head above).  Its two Y = V' C products need
+      // the step's reflectors but neither T nor the cross terms: at P == 1 they start behind "V of the step's last panel is
+      // final" (ev_v), beside that panel's second Gram product, k_build_t, the commit and the cross terms on the lane, and
+      // the rest of the head follows when the group is complete (r4: the wide stream used to stand still for all of it).
       if (has_head(si)) {
         const int64_t hi = pr.local_from(groups[glast + 2].last() + 1);
-        CHECK(apply_step(si, lo, hi - lo));
+        if (P == 1 && c->head_early && steps[si].ng == 2 && v_final[(size_t)glast]) {
+          HIPCHECK(hipStreamWaitEvent(sW, S.ev_v[(int)(groups[glast].last() % (2 * CS_EVR))], 0));
+          CHECK(apply_step(si, lo, hi - lo, 1));
+          HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[glast % CS_EVR], 0));
+          CHECK(apply_step(si, lo, hi - lo, 2));
+        } else {
+          HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[glast % CS_EVR], 0));
+          CHECK(apply_step(si, lo, hi - lo));
+        }
         lo = hi;
+      } else {
+        HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[glast % CS_EVR], 0));
       }
       HIPCHECK(hipEventRecord(S.ev_head[si % CS_EVR], sW));
       CHECK(apply_step(si, lo, pr.ncl - lo));
