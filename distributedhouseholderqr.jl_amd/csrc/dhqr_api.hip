@@ -68,7 +68,7 @@ struct dhqr_ctx {
                                  // (default) or inside its launches (DHQR_QUAD_HEAD=0: measured, slower -- see cs_run)
   int narrow_tn = 1;             // V'C of one or two column tiles (the look-ahead lane's updates, the heads, the cross term of a quad) through
                                  // k_gemm_tn in slot-sized workgroups (DHQR_NARROW_TN=0: k_gemm_tn2, one whole CU per workgroup)
-XX
+  int head_early = 0;            // DHQR_HEAD_EARLY=1 (P == 1): the head of a quad step starts its Y products when the last panel's V is final instead of when the group is complete -- measured SLOWER (r4: 32768^2 827 -> 831.5 ms, profiles/r04_ab_head_early.txt: the head's products contend with the end of the panel chain they overlap)
   int tn_streamk = 1;            // wide k_gemm_tn2 launches: stream-K decomposition (DHQR_TN_STREAMK=0: column-tile x row-slab units + the round model)
   int tn_model_min_tiles = 128;  // wide k_gemm_tn2 launches of at least this many column tiles: split-K factor from the round / partial-traffic estimate (below, the lane is the critical path and
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)

@@ -468,7 +468,9 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
       // head: the blocks of group glast + 2 -- what the lane needs first (has_head above).  Its two Y = V' C products need
       // the step's reflectors but neither T nor the cross terms: at P == 1 they start behind "V of the step's last panel is
       // final" (ev_v), beside that panel's second Gram product, k_build_t, the commit and the cross terms on the lane, and
-      // the rest of the head follows when the group is complete (r4: the wide stream used to stand still for all of it).
+      // the rest of the head follows when the group is complete.  OFF by default (DHQR_HEAD_EARLY=1): measured slower, the
+      // head's products slow down the end of the panel chain they overlap by more than the wait they remove
+      // (profiles/r04_ab_head_early.txt).
       if (has_head(si)) {
         const int64_t hi = pr.local_from(groups[glast + 2].last() + 1);
         if (P == 1 && c->head_early && steps[si].ng == 2 && v_final[(size_t)glast]) {
