@@ -15,6 +15,7 @@ import sys,json
 for l in sys.stdin:
     d=json.loads(l); print(d['m'],'x',d['n'],'nb',d['nb'],'ms', round(d['t1']*1e3,2), 'GFLOP/s', round(d['gflops'],1), 'resid', d.get('resid'))" ) > $O/sizes.txt
 DHQR_HOSTIO_TRACE=1 timeout 300 python tools/hostio_bench.py 32768 2 > $O/hostio.txt 2>&1
+( XTALL_KS=5 timeout 600 python tools/xtall_bench.py 32768,4096 20000,2048 24576,24576 32768,32768 2>&1 | grep -v amdgpu ) > $O/xtall.txt
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_blocked -o blocked -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-residual --no-also > $O/prof_blocked.log 2>&1
 hipcc -O2 -std=c++17 $R/tools/pmc_driver.cpp -o $R/tools/pmc_driver -L $R/distributedhouseholderqr.jl_amd -ldhqr_bench -Wl,-rpath,'$ORIGIN/../distributedhouseholderqr.jl_amd' > $O/pmc_driver_build.log 2>&1
@@ -31,5 +32,6 @@ DB=$(find $O/prof_blocked -name "*.db" | head -1)
 python tools/prof_summary.py $DB $O/blocked32768_kernel_stats.csv "$CMD (2 factorisations in the trace)" | tail -1
 python tools/prof_summary.py --by-stream $DB $O/blocked32768_kernel_stats_by_stream.csv "$CMD" | tail -1
 python tools/prof_summary.py --per-launch $DB $O/blocked32768_per_launch.csv "$CMD" | tail -1; gzip -f $O/blocked32768_per_launch.csv
+python tools/lane_gaps.py $O/blocked32768_per_launch.csv.gz --around 10 > $O/lane_gaps.txt 2>&1
 find $O -name "*.db" -delete; find $O/pmc -name "*kernel_trace.csv" -delete; find $O/pmc -name "*agent_info.csv" -delete
 du -sh $O; cat $O/sizes.txt $O/bench_complex8192.txt $O/logical_ranks.txt
