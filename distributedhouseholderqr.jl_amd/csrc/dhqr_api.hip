@@ -78,6 +78,9 @@ struct dhqr_ctx {
   int nn_chunk_tiles = 48;       // ... of at least this many 128-wide tiles each (DHQR_NN_CHUNK_TILES: the CPU emulator's tests set 1)
   int nn_split = 4;              // wide subtraction launches in up to this many chunks of columns (or rows) (nn_chunks; DHQR_NN_SPLIT=1: one launch)
   int rankk_pipe = 1;            // k_rankk_fused: the lead as K pipelined workgroups where the lead bounds the launch (launch_rankk; DHQR_RANKK_PIPE=0 never, 2 always)
+  int rankk_max_min_cols = 4096; // ... while more than this many columns are left (DHQR_RANKK_MAX_MIN_COLS: below, a launch is bound by its lead's chain, which grows with K)
+  int rankk_unfit = 0;           // set by launch_rankk if it was asked for a K its ladder step cannot hold (a driver bug: reported, never silent)
+  int rankk_max = 8;             // nb = 0, default DHQR_RANKK=5: up to this many reflectors per pass where the CU can hold them (columns of <= 6144 rows; DHQR_RANKK_MAX=5: never more than 5)
   int rankk_xtall = 5;           // nb = 0, columns of 16384 < rows <= 32768: reflectors per pass (k_rankk_xtall; DHQR_RANKK_XTALL=1: one per launch)
   int rankk_tall = 5;            // nb = 0, columns of 8192 < rows <= 16384: reflectors per pass (k_rankk_tall; DHQR_RANKK_TALL=1: one per launch)
   int ncu = 256;                 // compute units of the device
@@ -249,11 +252,19 @@ static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
   const bool pipe = c->rankk_pipe == 2 || (c->rankk_pipe == 1 && nbulk <= 3072 && cov >= 2048);
   const int nlead = pipe ? K : 1;
   const int epoch = ++c->zepoch;  // the launch's number in the flags (a value, not an expression in the launch's argument list)
+  // (workgroups per CU of the persistent bulk: as many as the threads allow unless the LDS-resident reflectors -- the lead's
+  // slots, or more than two of the pass's own -- leave room for one only; a K the ladder step cannot hold is never asked for:
+  // rankk_fit, factor_unblocked_cols)
 #define DHQR_RK(T_, E_)                                                                                  \
-  hipLaunchKernelGGL((k_rankk_fused<T_, E_, VEC, K>),                                                    \
-                     dim3((unsigned)(nlead + std::min<int64_t>(nbulk, std::max<int64_t>(1, (int64_t)c->rankk_wgs * (rankk_lead_slots(T_, E_, K) > 0 ? 1 : 1024 / T_) - nlead)))), \
-                     dim3(T_), 0, c->stream, P, ldp, rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha,  \
-                     pipe ? c->zflags : (int *)nullptr, epoch)
+  do {                                                                                                   \
+    if constexpr (K <= rankk_fit(T_, E_))                                                                \
+      hipLaunchKernelGGL((k_rankk_fused<T_, E_, VEC, K>),                                                \
+                         dim3((unsigned)(nlead + std::min<int64_t>(nbulk, std::max<int64_t>(1, (int64_t)c->rankk_wgs * ((rankk_lead_slots(T_, E_, K) > 0 || (K - rankk_kr(E_, K)) * T_ * E_ * 8 > 80 * 1024) ? 1 : 1024 / T_) - nlead)))), \
+                         dim3(T_), 0, c->stream, P, ldp, rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, \
+                         pipe ? c->zflags : (int *)nullptr, epoch);                                      \
+    else                                                                                                 \
+      c->rankk_unfit = K;                                                                                \
+  } while (0)
 #define DHQR_RKT(E_)                                                                                     \
   hipLaunchKernelGGL((k_rankk_tall<512, E_, VEC, K>),                                                     \
                      dim3((unsigned)(K + std::min<int64_t>(nbulk, std::max<int64_t>(1, (int64_t)c->rankk_wgs - K)))), dim3(512), 0, c->stream, P, ldp, \
@@ -268,6 +279,11 @@ static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int6
   // columns of 8192 < rows <= 16384 (factor_unblocked_cols sends them here when DHQR_RANKK_TALL >= 2)
   if (cov > 512 * 24) { DHQR_RKT(32); return; }
   if (cov > 1024 * 8) { DHQR_RKT(24); return; }
+  // six per pass for columns of 6145 ... 8192 rows: 16 elements per thread, four reflectors in registers (rankk_kr)
+  if constexpr (K == 6 && VEC == 2) {
+    if (cov > 448 * 16) { DHQR_RK(512, 16); return; }
+    if (cov > 768 * 8) { DHQR_RK(448, 16); return; }
+  }
   if (cov <= 256 * 2) DHQR_RK(256, 2);
   else if (cov <= 256 * 4) DHQR_RK(256, 4);
   else if (cov <= 256 * 8) DHQR_RK(256, 8);
@@ -289,13 +305,30 @@ static void launch_rankk(dhqr_ctx *c, bool vec, int K, double *P, int64_t ldp, i
   if (K == 2) DHQR_RKK(2);
   else if (K == 3) DHQR_RKK(3);
   else if (K == 4) DHQR_RKK(4);
-  else DHQR_RKK(5);
+  else if (K == 5) DHQR_RKK(5);
+  else if (K == 6) DHQR_RKK(6);
+  else if (K == 7) DHQR_RKK(7);
+  else DHQR_RKK(8);
 #undef DHQR_RKK
 }
 
+// most reflectors per pass the k_rankk_fused instantiation launch_rankk picks for columns of `cov` rows can hold
+static inline int rankk_fit_rows(int64_t cov, bool vec) {
+  if (cov <= 256 * 2) return rankk_fit(256, 2);
+  if (cov <= 256 * 4) return rankk_fit(256, 4);
+  if (cov <= 256 * 8) return rankk_fit(256, 8);
+  if (cov <= 384 * 8) return rankk_fit(384, 8);
+  if (cov <= 512 * 8) return rankk_fit(512, 8);
+  if (cov <= 640 * 8) return rankk_fit(640, 8);
+  if (cov <= 768 * 8) return rankk_fit(768, 8);
+  return vec ? 6 : 5;  // <= 8192 rows: the 16-elements-per-thread instantiations (launch_rankk; 16-byte path only: the scalar path spills 120 registers there) for six, 896 / 1024 x 8 for up to five
+}
 static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64_t ncols,
                                      int64_t ldp, double *alpha, int cat) {
   const int K = c->rankk;  // reflectors per pass over the trailing columns (1: one launch per reflector)
+  // ... and, at the default K = 5, as many as the CU can hold once the columns are short enough (rankk_fit: 6 at <= 6144 rows,
+  // 7 at <= 4096, 8 at <= 3072; DHQR_RANKK_MAX)
+  const int Kmax = (K >= 5) ? std::max(K, std::min(c->rankk_max, DHQR_RK_KMAX)) : K;
   const int Kt = std::min(K, c->rankk_tall);  // ... while a column has 8192 < rows <= 16384 (k_rankk_tall; < 2: one per launch)
   const int Kx = Kt >= 2 ? std::min(Kt, c->rankk_xtall) : 1;  // ... 16384 < rows <= 32768 (k_rankk_xtall; < 2: one per launch)
   // a reflector slot: the column's rows, zero-padded so that k_rankk_tall (512 threads x 32 elements from a row > rows -
@@ -304,9 +337,9 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
   const bool padded = (Kt >= 2 && rows > 1024 * 8) || c->rankk_pipe;
   const bool xpadded = Kx >= 2 && rows > 1024 * 16;
   const size_t vlen = (size_t)((rows + (xpadded ? 1024 * 16 : (padded ? 1024 * 8 : 0)) + 17) & ~(int64_t)15);
-  CHECK(ensure(c, c->vbuf, 2 * (size_t)std::max(K, 1) * vlen));
-  if (padded || xpadded) HIPCHECK(hipMemsetAsync(c->vbuf.p, 0, 2 * (size_t)std::max(K, 1) * vlen * sizeof(double), c->stream));
-  double *vset[2] = {c->vbuf.p, c->vbuf.p + (size_t)std::max(K, 1) * vlen};  // two sets of K reflectors
+  CHECK(ensure(c, c->vbuf, 2 * (size_t)std::max(Kmax, 1) * vlen));
+  if (padded || xpadded) HIPCHECK(hipMemsetAsync(c->vbuf.p, 0, 2 * (size_t)std::max(Kmax, 1) * vlen * sizeof(double), c->stream));
+  double *vset[2] = {c->vbuf.p, c->vbuf.p + (size_t)std::max(Kmax, 1) * vlen};  // two sets of Kmax reflectors
   const bool vec = (ldp % 2 == 0) && (rows % 2 == 0) && aligned16(P);
   auto account = [&](int64_t jlo, int64_t ncol_upd) {
     if (!c->profiling) return;
@@ -353,7 +386,18 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
     for (;;) {
       const int64_t c0 = jlo + kold;  // first column not yet final
       if (c0 >= ncols) break;
-      const int Kp = height(jlo) > 1024 * 16 ? Kx : (height(jlo) > 1024 * 8 ? Kt : K);  // reflectors this pass builds (and the next one applies)
+      // reflectors this pass builds (and the next one applies)
+      // (more than K only while the bulk clearly bounds the launch: below ~4000 columns a launch takes as long as its lead's
+      // chain, which grows with K -- 4096^2 31.4 -> 31.8 ms with 7 per pass; and never fewer than the previous pass built:
+      // the kernel that builds Kp holds at most Kp old reflectors on the CU)
+      int Kp;
+      if (height(jlo) > 1024 * 16) Kp = Kx;
+      else if (height(jlo) > 1024 * 8) Kp = Kt;
+      else {
+        const int fit = rankk_fit_rows(height(jlo), vec);
+        Kp = (ncols - c0 > c->rankk_max_min_cols + K) ? std::max(K, std::min(Kmax, fit)) : K;
+        Kp = std::max(Kp, std::min(kold, fit));
+      }
       CHECK(prof_begin(c, cat));
       launch_rankk(c, vec, Kp, P, ldp, rows, ncols, c0, jlo, kold, vset[cur], vset[cur ^ 1], (int64_t)vlen, alpha);
       CHECK(prof_end(c));
@@ -362,6 +406,11 @@ static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64
       jlo = c0;
       kold = Kp;
     }
+  }
+  if (c->rankk_unfit) {
+    const int k = c->rankk_unfit;
+    c->rankk_unfit = 0;
+    return set_err(DHQR_EINVAL, "internal: %d reflectors per pass asked of a kernel that cannot hold them", k);
   }
   LAUNCHCHECK();
   return DHQR_OK;
@@ -1405,6 +1454,8 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_RANKK")) c->rankk = std::min(5, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_RANKK_TALL")) c->rankk_tall = std::min(5, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_RANKK_XTALL")) c->rankk_xtall = std::min(5, std::max(1, atoi(e)));
+    if (const char *e = getenv("DHQR_RANKK_MAX")) c->rankk_max = std::min(DHQR_RK_KMAX, std::max(1, atoi(e)));
+    if (const char *e = getenv("DHQR_RANKK_MAX_MIN_COLS")) c->rankk_max_min_cols = std::max(0, atoi(e));
     if (const char *e = getenv("DHQR_NN_SPLIT_COLS")) c->nn_split_cols = atoi(e) != 0;
     if (const char *e = getenv("DHQR_NN_CHUNK_TILES")) c->nn_chunk_tiles = std::max(1, atoi(e));
     if (const char *e = getenv("DHQR_NN_SPLIT")) c->nn_split = std::min(16, std::max(1, atoi(e)));

@@ -157,8 +157,20 @@ __global__ __launch_bounds__(T) void k_rank1_fused(double *__restrict__ A, int64
 #ifndef DHQR_RK_LEAD_ROWS
 #define DHQR_RK_LEAD_ROWS 6144
 #endif
+// Most reflectors a pass of k_rankk_fused<T, EPT> can keep on the CU: three in registers + as many as fit 152 KiB of LDS
+// (r4: columns of at most 6144 rows take 6, of at most 4096 rows 7, of at most 3072 rows 8 -- the bytes per element and
+// reflector fall from 16/5 to 16/K there).
+#define DHQR_RK_KMAX 8
+// reflectors of the pass held in REGISTERS: three beside three column buffers of 8 elements per thread (1024 threads, 128
+// registers each); four in the 16-elements-per-thread instantiations (<= 512 threads: 256 registers each), which exist so
+// that columns of 6145 ... 8192 rows -- 58 % of the traffic of an 8192^2 factorisation -- get a sixth reflector per pass
+constexpr int rankk_kr(int EPT, int K) { return EPT >= 16 ? (K < 4 ? K : 4) : (K < 3 ? K : 3); }
+constexpr int rankk_fit(int T, int EPT) {
+  const int k = rankk_kr(EPT, DHQR_RK_KMAX) + (152 * 1024) / (T * EPT * 8);
+  return k > DHQR_RK_KMAX ? DHQR_RK_KMAX : k;
+}
 constexpr int rankk_lead_slots(int T, int EPT, int K) {
-  const int KL = K > 3 ? K - 3 : 0;
+  const int KL = K - rankk_kr(EPT, K);
   if (T * EPT > DHQR_RK_LEAD_ROWS) return 0;
   const int avail = (144 * 1024) / (T * EPT * 8) - KL;
   return avail < 0 ? 0 : (avail < K - 1 ? avail : K - 1);
@@ -175,7 +187,7 @@ __device__ __forceinline__ void rankk_lead_body(double *__restrict__ A, int64_t 
                                                 int64_t c0, int64_t rtop, int kold, const double *vold,
                                                 double *vnew, int64_t vlen, double *__restrict__ alpha,
                                                 double *red, double *reda, double *vl) {
-  constexpr int KR = K < 3 ? K : 3;
+  constexpr int KR = rankk_kr(EPT, K);
   constexpr int KL = K - KR;
   constexpr int NN = rankk_lead_slots(T, EPT, K);
   constexpr int HSLOT = 2 * (T / 64);
@@ -472,7 +484,7 @@ __global__ __launch_bounds__(T) void k_rankk_fused(double *__restrict__ A, int64
                                                    int64_t c0, int64_t rtop, int kold,
                                                    const double *__restrict__ vold, double *vnew, int64_t vlen,
                                                    double *__restrict__ alpha, int *flags, int epoch) {
-  constexpr int KR = K < 3 ? K : 3;  // reflectors held in registers ...
+  constexpr int KR = rankk_kr(EPT, K);  // reflectors held in registers ...
   constexpr int KL = K - KR;         // ... and in LDS (one workgroup per CU: 64 KiB each at 8192 rows)
   __shared__ double red[2 * (T / 64) + 2];   // the lead's double-double sums + the pivot slot
   __shared__ double reda[2 * (T / 64)];      // block_sum_alt: two halves in alternation

@@ -87,6 +87,8 @@ def test_factor_drivers_vs_oracle(emu, orc, m, n, nb):
 
 @pytest.mark.parametrize("m,n,Ks", [(200, 64, (2, 5)), (131, 37, (3,)), (70, 70, (4,)),
                                     (8300, 9, (3,)),  # columns of more than 8192 rows: k_rankk_tall, then k_rankk_fused
+                                    (8000, 14, (5,)),  # six per pass at 6145 ... 8192 rows: 512 threads x 16 elements, four reflectors in registers
+                                    (7000, 9, (5,)), (4000, 17, (5,)), (3000, 19, (5,)),  # 448 x 16 (six), 512 x 8 (seven), 384 x 8 (eight)
                                     (16420, 7, (3,)),  # more than 16384 rows: k_rankk_xtall (48 elements per thread), then k_rankk_tall
                                     (24590, 6, (2, 5))])  # k_rankk_xtall with 64 elements per thread
 def test_unblocked_k_reflectors_per_pass_is_the_same_arithmetic(emu, orc, m, n, Ks):
@@ -96,7 +98,8 @@ def test_unblocked_k_reflectors_per_pass_is_the_same_arithmetic(emu, orc, m, n, 
     A0 = orc.rand_matrix(m, n, 14)
     res = {}
     for K in (1,) + Ks:
-        h = _ctx(emu, DHQR_RANKK=K, DHQR_RANKK_WGS=2 + K % 2)  # the lead + 7 or 11 persistent bulk workgroups of 256 threads
+        # (DHQR_RANKK=5 also takes up to 8 per pass where the CU can hold them -- here from the first column on)
+        h = _ctx(emu, DHQR_RANKK=K, DHQR_RANKK_WGS=2 + K % 2, DHQR_RANKK_MAX_MIN_COLS=0)  # the lead + 7 or 11 persistent bulk workgroups of 256 threads
         A, al = _factor(emu, h, A0, 0)
         _check(orc, A0, A, al)
         res[K] = (A, al)

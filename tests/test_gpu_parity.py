@@ -77,6 +77,31 @@ def test_unblocked_vs_oracle(pkg, orc, m, n):
     assert pkg.residual(H, A0) < 1e-12
 
 
+@pytest.mark.parametrize("m,n", [(8000, 64), (8192, 30), (7000, 40), (6200, 33), (6144, 40), (4000, 60), (3000, 50), (1000, 120), (7001, 35), (8190, 8190)])
+def test_unblocked_more_than_five_reflectors_per_pass(pkg, orc, m, n, monkeypatch):
+    """Columns of at most 8192 rows take as many reflectors per pass as the CU can hold (six at 6145 ... 8192 rows through the
+    16-elements-per-thread instantiations, 16-byte path only; six / seven / eight at <= 6144 / 4096 / 3072 rows) while more
+    than 4096 columns are left -- here from the first column on (DHQR_RANKK_MAX_MIN_COLS=0)"""
+    if n > 1000:
+        monkeypatch.delenv("DHQR_RANKK_MAX_MIN_COLS", raising=False)  # the shipped threshold on a square matrix
+    else:
+        monkeypatch.setenv("DHQR_RANKK_MAX_MIN_COLS", "0")
+    api = pkg.api
+    old = api._contexts.pop(0, None)
+    try:
+        H, A0 = _factor_dev(pkg, m, n, 5, 0)
+        if n <= 1000:
+            Ho, ao = orc.householder(orc.rand_matrix(m, n, 5))
+            scale = np.abs(Ho).max()
+            assert np.abs(H.A.cpu().numpy() - Ho).max() <= TOL(Ho) * scale
+            assert np.abs(H.α.cpu().numpy() - ao).max() <= TOL(Ho) * scale
+        assert pkg.residual(H, A0) < 1e-12
+    finally:
+        api._contexts.pop(0, None)
+        if old is not None:
+            api._contexts[0] = old
+
+
 @pytest.mark.parametrize("K", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("m,n", [(2100, 300), (8203, 41), (517, 517), (8192, 40), (5000, 64), (12290, 23), (20010, 19)])
 def test_unblocked_reflectors_per_pass(pkg, orc, m, n, K, monkeypatch):
@@ -99,12 +124,13 @@ def test_unblocked_reflectors_per_pass(pkg, orc, m, n, K, monkeypatch):
             api._contexts[0] = old
 
 
-@pytest.mark.parametrize("m,n", [(12288, 64), (16390, 48), (9000, 40), (8192, 40)])
+@pytest.mark.parametrize("m,n", [(12288, 64), (16390, 48), (9000, 40), (8192, 40), (8000, 60), (6000, 60), (20000, 50)])
 def test_unblocked_few_workgroups_own_many_columns(pkg, orc, m, n, monkeypatch):
     """DHQR_RANKK_WGS=8: three bulk workgroups walk through all trailing columns of a pass (on 256 CUs the shapes above give
     every workgroup ONE column) -- the column-to-column pipeline of k_rankk_tall (next reflector streaming into LDS while the
     current one is applied, next column prefetched) and of k_rankk_fused against the oracle"""
     monkeypatch.setenv("DHQR_RANKK_WGS", "8")  # read by dhqr_create
+    monkeypatch.setenv("DHQR_RANKK_MAX_MIN_COLS", "0")  # six to eight per pass at <= 8192 rows whatever the number of columns
     api = pkg.api
     old = api._contexts.pop(0, None)
     try:
