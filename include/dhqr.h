@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DHQR_VERSION 200 /* 0.2.0 */
+#define DHQR_VERSION 300 /* 0.3.0: round 4 (distributed solve entry points, ComplexF64 distributed solve, comm timing) */
 
 #define DHQR_OK 0
 #define DHQR_EINVAL (-1)   /* bad argument (null pointer, m < n, ld < m, unsupported nb ...) */
