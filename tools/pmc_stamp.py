@@ -132,12 +132,22 @@ def main():
     ur, uw = per_launch(root, "FETCH_SIZE", 2.0 * 1024.0, "unblocked"), per_launch(root, "WRITE_SIZE", 1024.0, "unblocked")
     if ur.get("k_rankk_fused"):
         nu, K = 8192, 5
+
+        def fit(cov):  # rankk_fit_rows (dhqr_api.hip), 16-byte path: reflectors per pass the CU can hold at `cov` rows
+            for rows, k in ((512, 8), (1024, 8), (2048, 8), (3072, 8), (4096, 7), (5120, 6), (6144, 6)):
+                if cov <= rows:
+                    return k
+            return 6
+
         alg, c0, kold, launches = 0.0, 0, 0, 0
-        while c0 < nu:
+        while c0 < nu:  # factor_unblocked_cols: K per pass = 5, or what fits while more than 4096 + 5 columns are left, never fewer than the pass before built
             jlo = c0 - kold
-            alg += 16.0 * (nu - jlo) * (min(K, nu) if kold == 0 else nu - c0)
+            cov = nu - (jlo & ~1)
+            kp = max(K, min(8, fit(cov))) if nu - c0 > 4096 + K else K
+            kp = max(kp, min(kold, fit(cov)))
+            alg += 16.0 * (nu - jlo) * (min(kp, nu) if kold == 0 else nu - c0)
             launches += 1
-            c0, kold = c0 + K, K
+            c0, kold = c0 + kp, kp
         rsum, wsum = sum(ur["k_rankk_fused"]), sum(uw.get("k_rankk_fused", []))
         entries.append({"kernel_symbol": "k_rankk_fused", "sources": [srcs[1]], "workload": f"unblocked {nu}x{nu}",
                         "ratio_to_algorithmic": (rsum + wsum) / alg, "read_GB": rsum / 1e9, "write_GB": wsum / 1e9,
