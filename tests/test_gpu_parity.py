@@ -299,6 +299,32 @@ def test_column_cyclic_driver_single_rank(pkg, orc, m, n):
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
 
 
+@pytest.mark.parametrize("env", [{"DHQR_NARROW_TN": "0"}, {"DHQR_NARROW_TN": "1"}, {"DHQR_HEAD_EARLY": "1"},
+                                 {"DHQR_HEAD_EARLY": "1", "DHQR_NARROW_TN": "0"}, {"DHQR_LANE_SIDE": "0", "DHQR_HEAD_EARLY": "1"}])
+def test_lane_schedule_switches_on_a_small_matrix_with_quads(pkg, orc, monkeypatch, env):
+    """the round-4 schedule switches with quad steps forced onto a 2600 x 2560 matrix (five quads of pairs, heads, the
+    K = 512 cross term): narrow V'C products through whole-CU k_gemm_tn2 workgroups (DHQR_NARROW_TN=0) or slot-sized
+    k_gemm_tn workgroups with the two reflector blocks in blockIdx.z (1, default); the head's Y products started on "V of
+    the last panel final" (DHQR_HEAD_EARLY=1, off by default: measured slower), with and without the lane's side stream --
+    every variant is the oracle's factorisation"""
+    monkeypatch.setenv("DHQR_QUAD_MIN_COLS", "0")  # read by dhqr_create of the rank context
+    monkeypatch.setenv("DHQR_PAIR_MIN_N", "0")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    m, n = 2600, 2560
+    mg = pkg.MultiGpuQR(devices=[0])
+    try:
+        mg.alloc(m, n).fill(21)
+        mg.factor()
+        H, alpha = mg.download()
+        assert mg.residual(21) < 1e-12
+        Ho, ao = orc.householder(orc.rand_matrix(m, n, 21))
+        scale = np.abs(Ho).max()
+        assert np.abs(H - Ho).max() <= TOL(Ho) * scale and np.abs(alpha - ao).max() <= TOL(Ho) * scale
+    finally:
+        mg.close()
+
+
 @pytest.mark.parametrize("streamk", [1, 0])
 def test_wide_tn_split_model_on_a_small_matrix(pkg, orc, monkeypatch, streamk):
     """the decomposition of the wide k_gemm_tn2 launches (normally for >= 128 column tiles = matrices beyond 16384
