@@ -3,9 +3,18 @@
 # libdhqr.so (hand-written HIP for MI355X/gfx950) through `ccall`.  No AMDGPU.jl, no CUDA.jl, no
 # rocSOLVER.
 #
+# This file is the `src/` of a Julia PACKAGE with the reference's name and uuid (../Project.toml; deps LinearAlgebra,
+# Distributed, DistributedArrays, SharedArrays like the reference's Project.toml:1-13), so that the reference's own
+# tests load it the way they load the reference: `using DistributedHouseholderQR` on the master, `addprocs(np,
+# exeflags=["--proj=@.", ...])`, `@everywhere using DistributedHouseholderQR` (test/runtests.jl:8-9,32).  Run them with
+#   cd distributedhouseholderqr.jl_amd/julia && julia --project=@. -t 8 /root/reference/test/runtests.jl 2
+# (the package's own ../test/runtests.jl restates the same acceptance checks without the reference's benchmarking deps).
+#
 # STATUS: written against include/dhqr.h and reviewed by hand; NOT executed -- there is no Julia
 # toolchain in the build image or on the GPU box.  The identical C entry points are exercised by
-# the Python ctypes binding (distributedhouseholderqr.jl_amd/_lib.py, tests/).
+# the Python ctypes binding (distributedhouseholderqr.jl_amd/_lib.py, tests/); tests/test_abi.py checks the package
+# layout, that every ccall names a declared symbol with the prototype's arity, that every method is defined at module
+# top level (no definition hidden behind a hook nobody calls) and that every function has a caller or is API.
 #
 #   reference                                 this module
 #   qr!(A)                      src:311-315   qr!(A; nb=128)                -> dhqr_qr_f64
@@ -30,9 +39,9 @@
 module DistributedHouseholderQR
 
 using LinearAlgebra
-using Distributed          # only for the DArray method (worker bootstrap), like the reference
+using Distributed, DistributedArrays, SharedArrays   # src:3 -- the DArray methods and the SharedArray α (src:301-304)
 
-const libdhqr = get(ENV, "DHQR_LIB", joinpath(@__DIR__, "..", "libdhqr.so"))
+const libdhqr = get(ENV, "DHQR_LIB", joinpath(@__DIR__, "..", "..", "libdhqr.so"))
 const DHQR_NB = 128
 
 struct DHQRError <: Exception
@@ -63,6 +72,8 @@ struct DistributedHouseholderQRStruct{T1, T2}   # src:296-299
   α::T2
 end
 DistributedHouseholderQRStruct(A) = DistributedHouseholderQRStruct(A, zeros(eltype(A), size(A, 2)))  # src:306-309
+# src:301-304: a DArray factorisation keeps α in shared memory, visible to the master and to every worker of the host
+DistributedHouseholderQRStruct(A::DArray) = DistributedHouseholderQRStruct(A, SharedArray(zeros(eltype(A), size(A, 2))))
 
 # householder!(A, α) -- src:113.  In place on A (column-major Matrix{Float64}), fills α.
 # nb = 0 runs the reference's unblocked algorithm verbatim on the GPU; nb = 128 the blocked path.
@@ -309,12 +320,19 @@ end
 "devices the cached communicator of this worker was built with for the workers `ws` (nothing: no such communicator)"
 comm_devices(ws) = (_comm[] != C_NULL && _comm_key[] !== nothing && _comm_key[][1] == ws) ? _comm_key[][2] : nothing
 
+"GPU of the i-th worker when the caller names none: worker i -> device i-1 (RCCL needs one GPU per rank)"
+function default_devices(ws)
+  nd = remotecall_fetch(device_count, ws[1])
+  nd >= length(ws) || throw(ArgumentError("$(length(ws)) workers but $nd GPUs: the RCCL transport needs one GPU per worker"))
+  return collect(0:length(ws)-1)
+end
+
 "collective bootstrap over the workers `ws` (once per (workers, devices), not per call): returns the key"
 function ensure_comm(ws, devices)
   np = length(ws)
   devs = if devices === nothing            # `\\` after qr!(A; devices=...): reuse what qr! bound the workers to
     cached = remotecall_fetch(comm_devices, ws[1], ws)
-    cached === nothing ? collect(0:np-1) : cached
+    cached === nothing ? default_devices(ws) : cached
   else
     collect(devices)
   end
@@ -328,49 +346,84 @@ function ensure_comm(ws, devices)
   return key
 end
 
-# The DArray methods themselves need DistributedArrays (not a dependency of this file: the methods are defined when the
-# caller has loaded it, the way the reference's src:115-120, 226-230, 256-270 are written against it).
-function __init_darray_methods__(DistributedArrays)
-  @eval begin
-    function householder!(A::$(DistributedArrays).DArray{T, 2}, α::Vector{T}; devices=nothing) where {T<:Union{Float64, ComplexF64}}
-      ws = vec(procs(A))
-      m, n = size(A)
-      ensure_comm(ws, devices)
-      futs = [remotecall(p) do                                           # ONE call per worker (src:115-120 visits owners
-                al = zeros(T, n)                                         #   sequentially and fans out every column)
-                householder_local!($(DistributedArrays).localpart(A), m, n, al)
-              end for p in ws]
-      α .= fetch(futs[1])                                                # α is replicated (SharedArray in the reference)
-      foreach(wait, futs)
-      return (A, α)
-    end
-    function qr!(A::$(DistributedArrays).DArray{T, 2}; devices=nothing) where {T<:Union{Float64, ComplexF64}}   # src:311-315
-      H = DistributedHouseholderQRStruct(A, zeros(T, size(A, 2)))
-      householder!(H.A, H.α; devices=devices)
-      return H
-    end
-    # solve_householder!(b, H::DArray, α) -- src:284-294 with the distributed phases src:226-230 (Q'b, owners in turn) and
-    # src:256-270 (back substitution, partial dots summed over the owners): ONE collective call per worker on its factored
-    # block; b[1:n] is overwritten with x like the reference leaves it, x is returned.
-    function solve_householder!(b::Vector{T}, A::$(DistributedArrays).DArray{T, 2}, α::Vector{T}; devices=nothing) where {T<:Union{Float64, ComplexF64}}
-      ws = vec(procs(A))
-      m, n = size(A)
-      length(b) == m || throw(DimensionMismatch("b has length $(length(b)), the matrix $m rows"))
-      ensure_comm(ws, devices)
-      futs = [remotecall(p) do
-                solve_local($(DistributedArrays).localpart(A), m, n, α, b)
-              end for p in ws]
-      x = fetch(futs[1])                                                 # x is replicated
-      foreach(wait, futs)
-      b[1:n] .= x
-      return x
-    end
-    # qrA \ b for qrA = qr!(A::DArray) -- src:317-321; what test/runtests.jl:77-78 calls
-    function LinearAlgebra.:(\)(H::DistributedHouseholderQRStruct{<:$(DistributedArrays).DArray}, b::AbstractVector)
-      s = Vector{eltype(H.A)}(b)        # the reference copies b into a SharedArray (src:318)
-      return solve_householder!(s, H.A, Vector{eltype(H.A)}(H.α))
-    end
-  end
+"number of HIP devices this process sees"
+function device_count()
+  c = Ref{Int32}(0)
+  check(ccall((:dhqr_device_count, libdhqr), Int32, (Ref{Int32},), c))
+  return Int(c[])
+end
+
+"the columns DistributedArrays' default split gives worker `rank` (0-based) of `np` -- what dhqr_cs_qr_darray_* assumes"
+function contiguous_range(n::Integer, np::Integer, rank::Integer)
+  lo = Ref{Int64}(0); hi = Ref{Int64}(0)
+  ccall((:dhqr_cs_contiguous_range, libdhqr), Cvoid, (Int64, Int32, Int32, Ref{Int64}, Ref{Int64}),
+        Int64(n), Int32(np), Int32(rank), lo, hi)
+  return (Int(lo[]) + 1):Int(hi[])            # 0-based half-open -> 1-based inclusive
+end
+
+"a worker's column block must be full-height (src:33) and the default contiguous split (test/runtests.jl:71)"
+function check_layout(A::DArray, rank::Integer, np::Integer)
+  rows, cols = DistributedArrays.localindices(A)
+  rows == 1:size(A, 1) || throw(ArgumentError("every worker must own full rows (src:33)"))
+  cols == contiguous_range(size(A, 2), np, rank) ||
+    throw(ArgumentError("column block $cols of worker $(myid()) is not DistributedArrays' default split"))
+  return nothing
+end
+
+# executed ON a worker: its part of householder!(A::DArray, α) / of qrA \ b.  A DArray travels as a reference: on a
+# worker that holds a chunk, localpart(A) is that worker's own storage, factored in place like src:122-148 does.
+function householder_worker!(A::DArray{T, 2}, rank::Integer, np::Integer) where {T<:Union{Float64, ComplexF64}}
+  check_layout(A, rank, np)
+  m, n = size(A)
+  al = zeros(T, n)
+  householder_local!(localpart(A), m, n, al)
+  return al
+end
+function solve_worker(A::DArray{T, 2}, rank::Integer, np::Integer, α::Vector{T}, b::Vector{T}) where {T<:Union{Float64, ComplexF64}}
+  check_layout(A, rank, np)
+  m, n = size(A)
+  return solve_local(localpart(A), m, n, α, b)
+end
+
+# householder!(A::DArray, α) -- src:115-120.  ONE collective call per worker (the reference visits the owners in turn
+# and sends every column to every process, src:138-143).  α may be the SharedArray of src:301-304 or a plain Vector.
+function householder!(A::DArray{T, 2}, α::AbstractVector{T}; devices=nothing) where {T<:Union{Float64, ComplexF64}}
+  ws = vec(procs(A))
+  np = length(ws)
+  ensure_comm(ws, devices)
+  futs = [remotecall(householder_worker!, p, A, i - 1, np) for (i, p) in enumerate(ws)]
+  als = map(fetch, futs)                       # fetch rethrows a worker's exception
+  α .= als[1]                                  # the library returns α replicated; the master fills the shared vector
+  return (A, α)
+end
+
+function qr!(A::DArray{T, 2}; devices=nothing) where {T<:Union{Float64, ComplexF64}}   # src:311-315
+  H = DistributedHouseholderQRStruct(A)        # α::SharedArray, src:301-304
+  householder!(H.A, H.α; devices=devices)
+  return H
+end
+
+# solve_householder!(b, H::DArray, α) -- src:284-294 with the distributed phases src:226-230 (Q'b, owners in turn) and
+# src:256-270 (back substitution, partial dots summed over the owners): ONE collective call per worker on its factored
+# block; b[1:n] is overwritten with x like the reference leaves it, x is returned.  b may be the SharedArray of src:318.
+function solve_householder!(b::AbstractVector{T}, A::DArray{T, 2}, α::AbstractVector{T}; devices=nothing) where {T<:Union{Float64, ComplexF64}}
+  ws = vec(procs(A))
+  np = length(ws)
+  m, n = size(A)
+  length(b) == m || throw(DimensionMismatch("b has length $(length(b)), the matrix $m rows"))
+  ensure_comm(ws, devices)
+  αv = Vector{T}(α); bv = Vector{T}(b)         # plain copies travel to the workers
+  futs = [remotecall(solve_worker, p, A, i - 1, np, αv, bv) for (i, p) in enumerate(ws)]
+  xs = map(fetch, futs)
+  x = xs[1]                                    # x is replicated
+  b[1:n] .= x
+  return x
+end
+
+# qrA \ b for qrA = qr!(A::DArray) -- src:317-321; what test/runtests.jl:77-78 calls
+function LinearAlgebra.:(\)(H::DistributedHouseholderQRStruct{<:DArray}, b::AbstractVector)
+  s = SharedArray(Vector{eltype(H.A)}(b))      # src:318
+  return solve_householder!(s, H.A, H.α)
 end
 
 alphafactor(x::Real) = -sign(x)   # src:8 (kept for API completeness; the device applies the same rule)

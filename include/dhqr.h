@@ -5,7 +5,7 @@
  * The reference has no FFI layer; its boundary is the Julia function API.  Each entry point
  * below names the reference function (file:line) it replaces.  A Julia `ccall` wrapper with the
  * reference's names (`qr!`, `\`, `householder!`, `solve_householder!`, `partialdot`) is in
- * distributedhouseholderqr.jl_amd/julia/DistributedHouseholderQR.jl; the same ABI is bound from
+ * distributedhouseholderqr.jl_amd/julia/src/DistributedHouseholderQR.jl; the same ABI is bound from
  * Python (ctypes) by distributedhouseholderqr.jl_amd/_lib.py.  INTEGRATION.md shows both stubs.
  *
  * Conventions

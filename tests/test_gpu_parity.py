@@ -616,6 +616,28 @@ def test_column_split_full_size_eight_logical_ranks(pkg):
         mg.close()
 
 
+def test_row_split_full_size_eight_logical_ranks(pkg):
+    """BASELINE configs[4] at its FULL shape AND its partition: 262144 x 4096 with the rows split over 8 ranks (32768 rows
+    each) -- here 8 rank threads sharing cuda:0 through dhqr_mg_rs_* (in-process transport; every channel, event and
+    mailbox of the 8-GPU program live).  Size-independent properties: ||A-QR||/||A|| < 1e-12, no panel off the fast path,
+    and the cross-partition partial dots really are all-reduced: per pair of panels one Gram all-reduce per panel, one for
+    S = V'V / the cross term, one for the stacked V'C partial dots (DESIGN section 5 "Row split")"""
+    m, n = 262144, 4096
+    mg = pkg.MultiGpuQR(devices=[0] * 8)
+    try:
+        mg.rs_alloc(m, n).rs_fill(0)
+        c0 = mg.comm_counters(0)
+        mg.rs_factor()
+        c1 = mg.comm_counters(0)
+        n_ar = c1["n_allreduce"] - c0["n_allreduce"]
+        assert n // 128 * 2 <= n_ar <= n // 128 * 5, n_ar  # >= a Gram and an S all-reduce per panel; no per-column fallback
+        assert c1["bytes_allreduce"] - c0["bytes_allreduce"] >= (n // 128) * 128 * 128 * 8
+        assert mg.rs_residual(0) < 1e-12
+        assert sum(mg.stats(r)["panels_fallback"] for r in range(8)) == 0
+    finally:
+        mg.close()
+
+
 @pytest.mark.parametrize("ranks,m,n,tsqr", [(2, 6000, 512, 0), (2, 16384, 1024, 0), (8, 16384, 2048, 0), (3, 3000, 1100, 0),
                                             (2, 6000, 512, 1), (8, 16384, 1024, 1), (3, 3000, 1100, 1)])
 def test_row_split_logical_ranks_one_gpu(pkg, orc, ranks, m, n, tsqr, monkeypatch):
