@@ -234,6 +234,7 @@ def _householder_c64(A, α, nb=0):
         ctx = get_context(dev)
         ctx.use_torch_stream()
         check(L.dhqr_factor_c64_nb(ctx.handle, ptr, m, n, lda, _dev_vector(α, n, torch.complex128), nb))
+        ctx.synchronize()  # qr! is synchronous in the reference; this also collects a pipeline hand-over error (dhqr.h)
         return A, α
     if not isinstance(α, np.ndarray) or α.dtype != np.complex128 or α.size < A.shape[1] or not α.flags.c_contiguous:
         raise TypeError("α must be a contiguous complex128 numpy vector of length n")
@@ -259,6 +260,8 @@ def householder_(A, α, nb: Optional[int] = None):
         ctx = get_context(dev)
         ctx.use_torch_stream()
         check(L.dhqr_factor_f64(ctx.handle, ptr, m, n, lda, _dev_vector(α, n), nb))
+        if nb == 0:  # the unblocked path is fully asynchronous and uses the inter-workgroup lead pipeline: its error word
+            ctx.synchronize()  # is only reported by a synchronising entry point (the blocked driver reads it itself)
         return A, α
     if not isinstance(A, np.ndarray) or A.dtype != np.float64 or A.ndim != 2:
         raise TypeError("float64 numpy matrix or CUDA tensor expected")
@@ -293,7 +296,9 @@ def solve_householder_(b, H, α):
             ctx.use_torch_stream()
             check(L.dhqr_solve_c64(ctx.handle, ptr, m, n, lda, _dev_vector(α, n, torch.complex128),
                                    _dev_vector(b, m, torch.complex128)))
-            return b[:n].clone()
+            x = b[:n].clone()
+            ctx.synchronize()
+            return x
         m, n = H.shape
         F = H if H.flags.f_contiguous else np.asfortranarray(H)
         x = np.empty(n, dtype=np.complex128)
@@ -308,7 +313,9 @@ def solve_householder_(b, H, α):
         ctx = get_context(dev)
         ctx.use_torch_stream()
         check(L.dhqr_solve_f64(ctx.handle, ptr, m, n, lda, _dev_vector(α, n), _dev_vector(b, m)))
-        return b[:n].clone()
+        x = b[:n].clone()
+        ctx.synchronize()  # the flag-pipelined back substitution reports an expired hand-over wait here (dhqr.h)
+        return x
     m, n = H.shape
     F = H if H.flags.f_contiguous else np.asfortranarray(H)
     x = np.empty(n)

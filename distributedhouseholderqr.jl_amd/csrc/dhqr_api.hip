@@ -20,6 +20,7 @@
 #include "dhqr_rank1.h"
 #include "dhqr_recon.h"
 #include "dhqr_solve.h"
+#include "dhqr_qtb.h"
 #include "dhqr_tsqr.h"
 
 static thread_local char g_err[512] = "";
@@ -98,6 +99,15 @@ struct dhqr_ctx {
   bool lookahead = true;
   Buf vbuf, vt, vts, spart, spart2, sfull, scratch, pbuf;  // spart2: split-K partials of the cross terms on the side stream
   Buf zsolve_lo;         // low parts of the double-double right-hand side of the ComplexF64 solve
+  // the solve of dhqr_qtb.h: T' of every panel, Gram matrices, their slab partials, (partial dots | w | ints)
+  Buf sv_T, sv_S, sv_part, sv_small;
+  std::vector<int> sv_units;                 // host copy of the Gram pre-pass unit table, valid for (sv_m, sv_n)
+  int64_t sv_m = -1, sv_n = -1, sv_rps = 0;
+  const int *sv_units_dev = nullptr;         // where the table was uploaded (nullptr: not yet / shape changed)
+  hipStream_t wide_masked = nullptr;  // the wide stream with wide_spare CUs masked out (dhqr_dist.h, cs_run)
+  int wide_spare = 0;    // DHQR_WIDE_SPARE: CUs the wide trailing updates leave free for the look-ahead lane
+  int solve_pipe = 1;    // DHQR_SOLVE_PIPE=0: the round-1 solve (blocked apply on the MFMA kernels + 64-row back substitution)
+  int qtb_vec = -1;      // DHQR_QTB_VEC=1/2: rows per lane of k_qtb_step (-1: by the matrix height)
   Buf host_mat;          // device copy of the caller's HOST matrix (+ alpha) of dhqr_qr_f64, kept between calls
   int pair = 1;                  // 1: wide updates apply two panels per pass (DHQR_PAIR=0 disables)
   int64_t pair_min_n = 12288;    // below this the longer look-ahead lane of the pair driver costs more than it saves (profiles/r02_ab_pair_tail_and_threshold.txt)
@@ -749,10 +759,18 @@ static int32_t status_reset(dhqr_ctx *c) {
   return DHQR_OK;
 }
 // host copy of stat[0] (synchronises c->stream)
+static int32_t pipe_error_report(dhqr_ctx *c, int e);
+// (the same round trip brings the pipeline error word of dhqr_common.h: a hand-over wait that expired inside any of the
+// pass's launches is reported here, by every driver that reads its status once per pass)
 static int32_t status_read(dhqr_ctx *c, int *first_failed) {
   HIPCHECK(hipMemcpyAsync(c->hflag, c->dstat, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (c->zflags)
+    HIPCHECK(hipMemcpyAsync(c->hflag + 2, c->zflags + DHQR_PIPE_ERR_OFFSET, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  else
+    c->hflag[2] = 0;
   HIPCHECK(hipStreamSynchronize(c->stream));
   *first_failed = c->hflag[0];
+  if (c->hflag[2] != 0) return pipe_error_report(c, c->hflag[2]);
   return DHQR_OK;
 }
 
@@ -1304,6 +1322,25 @@ static int32_t factor_blocked_simple(dhqr_ctx *c, double *dA, int64_t m, int64_t
   return DHQR_OK;
 }
 
+// A stream whose kernels may use every CU but c->wide_spare of them.  Mask bit i = CU i in the runtime's order, which
+// walks the XCDs first (bit i -> XCD i % 8): DHQR_WIDE_SPARE_STRIDE picks which bits are cleared (spare CU q = bit
+// q * stride), so 1 keeps them on consecutive XCDs, 8 on one XCD.
+static int32_t create_masked_stream(dhqr_ctx *c) {
+  hipDeviceProp_t prop;
+  HIPCHECK(hipGetDeviceProperties(&prop, c->device));
+  const int ncu = prop.multiProcessorCount;
+  std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+  for (int i = 0; i < ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+  int stride = 1;
+  if (const char *e = getenv("DHQR_WIDE_SPARE_STRIDE")) stride = std::max(1, atoi(e));
+  for (int q = 0; q < c->wide_spare; ++q) {
+    const int bit = (q * stride) % ncu;
+    mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
+  }
+  HIPCHECK(hipExtStreamCreateWithCUMask(&c->wide_masked, (uint32_t)mask.size(), mask.data()));
+  return DHQR_OK;
+}
+
 #include "dhqr_comm.h"
 #include "dhqr_hostio.h"
 #include "dhqr_dist.h"
@@ -1467,7 +1504,16 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     HIPCHECK(hipMalloc((void **)&c->dstat, 16 * sizeof(int)));
     HIPCHECK(hipMalloc((void **)&c->zflags, DHQR_PIPE_INTS * sizeof(int)));  // 128 flags + the error word (dhqr_common.h)
     HIPCHECK(hipMemsetAsync(c->zflags, 0, DHQR_PIPE_INTS * sizeof(int), c->stream));
+    {
+      int limit = DHQR_PIPE_SPIN_LIMIT;
+      if (const char *e = getenv("DHQR_PIPE_SPIN_LIMIT")) limit = std::max(1, atoi(e));
+      HIPCHECK(hipMemcpyAsync(c->zflags + DHQR_PIPE_LIMIT_OFFSET, &limit, sizeof(int), hipMemcpyHostToDevice, c->stream));
+      HIPCHECK(hipStreamSynchronize(c->stream));  // `limit` is a stack variable
+    }
     if (const char *e = getenv("DHQR_ZPIPE")) c->zpipe = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_SOLVE_PIPE")) c->solve_pipe = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_WIDE_SPARE")) c->wide_spare = atoi(e);
+    if (const char *e = getenv("DHQR_QTB_VEC")) c->qtb_vec = atoi(e);
     hipLaunchKernelGGL(k_set_status, dim3(1), dim3(64), 0, c->stream, c->dstat, INT_MAX);
     LAUNCHCHECK();
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -1505,7 +1551,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
     c->hio = nullptr;
   }
   Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
-                 &c->ws[1].w1r, &c->ws[1].w2, &c->ws[2].w1, &c->ws[2].w1r, &c->ws[2].w2, &c->spart, &c->spart2, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo, &c->host_mat};
+                 &c->ws[1].w1r, &c->ws[1].w2, &c->ws[2].w1, &c->ws[2].w1r, &c->ws[2].w2, &c->spart, &c->spart2, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo, &c->host_mat, &c->sv_T, &c->sv_S, &c->sv_part, &c->sv_small};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {
@@ -1519,6 +1565,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
     if (e) (void)hipEventDestroy(e);
   if (c->hi) (void)hipStreamDestroy(c->hi);
   if (c->hi2) (void)hipStreamDestroy(c->hi2);
+  if (c->wide_masked) (void)hipStreamDestroy(c->wide_masked);
   if (c->own) (void)hipStreamDestroy(c->own);
   delete c;
   return DHQR_OK;
@@ -1536,16 +1583,19 @@ int32_t dhqr_use_own_stream(dhqr_ctx *c) {
 }
 // A column pipeline whose bounded hand-over wait expired (dhqr_common.h) has produced wrong numbers instead of hanging
 // the GPU: reported here, by the entry points that synchronise anyway.  c->stream must be idle.
+static int32_t pipe_error_report(dhqr_ctx *c, int e) {
+  HIPCHECK(hipMemsetAsync(c->zflags + DHQR_PIPE_ERR_OFFSET, 0, sizeof(int), c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return set_err(DHQR_EHIP, "an inter-workgroup pipeline (k_zpanel_pipe / rankk_lead_pipe / k_backsub_pipe, launch %d) gave up "
+                 "waiting for a lower-indexed workgroup: the results of that call are invalid; DHQR_ZPIPE=0 / DHQR_RANKK_PIPE=0 / "
+                 "DHQR_SOLVE_PIPE=0 select the kernels without inter-workgroup waits", e);
+}
 static int32_t pipe_error_check(dhqr_ctx *c) {
   if (!c->zflags) return DHQR_OK;
   int e = 0;
   HIPCHECK(hipMemcpy(&e, c->zflags + DHQR_PIPE_ERR_OFFSET, sizeof(int), hipMemcpyDeviceToHost));
   if (e == 0) return DHQR_OK;
-  HIPCHECK(hipMemsetAsync(c->zflags + DHQR_PIPE_ERR_OFFSET, 0, sizeof(int), c->stream));
-  HIPCHECK(hipStreamSynchronize(c->stream));
-  return set_err(DHQR_EHIP, "a column pipeline (k_zpanel_pipe / rankk_lead_pipe, launch %d) gave up waiting for a lower-indexed "
-                 "workgroup: the results of that factorisation are invalid; DHQR_ZPIPE=0 / DHQR_RANKK_PIPE=0 select the "
-                 "one-launch-per-column kernels", e);
+  return pipe_error_report(c, e);
 }
 
 int32_t dhqr_synchronize(dhqr_ctx *c) {
@@ -1716,6 +1766,71 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
   return rc;
 }
 
+// The solve of dhqr_qtb.h on c->stream: batched Gram / T' pre-pass, one k_qtb_step launch per panel, one pipelined
+// back-substitution launch.  Nothing synchronises; db[0:n] <- x.
+static int32_t solve_pipelined(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda, const double *dalpha,
+                               double *db) {
+  const int np = (int)((n + DHQR_NBV - 1) / DHQR_NBV);
+  const bool vec = (lda % 2 == 0) && (m % 2 == 0) && aligned16(dA) && aligned16(db);
+  // ---- unit table of the Gram pre-pass: panel k = rows [128 k, m), slabs of rps rows
+  if (c->sv_m != m || c->sv_n != n) {
+    int64_t total = 0;
+    for (int k = 0; k < np; ++k) total += m - (int64_t)k * DHQR_NBV;
+    int64_t rps = ((total / 1024 + 15) / 16) * 16;
+    rps = std::min<int64_t>(std::max<int64_t>(rps, 256), 4096);
+    c->sv_units.assign((size_t)np + 1, 0);
+    for (int k = 0; k < np; ++k)
+      c->sv_units[(size_t)k + 1] = c->sv_units[(size_t)k] + (int)((m - (int64_t)k * DHQR_NBV + rps - 1) / rps);
+    c->sv_rps = rps;
+    c->sv_m = m;
+    c->sv_n = n;
+    c->sv_units_dev = nullptr;
+  }
+  const int nunits = c->sv_units[(size_t)np];
+  const int VEC = (c->qtb_vec == 1 || !vec) ? 1 : (c->qtb_vec == 2 ? 2 : (m >= 16384 ? 2 : 1));
+  const int64_t SS = 64 * VEC;
+  const int64_t sl = SS * ((m + SS * 512 - 1) / (SS * 512));
+  const int64_t nsl = (m + sl - 1) / sl;
+  CHECK(ensure(c, c->sv_T, (size_t)np * QTB_NB2));
+  CHECK(ensure(c, c->sv_S, (size_t)np * QTB_NB2));
+  CHECK(ensure(c, c->sv_part, (size_t)nunits * QTB_NB2));
+  const size_t n_ypart = (size_t)nsl * QTB_NB, n_w = (size_t)(np + 1) * QTB_NB;
+  const size_t n_ints = (size_t)(np + 1) + (size_t)(np + 1) + (size_t)np;  // unit table | arrival counters | block flags
+  CHECK(ensure(c, c->sv_small, n_ypart + n_w + (n_ints + 1) / 2 + 16));
+  double *ypart = c->sv_small.p, *wbuf = ypart + n_ypart;
+  int *units = reinterpret_cast<int *>(wbuf + n_w), *counter = units + (np + 1), *flags = counter + (np + 1);
+  if (c->sv_units_dev != units) {  // the table stays on the device between calls on the same shape
+    HIPCHECK(hipMemcpyAsync(units, c->sv_units.data(), (size_t)(np + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->sv_units_dev = units;
+  }
+  HIPCHECK(hipMemsetAsync(counter, 0, (size_t)(2 * np + 1) * sizeof(int), c->stream));
+  // ---- pre-pass (independent of b): S_k = V_k'V_k, T_k' = (I + striu(S_k))^{-T}
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_tn_gram_batch<2>), dim3((unsigned)nunits), dim3(256), 0, c->stream, dA, lda, m, n, c->sv_rps,
+                       (const int *)units, np, c->sv_part.p);
+  else
+    hipLaunchKernelGGL((k_gemm_tn_gram_batch<1>), dim3((unsigned)nunits), dim3(256), 0, c->stream, dA, lda, m, n, c->sv_rps,
+                       (const int *)units, np, c->sv_part.p);
+  hipLaunchKernelGGL(k_qtb_sum_gram, dim3((unsigned)np, 16), dim3(256), 0, c->stream, (const double *)c->sv_part.p,
+                     (const int *)units, n, c->sv_S.p);
+  hipLaunchKernelGGL(k_build_t_batch, dim3((unsigned)np), dim3(1024), 0, c->stream, (const double *)c->sv_S.p, n, c->sv_T.p);
+  // ---- b <- Q'b (src:215-242): launch k updates by panel k-1 and forms the dots of panel k
+  for (int k = 0; k <= np; ++k) {
+    const int64_t rfirst = (int64_t)(k >= 1 ? k - 1 : 0) * DHQR_NBV;
+    const unsigned grid = (unsigned)(nsl - rfirst / sl);
+    if (VEC == 2)
+      hipLaunchKernelGGL((k_qtb_step<2>), dim3(grid), dim3(256), 0, c->stream, dA, lda, m, n, k, np, sl, db,
+                         (const double *)c->sv_T.p, wbuf, ypart, counter);
+    else
+      hipLaunchKernelGGL((k_qtb_step<1>), dim3(grid), dim3(256), 0, c->stream, dA, lda, m, n, k, np, sl, db,
+                         (const double *)c->sv_T.p, wbuf, ypart, counter);
+  }
+  // ---- back substitution (src:244-282): one pipelined launch
+  hipLaunchKernelGGL(k_backsub_pipe, dim3((unsigned)np), dim3(BSP_THREADS), 0, c->stream, dA, lda, dalpha, db, n, flags,
+                     c->zflags + DHQR_PIPE_ERR_OFFSET);
+  return DHQR_OK;
+}
+
 int32_t dhqr_solve_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda,
                        const double *dalpha, double *db) {
   ENTER(c);
@@ -1725,14 +1840,19 @@ int32_t dhqr_solve_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int6
   CHECK(prof_begin(c, CAT_SOLVE));
   const bool was = c->profiling;
   c->profiling = false;  // the solve is timed as one group
-  int32_t rc = apply_q_impl(c, dA, m, n, lda, dalpha, db, 1, m, 1, false);  // src:215-242
-  if (rc == DHQR_OK) {
-    for (int64_t hi = n; hi > 0; hi -= BS_NB) {  // src:244-282
-      const int64_t lo = std::max<int64_t>(0, hi - BS_NB);
-      hipLaunchKernelGGL(k_backsub_diag, dim3(1), dim3(64), 0, c->stream, dA, lda, dalpha, db, lo, hi);
-      if (lo > 0)
-        hipLaunchKernelGGL(k_backsub_update, dim3((unsigned)((lo + 255) / 256)), dim3(256), 0,
-                           c->stream, dA, lda, db, lo, hi);
+  int32_t rc;
+  if (c->solve_pipe) {
+    rc = solve_pipelined(c, dA, m, n, lda, dalpha, db);
+  } else {
+    rc = apply_q_impl(c, dA, m, n, lda, dalpha, db, 1, m, 1, false);  // src:215-242
+    if (rc == DHQR_OK) {
+      for (int64_t hi = n; hi > 0; hi -= BS_NB) {  // src:244-282
+        const int64_t lo = std::max<int64_t>(0, hi - BS_NB);
+        hipLaunchKernelGGL(k_backsub_diag, dim3(1), dim3(64), 0, c->stream, dA, lda, dalpha, db, lo, hi);
+        if (lo > 0)
+          hipLaunchKernelGGL(k_backsub_update, dim3((unsigned)((lo + 255) / 256)), dim3(256), 0,
+                             c->stream, dA, lda, db, lo, hi);
+      }
     }
   }
   c->profiling = was;

@@ -242,17 +242,21 @@ __device__ __forceinline__ double dhqr_alphafactor(double x) {
 #define DHQR_PIPE_FLAG_STRIDE 32
 #define DHQR_PIPE_NFLAGS 128
 #define DHQR_PIPE_ERR_OFFSET (DHQR_PIPE_NFLAGS * DHQR_PIPE_FLAG_STRIDE)
+#define DHQR_PIPE_LIMIT_OFFSET (DHQR_PIPE_ERR_OFFSET + 1)  // the waiters' poll bound (same 128-byte line as the error word)
 #define DHQR_PIPE_INTS (DHQR_PIPE_ERR_OFFSET + DHQR_PIPE_FLAG_STRIDE)
 #ifndef DHQR_PIPE_SPIN_LIMIT
 #define DHQR_PIPE_SPIN_LIMIT (1 << 24)  // x (one L2 poll + s_sleep 1) ~ several seconds; a hand-over takes microseconds
 #endif
 // called by ONE thread of the waiting workgroup: relaxed polls, then one acquire fence (an acquire LOAD at agent scope
 // would invalidate the XCD's L2 on every iteration)
+// The bound is a word of the flag block (DHQR_PIPE_LIMIT_OFFSET; written once by dhqr_create: DHQR_PIPE_SPIN_LIMIT, or
+// the environment variable of that name -- tests/test_gpu_kernels.py sets it to 1 to exercise the reporting path).
 __device__ __forceinline__ void dhqr_pipe_wait(int *flags, int idx, int epoch) {
   int spins = 0;
+  const int limit = flags[DHQR_PIPE_LIMIT_OFFSET];
   while (__hip_atomic_load(flags + idx * DHQR_PIPE_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > DHQR_PIPE_SPIN_LIMIT) {
+    if (++spins > limit) {
       __hip_atomic_store(flags + DHQR_PIPE_ERR_OFFSET, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }

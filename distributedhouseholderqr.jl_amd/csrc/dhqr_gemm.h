@@ -43,13 +43,16 @@ __device__ __forceinline__ dhqr_d4 mfma_f64(double a, double b, dhqr_d4 c) {
 // NBV = number of V columns (reflectors) = output rows: 128 for the trailing update, 32 / 64 for
 // the narrow block reflectors inside a panel.  Wave layout: NBV=128 -> 2 (cols) x 2 (p) waves of
 // 64 x 64; NBV=64 -> 4 x 1 waves of 32 cols x 64 p; NBV=32 -> 4 x 1 waves of 32 cols x 32 p.
-template <int VEC, int NCS, int NBV>
-__global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V, int64_t ldv,
-                                                    const double *__restrict__ C, int64_t ldc,
-                                                    int ncsplit, int64_t csplit_stride,
-                                                    int64_t rows, int64_t ncols, int64_t rps,
-                                                    double *__restrict__ out, int64_t ldo,
-                                                    int64_t osplit_stride) {
+// MASK (the batched Gram products of the solve, k_gemm_tn_gram_batch): V == C is a factored panel IN PLACE, whose top
+// block still holds R above the diagonal -- element (row r of the panel, column p) counts as 0 where r < p.
+template <int VEC, int NCS, int NBV, bool MASK>
+__device__ __forceinline__ void gemm_tn_body(const double *__restrict__ V, int64_t ldv,
+                                             const double *__restrict__ C, int64_t ldc,
+                                             int ncsplit, int64_t csplit_stride,
+                                             int64_t rows, int64_t ncols, int64_t rps,
+                                             double *__restrict__ out, int64_t ldo,
+                                             int64_t osplit_stride, const unsigned bx, const unsigned by,
+                                             const unsigned bz) {
   constexpr int NPI = (NBV >= 64) ? 4 : NBV / 16;  // p tiles per wave
   constexpr int WP = NBV / (16 * NPI);              // waves along p (1 or 2)
   constexpr int WC = 4 / WP;                        // waves along the columns
@@ -60,8 +63,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int i16 = lane & 15, k4 = lane >> 4;
   const int wc = (WP == 2) ? (w >> 1) : w, wp = (WP == 2) ? (w & 1) : 0;
-  const int64_t c0 = (int64_t)blockIdx.x * 128;
-  const int64_t rbeg = (int64_t)blockIdx.y * rps;
+  const int64_t c0 = (int64_t)bx * 128;
+  const int64_t rbeg = (int64_t)by * rps;
   const int64_t rend = (rbeg + rps < rows) ? rbeg + rps : rows;
   const int nkt = (int)((rend - rbeg + G_KT - 1) / G_KT);
   const int ncv = (int)((ncols - c0 < 128) ? ncols - c0 : 128);  // valid columns in this tile
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
   // 32-bit element offsets from the (uniform) tile base.
   // blockIdx.z (0 in every launch but the narrow two-panel product, narrow_vtc in dhqr_api.hip): the z-th block of NBV
   // reflectors of V, whose products go NBV rows further down in `out`.
-  const double *Vb = V + rbeg + (int64_t)blockIdx.z * NBV * ldv;
+  const double *Vb = V + rbeg + (int64_t)bz * NBV * ldv;
   const double *Cb = C + rbeg + c0 * ldc;
   uint32_t offv[4], offc[4];
   bool okc[4];
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
     const int q = t + i * 256;
     const int col = q >> 3;
     okc[i] = col < ncv;
-    offv[i] = (uint32_t)(col * ldv);
+    offv[i] = (uint32_t)(((MASK && !okc[i]) ? 0 : col) * ldv);  // MASK: V has no padding columns beyond ncols either
     offc[i] = (uint32_t)((okc[i] ? col : 0) * ldc);
   }
   // Software pipeline: load_tile only ISSUES the global loads of the next K-tile (raw values stay
@@ -145,6 +148,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
       if (!ok0) { x.x = 0.0; y.x = 0.0; }
       if (!ok1) { x.y = 0.0; y.y = 0.0; }
       if (!okc[i]) y = make_double2(0.0, 0.0);
+      if constexpr (MASK) {  // V == C, panel in place: zero above the diagonal of the top block
+        if (!okc[i]) x = make_double2(0.0, 0.0);
+        const int64_t r0 = rbeg + (int64_t)kt * G_KT + 2 * rp;
+        if (r0 < col) { x.x = 0.0; y.x = 0.0; }
+        if (r0 + 1 < col) { x.y = 0.0; y.y = 0.0; }
+      }
       if (i < NVL) *reinterpret_cast<double2 *>(&Vs[buf][col * G_LDK + 2 * rp]) = x;
       *reinterpret_cast<double2 *>(&Cs[buf][col * G_LDK + 2 * rp]) = y;
     }
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
     __syncthreads();
   }
 
-  double *o = out + (int64_t)blockIdx.y * osplit_stride + c0 * ldo + (int64_t)blockIdx.z * NBV;
+  double *o = out + (int64_t)by * osplit_stride + c0 * ldo + (int64_t)bz * NBV;
 #pragma unroll
   for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
@@ -190,6 +199,46 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
           o[(uint32_t)(wp * 64 + pi * 16 + i16) + (uint32_t)(cl * ldo)] = acc[ci][pi][g];
       }
     }
+}
+
+template <int VEC, int NCS, int NBV>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V, int64_t ldv,
+                                                    const double *__restrict__ C, int64_t ldc,
+                                                    int ncsplit, int64_t csplit_stride,
+                                                    int64_t rows, int64_t ncols, int64_t rps,
+                                                    double *__restrict__ out, int64_t ldo,
+                                                    int64_t osplit_stride) {
+  gemm_tn_body<VEC, NCS, NBV, false>(V, ldv, C, ldc, ncsplit, csplit_stride, rows, ncols, rps, out, ldo, osplit_stride,
+                                     blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Batched Gram products of the solve (dhqr_qtb.h): S_k = V_k' V_k for EVERY 128-column panel of a factored matrix in one
+// launch, V_k read in place (MASK).  unit_first[k] = index of panel k's first (panel, rps-row slab) unit, unit_first[np] =
+// number of units = gridDim.x; unit u of panel k writes its 128 x 128 partial sum to out + u * 128 * 128 (summed in slab
+// order by k_qtb_sum_gram).  A panel is rows [128 k, m) x columns [128 k, 128 k + w_k) of A.
+template <int VEC>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_gram_batch(const double *__restrict__ A, int64_t lda, int64_t m,
+                                                               int64_t n, int64_t rps, const int *__restrict__ unit_first,
+                                                               int np, double *__restrict__ out) {
+  __shared__ int kk_s;
+  if (threadIdx.x == 0) {  // largest k with unit_first[k] <= blockIdx.x
+    int lo = 0, hi = np - 1;
+    const int u = (int)blockIdx.x;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (unit_first[mid] <= u) lo = mid; else hi = mid - 1;
+    }
+    kk_s = lo;
+  }
+  __syncthreads();
+  const int k = kk_s;
+  const int64_t c0 = (int64_t)k * DHQR_NBV;
+  const int64_t w = (n - c0 < DHQR_NBV) ? n - c0 : DHQR_NBV;
+  const double *P = A + c0 + c0 * lda;
+  const unsigned y = blockIdx.x - (unsigned)unit_first[k];
+  gemm_tn_body<VEC, 1, DHQR_NBV, true>(P, lda, P, lda, 1, (int64_t)0, m - c0, w, rps,
+                                       out + (int64_t)blockIdx.x * (DHQR_NBV * DHQR_NBV) - (int64_t)y * (DHQR_NBV * DHQR_NBV),
+                                       (int64_t)DHQR_NBV, (int64_t)(DHQR_NBV * DHQR_NBV), 0u, y, 0u);
 }
 
 // -------------------------------------------------------------------------------------------

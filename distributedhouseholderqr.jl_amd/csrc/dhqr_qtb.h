@@ -1,0 +1,378 @@
+// dhqr_qtb.h -- the solve written for the machine ("device-side solve PERFORMANCE").
+//
+// Reference mapping (src/DistributedHouseholderQR.jl):
+//   _solve_householder1!  src:215-242   b <- Q'b: for every reflector j, s = partialdot(v_j, b, j:m); b[j:m] -= v_j s.
+//   _solve_householder2!  src:244-282   back substitution from row n up: b[i] = (b[i] - sum_{j>i} R[i,j] b[j]) / alpha[i].
+// Both are O(mn) passes over the factored matrix: HBM / latency bound, no MFMA tile for one right-hand side.
+//
+// Q'b, one launch per 128-column panel (k_qtb_step).  Panel k's 128 reflectors act as I - V_k T_k' V_k' (compact WY,
+// T_k^{-1} = I + striu(V_k'V_k)); V_k is read IN PLACE (the strict upper part of its top block holds R and counts as zero).
+// Launch k does, per slab of rows, (a) the update by panel k-1, b -= V_{k-1} w_{k-1}, and -- on the rows it has just
+// brought up to date -- (b) the partial dots of panel k, y_k = V_k' b; (c) the LAST workgroup to arrive (one atomic
+// counter per launch) sums the slabs' partial dots in slab order and forms w_k = T_k' y_k.  So V is streamed twice (once
+// as the dot operand, once -- one launch later, out of the L2 / MALL -- as the update operand), b never leaves the
+// workgroup between the two, and one dependent launch per PANEL replaces the reference's two passes per COLUMN.
+// T_k' for every panel comes from one batched pre-pass that does not depend on b: k_gemm_tn_gram_batch (dhqr_gemm.h,
+// FP64 MFMA, one pass over V) -> k_qtb_sum_gram -> k_build_t_batch (the blocked inverse of dhqr_recon.h).
+//
+// Back substitution, ONE launch (k_backsub_pipe): workgroup i owns the 128 rows of block s = nblk-1-i.  It streams its
+// row block of R from the right, R[s, J] for J = nblk-1 .. s+1, subtracting R[s, J] x_J as soon as the owner of block J has
+// published x_J (release / acquire flag per block), then solves its own triangular block and publishes x_s.  A workgroup
+// only waits for LOWER-indexed workgroups (dispatched first; the CPU emulator runs them in index order), the next R
+// block is in flight while the current one waits for its x, and what sits on the critical chain per block is one flag
+// hand-over, one 128 x 128 matrix-vector product and one 128-step triangular solve inside a single wave.
+#pragma once
+#include "dhqr_common.h"
+#include "dhqr_recon.h"
+
+#define QTB_NB DHQR_NBV
+#define QTB_NB2 (DHQR_NBV * DHQR_NBV)
+
+// S_k = sum over panel k's slab partials (fixed order); columns beyond the panel's width are zeroed.  grid (np, 16).
+__global__ __launch_bounds__(256) void k_qtb_sum_gram(const double *__restrict__ part, const int *__restrict__ unit_first,
+                                                      int64_t n, double *__restrict__ S) {
+  const int k = blockIdx.x;
+  const int u0 = unit_first[k], u1 = unit_first[k + 1];
+  const int64_t c0 = (int64_t)k * QTB_NB;
+  const int w = (int)((n - c0 < QTB_NB) ? n - c0 : QTB_NB);
+  for (int e = blockIdx.y * 256 + threadIdx.x; e < QTB_NB2; e += gridDim.y * 256) {
+    double s = 0.0;
+    if ((e >> 7) < w) {
+      int u = u0;
+      for (; u + 3 < u1; u += 4) {
+        const double a0 = part[(int64_t)u * QTB_NB2 + e], a1 = part[(int64_t)(u + 1) * QTB_NB2 + e];
+        const double a2 = part[(int64_t)(u + 2) * QTB_NB2 + e], a3 = part[(int64_t)(u + 3) * QTB_NB2 + e];
+        s += a0; s += a1; s += a2; s += a3;
+      }
+      for (; u < u1; ++u) s += part[(int64_t)u * QTB_NB2 + e];
+    }
+    S[(int64_t)k * QTB_NB2 + e] = s;
+  }
+}
+
+// Tt_k = T_k' with T_k = (I + striu(S_k))^{-1}, for every panel: one 1024-thread workgroup per panel (k_build_t's inverse).
+// Stored column-major, Tt[i + 128 j] = T'[i][j] = T[j][i]: lower triangular.
+__global__ __launch_bounds__(1024) void k_build_t_batch(const double *__restrict__ S_all, int64_t n,
+                                                         double *__restrict__ Tt_all) {
+  __shared__ rc5_lds L;
+  const int64_t k = blockIdx.x;
+  const int64_t c0 = k * QTB_NB;
+  const int w = (int)((n - c0 < QTB_NB) ? n - c0 : QTB_NB);
+  double x12[4];
+  rc_upper_inverse_blocked(S_all + k * QTB_NB2, w, true, L, x12);
+  double *Tt = Tt_all + k * QTB_NB2;
+  rc5_emit(L, x12, [&](int i, int j, double v) { Tt[j + i * QTB_NB] = v; });
+}
+
+// Sums of 32 per-lane values over the 64 lanes of a wave by halving: after the exchange with lane ^ 32 a lane keeps 16
+// of the 32 sums, after lane ^ 16 eight, ... -- 32 exchanges instead of 32 x 6.  Returns, in every lane, the total of value
+// index qtb_red_index(lane) (both lanes of a pair (l, l ^ 1) hold the same one).
+__device__ __forceinline__ int qtb_red_index(int lane) {
+  return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+}
+__device__ __forceinline__ double qtb_wave_reduce32(double (&y)[32], int lane) {
+#define QTB_HALVE(N_, BIT_)                                                  \
+  {                                                                          \
+    const bool up = (lane & (BIT_)) != 0;                                    \
+    _Pragma("unroll") for (int q = 0; q < (N_); ++q) {                       \
+      const double keep = up ? y[q + (N_)] : y[q];                           \
+      const double send = up ? y[q] : y[q + (N_)];                           \
+      y[q] = keep + __shfl_xor(send, (BIT_), 64);                            \
+    }                                                                        \
+  }
+  QTB_HALVE(16, 32)
+  QTB_HALVE(8, 16)
+  QTB_HALVE(4, 8)
+  QTB_HALVE(2, 4)
+  QTB_HALVE(1, 2)
+#undef QTB_HALVE
+  return y[0] + __shfl_xor(y[0], 1, 64);
+}
+
+// One panel step of b <- Q'b (file header).  k = 0 .. np (np = number of panels): update by panel k-1 (k >= 1), partial
+// dots of panel k (k < np), w_k by the last workgroup.  Slabs are `sl` global rows (multiple of 64 VEC); workgroup x of
+// launch k owns slab floor(first active row / sl) + x.  256 threads: wave g takes the panel's columns 32 g .. 32 g + 31,
+// lane l the rows r0 + VEC l .. of every 64 VEC-row sub-slab.  VEC = 2: 16-byte loads (lda, m even, 16-byte aligned A, b).
+// ypart: gridDim.x x 128 partial dots of this launch; counter[k]: arrivals (zeroed before the first launch).
+template <int VEC>
+__global__ __launch_bounds__(256) void k_qtb_step(const double *__restrict__ A, int64_t lda, int64_t m, int64_t n, int k,
+                                                  int np, int64_t sl, double *__restrict__ b,
+                                                  const double *__restrict__ Tt_all, double *__restrict__ wbuf,
+                                                  double *__restrict__ ypart, int *__restrict__ counter) {
+  constexpr int SS = 64 * VEC;
+  __shared__ double w_s[QTB_NB];
+  __shared__ double red[2][4][SS];
+  __shared__ double y_s[2][QTB_NB];
+  __shared__ int last_s;
+  const int t = threadIdx.x, lane = t & 63, g = t >> 6;
+  const bool upd = k >= 1, dot = k < np;
+  const int64_t cu = (int64_t)(k - 1) * QTB_NB;  // first column (= first row) of the panel that updates
+  const int64_t cd = (int64_t)k * QTB_NB;        // ... of the panel whose dot products are formed
+  const int wu = upd ? (int)((n - cu < QTB_NB) ? n - cu : QTB_NB) : 0;
+  const int wd = dot ? (int)((n - cd < QTB_NB) ? n - cd : QTB_NB) : 0;
+  const int64_t rfirst = upd ? cu : cd;
+  const int64_t slab = rfirst / sl + blockIdx.x;
+  const int64_t r_lo = (slab * sl > rfirst) ? slab * sl : rfirst;
+  const int64_t r_hi = ((slab + 1) * sl < m) ? (slab + 1) * sl : m;
+  if (upd && t < QTB_NB) w_s[t] = wbuf[(int64_t)(k - 1) * QTB_NB + t];
+  __syncthreads();
+  double yacc[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) yacc[q] = 0.0;
+  int par = 0;
+  for (int64_t r0 = r_lo; r0 < r_hi; r0 += SS) {
+    const int64_t r = r0 + (int64_t)lane * VEC;
+    const int64_t ra = (r + VEC <= m) ? r : (m - VEC);  // address row: never beyond the matrix (values masked below)
+    double bv[VEC];
+    if constexpr (VEC == 2) {
+      bv[0] = bv[1] = 0.0;
+      if (r < m) {  // m even: the pair is inside or outside as a whole
+        const double2 x = *reinterpret_cast<const double2 *>(b + r);
+        bv[0] = x.x; bv[1] = x.y;
+      }
+    } else {
+      bv[0] = (r < m) ? b[r] : 0.0;
+    }
+    const bool tail = r0 + SS > m;
+    if (upd) {
+      double acc[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
+      const double *Ac = A + ra + (cu + g * 32) * lda;
+      const int jn = (wu - g * 32 < 32) ? wu - g * 32 : 32;  // this wave's columns inside the panel (wave-uniform)
+      if (!tail && r0 >= cu + QTB_NB && jn == 32) {          // below the top block: no masks
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          double v[16][VEC];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            if constexpr (VEC == 2) {
+              const double2 x = *reinterpret_cast<const double2 *>(Ac + (int64_t)(h * 16 + q) * lda);
+              v[q][0] = x.x; v[q][1] = x.y;
+            } else {
+              v[q][0] = Ac[(int64_t)(h * 16 + q) * lda];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const double wj = w_s[g * 32 + h * 16 + q];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = fma(v[q][e], wj, acc[e]);
+          }
+        }
+      } else {
+        for (int q = 0; q < jn; ++q) {
+          const int j = g * 32 + q;
+          const double wj = w_s[j];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const bool ok = (r + e < m) && (r + e >= cu + j);  // rows of the top block above the diagonal hold R
+            const double x = Ac[(int64_t)q * lda + (ok ? (r + e - ra) : 0)];
+            acc[e] = fma(ok ? x : 0.0, wj, acc[e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) red[par][g][lane * VEC + e] = acc[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int i = lane * VEC + e;
+        bv[e] -= (red[par][0][i] + red[par][1][i]) + (red[par][2][i] + red[par][3][i]);  // src:219-221 for 128 reflectors
+      }
+      par ^= 1;
+      if (g == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (r + e < m) b[r + e] = bv[e];
+      }
+    }
+    if (dot && r0 + SS > cd) {
+      const double *Ac = A + ra + (cd + g * 32) * lda;
+      const int jn = (wd - g * 32 < 32) ? wd - g * 32 : 32;
+      if (!tail && r0 >= cd + QTB_NB && jn == 32) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          double v[16][VEC];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            if constexpr (VEC == 2) {
+              const double2 x = *reinterpret_cast<const double2 *>(Ac + (int64_t)(h * 16 + q) * lda);
+              v[q][0] = x.x; v[q][1] = x.y;
+            } else {
+              v[q][0] = Ac[(int64_t)(h * 16 + q) * lda];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) yacc[h * 16 + q] = fma(v[q][e], bv[e], yacc[h * 16 + q]);  // src:218
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+          if (q < jn) {
+            const int j = g * 32 + q;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const bool ok = (r + e < m) && (r + e >= cd + j);
+              const double x = Ac[(int64_t)q * lda + (ok ? (r + e - ra) : 0)];
+              yacc[q] = fma(ok ? x : 0.0, bv[e], yacc[q]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!dot) return;
+  {
+    const double tot = qtb_wave_reduce32(yacc, lane);
+    if ((lane & 1) == 0) ypart[(int64_t)blockIdx.x * QTB_NB + g * 32 + qtb_red_index(lane)] = tot;
+  }
+  __syncthreads();  // every wave's partial dots are stored (the barrier waits for the stores)
+  if (t == 0) {
+    const int prev = __hip_atomic_fetch_add(counter + k, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = (prev == (int)gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  {  // y_k: the slabs' partial dots in slab order (two interleaved halves, then the halves)
+    const int j = t & 127, h = t >> 7;
+    const int ns = (int)gridDim.x;
+    double s = 0.0;
+    int q = h;
+    for (; q + 6 < ns; q += 8) {
+      const double a0 = ypart[(int64_t)q * QTB_NB + j], a1 = ypart[(int64_t)(q + 2) * QTB_NB + j];
+      const double a2 = ypart[(int64_t)(q + 4) * QTB_NB + j], a3 = ypart[(int64_t)(q + 6) * QTB_NB + j];
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; q < ns; q += 2) s += ypart[(int64_t)q * QTB_NB + j];
+    y_s[h][j] = s;
+  }
+  __syncthreads();
+  if (t < QTB_NB) y_s[0][t] += y_s[1][t];
+  __syncthreads();
+  {  // w_k = T_k' y_k: thread (i, h) sums columns 64 h .. 64 h + 63 of row i (T' is lower triangular: zeros beyond i)
+    const int i = t & 127, h = t >> 7;
+    const double *Tt = Tt_all + (int64_t)k * QTB_NB2 + i;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+    for (int j = 64 * h; j < 64 * h + 64; j += 2) {
+      a0 = fma(Tt[(int64_t)j * QTB_NB], y_s[0][j], a0);
+      a1 = fma(Tt[(int64_t)(j + 1) * QTB_NB], y_s[0][j + 1], a1);
+    }
+    y_s[1][i] = 0.0;
+    __syncthreads();
+    if (h == 1) y_s[1][i] = a0 + a1;
+    __syncthreads();
+    if (h == 0) wbuf[(int64_t)k * QTB_NB + i] = (a0 + a1) + y_s[1][i];
+  }
+}
+
+// value of lane `src` (wave-uniform) in every lane: two v_readlane_b32, no LDS crossbar round trip
+__device__ __forceinline__ double qtb_lane_bcast(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+// ---- pipelined back substitution (file header) -----------------------------------------------------------------------
+// Bounded wait for block `idx`'s flag (one thread of the workgroup): relaxed polls + one acquire fence, like dhqr_pipe_wait;
+// a waiter that gives up records it in the context's pipeline error word (reported by the next synchronising entry point).
+__device__ __forceinline__ void qtb_flag_wait(int *flags, int idx, int *err) {
+  int spins = 0;
+  const int limit = err[1];  // DHQR_PIPE_LIMIT_OFFSET: the word behind the error word
+  while (__hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > limit) {
+      __hip_atomic_store(err, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+#define BSP_THREADS 512
+// x = R^{-1} b[0:n] in place (b[0:n] <- x).  grid = nblk = ceil(n / 128) workgroups of 512 threads; flags: nblk ints, zero.
+// Thread (r = t & 127, q = t >> 7): row r of the block, columns 32 q .. 32 q + 31 of every 128-column block to the right.
+// Rs: the workgroup's own diagonal block, column c scaled by 1 / alpha_c and zero on and below the diagonal, so that the
+// triangular solve's chain per column is one lane broadcast and one fma: b_t -= (R[t,c] / alpha_c) b_c, x_c = b_c / alpha_c.
+__global__ __launch_bounds__(BSP_THREADS) void k_backsub_pipe(const double *__restrict__ A, int64_t lda,
+                                                              const double *__restrict__ alpha, double *__restrict__ b,
+                                                              int64_t n, int *__restrict__ flags, int *__restrict__ err) {
+  __shared__ double Rs[QTB_NB * QTB_NB];  // 128 KiB: column c at Rs[128 c ..]
+  __shared__ double part[4][QTB_NB];
+  __shared__ double ainv[QTB_NB];
+  const int t = threadIdx.x, r = t & 127, q = t >> 7;
+  const int64_t nblk = (n + QTB_NB - 1) / QTB_NB;
+  const int64_t s = nblk - 1 - (int64_t)blockIdx.x;
+  const int64_t row0 = s * QTB_NB;
+  const int hb = (int)((n - row0 < QTB_NB) ? n - row0 : QTB_NB);  // rows (= columns) of the own block
+  const bool rok = r < hb;
+  const int64_t ra = row0 + (rok ? r : 0);
+
+  // the first block to the right is requested before anything else
+  double cur[32], nxt[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) cur[c] = nxt[c] = 0.0;
+  auto load_block = [&](int64_t J, double (&dst)[32]) {
+    const int64_t c0 = J * QTB_NB + q * 32;
+    const int wj = (int)((n - c0 < 32) ? ((n - c0 > 0) ? n - c0 : 0) : 32);
+    const double *p = A + ra + ((wj > 0) ? c0 : 0) * lda;  // a column group beyond the matrix reads column 0 (times x = 0)
+#pragma unroll
+    for (int c = 0; c < 32; ++c) dst[c] = p[(int64_t)((c < wj) ? c : 0) * lda];
+  };
+  if (s + 1 < nblk) load_block(nblk - 1, cur);
+  // own diagonal block -> LDS, scaled; 1 / alpha by reciprocal + two Newton steps (dhqr_rcp)
+  if (t < QTB_NB) ainv[t] = (t < hb) ? dhqr_rcp(alpha[row0 + t]) : 1.0;
+  __syncthreads();
+  for (int e = t; e < QTB_NB * QTB_NB; e += BSP_THREADS) {
+    const int i = e & 127, c = e >> 7;
+    double v = 0.0;
+    if (i < c && c < hb) v = A[(row0 + i) + (row0 + c) * lda] * ainv[c];
+    Rs[e] = v;
+  }
+  double acc = 0.0;  // this thread's part of sum_J R[s, J] x_J (its 32 columns of every block)
+  for (int64_t J = nblk - 1; J > s; --J) {
+    if (J - 1 > s) load_block(J - 1, nxt);
+    if (t == 0) qtb_flag_wait(flags, (int)J, err);
+    __syncthreads();
+    const int64_t c0 = J * QTB_NB + q * 32;
+    const int wj = (int)((n - c0 < 32) ? ((n - c0 > 0) ? n - c0 : 0) : 32);
+    const double xv = ((t & 31) < wj) ? b[c0 + (t & 31)] : 0.0;  // lanes 0..31 / 32..63 of a wave hold the same 32 x
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc = fma(cur[c], qtb_lane_bcast(xv, c), acc);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) cur[c] = nxt[c];
+  }
+  part[q][r] = acc;
+  __syncthreads();  // also: Rs and ainv are complete
+  if (t < 64) {     // one wave: rows t and t + 64
+    double b0 = (t < hb) ? b[row0 + t] : 0.0, b1 = (t + 64 < hb) ? b[row0 + t + 64] : 0.0;
+    b0 -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    b1 -= (part[0][t + 64] + part[1][t + 64]) + (part[2][t + 64] + part[3][t + 64]);
+    for (int c = hb - 1; c >= 64; --c) {  // src:248-251, column-oriented
+      const double bc = qtb_lane_bcast(b1, c - 64);
+      b0 = fma(-Rs[c * QTB_NB + t], bc, b0);
+      b1 = fma(-Rs[c * QTB_NB + 64 + t], bc, b1);
+    }
+    for (int c = ((hb < 64) ? hb : 64) - 1; c >= 0; --c) {
+      const double bc = qtb_lane_bcast(b0, c);
+      b0 = fma(-Rs[c * QTB_NB + t], bc, b0);
+    }
+    // x_c = b_c / alpha_c: reciprocal product + one correction step (the quotient to within an ulp)
+    if (t < hb) {
+      const double al = alpha[row0 + t];
+      double x = b0 * ainv[t];
+      x = fma(fma(-al, x, b0), ainv[t], x);
+      b[row0 + t] = x;
+    }
+    if (t + 64 < hb) {
+      const double al = alpha[row0 + t + 64];
+      double x = b1 * ainv[t + 64];
+      x = fma(fma(-al, x, b1), ainv[t + 64], x);
+      b[row0 + t + 64] = x;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the wave's stores of x, then the flag
+    if (t == 0) __hip_atomic_store(flags + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}

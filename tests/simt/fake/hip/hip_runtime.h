@@ -288,6 +288,7 @@ inline long long wall_clock64() {
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
 #define __hip_atomic_fetch_max(p, v, order, scope) __atomic_fetch_max((p), (v), (order))
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
@@ -398,7 +399,7 @@ struct simt_event { double t_ms; };
 typedef simt_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
-struct hipDeviceProp_t { char gcnArchName[256]; };
+struct hipDeviceProp_t { char gcnArchName[256]; int multiProcessorCount; };
 
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emulated HIP error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
@@ -416,6 +417,7 @@ inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return 
 inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
   std::strcpy(p->gcnArchName, "gfx950:sramecc+:xnack-");  // what the emulated kernels are written for
+  p->multiProcessorCount = 256;
   return hipSuccess;
 }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
@@ -449,6 +451,7 @@ inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)std::malloc(8); return hipSuccess; }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)std::malloc(8); return hipSuccess; }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t, const uint32_t *) { *s = (hipStream_t)std::malloc(8); return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { std::free(s); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = -1; return hipSuccess; }

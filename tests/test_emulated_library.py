@@ -329,6 +329,36 @@ def test_solve_apply_q_and_residual_entry_points(emu, orc):
     emu.dhqr_destroy(h)
 
 
+@pytest.mark.parametrize("m,n,env", [(300, 200, {}), (520, 384, {}), (777, 130, {}), (260, 257, {"DHQR_QTB_VEC": 2}),
+                                     (1100, 1000, {"DHQR_QTB_VEC": 2}), (640, 128, {"DHQR_QTB_VEC": 1}), (70, 50, {}),
+                                     (129, 129, {})])
+def test_pipelined_solve_kernels(emu, orc, m, n, env):
+    """dhqr_solve_f64 through dhqr_qtb.h (batched Gram / T' pre-pass on the factor in place, one k_qtb_step launch per
+    panel with the last-workgroup reduction, the flag-pipelined back substitution) against the oracle's solve
+    (src:215-294) and against the round-1 path (DHQR_SOLVE_PIPE=0): partial last panel, odd heights, both load widths"""
+    A0 = orc.rand_matrix(m, n, 31)
+    Ho, ao = orc.householder(A0)
+    b = orc.rand_vector(m, 32)
+    xo = orc.solve(Ho, ao, b)
+    H = np.asfortranarray(Ho)
+    xs = []
+    for pipe in (1, 0):
+        h = _ctx(emu, DHQR_SOLVE_PIPE=pipe, **env)
+        bb = b.copy()
+        assert emu.dhqr_solve_f64(h, _ptr(H), m, n, m, _ptr(ao), _ptr(bb)) == 0, emu.dhqr_last_error()
+        assert emu.dhqr_synchronize(h) == 0, emu.dhqr_last_error()
+        assert np.abs(bb[:n] - xo).max() <= 1e-10 * np.abs(xo).max(), (pipe, np.abs(bb[:n] - xo).max())
+        if pipe and m > n:  # b <- Q'b below the triangle: rows n..m of the oracle's Q'b (the reference leaves them in b, src:284-294)
+            qtb = b.copy()
+            for j in range(n):
+                s = Ho[j:, j] @ qtb[j:]
+                qtb[j:] -= Ho[j:, j] * s
+            assert np.abs(bb[n:] - qtb[n:]).max() <= 1e-12 * max(1.0, np.abs(qtb).max())
+        xs.append(bb[:n].copy())
+        emu.dhqr_destroy(h)
+    assert np.abs(xs[0] - xs[1]).max() <= 1e-11 * np.abs(xo).max()
+
+
 def test_complex_entry_points(emu, orc):
     h = _ctx(emu)
     m, n = 150, 90

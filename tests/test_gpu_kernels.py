@@ -106,3 +106,82 @@ def test_microbenchmarks_report(pkg, torch_cuda):
     gb = pkg.bench_stream_gbps(1 << 30, 0)
     print(f"\nFP64 MFMA issue-bound: {tf:.1f} TFLOP/s; streaming copy: {gb:.0f} GB/s")
     assert tf > 20.0 and gb > 1000.0
+
+
+@pytest.mark.parametrize("m,n,vec", [(440, 400, 0), (1100, 1000, 2), (2207, 2000, 0), (4400, 4000, 1), (4400, 4000, 2),
+                                     (2048, 2048, 0), (3000, 129, 0), (20000, 640, 2), (130, 130, 0)])
+def test_pipelined_solve_vs_oracle_and_round1_path(pkg, orc, torch_cuda, m, n, vec, monkeypatch):
+    """dhqr_solve_f64 through dhqr_qtb.h (batched Gram / T' pre-pass in place, one k_qtb_step launch per panel, the
+    flag-pipelined back substitution) on the oracle's factor: x against the oracle's solve (src:215-294) and against the
+    round-1 path (DHQR_SOLVE_PIPE=0); rows n..m of b hold Q'b like the reference leaves them (src:284-294)"""
+    torch = torch_cuda
+    L = pkg._lib.lib()
+    A0 = orc.rand_matrix(m, n, 77)
+    Ho, ao = orc.householder(A0)
+    b = orc.rand_vector(m, 78)
+    xo = orc.solve(Ho, ao, b)
+    H = torch.tensor(np.asfortranarray(Ho).T.copy(), device="cuda:0").T  # column-major device copy
+    assert H.stride() == (1, m)
+    al = torch.tensor(ao, device="cuda:0")
+    xs = []
+    for pipe in (1, 0):
+        monkeypatch.setenv("DHQR_SOLVE_PIPE", str(pipe))
+        if vec:
+            monkeypatch.setenv("DHQR_QTB_VEC", str(vec))
+        ctx = pkg.Context(0)  # the switches are read by dhqr_create
+        bb = torch.tensor(b, device="cuda:0")
+        torch.cuda.synchronize()
+        pkg._lib.check(L.dhqr_solve_f64(ctx.handle, ctypes.c_void_p(H.data_ptr()), m, n, m, ctypes.c_void_p(al.data_ptr()),
+                                   ctypes.c_void_p(bb.data_ptr())))
+        ctx.synchronize()
+        got = bb.cpu().numpy()
+        assert np.abs(got[:n] - xo).max() <= 1e-9 * np.abs(xo).max(), (pipe, np.abs(got[:n] - xo).max())
+        xs.append(got)
+        ctx.close()
+    if m > n:
+        assert np.abs(xs[0][n:] - xs[1][n:]).max() <= 1e-11 * max(1.0, np.abs(xs[1]).max())
+    assert np.abs(xs[0][:n] - xs[1][:n]).max() <= 1e-10 * np.abs(xo).max()
+
+
+def test_expired_pipeline_wait_is_reported(pkg, orc, torch_cuda, monkeypatch):
+    """a hand-over wait that gives up lets its kernel finish with wrong numbers; the context's error word must
+    reach the caller.  DHQR_PIPE_SPIN_LIMIT=1 (read by dhqr_create) makes every inter-workgroup wait expire at once:
+    the ComplexF64 panel pipeline and the pipelined back substitution both have to report through dhqr_synchronize, and
+    the blocked Float64 driver through its own status read."""
+    torch = torch_cuda
+    L = pkg._lib.lib()
+    monkeypatch.setenv("DHQR_PIPE_SPIN_LIMIT", "1")
+    ctx = pkg.Context(0)
+    try:
+        # (1) k_backsub_pipe: 32 blocks, every workgroup but the first waits for its predecessors
+        m, n = 4400, 4096
+        A = pkg.rand_colmajor(m, n, 3, "cuda:0")
+        al = torch.ones(n, dtype=torch.float64, device="cuda:0")
+        bb = pkg.rand_vector_device(m, 4, "cuda:0")
+        torch.cuda.synchronize()
+        pkg._lib.check(L.dhqr_solve_f64(ctx.handle, ctypes.c_void_p(A.data_ptr()), m, n, m, ctypes.c_void_p(al.data_ptr()),
+                                   ctypes.c_void_p(bb.data_ptr())))
+        with pytest.raises(pkg.DHQRError) as e:
+            ctx.synchronize()
+        assert "pipeline" in str(e.value)
+        ctx.synchronize()  # the word is cleared once reported
+        # (2) k_zpanel_pipe (blocked ComplexF64, 64-column panels)
+        Z = torch.view_as_complex(pkg.rand_colmajor(2 * 1024, 512, 5, "cuda:0").T.contiguous().view(512, 1024, 2)).T
+        assert Z.stride() == (1, 1024)
+        za = torch.zeros(512, dtype=torch.complex128, device="cuda:0")
+        torch.cuda.synchronize()
+        pkg._lib.check(L.dhqr_factor_c64_nb(ctx.handle, ctypes.c_void_p(Z.data_ptr()), 1024, 512, 1024,
+                                       ctypes.c_void_p(za.data_ptr()), 64))
+        with pytest.raises(pkg.DHQRError):
+            ctx.synchronize()
+    finally:
+        ctx.close()
+    monkeypatch.delenv("DHQR_PIPE_SPIN_LIMIT")
+    ctx = pkg.Context(0)  # a fresh context waits again
+    try:
+        bb = pkg.rand_vector_device(m, 4, "cuda:0")
+        pkg._lib.check(L.dhqr_solve_f64(ctx.handle, ctypes.c_void_p(A.data_ptr()), m, n, m, ctypes.c_void_p(al.data_ptr()),
+                                   ctypes.c_void_p(bb.data_ptr())))
+        ctx.synchronize()
+    finally:
+        ctx.close()
