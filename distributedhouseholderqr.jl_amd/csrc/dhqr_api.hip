@@ -104,8 +104,6 @@ struct dhqr_ctx {
   std::vector<int> sv_units;                 // host copy of the Gram pre-pass unit table, valid for (sv_m, sv_n)
   int64_t sv_m = -1, sv_n = -1, sv_rps = 0;
   const int *sv_units_dev = nullptr;         // where the table was uploaded (nullptr: not yet / shape changed)
-  hipStream_t wide_masked = nullptr;  // the wide stream with wide_spare CUs masked out (dhqr_dist.h, cs_run)
-  int wide_spare = 0;    // DHQR_WIDE_SPARE: CUs the wide trailing updates leave free for the look-ahead lane
   int solve_pipe = 1;    // DHQR_SOLVE_PIPE=0: the round-1 solve (blocked apply on the MFMA kernels + 64-row back substitution)
   int qtb_vec = -1;      // DHQR_QTB_VEC=1/2: rows per lane of k_qtb_step (-1: by the matrix height)
   Buf host_mat;          // device copy of the caller's HOST matrix (+ alpha) of dhqr_qr_f64, kept between calls
@@ -1322,25 +1320,6 @@ static int32_t factor_blocked_simple(dhqr_ctx *c, double *dA, int64_t m, int64_t
   return DHQR_OK;
 }
 
-// A stream whose kernels may use every CU but c->wide_spare of them.  Mask bit i = CU i in the runtime's order, which
-// walks the XCDs first (bit i -> XCD i % 8): DHQR_WIDE_SPARE_STRIDE picks which bits are cleared (spare CU q = bit
-// q * stride), so 1 keeps them on consecutive XCDs, 8 on one XCD.
-static int32_t create_masked_stream(dhqr_ctx *c) {
-  hipDeviceProp_t prop;
-  HIPCHECK(hipGetDeviceProperties(&prop, c->device));
-  const int ncu = prop.multiProcessorCount;
-  std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-  for (int i = 0; i < ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-  int stride = 1;
-  if (const char *e = getenv("DHQR_WIDE_SPARE_STRIDE")) stride = std::max(1, atoi(e));
-  for (int q = 0; q < c->wide_spare; ++q) {
-    const int bit = (q * stride) % ncu;
-    mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
-  }
-  HIPCHECK(hipExtStreamCreateWithCUMask(&c->wide_masked, (uint32_t)mask.size(), mask.data()));
-  return DHQR_OK;
-}
-
 #include "dhqr_comm.h"
 #include "dhqr_hostio.h"
 #include "dhqr_dist.h"
@@ -1512,7 +1491,6 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     }
     if (const char *e = getenv("DHQR_ZPIPE")) c->zpipe = atoi(e) != 0;
     if (const char *e = getenv("DHQR_SOLVE_PIPE")) c->solve_pipe = atoi(e) != 0;
-    if (const char *e = getenv("DHQR_WIDE_SPARE")) c->wide_spare = atoi(e);
     if (const char *e = getenv("DHQR_QTB_VEC")) c->qtb_vec = atoi(e);
     hipLaunchKernelGGL(k_set_status, dim3(1), dim3(64), 0, c->stream, c->dstat, INT_MAX);
     LAUNCHCHECK();
@@ -1565,7 +1543,6 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
     if (e) (void)hipEventDestroy(e);
   if (c->hi) (void)hipStreamDestroy(c->hi);
   if (c->hi2) (void)hipStreamDestroy(c->hi2);
-  if (c->wide_masked) (void)hipStreamDestroy(c->wide_masked);
   if (c->own) (void)hipStreamDestroy(c->own);
   delete c;
   return DHQR_OK;

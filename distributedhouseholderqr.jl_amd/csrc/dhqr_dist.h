@@ -234,13 +234,7 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
   // its GPU's four hardware queues to itself and the chain it shortens is the critical path)
   const bool want_side = c->lane_side == 2 || (c->lane_side == 1 && P == 1);
   if (want_side && !c->hi2) HIPCHECK(hipStreamCreateWithPriority(&c->hi2, hipStreamNonBlocking, c->hi_priority));
-  // The wide stream (r5): with c->wide_spare > 0 the trailing updates run on a stream whose CU mask leaves that many CUs
-  // to everybody else -- the lane's single-workgroup kernels (k_panel_top, k_build_t: 1024 threads, ~140 KB of LDS) need
-  // an EMPTY CU, and a wide subtraction launch keeps two workgroups on every CU it may use until it has drained.
-  hipStream_t sCaller = c->stream;
-  if (c->wide_spare > 0 && !c->wide_masked) CHECK(create_masked_stream(c));
-  const bool masked = c->wide_spare > 0 && c->wide_masked != nullptr;
-  hipStream_t sW = masked ? c->wide_masked : c->stream, sL = c->hi, sC = S.comm, sX = want_side ? c->hi2 : nullptr;
+  hipStream_t sW = c->stream, sL = c->hi, sC = S.comm, sX = want_side ? c->hi2 : nullptr;
   // Lane side stream (r4): what needs a panel's V but not its T runs on sX beside the panel's second Gram product, k_build_t
   // and the commit -- Y = V_a' C_b for the pair's second panel, the pair's cross term V_b' V_a, the quad's V_2' V_1.  Only
   // for panels this rank factors itself on the asynchronous fast path (a received panel has no "V final" event).
@@ -459,10 +453,6 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
 
   auto body = [&]() -> int32_t {
     // order the lane and the comm stream after whatever the caller queued (e.g. the fill)
-    if (masked) {
-      HIPCHECK(hipEventRecord(S.ev_start, sCaller));
-      HIPCHECK(hipStreamWaitEvent(sW, S.ev_start, 0));
-    }
     HIPCHECK(hipEventRecord(S.ev_start, sW));
     HIPCHECK(hipStreamWaitEvent(sL, S.ev_start, 0));
     HIPCHECK(hipStreamWaitEvent(sC, S.ev_start, 0));
@@ -519,11 +509,6 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
   on(sW, 0);
   c->epoch = saved_epoch;
   if (rc == DHQR_OK) rc = status_read(c, failed);
-  if (masked) {  // the caller's stream owns the result
-    (void)hipEventRecord(S.ev_end, sW);
-    (void)hipStreamWaitEvent(sCaller, S.ev_end, 0);
-    on(sCaller, 0);
-  }
   return rc;
 }
 

@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void k_qtb_step(const double *__restrict__ A, 
       double acc[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
-      const double *Ac = A + ra + (cu + g * 32) * lda;
       const int jn = (wu - g * 32 < 32) ? wu - g * 32 : 32;  // this wave's columns inside the panel (wave-uniform)
+      const double *Ac = A + ra + (cu + (jn > 0 ? g * 32 : 0)) * lda;  // (a wave beyond a partial panel reads column cu, masked)
       if (!tail && r0 >= cu + QTB_NB && jn == 32) {          // below the top block: no masks
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -160,15 +160,27 @@ __global__ __launch_bounds__(256) void k_qtb_step(const double *__restrict__ A, 
             for (int e = 0; e < VEC; ++e) acc[e] = fma(v[q][e], wj, acc[e]);
           }
         }
-      } else {
-        for (int q = 0; q < jn; ++q) {
-          const int j = g * 32 + q;
-          const double wj = w_s[j];
+      } else {  // top block (R above the diagonal counts as zero), last rows, partial panel: every load is issued
+                // unconditionally at a clamped address, the selects follow (a loop of dependent load -> fma iterations
+                // cost one memory latency per column: 25 us per launch on the slab that holds the top block)
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            const bool ok = (r + e < m) && (r + e >= cu + j);  // rows of the top block above the diagonal hold R
-            const double x = Ac[(int64_t)q * lda + (ok ? (r + e - ra) : 0)];
-            acc[e] = fma(ok ? x : 0.0, wj, acc[e]);
+        for (int h = 0; h < 2; ++h) {
+          double v[16][VEC];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int qq = (h * 16 + q < jn) ? h * 16 + q : 0;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[q][e] = Ac[(int64_t)qq * lda + ((r + e < m) ? (r + e - ra) : 0)];
+          }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int j = g * 32 + h * 16 + q;
+            const double wj = w_s[j];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const bool ok = (h * 16 + q < jn) && (r + e < m) && (r + e >= cu + j);
+              acc[e] = fma(ok ? v[q][e] : 0.0, wj, acc[e]);
+            }
           }
         }
       }
@@ -188,8 +200,8 @@ __global__ __launch_bounds__(256) void k_qtb_step(const double *__restrict__ A, 
       }
     }
     if (dot && r0 + SS > cd) {
-      const double *Ac = A + ra + (cd + g * 32) * lda;
       const int jn = (wd - g * 32 < 32) ? wd - g * 32 : 32;
+      const double *Ac = A + ra + (cd + (jn > 0 ? g * 32 : 0)) * lda;
       if (!tail && r0 >= cd + QTB_NB && jn == 32) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -210,14 +222,21 @@ __global__ __launch_bounds__(256) void k_qtb_step(const double *__restrict__ A, 
         }
       } else {
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-          if (q < jn) {
-            const int j = g * 32 + q;
+        for (int h = 0; h < 2; ++h) {
+          double v[16][VEC];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int qq = (h * 16 + q < jn) ? h * 16 + q : 0;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[q][e] = Ac[(int64_t)qq * lda + ((r + e < m) ? (r + e - ra) : 0)];
+          }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int j = g * 32 + h * 16 + q;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-              const bool ok = (r + e < m) && (r + e >= cd + j);
-              const double x = Ac[(int64_t)q * lda + (ok ? (r + e - ra) : 0)];
-              yacc[q] = fma(ok ? x : 0.0, bv[e], yacc[q]);
+              const bool ok = (h * 16 + q < jn) && (r + e < m) && (r + e >= cd + j);
+              yacc[h * 16 + q] = fma(ok ? v[q][e] : 0.0, bv[e], yacc[h * 16 + q]);
             }
           }
         }
@@ -257,10 +276,16 @@ __global__ __launch_bounds__(256) void k_qtb_step(const double *__restrict__ A, 
     const int i = t & 127, h = t >> 7;
     const double *Tt = Tt_all + (int64_t)k * QTB_NB2 + i;
     double a0 = 0.0, a1 = 0.0;
-#pragma unroll 8
-    for (int j = 64 * h; j < 64 * h + 64; j += 2) {
-      a0 = fma(Tt[(int64_t)j * QTB_NB], y_s[0][j], a0);
-      a1 = fma(Tt[(int64_t)(j + 1) * QTB_NB], y_s[0][j + 1], a1);
+#pragma unroll
+    for (int jb = 0; jb < 64; jb += 16) {
+      double tv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) tv[u] = Tt[(int64_t)(64 * h + jb + u) * QTB_NB];
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) {
+        a0 = fma(tv[u], y_s[0][64 * h + jb + u], a0);
+        a1 = fma(tv[u + 1], y_s[0][64 * h + jb + u + 1], a1);
+      }
     }
     y_s[1][i] = 0.0;
     __syncthreads();
@@ -350,14 +375,30 @@ __global__ __launch_bounds__(BSP_THREADS) void k_backsub_pipe(const double *__re
     double b0 = (t < hb) ? b[row0 + t] : 0.0, b1 = (t + 64 < hb) ? b[row0 + t + 64] : 0.0;
     b0 -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
     b1 -= (part[0][t + 64] + part[1][t + 64]) + (part[2][t + 64] + part[3][t + 64]);
-    for (int c = hb - 1; c >= 64; --c) {  // src:248-251, column-oriented
-      const double bc = qtb_lane_bcast(b1, c - 64);
-      b0 = fma(-Rs[c * QTB_NB + t], bc, b0);
-      b1 = fma(-Rs[c * QTB_NB + 64 + t], bc, b1);
+    // src:248-251, column-oriented, 16 columns at a time: their entries come out of LDS first (independent of the chain),
+    // the chain itself is lane broadcast -> fma per column.  Columns >= hb of a partial block are zero in Rs.
+#pragma unroll 1
+    for (int cb = 112; cb >= 64; cb -= 16) {
+      double ra[16], rb[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        ra[u] = Rs[(cb + u) * QTB_NB + t];
+        rb[u] = Rs[(cb + u) * QTB_NB + 64 + t];
+      }
+#pragma unroll
+      for (int u = 15; u >= 0; --u) {
+        const double bc = qtb_lane_bcast(b1, cb + u - 64);
+        b0 = fma(-ra[u], bc, b0);
+        b1 = fma(-rb[u], bc, b1);
+      }
     }
-    for (int c = ((hb < 64) ? hb : 64) - 1; c >= 0; --c) {
-      const double bc = qtb_lane_bcast(b0, c);
-      b0 = fma(-Rs[c * QTB_NB + t], bc, b0);
+#pragma unroll 1
+    for (int cb = 48; cb >= 0; cb -= 16) {
+      double ra[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) ra[u] = Rs[(cb + u) * QTB_NB + t];
+#pragma unroll
+      for (int u = 15; u >= 0; --u) b0 = fma(-ra[u], qtb_lane_bcast(b0, cb + u), b0);
     }
     // x_c = b_c / alpha_c: reciprocal product + one correction step (the quotient to within an ulp)
     if (t < hb) {
