@@ -539,6 +539,79 @@ def also_unblocked(pkg, torch, ctx, dev, steps=3, warmup=1, n=8192):
             "reflectors_per_pass": 16.0 * sum((m - j) * (n - j - 1) for j in range(n)) * steps / st["bytes_rank1"] if st["bytes_rank1"] > 0 else None}
 
 
+def cpu_baseline_lapack_ls(timeout_s=150):
+    """LAPACK `qr!(A) \\ b` (geqrf + ormqr + trtrs) at the reference's seven shapes on the host cores -- the time
+    test/runtests.jl:55-56,87-89 divides by (oracle/lapack_ls_bench.py, in a subprocess; the shapes finished in time)."""
+    import subprocess
+    try:
+        p = subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "lapack_ls_bench.py")], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, text=True)
+        try:
+            so, _ = p.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            so, _ = p.communicate()
+        lines = [ln for ln in (so or "").splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": "no shape finished"}
+    except Exception as e:  # a reported baseline, never fatal
+        return {"error": repr(e)[:200]}
+
+
+def also_solve(pkg, torch, dev, lapack=True):
+    """SURVEY 8 f1, "device-side solve performance": (1) dhqr_solve_f64 (b <- Q'b + back substitution, csrc/dhqr_qtb.h) on
+    factors already in HBM: ms, algorithmic GB/s (one pass over V + one over R) and the fraction of the 8 TB/s roof;
+    (2) the expression the reference's test file times, `qr!(A) \\ b` on HOST arrays (test/runtests.jl:59,66), at its seven
+    shapes beside LAPACK's geqrf + ormqr + trtrs on the host cores -- the ratio test/runtests.jl:87-89 prints."""
+    import numpy as np
+    out = {"device_resident": [], "qr_ldiv_host_arrays": []}
+    for m, n in ((4400, 4000), (8192, 8192), (32768, 32768)):
+        A = pkg.rand_colmajor(m, n, 0, dev)
+        H = pkg.qr_(A, nb=128)
+        b = pkg.rand_vector_device(m, 1, dev)
+        x = pkg.ldiv(H, b)  # warm-up: workspaces
+        ts = []
+        for _ in range(5):
+            bb = b.clone()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            pkg.solve_householder_(bb, H.A, H.α)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ms = min(ts)
+        byts = 8.0 * (m * n - n * n / 2.0) + 4.0 * n * n
+        A0 = pkg.rand_colmajor(m, n, 0, dev)
+        ne = float((A0.T @ (A0 @ x - b)).norm() / (A0.T @ b).norm())
+        out["device_resident"].append({"m": m, "n": n, "ms": ms, "algorithmic_bytes": byts, "GBps": byts / ms / 1e6,
+                                       "frac_of_8TBps": byts / ms / 1e6 / 8000.0, "normal_eq_rel": ne})
+        del A, A0, H, b, x
+        torch.cuda.empty_cache()
+    lp = cpu_baseline_lapack_ls() if lapack else {}
+    lps = {(d["m"], d["n"]): d for d in lp.get("shapes", [])}
+    for m, n in ((110, 100), (220, 200), (440, 400), (880, 800), (1100, 1000), (2200, 2000), (4400, 4000)):
+        A0 = np.asfortranarray(pkg.rand_colmajor(m, n, 0, dev).cpu().numpy())  # the library's generator (= the LAPACK leg's inputs)
+        b0 = pkg.rand_vector_device(m, 1, dev).cpu().numpy()
+        best = None
+        for _ in range(3):
+            A = A0.copy(order="F")
+            t0 = time.perf_counter()
+            x = pkg.ldiv(pkg.qr_(A), b0)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        r = A0 @ x - b0
+        e = {"m": m, "n": n, "seconds": best, "normal_eq": float(np.linalg.norm(A0.T @ r))}
+        if (m, n) in lps:
+            e["lapack_seconds"] = lps[(m, n)]["seconds"]
+            e["times_longer_than_lapack"] = best / lps[(m, n)]["seconds"]
+            e["lapack_normal_eq"] = lps[(m, n)]["normal_eq"]
+        out["qr_ldiv_host_arrays"].append(e)
+    out["lapack_threads"] = lp.get("threads")
+    if "error" in lp:
+        out["lapack_error"] = lp["error"]
+    return {"config": {"workload": "solve: dhqr_solve_f64 on resident factors; qr!(A) \\ b on host arrays at the reference's seven shapes"},
+            **out}
+
+
 def host_in_out(pkg, torch, dev, m, n, reps=2):
     """the PCIe-inclusive drop-in call `qr!(A::Matrix)` = dhqr_qr_f64 on a HOST matrix (pageable numpy memory, as a Julia
     Matrix would be): staged upload, factorisation, every column block downloaded behind its panel's commit
@@ -867,7 +940,8 @@ def main():
             # the other single-GPU configurations of BASELINE.json, driver-timed in the same run (a few seconds each)
             out["also"] = []
             for what, fn in (("unblocked 8192^2", lambda: also_unblocked(pkg, torch, ctx, dev)),
-                             ("row split 262144x4096", lambda: also_tallskinny(pkg, torch))):
+                             ("row split 262144x4096", lambda: also_tallskinny(pkg, torch)),
+                             ("solve", lambda: also_solve(pkg, torch, dev, lapack=not args.no_cpu_baseline))):
                 try:
                     progress(f"also: {what}")
                     out["also"].append(fn())

@@ -4,6 +4,7 @@
 #include <chrono>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdarg>
@@ -106,6 +107,8 @@ struct dhqr_ctx {
   const int *sv_units_dev = nullptr;         // where the table was uploaded (nullptr: not yet / shape changed)
   int solve_pipe = 1;    // DHQR_SOLVE_PIPE=0: the round-1 solve (blocked apply on the MFMA kernels + 64-row back substitution)
   int qtb_vec = -1;      // DHQR_QTB_VEC=1/2: rows per lane of k_qtb_step (-1: by the matrix height)
+  int qtb_persist = -1;  // DHQR_QTB_PERSIST=0/1: one launch per panel step / the persistent kernel (-1: persistent when safe)
+  bool coop = false;     // the device runs cooperative (all-resident) launches: false on the CPU emulator
   Buf host_mat;          // device copy of the caller's HOST matrix (+ alpha) of dhqr_qr_f64, kept between calls
   int pair = 1;                  // 1: wide updates apply two panels per pass (DHQR_PAIR=0 disables)
   int64_t pair_min_n = 12288;    // below this the longer look-ahead lane of the pair driver costs more than it saves (profiles/r02_ab_pair_tail_and_threshold.txt)
@@ -161,6 +164,10 @@ static int32_t ensure(dhqr_ctx *c, Buf &b, size_t need) {
   b.cap = need;
   return DHQR_OK;
 }
+
+// contexts alive per device in this process: kernels whose workgroups wait for each other in both directions (k_qtb_persist)
+// are only launched while a context has its device to itself -- two such launches could each hold slots the other needs
+static std::atomic<int> g_live_ctx[64];
 
 static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -1436,6 +1443,8 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
                    prop.gcnArchName);
   dhqr_ctx *c = new dhqr_ctx();
   c->device = device;
+  c->coop = prop.cooperativeLaunch != 0;
+  g_live_ctx[device & 63].fetch_add(1);
   memset(&c->st, 0, sizeof(c->st));
   auto init = [&]() -> int32_t {  // any failure below releases what was created so far (dhqr_destroy)
     HIPCHECK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
@@ -1492,6 +1501,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_ZPIPE")) c->zpipe = atoi(e) != 0;
     if (const char *e = getenv("DHQR_SOLVE_PIPE")) c->solve_pipe = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QTB_VEC")) c->qtb_vec = atoi(e);
+    if (const char *e = getenv("DHQR_QTB_PERSIST")) c->qtb_persist = atoi(e) != 0;
     hipLaunchKernelGGL(k_set_status, dim3(1), dim3(64), 0, c->stream, c->dstat, INT_MAX);
     LAUNCHCHECK();
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -1518,6 +1528,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
 
 int32_t dhqr_destroy(dhqr_ctx *c) {
   if (!c) return DHQR_OK;
+  g_live_ctx[c->device & 63].fetch_sub(1);
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   (void)hipDeviceSynchronize();
@@ -1766,21 +1777,23 @@ static int32_t solve_pipelined(dhqr_ctx *c, const double *dA, int64_t m, int64_t
   const int nunits = c->sv_units[(size_t)np];
   const int VEC = (c->qtb_vec == 1 || !vec) ? 1 : (c->qtb_vec == 2 ? 2 : (m >= 16384 ? 2 : 1));
   const int64_t SS = 64 * VEC;
-  const int64_t sl = SS * ((m + SS * 512 - 1) / (SS * 512));
+  const int64_t maxsl = std::max<int64_t>(8, std::min<int64_t>(c->ncu, 256));  // slabs = workgroups: at most one per CU
+  const int64_t sl = SS * ((m + SS * maxsl - 1) / (SS * maxsl));
   const int64_t nsl = (m + sl - 1) / sl;
   CHECK(ensure(c, c->sv_T, (size_t)np * QTB_NB2));
   CHECK(ensure(c, c->sv_S, (size_t)np * QTB_NB2));
   CHECK(ensure(c, c->sv_part, (size_t)nunits * QTB_NB2));
-  const size_t n_ypart = (size_t)nsl * QTB_NB, n_w = (size_t)(np + 1) * QTB_NB;
-  const size_t n_ints = (size_t)(np + 1) + (size_t)(np + 1) + (size_t)np;  // unit table | arrival counters | block flags
+  const size_t n_ypart = (size_t)std::max<int64_t>(nsl, (m + 63) / 64) * QTB_NB, n_w = (size_t)(np + 1) * QTB_NB;
+  const size_t n_ints = 3 * (size_t)(np + 1) + (size_t)np;  // unit table | arrival counters | w flags | block flags
   CHECK(ensure(c, c->sv_small, n_ypart + n_w + (n_ints + 1) / 2 + 16));
   double *ypart = c->sv_small.p, *wbuf = ypart + n_ypart;
-  int *units = reinterpret_cast<int *>(wbuf + n_w), *counter = units + (np + 1), *flags = counter + (np + 1);
+  int *units = reinterpret_cast<int *>(wbuf + n_w), *counter = units + (np + 1), *wflag = counter + (np + 1),
+      *flags = wflag + (np + 1);
   if (c->sv_units_dev != units) {  // the table stays on the device between calls on the same shape
     HIPCHECK(hipMemcpyAsync(units, c->sv_units.data(), (size_t)(np + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
     c->sv_units_dev = units;
   }
-  HIPCHECK(hipMemsetAsync(counter, 0, (size_t)(2 * np + 1) * sizeof(int), c->stream));
+  HIPCHECK(hipMemsetAsync(counter, 0, (size_t)(3 * np + 2) * sizeof(int), c->stream));
   // ---- pre-pass (independent of b): S_k = V_k'V_k, T_k' = (I + striu(S_k))^{-T}
   if (vec)
     hipLaunchKernelGGL((k_gemm_tn_gram_batch<2>), dim3((unsigned)nunits), dim3(256), 0, c->stream, dA, lda, m, n, c->sv_rps,
@@ -1791,16 +1804,32 @@ static int32_t solve_pipelined(dhqr_ctx *c, const double *dA, int64_t m, int64_t
   hipLaunchKernelGGL(k_qtb_sum_gram, dim3((unsigned)np, 16), dim3(256), 0, c->stream, (const double *)c->sv_part.p,
                      (const int *)units, n, c->sv_S.p);
   hipLaunchKernelGGL(k_build_t_batch, dim3((unsigned)np), dim3(1024), 0, c->stream, (const double *)c->sv_S.p, n, c->sv_T.p);
-  // ---- b <- Q'b (src:215-242): launch k updates by panel k-1 and forms the dots of panel k
-  for (int k = 0; k <= np; ++k) {
-    const int64_t rfirst = (int64_t)(k >= 1 ? k - 1 : 0) * DHQR_NBV;
-    const unsigned grid = (unsigned)(nsl - rfirst / sl);
-    if (VEC == 2)
-      hipLaunchKernelGGL((k_qtb_step<2>), dim3(grid), dim3(256), 0, c->stream, dA, lda, m, n, k, np, sl, db,
-                         (const double *)c->sv_T.p, wbuf, ypart, counter);
+  // ---- b <- Q'b (src:215-242): panel step k updates by panel k-1 and forms the dots of panel k.  One persistent launch
+  // when every workgroup is certain to be resident (one per CU at most, this context alone on the device, a real device:
+  // the CPU emulator runs workgroups one after the other and reports no cooperative launch), else one launch per step.
+  int *err = c->zflags + DHQR_PIPE_ERR_OFFSET;
+  const bool persist = c->qtb_persist == 1 || (c->qtb_persist < 0 && c->coop && g_live_ctx[c->device & 63].load() == 1);
+  // persistent form: one 64 VEC-row slab per workgroup (VEC = 1 with 4 waves up to 64 rows x #CU, VEC = 2 with 8 waves beyond)
+  const int pVEC = (!vec || m <= 64 * (int64_t)c->ncu) ? 1 : 2;
+  const int64_t pnsl = (m + 64 * pVEC - 1) / (64 * pVEC);
+  if (persist && pnsl <= (int64_t)c->ncu && c->qtb_vec <= 0) {
+    if (pVEC == 2)
+      hipLaunchKernelGGL((k_qtb_persist<2, 8>), dim3((unsigned)pnsl), dim3(512), 0, c->stream, dA, lda, m, n, np, db,
+                         (const double *)c->sv_T.p, wbuf, ypart, counter, wflag, err);
     else
-      hipLaunchKernelGGL((k_qtb_step<1>), dim3(grid), dim3(256), 0, c->stream, dA, lda, m, n, k, np, sl, db,
-                         (const double *)c->sv_T.p, wbuf, ypart, counter);
+      hipLaunchKernelGGL((k_qtb_persist<1, 4>), dim3((unsigned)pnsl), dim3(256), 0, c->stream, dA, lda, m, n, np, db,
+                         (const double *)c->sv_T.p, wbuf, ypart, counter, wflag, err);
+  } else {
+    for (int k = 0; k <= np; ++k) {
+      const int64_t rfirst = (int64_t)(k >= 1 ? k - 1 : 0) * DHQR_NBV;
+      const unsigned grid = (unsigned)(nsl - rfirst / sl);
+      if (VEC == 2)
+        hipLaunchKernelGGL((k_qtb_step<2>), dim3(grid), dim3(256), 0, c->stream, dA, lda, m, n, k, np, sl, db,
+                           (const double *)c->sv_T.p, wbuf, ypart, counter, err);
+      else
+        hipLaunchKernelGGL((k_qtb_step<1>), dim3(grid), dim3(256), 0, c->stream, dA, lda, m, n, k, np, sl, db,
+                           (const double *)c->sv_T.p, wbuf, ypart, counter, err);
+    }
   }
   // ---- back substitution (src:244-282): one pipelined launch
   hipLaunchKernelGGL(k_backsub_pipe, dim3((unsigned)np), dim3(BSP_THREADS), 0, c->stream, dA, lda, dalpha, db, n, flags,

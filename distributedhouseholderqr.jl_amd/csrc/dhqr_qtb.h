@@ -89,37 +89,72 @@ __device__ __forceinline__ double qtb_wave_reduce32(double (&y)[32], int lane) {
   return y[0] + __shfl_xor(y[0], 1, 64);
 }
 
-// One panel step of b <- Q'b (file header).  k = 0 .. np (np = number of panels): update by panel k-1 (k >= 1), partial
-// dots of panel k (k < np), w_k by the last workgroup.  Slabs are `sl` global rows (multiple of 64 VEC); workgroup x of
-// launch k owns slab floor(first active row / sl) + x.  256 threads: wave g takes the panel's columns 32 g .. 32 g + 31,
-// lane l the rows r0 + VEC l .. of every 64 VEC-row sub-slab.  VEC = 2: 16-byte loads (lda, m even, 16-byte aligned A, b).
-// ypart: gridDim.x x 128 partial dots of this launch; counter[k]: arrivals (zeroed before the first launch).
+// ---- b <- Q'b (file header) --------------------------------------------------------------------------------------------
+// Shared memory of the Q'b kernels.  Tp: T_k' packed by columns (column j holds rows j .. 127 at Tp[j * 128 - j (j - 1) / 2 ..]),
+// staged by the reducing workgroup BEFORE its own slab work so that the w_k = T_k' y_k product at the end of a panel step --
+// on the critical chain of every step -- reads LDS instead of waiting for 128 KB from the other end of the chip.
+#define QTB_TP_ELEMS (QTB_NB * (QTB_NB + 1) / 2)
 template <int VEC>
-__global__ __launch_bounds__(256) void k_qtb_step(const double *__restrict__ A, int64_t lda, int64_t m, int64_t n, int k,
-                                                  int np, int64_t sl, double *__restrict__ b,
-                                                  const double *__restrict__ Tt_all, double *__restrict__ wbuf,
-                                                  double *__restrict__ ypart, int *__restrict__ counter) {
+struct qtb_lds {
+  double w_s[QTB_NB];
+  double red[2][4][64 * VEC];
+  double y_s[2][QTB_NB];
+  double Tp[QTB_TP_ELEMS];
+};
+__device__ __forceinline__ int qtb_tp_off(int j) { return j * QTB_NB - (j * (j - 1)) / 2; }
+
+// Bounded wait (one thread): until *word >= want.  Relaxed polls + one acquire fence; an expired wait sets the context's
+// pipeline error word (err[0]; err[1] = the poll bound, DHQR_PIPE_LIMIT_OFFSET).
+__device__ __forceinline__ void qtb_wait_ge(int *word, int want, int *err) {
+  int spins = 0;
+  const int limit = err[1];
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > limit) {
+      __hip_atomic_store(err, 0x7ffffffe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// T_k' (dense, column-major, lower triangular) -> L.Tp (all 256 threads; the caller's next barrier publishes it)
+template <int VEC>
+__device__ __forceinline__ void qtb_stage_t(const double *__restrict__ Tt, qtb_lds<VEC> &L) {
+  const int t = threadIdx.x, i = t & 127, h = t >> 7;
+#pragma unroll 1
+  for (int ub = 0; ub < 64; ub += 32) {  // 32 loads in flight per thread, then their LDS stores: two memory latencies
+    double tv[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) tv[u] = Tt[i + (2 * (ub + u) + h) * QTB_NB];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const int j = 2 * (ub + u) + h;
+      if (i >= j) L.Tp[qtb_tp_off(j) + i - j] = tv[u];
+    }
+  }
+}
+
+// The slab phase of panel step k for rows [r_lo, r_hi) (r_lo a multiple of 64 VEC, >= the step's first active row):
+// (a) k >= 1: b -= V_{k-1} w_{k-1} (w in L.w_s), (b) k < np: this slab's partial dots of panel k -> yrow[0..128).
+// 256 threads: wave g takes the panel's columns 32 g .. 32 g + 31, lane l the rows r0 + VEC l .. of every 64 VEC-row
+// sub-slab.  VEC = 2: 16-byte loads (lda, m even, 16-byte aligned A, b).
+template <int VEC>
+__device__ __forceinline__ void qtb_slab_phase(const double *__restrict__ A, int64_t lda, int64_t m, int64_t n, int k, int np,
+                                               int64_t r_lo, int64_t r_hi, double *__restrict__ b, qtb_lds<VEC> &L,
+                                               double *__restrict__ yrow, int &par) {
   constexpr int SS = 64 * VEC;
-  __shared__ double w_s[QTB_NB];
-  __shared__ double red[2][4][SS];
-  __shared__ double y_s[2][QTB_NB];
-  __shared__ int last_s;
+  double (&w_s)[QTB_NB] = L.w_s;
+  double (&red)[2][4][SS] = L.red;
   const int t = threadIdx.x, lane = t & 63, g = t >> 6;
   const bool upd = k >= 1, dot = k < np;
   const int64_t cu = (int64_t)(k - 1) * QTB_NB;  // first column (= first row) of the panel that updates
   const int64_t cd = (int64_t)k * QTB_NB;        // ... of the panel whose dot products are formed
   const int wu = upd ? (int)((n - cu < QTB_NB) ? n - cu : QTB_NB) : 0;
   const int wd = dot ? (int)((n - cd < QTB_NB) ? n - cd : QTB_NB) : 0;
-  const int64_t rfirst = upd ? cu : cd;
-  const int64_t slab = rfirst / sl + blockIdx.x;
-  const int64_t r_lo = (slab * sl > rfirst) ? slab * sl : rfirst;
-  const int64_t r_hi = ((slab + 1) * sl < m) ? (slab + 1) * sl : m;
-  if (upd && t < QTB_NB) w_s[t] = wbuf[(int64_t)(k - 1) * QTB_NB + t];
-  __syncthreads();
   double yacc[32];
 #pragma unroll
   for (int q = 0; q < 32; ++q) yacc[q] = 0.0;
-  int par = 0;
   for (int64_t r0 = r_lo; r0 < r_hi; r0 += SS) {
     const int64_t r = r0 + (int64_t)lane * VEC;
     const int64_t ra = (r + VEC <= m) ? r : (m - VEC);  // address row: never beyond the matrix (values masked below)
@@ -244,54 +279,291 @@ __global__ __launch_bounds__(256) void k_qtb_step(const double *__restrict__ A, 
     }
   }
   if (!dot) return;
+  const double tot = qtb_wave_reduce32(yacc, lane);
+  if ((lane & 1) == 0) yrow[g * 32 + qtb_red_index(lane)] = tot;
+}
+
+// The reducing workgroup's part of panel step k: y_k = the sum of the ns slabs' partial dots in slab order (two interleaved
+// halves, then the halves), w_k = T_k' y_k out of L.Tp -> wk[0..128).  All 256 threads; ypart rows are 128 doubles.
+template <int VEC>
+__device__ __forceinline__ void qtb_reduce_phase(const double *__restrict__ ypart, int ns, qtb_lds<VEC> &L,
+                                                 double *__restrict__ wk) {
+  const int t = threadIdx.x, i = t & 127, h = t >> 7;
   {
-    const double tot = qtb_wave_reduce32(yacc, lane);
-    if ((lane & 1) == 0) ypart[(int64_t)blockIdx.x * QTB_NB + g * 32 + qtb_red_index(lane)] = tot;
-  }
-  __syncthreads();  // every wave's partial dots are stored (the barrier waits for the stores)
-  if (t == 0) {
-    const int prev = __hip_atomic_fetch_add(counter + k, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    last_s = (prev == (int)gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!last_s) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  {  // y_k: the slabs' partial dots in slab order (two interleaved halves, then the halves)
-    const int j = t & 127, h = t >> 7;
-    const int ns = (int)gridDim.x;
     double s = 0.0;
     int q = h;
     for (; q + 6 < ns; q += 8) {
-      const double a0 = ypart[(int64_t)q * QTB_NB + j], a1 = ypart[(int64_t)(q + 2) * QTB_NB + j];
-      const double a2 = ypart[(int64_t)(q + 4) * QTB_NB + j], a3 = ypart[(int64_t)(q + 6) * QTB_NB + j];
+      const double a0 = ypart[(int64_t)q * QTB_NB + i], a1 = ypart[(int64_t)(q + 2) * QTB_NB + i];
+      const double a2 = ypart[(int64_t)(q + 4) * QTB_NB + i], a3 = ypart[(int64_t)(q + 6) * QTB_NB + i];
       s += a0; s += a1; s += a2; s += a3;
     }
-    for (; q < ns; q += 2) s += ypart[(int64_t)q * QTB_NB + j];
-    y_s[h][j] = s;
+    for (; q < ns; q += 2) s += ypart[(int64_t)q * QTB_NB + i];
+    L.y_s[h][i] = s;
   }
   __syncthreads();
-  if (t < QTB_NB) y_s[0][t] += y_s[1][t];
+  if (t < QTB_NB) L.y_s[0][t] += L.y_s[1][t];
   __syncthreads();
-  {  // w_k = T_k' y_k: thread (i, h) sums columns 64 h .. 64 h + 63 of row i (T' is lower triangular: zeros beyond i)
-    const int i = t & 127, h = t >> 7;
-    const double *Tt = Tt_all + (int64_t)k * QTB_NB2 + i;
-    double a0 = 0.0, a1 = 0.0;
+  // thread (i, h): columns j = h, h + 2, ... <= i of row i (src:218-221 for the panel's 128 reflectors at once)
+  double a0 = 0.0;
+  for (int j = h; j <= i; j += 2) a0 = fma(L.Tp[qtb_tp_off(j) + i - j], L.y_s[0][j], a0);
+  if (h == 1) L.y_s[1][i] = a0;
+  __syncthreads();
+  if (h == 0) wk[i] = a0 + L.y_s[1][i];
+}
+
+// Row slabs of the Q'b kernels: `sl` rows (a multiple of 64 VEC); panel step k touches the slabs from floor(rfirst / sl) on,
+// rfirst = the first row of panel k-1 (k >= 1: its update) or 0.
+__device__ __forceinline__ int64_t qtb_rfirst(int k) { return (int64_t)(k >= 1 ? k - 1 : 0) * QTB_NB; }
+
+// One launch per panel step k = 0 .. np (the form the CPU emulator runs, and the fallback when several contexts share a
+// device: no workgroup of it waits for a HIGHER-indexed one).  Workgroup x owns slab floor(rfirst / sl) + x; the LAST
+// workgroup reduces: it stages T_k' first, does its slab, waits until the others have arrived (counter[k], one release
+// increment each), sums and writes w_k.  ypart: gridDim.x x 128; counter zeroed before the first launch.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_qtb_step(const double *__restrict__ A, int64_t lda, int64_t m, int64_t n, int k,
+                                                  int np, int64_t sl, double *__restrict__ b,
+                                                  const double *__restrict__ Tt_all, double *__restrict__ wbuf,
+                                                  double *__restrict__ ypart, int *__restrict__ counter,
+                                                  int *__restrict__ err) {
+  __shared__ qtb_lds<VEC> L;
+  const int t = threadIdx.x;
+  const bool dot = k < np, reducer = dot && blockIdx.x == gridDim.x - 1;
+  const int64_t rfirst = qtb_rfirst(k);
+  const int64_t slab = rfirst / sl + blockIdx.x;
+  const int64_t r_lo = (slab * sl > rfirst) ? slab * sl : rfirst;
+  const int64_t r_hi = ((slab + 1) * sl < m) ? (slab + 1) * sl : m;
+  if (reducer) qtb_stage_t<VEC>(Tt_all + (int64_t)k * QTB_NB2, L);
+  if (k >= 1 && t < QTB_NB) L.w_s[t] = wbuf[(int64_t)(k - 1) * QTB_NB + t];
+  __syncthreads();
+  int par = 0;
+  qtb_slab_phase<VEC>(A, lda, m, n, k, np, r_lo, r_hi, b, L, ypart + (int64_t)blockIdx.x * QTB_NB, par);
+  if (!dot) return;
+  __syncthreads();  // every wave's partial dots are stored (the barrier waits for the stores)
+  if (!reducer) {
+    if (t == 0) __hip_atomic_fetch_add(counter + k, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (t == 0) qtb_wait_ge(counter + k, (int)gridDim.x - 1, err);
+  __syncthreads();
+  qtb_reduce_phase<VEC>(ypart, (int)gridDim.x, L, wbuf + (int64_t)k * QTB_NB);
+}
+
+// ---- the same panel steps in ONE launch ----------------------------------------------------------------------------------
+// Workgroup s owns the 64 VEC rows of slab s for the whole of Q'b and retires when the panels have moved below it; the last
+// workgroup (the bottom slab, active to the end) also reduces every step and publishes w_k by raising wflag[k].  What this
+// form buys over one launch per step (measured with time stamps in the kernel, 8192^2: 20 us per step before, see DESIGN):
+//   * a workgroup's operands never leave its registers: its rows of b stay in bv, and the slab of V_k it loads for the dot
+//     products of step k IS the update operand of step k + 1 -- every element of V crosses the memory system ONCE;
+//   * the loads of step k's slab are issued BEFORE the wait for w_{k-1}, so the chain per step is flag -> w (128 doubles)
+//     -> 2 x CPW fma per lane -> LDS sum -> partial dots -> arrive; the reducer's T_k' loads are in flight while the last
+//     workgroups arrive, its gather of the partial dots is one batch of loads.
+// The workgroups wait for each other in BOTH directions (everybody for the reducer's w, the reducer for everybody's
+// arrival), so all of them must be resident: the host launches at most one workgroup per CU, and only while this context
+// has the device to itself (dhqr_api.hip).  NW waves per workgroup: wave g takes the panel's columns CPW g .. CPW g + CPW - 1.
+template <int NW>
+struct qtbp_lds {
+  double w_s[QTB_NB];
+  double red[2][NW][128];   // [parity][wave][row of the slab] (64 VEC <= 128 rows)
+  double y4[NW][QTB_NB];
+  double y_s[QTB_NB];
+};
+template <int N>
+__device__ __forceinline__ double qtb_wave_reduce_n(double (&y)[N], int lane);
+template <>
+__device__ __forceinline__ double qtb_wave_reduce_n<32>(double (&y)[32], int lane) { return qtb_wave_reduce32(y, lane); }
+// 16 values: four halvings, then the two remaining lane bits (index = bits 5..2 of the lane)
+template <>
+__device__ __forceinline__ double qtb_wave_reduce_n<16>(double (&y)[16], int lane) {
+#define QTB_HALVE(N_, BIT_)                                                  \
+  {                                                                          \
+    const bool up = (lane & (BIT_)) != 0;                                    \
+    _Pragma("unroll") for (int q = 0; q < (N_); ++q) {                       \
+      const double keep = up ? y[q + (N_)] : y[q];                           \
+      const double send = up ? y[q] : y[q + (N_)];                           \
+      y[q] = keep + __shfl_xor(send, (BIT_), 64);                            \
+    }                                                                        \
+  }
+  QTB_HALVE(8, 32)
+  QTB_HALVE(4, 16)
+  QTB_HALVE(2, 8)
+  QTB_HALVE(1, 4)
+#undef QTB_HALVE
+  double v = y[0] + __shfl_xor(y[0], 2, 64);
+  return v + __shfl_xor(v, 1, 64);
+}
+template <int N>
+__device__ __forceinline__ int qtb_red_index_n(int lane) {
+  if constexpr (N == 32) return qtb_red_index(lane);
+  return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+}
+
+template <int VEC, int NW>
+__global__ __launch_bounds__(64 * NW) void k_qtb_persist(const double *__restrict__ A, int64_t lda, int64_t m, int64_t n,
+                                                         int np, double *__restrict__ b, const double *__restrict__ Tt_all,
+                                                         double *__restrict__ wbuf, double *__restrict__ ypart,
+                                                         int *__restrict__ counter, int *__restrict__ wflag,
+                                                         int *__restrict__ err) {
+  constexpr int SS = 64 * VEC, CPW = QTB_NB / NW, NT = 64 * NW;
+  __shared__ qtbp_lds<NW> L;
+  const int t = threadIdx.x, lane = t & 63, g = t >> 6;
+  const int64_t slab = blockIdx.x, nsl = gridDim.x;
+  const bool reducer = slab == nsl - 1;
+  const int64_t s_lo = slab * SS, s_hi = (s_lo + SS < m) ? s_lo + SS : m;
+  const int64_t r = s_lo + (int64_t)lane * VEC;
+  const int64_t ra = (r + VEC <= m) ? r : (m - VEC);  // address row, never beyond the matrix (values masked at use)
+  double bv[VEC], va[CPW][VEC], vb[CPW][VEC];
 #pragma unroll
-    for (int jb = 0; jb < 64; jb += 16) {
-      double tv[16];
+  for (int e = 0; e < VEC; ++e) bv[e] = (r + e < m) ? b[r + e] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) tv[u] = Tt[(int64_t)(64 * h + jb + u) * QTB_NB];
+  for (int q = 0; q < CPW; ++q)
 #pragma unroll
-      for (int u = 0; u < 16; u += 2) {
-        a0 = fma(tv[u], y_s[0][64 * h + jb + u], a0);
-        a1 = fma(tv[u + 1], y_s[0][64 * h + jb + u + 1], a1);
+    for (int e = 0; e < VEC; ++e) va[q][e] = vb[q][e] = 0.0;
+  int par = 0;
+  for (int k = 0; k <= np; ++k) {
+    const int64_t rfirst = qtb_rfirst(k);
+    if (s_hi <= rfirst) return;  // the panels have moved below this slab
+    const int64_t first_slab = rfirst / SS;
+    const bool upd = k >= 1, dot = k < np;
+    const int64_t cu = (int64_t)(k - 1) * QTB_NB, cd = (int64_t)k * QTB_NB;
+    const int wu = upd ? (int)((n - cu < QTB_NB) ? n - cu : QTB_NB) : 0;
+    const int wd = dot ? (int)((n - cd < QTB_NB) ? n - cd : QTB_NB) : 0;
+    const bool dots_here = dot && s_hi > cd;  // (a slab that ends inside panel k-1's top block only takes the update)
+    // ---- this step's slab of V_k, requested before anything is waited for
+    if (dots_here) {
+      const int jn = (wd - g * CPW < CPW) ? wd - g * CPW : CPW;  // this wave's columns inside the panel (wave-uniform)
+      const double *Ac = A + ra + (cd + (jn > 0 ? g * CPW : 0)) * lda;
+#pragma unroll
+      for (int q = 0; q < CPW; ++q) {
+        const double *p = Ac + (int64_t)((q < jn) ? q : 0) * lda;
+        if constexpr (VEC == 2) {
+          const double2 x = *reinterpret_cast<const double2 *>(p);
+          vb[q][0] = x.x; vb[q][1] = x.y;
+        } else {
+          vb[q][0] = p[0];
+        }
       }
     }
-    y_s[1][i] = 0.0;
+    // ---- w_{k-1}
+    if (upd) {
+      if (!reducer) {  // (the reducer wrote w_{k-1} itself)
+        if (t == 0) qtb_wait_ge(wflag + (k - 1), 1, err);
+        __syncthreads();
+      }
+      if (t < QTB_NB) L.w_s[t] = wbuf[(int64_t)(k - 1) * QTB_NB + t];
+      __syncthreads();
+      // ---- b -= V_{k-1} w_{k-1} on this slab: va holds the slab of V_{k-1} loaded one step ago (src:219-221)
+      double acc[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
+#pragma unroll
+      for (int q = 0; q < CPW; ++q) {
+        const int j = g * CPW + q;
+        const double wj = L.w_s[j];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const bool ok = (j < wu) && (r + e < m) && (r + e >= cu + j);  // rows of the top block above the diagonal hold R
+          acc[e] = fma(ok ? va[q][e] : 0.0, wj, acc[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) L.red[par][g][lane * VEC + e] = acc[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += L.red[par][w][lane * VEC + e];
+        bv[e] -= sum;
+      }
+      par ^= 1;
+      if (g == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (r + e < m) b[r + e] = bv[e];
+      }
+    }
+    if (!dot) return;
+    // ---- partial dots of panel k on the rows just brought up to date (src:218)
+    double yq[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+      const int j = g * CPW + q;
+      double y = 0.0;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const bool ok = dots_here && (j < wd) && (r + e < m) && (r + e >= cd + j);
+        y = fma(ok ? vb[q][e] : 0.0, bv[e], y);
+      }
+      yq[q] = y;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) va[q][e] = vb[q][e];  // the update operand of the next step
+    }
+    {
+      const double tot = qtb_wave_reduce_n<CPW>(yq, lane);
+      const bool writer = (CPW == 32) ? ((lane & 1) == 0) : ((lane & 3) == 0);
+      if (writer) ypart[(slab - first_slab) * QTB_NB + g * CPW + qtb_red_index_n<CPW>(lane)] = tot;
+    }
+    __syncthreads();  // the partial dots are stored
+    if (!reducer) {
+      if (t == 0) __hip_atomic_fetch_add(counter + k, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    // ---- reducer: T_k' row pieces first (in flight while the last workgroups arrive), then the gather, then w_k = T_k' y_k
+    constexpr int NH = NT / QTB_NB, JW = QTB_NB / NH;  // thread (i, hh): row i, columns JW hh .. JW hh + JW - 1
+    const int i = t & 127, hh = t >> 7;
+    double tv[JW];
+    {
+      const double *Tt = Tt_all + (int64_t)k * QTB_NB2 + i + (int64_t)(JW * hh) * QTB_NB;
+#pragma unroll
+      for (int u = 0; u < JW; ++u) tv[u] = Tt[(int64_t)u * QTB_NB];
+    }
+    const int ns = (int)(nsl - first_slab);
+    if (t == 0) qtb_wait_ge(counter + k, ns - 1, err);
     __syncthreads();
-    if (h == 1) y_s[1][i] = a0 + a1;
+    {  // y_k: thread (columns 2 c2, 2 c2 + 1; row group rg): rows rg, rg + NW, ... in order, then the groups in order
+      const int c2 = t & 63, rg = t >> 6;
+      double s0 = 0.0, s1 = 0.0;
+      constexpr int PB = (NW == 8) ? 16 : 32;  // loads in flight per thread (512-thread workgroups have 256 registers a thread)
+      for (int q0 = rg; q0 < ns; q0 += PB * NW) {
+        double2 pv[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+          const int q = q0 + u * NW;
+          pv[u] = *reinterpret_cast<const double2 *>(ypart + (int64_t)((q < ns) ? q : rg) * QTB_NB + 2 * c2);
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u)
+          if (q0 + u * NW < ns) { s0 += pv[u].x; s1 += pv[u].y; }
+      }
+      L.y4[rg][2 * c2] = s0;
+      L.y4[rg][2 * c2 + 1] = s1;
+    }
     __syncthreads();
-    if (h == 0) wbuf[(int64_t)k * QTB_NB + i] = (a0 + a1) + y_s[1][i];
+    if (t < QTB_NB) {
+      double y = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) y += L.y4[w][t];
+      L.y_s[t] = y;
+    }
+    __syncthreads();
+    {
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int u = 0; u < JW; u += 2) {
+        a0 = fma(tv[u], L.y_s[JW * hh + u], a0);
+        a1 = fma(tv[u + 1], L.y_s[JW * hh + u + 1], a1);
+      }
+      L.y4[hh][i] = a0 + a1;  // (y4 is free again: every thread is past the sum above)
+    }
+    __syncthreads();
+    if (t < QTB_NB) {
+      double w = 0.0;
+#pragma unroll
+      for (int h2 = 0; h2 < NH; ++h2) w += L.y4[h2][t];
+      wbuf[(int64_t)k * QTB_NB + t] = w;
+    }
+    __syncthreads();  // w_k is stored by this workgroup's threads ...
+    if (t == 0) __hip_atomic_store(wflag + k, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // ... then the flag
   }
 }
 

@@ -399,7 +399,7 @@ struct simt_event { double t_ms; };
 typedef simt_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
-struct hipDeviceProp_t { char gcnArchName[256]; int multiProcessorCount; };
+struct hipDeviceProp_t { char gcnArchName[256]; int multiProcessorCount; int cooperativeLaunch; };
 
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emulated HIP error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
@@ -418,6 +418,7 @@ inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; 
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
   std::strcpy(p->gcnArchName, "gfx950:sramecc+:xnack-");  // what the emulated kernels are written for
   p->multiProcessorCount = 256;
+  p->cooperativeLaunch = 0;  // workgroups of a grid run one after the other here: nothing that needs all of them resident
   return hipSuccess;
 }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
