@@ -105,6 +105,15 @@ struct dhqr_ctx {
   std::vector<int> sv_units;                 // host copy of the Gram pre-pass unit table, valid for (sv_m, sv_n)
   int64_t sv_m = -1, sv_n = -1, sv_rps = 0;
   const int *sv_units_dev = nullptr;         // where the table was uploaded (nullptr: not yet / shape changed)
+  // kept T factors: a blocked single-GPU dhqr_factor_f64 leaves T_k' of every panel (and a copy of alpha) in the context;
+  // dhqr_solve_f64 on the same (dA, m, n, lda) whose alpha still equals that copy (checked on the device) skips its Gram /
+  // T' pre-pass.  tt_keep: where the panel being factored stores its T' (nullptr: nowhere).
+  Buf tc_T, tc_alpha;
+  double *tt_keep = nullptr, *tc_base = nullptr;
+  const double *tc_A = nullptr;
+  int64_t tc_m = 0, tc_n = 0, tc_lda = 0;
+  bool tc_valid = false;
+  int keep_t = 1;        // DHQR_KEEP_T=0: never keep / use them
   int solve_pipe = 1;    // DHQR_SOLVE_PIPE=0: the round-1 solve (blocked apply on the MFMA kernels + 64-row back substitution)
   int qtb_vec = -1;      // DHQR_QTB_VEC=1/2: rows per lane of k_qtb_step (-1: by the matrix height)
   int qtb_persist = -1;  // DHQR_QTB_PERSIST=0/1: one launch per panel step / the persistent kernel (-1: persistent when safe)
@@ -441,7 +450,8 @@ static inline void launch_recon_top(dhqr_ctx *c, const double *P, int64_t ldp, c
   hipLaunchKernelGGL(k_recon_top, dim3(1), dim3(1024), 0, c->stream, P, ldp, R, alpha, Rref, negMinv);
 }
 static inline void launch_build_t(dhqr_ctx *c, const double *S, int ncols, double *T, double *Tt) {
-  hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt, 0.0, (int *)nullptr, 0, (double *)nullptr);
+  hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, S, ncols, T, Tt, 0.0, (int *)nullptr, 0, (double *)nullptr,
+                     c->tt_keep);
 }
 
 // ---- where a factored panel's GEMM operands live --------------------------------------------------
@@ -958,7 +968,7 @@ static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t 
     CHECK(gram128(c, pb.V, ldv, rows, c->sfull.p));                                // S = V'V
     // T from S, fused with the acceptance decision (before the predicated commits)
     hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sfull.p, (int)DHQR_NBV, pb.T, pb.Tt,
-                       c->recon_tol, c->dstat, panel_idx, pb.alpha + DHQR_NBV);
+                       c->recon_tol, c->dstat, panel_idx, pb.alpha + DHQR_NBV, c->tt_keep);
     // commit (device-side predicate): reflectors, R, alpha in one launch; T is only ever read by accepted consumers
     dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
     hipLaunchKernelGGL(k_commit_panel, grid, dim3(256), 0, c->stream, P, ldp, rows, (const double *)pb.V, ldv, (const double *)Rref,
@@ -1321,7 +1331,10 @@ static int32_t factor_blocked_simple(dhqr_ctx *c, double *dA, int64_t m, int64_t
     const int64_t w = std::min<int64_t>(DHQR_NBV, n - c0), rows = m - c0;
     double *P = dA + c0 + c0 * lda;
     const PanelBuf pb = vt_view(c->vt.p, rows);
-    CHECK(factor_panel_sync(c, P, rows, w, lda, dalpha + c0, pb));
+    c->tt_keep = c->tc_base ? c->tc_base + (c0 / DHQR_NBV) * (int64_t)(DHQR_NBV * DHQR_NBV) : nullptr;
+    const int32_t rc = factor_panel_sync(c, P, rows, w, lda, dalpha + c0, pb);
+    c->tt_keep = nullptr;
+    CHECK(rc);
     if (c0 + w < n) CHECK(panel_apply(c, pb, rows, dA + c0 + (c0 + w) * lda, n - c0 - w, lda, 1));
   }
   return DHQR_OK;
@@ -1500,6 +1513,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     }
     if (const char *e = getenv("DHQR_ZPIPE")) c->zpipe = atoi(e) != 0;
     if (const char *e = getenv("DHQR_SOLVE_PIPE")) c->solve_pipe = atoi(e) != 0;
+    if (const char *e = getenv("DHQR_KEEP_T")) c->keep_t = atoi(e) != 0;
     if (const char *e = getenv("DHQR_QTB_VEC")) c->qtb_vec = atoi(e);
     if (const char *e = getenv("DHQR_QTB_PERSIST")) c->qtb_persist = atoi(e) != 0;
     hipLaunchKernelGGL(k_set_status, dim3(1), dim3(64), 0, c->stream, c->dstat, INT_MAX);
@@ -1540,7 +1554,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
     c->hio = nullptr;
   }
   Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
-                 &c->ws[1].w1r, &c->ws[1].w2, &c->ws[2].w1, &c->ws[2].w1r, &c->ws[2].w2, &c->spart, &c->spart2, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo, &c->host_mat, &c->sv_T, &c->sv_S, &c->sv_part, &c->sv_small};
+                 &c->ws[1].w1r, &c->ws[1].w2, &c->ws[2].w1, &c->ws[2].w1r, &c->ws[2].w2, &c->spart, &c->spart2, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo, &c->host_mat, &c->sv_T, &c->sv_S, &c->sv_part, &c->sv_small, &c->tc_T, &c->tc_alpha};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {
@@ -1654,6 +1668,7 @@ int32_t dhqr_fill_uniform_f64(dhqr_ctx *c, double *dA, int64_t rows, int64_t col
   CHECK(check_mat(dA, rows, cols, lda, false));
   if (colblock <= 0 || nranks <= 0 || rank < 0 || rank >= nranks || global_m < rows)
     return set_err(DHQR_EINVAL, "bad layout arguments to dhqr_fill_uniform_f64");
+  if (c->tc_A == dA) c->tc_valid = false;  // kept T factors belong to what this call overwrites
   const int64_t total = rows * cols;
   const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(k_fill_uniform, dim3(grid), dim3(256), 0, c->stream, dA, rows, cols, lda, seed,
@@ -1670,10 +1685,35 @@ int32_t dhqr_factor_f64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t l
   if (!dalpha) return set_err(DHQR_EINVAL, "null alpha pointer");
   if (nb != 0 && nb != DHQR_NB)
     return set_err(DHQR_EINVAL, "nb must be 0 (unblocked) or %d (blocked); got %d", DHQR_NB, nb);
+  if (c->tc_A == dA) c->tc_valid = false;  // whatever was kept for this matrix is gone
   if (nb == 0) return factor_unblocked_cols(c, dA, m, n, lda, dalpha, CAT_RANK1);
-  if (!c->lookahead || cs_nblocks(n) < 3) return factor_blocked_simple(c, dA, m, n, lda, dalpha);
-  const CsProblem pr = cs_single(c, dA, m, n, lda, dalpha);
-  return cs_factor(pr);
+  // kept T factors (solve_pipelined): every panel's k_build_t stores T' here as well
+  const int64_t np = cs_nblocks(n);
+  c->tc_valid = false;
+  c->tc_base = nullptr;
+  if (c->keep_t && c->solve_pipe) {
+    CHECK(ensure(c, c->tc_T, (size_t)np * DHQR_NBV * DHQR_NBV));
+    CHECK(ensure(c, c->tc_alpha, (size_t)n + 16));
+    c->tc_base = c->tc_T.p;
+  }
+  int32_t rc;
+  if (!c->lookahead || np < 3) {
+    rc = factor_blocked_simple(c, dA, m, n, lda, dalpha);
+  } else {
+    const CsProblem pr = cs_single(c, dA, m, n, lda, dalpha);
+    rc = cs_factor(pr);
+  }
+  if (rc == DHQR_OK && c->tc_base) {
+    HIPCHECK(hipMemcpyAsync(c->tc_alpha.p, dalpha, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    c->tc_A = dA;
+    c->tc_m = m;
+    c->tc_n = n;
+    c->tc_lda = lda;
+    c->tc_valid = true;
+  }
+  c->tc_base = nullptr;
+  c->tt_keep = nullptr;
+  return rc;
 }
 
 int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha,
@@ -1784,26 +1824,33 @@ static int32_t solve_pipelined(dhqr_ctx *c, const double *dA, int64_t m, int64_t
   CHECK(ensure(c, c->sv_S, (size_t)np * QTB_NB2));
   CHECK(ensure(c, c->sv_part, (size_t)nunits * QTB_NB2));
   const size_t n_ypart = (size_t)std::max<int64_t>(nsl, (m + 63) / 64) * QTB_NB, n_w = (size_t)(np + 1) * QTB_NB;
-  const size_t n_ints = 3 * (size_t)(np + 1) + (size_t)np;  // unit table | arrival counters | w flags | block flags
+  const size_t n_ints = 3 * (size_t)(np + 1) + (size_t)np + 2;  // unit table | arrival counters | w flags | block flags | kept-T flag
   CHECK(ensure(c, c->sv_small, n_ypart + n_w + (n_ints + 1) / 2 + 16));
   double *ypart = c->sv_small.p, *wbuf = ypart + n_ypart;
   int *units = reinterpret_cast<int *>(wbuf + n_w), *counter = units + (np + 1), *wflag = counter + (np + 1),
-      *flags = wflag + (np + 1);
+      *flags = wflag + (np + 1), *kept = flags + np;
   if (c->sv_units_dev != units) {  // the table stays on the device between calls on the same shape
     HIPCHECK(hipMemcpyAsync(units, c->sv_units.data(), (size_t)(np + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
     c->sv_units_dev = units;
   }
-  HIPCHECK(hipMemsetAsync(counter, 0, (size_t)(3 * np + 2) * sizeof(int), c->stream));
+  HIPCHECK(hipMemsetAsync(counter, 0, (size_t)(3 * np + 3) * sizeof(int), c->stream));  // (... and *kept = 0)
+  // kept T factors: this context's last blocked factorisation was of this very matrix -> compare alpha on the device
+  const bool maybe_kept = c->keep_t && c->tc_valid && c->tc_A == dA && c->tc_m == m && c->tc_n == n && c->tc_lda == lda &&
+                          c->tc_T.p != nullptr;
+  if (maybe_kept)
+    hipLaunchKernelGGL(k_qtb_same_alpha, dim3(1), dim3(1024), 0, c->stream, dalpha, (const double *)c->tc_alpha.p, n, kept);
+  const double *Tt_kept = maybe_kept ? c->tc_T.p : c->sv_T.p;
   // ---- pre-pass (independent of b): S_k = V_k'V_k, T_k' = (I + striu(S_k))^{-T}
   if (vec)
     hipLaunchKernelGGL((k_gemm_tn_gram_batch<2>), dim3((unsigned)nunits), dim3(256), 0, c->stream, dA, lda, m, n, c->sv_rps,
-                       (const int *)units, np, c->sv_part.p);
+                       (const int *)units, np, c->sv_part.p, (const int *)kept);
   else
     hipLaunchKernelGGL((k_gemm_tn_gram_batch<1>), dim3((unsigned)nunits), dim3(256), 0, c->stream, dA, lda, m, n, c->sv_rps,
-                       (const int *)units, np, c->sv_part.p);
+                       (const int *)units, np, c->sv_part.p, (const int *)kept);
   hipLaunchKernelGGL(k_qtb_sum_gram, dim3((unsigned)np, 16), dim3(256), 0, c->stream, (const double *)c->sv_part.p,
-                     (const int *)units, n, c->sv_S.p);
-  hipLaunchKernelGGL(k_build_t_batch, dim3((unsigned)np), dim3(1024), 0, c->stream, (const double *)c->sv_S.p, n, c->sv_T.p);
+                     (const int *)units, n, c->sv_S.p, (const int *)kept);
+  hipLaunchKernelGGL(k_build_t_batch, dim3((unsigned)np), dim3(1024), 0, c->stream, (const double *)c->sv_S.p, n, c->sv_T.p,
+                     (const int *)kept);
   // ---- b <- Q'b (src:215-242): panel step k updates by panel k-1 and forms the dots of panel k.  One persistent launch
   // when every workgroup is certain to be resident (one per CU at most, this context alone on the device, a real device:
   // the CPU emulator runs workgroups one after the other and reports no cooperative launch), else one launch per step.
@@ -1815,20 +1862,20 @@ static int32_t solve_pipelined(dhqr_ctx *c, const double *dA, int64_t m, int64_t
   if (persist && pnsl <= (int64_t)c->ncu && c->qtb_vec <= 0) {
     if (pVEC == 2)
       hipLaunchKernelGGL((k_qtb_persist<2, 8>), dim3((unsigned)pnsl), dim3(512), 0, c->stream, dA, lda, m, n, np, db,
-                         (const double *)c->sv_T.p, wbuf, ypart, counter, wflag, err);
+                         (const double *)c->sv_T.p, Tt_kept, (const int *)kept, wbuf, ypart, counter, wflag, err);
     else
       hipLaunchKernelGGL((k_qtb_persist<1, 4>), dim3((unsigned)pnsl), dim3(256), 0, c->stream, dA, lda, m, n, np, db,
-                         (const double *)c->sv_T.p, wbuf, ypart, counter, wflag, err);
+                         (const double *)c->sv_T.p, Tt_kept, (const int *)kept, wbuf, ypart, counter, wflag, err);
   } else {
     for (int k = 0; k <= np; ++k) {
       const int64_t rfirst = (int64_t)(k >= 1 ? k - 1 : 0) * DHQR_NBV;
       const unsigned grid = (unsigned)(nsl - rfirst / sl);
       if (VEC == 2)
         hipLaunchKernelGGL((k_qtb_step<2>), dim3(grid), dim3(256), 0, c->stream, dA, lda, m, n, k, np, sl, db,
-                           (const double *)c->sv_T.p, wbuf, ypart, counter, err);
+                           (const double *)c->sv_T.p, Tt_kept, (const int *)kept, wbuf, ypart, counter, err);
       else
         hipLaunchKernelGGL((k_qtb_step<1>), dim3(grid), dim3(256), 0, c->stream, dA, lda, m, n, k, np, sl, db,
-                           (const double *)c->sv_T.p, wbuf, ypart, counter, err);
+                           (const double *)c->sv_T.p, Tt_kept, (const int *)kept, wbuf, ypart, counter, err);
     }
   }
   // ---- back substitution (src:244-282): one pipelined launch
@@ -1901,6 +1948,7 @@ int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64
   const size_t mat = ((size_t)ldd * (size_t)n + 1) & ~(size_t)1;
   CHECK(ensure(c, c->host_mat, mat + (size_t)n + (size_t)m + 32));
   double *dA = c->host_mat.p, *dal = dA + mat, *db = dal + ((n + 1) & ~(int64_t)1);
+  if (c->tc_A == dA) c->tc_valid = false;  // the caller's factor is uploaded afresh: nothing kept applies to it
   static const bool overlap = [] { const char *e = getenv("DHQR_HOSTIO"); return !(e && atoi(e) == 0); }();
   auto body = [&]() -> int32_t {
     if (overlap) {

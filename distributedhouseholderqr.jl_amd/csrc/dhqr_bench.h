@@ -545,7 +545,7 @@ int32_t dhqr_bench_lane_probe_f64(dhqr_ctx *c, int64_t rows, int32_t nsplit, int
         hipLaunchKernelGGL((k_panel_top<false>), dim3(1), dim3(1024), 0, st, (const double *)G, (const double *)P, ldp, scr, scr + 1024,
                            scr + 1024 + NB * NB, (int *)(scr + 1024 + 2 * NB * NB));
         hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, st, (const double *)G, (int)NB, scr + 2048 + 2 * NB * NB, scr + 2048 + 3 * NB * NB,
-                           0.0, (int *)nullptr, 0, (double *)nullptr);
+                           0.0, (int *)nullptr, 0, (double *)nullptr, (double *)nullptr);
       } else if (heavy)
         hipLaunchKernelGGL(k_lane_standin<40>, dim3(1), dim3(1024), (size_t)lds_kb * 1024, st, sink, 128);
       else

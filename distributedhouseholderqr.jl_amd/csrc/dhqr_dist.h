@@ -376,6 +376,7 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
         }
         double *Pp = pr.A + x * NB + lc * lda;
         c->epoch = saved_epoch;
+        c->tt_keep = (c->tc_base && P == 1) ? c->tc_base + x * (NB * NB) : nullptr;  // kept T factors (dhqr_api.hip)
         if (panel_fast_eligible(c, rows, w) && !(robust_first && x == kstart)) {
           CHECK(panel_fast_enqueue(c, Pp, rows, lda, pr.alpha + x * NB, pbx, c->cholqr_passes, (int)x, side ? S.ev_v[pe] : nullptr));
           v_event[idx] = side;
@@ -393,6 +394,7 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
           if (run_it) CHECK(factor_panel_sync(c, Pp, rows, w, lda, pr.alpha + x * NB, pbx));
           hipLaunchKernelGGL(k_set_statword, dim3(1), dim3(64), 0, sL, (const int *)c->dstat, pbx.alpha + DHQR_NBV);
         }
+        c->tt_keep = nullptr;
         HIPCHECK(hipEventRecord(S.ev_ready[pe], sL));
         // host-in / host-out drop-in: the column block of a committed panel is final and may leave for the host
         if (c->panel_hook && P == 1) CHECK(c->panel_hook(c->panel_hook_arg, x, S.ev_ready[pe]));

@@ -219,8 +219,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
 template <int VEC>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_gram_batch(const double *__restrict__ A, int64_t lda, int64_t m,
                                                                int64_t n, int64_t rps, const int *__restrict__ unit_first,
-                                                               int np, double *__restrict__ out) {
+                                                               int np, double *__restrict__ out, const int *__restrict__ skip) {
   __shared__ int kk_s;
+  if (*skip) return;  // the context kept this factor's T' (dhqr_qtb.h, k_qtb_same_alpha): nothing to compute
   if (threadIdx.x == 0) {  // largest k with unit_first[k] <= blockIdx.x
     int lo = 0, hi = np - 1;
     const int u = (int)blockIdx.x;

@@ -28,9 +28,29 @@
 #define QTB_NB DHQR_NBV
 #define QTB_NB2 (DHQR_NBV * DHQR_NBV)
 
+// Kept T factors (dhqr_api.hip): the context holds T_k' of every panel of its last blocked factorisation of THIS matrix
+// (same pointer, shape, leading dimension -- checked on the host) together with a copy of alpha.  *same = 1 iff the caller's
+// alpha still is that copy bit for bit: a factor that was overwritten by another one since (the one way the kept T could be
+// stale) comes with another diag(R).  Then the pre-pass kernels return at once and the Q'b kernels read the kept T'.
+__global__ __launch_bounds__(1024) void k_qtb_same_alpha(const double *__restrict__ alpha, const double *__restrict__ kept,
+                                                          int64_t n, int *__restrict__ same) {
+  __shared__ int diff;
+  if (threadIdx.x == 0) diff = 0;
+  __syncthreads();
+  int d = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const unsigned long long a = __double_as_longlong(alpha[i]), b = __double_as_longlong(kept[i]);
+    d |= (a != b) ? 1 : 0;
+  }
+  if (d) diff = 1;  // (benign race: every writer stores 1)
+  __syncthreads();
+  if (threadIdx.x == 0) *same = diff ? 0 : 1;
+}
+
 // S_k = sum over panel k's slab partials (fixed order); columns beyond the panel's width are zeroed.  grid (np, 16).
 __global__ __launch_bounds__(256) void k_qtb_sum_gram(const double *__restrict__ part, const int *__restrict__ unit_first,
-                                                      int64_t n, double *__restrict__ S) {
+                                                      int64_t n, double *__restrict__ S, const int *__restrict__ skip) {
+  if (*skip) return;
   const int k = blockIdx.x;
   const int u0 = unit_first[k], u1 = unit_first[k + 1];
   const int64_t c0 = (int64_t)k * QTB_NB;
@@ -53,8 +73,9 @@ __global__ __launch_bounds__(256) void k_qtb_sum_gram(const double *__restrict__
 // Tt_k = T_k' with T_k = (I + striu(S_k))^{-1}, for every panel: one 1024-thread workgroup per panel (k_build_t's inverse).
 // Stored column-major, Tt[i + 128 j] = T'[i][j] = T[j][i]: lower triangular.
 __global__ __launch_bounds__(1024) void k_build_t_batch(const double *__restrict__ S_all, int64_t n,
-                                                         double *__restrict__ Tt_all) {
+                                                         double *__restrict__ Tt_all, const int *__restrict__ skip) {
   __shared__ rc5_lds L;
+  if (*skip) return;
   const int64_t k = blockIdx.x;
   const int64_t c0 = k * QTB_NB;
   const int w = (int)((n - c0 < QTB_NB) ? n - c0 : QTB_NB);
@@ -322,11 +343,13 @@ __device__ __forceinline__ int64_t qtb_rfirst(int k) { return (int64_t)(k >= 1 ?
 template <int VEC>
 __global__ __launch_bounds__(256) void k_qtb_step(const double *__restrict__ A, int64_t lda, int64_t m, int64_t n, int k,
                                                   int np, int64_t sl, double *__restrict__ b,
-                                                  const double *__restrict__ Tt_all, double *__restrict__ wbuf,
+                                                  const double *__restrict__ Tt_new, const double *__restrict__ Tt_kept,
+                                                  const int *__restrict__ use_kept, double *__restrict__ wbuf,
                                                   double *__restrict__ ypart, int *__restrict__ counter,
                                                   int *__restrict__ err) {
   __shared__ qtb_lds<VEC> L;
   const int t = threadIdx.x;
+  const double *Tt_all = *use_kept ? Tt_kept : Tt_new;
   const bool dot = k < np, reducer = dot && blockIdx.x == gridDim.x - 1;
   const int64_t rfirst = qtb_rfirst(k);
   const int64_t slab = rfirst / sl + blockIdx.x;
@@ -399,12 +422,14 @@ __device__ __forceinline__ int qtb_red_index_n(int lane) {
 
 template <int VEC, int NW>
 __global__ __launch_bounds__(64 * NW) void k_qtb_persist(const double *__restrict__ A, int64_t lda, int64_t m, int64_t n,
-                                                         int np, double *__restrict__ b, const double *__restrict__ Tt_all,
+                                                         int np, double *__restrict__ b, const double *__restrict__ Tt_new,
+                                                         const double *__restrict__ Tt_kept, const int *__restrict__ use_kept,
                                                          double *__restrict__ wbuf, double *__restrict__ ypart,
                                                          int *__restrict__ counter, int *__restrict__ wflag,
                                                          int *__restrict__ err) {
   constexpr int SS = 64 * VEC, CPW = QTB_NB / NW, NT = 64 * NW;
   __shared__ qtbp_lds<NW> L;
+  const double *Tt_all = *use_kept ? Tt_kept : Tt_new;
   const int t = threadIdx.x, lane = t & 63, g = t >> 6;
   const int64_t slab = blockIdx.x, nsl = gridDim.x;
   const bool reducer = slab == nsl - 1;

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(1024) void k_build_t(const double *__restrict__ S, 
                                                    double *__restrict__ Tout,
                                                    double *__restrict__ Ttout, double tol,
                                                    int *__restrict__ stat, int panel_idx,
-                                                   double *__restrict__ statword) {
+                                                   double *__restrict__ statword, double *__restrict__ Tt2) {
   __shared__ rc5_lds L;
   __shared__ int bad[RC_N];
   if (stat != nullptr) {
@@ -382,6 +382,7 @@ __global__ __launch_bounds__(1024) void k_build_t(const double *__restrict__ S, 
   rc5_emit(L, x12, [&](int i, int k, double v) {
     Tout[i + k * RC_N] = v;
     Ttout[k + i * RC_N] = v;
+    if (Tt2) Tt2[k + i * RC_N] = v;  // the context's copy of T' for a later solve (dhqr_api.hip, "kept T factors")
   });
 }
 

@@ -467,7 +467,7 @@ static int32_t rs_panel_fast(const RsProblem &pr, const RsWork &w, dhqr_comm *cm
     CHECK(rs_gram_allreduce(pr, cmx, Vdst, w.ldv, rows, w.S));                // S = sum V_r' V_r: same on every rank
   }
   hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, S, (int)NB, T, Tt, c->recon_tol, c->dstat, (int)k,
-                     (double *)nullptr);                                      // same decision on every rank
+                     (double *)nullptr, (double *)nullptr);                                      // same decision on every rank
   if (rows > 0) {
     dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
     if (diag_owner) {  // reflectors, R and alpha in one launch

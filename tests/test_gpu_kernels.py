@@ -185,3 +185,47 @@ def test_expired_pipeline_wait_is_reported(pkg, orc, torch_cuda, monkeypatch):
         ctx.synchronize()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("m,n", [(4400, 4000), (2207, 2000), (1100, 300)])
+def test_solve_with_kept_t_factors(pkg, orc, torch_cuda, m, n, monkeypatch):
+    """A blocked dhqr_factor_f64 leaves T' of every panel in the context; dhqr_solve_f64 on the same matrix skips its Gram /
+    T' pre-pass when alpha still is the factorisation's (device-side check).  (1) x with kept T == x without (DHQR_KEEP_T=0)
+    to rounding, both against the oracle; (2) ANOTHER factor written to the same address is noticed (its alpha differs):
+    the solve falls back to the pre-pass and is still right."""
+    torch = torch_cuda
+    L = pkg._lib.lib()
+    P = ctypes.c_void_p
+    b = orc.rand_vector(m, 91)
+    xs = {}
+    for keep in (1, 0):
+        monkeypatch.setenv("DHQR_KEEP_T", str(keep))
+        ctx = pkg.Context(0)
+        try:
+            A = pkg.rand_colmajor(m, n, 90, "cuda:0")
+            al = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()
+            pkg._lib.check(L.dhqr_factor_f64(ctx.handle, P(A.data_ptr()), m, n, m, P(al.data_ptr()), 128))
+            bb = torch.tensor(b, device="cuda:0")
+            pkg._lib.check(L.dhqr_solve_f64(ctx.handle, P(A.data_ptr()), m, n, m, P(al.data_ptr()), P(bb.data_ptr())))
+            ctx.synchronize()
+            xs[keep] = bb[:n].cpu().numpy()
+            if keep:
+                # (2) the same device buffers now receive a DIFFERENT factorisation (the oracle's, of another matrix)
+                A2 = orc.rand_matrix(m, n, 92)
+                H2, a2 = orc.householder(A2)
+                A.copy_(torch.tensor(np.asfortranarray(H2).T.copy(), device="cuda:0").T)
+                al.copy_(torch.tensor(a2, device="cuda:0"))
+                bb = torch.tensor(b, device="cuda:0")
+                torch.cuda.synchronize()
+                pkg._lib.check(L.dhqr_solve_f64(ctx.handle, P(A.data_ptr()), m, n, m, P(al.data_ptr()), P(bb.data_ptr())))
+                ctx.synchronize()
+                x2 = orc.solve(H2, a2, b)
+                assert np.abs(bb[:n].cpu().numpy() - x2).max() <= 1e-9 * np.abs(x2).max()
+        finally:
+            ctx.close()
+    Ho, ao = orc.householder(orc.rand_matrix(m, n, 90))
+    xo = orc.solve(Ho, ao, b)
+    for keep in (1, 0):
+        assert np.abs(xs[keep] - xo).max() <= 1e-9 * np.abs(xo).max(), keep
+    assert np.abs(xs[1] - xs[0]).max() <= 1e-10 * np.abs(xo).max()
