@@ -39,8 +39,8 @@ __global__ __launch_bounds__(1024) void k_qtb_same_alpha(const double *__restric
   __syncthreads();
   int d = 0;
   for (int64_t i = threadIdx.x; i < n; i += 1024) {
-    const unsigned long long a = __double_as_longlong(alpha[i]), b = __double_as_longlong(kept[i]);
-    d |= (a != b) ? 1 : 0;
+    const double a = alpha[i], b = kept[i];  // bit patterns (NaN != NaN must not count as "changed")
+    d |= (__double2hiint(a) != __double2hiint(b) || __double2loint(a) != __double2loint(b)) ? 1 : 0;
   }
   if (d) diff = 1;  // (benign race: every writer stores 1)
   __syncthreads();

@@ -67,7 +67,7 @@ int main(int argc, char **argv) {
     const int ncols = atoi(argv[4]);
     std::vector<double> T(NN, -7.0), Tt(NN, -7.0);
     simt::launch_block(1024, [&] {
-      k_build_t(S.data(), ncols, T.data(), Tt.data(), 0.0, nullptr, 0, nullptr);
+      k_build_t(S.data(), ncols, T.data(), Tt.data(), 0.0, nullptr, 0, nullptr, nullptr);
     });
     wr(argv[5], T);
     wr(argv[6], Tt);
@@ -89,7 +89,7 @@ int main(int argc, char **argv) {
     std::vector<double> T(NN, -7.0), Tt(NN, -7.0);
     int stat[2] = {2147483647, 0};
     double statword = -1.0;
-    simt::launch_block(1024, [&] { k_build_t(S.data(), RC_N, T.data(), Tt.data(), tol, stat, 5, &statword); });
+    simt::launch_block(1024, [&] { k_build_t(S.data(), RC_N, T.data(), Tt.data(), tol, stat, 5, &statword, nullptr); });
     wr(argv[5], T);
     wr(argv[6], Tt);
     wr(argv[7], std::vector<double>{(double)stat[0], (double)stat[1], statword});

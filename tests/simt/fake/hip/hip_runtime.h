@@ -241,6 +241,7 @@ inline int simt_update_dpp(int old, int src, int ctrl, int row_mask, int bank_ma
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) simt_update_dpp(old, src, ctrl, rm, bm, bc)
 inline int simt_readlane(int v, int l) { return simt_shfl_bits(v, l); }
 #define __builtin_amdgcn_readlane(v, l) simt_readlane(v, l)
+#define __builtin_amdgcn_readfirstlane(v) simt_readlane(v, 0)
 inline int __double2loint(double d) { uint64_t b; std::memcpy(&b, &d, 8); return (int)(uint32_t)b; }
 inline int __double2hiint(double d) { uint64_t b; std::memcpy(&b, &d, 8); return (int)(uint32_t)(b >> 32); }
 inline double __hiloint2double(int hi, int lo) {
