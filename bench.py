@@ -467,7 +467,7 @@ def roofline_groups(st, steps, m=0, n=0, nb=0):
         # a LATENCY chain (two single-workgroup kernels per panel), not a bandwidth kernel: `ms` is the elapsed time of the panel
         # factorisations on the lane INCLUDING their wait for CUs behind the wide launches (DESIGN.md section 3 "The chain
         # budget": ~0.29 ms per panel on an idle chip), priced against the reference's in-panel HBM traffic (16 B per element
-        # touched per reflector); the narrow updates / cross terms of the lane are timed only under DHQR_PROFILE_LANE=1
+        # touched per reflector); the narrow updates / cross terms of the lane are not timed (two event records per section on the critical chain)
         groups.append(dict(kernel="panel lane: the panel factorisations (Gram / Cholesky + replay / reconstruction kernels, dhqr_recon.h); elapsed incl. waits for CUs",
                            symbol="panel lane", bound="hbm", ms=st["ms_panel"], launches=st["n_panel"], work=st["bytes_panel"]))
     if st["ms_rank1"] > 0:

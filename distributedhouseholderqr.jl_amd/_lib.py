@@ -69,6 +69,7 @@ SIGNATURES = {
     "dhqr_set_stream": (_i32, [_p, _p]),
     "dhqr_use_own_stream": (_i32, [_p]),
     "dhqr_synchronize": (_i32, [_p]),
+    "dhqr_trim": (_i32, [_p]),
     "dhqr_set_profiling": (_i32, [_p, _i32]),
     "dhqr_reset_stats": (_i32, [_p]),
     "dhqr_get_stats": (_i32, [_p, ctypes.POINTER(Stats)]),

@@ -59,6 +59,10 @@ class Context:
     def synchronize(self):
         check(_lib.lib().dhqr_synchronize(self._h))
 
+    def trim(self):
+        """release the device copy / staging buffers / solve workspaces the context keeps between calls (dhqr_trim)"""
+        check(_lib.lib().dhqr_trim(self._h))
+
     def set_profiling(self, on: bool):
         check(_lib.lib().dhqr_set_profiling(self._h, 1 if on else 0))
 

@@ -230,9 +230,9 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
   const int64_t ldv_fixed = any_quad ? panel_ldv(m - groups[0].a * NB) : 0;
   auto gview = [&](int g) { return cs_gbuf_view(S.gbuf[g % CS_NGB].p, m - groups[g].a * NB, ldv_fixed); };
 
-  // (DHQR_LANE_SIDE=2 turns the side stream on at P > 1 too: for the first runs on a real multi-GPU node, where each rank has
-  // its GPU's four hardware queues to itself and the chain it shortens is the critical path)
-  const bool want_side = c->lane_side == 2 || (c->lane_side == 1 && P == 1);
+  // (single rank only: with the communication stream of P > 1 a fifth busy stream shares a hardware queue -- rank threads
+  // sharing one GPU, 32768^2 at 2 ranks: 904 -> 971 ms with it, profiles/r04_ab_side_stream_logical_ranks.txt)
+  const bool want_side = c->lane_side && P == 1;
   if (want_side && !c->hi2) HIPCHECK(hipStreamCreateWithPriority(&c->hi2, hipStreamNonBlocking, c->hi_priority));
   hipStream_t sW = c->stream, sL = c->hi, sC = S.comm, sX = want_side ? c->hi2 : nullptr;
   // Lane side stream (r4): what needs a panel's V but not its T runs on sX beside the panel's second Gram product, k_build_t
@@ -254,44 +254,40 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
       rc = panel_apply(c, gb.pa(), gb.rows_a, C, ncols, lda, 1);
     return rc;
   };
-  auto apply_step = [&](int si, int64_t lstart, int64_t ncols, int phase = 0) -> int32_t {  // step si -> local columns [lstart, lstart+ncols)
+  auto apply_step = [&](int si, int64_t lstart, int64_t ncols) -> int32_t {  // step si -> local columns [lstart, lstart+ncols)
     const CsStep &st = steps[si];
-    if (st.ng == 1) return apply_group(st.g0, lstart, ncols);  // (phases: quads only)
+    if (st.ng == 1) return apply_group(st.g0, lstart, ncols);
     if (ncols <= 0) return DHQR_OK;
     const CsGroupBuf g1 = gview(st.g0), g2 = gview(st.g0 + 1);
     c->epoch = (int)groups[st.g0 + 1].last();
     return quad_apply(c, g1.VA, g2.VA, g1.ldv, g1.rows_a, g1.pa().T, g1.pb().T, g1.Sba, g2.pa().T, g2.pb().T, g2.Sba, g2.S21,
-                      pr.A + groups[st.g0].a * NB + lstart * lda, ncols, lda, phase);
+                      pr.A + groups[st.g0].a * NB + lstart * lda, ncols, lda);
   };
   // group h's last panel went through the asynchronous fast path on this rank with a "V final" event (ev_v) recorded
   std::vector<char> v_final((size_t)G, 0);
   // Does wide step si apply itself to the blocks of group glast + 2 FIRST, as a separate head with its own event?  At P > 1
   // always (that group's owner needs its block early: its wide launches are short and its lane is not shut out for long).
-  // At P == 1 the only candidate is the second pair of a quad.  A head is six latency-bound launches on 256 columns (two
-  // k_gemm_tn2, the T products, the cross term, a narrow K = 512 subtraction: ~0.55 ms, 45 times per 32768^2) where the
-  // same columns would be two column tiles more of the wide launches, and the lane gets only a few kernels of the second
-  // pair's chain placed before k_gemm_nn_quad shuts it out -- yet folding the head into the wide launches
-  // (DHQR_QUAD_HEAD=0) was SLOWER on the same box (r4, profiles/r04_ab_quad_head.txt: the wide kernels gain 8 ms, the total
-  // loses 3 ms at 32768^2, 3 ms at 16384^2, 4 ms at 24576^2): what the lane gets done early is worth more than the head costs.
+  // At P == 1 the only candidate is the second pair of a quad: six latency-bound launches on 256 columns (~0.55 ms, 45
+  // times per 32768^2) where the same columns would be two column tiles more of the wide launches -- yet folding the head
+  // into the wide launches was SLOWER on the same box (r4, profiles/r04_ab_quad_head.txt: the wide kernels gain 8 ms, the
+  // total loses 3 ms at 32768^2, 3 ms at 16384^2, 4 ms at 24576^2) and the switch that did it is gone.
   auto has_head = [&](int si) -> bool {
     const int gl = steps[si].g0 + steps[si].ng - 1;
     if (gl + 2 >= G) return false;
     if (P > 1) return true;
-    return c->quad_head && steps[step_of[(size_t)(gl + 2)]].ng == 2 && steps[step_of[(size_t)(gl + 2)]].g0 == gl + 1;
+    return steps[step_of[(size_t)(gl + 2)]].ng == 2 && steps[step_of[(size_t)(gl + 2)]].g0 == gl + 1;
   };
-  // Lane sections outside the panel factorisations (narrow updates, cross terms): timed as part of the panel group only on
-  // request (DHQR_PROFILE_LANE=1).  Every timed section is two event records on the lane -- the critical chain -- and a
-  // profiled 32768^2 run had ~2000 of them per factorisation (~4 ms of bubbles inside bench.py's timed region, r4:
-  // 832-833 ms unprofiled against 836-838 ms profiled on one box); the panel factorisations keep their own pair.
+  // Lane sections outside the panel factorisations (narrow updates, cross terms) are never timed: every timed section is
+  // two event records on the lane -- the critical chain -- and a profiled 32768^2 run had ~2000 of them per factorisation
+  // (~4 ms of bubbles inside bench.py's timed region, r4); the panel factorisations keep their own pair.
   auto lane_begin = [&](bool &was) -> int32_t {
-    if (c->profile_lane) CHECK(prof_begin(c, CAT_PANEL));
     was = c->profiling;
     c->profiling = false;
     return DHQR_OK;
   };
   auto lane_end = [&](bool was) -> int32_t {
     c->profiling = was;
-    return c->profile_lane ? prof_end(c) : DHQR_OK;
+    return DHQR_OK;
   };
 
   // produce group h: owners update + factor their panels (lane), everybody takes part in the broadcasts (comm),
@@ -467,23 +463,12 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
       on(sW, 0);
       const int64_t after_next = groups[glast + 1].last() + 1;
       int64_t lo = pr.local_from(after_next);
-      // head: the blocks of group glast + 2 -- what the lane needs first (has_head above).  Its two Y = V' C products need
-      // the step's reflectors but neither T nor the cross terms: at P == 1 they start behind "V of the step's last panel is
-      // final" (ev_v), beside that panel's second Gram product, k_build_t, the commit and the cross terms on the lane, and
-      // the rest of the head follows when the group is complete.  OFF by default (DHQR_HEAD_EARLY=1): measured slower, the
-      // head's products slow down the end of the panel chain they overlap by more than the wait they remove
-      // (profiles/r04_ab_head_early.txt).
+      // head: the blocks of group glast + 2 -- what the lane needs first (has_head above).  (Starting the head's Y products
+      // behind "V of the step's last panel is final" was measured slower in round 4 and deleted: profiles/r04_ab_head_early.txt.)
       if (has_head(si)) {
         const int64_t hi = pr.local_from(groups[glast + 2].last() + 1);
-        if (P == 1 && c->head_early && steps[si].ng == 2 && v_final[(size_t)glast]) {
-          HIPCHECK(hipStreamWaitEvent(sW, S.ev_v[(int)(groups[glast].last() % (2 * CS_EVR))], 0));
-          CHECK(apply_step(si, lo, hi - lo, 1));
-          HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[glast % CS_EVR], 0));
-          CHECK(apply_step(si, lo, hi - lo, 2));
-        } else {
-          HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[glast % CS_EVR], 0));
-          CHECK(apply_step(si, lo, hi - lo));
-        }
+        HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[glast % CS_EVR], 0));
+        CHECK(apply_step(si, lo, hi - lo));
         lo = hi;
       } else {
         HIPCHECK(hipStreamWaitEvent(sW, S.ev_group[glast % CS_EVR], 0));

@@ -57,8 +57,13 @@ struct HostIo {
   int64_t use = 0;
 };
 
-static int32_t hio_init(HostIo &h, int64_t m) {
-  const size_t need = (size_t)m * DHQR_NBV;
+// ldd: leading dimension of the device copy = of the staging buffers, so that a block of w columns is ONE contiguous range
+// on both sides and travels as a 1-D copy (the copy engines; the pitched 2-D copies of round 4 ran as blit KERNELS --
+// __amd_rocclr_copyBuffer in the trace -- that competed with the trailing update for CUs: the factorisation stretched from
+// 0.83 to ~1.0 s under the download hook).  Staging: four buffers of ldd x min(n, 128) doubles (not m x 128
+// whatever n).
+static int32_t hio_init(HostIo &h, int64_t ldd, int64_t n) {
+  const size_t need = (size_t)ldd * (size_t)std::min<int64_t>(n, DHQR_NBV);
   if (!h.s[0])
     for (int i = 0; i < 2; ++i) {
       HIPCHECK(hipStreamCreateWithFlags(&h.s[i], hipStreamNonBlocking));
@@ -85,16 +90,15 @@ static void hio_free(HostIo &h) {
 
 // hA (m x n, ld lda, pageable or not) -> dA (ld ldd); `after`: the stream that will consume dA waits for both copy streams
 static int32_t hio_upload(HostIo &h, const double *hA, int64_t m, int64_t n, int64_t lda, double *dA, int64_t ldd, hipStream_t after) {
-  CHECK(hio_init(h, m));
+  CHECK(hio_init(h, ldd, n));
   const int64_t NB = DHQR_NBV, K = (n + NB - 1) / NB;
   for (int64_t k = 0; k < K; ++k) {
     const int si = (int)(k & 1);
     double *st = h.stage[2 * si + (int)((k >> 1) & 1)];
     const int64_t c0 = k * NB, w = std::min<int64_t>(NB, n - c0);
-    h.jobs.emplace_back(new HioJob{hA + c0 * lda, st, lda, m, m, w});
+    h.jobs.emplace_back(new HioJob{hA + c0 * lda, st, lda, ldd, m, w});
     HIPCHECK(hipLaunchHostFunc(h.s[si], hio_copy_cols, h.jobs.back().get()));
-    HIPCHECK(hipMemcpy2DAsync(dA + c0 * ldd, ldd * sizeof(double), st, m * sizeof(double), m * sizeof(double), w,
-                              hipMemcpyHostToDevice, h.s[si]));
+    HIPCHECK(hipMemcpyAsync(dA + c0 * ldd, st, (size_t)ldd * (size_t)w * sizeof(double), hipMemcpyHostToDevice, h.s[si]));
   }
   for (int i = 0; i < 2; ++i) {
     HIPCHECK(hipEventRecord(h.ev[i], h.s[i]));
@@ -109,9 +113,8 @@ static int32_t hio_download_block(HostIo &h, int64_t c0, int64_t w, hipEvent_t r
   const int si = (int)(k & 1);
   double *st = h.stage[2 * si + (int)((k >> 1) & 1)];
   if (ready) HIPCHECK(hipStreamWaitEvent(h.s[si], ready, 0));
-  HIPCHECK(hipMemcpy2DAsync(st, h.m * sizeof(double), h.dA + c0 * h.ldd, h.ldd * sizeof(double), h.m * sizeof(double), w,
-                            hipMemcpyDeviceToHost, h.s[si]));
-  h.jobs.emplace_back(new HioJob{st, h.hA + c0 * h.lda, h.m, h.lda, h.m, w});
+  HIPCHECK(hipMemcpyAsync(st, h.dA + c0 * h.ldd, (size_t)h.ldd * (size_t)w * sizeof(double), hipMemcpyDeviceToHost, h.s[si]));
+  h.jobs.emplace_back(new HioJob{st, h.hA + c0 * h.lda, h.ldd, h.lda, h.m, w});
   HIPCHECK(hipLaunchHostFunc(h.s[si], hio_copy_cols, h.jobs.back().get()));
   return DHQR_OK;
 }

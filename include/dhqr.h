@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DHQR_VERSION 300 /* 0.3.0: round 4 (distributed solve entry points, ComplexF64 distributed solve, comm timing) */
+#define DHQR_VERSION 400 /* 0.4.0: round 5 (the solve of csrc/dhqr_qtb.h, kept T factors, DHQR_TUNE; no entry point added or changed) */
 
 #define DHQR_OK 0
 #define DHQR_EINVAL (-1)   /* bad argument (null pointer, m < n, ld < m, unsupported nb ...) */
@@ -83,7 +83,17 @@ int32_t dhqr_destroy(dhqr_ctx *ctx);
  * back to the ctx-owned non-blocking stream (the state after dhqr_create). */
 int32_t dhqr_set_stream(dhqr_ctx *ctx, void *hip_stream);
 int32_t dhqr_use_own_stream(dhqr_ctx *ctx);
+/* Waits for the ctx stream AND reports what only the device knows: the library's inter-workgroup pipelines (the ComplexF64
+ * panel pipeline, the lead pipeline of the unblocked path, the flag-pipelined back substitution and the persistent Q'b
+ * kernel of dhqr_solve_f64) bound their waits; a wait that expires lets its kernel finish with wrong numbers and records
+ * the fact in an error word.  RESULTS OF AN ASYNCHRONOUS ENTRY POINT (dhqr_factor_f64 with nb == 0, dhqr_factor_c64*,
+ * dhqr_solve_f64 / _c64, dhqr_cs_factor_c64) ARE VALID ONLY AFTER dhqr_synchronize RETURNED DHQR_OK.  The synchronous
+ * entry points and every blocked driver (one status read per pass) check the word themselves. */
 int32_t dhqr_synchronize(dhqr_ctx *ctx);
+/* Release what the context keeps between calls for speed: the device copy and staging buffers of the host-in / host-out
+ * entry points, the solve's workspaces and kept T factors, the blocked driver's group buffers.  Synchronises; the next call
+ * that needs them allocates again. */
+int32_t dhqr_trim(dhqr_ctx *ctx);
 int32_t dhqr_set_profiling(dhqr_ctx *ctx, int32_t on);
 int32_t dhqr_reset_stats(dhqr_ctx *ctx);
 int32_t dhqr_get_stats(dhqr_ctx *ctx, dhqr_stats *out); /* synchronises the ctx stream */
@@ -124,8 +134,9 @@ int32_t dhqr_fill_uniform_f64(dhqr_ctx *ctx, double *dA, int64_t rows, int64_t c
  * src:198-213) for one GPU.  In place on dA (m x n, m >= n), writes dalpha[0:n].
  *   nb == 0      : unblocked path (BASELINE configs[1]) -- the reference's operations in the reference's order
  *                  (src:129-143, 208-209: each dot product over the column as updated so far); a launch applies K
- *                  consecutive reflectors to every trailing column it loads once (K = 5 where a column fits 8192
- *                  rows, K = 2 above) and builds the next K reflectors in its lead workgroup.
+ *                  consecutive reflectors to every trailing column it loads once (K = 5 ... 8 for columns of up to
+ *                  8192 rows, 5 up to 32768 rows, one reflector per launch above) and builds the next K reflectors
+ *                  in its lead workgroup(s).
  *   nb == DHQR_NB: blocked path -- panel factorisation + compact-WY trailing update
  *                  A -= V * (T' * (V' * A)) on FP64 MFMA (BASELINE configs[2]).
  * nb == 0 is asynchronous on the ctx stream.  nb == DHQR_NB enqueues the whole factorisation without host
@@ -135,14 +146,22 @@ int32_t dhqr_factor_f64(dhqr_ctx *ctx, double *dA, int64_t m, int64_t n, int64_t
                         double *dalpha, int32_t nb);
 
 /* dhqr_qr_f64: host-in / host-out drop-in for qr!(A::Matrix{Float64}) (src:311-315): uploads hA,
- * factors, downloads hA and halpha.  Synchronous. */
+ * factors, downloads hA and halpha.  Synchronous.  Column blocks travel back while later panels are still being
+ * factored, so ON AN ERROR RETURN hA IS UNDEFINED (a mix of original and factored columns) and halpha is not written.
+ * The device copy of the matrix (and the pinned staging buffers) stay in the context between calls -- 8 GiB at 32768^2;
+ * dhqr_trim releases them. */
 int32_t dhqr_qr_f64(dhqr_ctx *ctx, double *hA, int64_t m, int64_t n, int64_t lda, double *halpha,
                     int32_t nb);
 
 /* ------------------------------------------------------------------ solve
  * dhqr_solve_f64: device-resident replacement of solve_householder!(b, H, alpha) (src:284-294):
  * db (length m) <- Q' db (src:215-242), then back substitution with strict-upper dA and the
- * diagonal dalpha (src:244-282); the solution is db[0:n].  Mutates db like the reference. Async. */
+ * diagonal dalpha (src:244-282); the solution is db[0:n].  Mutates db like the reference.  Asynchronous (see
+ * dhqr_synchronize).  csrc/dhqr_qtb.h: per 128-column panel the compact-WY form I - V T' V' with V read in place, GEMV-class
+ * kernels (every element of V and of R crosses the memory system once), one persistent launch for Q'b and one
+ * flag-pipelined launch for the back substitution.  T' of every panel comes from a batched pre-pass over the factor --
+ * or, when this context's last blocked dhqr_factor_f64 was of this very matrix (same dA, m, n, lda) and dalpha still
+ * holds that factorisation's values (compared on the device), from what the factorisation kept (DHQR_KEEP_T). */
 int32_t dhqr_solve_f64(dhqr_ctx *ctx, const double *dA, int64_t m, int64_t n, int64_t lda,
                        const double *dalpha, double *db);
 

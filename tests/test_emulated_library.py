@@ -99,7 +99,7 @@ def test_unblocked_k_reflectors_per_pass_is_the_same_arithmetic(emu, orc, m, n, 
     res = {}
     for K in (1,) + Ks:
         # (DHQR_RANKK=5 also takes up to 8 per pass where the CU can hold them -- here from the first column on)
-        h = _ctx(emu, DHQR_RANKK=K, DHQR_RANKK_WGS=2 + K % 2, DHQR_RANKK_MAX_MIN_COLS=0)  # the lead + 7 or 11 persistent bulk workgroups of 256 threads
+        h = _ctx(emu, DHQR_RANKK=K, DHQR_TUNE=f"rankk_wgs={2 + K % 2},rankk_max_min_cols=0")  # the lead + 7 or 11 persistent bulk workgroups of 256 threads
         A, al = _factor(emu, h, A0, 0)
         _check(orc, A0, A, al)
         res[K] = (A, al)
@@ -142,15 +142,15 @@ def test_quad_steps_two_pairs_in_one_k512_update(emu, orc):
 
 
 def test_wide_subtraction_launches_in_chunks(emu, orc):
-    """nn_chunks: a wide subtraction launch issued as several launches (one tile per chunk is enough here) -- the quad's in up
-    to 4 COLUMN chunks (DHQR_NN_SPLIT_COLS), the pairs' in up to 3 ROW chunks (the default path of launches with few column
-    tiles: the row split, a rank's local block).  Chunks regroup the same tiles; a chunk's last tile takes the edge path (C tile
-    loaded up front instead of streamed in during the K loop: the same sum in another order), so equal to rounding"""
+    """nn_row_chunks: a wide subtraction launch of few column tiles issued as several launches over ROW ranges (one row tile
+    per chunk is enough here; the path of the row split and of a rank's local block).  Chunks regroup the same tiles; a
+    chunk's last tile takes the edge path (C tile loaded up front instead of streamed in during the K loop: the same sum in
+    another order), so equal to rounding"""
     A0 = orc.rand_matrix(650, 640, 12)
     res = []
     for env in ({"DHQR_PAIR_MIN_N": 0, "DHQR_QUAD_MIN_COLS": 0},
-                {"DHQR_PAIR_MIN_N": 0, "DHQR_QUAD_MIN_COLS": 0, "DHQR_NN_CHUNK_TILES": 1, "DHQR_NN_SPLIT_COLS": 1},
-                {"DHQR_PAIR_MIN_N": 0, "DHQR_QUAD": 0, "DHQR_NN_CHUNK_TILES": 1, "DHQR_NN_SPLIT": 3}):
+                {"DHQR_PAIR_MIN_N": 0, "DHQR_QUAD_MIN_COLS": 0, "DHQR_TUNE": "nn_chunk_tiles=1"},
+                {"DHQR_PAIR_MIN_N": 0, "DHQR_QUAD": 0, "DHQR_TUNE": "nn_chunk_tiles=1", "DHQR_NN_SPLIT": 3}):
         h = _ctx(emu, **env)
         A, al = _factor(emu, h, A0, 128)
         _check(orc, A0, A, al)
@@ -190,13 +190,13 @@ def test_wide_update_on_the_persistent_tn_kernel(emu, orc):
 
 @pytest.mark.parametrize("m,n", [(1040, 896), pytest.param(1161, 1152, marks=_SLOW)])
 def test_wide_tn_stream_k(emu, orc, m, n):
-    """stream-K decomposition of the wide k_gemm_tn2 launches (normally from 128 column tiles on; DHQR_TN_MODEL_MIN_TILES=3
+    """stream-K decomposition of the wide k_gemm_tn2 launches (normally from 128 column tiles on; DHQR_TUNE tn_min_tiles=3
     brings it to a small matrix): 128-row fine units numbered tile-major, a contiguous range per workgroup, a tile's
     partial sums = the workgroups that share it (k_reduce_pieces) -- against the oracle, even and odd m (16-byte / scalar
-    loads), and against the column-tile x row-slab units (DHQR_TN_STREAMK=0) to rounding"""
+    loads), and against the column-tile x row-slab units (tn_min_tiles beyond reach) to rounding"""
     A0 = orc.rand_matrix(m, n, 16)
     res = []
-    for env in ({"DHQR_TN_MODEL_MIN_TILES": 3}, {"DHQR_TN_MODEL_MIN_TILES": 3, "DHQR_TN_STREAMK": 0}):
+    for env in ({"DHQR_TUNE": "tn_min_tiles=3"}, {"DHQR_TUNE": "tn_min_tiles=1000000"}):
         h = _ctx(emu, **env)
         A, al = _factor(emu, h, A0, 128)
         _check(orc, A0, A, al)
@@ -329,8 +329,8 @@ def test_solve_apply_q_and_residual_entry_points(emu, orc):
     emu.dhqr_destroy(h)
 
 
-@pytest.mark.parametrize("m,n,env", [(300, 200, {}), (520, 384, {}), (777, 130, {}), (260, 257, {"DHQR_QTB_VEC": 2}),
-                                     (1100, 1000, {"DHQR_QTB_VEC": 2}), (640, 128, {"DHQR_QTB_VEC": 1}), (70, 50, {}),
+@pytest.mark.parametrize("m,n,env", [(300, 200, {}), (520, 384, {}), (777, 130, {}), (260, 257, {"DHQR_TUNE": "qtb_vec=2"}),
+                                     (1100, 1000, {"DHQR_TUNE": "qtb_vec=2"}), (640, 128, {"DHQR_TUNE": "qtb_vec=1"}), (70, 50, {}),
                                      (129, 129, {})])
 def test_pipelined_solve_kernels(emu, orc, m, n, env):
     """dhqr_solve_f64 through dhqr_qtb.h (batched Gram / T' pre-pass on the factor in place, one k_qtb_step launch per

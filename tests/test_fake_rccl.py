@@ -96,12 +96,12 @@ def _mg(L, ndev):
 # divide by 3 -> ring fallback inside the scatter+all-gather algorithm; 8 ranks with 2 cyclic blocks: six ranks own nothing
 @pytest.mark.parametrize("ndev,m,n,env", [
     (2, 520, 384, {"DHQR_BCAST": "ring"}),
-    (2, 520, 384, {"DHQR_BCAST": "ring", "DHQR_LANE_SIDE": 2}),  # the lane's side stream at P > 1 (off by default there)
-    pytest.param(2, 700, 512, {"DHQR_BCAST": "sag", "DHQR_BCAST_SAG_MIN": 1}, marks=_SLOW),
-    (2, 520, 384, {"DHQR_BCAST_SAG_MIN": 1}),
-    (3, 640, 522, {"DHQR_BCAST": "sag", "DHQR_BCAST_SAG_MIN": 1}),
-    (8, 600, 512, {"DHQR_BCAST": "sag", "DHQR_BCAST_SAG_MIN": 1}),
-    pytest.param(8, 2400, 2304, {"DHQR_BCAST": "sag", "DHQR_BCAST_SAG_MIN": 1}, marks=_SLOW),
+    (2, 520, 384, {"DHQR_BCAST": "ring", "DHQR_LANE_SIDE": 0}),
+    pytest.param(2, 700, 512, {"DHQR_BCAST": "sag", "DHQR_TUNE": "sag_min=1"}, marks=_SLOW),
+    (2, 520, 384, {"DHQR_TUNE": "sag_min=1"}),
+    (3, 640, 522, {"DHQR_BCAST": "sag", "DHQR_TUNE": "sag_min=1"}),
+    (8, 600, 512, {"DHQR_BCAST": "sag", "DHQR_TUNE": "sag_min=1"}),
+    pytest.param(8, 2400, 2304, {"DHQR_BCAST": "sag", "DHQR_TUNE": "sag_min=1"}, marks=_SLOW),
 ])
 def test_column_split_over_rccl(rk, orc, ndev, m, n, env):
     L, F = rk
@@ -192,7 +192,7 @@ def test_column_split_quad_steps_over_rccl(rk, orc, ndev, m, n, bad):
                                            pytest.param(8, 200, 130, "ring", marks=_SLOW), pytest.param(2, 200, 150, "sag", marks=_SLOW)])
 def test_complex_column_split_over_rccl(rk, orc, ndev, m, n, algo):
     L, F = rk
-    with _env(DHQR_BCAST=algo, DHQR_BCAST_SAG_MIN=1):
+    with _env(DHQR_BCAST=algo, DHQR_TUNE="sag_min=1"):
         h = _mg(L, ndev)
     A0 = orc.rand_matrix_c(m, n, 21)
     A, al = A0.copy(order="F"), np.zeros(n, dtype=complex)

@@ -127,7 +127,7 @@ def test_pipelined_solve_vs_oracle_and_round1_path(pkg, orc, torch_cuda, m, n, v
     for pipe in (1, 0):
         monkeypatch.setenv("DHQR_SOLVE_PIPE", str(pipe))
         if vec:
-            monkeypatch.setenv("DHQR_QTB_VEC", str(vec))
+            monkeypatch.setenv("DHQR_TUNE", f"qtb_vec={vec}")
         ctx = pkg.Context(0)  # the switches are read by dhqr_create
         bb = torch.tensor(b, device="cuda:0")
         torch.cuda.synchronize()
@@ -145,12 +145,12 @@ def test_pipelined_solve_vs_oracle_and_round1_path(pkg, orc, torch_cuda, m, n, v
 
 def test_expired_pipeline_wait_is_reported(pkg, orc, torch_cuda, monkeypatch):
     """a hand-over wait that gives up lets its kernel finish with wrong numbers; the context's error word must
-    reach the caller.  DHQR_PIPE_SPIN_LIMIT=1 (read by dhqr_create) makes every inter-workgroup wait expire at once:
+    reach the caller.  DHQR_TUNE=spin_limit=1 (read by dhqr_create) makes every inter-workgroup wait expire at once:
     the ComplexF64 panel pipeline and the pipelined back substitution both have to report through dhqr_synchronize, and
     the blocked Float64 driver through its own status read."""
     torch = torch_cuda
     L = pkg._lib.lib()
-    monkeypatch.setenv("DHQR_PIPE_SPIN_LIMIT", "1")
+    monkeypatch.setenv("DHQR_TUNE", "spin_limit=1")
     ctx = pkg.Context(0)
     try:
         # (1) k_backsub_pipe: 32 blocks, every workgroup but the first waits for its predecessors
@@ -176,7 +176,7 @@ def test_expired_pipeline_wait_is_reported(pkg, orc, torch_cuda, monkeypatch):
             ctx.synchronize()
     finally:
         ctx.close()
-    monkeypatch.delenv("DHQR_PIPE_SPIN_LIMIT")
+    monkeypatch.delenv("DHQR_TUNE")
     ctx = pkg.Context(0)  # a fresh context waits again
     try:
         bb = pkg.rand_vector_device(m, 4, "cuda:0")

@@ -81,11 +81,11 @@ def test_unblocked_vs_oracle(pkg, orc, m, n):
 def test_unblocked_more_than_five_reflectors_per_pass(pkg, orc, m, n, monkeypatch):
     """Columns of at most 8192 rows take as many reflectors per pass as the CU can hold (six at 6145 ... 8192 rows through the
     16-elements-per-thread instantiations, 16-byte path only; six / seven / eight at <= 6144 / 4096 / 3072 rows) while more
-    than 4096 columns are left -- here from the first column on (DHQR_RANKK_MAX_MIN_COLS=0)"""
+    than 4096 columns are left -- here from the first column on (DHQR_TUNE rankk_max_min_cols=0)"""
     if n > 1000:
-        monkeypatch.delenv("DHQR_RANKK_MAX_MIN_COLS", raising=False)  # the shipped threshold on a square matrix
+        monkeypatch.delenv("DHQR_TUNE", raising=False)  # the shipped threshold on a square matrix
     else:
-        monkeypatch.setenv("DHQR_RANKK_MAX_MIN_COLS", "0")
+        monkeypatch.setenv("DHQR_TUNE", "rankk_max_min_cols=0")
     api = pkg.api
     old = api._contexts.pop(0, None)
     try:
@@ -107,8 +107,6 @@ def test_unblocked_more_than_five_reflectors_per_pass(pkg, orc, m, n, monkeypatc
 def test_unblocked_reflectors_per_pass(pkg, orc, m, n, K, monkeypatch):
     """DHQR_RANKK = 1..5 reflectors per pass over the trailing columns: the same factorisation as the oracle's"""
     monkeypatch.setenv("DHQR_RANKK", str(K))  # read by dhqr_create
-    monkeypatch.setenv("DHQR_RANKK_TALL", str(K))
-    monkeypatch.setenv("DHQR_RANKK_XTALL", str(K))
     api = pkg.api
     old = api._contexts.pop(0, None)
     try:
@@ -126,11 +124,10 @@ def test_unblocked_reflectors_per_pass(pkg, orc, m, n, K, monkeypatch):
 
 @pytest.mark.parametrize("m,n", [(12288, 64), (16390, 48), (9000, 40), (8192, 40), (8000, 60), (6000, 60), (20000, 50)])
 def test_unblocked_few_workgroups_own_many_columns(pkg, orc, m, n, monkeypatch):
-    """DHQR_RANKK_WGS=8: three bulk workgroups walk through all trailing columns of a pass (on 256 CUs the shapes above give
+    """DHQR_TUNE rankk_wgs=8: three bulk workgroups walk through all trailing columns of a pass (on 256 CUs the shapes above give
     every workgroup ONE column) -- the column-to-column pipeline of k_rankk_tall (next reflector streaming into LDS while the
     current one is applied, next column prefetched) and of k_rankk_fused against the oracle"""
-    monkeypatch.setenv("DHQR_RANKK_WGS", "8")  # read by dhqr_create
-    monkeypatch.setenv("DHQR_RANKK_MAX_MIN_COLS", "0")  # six to eight per pass at <= 8192 rows whatever the number of columns
+    monkeypatch.setenv("DHQR_TUNE", "rankk_wgs=8,rankk_max_min_cols=0")  # six to eight per pass at <= 8192 rows whatever the number of columns
     api = pkg.api
     old = api._contexts.pop(0, None)
     try:
@@ -299,14 +296,12 @@ def test_column_cyclic_driver_single_rank(pkg, orc, m, n):
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
 
 
-@pytest.mark.parametrize("env", [{"DHQR_NARROW_TN": "0"}, {"DHQR_NARROW_TN": "1"}, {"DHQR_HEAD_EARLY": "1"},
-                                 {"DHQR_HEAD_EARLY": "1", "DHQR_NARROW_TN": "0"}, {"DHQR_LANE_SIDE": "0", "DHQR_HEAD_EARLY": "1"}])
+@pytest.mark.parametrize("env", [{}, {"DHQR_LANE_SIDE": "0"}, {"DHQR_NN_SPLIT": "1"}])
 def test_lane_schedule_switches_on_a_small_matrix_with_quads(pkg, orc, monkeypatch, env):
-    """the round-4 schedule switches with quad steps forced onto a 2600 x 2560 matrix (five quads of pairs, heads, the
-    K = 512 cross term): narrow V'C products through whole-CU k_gemm_tn2 workgroups (DHQR_NARROW_TN=0) or slot-sized
-    k_gemm_tn workgroups with the two reflector blocks in blockIdx.z (1, default); the head's Y products started on "V of
-    the last panel final" (DHQR_HEAD_EARLY=1, off by default: measured slower), with and without the lane's side stream --
-    every variant is the oracle's factorisation"""
+    """quad steps forced onto a 2600 x 2560 matrix (five quads of pairs, heads, the K = 512 cross term; narrow V'C products
+    through slot-sized k_gemm_tn workgroups with the two reflector blocks in blockIdx.z), with and without the lane's side
+    stream and the row chunks of the wide subtraction launches -- every variant is the oracle's factorisation.  (Round 4's
+    losing variants -- whole-CU narrow products, the early head, the head folded into the wide launches -- are deleted.)"""
     monkeypatch.setenv("DHQR_QUAD_MIN_COLS", "0")  # read by dhqr_create of the rank context
     monkeypatch.setenv("DHQR_PAIR_MIN_N", "0")
     for k, v in env.items():
@@ -325,14 +320,13 @@ def test_lane_schedule_switches_on_a_small_matrix_with_quads(pkg, orc, monkeypat
         mg.close()
 
 
-@pytest.mark.parametrize("streamk", [1, 0])
-def test_wide_tn_split_model_on_a_small_matrix(pkg, orc, monkeypatch, streamk):
+@pytest.mark.parametrize("min_tiles", [3, 1000000])
+def test_wide_tn_split_model_on_a_small_matrix(pkg, orc, monkeypatch, min_tiles):
     """the decomposition of the wide k_gemm_tn2 launches (normally for >= 128 column tiles = matrices beyond 16384
-    columns) forced onto a 2304^2 matrix -- stream-K (default: tile-major fine units, a contiguous range per workgroup,
-    k_reduce_pieces) and the column-tile x row-slab units with the round / partial-traffic estimate (DHQR_TN_STREAMK=0):
-    same factorisation as the oracle's"""
-    monkeypatch.setenv("DHQR_TN_MODEL_MIN_TILES", "3")  # read by dhqr_create of the rank context
-    monkeypatch.setenv("DHQR_TN_STREAMK", str(streamk))
+    columns) forced onto a 2304^2 matrix -- stream-K (tile-major fine units, a contiguous range per workgroup,
+    k_reduce_pieces; DHQR_TUNE tn_min_tiles=3) and the column-tile x row-slab units every smaller launch uses
+    (tn_min_tiles beyond reach): same factorisation as the oracle's"""
+    monkeypatch.setenv("DHQR_TUNE", f"tn_min_tiles={min_tiles}")  # read by dhqr_create of the rank context
     m = n = 2304
     mg = pkg.MultiGpuQR(devices=[0])
     try:
