@@ -441,7 +441,7 @@ def pmc_traffic(symbol, m, n, nb, launches, work):
         for src in e["sources"]:
             have, want = git_blob_hash(os.path.join(ROOT, src)), pm.get("source_hashes", {}).get(src)
             if have != want:
-                return None, f"committed counters were taken with {src} at blob {str(want)[:12]}, this tree has {str(have)[:12]}: re-run the counter passes of tools/gpu_r3_evidence.sh and tools/pmc_stamp.py"
+                return None, f"committed counters were taken with {src} at blob {str(want)[:12]}, this tree has {str(have)[:12]}: re-run the counter passes of tools/gpu_r5_evidence.sh and tools/pmc_stamp.py"
         # bytes of ONE factorisation step as the counters measured them: read + written by the launches the counter passes
         # cover (`counted`: the wide launches of the symbol; the narrow look-ahead launches of the same template are left out)
         info = {"bytes_per_step": (e["read_GB"] + e["write_GB"]) * 1e9, "counted_launches_per_step": e["launches"],
@@ -463,7 +463,7 @@ def roofline_groups(st, steps, m=0, n=0, nb=0):
         # one timed group = the TN launches of one wide update (one k_gemm_tn2 per pair of panels) + their split-K reductions
         groups.append(dict(kernel="k_gemm_tn2 / k_gemm_tn (W = [V_a V_b]'*A, FP64 MFMA)", symbol="k_gemm_tn2", bound="mfma", ms=st["ms_gemm_vta"],
                            launches=st["n_gemm_vta"], work=st["flops_gemm_vta"]))
-    if st["ms_panel"] > 0:
+    if st["ms_panel"] > 0 and st["bytes_panel"] > 0:  # (drivers that do not count the panel's algorithmic bytes get no entry: no placeholder)
         # a LATENCY chain (two single-workgroup kernels per panel), not a bandwidth kernel: `ms` is the elapsed time of the panel
         # factorisations on the lane INCLUDING their wait for CUs behind the wide launches (DESIGN.md section 3 "The chain
         # budget": ~0.29 ms per panel on an idle chip), priced against the reference's in-panel HBM traffic (16 B per element
@@ -492,9 +492,14 @@ def roofline_groups(st, steps, m=0, n=0, nb=0):
                  "launches": gr["launches"], "launches_per_step": per_step,
                  "avg_launch_ms": gr["ms"] / max(1, gr["launches"]), "total_ms": gr["ms"], "ms_per_step": gr["ms"] / max(1, steps)}
         if tinfo:
+            ratio = tinfo["ratio_to_algorithmic"]
+            if ratio is None and gr["bound"] == "hbm" and gr["work"] > 0:
+                # the counter file has no algorithmic figure for this group (the panel lane): this run's own count -- the
+                # reference's in-panel traffic, 16 B per element touched per reflector (bytes_panel) -- prices it
+                ratio = tinfo["bytes_per_step"] / (gr["work"] / max(1, steps))
             entry.update(traffic_bytes_per_step=tinfo["bytes_per_step"],
                          traffic_counted_launches_per_step=tinfo["counted_launches_per_step"],
-                         traffic_ratio_to_algorithmic=tinfo["ratio_to_algorithmic"],
+                         traffic_ratio_to_algorithmic=ratio,
                          traffic_GBps=tinfo["bytes_per_step"] / (gr["ms"] / max(1, steps)) / 1e6)
         rl_all.append(entry)
     # the north star grades the trailing update: the DOMINANT (largest total time) MFMA group

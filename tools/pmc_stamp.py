@@ -1,4 +1,4 @@
-"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `tools/pmc_driver blocked 32768` (tools/gpu_r3_evidence.sh)
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `tools/pmc_driver blocked 32768` (tools/gpu_r5_evidence.sh)
 -> profiles/pmc_traffic_current.json, the file bench.py reads for roofline.traffic, stamped with the git blob ids of the
 kernel sources.  Per kernel symbol: the WIDE launches (those that move at least 10 % of the symbol's largest launch; the
 narrow look-ahead launches of the same template are left out), their measured HBM bytes (gfx950: read = 2 x FETCH_SIZE
@@ -156,7 +156,7 @@ def main():
         for e in old.get("entries", []):  # the unblocked entry stays while its source is unchanged
             if e["kernel_symbol"] == "k_rankk_fused" and old.get("source_hashes", {}).get(srcs[1]) == blob(srcs[1]):
                 entries.append(e)
-    out = {"what": old["what"].replace("tools/gpu_pmc_traffic.sh + tools/pmc_stamp.py", "tools/gpu_r3_evidence.sh (pmc passes) + tools/pmc_stamp.py").replace("tools/gpu_r3_evidence.sh", "tools/gpu_r4_evidence.sh"),
+    out = {"what": old["what"].replace("tools/gpu_pmc_traffic.sh + tools/pmc_stamp.py", "tools/gpu_r3_evidence.sh (pmc passes) + tools/pmc_stamp.py").replace("tools/gpu_r3_evidence.sh", "tools/gpu_r5_evidence.sh").replace("tools/gpu_r4_evidence.sh", "tools/gpu_r5_evidence.sh"),
            "method": old["method"], "correction": old["correction"], "measured_at_commit": note,
            "source_hashes": {s: blob(s) for s in srcs}, "entries": entries}
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json"), "w"), indent=1)
