@@ -617,6 +617,37 @@ def also_solve(pkg, torch, dev, lapack=True):
             **out}
 
 
+def also_sizes(pkg, torch, ctx, dev, sizes=(8192, 16384), steps=3, warmup=1):
+    """the blocked path below the headline size, where the panel chain -- not the GEMMs -- bounds the run (DESIGN.md section 3
+    "The panel chain"): n x n Float64, nb = 128, device-resident, refill inside the timed region like the headline"""
+    import ctypes
+    L = pkg._lib.lib()
+    out = []
+    for n in sizes:
+        A = pkg.empty_colmajor(n, n, dev)
+        alpha = torch.zeros(n, dtype=torch.float64, device=dev)
+
+        def step():
+            ctx.use_torch_stream()
+            pkg._lib.check(L.dhqr_fill_uniform_f64(ctx.handle, ctypes.c_void_p(A.data_ptr()), n, n, n, 0, n, 0, pkg.NB, 1, 0))
+            pkg.householder_(A, alpha, nb=pkg.NB)
+
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        resid = pkg.residual(pkg.DistributedHouseholderQRStruct(A, alpha), pkg.rand_colmajor(n, n, 0, dev))
+        out.append({"m": n, "n": n, "nb": pkg.NB, "ms_per_step": dt * 1e3, "value": flops_qr(n, n) / dt / 1e9, "unit": "GFLOP/s",
+                    "frac_of_mfma_peak": flops_qr(n, n) / dt / 1e12 / PEAK_FP64_MFMA_TFLOPS, "residual": resid})
+        del A, alpha
+        torch.cuda.empty_cache()
+    return {"config": {"workload": "blocked Float64 QR below the headline size (chain-bound sizes)"}, "sizes": out}
+
+
 def host_in_out(pkg, torch, dev, m, n, reps=2):
     """the PCIe-inclusive drop-in call `qr!(A::Matrix)` = dhqr_qr_f64 on a HOST matrix (pageable numpy memory, as a Julia
     Matrix would be): staged upload, factorisation, every column block downloaded behind its panel's commit
@@ -946,7 +977,8 @@ def main():
             out["also"] = []
             for what, fn in (("unblocked 8192^2", lambda: also_unblocked(pkg, torch, ctx, dev)),
                              ("row split 262144x4096", lambda: also_tallskinny(pkg, torch)),
-                             ("solve", lambda: also_solve(pkg, torch, dev, lapack=not args.no_cpu_baseline))):
+                             ("solve", lambda: also_solve(pkg, torch, dev, lapack=not args.no_cpu_baseline)),
+                             ("blocked 8192^2 / 16384^2", lambda: also_sizes(pkg, torch, ctx, dev))):
                 try:
                     progress(f"also: {what}")
                     out["also"].append(fn())

@@ -229,3 +229,36 @@ def test_solve_with_kept_t_factors(pkg, orc, torch_cuda, m, n, monkeypatch):
     for keep in (1, 0):
         assert np.abs(xs[keep] - xo).max() <= 1e-9 * np.abs(xo).max(), keep
     assert np.abs(xs[1] - xs[0]).max() <= 1e-10 * np.abs(xo).max()
+
+
+def test_trim_releases_and_the_context_keeps_working(pkg, orc, torch_cuda):
+    """dhqr_trim (the host-in / host-out entry points keep an 8 GiB device copy at 32768^2 until dhqr_destroy): the
+    cached device matrix, staging buffers and solve workspaces are released, and the next calls allocate again"""
+    torch = torch_cuda
+    ctx = pkg.Context(0)
+    try:
+        L = pkg._lib.lib()
+        m, n = 3000, 2000
+        A0 = orc.rand_matrix(m, n, 55)
+        al = np.zeros(n)
+        free0 = torch.cuda.mem_get_info()[0]
+        A = A0.copy(order="F")
+        pkg._lib.check(L.dhqr_qr_f64(ctx.handle, A.ctypes.data_as(ctypes.c_void_p), m, n, m, al.ctypes.data_as(ctypes.c_void_p), 128))
+        free1 = torch.cuda.mem_get_info()[0]
+        assert free0 - free1 >= m * n * 8  # the device copy stays in the context
+        ctx.trim()
+        free2 = torch.cuda.mem_get_info()[0]
+        assert free2 - free1 >= m * n * 8
+        A2 = A0.copy(order="F")
+        al2 = np.zeros(n)
+        pkg._lib.check(L.dhqr_qr_f64(ctx.handle, A2.ctypes.data_as(ctypes.c_void_p), m, n, m, al2.ctypes.data_as(ctypes.c_void_p), 128))
+        assert np.array_equal(A, A2) and np.array_equal(al, al2)
+        b = orc.rand_vector(m, 56)
+        x = np.zeros(n)
+        pkg._lib.check(L.dhqr_ldiv_f64(ctx.handle, A2.ctypes.data_as(ctypes.c_void_p), m, n, m, al2.ctypes.data_as(ctypes.c_void_p),
+                                       b.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p)))
+        Ho, ao = orc.householder(A0)
+        xo = orc.solve(Ho, ao, b)
+        assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    finally:
+        ctx.close()

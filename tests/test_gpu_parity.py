@@ -67,7 +67,9 @@ def test_golden_fixtures(pkg, path, nb):
                                  # columns of 16384 < rows <= 32768 (k_rankk_xtall: one column in a workgroup's registers,
                                  # 512 threads x 48 / 64 elements, reflectors streamed twice per step), even / odd m, the
                                  # hand-over from the one-reflector kernels above 32768 rows and to k_rankk_tall at 16384
-                                 (32768, 24), (20000, 64), (24577, 21), (32790, 40), (16400, 36)])
+                                 (32768, 24), (20000, 64), (24577, 21), (32790, 40), (16400, 36),
+                                 # columns above 32768 rows: one reflector per launch until a column fits a K-pass kernel
+                                 (40000, 24), (65536, 16)])
 def test_unblocked_vs_oracle(pkg, orc, m, n):
     H, A0 = _factor_dev(pkg, m, n, 3, 0)
     Ho, ao = orc.householder(orc.rand_matrix(m, n, 3))
