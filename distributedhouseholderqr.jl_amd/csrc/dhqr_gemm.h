@@ -31,6 +31,39 @@ __device__ __forceinline__ dhqr_d4 mfma_f64(double a, double b, dhqr_d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// ---- direct global -> LDS operand loads (global_load_lds_dwordx4: 16 B per lane, 1 KiB per wave instruction) -------------
+// The LDS destination of lane l is  M0 (wave-uniform byte address) + 16 l  -- a linear image; the global source is per lane,
+// so a swizzled LDS layout is made by permuting which 16-byte chunk each lane fetches.  The load is issued from inline
+// assembly ON PURPOSE: with __builtin_amdgcn_global_load_lds hipcc orders every later ds_read behind it (s_waitcnt vmcnt(0)
+// in front of the first fragment read of the CURRENT tile, i.e. no prefetch at all; distinct LDS objects per buffer did not
+// change that).  Hidden from the compiler, the load is ordered by the caller: gemm_lds_landed() (vmcnt + s_barrier) between
+// the issue and the first ds_read of that buffer by any wave.  Compiler-visible global loads issued BEFORE a batch of these
+// are still waited for correctly (its vmcnt(N) under-counts what is in flight, which only waits longer); consume them before
+// the next batch is issued (sched_barrier) or they drag the whole batch into their wait.  m0 is not allocatable and nothing
+// else in these kernels uses it.  `lds` = any pointer into the workgroup's LDS, `byte_off` wave-uniform.
+// Measured (tools/gemm_lab.hip, 16384^2, K = 512): 60.3 -> 67.9 TFLOP/s, bit-identical results; what goes away is the staging
+// registers, 8 ds_write_b128 + ~30 masking VALU per K-tile and wave, and the vmcnt wait in front of them.
+__device__ __forceinline__ void glds16(const double *g, double *lds, uint32_t byte_off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds + byte_off;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(a)) : "memory");
+#else
+  double *d = reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + byte_off) + 2 * (threadIdx.x & 63);
+  d[0] = g[0];
+  d[1] = g[1];
+#endif
+}
+// every direct load this wave issued, except the last `KEEP` vector-memory operations, has landed; then the workgroup meets
+template <int KEEP>
+__device__ __forceinline__ void gemm_lds_landed() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (KEEP == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+#else
+  __syncthreads();
+#endif
+}
+
 // -------------------------------------------------------------------------------------------
 // k_gemm_tn:  out[y][p + c*ldo] = sum_{r in slab y} V[r + p*ldv] * Ceff[r + c*ldc]
 //   p in [0,128), c in [0,ncols); slab y = rows [y*rps, min(rows,(y+1)*rps)), rps % 16 == 0.
@@ -258,11 +291,156 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_gram_batch(const double *__r
 // one per row slab (up to 12): the split-K partials written and re-read by the reduction shrink accordingly.  Segment of
 // workgroup b in tile t goes to partial slot (b - floor(t S / q), t) with S = slabs per tile; k_reduce_pieces sums a
 // tile's floor(((t + 1) S - 1) / q) - floor(t S / q) + 1 slots.
+// VEC = 2 (r5): operands by direct global -> LDS loads into a ring of THREE 48 KiB stages (glds16 above; 6 loads per wave and
+// K-tile, issued two K-tiles ahead: the leader of an XCD's workgroups pays an HBM round trip for every operand slice, which
+// one K-tile of distance does not cover), unpadded swizzled images (column c = 8 chunks of 16 B, slot s holds chunk
+// s ^ ((c >> 1) & 7)), no staging registers / ds_write / masking.  A slab whose last K-tile is partial stages that one tile
+// through registers (zeros below the slab) into the same image.  Same unit decomposition, same sums in the same order:
+// bit-identical to the register-staged program, which stays as the VEC = 1 instantiation.
+template <bool SK>
+__device__ __forceinline__ void gemm_tn2_direct(const double *__restrict__ V, int64_t ldv, const double *__restrict__ C,
+                                                int64_t ldc, int64_t rows, int64_t ncols, int64_t rps,
+                                                double *__restrict__ out, int64_t osplit_stride, int64_t skq) {
+  constexpr int NP = 256, STG = (NP + 128) * G_KT;  // doubles per stage: V image (256 columns) then C image (128)
+  __shared__ __attribute__((aligned(1024))) double ring[3 * STG];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int i16 = lane & 15, k4 = lane >> 4;
+  const int wc = w >> 2, wp = w & 3;
+  const int64_t ntiles = (ncols + 127) / 128, nslab = (rows + rps - 1) / rps;
+  const int64_t ufirst = SK ? (int64_t)blockIdx.x * skq : (int64_t)blockIdx.x;
+  const int64_t ulast = SK ? (ufirst + skq < ntiles * nslab ? ufirst + skq : ntiles * nslab) : ntiles * nslab;
+  // fragment addresses (doubles from the stage base): k-step kk, column i16 (+16 x) of the wave's 64
+  int af[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) af[kk] = i16 * G_KT + (((2 * kk + (k4 >> 1)) ^ (i16 >> 1)) * 2) + (k4 & 1);
+  // this wave's loads per K-tile: V column groups 4 w .. 4 w + 3 (8 columns each), C column groups 2 w, 2 w + 1
+  // lane -> (column lcol of the group, chunk): group g = columns 8 g .. 8 g + 7, so (column >> 1) & 7 = (4 (g & 1) + (lcol >> 1)) & 7;
+  // the i-th V group of a wave is 4 w + i, the i-th C group 2 w + i: the parity of g is the parity of i
+  const int lcol = lane >> 3;
+  const int ljp[2] = {(lane & 7) ^ (lcol >> 1), (lane & 7) ^ (4 + (lcol >> 1))};
+  uint32_t gv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gv[i] = (uint32_t)((8 * (4 * w + i) + lcol) * ldv) + 2 * ljp[i & 1];
+  for (int64_t u = ufirst; u < ulast;) {
+    int64_t ux, uy, rbeg, rend;
+    if constexpr (SK) {
+      ux = u / nslab;
+      const int64_t s0 = u - ux * nslab;
+      const int64_t s1 = (s0 + (ulast - u) < nslab) ? s0 + (ulast - u) : nslab;
+      rbeg = s0 * rps;
+      rend = (s1 * rps < rows) ? s1 * rps : rows;
+      uy = (int64_t)blockIdx.x - (ux * nslab) / skq;  // this workgroup's piece of tile ux
+      u += s1 - s0;
+    } else {
+      ux = u % ntiles;
+      uy = u / ntiles;
+      rbeg = uy * rps;
+      rend = (rbeg + rps < rows) ? rbeg + rps : rows;
+      u += gridDim.x;
+    }
+    const int64_t c0 = ux * 128;
+    const int nkt = (int)((rend - rbeg + G_KT - 1) / G_KT);
+    const int ncv = (int)((ncols - c0 < 128) ? ncols - c0 : 128);
+    const int tail = (int)(rend - rbeg) - (nkt - 1) * G_KT;  // valid rows of the last K-tile (1..16)
+    const double *Vb = V + rbeg;
+    const double *Cb = C + rbeg + c0 * ldc;
+    uint32_t gc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int col = 8 * (2 * w + i) + lcol;
+      gc[i] = (uint32_t)((col < ncv ? col : 0) * ldc) + 2 * ljp[i & 1];  // columns beyond the matrix: any valid address, never stored
+    }
+    dhqr_d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+    auto issue_tile = [&](int kt, int stage) {
+      const double *Vt = Vb + kt * G_KT;
+      const double *Ct = Cb + kt * G_KT;
+      double *st = ring + stage * STG;
+      if (kt == nkt - 1 && tail < G_KT) {  // uniform; partial tile: through registers, rows >= tail are zeros
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          double2 x = make_double2(0.0, 0.0);
+          if (2 * ljp[i & 1] < tail) x = *reinterpret_cast<const double2 *>(Vt + gv[i]);  // rows even: pair all-or-nothing
+          *reinterpret_cast<double2 *>(st + (8 * (4 * w + i)) * G_KT + 2 * lane) = x;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          double2 x = make_double2(0.0, 0.0);
+          if (2 * ljp[i & 1] < tail) x = *reinterpret_cast<const double2 *>(Ct + gc[i]);
+          *reinterpret_cast<double2 *>(st + NP * G_KT + (8 * (2 * w + i)) * G_KT + 2 * lane) = x;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(Vt + gv[i], st, (uint32_t)((8 * (4 * w + i)) * G_KT * 8));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(Ct + gc[i], st, (uint32_t)((NP * G_KT + (8 * (2 * w + i)) * G_KT) * 8));
+      }
+    };
+    auto mma_tile = [&](int stage) {
+      const double *vs = ring + stage * STG + (wp * 64) * G_KT;
+      const double *cs = ring + stage * STG + NP * G_KT + (wc * 64) * G_KT;
+#pragma unroll
+      for (int kk = 0; kk < G_KT / 4; ++kk) {
+        double a[4], b[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          a[x] = cs[af[kk] + x * 16 * G_KT];
+          b[x] = vs[af[kk] + x * 16 * G_KT];
+        }
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+          for (int pi = 0; pi < 4; ++pi) acc[ci][pi] = mfma_f64(a[ci], b[pi], acc[ci][pi]);
+      }
+    };
+    if (nkt > 0) {
+      issue_tile(0, 0);
+      if (nkt > 1) {
+        issue_tile(1, 1);
+        gemm_lds_landed<6>();  // tile 0 is in; tile 1's six loads stay in flight (a register-staged tile 1 is complete: waits longer, still right)
+      } else {
+        gemm_lds_landed<0>();
+      }
+    }
+    int s0 = 0, s1 = 1, s2 = 2;  // stages of tiles kt, kt + 1, kt + 2
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + 2 < nkt) issue_tile(kt + 2, s2);  // stage s2 was read during K-tile kt - 1: every wave is past that barrier
+      __builtin_amdgcn_sched_barrier(0);
+      mma_tile(s0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < nkt) gemm_lds_landed<6>();    // tile kt + 1 has landed everywhere; tile kt + 2 stays in flight
+      else gemm_lds_landed<0>();                 // also after the last K-tile: the next unit refills the ring
+      const int sx = s0;
+      s0 = s1;
+      s1 = s2;
+      s2 = sx;
+    }
+    double *o = out + uy * osplit_stride + c0 * NP;
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cl = wc * 64 + ci * 16 + k4 + 4 * g;
+        if (cl < ncv) {
+#pragma unroll
+          for (int pi = 0; pi < 4; ++pi) o[(uint32_t)(wp * 64 + pi * 16 + i16) + (uint32_t)(cl * NP)] = acc[ci][pi][g];
+        }
+      }
+  }
+}
+
 template <int VEC, bool SK = false>
 __global__ __launch_bounds__(512) void k_gemm_tn2(const double *__restrict__ V, int64_t ldv,
                                                   const double *__restrict__ C, int64_t ldc, int64_t rows,
                                                   int64_t ncols, int64_t rps, double *__restrict__ out,
                                                   int64_t osplit_stride, int64_t skq) {
+  if constexpr (VEC == 2) {
+    gemm_tn2_direct<SK>(V, ldv, C, ldc, rows, ncols, rps, out, osplit_stride, skq);
+    return;
+  }
   constexpr int NP = 256;
   __shared__ __attribute__((aligned(16))) double Vs[2][NP * G_LDK];
   __shared__ __attribute__((aligned(16))) double Cs[2][128 * G_LDK];
@@ -439,8 +617,11 @@ __device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, i
   constexpr int LDRV = (TR == 128) ? G_LDR : 66;   // LDS stride of a V tile column (k rows 4 banks apart for ds_read_b128)
   constexpr int NVL = TR / 32;                     // V staging chunks per thread: 16 p x TR/2 row pairs / 256 threads
   constexpr int RPSH = (TR == 128) ? 6 : 5;        // log2(row pairs per tile column)
-  __shared__ __attribute__((aligned(16))) double Vs[2][G_KT * LDRV];
-  __shared__ __attribute__((aligned(16))) double Ws[2][128 * G_LDK];
+  // one LDS block, two views: [Vs | Ws] padded (register-staged general path) and, for the interior tiles of the trailing
+  // updates, four linear 16 KiB operand images filled by direct loads (below)
+  __shared__ __attribute__((aligned(1024))) double lds_raw[2 * G_KT * LDRV + 2 * 128 * G_LDK];
+  double(*const Vs)[G_KT * LDRV] = reinterpret_cast<double(*)[G_KT * LDRV]>(lds_raw);
+  double(*const Ws)[128 * G_LDK] = reinterpret_cast<double(*)[128 * G_LDK]>(lds_raw + 2 * G_KT * LDRV);
   if (stat != nullptr && stat[0] <= epoch) return;  // uniform: every workgroup of the launch takes the same branch
   long long tph[5] = {0, 0, 0, 0, 0};
   if constexpr (TIME) tph[0] = clock64();
@@ -519,14 +700,17 @@ __device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, i
     }
   };
 
-  load_tile(0);
+  // interior tiles of the trailing updates take the direct-to-LDS program below; everything else is register staged
+  constexpr bool STREAM = !INIT0 && VEC == 2 && (KW == 512 || KW == 256 || KW == 128) && TR == 128;
+  const bool full = (VEC == 2) && nrv == TR && ncv == 128;
+  const bool direct = STREAM && full && below2;  // uniform
+  if (!direct) load_tile(0);
 
   // Accumulator map.  The 16 x 16 MFMA tile ri of a wave does NOT hold 16 consecutive rows: lane i16 of tile ri owns
   // row 4*i16 + ri of the wave's 64 rows (the V fragments are read with the same map), so the four tiles together
   // give every lane FOUR CONSECUTIVE ROWS per column:  lane (i16,k4), register g of tile (ci,ri) holds
   //     C[r0 + wr*64 + 4*i16 + ri][c0 + wc*64 + ci*16 + k4 + 4g].
   // Interior tiles move C with 16-byte accesses (32 B per lane and column, 512 contiguous bytes per 16 lanes).
-  const bool full = (VEC == 2) && nrv == TR && ncv == 128;
   constexpr int NKT = KW / G_KT;
   dhqr_d4 acc[NCI][4];
   auto mma_tile = [&](int buf) {
@@ -578,22 +762,75 @@ __device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, i
     }
   };
 
-  // ---- interior tiles of the trailing updates: C streams in DURING the K loop --------------------------------------
-  // acc = C - V W is a sum: the accumulators start at zero and every K-tile adds 16 / NKT of the lane's sixteen
-  // (column, 4-row) units of C, requested at the top of the K-tile and added below its 64 MFMAs.  The tile has no
-  // C prologue any more.  Why: with the C tile fetched up front the whole chip falls into a convoy -- every workgroup
-  // waits for its 128 KB while the HBM serves all 512 of them at once (phase clock: 28k of a tile's 167k cycles with
-  // idle matrix pipes; during the K loops the two waves of a SIMD saturate the pipe, 2 x 1024 x 64 cycles), and waiting
-  // on a saturated memory re-forms the convoy after any perturbation (random start phases changed nothing).  Streaming
+  // ---- interior tiles of the trailing updates: operands by direct loads, C streams in DURING the K loop ---------------
+  // acc = V W - C is a sum: the accumulators start at zero and every K-tile subtracts 16 / NKT of the lane's sixteen
+  // (column, 4-row) units of C, requested at the top of the K-tile and subtracted below its 64 MFMAs; the stores write
+  // -acc (the same numbers, bit for bit, as C - V W accumulated with a negated W).  The tile has no C prologue.  Why: with
+  // the C tile fetched up front the whole chip falls into a convoy -- every workgroup waits for its 128 KB while the HBM
+  // serves all 512 of them at once (phase clock: 28k of a tile's 167k cycles with idle matrix pipes), and waiting on a
+  // saturated memory re-forms the convoy after any perturbation (random start phases changed nothing).  Streaming
   // spreads the same reads evenly over the K loops.
-  constexpr bool STREAM = !INIT0 && VEC == 2 && (KW == 512 || KW == 256 || KW == 128) && TR == 128;
-  if constexpr (STREAM) if (full && below2) {  // uniform branch
+  // Operands (r5): global -> LDS directly (glds16), two 32 KiB stages, the next K-tile's 8 loads per wave issued at the
+  // top of the current one; one wait + barrier per K-tile.  LDS images (linear per wave instruction; the swizzle is in
+  // the per-lane global address, conflict-free fragment reads without padding):
+  //   V tile: column p (16) = 64 chunks of 16 B (rows 2 ch, 2 ch + 1); position pos holds chunk pos ^ ((pos >> 4) & 1)
+  //   W tile: column c (128) = 8 chunks of 16 B (k = 2 j, 2 j + 1);     slot s holds chunk s ^ ((c >> 1) & 7)
+  // Per workgroup-timeline (tools/gemm_lab.hip, gemm_lab_timeline.py, 16384^2): tile = 288k cycles of which the K loop
+  // 272k (floor with two workgroups per CU: 262k), prologue 9k, stores 7k, 7k until the successor starts.
+  if constexpr (STREAM) if (direct) {  // uniform branch
+    double *const Vg = lds_raw, *const Wg = lds_raw + 2 * G_KT * 128;  // [2][16 * 128] each
+    uint32_t gv[4], gw[4];  // this wave's 4 V columns (p = 4 w + i) and 4 W column groups (columns 8 (4 w + i) .. + 7)
+    {
+      const int ch = lane ^ ((lane >> 4) & 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        gv[i] = (uint32_t)((4 * w + i) * ldv) + 2 * ch;
+        const int col = 8 * (4 * w + i) + (lane >> 3), j = (lane & 7) ^ ((col >> 1) & 7);
+        gw[i] = (uint32_t)(col * ldw) + 2 * j;
+      }
+    }
+    auto issue_tile = [&](int kt) {
+      const double *Vt = (KW == 512 && kt >= KW / (2 * G_KT)) ? Vb2 + (int64_t)(kt - KW / (2 * G_KT)) * G_KT * ldv
+                                                              : Vb + (int64_t)kt * G_KT * ldv;
+      const double *Wt = Wb + kt * G_KT;
+      const uint32_t bo = (uint32_t)(((kt & 1) * G_KT * 128 + (4 * w) * 128) * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        glds16(Vt + gv[i], Vg, bo + (uint32_t)i * 1024u);
+        glds16(Wt + gw[i], Wg, bo + (uint32_t)i * 1024u);
+      }
+    };
+    int aw[4];  // W fragment of k-step kk: column wc*64 + i16 (+16 x), chunk (2 kk + (k4 >> 1)) ^ (i16 >> 1), half k4 & 1
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) aw[kk] = (wc * 64 + i16) * G_KT + (((2 * kk + (k4 >> 1)) ^ (i16 >> 1)) * 2) + (k4 & 1);
+    const int ch0 = wr * 32 + 2 * i16, fl = (i16 >> 3) & 1;  // rows 4 i16 .. + 3 of the wave: chunks ch0, ch0 + 1
+    const int av0 = k4 * 128 + ((ch0 ^ fl) * 2), av1 = k4 * 128 + (((ch0 ^ fl) ^ 1) * 2);
+    auto mma_direct = [&](int buf) {
+      const double *ws = Wg + buf * (G_KT * 128);
+      const double *vs = Vg + buf * (G_KT * 128);
+#pragma unroll
+      for (int kk = 0; kk < G_KT / 4; ++kk) {
+        double a[4], b[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) a[x] = ws[aw[kk] + x * 16 * G_KT];
+        const double2 b01 = *reinterpret_cast<const double2 *>(vs + av0 + kk * 4 * 128);
+        const double2 b23 = *reinterpret_cast<const double2 *>(vs + av1 + kk * 4 * 128);
+        b[0] = b01.x;
+        b[1] = b01.y;
+        b[2] = b23.x;
+        b[3] = b23.y;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+          for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = mfma_f64(a[ci], b[ri], acc[ci][ri]);
+      }
+    };
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
       for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
-    store_tile(0);
-    __syncthreads();
+    issue_tile(0);
+    gemm_lds_landed<0>();
     if constexpr (TIME) tph[1] = clock64();
     constexpr int KTPU = NKT > 16 ? NKT / 16 : 1;     // K-tiles per unit (KW = 512: a unit every second K-tile)
     constexpr int UPT = NKT > 16 ? 1 : 16 / NKT;      // units per K-tile that carries units
@@ -610,28 +847,36 @@ __device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, i
           cin += cstep;
         }
       }
-      if (kt + 1 < NKT) load_tile(kt + 1);
+      if (kt + 1 < NKT) issue_tile(kt + 1);
       __builtin_amdgcn_sched_barrier(0);
-      mma_tile(kt & 1);
+      mma_direct(kt & 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (kt + 1 < NKT) store_tile((kt & 1) ^ 1);
       if (carry) {
 #pragma unroll
         for (int u = 0; u < UPT; ++u) {
           const int ci = ((kt / KTPU) * UPT + u) >> 2, g = ((kt / KTPU) * UPT + u) & 3;
-          acc[ci][0][g] += cu[u][0].x;
-          acc[ci][1][g] += cu[u][0].y;
-          acc[ci][2][g] += cu[u][1].x;
-          acc[ci][3][g] += cu[u][1].y;
+          acc[ci][0][g] -= cu[u][0].x;
+          acc[ci][1][g] -= cu[u][0].y;
+          acc[ci][2][g] -= cu[u][1].x;
+          acc[ci][3][g] -= cu[u][1].y;
         }
       }
-      if (kt + 1 < NKT) __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);  // the C units are consumed (their vmcnt wait sits) BEFORE the next loads go out
+      if (kt + 1 < NKT) gemm_lds_landed<0>();
     }
     if constexpr (TIME) {
       __builtin_amdgcn_sched_barrier(0);
       tph[2] = clock64();
     }
-    store_full();
+    {
+      double *cp = cunit0;
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        *reinterpret_cast<double2 *>(cp) = make_double2(-acc[n >> 2][0][n & 3], -acc[n >> 2][1][n & 3]);
+        *reinterpret_cast<double2 *>(cp + 2) = make_double2(-acc[n >> 2][2][n & 3], -acc[n >> 2][3][n & 3]);
+        cp += cstep;
+      }
+    }
     time_end();
     return;
   }

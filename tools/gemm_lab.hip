@@ -1,0 +1,518 @@
+// gemm_lab.hip -- standalone laboratory for the wide subtraction C -= [V | V2] W (k_gemm_nn_quad / k_gemm_nn_sub of
+// csrc/dhqr_gemm.h): ablations of the shipped kernel, a per-workgroup timeline, and candidate rewrites, each checked
+// bit for bit against the shipped kernel on random operands.  Torch-free, seconds to build:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/gemm_lab.hip -o tools/gemm_lab
+//   tools/gemm_lab <variant> [rows ncols reps [timeline.bin]]
+// Not part of the product.
+#include "../distributedhouseholderqr.jl_amd/csrc/dhqr_gemm.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CK(x)                                                                                   \
+  do {                                                                                          \
+    hipError_t e_ = (x);                                                                        \
+    if (e_ != hipSuccess) {                                                                     \
+      fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));         \
+      exit(1);                                                                                  \
+    }                                                                                           \
+  } while (0)
+
+enum { F_TL = 1, F_NOC = 2, F_NOSTAGE = 4, F_NOBAR = 8, F_PRIO = 16, F_CLATE = 32, F_TL2 = 64 };
+#define TLS 232  // timeline words per workgroup: 40 (F_TL) + 32 K-tiles x (wave 0: after vmcnt wait, after barrier... see F_TL2)
+
+__global__ void k_fill(double *x, int64_t n, uint64_t seed, double scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = (dhqr_u01(seed, (uint64_t)i) - 0.5) * scale;
+}
+__global__ void k_neg(double *x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = -x[i];
+}
+__global__ void k_diff(const double *a, const double *b, int64_t n, unsigned long long *ndiff, double *maxabs) {
+  unsigned long long c = 0;
+  double m = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (__double_as_longlong(a[i]) != __double_as_longlong(b[i])) ++c;
+    const double d = fabs(a[i] - b[i]);
+    if (d > m || d != d) m = d;
+  }
+  if (c) atomicAdd(ndiff, c);
+  if (m > 0.0 || m != m) atomicMax((unsigned long long *)maxabs, (unsigned long long)__double_as_longlong(m != m ? 1e300 : m));
+}
+
+__device__ __forceinline__ void tile_of(int64_t rows, int64_t ncols, int64_t &tr, int64_t &tc, bool &ok) {
+  const int64_t gx = (rows + 127) / 128, gy = (ncols + 127) / 128;
+  const int64_t bx = (gx + 7) / 8;
+  const int64_t L = blockIdx.x;
+  const int64_t xcd = L & 7, sq = L >> 3;
+  const int64_t blk = (sq >> 6) * 8 + xcd, idx = sq & 63;
+  tr = (blk % bx) * 8 + (idx & 7);
+  tc = (blk / bx) * 8 + (idx >> 3);
+  ok = tr < gx && tc < gy;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// lab_nn: the interior-tile ("STREAM") path of gemm_nn_sub_body, copied, with ablation flags and a timeline.
+template <int KW, int FL>
+__global__ __launch_bounds__(256, 2) void lab_nn(const double *__restrict__ V, const double *__restrict__ V2, int64_t ldv,
+                                                 const double *__restrict__ W, int64_t ldw, double *__restrict__ C,
+                                                 int64_t ldc, int64_t rows, int64_t ncols, unsigned long long *tl,
+                                                 int never) {
+  constexpr int NKT = KW / G_KT;
+  __shared__ __attribute__((aligned(16))) double Vs[2][G_KT * G_LDR];
+  __shared__ __attribute__((aligned(16))) double Ws[2][128 * G_LDK];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int i16 = lane & 15, k4 = lane >> 4;
+  const int wr = w & 1, wc = w >> 1;
+  int64_t tr, tc;
+  bool ok;
+  tile_of(rows, ncols, tr, tc, ok);
+  if (!ok) return;
+  unsigned long long *mytl = tl + (int64_t)blockIdx.x * TLS;
+  if constexpr (FL & F_TL) {
+    if (t == 0) {
+      mytl[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      mytl[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      mytl[2] = __builtin_amdgcn_s_memtime();
+    }
+  }
+  if constexpr (FL & F_PRIO) {
+    if (__builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 8)) & 1) __builtin_amdgcn_s_setprio(1);
+  }
+  const int64_t r0 = tr * 128, c0 = tc * 128;
+  const double *Vb = V + r0, *Vb2 = V2 + r0, *Wb = W + c0 * ldw;
+  double *Cb = C + r0 + c0 * ldc;
+  uint32_t offv[4], offw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = t + i * 256;
+    offv[i] = (uint32_t)(((q >> 6) & 15) * ldv) + 2 * (q & 63);
+    offw[i] = (uint32_t)((q >> 3) * ldw) + 2 * (q & 7);
+  }
+  double2 sv[4], sw[4];
+  auto load_tile = [&](int kt) {
+    const double *Vt = (KW == 512 && kt >= KW / (2 * G_KT)) ? Vb2 + (int64_t)(kt - KW / (2 * G_KT)) * G_KT * ldv
+                                                            : Vb + (int64_t)kt * G_KT * ldv;
+    const double *Wt = Wb + kt * G_KT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sv[i] = *reinterpret_cast<const double2 *>(Vt + offv[i]);
+      sw[i] = *reinterpret_cast<const double2 *>(Wt + offw[i]);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = t + i * 256;
+      *reinterpret_cast<double2 *>(&Vs[buf][(q >> 6) * G_LDR + 2 * (q & 63)]) = sv[i];
+      *reinterpret_cast<double2 *>(&Ws[buf][(q >> 3) * G_LDK + 2 * (q & 7)]) = make_double2(-sw[i].x, -sw[i].y);
+    }
+  };
+  load_tile(0);
+  dhqr_d4 acc[4][4];
+  auto mma_tile = [&](int buf) {
+    const double *ws = &Ws[buf][(wc * 64 + i16) * G_LDK + k4];
+    const double *vs = &Vs[buf][k4 * G_LDR + wr * 64 + 4 * i16];
+#pragma unroll
+    for (int kk = 0; kk < G_KT / 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) a[x] = ws[x * 16 * G_LDK + kk * 4];
+      const double2 b01 = *reinterpret_cast<const double2 *>(vs + kk * 4 * G_LDR);
+      const double2 b23 = *reinterpret_cast<const double2 *>(vs + kk * 4 * G_LDR + 2);
+      b[0] = b01.x; b[1] = b01.y; b[2] = b23.x; b[3] = b23.y;
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = mfma_f64(a[ci], b[ri], acc[ci][ri]);
+    }
+  };
+  double *const cunit0 = Cb + ((uint32_t)((wc * 64 + k4) * ldc) + (uint32_t)(wr * 64 + 4 * i16));
+  const int64_t cstep = 4 * ldc;
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+  store_tile(0);
+  __syncthreads();
+  if constexpr (FL & F_TL) if (t == 0) mytl[3] = __builtin_amdgcn_s_memtime();
+  constexpr int KTPU = NKT > 16 ? NKT / 16 : 1;
+  constexpr int UPT = NKT > 16 ? 1 : 16 / NKT;
+  const double *cin = cunit0;
+  double2 cu[UPT][2];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const bool carry = (kt % KTPU) == 0;
+    constexpr bool late = (FL & F_CLATE) && KTPU == 2;  // C requested behind the operand loads, added one K-tile later
+    if (!(FL & F_NOC) && carry && !late) {
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) {
+        cu[u][0] = *reinterpret_cast<const double2 *>(cin);
+        cu[u][1] = *reinterpret_cast<const double2 *>(cin + 2);
+        cin += cstep;
+      }
+    }
+    if (!(FL & F_NOSTAGE) && kt + 1 < NKT) load_tile(kt + 1);
+    if (!(FL & F_NOC) && carry && late) {
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) {
+        cu[u][0] = *reinterpret_cast<const double2 *>(cin);
+        cu[u][1] = *reinterpret_cast<const double2 *>(cin + 2);
+        cin += cstep;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tile((FL & F_NOSTAGE) ? 0 : (kt & 1));
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(FL & F_NOSTAGE) && kt + 1 < NKT) store_tile((kt & 1) ^ 1);
+    if (!(FL & F_NOC) && (late ? !carry : carry)) {
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) {
+        const int ci = ((kt / KTPU) * UPT + u) >> 2, g = ((kt / KTPU) * UPT + u) & 3;
+        acc[ci][0][g] += cu[u][0].x;
+        acc[ci][1][g] += cu[u][0].y;
+        acc[ci][2][g] += cu[u][1].x;
+        acc[ci][3][g] += cu[u][1].y;
+      }
+    }
+    if (!(FL & F_NOBAR) && kt + 1 < NKT) __syncthreads();
+    if constexpr (FL & F_TL) if (t == 0) mytl[4 + kt] = __builtin_amdgcn_s_memtime();
+  }
+  if (!(FL & F_NOC) || never) {
+    double *cp = cunit0;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      *reinterpret_cast<double2 *>(cp) = make_double2(acc[n >> 2][0][n & 3], acc[n >> 2][1][n & 3]);
+      *reinterpret_cast<double2 *>(cp + 2) = make_double2(acc[n >> 2][2][n & 3], acc[n >> 2][3][n & 3]);
+      cp += cstep;
+    }
+  }
+  if constexpr (FL & F_TL) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (t == 0) mytl[4 + NKT] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (t == 0) mytl[5 + NKT] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+// direct global -> LDS load of 16 B per lane, issued behind the compiler's back: with the builtin, hipcc orders every later
+// ds_read behind the load (s_waitcnt vmcnt(0) before the first fragment read: no prefetch at all).  The LDS destination is
+// M0 (wave-uniform byte address) + lane * 16.  The caller orders the data itself: s_waitcnt vmcnt + s_barrier.
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
+__device__ __forceinline__ void glds16(const double *g, uint32_t lds_byte) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_byte))
+               : "memory");  // m0 is reserved (not allocatable): nothing else in these kernels uses it
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// lab_glds: the same tile program with the operands loaded global -> LDS directly (no staging registers, no ds_write, no
+// masking VALU).  W is NOT negated on the way in: acc = V W - C, the stores write -acc (bitwise the same numbers).
+// LDS images (linear per wave instruction, the swizzle is in the per-lane global address):
+//   V tile: column p (16 of them) = 64 chunks of 16 B (rows 2ch, 2ch+1); position pos holds chunk pos ^ ((pos >> 4) & 1)
+//   W tile: column c (128 of them) = 8 chunks of 16 B (k = 2j, 2j+1);   slot s holds chunk s ^ ((c >> 1) & 7)
+template <int KW, int FL>
+__global__ __launch_bounds__(256, 2) void lab_glds(const double *__restrict__ V, const double *__restrict__ V2, int64_t ldv,
+                                                   const double *__restrict__ W, int64_t ldw, double *__restrict__ C,
+                                                   int64_t ldc, int64_t rows, int64_t ncols, unsigned long long *tl,
+                                                   int never) {
+  constexpr int NKT = KW / G_KT;
+  // one LDS object per buffer: the compiler orders a ds_read behind an in-flight direct load (vmcnt) unless it can tell
+  // the objects apart
+  __shared__ __attribute__((aligned(1024))) double Vs0[G_KT * 128], Vs1[G_KT * 128];
+  __shared__ __attribute__((aligned(1024))) double Ws0[128 * G_KT], Ws1[128 * G_KT];
+  __shared__ unsigned long long stamp[(FL & F_TL) ? TLS : 1];  // in-loop stamps go to LDS (a global store would sit in vmcnt)
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int i16 = lane & 15, k4 = lane >> 4;
+  const int wr = w & 1, wc = w >> 1;
+  int64_t tr, tc;
+  bool ok;
+  tile_of(rows, ncols, tr, tc, ok);
+  if (!ok) return;
+  unsigned long long *mytl = tl + (int64_t)blockIdx.x * TLS;
+  if constexpr (FL & F_TL) {
+    if (t == 0) {
+      mytl[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      mytl[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      mytl[2] = __builtin_amdgcn_s_memtime();
+    }
+  }
+  const int64_t r0 = tr * 128, c0 = tc * 128;
+  const double *Vb = V + r0, *Vb2 = V2 + r0, *Wb = W + c0 * ldw;
+  double *Cb = C + r0 + c0 * ldc;
+  // this wave's 4 V columns (p = 4 w + i) and 4 W column groups (q = 4 w + i: columns 8 q .. 8 q + 7)
+  uint32_t offv[4], offw[4];
+  {
+    const int ch = lane ^ ((lane >> 4) & 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      offv[i] = (uint32_t)((4 * w + i) * ldv) + 2 * ch;
+      const int col = 8 * (4 * w + i) + (lane >> 3), j = (lane & 7) ^ ((col >> 1) & 7);
+      offw[i] = (uint32_t)(col * ldw) + 2 * j;
+    }
+  }
+  const uint32_t lv0 = lds_addr(Vs0), lv1 = lds_addr(Vs1), lw0 = lds_addr(Ws0), lw1 = lds_addr(Ws1);
+  auto issue_tile = [&](int kt, int buf) {
+    const double *Vt = (KW == 512 && kt >= KW / (2 * G_KT)) ? Vb2 + (int64_t)(kt - KW / (2 * G_KT)) * G_KT * ldv
+                                                            : Vb + (int64_t)kt * G_KT * ldv;
+    const double *Wt = Wb + kt * G_KT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(Vt + offv[i], (buf ? lv1 : lv0) + (uint32_t)(4 * w + i) * 1024u);
+      glds16(Wt + offw[i], (buf ? lw1 : lw0) + (uint32_t)(4 * w + i) * 1024u);
+    }
+  };
+  dhqr_d4 acc[4][4];
+  // fragment addresses (doubles)
+  int aw[4];  // W fragment base per kk: column (wc*64 + i16), chunk ((2kk + (k4>>1)) ^ (i16>>1)), half (k4&1)
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) aw[kk] = (wc * 64 + i16) * G_KT + (((2 * kk + (k4 >> 1)) ^ (i16 >> 1)) * 2) + (k4 & 1);
+  const int ch0 = wr * 32 + 2 * i16, fl = (i16 >> 3) & 1;
+  const int av0 = k4 * 128 + ((ch0 ^ fl) * 2), av1 = k4 * 128 + (((ch0 ^ fl) ^ 1) * 2);
+  auto mma_tile = [&](int buf) {
+    const double *ws = buf ? Ws1 : Ws0;
+    const double *vs = buf ? Vs1 : Vs0;
+#pragma unroll
+    for (int kk = 0; kk < G_KT / 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) a[x] = ws[aw[kk] + x * 16 * G_KT];
+      const double2 b01 = *reinterpret_cast<const double2 *>(vs + av0 + kk * 4 * 128);
+      const double2 b23 = *reinterpret_cast<const double2 *>(vs + av1 + kk * 4 * 128);
+      b[0] = b01.x; b[1] = b01.y; b[2] = b23.x; b[3] = b23.y;
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = mfma_f64(a[ci], b[ri], acc[ci][ri]);
+    }
+  };
+  double *const cunit0 = Cb + ((uint32_t)((wc * 64 + k4) * ldc) + (uint32_t)(wr * 64 + 4 * i16));
+  const int64_t cstep = 4 * ldc;
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = (dhqr_d4){0.0, 0.0, 0.0, 0.0};
+  issue_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if constexpr (FL & F_TL) if (t == 0) stamp[3] = __builtin_amdgcn_s_memtime();
+  constexpr int KTPU = NKT > 16 ? NKT / 16 : 1;
+  constexpr int UPT = NKT > 16 ? 1 : 16 / NKT;
+  const double *cin = cunit0;
+  double2 cu[UPT][2];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const bool carry = (kt % KTPU) == 0;
+    constexpr bool late = (FL & F_CLATE) && KTPU == 2;
+    if (!(FL & F_NOC) && carry && !late) {
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) {
+        cu[u][0] = *reinterpret_cast<const double2 *>(cin);
+        cu[u][1] = *reinterpret_cast<const double2 *>(cin + 2);
+        cin += cstep;
+      }
+    }
+    if (kt + 1 < NKT) issue_tile(kt + 1, (kt + 1) & 1);
+    if (!(FL & F_NOC) && carry && late) {
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) {
+        cu[u][0] = *reinterpret_cast<const double2 *>(cin);
+        cu[u][1] = *reinterpret_cast<const double2 *>(cin + 2);
+        cin += cstep;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tile(kt & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FL & F_TL2) {  // every wave: the last MFMA of the K-tile has been issued
+      if (lane == 0) stamp[40 + 6 * kt + w] = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!(FL & F_NOC) && (late ? !carry : carry)) {
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) {
+        const int ci = ((kt / KTPU) * UPT + u) >> 2, g = ((kt / KTPU) * UPT + u) & 3;
+        acc[ci][0][g] -= cu[u][0].x;
+        acc[ci][1][g] -= cu[u][0].y;
+        acc[ci][2][g] -= cu[u][1].x;
+        acc[ci][3][g] -= cu[u][1].y;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the C units are added (and their vmcnt wait sits) BEFORE the next tile's loads go out
+    if (kt + 1 < NKT) {
+      if (late && carry) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // the two C loads issued last stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (FL & F_TL2) if (t == 0) stamp[40 + 6 * kt + 4] = __builtin_amdgcn_s_memtime();  // operands of the next tile landed
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    if constexpr (FL & F_TL) if (t == 0) stamp[4 + kt] = __builtin_amdgcn_s_memtime();
+  }
+  if (!(FL & F_NOC) || never) {
+    double *cp = cunit0;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      *reinterpret_cast<double2 *>(cp) = make_double2(-acc[n >> 2][0][n & 3], -acc[n >> 2][1][n & 3]);
+      *reinterpret_cast<double2 *>(cp + 2) = make_double2(-acc[n >> 2][2][n & 3], -acc[n >> 2][3][n & 3]);
+      cp += cstep;
+    }
+  }
+  if constexpr (FL & F_TL) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (t == 0) mytl[4 + NKT] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (t == 0) mytl[5 + NKT] = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    for (int i = 3 + t; i < TLS; i += 256)
+      if (i < 4 + NKT || i >= 40) mytl[i] = stamp[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct Variant {
+  const char *name;
+  int kw;
+  void (*fn)(const double *, const double *, int64_t, const double *, int64_t, double *, int64_t, int64_t, int64_t,
+             unsigned long long *, int);
+  bool exact;  // expected to reproduce the shipped kernel bit for bit
+  bool tl;
+};
+
+int main(int argc, char **argv) {
+  const std::string want = argc > 1 ? argv[1] : "all";
+  const int64_t rows = argc > 2 ? atoll(argv[2]) : 16384, ncols = argc > 3 ? atoll(argv[3]) : 16384;
+  const int reps = argc > 4 ? atoi(argv[4]) : 5;
+  const char *tlfile = argc > 5 ? argv[5] : nullptr;
+  const int warm = getenv("LAB_WARM") ? atoi(getenv("LAB_WARM")) : 20;  // launches before the timed ones (clocks settle under load)
+  if (rows % 128 || ncols % 128) return 2;
+  const int64_t ldv = rows, ldc = rows, ldw = 512;
+  double *V, *W, *Wn, *C, *C0, *Cref;
+  unsigned long long *tl, *nd;
+  double *mx;
+  const int64_t gx = rows / 128, gy = ncols / 128;
+  const unsigned grid = (unsigned)((((gx + 7) / 8) * ((gy + 7) / 8) + 7) / 8 * 512);
+  CK(hipMalloc(&V, (size_t)ldv * 512 * 8));
+  CK(hipMalloc(&W, (size_t)ldw * ncols * 8));
+  CK(hipMalloc(&Wn, (size_t)ldw * ncols * 8));
+  CK(hipMalloc(&C, (size_t)ldc * ncols * 8));
+  CK(hipMalloc(&C0, (size_t)ldc * ncols * 8));
+  CK(hipMalloc(&Cref, (size_t)ldc * ncols * 8));
+  CK(hipMalloc(&tl, (size_t)grid * TLS * 8));
+  CK(hipMalloc(&nd, 8));
+  CK(hipMalloc(&mx, 8));
+  hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, V, ldv * 512, 1ull, 2.0);
+  hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, W, ldw * ncols, 2ull, 2.0);
+  hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, C0, ldc * ncols, 3ull, 2.0);
+  CK(hipDeviceSynchronize());
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+
+  const Variant vars[] = {
+      {"nn512", 512, lab_nn<512, 0>, true, false},
+      {"nn512_tl", 512, lab_nn<512, F_TL>, true, true},
+      {"nn512_noc", 512, lab_nn<512, F_NOC>, false, false},
+      {"nn512_nostage", 512, lab_nn<512, F_NOC | F_NOSTAGE>, false, false},
+      {"nn512_nobar", 512, lab_nn<512, F_NOC | F_NOSTAGE | F_NOBAR>, false, false},
+      {"nn512_prio", 512, lab_nn<512, F_PRIO>, true, false},
+      {"nn512_clate", 512, lab_nn<512, F_CLATE>, false, false},
+      {"glds512", 512, lab_glds<512, 0>, true, false},
+      {"glds512_tl", 512, lab_glds<512, F_TL>, true, true},
+      {"glds512_tl2", 512, lab_glds<512, F_TL | F_TL2>, true, true},
+      {"glds512_clate", 512, lab_glds<512, F_CLATE>, false, false},
+      {"glds512_noc", 512, lab_glds<512, F_NOC>, false, false},
+      {"nn256", 256, lab_nn<256, 0>, true, false},
+      {"glds256", 256, lab_glds<256, 0>, true, false},
+  };
+  auto run_ship = [&](int kw, double *Cx) {
+    if (kw == 512)
+      hipLaunchKernelGGL((k_gemm_nn_quad<2, 128>), dim3(grid), dim3(256), 0, 0, (const double *)V, (const double *)(V + 256 * ldv),
+                         ldv, (int64_t)0, (const double *)W, ldw, Cx, ldc, rows, ncols, 1, (const int *)nullptr, 0);
+    else
+      hipLaunchKernelGGL((k_gemm_nn_sub<2, 256>), dim3(grid), dim3(256), 0, 0, (const double *)V, ldv, (const double *)W, ldw, Cx,
+                         ldc, rows, ncols, 1, (const int *)nullptr, 0);
+  };
+  auto time_it = [&](auto &&launch, const char *name, int kw) {
+    for (int r = 0; r < warm; ++r) launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    for (int r = 0; r < reps; ++r) launch();
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, a, b));
+    ms /= reps;
+    const double tf = 2.0 * kw * (double)rows * (double)ncols / (ms * 1e-3) / 1e12;
+    printf("%-16s K=%d %lldx%lld: %.3f ms  %.2f TFLOP/s  (%.3f of 78.6)", name, kw, (long long)rows, (long long)ncols, ms, tf, tf / 78.6);
+  };
+  if (want == "all" || want == "tn2") {  // stream-K k_gemm_tn2: register-staged (VEC = 1) against direct loads (VEC = 2), every partial slot
+    const int64_t FU = 128, S = (rows + FU - 1) / FU, ntl = ncols / 128, U = ntl * S;
+    const int64_t G = U < 256 ? U : 256, q = (U + G - 1) / G, Gq = (U + q - 1) / q;
+    const int64_t pieces = (q >= S) ? 2 : (S + q - 1) / q + 1, wstride = 256 * ncols;
+    double *o1, *o2;
+    CK(hipMalloc(&o1, (size_t)pieces * wstride * 8));
+    CK(hipMalloc(&o2, (size_t)pieces * wstride * 8));
+    CK(hipMemset(o1, 0, (size_t)pieces * wstride * 8));
+    CK(hipMemset(o2, 0, (size_t)pieces * wstride * 8));
+    auto l1 = [&]() { hipLaunchKernelGGL((k_gemm_tn2<1, true>), dim3((unsigned)Gq), dim3(512), 0, 0, (const double *)V, ldv, (const double *)C0, ldc, rows, ncols, FU, o1, wstride, q); };
+    auto l2 = [&]() { hipLaunchKernelGGL((k_gemm_tn2<2, true>), dim3((unsigned)Gq), dim3(512), 0, 0, (const double *)V, ldv, (const double *)C0, ldc, rows, ncols, FU, o2, wstride, q); };
+    for (int rep = 0; rep < 2; ++rep) {
+      time_it(l1, "tn2_staged", 256);
+      printf("\n");
+      time_it(l2, "tn2_direct", 256);
+      CK(hipMemset(nd, 0, 8));
+      CK(hipMemset(mx, 0, 8));
+      hipLaunchKernelGGL(k_diff, dim3(1024), dim3(256), 0, 0, (const double *)o1, (const double *)o2, pieces * wstride, nd, mx);
+      unsigned long long hnd;
+      double hmx;
+      CK(hipMemcpy(&hnd, nd, 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(&hmx, mx, 8, hipMemcpyDeviceToHost));
+      printf("  | staged vs direct: %llu elements differ, max |d| %.3g%s\n", hnd, hmx, hnd ? "  ** MISMATCH **" : "  (bitwise equal)");
+    }
+    CK(hipFree(o1));
+    CK(hipFree(o2));
+  }
+  for (int kw : {512, 256}) {
+    if (want == "all" || want == "ship") {
+      time_it([&]() { run_ship(kw, C); }, kw == 512 ? "ship_quad" : "ship_nn256", kw);
+      printf("\n");
+    }
+  }
+  for (const Variant &v : vars) {
+    if (!(want == "all" || want == v.name)) continue;
+    if (v.tl && !tlfile && want == "all") continue;
+    // reference result of one application
+    CK(hipMemcpy(Cref, C0, (size_t)ldc * ncols * 8, hipMemcpyDeviceToDevice));
+    run_ship(v.kw, Cref);
+    CK(hipMemcpy(C, C0, (size_t)ldc * ncols * 8, hipMemcpyDeviceToDevice));
+    CK(hipMemset(tl, 0, (size_t)grid * TLS * 8));
+    const double *V2 = v.kw == 512 ? V + 256 * ldv : V;
+    hipLaunchKernelGGL(v.fn, dim3(grid), dim3(256), 0, 0, (const double *)V, V2, ldv, (const double *)W, ldw, C, ldc, rows, ncols, tl, 0);
+    CK(hipDeviceSynchronize());
+    CK(hipMemset(nd, 0, 8));
+    CK(hipMemset(mx, 0, 8));
+    hipLaunchKernelGGL(k_diff, dim3(1024), dim3(256), 0, 0, (const double *)C, (const double *)Cref, ldc * ncols, nd, mx);
+    unsigned long long hnd;
+    double hmx;
+    CK(hipMemcpy(&hnd, nd, 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&hmx, mx, 8, hipMemcpyDeviceToHost));
+    if (v.tl && tlfile) {
+      std::vector<unsigned long long> h((size_t)grid * TLS);
+      CK(hipMemcpy(h.data(), tl, h.size() * 8, hipMemcpyDeviceToHost));
+      std::string fn = std::string(tlfile) + "." + v.name;
+      FILE *f = fopen(fn.c_str(), "wb");
+      const long long hdr[4] = {(long long)grid, TLS, v.kw / 16, 0};
+      fwrite(hdr, 8, 4, f);
+      fwrite(h.data(), 8, h.size(), f);
+      fclose(f);
+    }
+    time_it([&]() { hipLaunchKernelGGL(v.fn, dim3(grid), dim3(256), 0, 0, (const double *)V, V2, ldv, (const double *)W, ldw, C, ldc, rows, ncols, tl, 0); }, v.name, v.kw);
+    printf("  | vs shipped: %llu elements differ, max |d| %.3g%s\n", hnd, hmx, v.exact ? (hnd ? "  ** MISMATCH **" : "  (bitwise equal)") : "  (ablation: not expected to match)");
+    fflush(stdout);
+  }
+  return 0;
+}
