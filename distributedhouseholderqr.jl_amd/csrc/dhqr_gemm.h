@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_gram_batch(const double *__r
 // s ^ ((c >> 1) & 7)), no staging registers / ds_write / masking.  A slab whose last K-tile is partial stages that one tile
 // through registers (zeros below the slab) into the same image.  Same unit decomposition, same sums in the same order:
 // bit-identical to the register-staged program, which stays as the VEC = 1 instantiation.
-template <bool SK>
+template <bool SK, int OPT = 0>
 __device__ __forceinline__ void gemm_tn2_direct(const double *__restrict__ V, int64_t ldv, const double *__restrict__ C,
                                                 int64_t ldc, int64_t rows, int64_t ncols, int64_t rps,
                                                 double *__restrict__ out, int64_t osplit_stride, int64_t skq) {
@@ -379,7 +379,7 @@ __device__ __forceinline__ void gemm_tn2_direct(const double *__restrict__ V, in
         for (int i = 0; i < 2; ++i) glds16(Ct + gc[i], st, (uint32_t)((NP * G_KT + (8 * (2 * w + i)) * G_KT) * 8));
       }
     };
-    auto mma_tile = [&](int stage) {
+    auto mma_tile = [&](int stage, int kt_issue, int stage_issue) {
       const double *vs = ring + stage * STG + (wp * 64) * G_KT;
       const double *cs = ring + stage * STG + NP * G_KT + (wc * 64) * G_KT;
 #pragma unroll
@@ -391,9 +391,15 @@ __device__ __forceinline__ void gemm_tn2_direct(const double *__restrict__ V, in
           b[x] = vs[af[kk] + x * 16 * G_KT];
         }
 #pragma unroll
-        for (int ci = 0; ci < 4; ++ci)
+        for (int ci = 0; ci < 4; ++ci) {
+          if ((OPT & 1) && kk == 1 && ci == 2) {  // the loads of tile kt + 2 go out in the middle of the MFMA stream
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt_issue >= 0) issue_tile(kt_issue, stage_issue);
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int pi = 0; pi < 4; ++pi) acc[ci][pi] = mfma_f64(a[ci], b[pi], acc[ci][pi]);
+        }
       }
     };
     if (nkt > 0) {
@@ -407,9 +413,9 @@ __device__ __forceinline__ void gemm_tn2_direct(const double *__restrict__ V, in
     }
     int s0 = 0, s1 = 1, s2 = 2;  // stages of tiles kt, kt + 1, kt + 2
     for (int kt = 0; kt < nkt; ++kt) {
-      if (kt + 2 < nkt) issue_tile(kt + 2, s2);  // stage s2 was read during K-tile kt - 1: every wave is past that barrier
+      if (!(OPT & 1) && kt + 2 < nkt) issue_tile(kt + 2, s2);  // stage s2 was read during K-tile kt - 1: every wave is past that barrier
       __builtin_amdgcn_sched_barrier(0);
-      mma_tile(s0);
+      mma_tile(s0, kt + 2 < nkt ? kt + 2 : -1, s2);
       __builtin_amdgcn_sched_barrier(0);
       if (kt + 2 < nkt) gemm_lds_landed<6>();    // tile kt + 1 has landed everywhere; tile kt + 2 stays in flight
       else gemm_lds_landed<0>();                 // also after the last K-tile: the next unit refills the ring
@@ -805,7 +811,10 @@ __device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, i
     for (int kk = 0; kk < 4; ++kk) aw[kk] = (wc * 64 + i16) * G_KT + (((2 * kk + (k4 >> 1)) ^ (i16 >> 1)) * 2) + (k4 & 1);
     const int ch0 = wr * 32 + 2 * i16, fl = (i16 >> 3) & 1;  // rows 4 i16 .. + 3 of the wave: chunks ch0, ch0 + 1
     const int av0 = k4 * 128 + ((ch0 ^ fl) * 2), av1 = k4 * 128 + (((ch0 ^ fl) ^ 1) * 2);
-    auto mma_direct = [&](int buf) {
+    // kt_next >= 0: the loads of that K-tile are issued from the MIDDLE of this tile's MFMA stream (behind 24 of the 64):
+    // a direct load costs ~60 cycles of issue (s_mov m0, address, the load); at the top of the K-tile, where the wave has
+    // no MFMA in flight, 8 of them stood between the barrier and the first MFMA (67.98 -> 70.32 TFLOP/s, same bits)
+    auto mma_direct = [&](int buf, int kt_next) {
       const double *ws = Wg + buf * (G_KT * 128);
       const double *vs = Vg + buf * (G_KT * 128);
 #pragma unroll
@@ -820,9 +829,15 @@ __device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, i
         b[2] = b23.x;
         b[3] = b23.y;
 #pragma unroll
-        for (int ci = 0; ci < 4; ++ci)
+        for (int ci = 0; ci < 4; ++ci) {
+          if (kk == 1 && ci == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt_next >= 0) issue_tile(kt_next);
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = mfma_f64(a[ci], b[ri], acc[ci][ri]);
+        }
       }
     };
 #pragma unroll
@@ -847,9 +862,8 @@ __device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, i
           cin += cstep;
         }
       }
-      if (kt + 1 < NKT) issue_tile(kt + 1);
       __builtin_amdgcn_sched_barrier(0);
-      mma_direct(kt & 1);
+      mma_direct(kt & 1, kt + 1 < NKT ? kt + 1 : -1);
       __builtin_amdgcn_sched_barrier(0);
       if (carry) {
 #pragma unroll

@@ -20,7 +20,7 @@
     }                                                                                           \
   } while (0)
 
-enum { F_TL = 1, F_NOC = 2, F_NOSTAGE = 4, F_NOBAR = 8, F_PRIO = 16, F_CLATE = 32, F_TL2 = 64 };
+enum { F_TL = 1, F_NOC = 2, F_NOSTAGE = 4, F_NOBAR = 8, F_PRIO = 16, F_CLATE = 32, F_TL2 = 64, F_MID = 128 };
 #define TLS 232  // timeline words per workgroup: 40 (F_TL) + 32 K-tiles x (wave 0: after vmcnt wait, after barrier... see F_TL2)
 
 __global__ void k_fill(double *x, int64_t n, uint64_t seed, double scale) {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void lab_glds(const double *__restrict__ V,
   for (int kk = 0; kk < 4; ++kk) aw[kk] = (wc * 64 + i16) * G_KT + (((2 * kk + (k4 >> 1)) ^ (i16 >> 1)) * 2) + (k4 & 1);
   const int ch0 = wr * 32 + 2 * i16, fl = (i16 >> 3) & 1;
   const int av0 = k4 * 128 + ((ch0 ^ fl) * 2), av1 = k4 * 128 + (((ch0 ^ fl) ^ 1) * 2);
-  auto mma_tile = [&](int buf) {
+  auto mma_tile = [&](int buf, int kt_issue) {
     const double *ws = buf ? Ws1 : Ws0;
     const double *vs = buf ? Vs1 : Vs0;
 #pragma unroll
@@ -284,9 +284,15 @@ __global__ __launch_bounds__(256, 2) void lab_glds(const double *__restrict__ V,
       const double2 b23 = *reinterpret_cast<const double2 *>(vs + av1 + kk * 4 * 128);
       b[0] = b01.x; b[1] = b01.y; b[2] = b23.x; b[3] = b23.y;
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
+      for (int ci = 0; ci < 4; ++ci) {
+        if ((FL & F_MID) && kk == 1 && ci == 2) {  // the next tile's loads go out in the middle of the MFMA stream (issue cost under cover)
+          __builtin_amdgcn_sched_barrier(0);
+          if (kt_issue >= 0) issue_tile(kt_issue, kt_issue & 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = mfma_f64(a[ci], b[ri], acc[ci][ri]);
+      }
     }
   };
   double *const cunit0 = Cb + ((uint32_t)((wc * 64 + k4) * ldc) + (uint32_t)(wr * 64 + 4 * i16));
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void lab_glds(const double *__restrict__ V,
         cin += cstep;
       }
     }
-    if (kt + 1 < NKT) issue_tile(kt + 1, (kt + 1) & 1);
+    if (!(FL & F_MID) && kt + 1 < NKT) issue_tile(kt + 1, (kt + 1) & 1);
     if (!(FL & F_NOC) && carry && late) {
 #pragma unroll
       for (int u = 0; u < UPT; ++u) {
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void lab_glds(const double *__restrict__ V,
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    mma_tile(kt & 1);
+    mma_tile(kt & 1, kt + 1 < NKT ? kt + 1 : -1);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FL & F_TL2) {  // every wave: the last MFMA of the K-tile has been issued
       if (lane == 0) stamp[40 + 6 * kt + w] = __builtin_amdgcn_s_memtime();
@@ -370,6 +376,13 @@ __global__ __launch_bounds__(256, 2) void lab_glds(const double *__restrict__ V,
     for (int i = 3 + t; i < TLS; i += 256)
       if (i < 4 + NKT || i >= 40) mytl[i] = stamp[i];
   }
+}
+
+template <int OPT>
+__global__ __launch_bounds__(512) void lab_tn2(const double *__restrict__ V, int64_t ldv, const double *__restrict__ C, int64_t ldc,
+                                               int64_t rows, int64_t ncols, int64_t rps, double *__restrict__ out,
+                                               int64_t osplit_stride, int64_t skq) {
+  gemm_tn2_direct<true, OPT>(V, ldv, C, ldc, rows, ncols, rps, out, osplit_stride, skq);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -424,6 +437,8 @@ int main(int argc, char **argv) {
       {"glds512_tl", 512, lab_glds<512, F_TL>, true, true},
       {"glds512_tl2", 512, lab_glds<512, F_TL | F_TL2>, true, true},
       {"glds512_clate", 512, lab_glds<512, F_CLATE>, false, false},
+      {"glds512_mid", 512, lab_glds<512, F_MID>, true, false},
+      {"glds512_midlate", 512, lab_glds<512, F_MID | F_CLATE>, false, false},
       {"glds512_noc", 512, lab_glds<512, F_NOC>, false, false},
       {"nn256", 256, lab_nn<256, 0>, true, false},
       {"glds256", 256, lab_glds<256, 0>, true, false},
@@ -460,8 +475,11 @@ int main(int argc, char **argv) {
     CK(hipMemset(o2, 0, (size_t)pieces * wstride * 8));
     auto l1 = [&]() { hipLaunchKernelGGL((k_gemm_tn2<1, true>), dim3((unsigned)Gq), dim3(512), 0, 0, (const double *)V, ldv, (const double *)C0, ldc, rows, ncols, FU, o1, wstride, q); };
     auto l2 = [&]() { hipLaunchKernelGGL((k_gemm_tn2<2, true>), dim3((unsigned)Gq), dim3(512), 0, 0, (const double *)V, ldv, (const double *)C0, ldc, rows, ncols, FU, o2, wstride, q); };
+    auto l3 = [&]() { hipLaunchKernelGGL((lab_tn2<1>), dim3((unsigned)Gq), dim3(512), 0, 0, (const double *)V, ldv, (const double *)C0, ldc, rows, ncols, FU, o2, wstride, q); };
     for (int rep = 0; rep < 2; ++rep) {
       time_it(l1, "tn2_staged", 256);
+      printf("\n");
+      time_it(l3, "tn2_direct_mid", 256);
       printf("\n");
       time_it(l2, "tn2_direct", 256);
       CK(hipMemset(nd, 0, 8));
