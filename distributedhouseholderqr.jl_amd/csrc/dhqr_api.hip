@@ -1725,8 +1725,13 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
   const int64_t ldd = (m + 1) & ~(int64_t)1;
   CHECK(ensure(c, c->host_mat, (size_t)ldd * (size_t)n + (size_t)n + (size_t)m + 32));  // (dhqr_ldiv_f64 keeps b behind alpha)
   double *dA = c->host_mat.p, *dal = dA + (((size_t)ldd * (size_t)n + 1) & ~(size_t)1);
-  // DHQR_HOSTIO=0: the plain three-phase form (one hipMemcpy2D up, factorisation, one down)
-  static const bool overlap = [] { const char *e = getenv("DHQR_HOSTIO"); return !(e && atoi(e) == 0); }();
+  // Default: the plain three-phase form (one hipMemcpy2D up, factorisation, one down).  DHQR_HOSTIO=1: the staged form of
+  // dhqr_hostio.h (every committed column block travels back while later panels are factored).  It lost every A/B on this
+  // stack (32768^2: 1.16-1.25 s against 1.10-1.15 s, profiles/r04_hostio*.txt, r05_hostio*.txt): an asynchronous
+  // device-to-host copy runs as a blit kernel whose grid covers the chip while it moves data at the PCIe rate, and the
+  // factorisation stretches by what the download was meant to hide; a 16-workgroup copy-out kernel storing into the pinned
+  // buffer was slower still (1.29 s).  Kept for stacks whose copies run on the DMA engines.
+  static const bool overlap = [] { const char *e = getenv("DHQR_HOSTIO"); return e && atoi(e) == 1; }();
   int32_t rc = DHQR_OK;
   auto plain = [&]() -> int32_t {
     HIPCHECK(hipMemcpy2DAsync(dA, ldd * sizeof(double), hA, lda * sizeof(double), m * sizeof(double),

@@ -1,5 +1,5 @@
-"""Host-in / host-out drop-in dhqr_qr_f64 (`qr!(A::Matrix)`): wall time of the call with the staged, overlapped PCIe path
-(default) and with the plain three-phase form (DHQR_HOSTIO=0), next to the device-resident factorisation.
+"""Host-in / host-out drop-in dhqr_qr_f64 (`qr!(A::Matrix)`): wall time of the call with the plain three-phase form
+(DHQR_HOSTIO=0, the default) and with the staged, overlapped PCIe path (DHQR_HOSTIO=1), next to the device-resident factorisation.
   python tools/hostio_bench.py [n=32768] [reps=3]"""
 import json
 import os
@@ -34,7 +34,7 @@ def run(n, reps):
     Hd = pkg.qr_(Ad, nb=128)
     torch.cuda.synchronize()
     same = all(np.array_equal(H.A[:, c], Hd.A[:, c].cpu().numpy()) for c in cols) and np.array_equal(H.α, Hd.α.cpu().numpy())
-    print(json.dumps({"n": n, "hostio": os.environ.get("DHQR_HOSTIO", "1"), "first_call_s": ts[0], "best_s": min(ts[1:]),
+    print(json.dumps({"n": n, "hostio": os.environ.get("DHQR_HOSTIO", "0"), "first_call_s": ts[0], "best_s": min(ts[1:]),
                       "calls_s": [round(t, 3) for t in ts], "v2": v2, "bitwise_equal_to_device_resident_run": bool(same)}), flush=True)
 
 
@@ -44,5 +44,5 @@ if __name__ == "__main__":
     else:
         n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
         reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-        for mode in ("1", "0"):
+        for mode in ("0", "1"):
             subprocess.run([sys.executable, os.path.abspath(__file__), "--inner", str(n), str(reps)], env=dict(os.environ, DHQR_HOSTIO=mode))
