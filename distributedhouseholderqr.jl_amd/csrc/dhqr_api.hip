@@ -114,7 +114,7 @@ struct dhqr_ctx {
   bool coop = false;     // the device runs cooperative (all-resident) launches: false on the CPU emulator
   Buf host_mat;          // device copy of the caller's HOST matrix (+ alpha) of dhqr_qr_f64, kept between calls
   int pair = 1;                  // 1: wide updates apply two panels per pass (DHQR_PAIR=0 disables)
-  int64_t pair_min_n = 12288;    // below this the longer look-ahead lane of the pair driver costs more than it saves (profiles/r02_ab_pair_tail_and_threshold.txt)
+  int64_t pair_min_n = 4096;     // below this the longer look-ahead lane of the pair driver costs more than it saves (r2: 12288, profiles/r02_ab_pair_tail_and_threshold.txt; r5, with the direct-load GEMMs: 4096^2 12.11 -> 11.84 ms, 8192^2 31.97 -> 31.39, 12288^2 68.18 -> 67.71, profiles/r05_ab_thresholds.txt)
   int panel_impl = 3;  // 3: R-first (CholeskyQR + reconstruction, dhqr_recon.h) with fallback to 2;
                        // 2: row-split sub-panel kernels (dhqr_panel.h); 1: one workgroup per column
   int zpipe = 1;         // ComplexF64 panels of <= 128 columns and <= 8192 rows in one column-pipelined launch (k_zpanel_pipe; DHQR_ZPIPE=0: one launch per column)

@@ -14,11 +14,13 @@
 // 16-lane group stores/loads one contiguous 128-byte segment.
 //
 // Tiles: 256 threads = 4 waves, output tile 128 x 128, each wave 64 x 64 = 4 x 4 MFMA tiles
-// (16 accumulators x 4 doubles = 128 VGPRs), K-tile 16, operands staged global -> registers ->
-// LDS (double buffered, one barrier per K-tile, next tile's global loads in flight during the
-// 64 MFMAs of the current one).  LDS strides are chosen so the fragment reads (ds_read_b64,
-// 64-bank) are conflict free: 18 doubles (36 dwords) for k-contiguous tiles, 130 doubles for the
-// row-contiguous V tile of k_gemm_nn_sub (read with ds_read_b128).
+// (16 accumulators x 4 doubles = 128 VGPRs), K-tile 16, one barrier per K-tile.  Two operand paths:
+//  * the WIDE kernels (k_gemm_tn2; interior tiles of k_gemm_nn_quad / k_gemm_nn_sub) load global -> LDS directly
+//    (glds16 below: no staging registers, unpadded images, the bank swizzle in the per-lane global address);
+//  * everything else (k_gemm_tn, edge tiles, unaligned operands, the lane's 64-row tiles) stages global -> registers ->
+//    LDS (double buffered, next tile's global loads in flight during the 64 MFMAs of the current one) with padded
+//    strides: 18 doubles (36 dwords) for k-contiguous tiles, 130 doubles for the row-contiguous V tile of
+//    k_gemm_nn_sub (read with ds_read_b128) -- conflict-free fragment reads (ds_read_b64, 64 banks).
 #pragma once
 #include "dhqr_common.h"
 #include <type_traits>

@@ -8,7 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# the two-panel (K = 256) driver normally engages only for n >= 12288; tests exercise it on small shapes
+# the two-panel (K = 256) driver normally engages only for n >= 4096; tests exercise it on small shapes
 os.environ.setdefault("DHQR_PAIR_MIN_N", "512")
 
 

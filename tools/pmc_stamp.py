@@ -32,7 +32,7 @@ def per_launch(root, ctr, scale, cfg="blocked"):
     return {k: [v for _, v in sorted(vs)] for k, vs in out.items()}
 
 
-def plan(n, pair_min_n=12288, quad_min_cols=10240, quad_head=False):
+def plan(n, pair_min_n=4096, quad_min_cols=10240, quad_head=False):
     """(rows, ncols) of the wide launches of the single-GPU blocked driver: NN launches, TN2 launches"""
     m = n
     K = n // NB
