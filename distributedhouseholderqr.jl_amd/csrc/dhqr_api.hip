@@ -65,6 +65,8 @@ struct dhqr_ctx {
                                  // communication stream of P > 1 (and RCCL's own) a fifth stream serialises something
                                  // (measured with rank threads sharing one GPU: 32768^2 at 2 ranks 904 -> 971 ms)
   int hi_priority = 0;
+  int tn_spare = 32;                // CUs a wide k_gemm_tn2 launch on a small trailing matrix leaves to the lane (wide_slots) ...
+  int64_t tn_spare_cols = 16384;    // ... "small": at most this many trailing columns (DHQR_TUNE tn_spare, tn_spare_cols)
   int tn_model_min_tiles = 128;  // wide k_gemm_tn2 launches of at least this many column tiles: split-K factor from the round / partial-traffic estimate (below, the lane is the critical path and
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
   int rankk_wgs = 256;           // ... bulk workgroups of 1024 threads resident at once (CU count; DHQR_RANKK_WGS)
@@ -522,7 +524,16 @@ static void launch_nn_sub(dhqr_ctx *c, bool vec, dim3 grid, const double *V, int
 }
 
 // Workgroups of a persistent wide launch: one per CU, minus the CUs kept free for the lane / RCCL (ctx->spare_cus).
-static inline int64_t wide_slots(const dhqr_ctx *c) { return std::max<int64_t>(8, (int64_t)c->ncu - c->spare_cus); }
+// r5: on a SMALL trailing matrix (ncols <= tn_spare_cols) the V'C pass also leaves tn_spare CUs to the look-ahead lane:
+// k_gemm_tn2's workgroups hold whole CUs for the whole launch, the lane makes no progress under them, and once a wide
+// step is no longer than the lane's chain (two panels x 290 us) the step is wide + chain instead of max(wide, chain).
+// Measured (profiles/r05_ab_tn_spare.txt): 32 CUs: 8192^2 31.8 -> 30.2 ms, 12288^2 68.5 -> 64.5, 16384^2 128.8 -> 124.3.
+static inline int64_t wide_slots(const dhqr_ctx *c, int64_t ncols = -1) {
+  int spare = c->spare_cus;
+  if (ncols >= 0 && ncols <= c->tn_spare_cols && c->lookahead && !c->spare_cus_set)
+    spare = std::max(spare, ncols <= c->tn_spare_cols / 2 ? 2 * c->tn_spare : c->tn_spare);  // (64 below 8192 columns: 8192^2 30.4 -> 29.8 ms)
+  return std::max<int64_t>(8, (int64_t)c->ncu - spare);
+}
 
 // Split-K factor for k_gemm_tn: `ntiles` column tiles x ns row slabs should fill the 512 resident
 // workgroup slots (256 CUs x 2) in whole waves -- 765 workgroups on 512 slots run at 75 %.
@@ -1090,7 +1101,7 @@ static int32_t pair_vtc(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows
   if (ntiles <= 2) return narrow_vtc(c, Vp, ldv, rows, C, ldc, ncols, vec, c->ws[c->cur_ws].w1, Y);
   int64_t nsplit, rps;
   // k_gemm_tn2 workgroups have 512 threads and 110 KB of LDS: one per CU, 256 resident
-  const int64_t slots = wide_slots(c);
+  const int64_t slots = wide_slots(c, ncols);
   pick_split(rows, ntiles, slots, ntiles <= 2 ? 256 : 64, &nsplit, &rps, slots, ntiles <= 2 ? 64 : 128);
   if (ntiles >= c->tn_model_min_tiles) {
     // Wide launches: k_gemm_tn2 runs ONE workgroup per CU, all of the same size, so a launch takes
@@ -1472,6 +1483,8 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_NN_SPLIT")) c->nn_split = std::min(16, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_RANKK_PIPE")) c->rankk_pipe = std::min(2, std::max(0, atoi(e)));
     { long long v; if (tune_get("tn_min_tiles", &v)) c->tn_model_min_tiles = (int)v; }
+    { long long v; if (tune_get("tn_spare", &v)) c->tn_spare = std::max(0, std::min((c->ncu - 8) / 2, (int)v)); }
+    { long long v; if (tune_get("tn_spare_cols", &v)) c->tn_spare_cols = v; }
     if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;
     if (const char *e = getenv("DHQR_PAIR_MIN_N")) c->pair_min_n = atoll(e);
     HIPCHECK(hipHostMalloc((void **)&c->hflag, 4 * sizeof(int), hipHostMallocDefault));
