@@ -376,7 +376,10 @@ int32_t dhqr_bench_gemm_f64(dhqr_ctx *c, int32_t kind, int64_t rows, int64_t nco
         else
           launch_nn_sub<256>(c, true, grid, V, ldv, W, ld2, C, ldc, rows, ncols, swz, false);
       } else {
+        const int keep = c->tn_spare;  // the kernel ALONE: no CUs left to a lane that is not running (wide_slots)
+        c->tn_spare = 0;
         (void)pair_vtc(c, V, ldv, rows, C, ldc, ncols, true, Y);
+        c->tn_spare = keep;
       }
     };
     launch();
