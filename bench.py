@@ -650,8 +650,8 @@ def also_sizes(pkg, torch, ctx, dev, sizes=(8192, 16384), steps=3, warmup=1):
 
 def host_in_out(pkg, torch, dev, m, n, reps=2):
     """the PCIe-inclusive drop-in call `qr!(A::Matrix)` = dhqr_qr_f64 on a HOST matrix (pageable numpy memory, as a Julia
-    Matrix would be): staged upload, factorisation, every column block downloaded behind its panel's commit
-    (csrc/dhqr_hostio.h).  Reported beside the device-resident time; never the headline `value`."""
+    Matrix would be): copy up, factorisation, copy down (the staged / overlapped form of csrc/dhqr_hostio.h is
+    DHQR_HOSTIO=1: slower on this stack).  Reported beside the device-resident time; never the headline `value`."""
     import numpy as np
     Ad = pkg.rand_colmajor(m, n, 0, dev)
     A0 = Ad.cpu().numpy()           # column-major view of the same synthetic input, on the host
@@ -669,7 +669,7 @@ def host_in_out(pkg, torch, dev, m, n, reps=2):
         ts.append((time.perf_counter() - t0) * 1e3)
     v2 = float((H.A[n // 2:, n // 2] ** 2).sum())
     return {"ms": min(ts[1:]), "first_call_ms": ts[0], "calls": reps, "gflops": flops_qr(m, n) / (min(ts[1:]) / 1e3) / 1e9,
-            "check_v_norm2": v2, "note": "wall time of dhqr_qr_f64 on pageable host memory (upload + factorisation + download overlapped)"}
+            "check_v_norm2": v2, "note": "wall time of dhqr_qr_f64 on pageable host memory (upload, factorisation, download; DHQR_HOSTIO=1 overlaps the download)"}
 
 
 def also_tallskinny(pkg, torch, steps=3, warmup=1, m=262144, n=4096):
