@@ -663,10 +663,23 @@ static int32_t cs_residual(const CsProblem &pr, uint64_t seed, double *dW, doubl
 // every rank accumulates the contribution of ITS columns to the rows above; per block one all-reduce sums those
 // partial dots (the reference's sum(fetch.(futures)), src:262-266), the owner solves the diagonal block and
 // broadcasts x.  du: scratch of m + 128 doubles.
+static int32_t solve_pipelined(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda, const double *dalpha, double *db);
 static int32_t cs_solve(const CsProblem &pr, double *db, double *du) {
   dhqr_ctx *c = pr.c;
   const int64_t NB = DHQR_NBV, m = pr.m;
   dhqr_comm *cm = (pr.cm && pr.P > 1) ? pr.cm : nullptr;
+  // one rank: the block-cyclic layout is the matrix itself -- the solve of dhqr_qtb.h (r5: Q'b in one persistent launch, the
+  // pipelined back substitution; 8192^2 1.2 ms against 11.5 ms for the per-panel form below, which P > 1 keeps)
+  if (!cm && pr.P == 1 && c->solve_pipe) {
+    CHECK(prof_begin(c, CAT_SOLVE));
+    const bool was1 = c->profiling;
+    c->profiling = false;
+    const int32_t rc1 = solve_pipelined(c, pr.A, m, pr.n, pr.lda, pr.alpha, db);
+    c->profiling = was1;
+    CHECK(rc1);
+    CHECK(prof_end(c));
+    return DHQR_OK;
+  }
   CHECK(cs_prepare(pr));
   const bool was = c->profiling;
   CHECK(prof_begin(c, CAT_SOLVE));

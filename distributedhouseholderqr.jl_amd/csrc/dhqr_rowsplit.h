@@ -791,6 +791,19 @@ static int32_t rs_residual(const RsProblem &pr, uint64_t seed, double *dB, doubl
 static int32_t rs_solve(const RsProblem &pr, double *db, double *dx) {
   dhqr_ctx *c = pr.c;
   dhqr_comm *cm = (pr.cm && pr.P > 1) ? pr.cm : nullptr;
+  // one rank: its rows are the matrix -- the solve of dhqr_qtb.h (see cs_solve), x copied out of b[0:n]
+  if (!cm && pr.P == 1 && c->solve_pipe && pr.mloc == pr.m) {
+    CHECK(prof_begin(c, CAT_SOLVE));
+    const bool was1 = c->profiling;
+    c->profiling = false;
+    int32_t rc1 = solve_pipelined(c, pr.A, pr.m, pr.n, pr.lda, pr.alpha, db);
+    if (rc1 == DHQR_OK && dx != db)
+      rc1 = hipMemcpyAsync(dx, db, (size_t)pr.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) == hipSuccess ? DHQR_OK : DHQR_EHIP;
+    c->profiling = was1;
+    CHECK(rc1);
+    CHECK(prof_end(c));
+    return DHQR_OK;
+  }
   RsWork w;
   CHECK(rs_prepare(pr, &w));
   const int64_t NB = DHQR_NBV, n = pr.n, K = (n + NB - 1) / NB, ldb = std::max<int64_t>(pr.mloc, 1);
