@@ -67,7 +67,7 @@ struct dhqr_ctx {
   int hi_priority = 0;
   int tn_spare = 32;                // CUs a wide k_gemm_tn2 launch on a small trailing matrix leaves to the lane (wide_slots) ...
   int64_t tn_spare_cols = 16384;    // ... "small": at most this many trailing columns (DHQR_TUNE tn_spare, tn_spare_cols)
-  int tn_model_min_tiles = 128;  // wide k_gemm_tn2 launches of at least this many column tiles: split-K factor from the round / partial-traffic estimate (below, the lane is the critical path and
+  int tn_model_min_tiles = 32;   // (r5: 32, with the direct-load kernel; 128 before: 8192^2 29.9 -> 29.1 ms, 16384^2 123.6 -> 120.2, 32768^2 783.7 -> 775.7, profiles/r05_ab_thresholds.txt) wide k_gemm_tn2 launches of at least this many column tiles: split-K factor from the round / partial-traffic estimate (below, the lane is the critical path and
                                  // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
   int rankk_wgs = 256;           // ... bulk workgroups of 1024 threads resident at once (CU count; DHQR_RANKK_WGS)
   int rankk = 5;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..5; beyond 3 the further ones are held in LDS)

@@ -190,7 +190,7 @@ def test_wide_update_on_the_persistent_tn_kernel(emu, orc):
 
 @pytest.mark.parametrize("m,n", [(1040, 896), pytest.param(1161, 1152, marks=_SLOW)])
 def test_wide_tn_stream_k(emu, orc, m, n):
-    """stream-K decomposition of the wide k_gemm_tn2 launches (normally from 128 column tiles on; DHQR_TUNE tn_min_tiles=3
+    """stream-K decomposition of the wide k_gemm_tn2 launches (normally from 32 column tiles on; DHQR_TUNE tn_min_tiles=3
     brings it to a small matrix): 128-row fine units numbered tile-major, a contiguous range per workgroup, a tile's
     partial sums = the workgroups that share it (k_reduce_pieces) -- against the oracle, even and odd m (16-byte / scalar
     loads), and against the column-tile x row-slab units (tn_min_tiles beyond reach) to rounding"""

@@ -324,7 +324,7 @@ def test_lane_schedule_switches_on_a_small_matrix_with_quads(pkg, orc, monkeypat
 
 @pytest.mark.parametrize("min_tiles", [3, 1000000])
 def test_wide_tn_split_model_on_a_small_matrix(pkg, orc, monkeypatch, min_tiles):
-    """the decomposition of the wide k_gemm_tn2 launches (normally for >= 128 column tiles = matrices beyond 16384
+    """the decomposition of the wide k_gemm_tn2 launches (normally for >= 32 column tiles = matrices beyond 4096
     columns) forced onto a 2304^2 matrix -- stream-K (tile-major fine units, a contiguous range per workgroup,
     k_reduce_pieces; DHQR_TUNE tn_min_tiles=3) and the column-tile x row-slab units every smaller launch uses
     (tn_min_tiles beyond reach): same factorisation as the oracle's"""
