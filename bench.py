@@ -41,6 +41,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # the host driver only supports dmabuf IPC; must be in the environment before the HSA runtime starts
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# kernel arguments written straight into device memory: a few microseconds less per launch; the blocked driver issues ~40
+# launches per panel (profiles/r05_ab_dev_kernarg.txt: 2048^2 -10 %, 8192^2 -2.6 %, 32768^2 within noise).  Read when the HIP
+# runtime initialises, i.e. before torch touches the device; a caller's own setting wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 PEAK_FP64_MFMA_TFLOPS = 78.6   # AMD MI355X datasheet FP64 matrix (== vector) peak; the local
                                # MI355X_MICROARCH.md guide lists no FP64 number
@@ -617,7 +621,7 @@ def also_solve(pkg, torch, dev, lapack=True):
             **out}
 
 
-def also_sizes(pkg, torch, ctx, dev, sizes=(8192, 16384), steps=3, warmup=1):
+def also_sizes(pkg, torch, ctx, dev, sizes=(8192, 16384), steps=8, warmup=3):
     """the blocked path below the headline size, where the panel chain -- not the GEMMs -- bounds the run (DESIGN.md section 3
     "The panel chain"): n x n Float64, nb = 128, device-resident, refill inside the timed region like the headline"""
     import ctypes

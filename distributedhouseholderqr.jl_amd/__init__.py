@@ -5,6 +5,13 @@ registers it in sys.modules as `dhqr_amd`.  Contents: csrc/ (HIP kernels + the C
 include/dhqr.h), _lib.py (ctypes binding), api.py (host mirror of the reference's Julia API),
 partition.py (index maps), distributed.py (front-ends of the multi-GPU C drivers), rowsplit.py, julia/ (ccall wrapper).
 """
+import os as _os
+
+# Kernel arguments written straight into device memory (a few microseconds less per launch; the blocked driver issues
+# ~40 launches per panel: profiles/r05_ab_dev_kernarg.txt).  Only effective when the HIP runtime has not initialised yet
+# (importing torch does not initialise it); a caller's own setting wins.  C / Julia callers: INTEGRATION.md section 5.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 from . import _lib
 from ._lib import NB, DHQRError, build
 from .api import (Context, DistributedHouseholderQRStruct, apply_q_, bench_check, bench_context, bench_mfma_tflops,
