@@ -9,7 +9,7 @@ the blocks of pair g+2 first); a panel is available to the other ranks one broad
 
 Inputs measured on one MI355X (profiles/r02_*; round 4 re-checked the chain against the per-launch trace
 profiles/r04_blocked32768_per_launch.csv.gz: 290 us per 32768-row panel incl. ~40 us of event bubbles, unchanged kernels):
-  trailing GEMMs in situ                          54 TFLOP/s per GPU (K = 256 pair update, both passes; 60 with quad steps at one GPU)
+  trailing GEMMs in situ                          61 TFLOP/s per GPU (r5, direct-load kernels: K = 256 pair update, both passes; 64 with quad steps at one GPU; r4: 54 / 60)
   panel chain, uncontended                        0.215 ms single-workgroup kernels + small GEMMs + launch gaps (fixed)
                                                 + 0.035 ms * rows/32768 (Gram / product GEMMs, commit)
                                                   [fit to the per-panel time of the no-look-ahead driver at 8192^2 /
@@ -24,7 +24,7 @@ Assumed (NOT measured): broadcast of one panel = latency + bytes / bandwidth.
 import argparse
 
 
-def simulate(P, n=32768, nb=128, gemm_tflops=54.0, small_ms=0.215, var_ms=0.035, bw_gbps=100.0, lat_us=40.0, own=2, side=False):
+def simulate(P, n=32768, nb=128, gemm_tflops=61.0, small_ms=0.215, var_ms=0.035, bw_gbps=100.0, lat_us=40.0, own=2, side=False):
     # own = panels per cyclic block: 2 (DHQR_CS_BLOCK = 256: the shipped layout) or 1 (the earlier 128-column blocks)
     K = n // nb
     G = K // 2
@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--bw-gbps", type=float, default=100.0)
     ap.add_argument("--lat-us", type=float, default=40.0)
     ap.add_argument("--own", type=int, default=2, help="panels per cyclic block: 2 (shipped) or 1 (128-column blocks)")
-    ap.add_argument("--t1", type=float, default=0.843, help="measured 1-GPU time in seconds (round 4: 0.843)")
+    ap.add_argument("--t1", type=float, default=0.774, help="measured 1-GPU time in seconds (round 4: 0.774)")
     a = ap.parse_args()
     t1 = simulate(1, small_ms=a.small_ms, var_ms=a.var_ms)
     print(f"fixed part of the panel chain {a.small_ms:.2f} ms, broadcast {a.bw_gbps:.0f} GB/s + {a.lat_us:.0f} us (assumed)")
