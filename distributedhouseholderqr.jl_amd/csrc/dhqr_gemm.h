@@ -786,6 +786,7 @@ __device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, i
   // Per workgroup-timeline (tools/gemm_lab.hip, gemm_lab_timeline.py, 16384^2): tile = 288k cycles of which the K loop
   // 272k (floor with two workgroups per CU: 262k), prologue 9k, stores 7k, 7k until the successor starts.
   if constexpr (STREAM) if (direct) {  // uniform branch
+    typedef double dhqr_d2 __attribute__((ext_vector_type(2)));
     double *const Vg = lds_raw, *const Wg = lds_raw + 2 * G_KT * 128;  // [2][16 * 128] each
     uint32_t gv[4], gw[4];  // this wave's 4 V columns (p = 4 w + i) and 4 W column groups (columns 8 (4 w + i) .. + 7)
     {
@@ -858,9 +859,11 @@ __device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, i
       double2 cu[UPT][2];
       if (carry) {
 #pragma unroll
-        for (int u = 0; u < UPT; ++u) {
-          cu[u][0] = *reinterpret_cast<const double2 *>(cin);
-          cu[u][1] = *reinterpret_cast<const double2 *>(cin + 2);
+        for (int u = 0; u < UPT; ++u) {  // non-temporal: C passes through once and should not push the operands out of L2
+          const dhqr_d2 x0 = __builtin_nontemporal_load(reinterpret_cast<const dhqr_d2 *>(cin));
+          const dhqr_d2 x1 = __builtin_nontemporal_load(reinterpret_cast<const dhqr_d2 *>(cin + 2));
+          cu[u][0] = make_double2(x0[0], x0[1]);
+          cu[u][1] = make_double2(x1[0], x1[1]);
           cin += cstep;
         }
       }
@@ -888,8 +891,13 @@ __device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, i
       double *cp = cunit0;
 #pragma unroll
       for (int n = 0; n < 16; ++n) {
-        *reinterpret_cast<double2 *>(cp) = make_double2(-acc[n >> 2][0][n & 3], -acc[n >> 2][1][n & 3]);
-        *reinterpret_cast<double2 *>(cp + 2) = make_double2(-acc[n >> 2][2][n & 3], -acc[n >> 2][3][n & 3]);
+        dhqr_d2 y0, y1;  // (non-temporal like the loads: HBM-side reads of a K = 256 launch 15.0 -> 11.4 GB, K = 512 20.0 -> 18.9 GB
+        y0[0] = -acc[n >> 2][0][n & 3];  //  at 32768 x 28672, same bits, K = 256 1 % faster: profiles/r05_ab_gemm_structure.txt)
+        y0[1] = -acc[n >> 2][1][n & 3];
+        y1[0] = -acc[n >> 2][2][n & 3];
+        y1[1] = -acc[n >> 2][3][n & 3];
+        __builtin_nontemporal_store(y0, reinterpret_cast<dhqr_d2 *>(cp));
+        __builtin_nontemporal_store(y1, reinterpret_cast<dhqr_d2 *>(cp + 2));
         cp += cstep;
       }
     }

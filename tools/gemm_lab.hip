@@ -20,7 +20,7 @@
     }                                                                                           \
   } while (0)
 
-enum { F_TL = 1, F_NOC = 2, F_NOSTAGE = 4, F_NOBAR = 8, F_PRIO = 16, F_CLATE = 32, F_TL2 = 64, F_MID = 128 };
+enum { F_TL = 1, F_NOC = 2, F_NOSTAGE = 4, F_NOBAR = 8, F_PRIO = 16, F_CLATE = 32, F_TL2 = 64, F_MID = 128, F_NT = 256 };
 #define TLS 232  // timeline words per workgroup: 40 (F_TL) + 32 K-tiles x (wave 0: after vmcnt wait, after barrier... see F_TL2)
 
 __global__ void k_fill(double *x, int64_t n, uint64_t seed, double scale) {
@@ -317,8 +317,16 @@ __global__ __launch_bounds__(256, 2) void lab_glds(const double *__restrict__ V,
     if (!(FL & F_NOC) && carry && !late) {
 #pragma unroll
       for (int u = 0; u < UPT; ++u) {
+        if constexpr (FL & F_NT) {  // C passes through once: keep it out of the way of the operands in L2
+          typedef double d2v __attribute__((ext_vector_type(2)));
+          const d2v x0 = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(cin));
+          const d2v x1 = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(cin + 2));
+          cu[u][0] = make_double2(x0[0], x0[1]);
+          cu[u][1] = make_double2(x1[0], x1[1]);
+        } else {
         cu[u][0] = *reinterpret_cast<const double2 *>(cin);
         cu[u][1] = *reinterpret_cast<const double2 *>(cin + 2);
+        }
         cin += cstep;
       }
     }
@@ -326,8 +334,16 @@ __global__ __launch_bounds__(256, 2) void lab_glds(const double *__restrict__ V,
     if (!(FL & F_NOC) && carry && late) {
 #pragma unroll
       for (int u = 0; u < UPT; ++u) {
+        if constexpr (FL & F_NT) {  // C passes through once: keep it out of the way of the operands in L2
+          typedef double d2v __attribute__((ext_vector_type(2)));
+          const d2v x0 = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(cin));
+          const d2v x1 = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(cin + 2));
+          cu[u][0] = make_double2(x0[0], x0[1]);
+          cu[u][1] = make_double2(x1[0], x1[1]);
+        } else {
         cu[u][0] = *reinterpret_cast<const double2 *>(cin);
         cu[u][1] = *reinterpret_cast<const double2 *>(cin + 2);
+        }
         cin += cstep;
       }
     }
@@ -362,8 +378,17 @@ __global__ __launch_bounds__(256, 2) void lab_glds(const double *__restrict__ V,
     double *cp = cunit0;
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
+      if constexpr (FL & F_NT) {
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        d2v y0, y1;
+        y0[0] = -acc[n >> 2][0][n & 3]; y0[1] = -acc[n >> 2][1][n & 3];
+        y1[0] = -acc[n >> 2][2][n & 3]; y1[1] = -acc[n >> 2][3][n & 3];
+        __builtin_nontemporal_store(y0, reinterpret_cast<d2v *>(cp));
+        __builtin_nontemporal_store(y1, reinterpret_cast<d2v *>(cp + 2));
+      } else {
       *reinterpret_cast<double2 *>(cp) = make_double2(-acc[n >> 2][0][n & 3], -acc[n >> 2][1][n & 3]);
       *reinterpret_cast<double2 *>(cp + 2) = make_double2(-acc[n >> 2][2][n & 3], -acc[n >> 2][3][n & 3]);
+      }
       cp += cstep;
     }
   }
@@ -438,6 +463,9 @@ int main(int argc, char **argv) {
       {"glds512_tl2", 512, lab_glds<512, F_TL | F_TL2>, true, true},
       {"glds512_clate", 512, lab_glds<512, F_CLATE>, false, false},
       {"glds512_mid", 512, lab_glds<512, F_MID>, true, false},
+      {"glds512_mid_nt", 512, lab_glds<512, F_MID | F_NT>, true, false},
+      {"glds256_mid", 256, lab_glds<256, F_MID>, true, false},
+      {"glds256_mid_nt", 256, lab_glds<256, F_MID | F_NT>, true, false},
       {"glds512_midlate", 512, lab_glds<512, F_MID | F_CLATE>, false, false},
       {"glds512_noc", 512, lab_glds<512, F_NOC>, false, false},
       {"nn256", 256, lab_nn<256, 0>, true, false},
