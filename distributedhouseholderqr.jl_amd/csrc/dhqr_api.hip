@@ -1975,7 +1975,8 @@ int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64
   CHECK(ensure(c, c->host_mat, mat + (size_t)n + (size_t)m + 32));
   double *dA = c->host_mat.p, *dal = dA + mat, *db = dal + ((n + 1) & ~(int64_t)1);
   if (c->tc_A == dA) c->tc_valid = false;  // the caller's factor is uploaded afresh: nothing kept applies to it
-  static const bool overlap = [] { const char *e = getenv("DHQR_HOSTIO"); return !(e && atoi(e) == 0); }();
+  // the same switch and the same default as dhqr_qr_f64: the plain copy unless DHQR_HOSTIO=1
+  static const bool overlap = [] { const char *e = getenv("DHQR_HOSTIO"); return e && atoi(e) == 1; }();
   auto body = [&]() -> int32_t {
     bool staged = overlap;
     if (staged) {
@@ -1993,7 +1994,7 @@ int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64
     CHECK(dhqr_solve_f64(c, dA, m, n, ldd, dal, db));
     HIPCHECK(hipMemcpyAsync(hx, db, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));  // src:320
     HIPCHECK(hipStreamSynchronize(c->stream));
-    return DHQR_OK;
+    return pipe_error_check(c);  // a synchronous entry point reports an expired inter-workgroup wait itself (dhqr.h)
   };
   int32_t rc = body();
   (void)hipStreamSynchronize(c->stream);
@@ -2821,7 +2822,7 @@ int32_t dhqr_cs_ldiv_darray_f64(dhqr_comm *cm, const double *hBlock, int64_t m, 
     CHECK(cs_solve(pr, dvec, dvec + mpad));
     HIPCHECK(hipMemcpyAsync(hx, dvec, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));  // src:320
     HIPCHECK(hipStreamSynchronize(c->stream));
-    return DHQR_OK;
+    return pipe_error_check(c);  // (the solve of dhqr_qtb.h has bounded inter-workgroup waits)
   };
   const int32_t rc = body();
   (void)hipDeviceSynchronize();
@@ -3100,7 +3101,7 @@ int32_t dhqr_mg_solve_f64(dhqr_mg *g, const double *hb, double *hx) {
     CHECK(cs_solve(mg_problem(g, r), db, du));
     if (r == 0) HIPCHECK(hipMemcpyAsync(hx, db, (size_t)g->n * sizeof(double), hipMemcpyDeviceToHost, k.c->stream));
     HIPCHECK(hipStreamSynchronize(k.c->stream));
-    return DHQR_OK;
+    return pipe_error_check(k.c);
   });
 }
 
@@ -3500,7 +3501,7 @@ int32_t dhqr_mg_rs_solve_f64(dhqr_mg *g, const double *hb, double *hx) {
     CHECK(rs_solve(pr, db, dx));
     if (r == 0) HIPCHECK(hipMemcpyAsync(hx, dx, (size_t)pr.n * sizeof(double), hipMemcpyDeviceToHost, pr.c->stream));
     HIPCHECK(hipStreamSynchronize(pr.c->stream));
-    return DHQR_OK;
+    return pipe_error_check(pr.c);
   });
 }
 

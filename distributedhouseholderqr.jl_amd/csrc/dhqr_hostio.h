@@ -70,9 +70,14 @@ static int32_t hio_init(HostIo &h, int64_t ldd, int64_t n) {
       HIPCHECK(hipEventCreateWithFlags(&h.ev[i], hipEventDisableTiming));
     }
   if (need > h.cap) {
+    // cap describes ALL four buffers: it is zero from the moment the first one is released until the last new one exists, so
+    // a failure part-way (the caller then falls back to the plain copy form) never leaves a non-zero cap over null or
+    // mismatched buffers for a later, smaller call to trust
+    h.cap = 0;
     for (double *&p : h.stage) {
-      if (p) HIPCHECK(hipHostFree(p));
+      double *q = p;
       p = nullptr;
+      if (q) HIPCHECK(hipHostFree(q));
     }
     for (double *&p : h.stage) HIPCHECK(hipHostMalloc((void **)&p, need * sizeof(double), hipHostMallocDefault));
     h.cap = need;

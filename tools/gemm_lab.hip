@@ -205,7 +205,7 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 }
 __device__ __forceinline__ void glds16(const double *g, uint32_t lds_byte) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_byte))
-               : "memory");  // m0 is reserved (not allocatable): nothing else in these kernels uses it
+               : "memory", "m0");
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
