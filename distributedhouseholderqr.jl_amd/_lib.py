@@ -76,6 +76,7 @@ SIGNATURES = {
     "dhqr_get_panel_counters": (_i32, [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dhqr_set_r_source": (_i32, [_p, _i32]),
     "dhqr_set_tsqr_rung": (_i32, [_p, _i32]),
+    "dhqr_set_small_route": (_i32, [_p, _i32]),
     "dhqr_tsqr_r_f64": (_i32, [_p, _p, _i64, _i64, _p]),
     "dhqr_get_tsqr_count": (_i32, [_p, ctypes.POINTER(_i64)]),
     "dhqr_fill_uniform_f64": (_i32, [_p, _p, _i64, _i64, _i64, _u64, _i64, _i64, _i64, _i32, _i32]),

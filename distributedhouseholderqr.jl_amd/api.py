@@ -88,6 +88,10 @@ class Context:
         """False: rejected panels skip the TSQR-HR rung (straight to the column-by-column kernels)"""
         check(_lib.lib().dhqr_set_tsqr_rung(self._h, 1 if on else 0))
 
+    def set_small_route(self, on: bool):
+        """False: matrices that fit one compute unit's registers go through the general drivers too (csrc/dhqr_small.h)"""
+        check(_lib.lib().dhqr_set_small_route(self._h, 1 if on else 0))
+
     def tsqr_count(self) -> int:
         a = ctypes.c_int64()
         check(_lib.lib().dhqr_get_tsqr_count(self._h, ctypes.byref(a)))

@@ -22,6 +22,7 @@
 #include "dhqr_recon.h"
 #include "dhqr_solve.h"
 #include "dhqr_qtb.h"
+#include "dhqr_small.h"
 #include "dhqr_tsqr.h"
 
 static thread_local char g_err[512] = "";
@@ -113,6 +114,11 @@ struct dhqr_ctx {
                          // else lives on the device (tests), 0 the round-1 solve (blocked apply on the MFMA kernels + 64-row back
                          // substitution: no inter-workgroup waits at all)
   int qtb_vec = -1;      // DHQR_QTB_VEC=1/2: rows per lane of k_qtb_step (-1: by the matrix height)
+  int small_route = 1;   // matrices that fit the registers of one compute unit: ONE single-workgroup launch per qr! / per
+                         // `\` (dhqr_small.h; DHQR_SMALL=0 or dhqr_set_small_route(ctx, 0): the general drivers)
+  double *small_pin = nullptr;  // pinned host staging of the host-array entry points on that route: the kernels read and
+  size_t small_pin_cap = 0;     // write it across PCIe themselves (no hipMemcpy on the path); doubles
+  Buf small_dev;                // device copy of a host factor inside k_small_ldiv (256 x 256)
   bool coop = false;     // the device runs cooperative (all-resident) launches: false on the CPU emulator
   Buf host_mat;          // device copy of the caller's HOST matrix (+ alpha) of dhqr_qr_f64, kept between calls
   int pair = 1;                  // 1: wide updates apply two panels per pass (DHQR_PAIR=0 disables)
@@ -1354,6 +1360,50 @@ static CsProblem cs_single(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_
   return pr;
 }
 
+// ---- the single-workgroup route for small matrices (dhqr_small.h) -------------------------------------------------
+// instantiations of k_small_qr<NR, NQ>: rows <= 16 NR, columns <= 16 NQ, NR * NQ doubles of matrix per lane
+static inline int small_qr_fit(const dhqr_ctx *c, int64_t m, int64_t n) {
+  if (!c->small_route || m < n || n < 1) return -1;
+  if (m <= 128 && n <= 128) return 0;
+  if (m <= 224 && n <= 224) return 1;
+  if (m <= 256 && n <= 192) return 2;
+  return -1;
+}
+static inline bool small_ldiv_fit(const dhqr_ctx *c, int64_t m, int64_t n) {
+  return c->small_route && m <= SML_LDR && n >= 1 && n <= m;
+}
+static int32_t small_qr_launch(dhqr_ctx *c, int fit, const double *Asrc, int64_t lds, double *Adst, int64_t ldd, int64_t m,
+                               int64_t n, double *alpha) {
+  if (fit == 0)
+    hipLaunchKernelGGL((k_small_qr<8, 4>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+  else if (fit == 1)
+    hipLaunchKernelGGL((k_small_qr<14, 7>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+  else
+    hipLaunchKernelGGL((k_small_qr<16, 6>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+static int32_t small_pin_ensure(dhqr_ctx *c, size_t need) {
+  if (need <= c->small_pin_cap) return DHQR_OK;
+  c->small_pin_cap = 0;
+  if (c->small_pin) {
+    double *q = c->small_pin;
+    c->small_pin = nullptr;
+    HIPCHECK(hipHostFree(q));
+  }
+  need = (need + 4095) & ~(size_t)4095;
+  HIPCHECK(hipHostMalloc((void **)&c->small_pin, need * sizeof(double), hipHostMallocDefault));
+  c->small_pin_cap = need;
+  return DHQR_OK;
+}
+static inline void copy_cols(double *dst, int64_t ldd, const double *src, int64_t lds, int64_t m, int64_t n) {
+  if (ldd == m && lds == m) {
+    memcpy(dst, src, (size_t)m * (size_t)n * sizeof(double));
+    return;
+  }
+  for (int64_t j = 0; j < n; ++j) memcpy(dst + j * ldd, src + j * lds, (size_t)m * sizeof(double));
+}
+
 // Every entry point runs on the context's device and restores the caller's current device on return (torch and
 // other HIP users of the process read the current device from the runtime).
 struct DeviceGuard {
@@ -1497,6 +1547,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
       HIPCHECK(hipMemcpyAsync(c->zflags + DHQR_PIPE_LIMIT_OFFSET, &limit, sizeof(int), hipMemcpyHostToDevice, c->stream));
       HIPCHECK(hipStreamSynchronize(c->stream));  // `limit` is a stack variable
     }
+    if (const char *e = getenv("DHQR_SMALL")) c->small_route = atoi(e) != 0;
     if (const char *e = getenv("DHQR_ZPIPE")) c->zpipe = atoi(e) != 0;
     if (const char *e = getenv("DHQR_SOLVE_PIPE")) c->solve_pipe = std::max(0, std::min(3, atoi(e)));
     if (const char *e = getenv("DHQR_KEEP_T")) c->keep_t = atoi(e) != 0;
@@ -1538,7 +1589,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
     c->hio = nullptr;
   }
   Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
-                 &c->ws[1].w1r, &c->ws[1].w2, &c->ws[2].w1, &c->ws[2].w1r, &c->ws[2].w2, &c->spart, &c->spart2, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo, &c->host_mat, &c->sv_T, &c->sv_S, &c->sv_part, &c->sv_small, &c->tc_T, &c->tc_alpha};
+                 &c->ws[1].w1r, &c->ws[1].w2, &c->ws[2].w1, &c->ws[2].w1r, &c->ws[2].w2, &c->spart, &c->spart2, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo, &c->host_mat, &c->sv_T, &c->sv_S, &c->sv_part, &c->sv_small, &c->tc_T, &c->tc_alpha, &c->small_dev};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {
@@ -1546,6 +1597,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
     (void)hipEventDestroy(e.b);
   }
   if (c->hflag) (void)hipHostFree(c->hflag);
+  if (c->small_pin) (void)hipHostFree(c->small_pin);
   if (c->dstat) (void)hipFree(c->dstat);
   if (c->zflags) (void)hipFree(c->zflags);
   for (hipEvent_t e : c->zev)
@@ -1659,6 +1711,12 @@ int32_t dhqr_set_tsqr_rung(dhqr_ctx *c, int32_t on) {
   return DHQR_OK;
 }
 
+int32_t dhqr_set_small_route(dhqr_ctx *c, int32_t on) {
+  if (!c) return set_err(DHQR_EINVAL, "null context");
+  c->small_route = on != 0 ? 1 : 0;
+  return DHQR_OK;
+}
+
 int32_t dhqr_get_tsqr_count(dhqr_ctx *c, int64_t *n_tsqr) {
   if (!c || !n_tsqr) return set_err(DHQR_EINVAL, "null argument");
   *n_tsqr = c->n_tsqr;
@@ -1697,6 +1755,13 @@ int32_t dhqr_factor_f64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t l
   if (nb != 0 && nb != DHQR_NB)
     return set_err(DHQR_EINVAL, "nb must be 0 (unblocked) or %d (blocked); got %d", DHQR_NB, nb);
   if (c->tc_A == dA) c->tc_valid = false;  // whatever was kept for this matrix is gone
+  if (const int fit = small_qr_fit(c, m, n); fit >= 0) {  // the reference's algorithm in one launch, whatever nb says
+    CHECK(prof_begin(c, CAT_RANK1));
+    CHECK(small_qr_launch(c, fit, dA, lda, dA, lda, m, n, dalpha));
+    if (c->profiling)
+      for (int64_t j = 0; j + 1 < n; ++j) c->st.bytes_rank1 += 16.0 * (double)(m - j) * (double)(n - j - 1);
+    return prof_end(c);
+  }
   if (nb == 0) return factor_unblocked_cols(c, dA, m, n, lda, dalpha, CAT_RANK1);
   // kept T factors (solve_pipelined): every panel's k_build_t stores T' here as well
   const int64_t np = cs_nblocks(n);
@@ -1733,6 +1798,21 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
   if (no_columns(m, n)) return DHQR_OK;
   CHECK(check_mat(hA, m, n, lda, true));
   if (!halpha) return set_err(DHQR_EINVAL, "null alpha pointer");
+  if (nb != 0 && nb != DHQR_NB)
+    return set_err(DHQR_EINVAL, "nb must be 0 (unblocked) or %d (blocked); got %d", DHQR_NB, nb);
+  if (const int fit = small_qr_fit(c, m, n); fit >= 0) {
+    // memcpy -> ONE launch that reads and writes the pinned staging buffer across PCIe itself -> one synchronisation ->
+    // memcpy (dhqr_small.h): no hipMemcpy, no device copy
+    const size_t na = (size_t)m * (size_t)n;
+    CHECK(small_pin_ensure(c, na + (size_t)n));
+    double *pA = c->small_pin, *pal = pA + na;
+    copy_cols(pA, m, hA, lda, m, n);
+    CHECK(small_qr_launch(c, fit, pA, m, pA, m, m, n, pal));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    copy_cols(hA, lda, pA, m, m, n);
+    memcpy(halpha, pal, (size_t)n * sizeof(double));
+    return DHQR_OK;
+  }
   // The device copy of the matrix lives in the context between calls (hipMalloc + hipFree of 8 GiB cost ~0.3 s per call at
   // 32768^2, a third of the factorisation; `qr!` is typically called in a loop, test/runtests.jl:84); freed by dhqr_destroy.
   const int64_t ldd = (m + 1) & ~(int64_t)1;
@@ -1917,6 +1997,12 @@ int32_t dhqr_solve_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int6
   CHECK(check_mat(dA, m, n, lda, true));
   if (!dalpha || !db) return set_err(DHQR_EINVAL, "null alpha or b pointer");
   CHECK(prof_begin(c, CAT_SOLVE));
+  if (small_ldiv_fit(c, m, n)) {  // one single-workgroup launch (dhqr_small.h)
+    hipLaunchKernelGGL(k_small_ldiv, dim3(1), dim3(SML_THREADS), 0, c->stream, dA, lda, (int)m, (int)n, dalpha, (const double *)db,
+                       db, (double *)nullptr, (double *)nullptr);
+    LAUNCHCHECK();
+    return prof_end(c);
+  }
   const bool was = c->profiling;
   c->profiling = false;  // the solve is timed as one group
   int32_t rc;
@@ -1968,6 +2054,23 @@ int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64
   if (no_columns(m, n)) return DHQR_OK;
   CHECK(check_mat(hA, m, n, lda, true));
   if (!halpha || !hb || !hx) return set_err(DHQR_EINVAL, "null pointer argument");
+  if (small_ldiv_fit(c, m, n)) {  // (same form as dhqr_qr_f64's small route: the kernel works on the pinned staging buffer)
+    const size_t na = (size_t)m * (size_t)n;
+    CHECK(small_pin_ensure(c, na + 2 * (size_t)n + (size_t)m));
+    double *pA = c->small_pin, *pal = pA + na, *pb = pal + n, *px = pb + m;
+    copy_cols(pA, m, hA, lda, m, n);
+    memcpy(pal, halpha, (size_t)n * sizeof(double));
+    memcpy(pb, hb, (size_t)m * sizeof(double));  // src:318 copy of b
+    // the kernel first brings the factor from the pinned buffer into device memory (its chunk pipeline would otherwise pay
+    // a PCIe round trip per chunk)
+    CHECK(ensure(c, c->small_dev, (size_t)SML_LDR * SML_LDR));
+    hipLaunchKernelGGL(k_small_ldiv, dim3(1), dim3(SML_THREADS), 0, c->stream, (const double *)pA, m, (int)m, (int)n,
+                       (const double *)pal, (const double *)pb, pb, px, c->small_dev.p);
+    LAUNCHCHECK();
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    memcpy(hx, px, (size_t)n * sizeof(double));  // src:320
+    return DHQR_OK;
+  }
   // the device copy of the context (shared with dhqr_qr_f64: no 8 GiB hipMalloc / hipFree per call) and the staged upload
   // of dhqr_hostio.h; the factor is uploaded again -- the caller may have changed it since qr! (H.A is the caller's memory)
   const int64_t ldd = (m + 1) & ~(int64_t)1;

@@ -41,14 +41,19 @@ __device__ __forceinline__ dhqr_d4 mfma_f64(double a, double b, dhqr_d4 c) {
 // change that).  Hidden from the compiler, the load is ordered by the caller: gemm_lds_landed() (vmcnt + s_barrier) between
 // the issue and the first ds_read of that buffer by any wave.  Compiler-visible global loads issued BEFORE a batch of these
 // are still waited for correctly (its vmcnt(N) under-counts what is in flight, which only waits longer); consume them before
-// the next batch is issued (sched_barrier) or they drag the whole batch into their wait.  m0 is declared clobbered (the compiler may use it
-// itself: movrel, LDS-direct, sendmsg).  `lds` = any pointer into the workgroup's LDS, `byte_off` wave-uniform.
+// the next batch is issued (sched_barrier) or they drag the whole batch into their wait.  m0 is a reserved register (a clobber declaration is not honoured for it), so the
+// statement saves and restores it: whatever the compiler keeps there (movrel, LDS-direct, sendmsg) survives; the load
+// latches m0 when it issues (consecutive loads with different m0 were always issued back to back).  `lds` = any pointer into the workgroup's LDS, `byte_off` wave-uniform.
 // Measured (tools/gemm_lab.hip, 16384^2, K = 512): 60.3 -> 67.9 TFLOP/s, bit-identical results; what goes away is the staging
 // registers, 8 ds_write_b128 + ~30 masking VALU per K-tile and wave, and the vmcnt wait in front of them.
 __device__ __forceinline__ void glds16(const double *g, double *lds, uint32_t byte_off) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds + byte_off;
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(a)) : "memory", "m0");
+  uint32_t m0_saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_saved)
+               : "v"(g), "s"(__builtin_amdgcn_readfirstlane(a))
+               : "memory");
 #else
   double *d = reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + byte_off) + 2 * (threadIdx.x & 63);
   d[0] = g[0];

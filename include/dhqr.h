@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DHQR_VERSION 400 /* 0.4.0: round 5 (the solve of csrc/dhqr_qtb.h, kept T factors, DHQR_TUNE; no entry point added or changed) */
+#define DHQR_VERSION 500 /* 0.5.0: round 6 (dhqr_set_small_route added; nothing else changed) */
 
 #define DHQR_OK 0
 #define DHQR_EINVAL (-1)   /* bad argument (null pointer, m < n, ld < m, unsupported nb ...) */
@@ -118,6 +118,12 @@ int32_t dhqr_set_tsqr_rung(dhqr_ctx *ctx, int32_t on);
  * signs R_jj = alpha_j when the tree feeds a factorisation).  Async on the ctx stream. */
 int32_t dhqr_tsqr_r_f64(dhqr_ctx *ctx, const double *dP, int64_t rows, int64_t ldp, double *dR);
 int32_t dhqr_get_tsqr_count(dhqr_ctx *ctx, int64_t *n_tsqr);
+/* Small matrices -- the reference's own test shapes start at 110 x 100, test/runtests.jl:42 -- take ONE single-workgroup
+ * launch per qr! (m <= 128 and n <= 128, m <= 224 and n <= 224, or m <= 256 and n <= 192: the matrix lives in the
+ * registers of one compute unit, the reference's column-by-column algorithm src:122-148,198-213 as written) and per `\`
+ * (m <= 256), whatever `nb` says; the host-array entry points dhqr_qr_f64 / dhqr_ldiv_f64 then run the kernel directly
+ * on a pinned staging buffer (csrc/dhqr_small.h).  on = 0: the general drivers for every shape (also DHQR_SMALL=0). */
+int32_t dhqr_set_small_route(dhqr_ctx *ctx, int32_t on);
 
 /* ------------------------------------------------------------------ synthetic inputs
  * Replaces rand(T,m,n) / rand(T,m) of test/runtests.jl:45-46 with the portable counter-based

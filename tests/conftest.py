@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 # the two-panel (K = 256) driver normally engages only for n >= 4096; tests exercise it on small shapes
 os.environ.setdefault("DHQR_PAIR_MIN_N", "512")
+# the single-workgroup route for matrices that fit one compute unit (csrc/dhqr_small.h) is the product default; the suite
+# keeps exercising the GENERAL drivers on its many small shapes and switches the route on where it tests it
+# (Context.set_small_route / DHQR_SMALL=1: test_small_route_* in test_gpu_kernels.py and test_emulated_library.py)
+os.environ.setdefault("DHQR_SMALL", "0")
 
 
 def pytest_configure(config):

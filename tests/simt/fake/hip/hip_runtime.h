@@ -242,6 +242,9 @@ inline int simt_update_dpp(int old, int src, int ctrl, int row_mask, int bank_ma
 inline int simt_readlane(int v, int l) { return simt_shfl_bits(v, l); }
 #define __builtin_amdgcn_readlane(v, l) simt_readlane(v, l)
 #define __builtin_amdgcn_readfirstlane(v) simt_readlane(v, 0)
+// s_nop-sized on the hardware (a wave executes in lockstep; the builtin only pins the compiler's schedule).  Here the lanes
+// of a wave are independent fibers / threads: lanes that hand data to each other through LDS meet at an exchange.
+#define __builtin_amdgcn_wave_barrier() ((void)simt_readlane(0, 0))
 inline int __double2loint(double d) { uint64_t b; std::memcpy(&b, &d, 8); return (int)(uint32_t)b; }
 inline int __double2hiint(double d) { uint64_t b; std::memcpy(&b, &d, 8); return (int)(uint32_t)(b >> 32); }
 inline double __hiloint2double(int hi, int lo) {
@@ -291,6 +294,7 @@ inline long long wall_clock64() {
 #define __hip_atomic_fetch_max(p, v, order, scope) __atomic_fetch_max((p), (v), (order))
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
   return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);

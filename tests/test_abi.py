@@ -52,7 +52,7 @@ def test_layout_constants_match_the_header(pkg):
 
 def test_version_and_error_string(pkg):
     L = pkg._lib.lib()
-    assert L.dhqr_version() == 400
+    assert L.dhqr_version() == 500
     assert isinstance(L.dhqr_last_error(), bytes)
     assert L.dhqr_panel_ldv(100) == 112 and L.dhqr_panel_ldv(128) == 128
     assert L.dhqr_panel_buffer_elems(256) == 256 * 128 + 2 * 128 * 128 + 128 + 16  # V | T | Tt | alpha | status

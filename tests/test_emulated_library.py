@@ -359,6 +359,80 @@ def test_pipelined_solve_kernels(emu, orc, m, n, env):
     assert np.abs(xs[0] - xs[1]).max() <= 1e-11 * np.abs(xo).max()
 
 
+SMALL_SHAPES = [(1, 1), (5, 3), (33, 33), (64, 64), (111, 100), (128, 128), (130, 20), (220, 200), (224, 224), (224, 208), (256, 192),
+                (256, 17), (129, 129)]
+
+
+@pytest.mark.parametrize("m,n", SMALL_SHAPES)
+def test_small_route_single_workgroup_kernels(emu, orc, m, n):
+    """csrc/dhqr_small.h: qr! and `\\` of a matrix that fits one compute unit's registers in ONE launch each (k_small_qr: the
+    reference's column-by-column algorithm with the matrix in registers; k_small_ldiv: Q'b + back substitution with the
+    factor streamed through LDS) -- device pointers and the host-array entry points on the pinned staging buffer, every
+    instantiation and its edges, against the oracle; nb is ignored on this route"""
+    h = _ctx(emu, DHQR_SMALL=1)
+    A0 = orc.rand_matrix(m, n, 41)
+    Ho, ao = orc.householder(A0)
+    for nb in (0, 128):
+        A, al = _factor(emu, h, A0, nb)
+        _check(orc, A0, A, al)
+    fa, fb = _counters(emu, h)
+    assert fa == 0 and fb == 0  # no panel went through the blocked drivers
+    A2 = A0.copy(order="F")
+    al2 = np.zeros(n)
+    assert emu.dhqr_qr_f64(h, _ptr(A2), m, n, m, _ptr(al2), 128) == 0, emu.dhqr_last_error()
+    assert np.array_equal(A2, A) and np.array_equal(al2, al)  # same kernel, same arithmetic
+    b = orc.rand_vector(m, 42)
+    xo = orc.solve(Ho, ao, b)
+    bb = b.copy()
+    assert emu.dhqr_solve_f64(h, _ptr(A), m, n, m, _ptr(al), _ptr(bb)) == 0, emu.dhqr_last_error()
+    assert emu.dhqr_synchronize(h) == 0
+    assert np.abs(bb[:n] - xo).max() <= 1e-10 * np.abs(xo).max()
+    qtb = b.copy()
+    for j in range(n):
+        s_ = Ho[j:, j] @ qtb[j:]
+        qtb[j:] -= Ho[j:, j] * s_
+    if m > n:  # the reference leaves Q'b below the triangle (src:284-294)
+        assert np.abs(bb[n:] - qtb[n:]).max() <= 1e-12 * max(1.0, np.abs(qtb).max())
+    x = np.zeros(n)
+    b2 = b.copy()
+    assert emu.dhqr_ldiv_f64(h, _ptr(A), m, n, m, _ptr(al), _ptr(b2), _ptr(x)) == 0
+    assert np.array_equal(b2, b) and np.array_equal(x, bb[:n])
+    # a padded leading dimension on the host side
+    ld = m + 3
+    A3 = np.zeros((ld, n), order="F")
+    A3[:m] = A0
+    al3 = np.zeros(n)
+    assert emu.dhqr_qr_f64(h, _ptr(A3), m, n, ld, _ptr(al3), 0) == 0
+    assert np.array_equal(A3[:m], A) and np.all(A3[m:] == 0.0)
+    emu.dhqr_destroy(h)
+
+
+def test_small_route_off_and_out_of_range(emu, orc):
+    """dhqr_set_small_route(ctx, 0) and shapes beyond the instantiations take the general drivers (seen in the launch-group
+    statistics: the small route is ONE group of the reflector-apply category, the blocked drivers time panels)"""
+    h = _ctx(emu, DHQR_SMALL=1)
+
+    def groups(A0, nb=128):
+        assert emu.dhqr_reset_stats(h) == 0 and emu.dhqr_set_profiling(h, 1) == 0
+        A, al = _factor(emu, h, A0, nb)
+        _check(orc, A0, A, al)
+        st = emu.Stats()
+        assert emu.dhqr_get_stats(h, ctypes.byref(st)) == 0
+        assert emu.dhqr_set_profiling(h, 0) == 0
+        return st.n_rank1, st.n_panel
+
+    A0 = orc.rand_matrix(200, 130, 3)
+    assert groups(A0) == (1, 0)
+    assert emu.dhqr_set_small_route(h, 0) == 0
+    r1, pn = groups(A0)
+    assert r1 == 0 and pn >= 2          # two panels through the blocked driver
+    assert emu.dhqr_set_small_route(h, 1) == 0
+    r1, pn = groups(orc.rand_matrix(300, 225, 4))    # 225 columns: beyond every instantiation
+    assert r1 == 0 and pn >= 2
+    assert groups(orc.rand_matrix(224, 208, 4), nb=0) == (1, 0)
+    emu.dhqr_destroy(h)
+
+
 def test_complex_entry_points(emu, orc):
     h = _ctx(emu)
     m, n = 150, 90

@@ -262,3 +262,95 @@ def test_trim_releases_and_the_context_keeps_working(pkg, orc, torch_cuda):
         assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     finally:
         ctx.close()
+
+
+SMALL_SHAPES = [(1, 1), (5, 3), (33, 33), (64, 64), (110, 100), (111, 100), (128, 128), (130, 20), (220, 200), (224, 208),
+                (256, 192), (256, 17), (129, 129)]
+
+
+@pytest.fixture
+def small_route(pkg):
+    """the product default (csrc/dhqr_small.h) on the shared context for the duration of one test (conftest.py switches it
+    off for the rest of the suite, which exercises the general drivers on small shapes)"""
+    ctx = pkg.get_context(0)
+    ctx.set_small_route(True)
+    yield ctx
+    ctx.set_small_route(False)
+
+
+@pytest.mark.parametrize("m,n", SMALL_SHAPES)
+def test_small_route_vs_oracle(pkg, orc, torch_cuda, small_route, m, n):
+    """qr! and `\\` of a matrix that fits one compute unit's registers: ONE single-workgroup launch each (k_small_qr,
+    k_small_ldiv), on device tensors and on host arrays (the kernels then work on the pinned staging buffer across PCIe),
+    every instantiation and its edges, against the oracle (src:122-148,198-213,215-294)"""
+    torch = torch_cuda
+    A0 = orc.rand_matrix(m, n, 41)
+    Ho, ao = orc.householder(A0)
+    b = orc.rand_vector(m, 42)
+    xo = orc.solve(Ho, ao, b)
+    scale = np.abs(Ho).max()
+    tol = 8.0 * max(n, 8) * np.finfo(np.float64).eps
+    got = []
+    for nb in (0, 128):
+        A = pkg.rand_colmajor(m, n, 41, "cuda:0")
+        H = pkg.qr_(A, nb=nb)
+        torch.cuda.synchronize()
+        assert np.abs(H.A.cpu().numpy() - Ho).max() <= tol * scale
+        assert np.abs(H.α.cpu().numpy() - ao).max() <= tol * scale
+        got.append(H.A.cpu().numpy())
+    assert np.array_equal(got[0], got[1])  # nb is ignored on this route: same launch
+    bd = torch.tensor(b, device="cuda:0")
+    x = pkg.ldiv(H, bd)
+    assert np.array_equal(bd.cpu().numpy(), b), "H \\ b must not modify b (src:318)"
+    assert np.abs(x.cpu().numpy() - xo).max() <= 1e-9 * np.abs(xo).max()
+    assert pkg.residual(H, pkg.rand_colmajor(m, n, 41, "cuda:0")) < 1e-12
+    # host arrays: the drop-in qr!(A::Matrix) / H \ b
+    Ah = np.asfortranarray(A0.copy())
+    Hh = pkg.qr_(Ah)
+    assert np.array_equal(Hh.A, got[0]) and np.array_equal(Hh.α, H.α.cpu().numpy())
+    xh = pkg.ldiv(Hh, b)
+    assert np.array_equal(xh, x.cpu().numpy())
+    # a strided host matrix (leading dimension > m)
+    big = np.zeros((m + 5, n), order="F")
+    big[:m] = A0
+    Hv = pkg.qr_(big[:m])
+    assert np.array_equal(np.asarray(Hv.A), got[0]) and np.all(big[m:] == 0.0)
+
+
+def test_small_route_is_one_launch_group(pkg, orc, torch_cuda, small_route):
+    """the route is taken (one reflector-apply group, no panel group) and leaves it when switched off or out of range"""
+    ctx = small_route
+
+    def groups(m, n, nb):
+        ctx.reset_stats()
+        ctx.set_profiling(True)
+        A = pkg.rand_colmajor(m, n, 1, "cuda:0")
+        pkg.qr_(A, nb=nb)
+        st = ctx.stats()
+        ctx.set_profiling(False)
+        return st["n_rank1"], st["n_panel"]
+
+    assert groups(220, 200, 128) == (1, 0)
+    assert groups(110, 100, 0) == (1, 0)
+    r1, pn = groups(300, 225, 128)
+    assert r1 == 0 and pn >= 2
+    ctx.set_small_route(False)
+    r1, pn = groups(220, 200, 128)
+    assert r1 == 0 and pn >= 2
+    ctx.set_small_route(True)
+
+
+def test_small_route_reference_inequality(pkg, orc, torch_cuda, small_route):
+    """test/runtests.jl:61-63 at the two reference shapes the route covers: ||A'(Ax - b)|| < 8 x LAPACK's, several draws"""
+    import scipy.linalg as sl
+    for (m, n) in ((110, 100), (220, 200)):
+        for seed in range(5):
+            A0 = np.asfortranarray(orc.rand_matrix(m, n, 100 + seed))
+            b = orc.rand_vector(m, 200 + seed)
+            H = pkg.qr_(A0.copy(order="F"))
+            x = pkg.ldiv(H, b)
+            q, r = sl.qr(A0, mode="economic")
+            x1 = sl.solve_triangular(r, q.T @ b)
+            ne = np.linalg.norm(A0.T @ (A0 @ x - b))
+            ne1 = np.linalg.norm(A0.T @ (A0 @ x1 - b))
+            assert ne < 8 * ne1, (m, n, seed, ne, ne1)

@@ -204,8 +204,11 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
 }
 __device__ __forceinline__ void glds16(const double *g, uint32_t lds_byte) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_byte))
-               : "memory", "m0");
+  uint32_t m0_saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_saved)
+               : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_byte))
+               : "memory");
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
