@@ -114,6 +114,15 @@ struct dhqr_ctx {
                          // else lives on the device (tests), 0 the round-1 solve (blocked apply on the MFMA kernels + 64-row back
                          // substitution: no inter-workgroup waits at all)
   int qtb_vec = -1;      // DHQR_QTB_VEC=1/2: rows per lane of k_qtb_step (-1: by the matrix height)
+  int gram_strips = 1;   // the panel chain's Gram products as four 32-row strips (gram128; DHQR_TUNE gram_strips=0: one tile)
+  int fuse_fix = 1;      // k_recon_fix in the epilogue of V = P M^{-1} (mul128; DHQR_TUNE fuse_fix=0: its own launch)
+  int commit_off = -1;   // an accepted panel's commit (12 us of copies into the matrix) leaves the lane: -1 (default) with more
+                         // than one rank, where it runs on the communication stream BEHIND the panel's broadcast; 0 never;
+                         // 1 also at one rank, on a stream of its own -- measured there (profiles/r06_ab_chain.txt): a
+                         // fourth busy stream beside wide / lane / side shares a hardware queue and the factorisation
+                         // takes 1.9 x as long at 8192^2, 1.13 x at 32768^2 (DHQR_TUNE commit_off)
+  hipStream_t cstream = nullptr;  // ... that stream (created on first use)
+  hipEvent_t ev_commit[2] = {nullptr, nullptr};  // behind the off-lane commit of the last panel of each parity
   int small_route = 1;   // matrices that fit the registers of one compute unit: ONE single-workgroup launch per qr! / per
                          // `\` (dhqr_small.h; DHQR_SMALL=0 or dhqr_set_small_route(ctx, 0): the general drivers)
   double *small_pin = nullptr;  // pinned host staging of the host-array entry points on that route: the kernels read and
@@ -766,18 +775,35 @@ static int32_t factor_panel_v2(dhqr_ctx *c, double *P, int64_t rows, int64_t w, 
 // ---- panel factorisation, R-first fast path (dhqr_recon.h) -------------------------------------
 // G = X'X (128 x 128) for a rows x 128 operand: split-K TN GEMM + deterministic reduction.
 static int32_t gram128(dhqr_ctx *c, const double *X, int64_t ldx, int64_t rows, double *out) {
-  int64_t nsplit, rps;
-  pick_split(rows, 1, 512, 256, &nsplit, &rps, 512, 64);
-  CHECK(ensure(c, c->spart, (size_t)nsplit * DHQR_NBV * DHQR_NBV));
   const bool vec = (ldx % 2 == 0) && (rows % 2 == 0) && aligned16(X);
-  if (vec)
-    hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, X, ldx, X, ldx,
-                       1, (int64_t)0, rows, (int64_t)DHQR_NBV, rps, c->spart.p, (int64_t)DHQR_NBV,
-                       (int64_t)DHQR_NBV * DHQR_NBV);
-  else
-    hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, X, ldx, X, ldx,
-                       1, (int64_t)0, rows, (int64_t)DHQR_NBV, rps, c->spart.p, (int64_t)DHQR_NBV,
-                       (int64_t)DHQR_NBV * DHQR_NBV);
+  int64_t nsplit, rps;
+  if (c->gram_strips && rows >= 1024) {
+    // r6: FOUR 32-row strips of the 128 x 128 result (blockIdx.z) over at most 64 row slabs instead of one 128-row tile over
+    // up to 256: the same ~256 workgroups and the same K-loop time (the product is MFMA-bound either way), a QUARTER of the
+    // split-K partials per element -- at 32768 rows 8 MiB instead of 32 MiB written by the product and read back by the
+    // reduction, which is most of what the reduction launch costs on the panel chain.  The four strips of a slab run on
+    // one XCD (workgroup ids 64 apart) and share the slab through its L2.
+    pick_split(rows, 4, 256, 64, &nsplit, &rps, 256, 64);
+    CHECK(ensure(c, c->spart, (size_t)nsplit * DHQR_NBV * DHQR_NBV));
+    const dim3 grid(1, (unsigned)nsplit, 4);
+    if (vec)
+      hipLaunchKernelGGL((k_gemm_tn<2, 1, 32>), grid, dim3(256), 0, c->stream, X, ldx, X, ldx, 1, (int64_t)0, rows,
+                         (int64_t)DHQR_NBV, rps, c->spart.p, (int64_t)DHQR_NBV, (int64_t)DHQR_NBV * DHQR_NBV);
+    else
+      hipLaunchKernelGGL((k_gemm_tn<1, 1, 32>), grid, dim3(256), 0, c->stream, X, ldx, X, ldx, 1, (int64_t)0, rows,
+                         (int64_t)DHQR_NBV, rps, c->spart.p, (int64_t)DHQR_NBV, (int64_t)DHQR_NBV * DHQR_NBV);
+  } else {
+    pick_split(rows, 1, 512, 256, &nsplit, &rps, 512, 64);
+    CHECK(ensure(c, c->spart, (size_t)nsplit * DHQR_NBV * DHQR_NBV));
+    if (vec)
+      hipLaunchKernelGGL((k_gemm_tn<2, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, X, ldx, X, ldx,
+                         1, (int64_t)0, rows, (int64_t)DHQR_NBV, rps, c->spart.p, (int64_t)DHQR_NBV,
+                         (int64_t)DHQR_NBV * DHQR_NBV);
+    else
+      hipLaunchKernelGGL((k_gemm_tn<1, 1, 128>), dim3(1, (unsigned)nsplit), dim3(256), 0, c->stream, X, ldx, X, ldx,
+                         1, (int64_t)0, rows, (int64_t)DHQR_NBV, rps, c->spart.p, (int64_t)DHQR_NBV,
+                         (int64_t)DHQR_NBV * DHQR_NBV);
+  }
   hipLaunchKernelGGL(k_reduce_splits, dim3(DHQR_NBV * DHQR_NBV / 64), dim3(256), 0, c->stream,
                      (const double *)c->spart.p, (int)nsplit, (int64_t)DHQR_NBV * DHQR_NBV,
                      (int64_t)DHQR_NBV * DHQR_NBV, out);
@@ -785,9 +811,21 @@ static int32_t gram128(dhqr_ctx *c, const double *X, int64_t ldx, int64_t rows, 
 }
 // out (rows x 128, ld ldo) = X (rows x 128, ld ldx) * Y with negY = -Y given (128 x 128, ld 128)
 static int32_t mul128(dhqr_ctx *c, const double *X, int64_t ldx, int64_t rows, const double *negY, double *out,
-                      int64_t ldo) {
+                      int64_t ldo, const double *fix_alpha = nullptr) {
   const bool vec = (ldx % 2 == 0) && (ldo % 2 == 0) && (rows % 2 == 0) && aligned16(X) && aligned16(out);
   dim3 grid((unsigned)((rows + 127) / 128), 1);
+  if (fix_alpha) {  // the panel's V = tril((X - alpha E) Y) in the product's epilogue (k_gemm_nn_vfix, dhqr_gemm.h)
+    if (vec && ((rows + 127) / 128) < 512)
+      hipLaunchKernelGGL((k_gemm_nn_vfix<2, 64>), dim3((unsigned)((rows + 63) / 64), 1), dim3(256), 0, c->stream, X, ldx, negY,
+                         (int64_t)DHQR_NBV, out, ldo, rows, (int64_t)DHQR_NBV, fix_alpha);
+    else if (vec)
+      hipLaunchKernelGGL((k_gemm_nn_vfix<2, 128>), grid, dim3(256), 0, c->stream, X, ldx, negY, (int64_t)DHQR_NBV, out, ldo, rows,
+                         (int64_t)DHQR_NBV, fix_alpha);
+    else
+      hipLaunchKernelGGL((k_gemm_nn_vfix<1, 128>), grid, dim3(256), 0, c->stream, X, ldx, negY, (int64_t)DHQR_NBV, out, ldo, rows,
+                         (int64_t)DHQR_NBV, fix_alpha);
+    return DHQR_OK;
+  }
   launch_nn_sub<128, true>(c, vec, grid, X, ldx, negY, (int64_t)DHQR_NBV, out, ldo, rows, (int64_t)DHQR_NBV, 0, false);
   return DHQR_OK;
 }
@@ -947,15 +985,41 @@ static int32_t tsqr_local_r(dhqr_ctx *c, const double *P, int64_t ldp, int64_t r
 // verification: nothing is written to P, alpha or pb.T/Tt/alpha unless the panel is accepted on the device
 // (k_build_t); once a panel has failed every later commit / trailing update with epoch >= its index is a
 // no-op, and the driver resumes from it with factor_panel_sync after its single final synchronisation.
+// The 128 x 128 scratch matrices of a panel (R1, -R1^{-1}, R, Rref, -M^{-1}, G | alpha_tmp): TWO sets, by panel parity -- a
+// panel's commit (reads Rref, alpha_tmp) may run on another stream while the next panel's chain fills the other set.
+static inline size_t panel_rbuf_elems() { return 6 * (size_t)DHQR_NBV * DHQR_NBV + 1024; }
+static inline double *panel_rbuf(dhqr_ctx *c, int panel_idx) { return c->rbuf.p + (size_t)(panel_idx & 1) * panel_rbuf_elems(); }
+// commit of an accepted panel (device-side predicate): reflectors, R, alpha in one launch, on `stream`
+// part: 0 everything; 1 only alpha -> the panel buffer's tail (what a broadcast of the buffer carries to the peers: must be
+// in place BEFORE the broadcast); 2 everything else (reflectors and R -> the matrix, alpha -> the caller's vector)
+static int32_t panel_commit_enqueue(dhqr_ctx *c, hipStream_t stream, double *P, int64_t rows, int64_t ldp, double *alpha,
+                                    const PanelBuf &pb, int panel_idx, int part = 0) {
+  const size_t NN = (size_t)DHQR_NBV * DHQR_NBV;
+  const double *Rref = panel_rbuf(c, panel_idx) + 3 * NN, *altmp = panel_rbuf(c, panel_idx) + 6 * NN;
+  if (part == 1) {
+    hipLaunchKernelGGL(k_commit_alpha, dim3(1), dim3(DHQR_NBV), 0, stream, altmp, (int)DHQR_NBV, (double *)nullptr, pb.alpha,
+                       (const int *)c->dstat, panel_idx);
+  } else {
+    dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
+    hipLaunchKernelGGL(k_commit_panel, grid, dim3(256), 0, stream, P, ldp, rows, (const double *)pb.V, pb.ldv, Rref, altmp, alpha,
+                       part == 2 ? (double *)nullptr : pb.alpha, (const int *)c->dstat, panel_idx);
+  }
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+// ev_t != nullptr: the commit is left to the caller (panel_commit_enqueue on a stream that waits for ev_t, recorded here
+// behind k_build_t; the caller records c->ev_commit[panel_idx & 1] behind the commit) -- r6: 12 us less on the lane per panel.
 static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t ldp, double *alpha, const PanelBuf &pb,
-                                  int passes, int panel_idx, hipEvent_t ev_v = nullptr) {
+                                  int passes, int panel_idx, hipEvent_t ev_v = nullptr, hipEvent_t ev_t = nullptr) {
   const int64_t ldv = pb.ldv;
   const size_t NN = (size_t)DHQR_NBV * DHQR_NBV;
-  CHECK(ensure(c, c->rbuf, 6 * NN + 1024));
+  CHECK(ensure(c, c->rbuf, 2 * panel_rbuf_elems()));
   if (passes == 2) CHECK(ensure(c, c->vts, (size_t)panel_elems(rows)));
   if (passes == 3) CHECK(ensure(c, c->tsq, TsqrLocal::elems(rows)));
   CHECK(ensure(c, c->sfull, NN));
-  double *R1 = c->rbuf.p, *negR1inv = R1 + NN, *Rf = R1 + 2 * NN, *Rref = R1 + 3 * NN, *negMinv = R1 + 4 * NN;
+  // this panel's scratch set was last read by the commit of panel_idx - 2 (a no-op wait unless that commit left the lane)
+  if (c->ev_commit[panel_idx & 1]) HIPCHECK(hipStreamWaitEvent(c->stream, c->ev_commit[panel_idx & 1], 0));
+  double *R1 = panel_rbuf(c, panel_idx), *negR1inv = R1 + NN, *Rf = R1 + 2 * NN, *Rref = R1 + 3 * NN, *negMinv = R1 + 4 * NN;
   double *G = R1 + 5 * NN, *altmp = R1 + 6 * NN;
   int *bflag = c->dstat + 1;
   CHECK(prof_begin(c, CAT_PANEL));
@@ -988,9 +1052,13 @@ static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t 
       hipLaunchKernelGGL((k_panel_top<false>), dim3(1), dim3(1024), 0, c->stream, (const double *)G, (const double *)P, ldp, altmp,
                          Rref, negMinv, bflag);
     }
-    CHECK(mul128(c, X, ldx, rows, negMinv, pb.V, ldv));                            // Vw = X M^{-1}
-    hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, pb.V, ldv,
-                       (const double *)(passes == 3 ? G : altmp), (const double *)negMinv);  // Vw = tril((X - aE) M^{-1})
+    if (c->fuse_fix) {
+      CHECK(mul128(c, X, ldx, rows, negMinv, pb.V, ldv, passes == 3 ? G : altmp));  // Vw = tril((X - aE) M^{-1}), one launch
+    } else {
+      CHECK(mul128(c, X, ldx, rows, negMinv, pb.V, ldv));                            // Vw = X M^{-1}
+      hipLaunchKernelGGL(k_recon_fix, dim3(NN / 256), dim3(256), 0, c->stream, pb.V, ldv,
+                         (const double *)(passes == 3 ? G : altmp), (const double *)negMinv);  // Vw = tril((X - aE) M^{-1})
+    }
     // pb.V holds the reflectors from here on (T, the verdict and the commit follow): what needs V alone may start
     if (ev_v) HIPCHECK(hipEventRecord(ev_v, c->stream));
     if (passes == 3)  // R = D R_t, alpha = diag(R)
@@ -1001,9 +1069,8 @@ static int32_t panel_fast_enqueue(dhqr_ctx *c, double *P, int64_t rows, int64_t 
     hipLaunchKernelGGL(k_build_t, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sfull.p, (int)DHQR_NBV, pb.T, pb.Tt,
                        c->recon_tol, c->dstat, panel_idx, pb.alpha + DHQR_NBV, c->tt_keep);
     // commit (device-side predicate): reflectors, R, alpha in one launch; T is only ever read by accepted consumers
-    dim3 grid((unsigned)std::min<int64_t>((rows + 255) / 256, 64), DHQR_NBV);
-    hipLaunchKernelGGL(k_commit_panel, grid, dim3(256), 0, c->stream, P, ldp, rows, (const double *)pb.V, ldv, (const double *)Rref,
-                       (const double *)altmp, alpha, pb.alpha, (const int *)c->dstat, panel_idx);
+    if (ev_t) HIPCHECK(hipEventRecord(ev_t, c->stream));
+    else CHECK(panel_commit_enqueue(c, c->stream, P, rows, ldp, alpha, pb, panel_idx));
     LAUNCHCHECK();
     return DHQR_OK;
   };
@@ -1552,6 +1619,9 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_SOLVE_PIPE")) c->solve_pipe = std::max(0, std::min(3, atoi(e)));
     if (const char *e = getenv("DHQR_KEEP_T")) c->keep_t = atoi(e) != 0;
     { long long v; if (tune_get("qtb_vec", &v)) c->qtb_vec = (int)v; }
+    { long long v; if (tune_get("gram_strips", &v)) c->gram_strips = v != 0; }
+    { long long v; if (tune_get("fuse_fix", &v)) c->fuse_fix = v != 0; }
+    { long long v; if (tune_get("commit_off", &v)) c->commit_off = (int)v; }
     hipLaunchKernelGGL(k_set_status, dim3(1), dim3(64), 0, c->stream, c->dstat, INT_MAX);
     LAUNCHCHECK();
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -1604,6 +1674,9 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
     if (e) (void)hipEventDestroy(e);
   if (c->hi) (void)hipStreamDestroy(c->hi);
   if (c->hi2) (void)hipStreamDestroy(c->hi2);
+  if (c->cstream) (void)hipStreamDestroy(c->cstream);
+  for (hipEvent_t e : c->ev_commit)
+    if (e) (void)hipEventDestroy(e);
   if (c->own) (void)hipStreamDestroy(c->own);
   delete c;
   return DHQR_OK;

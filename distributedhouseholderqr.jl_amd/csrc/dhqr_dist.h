@@ -36,6 +36,7 @@ struct CsState {
   hipEvent_t ev_group[CS_EVR], ev_wide[CS_EVR], ev_head[CS_EVR], ev_lane[CS_EVR];
   hipEvent_t ev_ready[2 * CS_EVR], ev_recv[2 * CS_EVR];
   hipEvent_t ev_v[2 * CS_EVR], ev_y[2 * CS_EVR], ev_x[CS_EVR];  // lane side stream: V of a panel final / Y = V_a' C_b done / a group's cross terms done
+  hipEvent_t ev_t[2 * CS_EVR];  // a panel's T and verdict are final (k_build_t done): what its off-lane commit waits for
   hipEvent_t ev_start = nullptr, ev_end = nullptr;
   int64_t ticket[2 * CS_EVR];
   Buf gbuf[CS_NGB];
@@ -61,6 +62,7 @@ static int32_t cs_state_init(dhqr_ctx *c) {
     HIPCHECK(hipEventCreateWithFlags(&s.ev_recv[i], hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&s.ev_v[i], hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&s.ev_y[i], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&s.ev_t[i], hipEventDisableTiming));
     s.ticket[i] = -1;
   }
   HIPCHECK(hipEventCreateWithFlags(&s.ev_start, hipEventDisableTiming));
@@ -84,6 +86,7 @@ static void cs_state_free(dhqr_ctx *c) {
       (void)hipEventDestroy(s.ev_recv[i]);
       (void)hipEventDestroy(s.ev_v[i]);
       (void)hipEventDestroy(s.ev_y[i]);
+      (void)hipEventDestroy(s.ev_t[i]);
     }
     (void)hipEventDestroy(s.ev_start);
     (void)hipEventDestroy(s.ev_end);
@@ -234,7 +237,18 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
   // sharing one GPU, 32768^2 at 2 ranks: 904 -> 971 ms with it, profiles/r04_ab_side_stream_logical_ranks.txt)
   const bool want_side = c->lane_side && P == 1;
   if (want_side && !c->hi2) HIPCHECK(hipStreamCreateWithPriority(&c->hi2, hipStreamNonBlocking, c->hi_priority));
+  // r6: the commit of an accepted panel (12 us of copies into the matrix) leaves the lane at P > 1: it runs on the
+  // communication stream BEHIND the panel's broadcast (which sends the group buffer, not the matrix); the broadcast -- the
+  // critical chain of the column split -- leaves at "T and verdict final".  (One rank: DHQR_TUNE commit_off=1 puts it on a
+  // stream of its own, which lost badly: see dhqr_ctx::commit_off.)
+  const bool commit_off = c->commit_off > 0 || (c->commit_off < 0 && P > 1);
+  if (commit_off) {
+    if (P == 1 && !c->cstream) HIPCHECK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+    for (hipEvent_t &e : c->ev_commit)
+      if (!e) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   hipStream_t sW = c->stream, sL = c->hi, sC = S.comm, sX = want_side ? c->hi2 : nullptr;
+  hipStream_t sK = commit_off ? (P == 1 ? c->cstream : sC) : nullptr;
   // Lane side stream (r4): what needs a panel's V but not its T runs on sX beside the panel's second Gram product, k_build_t
   // and the commit -- Y = V_a' C_b for the pair's second panel, the pair's cross term V_b' V_a, the quad's V_2' V_1.  Only
   // for panels this rank factors itself on the asynchronous fast path (a received panel has no "V final" event).
@@ -373,8 +387,11 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
         double *Pp = pr.A + x * NB + lc * lda;
         c->epoch = saved_epoch;
         c->tt_keep = (c->tc_base && P == 1) ? c->tc_base + x * (NB * NB) : nullptr;  // kept T factors (dhqr_api.hip)
+        bool deferred = false;
         if (panel_fast_eligible(c, rows, w) && !(robust_first && x == kstart)) {
-          CHECK(panel_fast_enqueue(c, Pp, rows, lda, pr.alpha + x * NB, pbx, c->cholqr_passes, (int)x, side ? S.ev_v[pe] : nullptr));
+          deferred = sK != nullptr;
+          CHECK(panel_fast_enqueue(c, Pp, rows, lda, pr.alpha + x * NB, pbx, c->cholqr_passes, (int)x, side ? S.ev_v[pe] : nullptr,
+                                   deferred ? S.ev_t[pe] : nullptr));
           v_event[idx] = side;
           fast_idx.push_back(x);
         } else {
@@ -391,13 +408,26 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
           hipLaunchKernelGGL(k_set_statword, dim3(1), dim3(64), 0, sL, (const int *)c->dstat, pbx.alpha + DHQR_NBV);
         }
         c->tt_keep = nullptr;
-        HIPCHECK(hipEventRecord(S.ev_ready[pe], sL));
+        auto commit_on = [&](hipStream_t s, int part) -> int32_t {
+          CHECK(panel_commit_enqueue(c, s, Pp, rows, lda, pr.alpha + x * NB, pbx, (int)x, part));
+          if (part != 1) HIPCHECK(hipEventRecord(c->ev_commit[x & 1], s));
+          return DHQR_OK;
+        };
+        if (deferred && P == 1) {  // commit on its own stream behind "T and verdict final"
+          HIPCHECK(hipStreamWaitEvent(sK, S.ev_t[pe], 0));
+          CHECK(commit_on(sK, 0));
+          HIPCHECK(hipEventRecord(S.ev_ready[pe], sK));
+        } else if (!deferred) {
+          HIPCHECK(hipEventRecord(S.ev_ready[pe], sL));
+        }
         // host-in / host-out drop-in: the column block of a committed panel is final and may leave for the host
         if (c->panel_hook && P == 1) CHECK(c->panel_hook(c->panel_hook_arg, x, S.ev_ready[pe]));
         if (cm && P > 1) {
-          HIPCHECK(hipStreamWaitEvent(sC, S.ev_ready[pe], 0));
+          HIPCHECK(hipStreamWaitEvent(sC, deferred ? S.ev_t[pe] : S.ev_ready[pe], 0));
+          if (deferred) CHECK(commit_on(sC, 1));  // alpha -> the buffer's tail: travels with the broadcast
           CHECK(comm_bcast(cm, gb.region(idx), gb.region_elems(), pr.r, sC, &S.ticket[pe]));
           HIPCHECK(hipEventRecord(S.ev_recv[pe], sC));
+          if (deferred) CHECK(commit_on(sC, 2));  // the rest behind the broadcast: the peers need the group buffer, not the matrix
         }
       } else {
         CHECK(guard(sC));
@@ -455,6 +485,7 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
     HIPCHECK(hipStreamWaitEvent(sL, S.ev_start, 0));
     HIPCHECK(hipStreamWaitEvent(sC, S.ev_start, 0));
     if (sX) HIPCHECK(hipStreamWaitEvent(sX, S.ev_start, 0));
+    if (sK && sK != sC) HIPCHECK(hipStreamWaitEvent(sK, S.ev_start, 0));
     for (int q = 0; q < steps[0].ng; ++q) CHECK(produce(steps[0].g0 + q));
     for (int si = 0; si < NS; ++si) {
       const int glast = steps[si].g0 + steps[si].ng - 1;
@@ -490,6 +521,10 @@ static int32_t cs_run(const CsProblem &pr, int64_t kstart, bool robust_first, in
       HIPCHECK(hipEventRecord(S.ev_end, sX));
       HIPCHECK(hipStreamWaitEvent(sW, S.ev_end, 0));
     }
+    if (sK && sK != sC) {
+      HIPCHECK(hipEventRecord(S.ev_end, sK));
+      HIPCHECK(hipStreamWaitEvent(sW, S.ev_end, 0));
+    }
     return DHQR_OK;
   };
   int32_t rc = body();
@@ -519,7 +554,7 @@ static int32_t cs_prepare(const CsProblem &pr) {
   CHECK(ensure(c, c->spart, (size_t)512 * NN));  // Gram partials; 128 slabs of the 256 x 256 cross term of a quad
   CHECK(ensure(c, c->spart2, (size_t)512 * NN));  // the same for the cross terms built on the lane's side stream
   CHECK(ensure(c, c->sfull, NN));
-  CHECK(ensure(c, c->rbuf, 6 * NN + 1024));
+  CHECK(ensure(c, c->rbuf, 2 * panel_rbuf_elems()));
   if (c->cholqr_passes == 3) CHECK(ensure(c, c->tsq, TsqrLocal::elems(m)));  // TSQR-HR for every panel
   CHECK(ensure(c, c->scratch, 4096));
   return DHQR_OK;

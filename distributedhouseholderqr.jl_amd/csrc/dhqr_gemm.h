@@ -623,7 +623,8 @@ template <int VEC, int KW, bool INIT0, bool TIME, int TR>
 __device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, int64_t ldv, const double *__restrict__ V2,
                                                  int64_t skip2, const double *__restrict__ W, int64_t ldw,
                                                  double *__restrict__ C, int64_t ldc, int64_t rows, int64_t ncols, int swz,
-                                                 const int *__restrict__ stat, int epoch) {
+                                                 const int *__restrict__ stat, int epoch,
+                                                 const double *__restrict__ fix_alpha = nullptr) {
   static_assert(TR == 128 || TR == 64, "tile rows");
   constexpr int NCI = TR / 32;                     // 16-column MFMA tiles per wave: 4 (64 columns) or 2 (32 columns)
   constexpr int WCOLS = NCI * 16;                  // columns per wave
@@ -975,6 +976,25 @@ __device__ __forceinline__ void gemm_nn_sub_body(const double *__restrict__ V, i
     __builtin_amdgcn_sched_barrier(0);
     tph[2] = clock64();
   }
+  if constexpr (INIT0) {
+    // The panel's V = tril((P - alpha E) M^{-1}) (dhqr_recon.h) in the product's own epilogue: the launch computed P M^{-1}
+    // (W = -M^{-1}); on the top 128 rows subtract alpha_i M^{-1}[i][j] on and below the diagonal and clear what lies above
+    // it -- one launch (k_recon_fix) less on the panel chain.
+    if (fix_alpha != nullptr && r0 < 128) {
+#pragma unroll
+      for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = (int)c0 + wc * WCOLS + ci * 16 + k4 + 4 * g;
+#pragma unroll
+          for (int ri = 0; ri < 4; ++ri) {
+            const int row = (int)r0 + wr * 64 + 4 * i16 + ri;
+            if (row < 128 && col < 128)
+              acc[ci][ri][g] = (row >= col) ? acc[ci][ri][g] + fix_alpha[row] * W[row + col * ldw] : 0.0;
+          }
+        }
+    }
+  }
   if (full) {
     store_full();
   } else {
@@ -1004,6 +1024,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sub(const double *__restrict
                                                         const int *__restrict__ stat, int epoch) {
   static_assert(KW != 512, "K = 512 takes two reflector operands: k_gemm_nn_quad");
   gemm_nn_sub_body<VEC, KW, INIT0, TIME, TR>(V, ldv, nullptr, 0, W, ldw, C, ldc, rows, ncols, swz, stat, epoch);
+}
+
+// out = -V W with the reflector fix of the panel chain in the epilogue (gemm_nn_sub_body, INIT0): V = tril((P - alpha E) M^{-1})
+template <int VEC, int TR>
+__global__ __launch_bounds__(256, 2) void k_gemm_nn_vfix(const double *__restrict__ V, int64_t ldv, const double *__restrict__ W,
+                                                         int64_t ldw, double *__restrict__ C, int64_t ldc, int64_t rows,
+                                                         int64_t ncols, const double *__restrict__ fix_alpha) {
+  gemm_nn_sub_body<VEC, 128, true, false, TR>(V, ldv, nullptr, 0, W, ldw, C, ldc, rows, ncols, 0, nullptr, 0, fix_alpha);
 }
 
 // The four-panel update C -= [V | V2] W (W: 512 x ncols, rows 0..255 for V, 256..511 for V2), see gemm_nn_sub_body.
