@@ -1,24 +1,14 @@
 // dhqr_api.hip -- host side of libdhqr.so: context, workspaces, panel/trailing-update drivers and
 // the extern "C" entry points declared in include/dhqr.h.  gfx950 only; no CPU fallback.
-#include <hip/hip_runtime.h>
+// (The nb = 0 path lives in dhqr_unblocked.hip; what the two units share is in dhqr_internal.h.)
 #include <chrono>
-
-#include <algorithm>
-#include <atomic>
-#include <climits>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
 #include <mutex>
-#include <vector>
 
-#include "../../include/dhqr.h"
-#include "dhqr_common.h"
+#include "dhqr_internal.h"
 #include "dhqr_complex.h"
 #include "dhqr_gemm.h"
+#include "dhqr_pack.h"
 #include "dhqr_panel.h"
-#include "dhqr_rank1.h"
 #include "dhqr_recon.h"
 #include "dhqr_solve.h"
 #include "dhqr_qtb.h"
@@ -26,149 +16,14 @@
 #include "dhqr_tsqr.h"
 
 static thread_local char g_err[512] = "";
-static int32_t set_err(int32_t code, const char *fmt, ...) {
+int32_t set_err(int32_t code, const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
 }
-#define HIPCHECK(expr)                                                                        \
-  do {                                                                                        \
-    hipError_t e_ = (expr);                                                                   \
-    if (e_ != hipSuccess)                                                                     \
-      return set_err(DHQR_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),        \
-                     __FILE__, __LINE__);                                                     \
-  } while (0)
-#define CHECK(expr)                  \
-  do {                               \
-    int32_t rc_ = (expr);            \
-    if (rc_ != DHQR_OK) return rc_;  \
-  } while (0)
-#define LAUNCHCHECK() HIPCHECK(hipGetLastError())
-
-enum { CAT_PANEL = 0, CAT_TBUILD, CAT_VTA, CAT_TW, CAT_AVW, CAT_RANK1, CAT_SOLVE, CAT_N };
-
-struct Buf {
-  double *p = nullptr;
-  size_t cap = 0;  // doubles
-};
-
-struct dhqr_ctx {
-  int device = 0;
-  hipStream_t own = nullptr, stream = nullptr;
-  bool profiling = false;
-  hipStream_t hi = nullptr;      // high-priority stream: panel factorisation under look-ahead
-  hipStream_t hi2 = nullptr;     // its side stream: products that need a panel's V but not its T (V_a' C_b of the pair's second
-                                 // panel, the pair / quad cross terms) run here beside the panel's verification and commit
-  int lane_side = 1;             // ... DHQR_LANE_SIDE=0: everything on the one lane stream.  Single rank only: a device has
-                                 // GPU_MAX_HW_QUEUES = 4 hardware queues and streams beyond them share one -- with the
-                                 // communication stream of P > 1 (and RCCL's own) a fifth stream serialises something
-                                 // (measured with rank threads sharing one GPU: 32768^2 at 2 ranks 904 -> 971 ms)
-  int hi_priority = 0;
-  int tn_spare = 32;                // CUs a wide k_gemm_tn2 launch on a small trailing matrix leaves to the lane (wide_slots) ...
-  int64_t tn_spare_cols = 16384;    // ... "small": at most this many trailing columns (DHQR_TUNE tn_spare, tn_spare_cols)
-  int tn_model_min_tiles = 32;   // (r5: 32, with the direct-load kernel; 128 before: 8192^2 29.9 -> 29.1 ms, 16384^2 123.6 -> 120.2, 32768^2 783.7 -> 775.7, profiles/r05_ab_thresholds.txt) wide k_gemm_tn2 launches of at least this many column tiles: split-K factor from the round / partial-traffic estimate (below, the lane is the critical path and
-                                 // prefers many short workgroups: a k_gemm_tn2 workgroup leaves no room for a lane kernel on its CU)
-  int rankk_wgs = 256;           // ... bulk workgroups of 1024 threads resident at once (CU count; DHQR_RANKK_WGS)
-  int rankk = 5;                 // unblocked path: reflectors applied per pass over the trailing columns (DHQR_RANKK=1..5; beyond 3 the further ones are held in LDS)
-  int nn_chunk_tiles = 48;       // ... of at least this many 128-wide tiles each (DHQR_NN_CHUNK_TILES: the CPU emulator's tests set 1)
-  int nn_split = 4;              // wide subtraction launches in up to this many chunks of columns (or rows) (nn_chunks; DHQR_NN_SPLIT=1: one launch)
-  int rankk_pipe = 1;            // k_rankk_fused: the lead as K pipelined workgroups where the lead bounds the launch (launch_rankk; DHQR_RANKK_PIPE=0 never, 2 always)
-  int rankk_max_min_cols = 4096; // ... while more than this many columns are left (DHQR_RANKK_MAX_MIN_COLS: below, a launch is bound by its lead's chain, which grows with K)
-  int rankk_unfit = 0;           // set by launch_rankk if it was asked for a K its ladder step cannot hold (a driver bug: reported, never silent)
-  int rankk_max = 8;             // nb = 0, default DHQR_RANKK=5: up to this many reflectors per pass where the CU can hold them (columns of <= 6144 rows; DHQR_RANKK_MAX=5: never more than 5)
-  int rankk_xtall = 5;           // nb = 0, columns of 16384 < rows <= 32768: reflectors per pass (k_rankk_xtall; DHQR_RANKK_XTALL=1: one per launch)
-  int rankk_tall = 5;            // nb = 0, columns of 8192 < rows <= 16384: reflectors per pass (k_rankk_tall; DHQR_RANKK_TALL=1: one per launch)
-  int ncu = 256;                 // compute units of the device
-  int spare_cus = 0;             // CUs the persistent wide k_gemm_tn2 launches leave free for the look-ahead lane's
-                                 // single-workgroup kernels and for RCCL's kernels (DHQR_SPARE_CUS; multiple of 8: one per XCD).
-                                 // Default 0 on one GPU (measured: 8 spare CUs cost the wide kernels more than the lane gains);
-                                 // 8 when the context is bound to an RCCL communicator of more than one rank: the panel
-                                 // broadcast sits on the critical chain there and RCCL's kernels need CUs of their own while a
-                                 // persistent launch holds every CU it was given (comm_bind_rccl)
-  bool spare_cus_set = false;    // DHQR_SPARE_CUS given: never overridden
-  int quad = 1;                  // P == 1: two consecutive pairs applied in ONE K = 512 pass (quad_apply; DHQR_QUAD=0: pairs only)
-  int64_t quad_min_cols = 10240;  // ... while at least this many columns lie to the right of the quad (DHQR_QUAD_MIN_COLS)
-  struct WS { Buf w1, w1r, w2; } ws[3];  // [0] wide trailing update, [1] panel / narrow updates, [2] the lane's side stream (hi2)
-  int cur_ws = 0;
-  bool lookahead = true;
-  Buf vbuf, vt, vts, spart, spart2, sfull, scratch, pbuf;  // spart2: split-K partials of the cross terms on the side stream
-  Buf zsolve_lo;         // low parts of the double-double right-hand side of the ComplexF64 solve
-  // the solve of dhqr_qtb.h: T' of every panel, Gram matrices, their slab partials, (partial dots | w | ints)
-  Buf sv_T, sv_S, sv_part, sv_small;
-  std::vector<int> sv_units;                 // host copy of the Gram pre-pass unit table, valid for (sv_m, sv_n)
-  int64_t sv_m = -1, sv_n = -1, sv_rps = 0;
-  const int *sv_units_dev = nullptr;         // where the table was uploaded (nullptr: not yet / shape changed)
-  // kept T factors: a blocked single-GPU dhqr_factor_f64 leaves T_k' of every panel (and a copy of alpha) in the context;
-  // dhqr_solve_f64 on the same (dA, m, n, lda) whose alpha still equals that copy (checked on the device) skips its Gram /
-  // T' pre-pass.  tt_keep: where the panel being factored stores its T' (nullptr: nowhere).
-  Buf tc_T, tc_alpha;
-  double *tt_keep = nullptr, *tc_base = nullptr;
-  const double *tc_A = nullptr;
-  int64_t tc_m = 0, tc_n = 0, tc_lda = 0;
-  bool tc_valid = false;
-  int keep_t = 1;        // DHQR_KEEP_T=0: never keep / use them
-  int solve_pipe = 1;    // DHQR_SOLVE_PIPE: 1 the solve of dhqr_qtb.h (persistent Q'b kernel when this context has its device to itself),
-                         // 2 the same without the persistent kernel (one launch per panel step), 3 the persistent kernel whatever
-                         // else lives on the device (tests), 0 the round-1 solve (blocked apply on the MFMA kernels + 64-row back
-                         // substitution: no inter-workgroup waits at all)
-  int qtb_vec = -1;      // DHQR_QTB_VEC=1/2: rows per lane of k_qtb_step (-1: by the matrix height)
-  int gram_strips = 1;   // the panel chain's Gram products as four 32-row strips (gram128; DHQR_TUNE gram_strips=0: one tile)
-  int fuse_fix = 1;      // k_recon_fix in the epilogue of V = P M^{-1} (mul128; DHQR_TUNE fuse_fix=0: its own launch)
-  int commit_off = -1;   // an accepted panel's commit (12 us of copies into the matrix) leaves the lane: -1 (default) with more
-                         // than one rank, where it runs on the communication stream BEHIND the panel's broadcast; 0 never;
-                         // 1 also at one rank, on a stream of its own -- measured there (profiles/r06_ab_chain.txt): a
-                         // fourth busy stream beside wide / lane / side shares a hardware queue and the factorisation
-                         // takes 1.9 x as long at 8192^2, 1.13 x at 32768^2 (DHQR_TUNE commit_off)
-  hipStream_t cstream = nullptr;  // ... that stream (created on first use)
-  hipEvent_t ev_commit[2] = {nullptr, nullptr};  // behind the off-lane commit of the last panel of each parity
-  int small_route = 1;   // matrices that fit the registers of one compute unit: ONE single-workgroup launch per qr! / per
-                         // `\` (dhqr_small.h; DHQR_SMALL=0 or dhqr_set_small_route(ctx, 0): the general drivers)
-  double *small_pin = nullptr;  // pinned host staging of the host-array entry points on that route: the kernels read and
-  size_t small_pin_cap = 0;     // write it across PCIe themselves (no hipMemcpy on the path); doubles
-  Buf small_dev;                // device copy of a host factor inside k_small_ldiv (256 x 256)
-  bool coop = false;     // the device runs cooperative (all-resident) launches: false on the CPU emulator
-  Buf host_mat;          // device copy of the caller's HOST matrix (+ alpha) of dhqr_qr_f64, kept between calls
-  int pair = 1;                  // 1: wide updates apply two panels per pass (DHQR_PAIR=0 disables)
-  int64_t pair_min_n = 4096;     // below this the longer look-ahead lane of the pair driver costs more than it saves (r2: 12288, profiles/r02_ab_pair_tail_and_threshold.txt; r5, with the direct-load GEMMs: 4096^2 12.11 -> 11.84 ms, 8192^2 31.97 -> 31.39, 12288^2 68.18 -> 67.71, profiles/r05_ab_thresholds.txt)
-  int panel_impl = 3;  // 3: R-first (CholeskyQR + reconstruction, dhqr_recon.h) with fallback to 2;
-                       // 2: row-split sub-panel kernels (dhqr_panel.h); 1: one workgroup per column
-  int zpipe = 1;         // ComplexF64 panels of <= 128 columns and <= 8192 rows in one column-pipelined launch (k_zpanel_pipe; DHQR_ZPIPE=0: one launch per column)
-  hipEvent_t zev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // look-ahead of the blocked ComplexF64 driver
-  int *zflags = nullptr; // its 128 ready flags (device), never reset: a flag holds the number of the launch that set it
-  int zepoch = 0;
-  int *hflag = nullptr;  // pinned host copy of the device status block
-  int *dstat = nullptr;  // device status block (ints): [0] first rejected panel of the running factorisation
-                         // (INT_MAX: none), [1] Cholesky breakdown flag of the panel in flight
-  int epoch = -1;        // >= 0 while an asynchronous factorisation is enqueued: matrix-writing launches carry
-                         // (dstat, epoch) and are no-ops once a panel <= epoch was rejected
-  Buf rbuf;              // R1, -R1^{-1}, R, Rref, -M^{-1}, alpha_tmp
-  Buf tsq;               // R factors, reflectors and Q of the TSQR tree (dhqr_tsqr.h)
-  int tsqr_rung = -1;    // rejected panels try TSQR-HR before the column-by-column kernels: 1 yes, 0 no, -1 (default)
-                         // only where the last rung costs collectives per column (row split over more than one rank):
-                         // on one GPU the column kernels redo a panel in ~1 ms, the tree takes ~7 ms at 32768 rows
-  int n_tsqr = 0;        // panels whose R came from the TSQR tree (dhqr_get_panel_counters: counted as fast)
-  int64_t n_fast = 0, n_fallback = 0;
-  int cholqr_passes = 1;  // where the fast path gets R from: 1 Gram/Cholesky, 2 CholeskyQR2, 3 TSQR tree (DHQR_TSQR=1)
-  double recon_tol = 2e-12;  // accepted deviation of ||v_j||^2 from 2 before falling back
-  int ib = DHQR_IB;
-  struct CsState *cs = nullptr;  // streams / events / group buffers of the blocked driver (dhqr_dist.h)
-  struct RsState *rs = nullptr;  // events / group ring of the row-split driver (dhqr_rowsplit.h)
-  // host-in / host-out drop-in (dhqr_hostio.h): the blocked driver reports every committed panel (index, event) to this
-  // hook so that the finished column block can travel to the host while later panels are factored
-  int32_t (*panel_hook)(void *, int64_t, hipEvent_t) = nullptr;
-  void *panel_hook_arg = nullptr;
-  struct HostIo *hio = nullptr;
-  int64_t n_resume = 0;  // passes of the blocked driver that resumed after a rejected panel
-  // profiling
-  struct Ev { hipEvent_t a, b; int cat; int start_from = -1; };  // start_from >= 0: the section starts at the END event of that entry (prof_switch)
-  std::vector<Ev> evs;
-  size_t ev_used = 0;
-  dhqr_stats st;
-};
-
-static int32_t ensure(dhqr_ctx *c, Buf &b, size_t need) {
+int32_t ensure(dhqr_ctx *c, Buf &b, size_t need) {
   if (need <= b.cap) return DHQR_OK;
   if (b.p) {
     HIPCHECK(hipDeviceSynchronize());  // another stream of this ctx may still use the old buffer
@@ -187,7 +42,7 @@ static int32_t ensure(dhqr_ctx *c, Buf &b, size_t need) {
 
 // DHQR_TUNE="key=value,key=value,...": the size thresholds and grid sizes that only tests and tuning runs change, in ONE
 // switch (INTEGRATION.md section 5 lists the keys).  Returns true and *out when `key` is present.
-static bool tune_get(const char *key, long long *out) {
+bool tune_get(const char *key, long long *out) {
   const char *e = getenv("DHQR_TUNE");
   if (!e) return false;
   const size_t kl = strlen(key);
@@ -208,10 +63,9 @@ static bool tune_get(const char *key, long long *out) {
 // are only launched while a context has its device to itself -- two such launches could each hold slots the other needs
 static std::atomic<int> g_live_ctx[64];
 
-static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 // ---- profiling: one hipEvent pair per timed launch group, resolved in dhqr_get_stats ---------
-static int32_t prof_begin(dhqr_ctx *c, int cat) {
+int32_t prof_begin(dhqr_ctx *c, int cat) {
   if (!c->profiling) return DHQR_OK;
   if (c->ev_used == c->evs.size()) {
     dhqr_ctx::Ev e;
@@ -225,7 +79,7 @@ static int32_t prof_begin(dhqr_ctx *c, int cat) {
   HIPCHECK(hipEventRecord(c->evs[c->ev_used].a, c->stream));
   return DHQR_OK;
 }
-static int32_t prof_end(dhqr_ctx *c) {
+int32_t prof_end(dhqr_ctx *c) {
   if (!c->profiling) return DHQR_OK;
   HIPCHECK(hipEventRecord(c->evs[c->ev_used].b, c->stream));
   c->ev_used++;
@@ -234,7 +88,7 @@ static int32_t prof_end(dhqr_ctx *c) {
 // End the running section and begin the next one (category `cat`) at the SAME point of the same stream with ONE event
 // record instead of two: every record is a bubble on the stream, and the wide stream carries three back-to-back sections
 // per update (V'C | T products | subtraction).
-static int32_t prof_switch(dhqr_ctx *c, int cat) {
+int32_t prof_switch(dhqr_ctx *c, int cat) {
   if (!c->profiling) return DHQR_OK;
   CHECK(prof_end(c));
   if (c->ev_used == c->evs.size()) {
@@ -262,212 +116,6 @@ static int32_t prof_resolve(dhqr_ctx *c) {
     *cnt[c->evs[i].cat] += 1;
   }
   c->ev_used = 0;
-  return DHQR_OK;
-}
-
-// ---- unblocked factorisation of the columns of a rows x ncols block (src:122-148,198-213) ----
-// P's row 0 is the diagonal row of column 0.  One launch per column (k_rank1_*), the workgroup
-// owning column j+1 builds the next reflector in the same launch.
-template <int VEC>
-static void launch_rank1(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int64_t j, int64_t nupd,
-                         const double *vcur, double *vnext, double *alpha) {
-  const int64_t r0 = (VEC == 2) ? (j & ~(int64_t)1) : j;
-  const int64_t cov = rows - r0;
-  dim3 grid((unsigned)nupd);
-#define DHQR_R1(T_, E_)                                                                          \
-  hipLaunchKernelGGL((k_rank1_fused<T_, E_, VEC>), grid, dim3(T_), 0, c->stream, P, ldp, rows, j, \
-                     vcur, vnext, alpha)
-  if (cov <= 256 * 2) DHQR_R1(256, 2);
-  else if (cov <= 256 * 4) DHQR_R1(256, 4);
-  else if (cov <= 256 * 8) DHQR_R1(256, 8);
-  else if (cov <= 512 * 8) DHQR_R1(512, 8);
-  else if (cov <= 1024 * 8) DHQR_R1(1024, 8);
-  else
-    hipLaunchKernelGGL((k_rank1_generic<1024, VEC>), grid, dim3(1024), 0, c->stream, P, ldp, rows,
-                       j, vcur, vnext, alpha);
-#undef DHQR_R1
-}
-
-// K steps per pass over the columns >= c0 (k_rankk_fused): the `kold` reflectors in `vold` are applied, the lead
-// workgroup builds the next K into `vnew`
-template <int VEC, int K>
-static void launch_rankk(dhqr_ctx *c, double *P, int64_t ldp, int64_t rows, int64_t ncols, int64_t c0, int64_t jlo,
-                         int kold, const double *vold, double *vnew, int64_t vlen, double *alpha) {
-  const int64_t rtop = (VEC == 2) ? (jlo & ~(int64_t)1) : jlo;
-  const int64_t cov = rows - rtop;
-  // lead workgroup + persistent bulk workgroups: as many as run at once (one 1024-thread workgroup per CU), less the
-  // lead's place
-  const int64_t nbulk = (kold == 0) ? 0 : std::max<int64_t>(0, ncols - c0 - K);
-  // The lead as K pipelined workgroups (rankk_lead_pipe) where the LEAD bounds the launch: few columns left for the bulk
-  // (its traffic takes less than the one-workgroup lead's ~105 us x cov / 8192 below ~3000 columns, whatever cov) and
-  // columns long enough for K - 1 hand-overs (~8 us each) to cost less than the one workgroup's K (K + 1) / 2 extra applies.
-  // 8192 x 2048: 43 -> 25 ms; on squares K - 1 fewer bulk workgroups cost 1.6 % while the bulk bounds the launch, hence
-  // not everywhere (profiles/r03_unblocked_pipelined_lead.txt).  DHQR_RANKK_PIPE=0: never, 2: always.
-  const bool pipe = c->rankk_pipe == 2 || (c->rankk_pipe == 1 && nbulk <= 3072 && cov >= 2048);
-  const int nlead = pipe ? K : 1;
-  const int epoch = ++c->zepoch;  // the launch's number in the flags (a value, not an expression in the launch's argument list)
-  // (workgroups per CU of the persistent bulk: as many as the threads allow unless the LDS-resident reflectors -- the lead's
-  // slots, or more than two of the pass's own -- leave room for one only; a K the ladder step cannot hold is never asked for:
-  // rankk_fit, factor_unblocked_cols)
-#define DHQR_RK(T_, E_)                                                                                  \
-  do {                                                                                                   \
-    if constexpr (K <= rankk_fit(T_, E_))                                                                \
-      hipLaunchKernelGGL((k_rankk_fused<T_, E_, VEC, K>),                                                \
-                         dim3((unsigned)(nlead + std::min<int64_t>(nbulk, std::max<int64_t>(1, (int64_t)c->rankk_wgs * ((rankk_lead_slots(T_, E_, K) > 0 || (K - rankk_kr(E_, K)) * T_ * E_ * 8 > 80 * 1024) ? 1 : 1024 / T_) - nlead)))), \
-                         dim3(T_), 0, c->stream, P, ldp, rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, \
-                         pipe ? c->zflags : (int *)nullptr, epoch);                                      \
-    else                                                                                                 \
-      c->rankk_unfit = K;                                                                                \
-  } while (0)
-#define DHQR_RKT(E_)                                                                                     \
-  hipLaunchKernelGGL((k_rankk_tall<512, E_, VEC, K>),                                                     \
-                     dim3((unsigned)(K + std::min<int64_t>(nbulk, std::max<int64_t>(1, (int64_t)c->rankk_wgs - K)))), dim3(512), 0, c->stream, P, ldp, \
-                     rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, c->zflags, epoch)
-#define DHQR_RKX(E_)                                                                                     \
-  hipLaunchKernelGGL((k_rankk_xtall<512, E_, VEC, K>),                                                    \
-                     dim3((unsigned)(K + std::min<int64_t>(nbulk, std::max<int64_t>(1, (int64_t)c->rankk_wgs - K)))), dim3(512), 0, c->stream, P, ldp, \
-                     rows, ncols, c0, rtop, kold, vold, vnew, vlen, alpha, c->zflags, epoch)
-  // columns of 16384 < rows <= 32768 (DHQR_RANKK_XTALL >= 2): one column per workgroup in registers, reflectors streamed
-  if (cov > 512 * 48) { DHQR_RKX(64); return; }
-  if (cov > 512 * 32) { DHQR_RKX(48); return; }
-  // columns of 8192 < rows <= 16384 (factor_unblocked_cols sends them here when DHQR_RANKK_TALL >= 2)
-  if (cov > 512 * 24) { DHQR_RKT(32); return; }
-  if (cov > 1024 * 8) { DHQR_RKT(24); return; }
-  // six per pass for columns of 6145 ... 8192 rows: 16 elements per thread, four reflectors in registers (rankk_kr)
-  if constexpr (K == 6 && VEC == 2) {
-    if (cov > 448 * 16) { DHQR_RK(512, 16); return; }
-    if (cov > 768 * 8) { DHQR_RK(448, 16); return; }
-  }
-  if (cov <= 256 * 2) DHQR_RK(256, 2);
-  else if (cov <= 256 * 4) DHQR_RK(256, 4);
-  else if (cov <= 256 * 8) DHQR_RK(256, 8);
-  else if (cov <= 384 * 8) DHQR_RK(384, 8);
-  else if (cov <= 512 * 8) DHQR_RK(512, 8);
-  else if (cov <= 640 * 8) DHQR_RK(640, 8);
-  else if (cov <= 768 * 8) DHQR_RK(768, 8);
-  else if (cov <= 896 * 8) DHQR_RK(896, 8);
-  else DHQR_RK(1024, 8);
-#undef DHQR_RK
-#undef DHQR_RKT
-#undef DHQR_RKX
-}
-static void launch_rankk(dhqr_ctx *c, bool vec, int K, double *P, int64_t ldp, int64_t rows, int64_t ncols, int64_t c0,
-                         int64_t jlo, int kold, const double *vold, double *vnew, int64_t vlen, double *alpha) {
-#define DHQR_RKK(K_)                                                                              \
-  (vec ? launch_rankk<2, K_>(c, P, ldp, rows, ncols, c0, jlo, kold, vold, vnew, vlen, alpha)      \
-       : launch_rankk<1, K_>(c, P, ldp, rows, ncols, c0, jlo, kold, vold, vnew, vlen, alpha))
-  if (K == 2) DHQR_RKK(2);
-  else if (K == 3) DHQR_RKK(3);
-  else if (K == 4) DHQR_RKK(4);
-  else if (K == 5) DHQR_RKK(5);
-  else if (K == 6) DHQR_RKK(6);
-  else if (K == 7) DHQR_RKK(7);
-  else DHQR_RKK(8);
-#undef DHQR_RKK
-}
-
-// most reflectors per pass the k_rankk_fused instantiation launch_rankk picks for columns of `cov` rows can hold
-static inline int rankk_fit_rows(int64_t cov, bool vec) {
-  if (cov <= 256 * 2) return rankk_fit(256, 2);
-  if (cov <= 256 * 4) return rankk_fit(256, 4);
-  if (cov <= 256 * 8) return rankk_fit(256, 8);
-  if (cov <= 384 * 8) return rankk_fit(384, 8);
-  if (cov <= 512 * 8) return rankk_fit(512, 8);
-  if (cov <= 640 * 8) return rankk_fit(640, 8);
-  if (cov <= 768 * 8) return rankk_fit(768, 8);
-  return vec ? 6 : 5;  // <= 8192 rows: the 16-elements-per-thread instantiations (launch_rankk; 16-byte path only: the scalar path spills 120 registers there) for six, 896 / 1024 x 8 for up to five
-}
-static int32_t factor_unblocked_cols(dhqr_ctx *c, double *P, int64_t rows, int64_t ncols,
-                                     int64_t ldp, double *alpha, int cat) {
-  const int K = c->rankk;  // reflectors per pass over the trailing columns (1: one launch per reflector)
-  // ... and, at the default K = 5, as many as the CU can hold once the columns are short enough (rankk_fit: 6 at <= 6144 rows,
-  // 7 at <= 4096, 8 at <= 3072; DHQR_RANKK_MAX)
-  const int Kmax = (K >= 5) ? std::max(K, std::min(c->rankk_max, DHQR_RK_KMAX)) : K;
-  const int Kt = std::min(K, c->rankk_tall);  // ... while a column has 8192 < rows <= 16384 (k_rankk_tall; < 2: one per launch)
-  const int Kx = Kt >= 2 ? std::min(Kt, c->rankk_xtall) : 1;  // ... 16384 < rows <= 32768 (k_rankk_xtall; < 2: one per launch)
-  // a reflector slot: the column's rows, zero-padded so that k_rankk_tall (512 threads x 32 elements from a row > rows -
-  // 16384) and k_rankk_xtall (512 x 64 from a row > rows - 32768) read reflectors without clamping or masking -- the
-  // kernels never write beyond row `rows`
-  const bool padded = (Kt >= 2 && rows > 1024 * 8) || c->rankk_pipe;
-  const bool xpadded = Kx >= 2 && rows > 1024 * 16;
-  const size_t vlen = (size_t)((rows + (xpadded ? 1024 * 16 : (padded ? 1024 * 8 : 0)) + 17) & ~(int64_t)15);
-  CHECK(ensure(c, c->vbuf, 2 * (size_t)std::max(Kmax, 1) * vlen));
-  if (padded || xpadded) HIPCHECK(hipMemsetAsync(c->vbuf.p, 0, 2 * (size_t)std::max(Kmax, 1) * vlen * sizeof(double), c->stream));
-  double *vset[2] = {c->vbuf.p, c->vbuf.p + (size_t)std::max(Kmax, 1) * vlen};  // two sets of Kmax reflectors
-  const bool vec = (ldp % 2 == 0) && (rows % 2 == 0) && aligned16(P);
-  auto account = [&](int64_t jlo, int64_t ncol_upd) {
-    if (!c->profiling) return;
-    // algorithmic HBM bytes of the launch as implemented: every column it touches is read once and written once
-    const double by = 16.0 * (double)(rows - jlo) * (double)ncol_upd;
-    if (cat == CAT_RANK1) c->st.bytes_rank1 += by;
-    else c->st.bytes_panel += by;
-  };
-  // Phase 1 -- columns taller than one workgroup's registers (> 8192 rows below the diagonal), or DHQR_RANKK=1: one
-  // reflector per launch, v_j / v_j+1 ping-pong between slot 0 of the two sets.
-  int64_t j = 0;
-  int cur = 0;
-  auto height = [&](int64_t jj) { return rows - (vec ? (jj & ~(int64_t)1) : jj); };
-  auto tall = [&](int64_t jj) { return K < 2 || height(jj) > (Kx >= 2 ? 1024 * 32 : (Kt >= 2 ? 1024 * 16 : 1024 * 8)); };
-  bool have_v = false;  // v_j built (in vset[cur][0])
-  if (tall(0)) {
-    CHECK(prof_begin(c, cat));
-    hipLaunchKernelGGL((k_reflector<1024>), dim3(1), dim3(1024), 0, c->stream, P, rows, (int64_t)0, vset[0], alpha);
-    CHECK(prof_end(c));
-    have_v = true;
-    for (; j + 1 < ncols && tall(j); ++j) {
-      const int64_t nupd = ncols - (j + 1);
-      CHECK(prof_begin(c, cat));
-      if (vec) launch_rank1<2>(c, P, ldp, rows, j, nupd, vset[cur], vset[cur ^ 1], alpha);
-      else launch_rank1<1>(c, P, ldp, rows, j, nupd, vset[cur], vset[cur ^ 1], alpha);
-      CHECK(prof_end(c));
-      account(j, nupd);
-      cur ^= 1;
-    }
-  }
-  // Phase 2 -- K reflectors per pass: each trailing column is loaded once, updated by v_jlo .. v_jlo+K-1 in the
-  // reference's order and arithmetic, and stored once (16/K B of HBM traffic per element and reflector); the lead
-  // workgroup of the pass builds the next K reflectors, so one launch per K columns.
-  if (K >= 2 && (have_v ? j + 1 < ncols : ncols > 0)) {
-    int64_t jlo;  // oldest reflector not yet applied to the trailing columns
-    int kold;
-    if (have_v) {  // continue from phase 1: v_j alone
-      jlo = j;
-      kold = 1;
-    } else {       // first K reflectors from scratch (one workgroup)
-      jlo = 0;
-      kold = 0;
-    }
-    for (;;) {
-      const int64_t c0 = jlo + kold;  // first column not yet final
-      if (c0 >= ncols) break;
-      // reflectors this pass builds (and the next one applies)
-      // (more than K is STARTED only while the bulk clearly bounds the launch: a factorisation that begins with fewer than
-      // ~4000 columns never goes above K -- 4096^2 31.4 -> 31.8 ms with 7 per pass.  Once a pass has built kold > K reflectors
-      // the count does not come down again: the kernel that builds Kp holds at most Kp OLD reflectors on the CU, so the tail of
-      // a larger factorisation -- the last 4096 columns of 8192^2 -- keeps 6-7 per pass; a step-down pass was not built.)
-      int Kp;
-      if (height(jlo) > 1024 * 16) Kp = Kx;
-      else if (height(jlo) > 1024 * 8) Kp = Kt;
-      else {
-        const int fit = rankk_fit_rows(height(jlo), vec);
-        Kp = (ncols - c0 > c->rankk_max_min_cols + K) ? std::max(K, std::min(Kmax, fit)) : K;
-        Kp = std::max(Kp, std::min(kold, fit));
-      }
-      CHECK(prof_begin(c, cat));
-      launch_rankk(c, vec, Kp, P, ldp, rows, ncols, c0, jlo, kold, vset[cur], vset[cur ^ 1], (int64_t)vlen, alpha);
-      CHECK(prof_end(c));
-      account(jlo, kold == 0 ? std::min<int64_t>(Kp, ncols) : ncols - c0);
-      cur ^= 1;
-      jlo = c0;
-      kold = Kp;
-    }
-  }
-  if (c->rankk_unfit) {
-    const int k = c->rankk_unfit;
-    c->rankk_unfit = 0;
-    return set_err(DHQR_EINVAL, "internal: %d reflectors per pass asked of a kernel that cannot hold them", k);
-  }
-  LAUNCHCHECK();
   return DHQR_OK;
 }
 

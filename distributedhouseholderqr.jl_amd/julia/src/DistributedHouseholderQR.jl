@@ -55,16 +55,17 @@ function check(rc::Int32)
   throw(DHQRError(rc, msg))
 end
 
-# one context per (process, GPU); created lazily, destroyed at exit
-const _ctx = Ref{Ptr{Cvoid}}(C_NULL)
+# one context per (process, GPU): keyed by the device, created lazily, destroyed at exit.  (A master that has factored
+# on GPU 0 and is later used as worker rank i of a DArray factorisation gets a context on GPU i, not the cached one.)
+const _ctx = Dict{Int, Ptr{Cvoid}}()
 function context(device::Integer=0)
-  if _ctx[] == C_NULL
+  get!(_ctx, Int(device)) do
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:dhqr_create, libdhqr), Int32, (Ref{Ptr{Cvoid}}, Int32), h, Int32(device)))
-    _ctx[] = h[]
-    atexit(() -> ccall((:dhqr_destroy, libdhqr), Int32, (Ptr{Cvoid},), _ctx[]))
+    hd = h[]
+    atexit(() -> ccall((:dhqr_destroy, libdhqr), Int32, (Ptr{Cvoid},), hd))
+    hd
   end
-  return _ctx[]
 end
 
 struct DistributedHouseholderQRStruct{T1, T2}   # src:296-299
@@ -320,11 +321,113 @@ end
 "devices the cached communicator of this worker was built with for the workers `ws` (nothing: no such communicator)"
 comm_devices(ws) = (_comm[] != C_NULL && _comm_key[] !== nothing && _comm_key[][1] == ws) ? _comm_key[][2] : nothing
 
-"GPU of the i-th worker when the caller names none: worker i -> device i-1 (RCCL needs one GPU per rank)"
+"GPU of the i-th worker when the caller names none: worker i -> device i-1; with fewer GPUs than workers (the reference's
+own test starts two workers whatever the machine, test/runtests.jl:4,9) the workers share the GPUs round robin and the
+collectives travel through Julia (`comm_init_callbacks`) -- RCCL cannot put two ranks on one device"
 function default_devices(ws)
   nd = remotecall_fetch(device_count, ws[1])
-  nd >= length(ws) || throw(ArgumentError("$(length(ws)) workers but $nd GPUs: the RCCL transport needs one GPU per worker"))
-  return collect(0:length(ws)-1)
+  nd >= 1 || throw(ArgumentError("no GPU visible on worker $(ws[1])"))
+  return [(i - 1) % nd for i in 1:length(ws)]
+end
+
+# ---- the CALLBACK transport (include/dhqr.h: dhqr_comm_create_callbacks) carried by Distributed.jl.  Every worker owns a
+# mailbox (a RemoteChannel on itself); a message is (source rank, bytes).  The library calls back into Julia from inside
+# dhqr_cs_* with a DEVICE pointer and the stream already synchronised; the callback copies through host memory
+# (hipMemcpy of the HIP runtime the library is linked against) and returns when the data is visible to the device.
+# The SPMD program issues its collectives in the same order on every rank, but a fast rank may already have sent its
+# message of the NEXT collective: what arrives from a source other than the awaited one is parked per source.
+const libhip = get(ENV, "DHQR_HIP_LIB", "libamdhip64.so")
+mutable struct CallbackState
+  boxes::Vector{RemoteChannel{Channel{Tuple{Int, Vector{UInt8}}}}}
+  np::Int
+  rank::Int
+  parked::Vector{Vector{Vector{UInt8}}}
+end
+const _cb = Ref{Union{Nothing, CallbackState}}(nothing)
+
+"this worker's mailbox (created on the worker, shipped to the others by the master)"
+mailbox_create() = RemoteChannel(() -> Channel{Tuple{Int, Vector{UInt8}}}(1024), myid())
+
+function hip_copy(dst::Ptr{Cvoid}, src::Ptr{Cvoid}, bytes::Integer, kind::Integer)   # 1: host -> device, 2: device -> host
+  rc = ccall((:hipMemcpy, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), dst, src, Csize_t(bytes), Cint(kind))
+  rc == 0 || error("hipMemcpy failed with code $rc")
+  return nothing
+end
+
+"next message from rank `src` (0-based) in this worker's mailbox"
+function mailbox_recv(st::CallbackState, src::Integer)
+  q = st.parked[src + 1]
+  while isempty(q)
+    from, bytes = take!(st.boxes[st.rank + 1])
+    push!(st.parked[from + 1], bytes)
+  end
+  return popfirst!(q)
+end
+
+function cb_bcast(user::Ptr{Cvoid}, dbuf::Ptr{Cvoid}, bytes::Int64, root::Int32, stream::Ptr{Cvoid})::Int32
+  try
+    st = _cb[]::CallbackState
+    if st.rank == root
+      buf = Vector{UInt8}(undef, bytes)
+      GC.@preserve buf hip_copy(Ptr{Cvoid}(pointer(buf)), dbuf, bytes, 2)
+      for r in 0:st.np-1
+        r == root || put!(st.boxes[r + 1], (st.rank, buf))
+      end
+    else
+      buf = mailbox_recv(st, root)
+      length(buf) == bytes || error("broadcast of $bytes bytes received $(length(buf))")
+      GC.@preserve buf hip_copy(dbuf, Ptr{Cvoid}(pointer(buf)), bytes, 1)
+    end
+    return Int32(0)
+  catch err
+    @error "dhqr broadcast callback failed" exception = err
+    return Int32(1)
+  end
+end
+
+function cb_allreduce(user::Ptr{Cvoid}, dbuf::Ptr{Cvoid}, count::Int64, stream::Ptr{Cvoid})::Int32   # in-place sum of Float64
+  try
+    st = _cb[]::CallbackState
+    bytes = 8 * count
+    buf = Vector{UInt8}(undef, bytes)
+    GC.@preserve buf hip_copy(Ptr{Cvoid}(pointer(buf)), dbuf, bytes, 2)
+    if st.rank == 0                       # rank 0 sums in rank order (deterministic), everybody receives the total
+      acc = copy(reinterpret(Float64, buf))
+      for r in 1:st.np-1
+        acc .+= reinterpret(Float64, mailbox_recv(st, r))
+      end
+      buf = Vector{UInt8}(reinterpret(UInt8, acc))
+      for r in 1:st.np-1
+        put!(st.boxes[r + 1], (0, buf))
+      end
+    else
+      put!(st.boxes[1], (st.rank, buf))
+      buf = mailbox_recv(st, 0)
+    end
+    GC.@preserve buf hip_copy(dbuf, Ptr{Cvoid}(pointer(buf)), bytes, 1)
+    return Int32(0)
+  catch err
+    @error "dhqr all-reduce callback failed" exception = err
+    return Int32(1)
+  end
+end
+
+"collective over the workers: bind this worker (rank `rank` of `nranks`, 0-based) to GPU `device` with Julia carrying the
+collectives (workers that share a GPU); `boxes[i]` is the mailbox of rank i-1"
+function comm_init_callbacks(boxes, nranks::Integer, rank::Integer, device::Integer, key=nothing)
+  first_time = _comm_key[] === nothing && _comm[] == C_NULL
+  comm_free()
+  _cb[] = CallbackState(collect(boxes), Int(nranks), Int(rank), [Vector{Vector{UInt8}}() for _ in 1:nranks])
+  bc = @cfunction(cb_bcast, Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}))
+  ar = @cfunction(cb_allreduce, Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}))
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  check(ccall((:dhqr_comm_create_callbacks, libdhqr), Int32,
+              (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+              h, context(device), Int32(nranks), Int32(rank), bc, ar, C_NULL))
+  _comm[] = h[]
+  _comm_key[] = key
+  first_time && atexit(comm_free)
+  return nothing
 end
 
 "collective bootstrap over the workers `ws` (once per (workers, devices), not per call): returns the key"
@@ -338,9 +441,16 @@ function ensure_comm(ws, devices)
   end
   key = (ws, devs)
   if !all(remotecall_fetch(comm_cached, p, key) for p in ws)
-    id = remotecall_fetch(comm_unique_id, ws[1])                       # replaces the SharedArray bootstrap (src:301-304)
-    @sync for (i, p) in enumerate(ws)                                  # ncclCommInitRank is collective
-      @async remotecall_wait(comm_init, p, id, np, i - 1, devs[i], key)
+    if allunique(devs)                                                   # one GPU per worker: RCCL over xGMI
+      id = remotecall_fetch(comm_unique_id, ws[1])                       # replaces the SharedArray bootstrap (src:301-304)
+      @sync for (i, p) in enumerate(ws)                                  # ncclCommInitRank is collective
+        @async remotecall_wait(comm_init, p, id, np, i - 1, devs[i], key)
+      end
+    else                                                                 # workers share a GPU: collectives through Julia
+      boxes = [remotecall_fetch(mailbox_create, p) for p in ws]
+      @sync for (i, p) in enumerate(ws)
+        @async remotecall_wait(comm_init_callbacks, p, boxes, np, i - 1, devs[i], key)
+      end
     end
   end
   return key

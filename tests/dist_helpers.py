@@ -56,13 +56,15 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 def build_emulated_library(outdir):
-    """host-compile csrc/dhqr_api.hip against tests/simt/fake (fiber mode) -> path of the .so"""
+    """host-compile the library's translation units (csrc/dhqr_api.hip, csrc/dhqr_unblocked.hip) against tests/simt/fake
+    (fiber mode) -> path of the .so"""
     import subprocess
     so = os.path.join(str(outdir), "libdhqr_emulated.so")
+    csrc = os.path.join(ROOT, "distributedhouseholderqr.jl_amd", "csrc")
     subprocess.check_call([CLANG, "-x", "c++", "-std=c++20", "-O2", "-DSIMT_FIBERS", "-fPIC", "-shared",
                            "-Wno-unknown-attributes", "-Wno-psabi", "-Wno-unused-value",
                            "-I", os.path.join(ROOT, "tests", "simt", "fake"),
-                           os.path.join(ROOT, "distributedhouseholderqr.jl_amd", "csrc", "dhqr_api.hip"), "-o", so])
+                           os.path.join(csrc, "dhqr_api.hip"), os.path.join(csrc, "dhqr_unblocked.hip"), "-o", so])
     return so
 
 
