@@ -77,6 +77,7 @@ SIGNATURES = {
     "dhqr_set_r_source": (_i32, [_p, _i32]),
     "dhqr_set_tsqr_rung": (_i32, [_p, _i32]),
     "dhqr_set_small_route": (_i32, [_p, _i32]),
+    "dhqr_get_solve_retries": (_i32, [_p, _pi64]),
     "dhqr_tsqr_r_f64": (_i32, [_p, _p, _i64, _i64, _p]),
     "dhqr_get_tsqr_count": (_i32, [_p, ctypes.POINTER(_i64)]),
     "dhqr_fill_uniform_f64": (_i32, [_p, _p, _i64, _i64, _i64, _u64, _i64, _i64, _i64, _i32, _i32]),
@@ -173,6 +174,7 @@ BENCH_SIGNATURES = {
     "dhqr_bench_gemm_f64": (_i32, [_p, _i32, _i64, _i64, _i32, _pd]),
     "dhqr_bench_mma_probe_f64": (_i32, [_p, _i32, _i32, _pd]),
     "dhqr_bench_lane_probe_f64": (_i32, [_p, _i64, _i32, _i32, _i32, _pd]),
+    "dhqr_debug_hold_cus": (_i32, [_p, _i32, _i32, _i32]),
 }
 
 _lib = None

@@ -92,6 +92,12 @@ class Context:
         """False: matrices that fit one compute unit's registers go through the general drivers too (csrc/dhqr_small.h)"""
         check(_lib.lib().dhqr_set_small_route(self._h, 1 if on else 0))
 
+    def solve_retries(self) -> int:
+        """solves repeated with the per-step kernels after a wait of the persistent Q'b kernel expired (dhqr.h)"""
+        a = ctypes.c_int64()
+        check(_lib.lib().dhqr_get_solve_retries(self._h, ctypes.byref(a)))
+        return a.value
+
     def tsqr_count(self) -> int:
         a = ctypes.c_int64()
         check(_lib.lib().dhqr_get_tsqr_count(self._h, ctypes.byref(a)))
@@ -321,9 +327,8 @@ def solve_householder_(b, H, α):
         ctx = get_context(dev)
         ctx.use_torch_stream()
         check(L.dhqr_solve_f64(ctx.handle, ptr, m, n, lda, _dev_vector(α, n), _dev_vector(b, m)))
-        x = b[:n].clone()
-        ctx.synchronize()  # the flag-pipelined back substitution reports an expired hand-over wait here (dhqr.h)
-        return x
+        ctx.synchronize()  # an expired hand-over wait is reported here -- or the solve repeated without the persistent kernel (dhqr.h)
+        return b[:n].clone()
     m, n = H.shape
     F = H if H.flags.f_contiguous else np.asfortranarray(H)
     x = np.empty(n)

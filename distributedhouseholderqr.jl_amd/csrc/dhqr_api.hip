@@ -492,6 +492,8 @@ static int32_t status_reset(dhqr_ctx *c) {
 }
 // host copy of stat[0] (synchronises c->stream)
 static int32_t pipe_error_report(dhqr_ctx *c, int e);
+static int32_t solve_pipelined(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda, const double *dalpha, double *db,
+                               bool allow_persist);
 // (the same round trip brings the pipeline error word of dhqr_common.h: a hand-over wait that expired inside any of the
 // pass's launches is reported here, by every driver that reads its status once per pass)
 static int32_t status_read(dhqr_ctx *c, int *first_failed) {
@@ -1307,7 +1309,7 @@ int32_t dhqr_destroy(dhqr_ctx *c) {
     c->hio = nullptr;
   }
   Buf *bufs[] = {&c->vbuf, &c->vt, &c->vts, &c->ws[0].w1, &c->ws[0].w1r, &c->ws[0].w2, &c->ws[1].w1,
-                 &c->ws[1].w1r, &c->ws[1].w2, &c->ws[2].w1, &c->ws[2].w1r, &c->ws[2].w2, &c->spart, &c->spart2, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo, &c->host_mat, &c->sv_T, &c->sv_S, &c->sv_part, &c->sv_small, &c->tc_T, &c->tc_alpha, &c->small_dev};
+                 &c->ws[1].w1r, &c->ws[1].w2, &c->ws[2].w1, &c->ws[2].w1r, &c->ws[2].w2, &c->spart, &c->spart2, &c->sfull, &c->scratch, &c->pbuf, &c->rbuf, &c->tsq, &c->zsolve_lo, &c->host_mat, &c->sv_T, &c->sv_S, &c->sv_part, &c->sv_small, &c->tc_T, &c->tc_alpha, &c->small_dev, &c->sv_bkp};
   for (Buf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &e : c->evs) {
@@ -1354,6 +1356,24 @@ static int32_t pipe_error_check(dhqr_ctx *c) {
   int e = 0;
   HIPCHECK(hipMemcpy(&e, c->zflags + DHQR_PIPE_ERR_OFFSET, sizeof(int), hipMemcpyDeviceToHost));
   if (e == 0) return DHQR_OK;
+  if (e == 0x7ffffffe && c->retry.valid) {
+    // A wait of the Q'b kernels expired and the last solve took the persistent kernel (whose workgroups must all be resident:
+    // something else held compute units).  Repeat it from the saved b with one launch per panel step -- no workgroup of
+    // that form waits for a higher-indexed one -- and report only if that fails as well.
+    const dhqr_ctx::SolveRetry r = c->retry;
+    c->retry.valid = false;
+    HIPCHECK(hipMemsetAsync(c->zflags + DHQR_PIPE_ERR_OFFSET, 0, sizeof(int), c->stream));
+    HIPCHECK(hipMemcpyAsync(r.b, c->sv_bkp.p, (size_t)r.m * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    const bool was = c->profiling;
+    c->profiling = false;
+    const int32_t rc = solve_pipelined(c, r.A, r.m, r.n, r.lda, r.alpha, r.b, false);
+    c->profiling = was;
+    CHECK(rc);
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    c->n_solve_retry++;
+    HIPCHECK(hipMemcpy(&e, c->zflags + DHQR_PIPE_ERR_OFFSET, sizeof(int), hipMemcpyDeviceToHost));
+    if (e == 0) return DHQR_OK;
+  }
   return pipe_error_report(c, e);
 }
 
@@ -1438,6 +1458,12 @@ int32_t dhqr_set_small_route(dhqr_ctx *c, int32_t on) {
   return DHQR_OK;
 }
 
+int32_t dhqr_get_solve_retries(dhqr_ctx *c, int64_t *n_retries) {
+  if (!c || !n_retries) return set_err(DHQR_EINVAL, "null argument");
+  *n_retries = c->n_solve_retry;
+  return DHQR_OK;
+}
+
 int32_t dhqr_get_tsqr_count(dhqr_ctx *c, int64_t *n_tsqr) {
   if (!c || !n_tsqr) return set_err(DHQR_EINVAL, "null argument");
   *n_tsqr = c->n_tsqr;
@@ -1476,6 +1502,7 @@ int32_t dhqr_factor_f64(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_t l
   if (nb != 0 && nb != DHQR_NB)
     return set_err(DHQR_EINVAL, "nb must be 0 (unblocked) or %d (blocked); got %d", DHQR_NB, nb);
   if (c->tc_A == dA) c->tc_valid = false;  // whatever was kept for this matrix is gone
+  c->retry.valid = false;
   if (const int fit = small_qr_fit(c, m, n); fit >= 0) {  // the reference's algorithm in one launch, whatever nb says
     CHECK(prof_begin(c, CAT_RANK1));
     CHECK(small_qr_launch(c, fit, dA, lda, dA, lda, m, n, dalpha));
@@ -1624,8 +1651,9 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
 // The solve of dhqr_qtb.h on c->stream: batched Gram / T' pre-pass, one k_qtb_step launch per panel, one pipelined
 // back-substitution launch.  Nothing synchronises; db[0:n] <- x.
 static int32_t solve_pipelined(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda, const double *dalpha,
-                               double *db) {
+                               double *db, bool allow_persist) {
   const int np = (int)((n + DHQR_NBV - 1) / DHQR_NBV);
+  c->retry.valid = false;
   const bool vec = (lda % 2 == 0) && (m % 2 == 0) && aligned16(dA) && aligned16(db);
   // ---- unit table of the Gram pre-pass: panel k = rows [128 k, m), slabs of rps rows
   if (c->sv_m != m || c->sv_n != n) {
@@ -1682,11 +1710,22 @@ static int32_t solve_pipelined(dhqr_ctx *c, const double *dA, int64_t m, int64_t
   // when every workgroup is certain to be resident (one per CU at most, this context alone on the device, a real device:
   // the CPU emulator runs workgroups one after the other and reports no cooperative launch), else one launch per step.
   int *err = c->zflags + DHQR_PIPE_ERR_OFFSET;
-  const bool persist = c->solve_pipe == 3 || (c->solve_pipe == 1 && c->coop && g_live_ctx[c->device & 63].load() == 1);
+  const bool persist = allow_persist &&
+                       (c->solve_pipe == 3 || (c->solve_pipe == 1 && c->coop && g_live_ctx[c->device & 63].load() == 1));
   // persistent form: one 64 VEC-row slab per workgroup (VEC = 1 with 4 waves up to 64 rows x #CU, VEC = 2 with 8 waves beyond)
   const int pVEC = (!vec || m <= 64 * (int64_t)c->ncu) ? 1 : 2;
   const int64_t pnsl = (m + 64 * pVEC - 1) / (64 * pVEC);
   if (persist && pnsl <= (int64_t)c->ncu && c->qtb_vec <= 0) {
+    // what a repetition needs (pipe_error_check): b as it is now, and the arguments
+    CHECK(ensure(c, c->sv_bkp, (size_t)m));
+    HIPCHECK(hipMemcpyAsync(c->sv_bkp.p, db, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    c->retry.valid = true;
+    c->retry.A = dA;
+    c->retry.alpha = dalpha;
+    c->retry.b = db;
+    c->retry.m = m;
+    c->retry.n = n;
+    c->retry.lda = lda;
     if (pVEC == 2)
       hipLaunchKernelGGL((k_qtb_persist<2, 8>), dim3((unsigned)pnsl), dim3(512), 0, c->stream, dA, lda, m, n, np, db,
                          (const double *)c->sv_T.p, Tt_kept, (const int *)kept, wbuf, ypart, counter, wflag, err);
@@ -1728,7 +1767,7 @@ int32_t dhqr_solve_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int6
   c->profiling = false;  // the solve is timed as one group
   int32_t rc;
   if (c->solve_pipe) {
-    rc = solve_pipelined(c, dA, m, n, lda, dalpha, db);
+    rc = solve_pipelined(c, dA, m, n, lda, dalpha, db, true);
   } else {
     rc = apply_q_impl(c, dA, m, n, lda, dalpha, db, 1, m, 1, false);  // src:215-242
     if (rc == DHQR_OK) {
@@ -1816,9 +1855,12 @@ int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64
     HIPCHECK(hipMemcpyAsync(dal, halpha, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(db, hb, m * sizeof(double), hipMemcpyHostToDevice, c->stream));  // src:318 copy of b
     CHECK(dhqr_solve_f64(c, dA, m, n, ldd, dal, db));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    CHECK(pipe_error_check(c));  // a synchronous entry point reports an expired inter-workgroup wait itself (dhqr.h), after
+                                 // repeating a solve whose persistent kernel could not get all its workgroups resident
     HIPCHECK(hipMemcpyAsync(hx, db, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));  // src:320
     HIPCHECK(hipStreamSynchronize(c->stream));
-    return pipe_error_check(c);  // a synchronous entry point reports an expired inter-workgroup wait itself (dhqr.h)
+    return DHQR_OK;
   };
   int32_t rc = body();
   (void)hipStreamSynchronize(c->stream);

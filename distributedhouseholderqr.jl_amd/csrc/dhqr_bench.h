@@ -589,5 +589,40 @@ int32_t dhqr_debug_mfma_probe(dhqr_ctx *c, const double *da, const double *db, d
   return DHQR_OK;
 }
 
+// ---- test hook: hold compute units (include/dhqr_bench.h) ---------------------------------------------------------------
+extern "C++" {
+// 1024 threads + 150 KB of LDS: one workgroup per CU, and nothing else fits beside it.  Spins on a word of pinned host
+// memory; gives up after `max_cycles` of the constant 100 MHz counter (s_memrealtime) whatever the host does.
+__global__ __launch_bounds__(1024) void k_hold_cu(volatile int *release, unsigned long long max_ticks, int *sink) {
+  __shared__ int ballast[150 * 1024 / 4];
+  if (threadIdx.x == 0) ballast[blockIdx.x & 1023] = 1;
+  const unsigned long long t0 = wall_clock64();
+  if (threadIdx.x == 0) {
+    while (*release == 0 && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(64);
+  }
+  __syncthreads();
+  if (ballast[threadIdx.x] == 12345 && sink) sink[0] = 1;  // keep the LDS allocation alive
+}
+static hipStream_t g_hold_stream = nullptr;
+static int *g_hold_flag = nullptr;  // pinned host word
+}  // extern "C++"
+int32_t dhqr_debug_hold_cus(dhqr_ctx *c, int32_t nwg, int32_t max_ms, int32_t release) {
+  ENTER(c);
+  if (!g_hold_stream) {
+    HIPCHECK(hipStreamCreateWithFlags(&g_hold_stream, hipStreamNonBlocking));
+    HIPCHECK(hipHostMalloc((void **)&g_hold_flag, 64, hipHostMallocDefault));
+  }
+  if (release) {
+    *(volatile int *)g_hold_flag = 1;
+    HIPCHECK(hipStreamSynchronize(g_hold_stream));
+    return DHQR_OK;
+  }
+  if (nwg < 1 || nwg > 1024 || max_ms < 1 || max_ms > 5000) return set_err(DHQR_EINVAL, "bad arguments");
+  *(volatile int *)g_hold_flag = 0;
+  hipLaunchKernelGGL(k_hold_cu, dim3((unsigned)nwg), dim3(1024), 0, g_hold_stream, (volatile int *)g_hold_flag,
+                     (unsigned long long)max_ms * 100000ull, (int *)nullptr);  // wall_clock64: 100 MHz
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
 
 }  // extern "C"

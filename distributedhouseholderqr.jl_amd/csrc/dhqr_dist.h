@@ -698,7 +698,6 @@ static int32_t cs_residual(const CsProblem &pr, uint64_t seed, double *dW, doubl
 // every rank accumulates the contribution of ITS columns to the rows above; per block one all-reduce sums those
 // partial dots (the reference's sum(fetch.(futures)), src:262-266), the owner solves the diagonal block and
 // broadcasts x.  du: scratch of m + 128 doubles.
-static int32_t solve_pipelined(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int64_t lda, const double *dalpha, double *db);
 static int32_t cs_solve(const CsProblem &pr, double *db, double *du) {
   dhqr_ctx *c = pr.c;
   const int64_t NB = DHQR_NBV, m = pr.m;
@@ -709,7 +708,7 @@ static int32_t cs_solve(const CsProblem &pr, double *db, double *du) {
     CHECK(prof_begin(c, CAT_SOLVE));
     const bool was1 = c->profiling;
     c->profiling = false;
-    const int32_t rc1 = solve_pipelined(c, pr.A, m, pr.n, pr.lda, pr.alpha, db);
+    const int32_t rc1 = solve_pipelined(c, pr.A, m, pr.n, pr.lda, pr.alpha, db, true);
     c->profiling = was1;
     CHECK(rc1);
     CHECK(prof_end(c));

@@ -102,6 +102,18 @@ struct dhqr_ctx {
                          // else lives on the device (tests), 0 the round-1 solve (blocked apply on the MFMA kernels + 64-row back
                          // substitution: no inter-workgroup waits at all)
   int qtb_vec = -1;      // DHQR_QTB_VEC=1/2: rows per lane of k_qtb_step (-1: by the matrix height)
+  // k_qtb_persist's workgroups wait for each other in both directions; should one of its bounded waits expire (workgroups
+  // that could not all become resident: another process or stream holding compute units), the solve is REPEATED with one
+  // launch per panel step by the first synchronising entry point that finds the error word (pipe_error_check) instead of
+  // being reported: b is saved before the persistent launch, the arguments are remembered here.
+  struct SolveRetry {
+    bool valid = false;
+    const double *A = nullptr, *alpha = nullptr;
+    double *b = nullptr;
+    int64_t m = 0, n = 0, lda = 0;
+  } retry;
+  Buf sv_bkp;            // b as it was handed to the last solve that took the persistent kernel
+  int64_t n_solve_retry = 0;  // solves repeated that way (dhqr_get_solve_retries)
   int gram_strips = 1;   // the panel chain's Gram products as four 32-row strips (gram128; DHQR_TUNE gram_strips=0: one tile)
   int fuse_fix = 1;      // k_recon_fix in the epilogue of V = P M^{-1} (mul128; DHQR_TUNE fuse_fix=0: its own launch)
   int commit_off = -1;   // an accepted panel's commit (12 us of copies into the matrix) leaves the lane: -1 (default) with more

@@ -131,7 +131,8 @@ __device__ __forceinline__ void qtb_wait_ge(int *word, int want, int *err) {
   const int limit = err[1];
   while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > limit) {
+    // (once any wait of the call has expired its results are void: the others give up at once instead of one bound each)
+    if (++spins > limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
       __hip_atomic_store(err, 0x7ffffffe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }

@@ -796,7 +796,7 @@ static int32_t rs_solve(const RsProblem &pr, double *db, double *dx) {
     CHECK(prof_begin(c, CAT_SOLVE));
     const bool was1 = c->profiling;
     c->profiling = false;
-    int32_t rc1 = solve_pipelined(c, pr.A, pr.m, pr.n, pr.lda, pr.alpha, db);
+    int32_t rc1 = solve_pipelined(c, pr.A, pr.m, pr.n, pr.lda, pr.alpha, db, true);
     if (rc1 == DHQR_OK && dx != db)
       rc1 = hipMemcpyAsync(dx, db, (size_t)pr.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) == hipSuccess ? DHQR_OK : DHQR_EHIP;
     c->profiling = was1;

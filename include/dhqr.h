@@ -124,6 +124,11 @@ int32_t dhqr_get_tsqr_count(dhqr_ctx *ctx, int64_t *n_tsqr);
  * (m <= 256), whatever `nb` says; the host-array entry points dhqr_qr_f64 / dhqr_ldiv_f64 then run the kernel directly
  * on a pinned staging buffer (csrc/dhqr_small.h).  on = 0: the general drivers for every shape (also DHQR_SMALL=0). */
 int32_t dhqr_set_small_route(dhqr_ctx *ctx, int32_t on);
+/* Solves this context REPEATED with one launch per panel step because a wait of the persistent Q'b kernel (all of whose
+ * workgroups must be resident at once) expired -- another process or stream held compute units.  The repetition happens
+ * inside the first synchronising entry point after the solve (dhqr_synchronize, dhqr_ldiv_f64, ...), from a copy of b
+ * taken before the persistent launch; the caller sees a correct x and DHQR_OK. */
+int32_t dhqr_get_solve_retries(dhqr_ctx *ctx, int64_t *n_retries);
 
 /* ------------------------------------------------------------------ synthetic inputs
  * Replaces rand(T,m,n) / rand(T,m) of test/runtests.jl:45-46 with the portable counter-based

@@ -49,6 +49,13 @@ int32_t dhqr_bench_mma_probe_f64(dhqr_ctx *ctx, int32_t mode, int32_t threads, d
  * LDS, 128 barrier steps).  out4 = {ms Gram + reduction, ms stand-in, ms total, 0} per repetition.  Synchronous. */
 int32_t dhqr_bench_lane_probe_f64(dhqr_ctx *ctx, int64_t rows, int32_t nsplit, int32_t lds_kb, int32_t reps, double *out4);
 
+/* Test hook: occupy compute units.  release = 0: launch, on a stream of its own, `nwg` workgroups of 1024 threads with
+ * 150 KB of LDS each (one per CU; nothing else fits beside one) that spin until released or until `max_ms` have passed
+ * (bounded: the hook can never hang the device), and return at once; release = 1: let them go and wait for them.
+ * tests/test_gpu_kernels.py holds all but a few CUs this way while a solve's persistent kernel needs every workgroup
+ * resident: its bounded waits expire and the solve must be repeated with the per-step kernels. */
+int32_t dhqr_debug_hold_cus(dhqr_ctx *ctx, int32_t nwg, int32_t max_ms, int32_t release);
+
 #ifdef __cplusplus
 }
 #endif
