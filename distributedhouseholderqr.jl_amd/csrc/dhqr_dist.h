@@ -698,6 +698,158 @@ static int32_t cs_residual(const CsProblem &pr, uint64_t seed, double *dW, doubl
 // every rank accumulates the contribution of ITS columns to the rows above; per block one all-reduce sums those
 // partial dots (the reference's sum(fetch.(futures)), src:262-266), the owner solves the diagonal block and
 // broadcasts x.  du: scratch of m + 128 doubles.
+// r6: the column split's solve at P > 1 on the kernels of dhqr_qtb.h, one cyclic block (a PAIR of panels, both on one rank)
+// per step -- half the collectives of the per-panel form below and none of its re-packing:
+//   pre-pass (no collective, every rank on its own pairs, independent of b): S = V'V and T' of every local panel by the
+//     batched Gram / sum / inverse kernels, each pair addressed as the (m - c0) x 256 sub-matrix whose top-left corner
+//     is the pair's diagonal;
+//   Q'b: the pair's owner runs the panel steps of k_qtb_step on that sub-matrix and b[c0:m] (V read in place, b never
+//     leaves the workgroup between update and dots), then broadcasts b[c0:m] -- the reference hands b from owner to
+//     owner through shared memory (src:226-230);
+//   back substitution, pairs from the right: ONE all-reduce of the 256 partial sums the ranks have accumulated for the
+//     pair's rows (the reference's sum(fetch.(futures)), src:262-266), the owner solves its 256 x 256 triangle with the
+//     pipelined kernel (two workgroups) and broadcasts the 256 solved entries, every rank subtracts the contribution of
+//     ITS columns... only the owner holds the pair's columns: it subtracts R[0:c0, pair] x from its accumulator.
+// du: m doubles of scratch (the accumulator).  Synchronises only where the LOCAL transport needs it.
+static int32_t cs_solve_pairs(const CsProblem &pr, double *db, double *du) {
+  dhqr_ctx *c = pr.c;
+  dhqr_comm *cm = pr.cm;
+  const int64_t NB = DHQR_NBV, m = pr.m, lda = pr.lda;
+  const int64_t npairs = (pr.K + 1) / 2;
+  auto pair_c0 = [&](int64_t q) { return q * CS_CB; };
+  auto pair_cols = [&](int64_t q) { return std::min<int64_t>(CS_CB, pr.n - q * CS_CB); };
+  auto sync_local = [&]() -> int32_t {
+    if (cm->kind == COMM_LOCAL) {
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      CHECK(comm_host_barrier(cm));
+    }
+    return DHQR_OK;
+  };
+  // ---- workspaces: T' / S per local panel, Gram partials of the tallest pair, [ypart | w | x | ints]
+  std::vector<int64_t> mine;
+  for (int64_t q = 0; q < npairs; ++q)
+    if (pr.mine(2 * q)) mine.push_back(q);
+  const size_t nlp = 2 * mine.size() + 2;
+  CHECK(ensure(c, c->sv_T, nlp * QTB_NB2));
+  CHECK(ensure(c, c->sv_S, nlp * QTB_NB2));
+  auto pair_rps = [&](int64_t mq, int64_t nq) {
+    const int npq = (int)((nq + NB - 1) / NB);
+    int64_t total = 0;
+    for (int k = 0; k < npq; ++k) total += mq - (int64_t)k * NB;
+    int64_t rps = ((total / 1024 + 15) / 16) * 16;
+    return std::min<int64_t>(std::max<int64_t>(rps, 256), 4096);
+  };
+  size_t max_units = 4;
+  std::vector<int> tables;  // three ints per local pair: the unit table of its Gram pre-pass
+  for (int64_t q : mine) {
+    const int64_t mq = m - pair_c0(q), nq = pair_cols(q), rps = pair_rps(mq, nq);
+    const int npq = (int)((nq + NB - 1) / NB);
+    int u[3] = {0, 0, 0};
+    for (int k = 0; k < npq; ++k) u[k + 1] = u[k] + (int)((mq - (int64_t)k * NB + rps - 1) / rps);
+    if (npq == 1) u[2] = u[1];
+    max_units = std::max<size_t>(max_units, (size_t)u[npq]);
+    tables.insert(tables.end(), u, u + 3);
+  }
+  CHECK(ensure(c, c->sv_part, max_units * QTB_NB2));
+  const int64_t SSmax = 128, maxsl = std::max<int64_t>(8, std::min<int64_t>(c->ncu, 256));
+  const size_t n_ypart = (size_t)std::max<int64_t>(maxsl + 2, (m + 63) / 64) * QTB_NB, n_w = 3 * (size_t)QTB_NB;
+  const size_t n_ints = tables.size() + 3 * mine.size() + 2 * (size_t)npairs + 8;
+  CHECK(ensure(c, c->sv_small, n_ypart + n_w + (n_ints + 1) / 2 + 16));
+  (void)SSmax;
+  double *ypart = c->sv_small.p, *wbuf = ypart + n_ypart;
+  int *ints = reinterpret_cast<int *>(wbuf + n_w);
+  int *tab_dev = ints, *counters = tab_dev + tables.size(), *flags = counters + 3 * mine.size(), *zero = flags + 2 * npairs;
+  HIPCHECK(hipMemsetAsync(ints, 0, n_ints * sizeof(int), c->stream));
+  if (!tables.empty()) {
+    // (the table is a host vector that dies with this call: the copy is waited for below, before anything else can fail)
+    HIPCHECK(hipMemcpyAsync(tab_dev, tables.data(), tables.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+  }
+  const bool was = c->profiling;
+  CHECK(prof_begin(c, CAT_SOLVE));
+  c->profiling = false;
+  int *err = c->zflags + DHQR_PIPE_ERR_OFFSET;
+  auto body = [&]() -> int32_t {
+    // ---- pre-pass on this rank's pairs
+    for (size_t i = 0; i < mine.size(); ++i) {
+      const int64_t q = mine[i], c0 = pair_c0(q), mq = m - c0, nq = pair_cols(q), rps = pair_rps(mq, nq);
+      const int npq = (int)((nq + NB - 1) / NB);
+      const double *sub = pr.A + c0 + pr.lcol(2 * q) * lda;
+      const bool vec = (lda % 2 == 0) && (mq % 2 == 0) && aligned16(sub);
+      const int *tab = tab_dev + 3 * i;
+      const int nunits = tables[3 * i + npq];
+      if (vec)
+        hipLaunchKernelGGL((k_gemm_tn_gram_batch<2>), dim3((unsigned)nunits), dim3(256), 0, c->stream, sub, lda, mq, nq, rps, tab,
+                           npq, c->sv_part.p, (const int *)zero);
+      else
+        hipLaunchKernelGGL((k_gemm_tn_gram_batch<1>), dim3((unsigned)nunits), dim3(256), 0, c->stream, sub, lda, mq, nq, rps, tab,
+                           npq, c->sv_part.p, (const int *)zero);
+      hipLaunchKernelGGL(k_qtb_sum_gram, dim3((unsigned)npq, 16), dim3(256), 0, c->stream, (const double *)c->sv_part.p, tab, nq,
+                         c->sv_S.p + 2 * i * QTB_NB2, (const int *)zero);
+      hipLaunchKernelGGL(k_build_t_batch, dim3((unsigned)npq), dim3(1024), 0, c->stream, (const double *)(c->sv_S.p + 2 * i * QTB_NB2),
+                         nq, c->sv_T.p + 2 * i * QTB_NB2, (const int *)zero);
+    }
+    LAUNCHCHECK();
+    // ---- b <- Q'b, pair by pair (src:215-242)
+    size_t li = 0;
+    for (int64_t q = 0; q < npairs; ++q) {
+      const int64_t c0 = pair_c0(q), mq = m - c0, nq = pair_cols(q);
+      const int npq = (int)((nq + NB - 1) / NB);
+      if (pr.mine(2 * q)) {
+        const double *sub = pr.A + c0 + pr.lcol(2 * q) * lda;
+        const bool vec = (lda % 2 == 0) && (mq % 2 == 0) && aligned16(sub) && aligned16(db + c0);
+        const int VEC = (c->qtb_vec == 1 || !vec) ? 1 : (c->qtb_vec == 2 ? 2 : (mq >= 16384 ? 2 : 1));
+        const int64_t SS = 64 * VEC;
+        const int64_t sl = SS * ((mq + SS * maxsl - 1) / (SS * maxsl));
+        const int64_t nsl = (mq + sl - 1) / sl;
+        const double *Tt = c->sv_T.p + 2 * li * QTB_NB2;
+        for (int k = 0; k <= npq; ++k) {
+          const int64_t rfirst = (int64_t)(k >= 1 ? k - 1 : 0) * NB;
+          const unsigned grid = (unsigned)(nsl - rfirst / sl);
+          if (VEC == 2)
+            hipLaunchKernelGGL((k_qtb_step<2>), dim3(grid), dim3(256), 0, c->stream, sub, lda, mq, nq, k, npq, sl, db + c0, Tt, Tt,
+                               (const int *)zero, wbuf, ypart, counters + 3 * li, err);
+          else
+            hipLaunchKernelGGL((k_qtb_step<1>), dim3(grid), dim3(256), 0, c->stream, sub, lda, mq, nq, k, npq, sl, db + c0, Tt, Tt,
+                               (const int *)zero, wbuf, ypart, counters + 3 * li, err);
+        }
+        LAUNCHCHECK();
+        ++li;
+      }
+      CHECK(comm_bcast(cm, db + c0, mq, pr.owner(2 * q), c->stream, nullptr));
+      CHECK(sync_local());
+    }
+    // ---- back substitution, pairs from the right (src:244-282)
+    HIPCHECK(hipMemsetAsync(du, 0, (size_t)m * sizeof(double), c->stream));
+    for (int64_t q = npairs - 1; q >= 0; --q) {
+      const int64_t c0 = pair_c0(q), nq = pair_cols(q);
+      CHECK(comm_allreduce_sum(cm, du + c0, nq, c->stream));
+      if (pr.mine(2 * q)) {
+        const double *sub = pr.A + c0 + pr.lcol(2 * q) * lda;
+        hipLaunchKernelGGL(k_axpy_n, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, c->stream, db + c0, (const double *)(du + c0),
+                           (int)nq);
+        hipLaunchKernelGGL(k_backsub_pipe, dim3((unsigned)((nq + NB - 1) / NB)), dim3(BSP_THREADS), 0, c->stream, sub, lda,
+                           (const double *)(pr.alpha + c0), db + c0, nq, flags + 2 * q, err);
+        LAUNCHCHECK();
+      }
+      CHECK(comm_bcast(cm, db + c0, nq, pr.owner(2 * q), c->stream, nullptr));
+      CHECK(sync_local());
+      if (pr.mine(2 * q) && c0 > 0) {
+        const double *cols = pr.A + pr.lcol(2 * q) * lda;  // the pair's columns from row 0: R above the pair
+        hipLaunchKernelGGL(k_backsub_update_wide, dim3((unsigned)((c0 + 255) / 256)), dim3(256), 0, c->stream, cols, lda, du, c0,
+                           (const double *)(db + c0), (int)nq);
+        LAUNCHCHECK();
+      }
+    }
+    return DHQR_OK;
+  };
+  const int32_t rc = body();
+  c->profiling = was;
+  CHECK(rc);
+  CHECK(prof_end(c));
+  return DHQR_OK;
+}
+
 static int32_t cs_solve(const CsProblem &pr, double *db, double *du) {
   dhqr_ctx *c = pr.c;
   const int64_t NB = DHQR_NBV, m = pr.m;
@@ -714,6 +866,7 @@ static int32_t cs_solve(const CsProblem &pr, double *db, double *du) {
     CHECK(prof_end(c));
     return DHQR_OK;
   }
+  if (cm && c->solve_pipe) return cs_solve_pairs(pr, db, du);
   CHECK(cs_prepare(pr));
   const bool was = c->profiling;
   CHECK(prof_begin(c, CAT_SOLVE));

@@ -71,6 +71,31 @@ __global__ __launch_bounds__(256) void k_backsub_update_range(const double *__re
   b[r] -= acc;
 }
 
+// acc[0:rows] -= A[0:rows, 0:nb] * x[0:nb], nb <= 256: what a pair of panels solved on this rank contributes to the rows above
+// it (cs_solve at P > 1, dhqr_dist.h); A = the pair's columns from row 0, x = the pair's solved entries
+__global__ __launch_bounds__(256) void k_backsub_update_wide(const double *__restrict__ A, int64_t lda, double *__restrict__ acc,
+                                                             int64_t rows, const double *__restrict__ x, int nb) {
+  __shared__ double xs[256];
+  const int t = threadIdx.x;
+  xs[t] = (t < nb) ? x[t] : 0.0;
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + t;
+  if (r >= rows) return;
+  double a0 = 0.0, a1 = 0.0;
+  int c = 0;
+  for (; c + 1 < nb; c += 2) {
+    a0 = fma(A[r + (int64_t)c * lda], xs[c], a0);
+    a1 = fma(A[r + (int64_t)(c + 1) * lda], xs[c + 1], a1);
+  }
+  if (c < nb) a0 = fma(A[r + (int64_t)c * lda], xs[c], a0);
+  acc[r] -= a0 + a1;
+}
+// x[i] += s[i], i < n (any n)
+__global__ __launch_bounds__(256) void k_axpy_n(double *__restrict__ x, const double *__restrict__ s, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] += s[i];
+}
+
 // partialdot hook: partial sums per workgroup, then one workgroup finishes.
 __global__ __launch_bounds__(256) void k_partialdot_partial(const double *__restrict__ a,
                                                             const double *__restrict__ b,
