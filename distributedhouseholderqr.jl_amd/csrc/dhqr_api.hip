@@ -1078,7 +1078,7 @@ static CsProblem cs_single(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_
 }
 
 // ---- the single-workgroup route for small matrices (dhqr_small.h) -------------------------------------------------
-// instantiations of k_small_qr<NR, NQ>: rows <= 16 NR, columns <= 16 NQ, NR * NQ doubles of matrix per lane
+// instantiations of k_small_qr_b<NR, NQ, EXTRA>: rows <= 16 NR, columns <= 32 NQ, NR * NQ doubles of matrix per lane
 static inline int small_qr_fit(const dhqr_ctx *c, int64_t m, int64_t n) {
   if (!c->small_route || m < n || n < 1) return -1;
   if (m <= 128 && n <= 128) return 0;
@@ -1091,12 +1091,26 @@ static inline bool small_ldiv_fit(const dhqr_ctx *c, int64_t m, int64_t n) {
 }
 static int32_t small_qr_launch(dhqr_ctx *c, int fit, const double *Asrc, int64_t lds, double *Adst, int64_t ldd, int64_t m,
                                int64_t n, double *alpha) {
+  // (k_small_qr_b: the reflectors are built by a ninth wave / by another wave than the column's owner, dhqr_small.h)
   if (fit == 0)
-    hipLaunchKernelGGL((k_small_qr<8, 4>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+    hipLaunchKernelGGL((k_small_qr_b<8, 4, true>), dim3(1), dim3(SMB_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
   else if (fit == 1)
-    hipLaunchKernelGGL((k_small_qr<14, 7>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+    hipLaunchKernelGGL((k_small_qr_b<14, 7, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
   else
-    hipLaunchKernelGGL((k_small_qr<16, 6>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+    hipLaunchKernelGGL((k_small_qr_b<16, 6, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+  LAUNCHCHECK();
+  return DHQR_OK;
+}
+static int32_t small_ldiv_launch(dhqr_ctx *c, const double *A, int64_t lda, int64_t m, int64_t n, const double *alpha,
+                                 const double *bin, double *bout, double *xout, double *Awork) {
+#define DHQR_SML(RPL_)                                                                                                     \
+  hipLaunchKernelGGL((k_small_ldiv<RPL_>), dim3(1), dim3(SML_THREADS), 0, c->stream, A, lda, (int)m, (int)n, alpha, bin, bout, \
+                     xout, Awork)
+  if (m <= 64) DHQR_SML(1);
+  else if (m <= 128) DHQR_SML(2);
+  else if (m <= 192) DHQR_SML(3);
+  else DHQR_SML(4);
+#undef DHQR_SML
   LAUNCHCHECK();
   return DHQR_OK;
 }
@@ -1758,9 +1772,7 @@ int32_t dhqr_solve_f64(dhqr_ctx *c, const double *dA, int64_t m, int64_t n, int6
   if (!dalpha || !db) return set_err(DHQR_EINVAL, "null alpha or b pointer");
   CHECK(prof_begin(c, CAT_SOLVE));
   if (small_ldiv_fit(c, m, n)) {  // one single-workgroup launch (dhqr_small.h)
-    hipLaunchKernelGGL(k_small_ldiv, dim3(1), dim3(SML_THREADS), 0, c->stream, dA, lda, (int)m, (int)n, dalpha, (const double *)db,
-                       db, (double *)nullptr, (double *)nullptr);
-    LAUNCHCHECK();
+    CHECK(small_ldiv_launch(c, dA, lda, m, n, dalpha, db, db, nullptr, nullptr));
     return prof_end(c);
   }
   const bool was = c->profiling;
@@ -1824,9 +1836,7 @@ int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64
     // the kernel first brings the factor from the pinned buffer into device memory (its chunk pipeline would otherwise pay
     // a PCIe round trip per chunk)
     CHECK(ensure(c, c->small_dev, (size_t)SML_LDR * SML_LDR));
-    hipLaunchKernelGGL(k_small_ldiv, dim3(1), dim3(SML_THREADS), 0, c->stream, (const double *)pA, m, (int)m, (int)n,
-                       (const double *)pal, (const double *)pb, pb, px, c->small_dev.p);
-    LAUNCHCHECK();
+    CHECK(small_ldiv_launch(c, pA, m, m, n, pal, pb, pb, px, c->small_dev.p));
     HIPCHECK(hipStreamSynchronize(c->stream));
     memcpy(hx, px, (size_t)n * sizeof(double));  // src:320
     return DHQR_OK;

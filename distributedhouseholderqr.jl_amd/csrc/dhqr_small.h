@@ -7,16 +7,17 @@
 // (src:122-148, 198-213) runs here exactly as written -- one reflector after the other, every trailing column updated by
 // every reflector -- with the whole matrix resident in VGPRs and ONE workgroup barrier per column:
 //
-//   k_small_qr<NR, NQ>   512 threads = 8 waves (two per SIMD, 256 registers per lane).  Lane (rg, cs) of wave w holds
-//                        rows rg + 16 r (r < NR) of the columns 32 q + 4 w + cs (q < NQ): a 16-lane DPP row spans 16
-//                        consecutive matrix rows of one column, the four rows of a wave are four adjacent columns.  The dot
+//   k_small_qr_b<NR, NQ> 512 threads = 8 waves (two per SIMD, 256 registers per lane; + a ninth for m <= 128).  Lane (rg, cs) of
+//                        wave w holds rows rg + 16 r (r < NR) of the columns 32 q + 4 w + cs (q < NQ): a 16-lane DPP row spans
+//                        16 consecutive matrix rows of one column, the four rows of a wave are four adjacent columns.  The dot
 //                        product v_j' a_c (partialdot, src:42-49) is NR fma per lane + a 4-step DPP reduction inside the
 //                        16-lane row (VALU only, four columns per instruction); the update (hotloop!, src:156-160) NR fma.
-//                        The wave that owns column j + 1 updates it FIRST and builds reflector j + 1 (norm in
-//                        double-double like every other path, src:129-135) while the other waves are still applying
-//                        reflector j: the reflector chain overlaps the trailing update, v travels through 2 x 16 NR
-//                        doubles of LDS (double buffered by column parity).
-//   k_small_ldiv         b <- Q'b (src:215-224) and the back substitution (src:244-254) in one launch: wave 0 keeps b in
+//                        The wave that owns column j + 1 updates it FIRST and hands it to a builder wave, which forms
+//                        reflector j + 1 (norm in double-double like every other path, src:129-135) while the others are
+//                        still applying reflector j; v travels through 2 x 16 NR doubles of LDS (double buffered by column
+//                        parity).  The kernels are bound by instruction issue (one or two waves per SIMD, 6.3 cycles per
+//                        FP64 instruction), not by latency or memory.
+//   k_small_ldiv<RPL>    b <- Q'b (src:215-224) and the back substitution (src:244-254) in one launch: wave 0 keeps b in
 //                        registers and walks the columns, waves 1-3 stream the factor in 16-column chunks into a
 //                        double-buffered LDS stage ahead of it (once left to right for Q'b, once right to left -- upper
 //                        triangle only -- for R).
@@ -108,14 +109,31 @@ __device__ __forceinline__ void smq_pass(double (&a)[NQ][NR], const double (&vr)
 }
 
 // householder!(A, alpha) (src:113, 122-148, 198-213) for m <= 16 NR, n <= 32 NQ, m >= n.  Asrc / Adst may alias.
-template <int NR, int NQ>
-__global__ __launch_bounds__(SMQ_THREADS) void k_small_qr(const double *Asrc, int64_t lds, double *Adst, int64_t ldd, int m,
-                                                          int n, double *__restrict__ alpha) {
+// The reflector construction is taken OFF the owner of the look-ahead column (the first version built it there: first the
+// owner's update of the column, then norm / square roots / scaling, then its share of the trailing update -- ~1000
+// instructions at 6.3 cycles each where the other seven waves had 350 and waited at the barrier: 169 us at 110 x 100, 602 us
+// at 220 x 200; now 125 / 560).  The owner only brings its column up to date and hands it over through LDS (xcol); a BUILDER
+// wave turns it into reflector j + 1 (double-double norm, the refinement chains of dhqr_common.h):
+//   EXTRA = true   (m <= 128: registers to spare) a ninth wave that holds no part of the matrix builds WHILE all eight
+//                  matrix waves apply reflector j;
+//   EXTRA = false  the wave four places from the owner (another SIMD) builds after its own share of the update: the
+//                  longest wave of a step has update + build (~600 instructions) instead of update + build + update.
+// The owner never sees the scaled column again during the factorisation -- a finished column is only ever stored -- so the
+// scaling of the matrix copy is deferred to the end: f_j and the new pivot entry of every column wait in LDS.
+// Two barriers per column: "column j + 1 is in xcol" and "reflector j + 1 is in vb / reflector j is applied".
+#define SMB_THREADS (SMQ_THREADS + 64)
+template <int NR, int NQ, bool EXTRA>
+__global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_b(const double *Asrc, int64_t lds, double *Adst,
+                                                                                   int64_t ldd, int m, int n,
+                                                                                   double *__restrict__ alpha) {
+  constexpr int RBL = (16 * NR + 63) / 64;  // rows of the handed-over column per lane of the builder
+  constexpr int NT = EXTRA ? SMB_THREADS : SMQ_THREADS;
   __shared__ double vb[2][16 * NR];
-  __shared__ double als[SMQ_GW * NQ];  // alpha leaves in one piece at the end: a store per column to (possibly host) memory
-                                       // would put a PCIe round trip in front of every barrier (measured: 2.4 us per column)
+  __shared__ double xcol[64 * RBL];
+  __shared__ double als[SMQ_GW * NQ], fcol[SMQ_GW * NQ], pcol[SMQ_GW * NQ];
   const int t = threadIdx.x, w = t >> 6, l = t & 63, rg = l & 15, cs = l >> 4;
-  const int cbase = 4 * w + cs;  // this lane's column of group q: 32 q + cbase
+  const bool xwave = EXTRA && w == 8;  // holds no part of the matrix
+  const int cbase = 4 * w + cs;        // this lane's column of group q: 32 q + cbase (matrix waves)
   double a[NQ][NR];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
@@ -123,40 +141,35 @@ __global__ __launch_bounds__(SMQ_THREADS) void k_small_qr(const double *Asrc, in
     for (int r = 0; r < NR; ++r) {
       const int row = rg + 16 * r, col = SMQ_GW * q + cbase;
       a[q][r] = 0.0;
-      if (row < m && col < n) a[q][r] = Asrc[(int64_t)row + (int64_t)col * lds];
+      if (!xwave && row < m && col < n) a[q][r] = Asrc[(int64_t)row + (int64_t)col * lds];
     }
-
-  // Reflector of column jn from its updated entries (src:129-135); executed by every lane of the wave that holds it, on
-  // the matrix registers in place (the column sits in the 16 lanes cs == cs1; the other three rows of the wave compute
-  // along on their own columns and discard the result).  Row blocks above the pivot's are skipped (uniform branches).
-  auto build = [&](int jn) __attribute__((always_inline)) {
-    const int q1 = jn / SMQ_GW, r1 = jn >> 4, cs1 = jn & 3, srcl = (cs1 << 4) | (jn & 15);
-    dhqr_dd acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
-    double hc = 0.0;
+  for (int i = 16 * NR + t; i < 64 * RBL; i += NT) xcol[i] = 0.0;  // rows beyond the matrix registers: never handed over
+  // owner of column jn: its (up to date) column -> xcol (the prologue's; a step hands over inside its update of the group:
+  // as a separate pass over the registers the compiler kept a shadow copy of the group in scratch memory)
+  auto hand_over = [&](int jn) __attribute__((always_inline)) {
+    const int q1 = jn / SMQ_GW, cs1 = jn & 3;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       if (q == q1) {
 #pragma unroll
         for (int r = 0; r < NR; ++r)
-          if (r >= r1) {
-            const int row = rg + 16 * r;
-            const double xv = (row >= jn) ? a[q][r] : 0.0;  // rows >= m hold zeros
-            if (row == jn) hc = a[q][r];
-            if (r & 1) dd_add_sq(acc1, xv);
-            else dd_add_sq(acc0, xv);
-          }
+          if (cs == cs1) xcol[rg + 16 * r] = a[q][r];
       }
-    const double h = smq_readlane(hc, srcl);
-    acc0.lo += acc1.lo;
-    {
-      double e;
-      dd_two_sum(acc0.hi, acc1.hi, acc0.hi, e);
-      acc0.lo += e;
+  };
+  // builder wave: reflector jn from xcol (src:129-135) -> vb[jn & 1], alpha, and what the deferred scaling needs
+  auto build = [&](int jn) __attribute__((always_inline)) {
+    double x[RBL];
+    dhqr_dd acc = {0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < RBL; ++r) {
+      x[r] = xcol[l + 64 * r];
+      dd_add_sq(acc, l + 64 * r >= jn ? x[r] : 0.0);  // rows >= m hold zeros
     }
-    const dhqr_dd ss = row16_sum_dd(acc0);
-    const double s2 = smq_readlane(ss.hi + ss.lo, srcl);
+    const double h = xcol[jn];
+    const dhqr_dd ss = wave_sum_dd(acc);
+    const double s2 = ss.hi + ss.lo;
     double sn, f;
-    if (s2 > 0.0 && s2 < 1e300) {  // (uniform) the refinement chains of dhqr_common.h: half the dependent instructions
+    if (s2 > 0.0 && s2 < 1e300) {
       double rinv, sq;
       dhqr_sqrt_rsqrt(s2, sn, rinv);                // src:129
       dhqr_sqrt_rsqrt(sn * (sn + fabs(h)), sq, f);  // src:131
@@ -165,62 +178,56 @@ __global__ __launch_bounds__(SMQ_THREADS) void k_small_qr(const double *Asrc, in
       f = 1.0 / sqrt(sn * (sn + fabs(h)));
     }
     const double al = sn * dhqr_alphafactor(h);     // src:130
+    const double piv = (h - al) * f;                // src:132
     double *vo = vb[jn & 1];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-      if (q == q1) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const int row = rg + 16 * r;
-          if (r >= r1) {
-            const double xv = a[q][r];
-            const double val = row > jn ? xv * f : (row == jn ? (h - al) * f : xv);  // src:132-135
-            if (cs == cs1) {
-              a[q][r] = val;
-              vo[row] = row >= jn ? val : 0.0;  // src:138-140 (Hj)
-            }
-          } else if (cs == cs1) {
-            vo[row] = 0.0;
-          }
-        }
-      }
-    if (l == srcl) als[jn] = al;
+    for (int r = 0; r < RBL; ++r) {
+      const int row = l + 64 * r;
+      if (row < 16 * NR) vo[row] = row > jn ? x[r] * f : (row == jn ? piv : 0.0);  // src:133-140
+    }
+    if (l == 0) {
+      als[jn] = al;
+      fcol[jn] = f;
+      pcol[jn] = piv;
+    }
   };
-
-  // one column step; R0: rows below 16 R0 lie above row j (compile time: the loop below runs in four phases, a quarter of
-  // the rows apart -- four code versions inside ONE loop body made the register allocator spill ~1000 registers at the
-  // merge, four loops one after the other do not)
   auto step = [&](auto r0c, int j) __attribute__((always_inline)) {
     constexpr int R0 = decltype(r0c)::value;
+    const int jn = j + 1, qn = jn / SMQ_GW, wn = (jn & (SMQ_GW - 1)) >> 2;  // wn: the wave that holds column j + 1
     double vr[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) vr[r] = (r >= R0) ? vb[j & 1][rg + 16 * r] : 0.0;
-    const int jn = j + 1, qn = jn / SMQ_GW;
     int qskip = -1;
-    if (w == ((jn & (SMQ_GW - 1)) >> 2)) {
-      // the wave that holds column j + 1 updates that column's group first and builds the next reflector while the
-      // other waves are still applying this one
+    if (!xwave) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        if (q == qn) {
-          double p0 = 0.0, p1 = 0.0;
+      for (int r = 0; r < NR; ++r) vr[r] = (r >= R0) ? vb[j & 1][rg + 16 * r] : 0.0;
+      if (w == wn) {  // the owner of column j + 1: that column's group first, handed over as it is updated
 #pragma unroll
-          for (int r = R0; r < NR; r += 2) {
-            p0 = fma(vr[r], a[q][r], p0);
-            if (r + 1 < NR) p1 = fma(vr[r + 1], a[q][r + 1], p1);
+        for (int q = 0; q < NQ; ++q)
+          if (q == qn) {
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int r = R0; r < NR; r += 2) {
+              p0 = fma(vr[r], a[q][r], p0);
+              if (r + 1 < NR) p1 = fma(vr[r + 1], a[q][r + 1], p1);
+            }
+            const double p = row16_sum(p0 + p1);
+            const double d = (SMQ_GW * q + cbase > j) ? p : 0.0;
+#pragma unroll
+            for (int r = R0; r < NR; ++r) a[q][r] = fma(-vr[r], d, a[q][r]);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+              if (cs == (jn & 3)) xcol[rg + 16 * r] = a[q][r];
           }
-          const double p = row16_sum(p0 + p1);
-          const double d = (SMQ_GW * q + cbase > j) ? p : 0.0;
-#pragma unroll
-          for (int r = R0; r < NR; ++r) a[q][r] = fma(-vr[r], d, a[q][r]);
-        }
-      build(jn);
-      qskip = qn;
+        qskip = qn;
+      }
     }
-    smq_pass<NR, NQ, R0>(a, vr, j, cbase, qskip);
-    __syncthreads();
+    __syncthreads();  // column j + 1 is in xcol
+    if (!xwave) smq_pass<NR, NQ, R0>(a, vr, j, cbase, qskip);
+    if (w == (EXTRA ? 8 : ((wn + 4) & 7))) build(jn);
+    __syncthreads();  // reflector j + 1 is in vb; reflector j is applied everywhere
   };
-  if (w == 0) build(0);
+  if (w == 0) hand_over(0);
+  __syncthreads();
+  if (w == (EXTRA ? 8 : 4)) build(0);
   __syncthreads();
   {
     constexpr int RA = NR / 4, RB = NR / 2, RC = (3 * NR) / 4;
@@ -230,14 +237,23 @@ __global__ __launch_bounds__(SMQ_THREADS) void k_small_qr(const double *Asrc, in
     for (; j + 1 < n && j < 16 * RC; ++j) step(std::integral_constant<int, RB>{}, j);
     for (; j + 1 < n; ++j) step(std::integral_constant<int, RC>{}, j);
   }
+  if (!xwave) {
+    // the deferred scaling (src:132-135): below the diagonal times f_col, the pivot entry replaced; R above it untouched
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
+    for (int q = 0; q < NQ; ++q) {
+      const int col = SMQ_GW * q + cbase;
+      const double f = (col < n) ? fcol[col] : 0.0, piv = (col < n) ? pcol[col] : 0.0;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int row = rg + 16 * r, col = SMQ_GW * q + cbase;
-      if (row < m && col < n) Adst[(int64_t)row + (int64_t)col * ldd] = a[q][r];
+      for (int r = 0; r < NR; ++r) {
+        const int row = rg + 16 * r;
+        if (row < m && col < n) {
+          const double x = a[q][r];
+          Adst[(int64_t)row + (int64_t)col * ldd] = row > col ? x * f : (row == col ? piv : x);
+        }
+      }
     }
-  for (int i = t; i < n; i += SMQ_THREADS) alpha[i] = als[i];
+  }
+  for (int i = t; i < n; i += NT) alpha[i] = als[i];
 }
 
 // solve_householder!(b, H, alpha) (src:284-294) for m <= 256: b (m) <- [x; tail of Q'b], xout (n, may be nullptr) <- x.
@@ -249,8 +265,11 @@ __global__ __launch_bounds__(SMQ_THREADS) void k_small_qr(const double *Asrc, in
 // (docs/DESIGN_rounds1-4.md, section 1).
 // Awork != nullptr: the factor is first copied there (m x n, leading dimension m; device memory) with every load in
 // flight at once -- A is then pinned HOST memory, and the chunk pipeline below would pay a PCIe round trip per chunk.
+// The solving wave is bound by instruction issue (~150 double-double instructions per reflector at four rows per lane, one
+// wave on its SIMD: 6.3 cycles each): RPL = ceil(m / 64) rows per lane, not always four.
 #define SML_CH 16    // columns per LDS chunk
 #define SML_LDR 256  // rows of a staged column
+template <int RPL>  // rows of b per lane of the solving wave: m <= 64 RPL
 __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__restrict__ A, int64_t lda, int m, int n,
                                                             const double *__restrict__ alpha, const double *bin, double *bout,
                                                             double *xout, double *__restrict__ Awork) {
@@ -307,10 +326,10 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
     }
     if (t >= 64 && t < 64 + SML_CH) als[c & 1][t - 64] = (SML_CH * c + t - 64 < n) ? alpha[SML_CH * c + t - 64] : 1.0;
   };
-  dhqr_dd b[4];
+  dhqr_dd b[RPL];
   if (w == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RPL; ++r) {
       b[r].hi = (l + 64 * r < m) ? bin[l + 64 * r] : 0.0;
       b[r].lo = 0.0;
     }
@@ -325,10 +344,10 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
 #pragma unroll 4
       for (int jj = 0; jj < SML_CH; ++jj) {
         const int j = SML_CH * c + jj;  // (columns >= n are staged as zeros: no-ops)
-        double v[4];
+        double v[RPL];
         dhqr_dd p = {0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RPL; ++r) {
           const int row = l + 64 * r;
           v[r] = row >= j ? B[jj][row] : 0.0;  // rows < j of a factored column hold R
           dd_add_prod(p, v[r], b[r].hi);       // src:217: sum v_i b_i, b_i = hi + lo
@@ -337,7 +356,7 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
         const dhqr_dd sd = wave_sum_dd(p);
         const double s = sd.hi + sd.lo;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {  // src:218-220: b_i -= v_i s
+        for (int r = 0; r < RPL; ++r) {  // src:218-220: b_i -= v_i s
           dd_add_prod(b[r], -s, v[r]);
           dd_renorm(b[r]);
         }
@@ -362,7 +381,7 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
           const int rj = j >> 6;
           double bj = 0.0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
+          for (int r = 0; r < RPL; ++r)
             if (r == rj) bj = b[r].hi + b[r].lo;
           // src:251 b_j / alpha_j: reciprocal (computed for the whole chunk before the loop, off the chain) times b_j and one
           // correction step -- the quotient to the last bit in all but rare half-way cases, three dependent operations
@@ -371,7 +390,7 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
           double xj = bq * ri;
           xj = fma(fma(-aj, xj, bq), ri, xj);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
+          for (int r = 0; r < RPL; ++r) {
             const int row = l + 64 * r;
             if (row == j) {
               b[r].hi = xj;
@@ -389,7 +408,7 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
   }
   if (w == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RPL; ++r) {
       const int row = l + 64 * r;
       const double val = b[r].hi + b[r].lo;
       if (row < m) bout[row] = val;
