@@ -1752,10 +1752,10 @@ static int32_t solve_pipelined(dhqr_ctx *c, const double *dA, int64_t m, int64_t
       const unsigned grid = (unsigned)(nsl - rfirst / sl);
       if (VEC == 2)
         hipLaunchKernelGGL((k_qtb_step<2>), dim3(grid), dim3(256), 0, c->stream, dA, lda, m, n, k, np, sl, db,
-                           (const double *)c->sv_T.p, Tt_kept, (const int *)kept, wbuf, ypart, counter, err);
+                           (const double *)c->sv_T.p, Tt_kept, (const int *)kept, wbuf, ypart, counter, err, (int64_t)0, (double *)nullptr);
       else
         hipLaunchKernelGGL((k_qtb_step<1>), dim3(grid), dim3(256), 0, c->stream, dA, lda, m, n, k, np, sl, db,
-                           (const double *)c->sv_T.p, Tt_kept, (const int *)kept, wbuf, ypart, counter, err);
+                           (const double *)c->sv_T.p, Tt_kept, (const int *)kept, wbuf, ypart, counter, err, (int64_t)0, (double *)nullptr);
     }
   }
   // ---- back substitution (src:244-282): one pipelined launch

@@ -808,10 +808,10 @@ static int32_t cs_solve_pairs(const CsProblem &pr, double *db, double *du) {
           const unsigned grid = (unsigned)(nsl - rfirst / sl);
           if (VEC == 2)
             hipLaunchKernelGGL((k_qtb_step<2>), dim3(grid), dim3(256), 0, c->stream, sub, lda, mq, nq, k, npq, sl, db + c0, Tt, Tt,
-                               (const int *)zero, wbuf, ypart, counters + 3 * li, err);
+                               (const int *)zero, wbuf, ypart, counters + 3 * li, err, (int64_t)0, (double *)nullptr);
           else
             hipLaunchKernelGGL((k_qtb_step<1>), dim3(grid), dim3(256), 0, c->stream, sub, lda, mq, nq, k, npq, sl, db + c0, Tt, Tt,
-                               (const int *)zero, wbuf, ypart, counters + 3 * li, err);
+                               (const int *)zero, wbuf, ypart, counters + 3 * li, err, (int64_t)0, (double *)nullptr);
         }
         LAUNCHCHECK();
         ++li;

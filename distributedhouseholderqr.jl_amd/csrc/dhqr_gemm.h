@@ -85,7 +85,7 @@ __device__ __forceinline__ void gemm_lds_landed() {
 // 64 x 64; NBV=64 -> 4 x 1 waves of 32 cols x 64 p; NBV=32 -> 4 x 1 waves of 32 cols x 32 p.
 // MASK (the batched Gram products of the solve, k_gemm_tn_gram_batch): V == C is a factored panel IN PLACE, whose top
 // block still holds R above the diagonal -- element (row r of the panel, column p) counts as 0 where r < p.
-template <int VEC, int NCS, int NBV, bool MASK>
+template <int VEC, int NCS, int NBV, int MASK>  // MASK: 0 none, 1 panel in place (triangle + no padding columns), 2 no padding columns only
 __device__ __forceinline__ void gemm_tn_body(const double *__restrict__ V, int64_t ldv,
                                              const double *__restrict__ C, int64_t ldc,
                                              int ncsplit, int64_t csplit_stride,
@@ -128,7 +128,7 @@ __device__ __forceinline__ void gemm_tn_body(const double *__restrict__ V, int64
     const int q = t + i * 256;
     const int col = q >> 3;
     okc[i] = col < ncv;
-    offv[i] = (uint32_t)(((MASK && !okc[i]) ? 0 : col) * ldv);  // MASK: V has no padding columns beyond ncols either
+    offv[i] = (uint32_t)((((MASK != 0) && !okc[i]) ? 0 : col) * ldv);  // MASK: V has no padding columns beyond ncols either
     offc[i] = (uint32_t)((okc[i] ? col : 0) * ldc);
   }
   // Software pipeline: load_tile only ISSUES the global loads of the next K-tile (raw values stay
@@ -188,11 +188,13 @@ __device__ __forceinline__ void gemm_tn_body(const double *__restrict__ V, int64
       if (!ok0) { x.x = 0.0; y.x = 0.0; }
       if (!ok1) { x.y = 0.0; y.y = 0.0; }
       if (!okc[i]) y = make_double2(0.0, 0.0);
-      if constexpr (MASK) {  // V == C, panel in place: zero above the diagonal of the top block
+      if constexpr (MASK != 0) {  // V == C, panel in place: no padding columns ...
         if (!okc[i]) x = make_double2(0.0, 0.0);
-        const int64_t r0 = rbeg + (int64_t)kt * G_KT + 2 * rp;
-        if (r0 < col) { x.x = 0.0; y.x = 0.0; }
-        if (r0 + 1 < col) { x.y = 0.0; y.y = 0.0; }
+        if constexpr (MASK == 1) {  // ... and zero above the diagonal of the top block
+          const int64_t r0 = rbeg + (int64_t)kt * G_KT + 2 * rp;
+          if (r0 < col) { x.x = 0.0; y.x = 0.0; }
+          if (r0 + 1 < col) { x.y = 0.0; y.y = 0.0; }
+        }
       }
       if (i < NVL) *reinterpret_cast<double2 *>(&Vs[buf][col * G_LDK + 2 * rp]) = x;
       *reinterpret_cast<double2 *>(&Cs[buf][col * G_LDK + 2 * rp]) = y;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
                                                     int64_t rows, int64_t ncols, int64_t rps,
                                                     double *__restrict__ out, int64_t ldo,
                                                     int64_t osplit_stride) {
-  gemm_tn_body<VEC, NCS, NBV, false>(V, ldv, C, ldc, ncsplit, csplit_stride, rows, ncols, rps, out, ldo, osplit_stride,
+  gemm_tn_body<VEC, NCS, NBV, 0>(V, ldv, C, ldc, ncsplit, csplit_stride, rows, ncols, rps, out, ldo, osplit_stride,
                                      blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -256,7 +258,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const double *__restrict__ V
 // launch, V_k read in place (MASK).  unit_first[k] = index of panel k's first (panel, rps-row slab) unit, unit_first[np] =
 // number of units = gridDim.x; unit u of panel k writes its 128 x 128 partial sum to out + u * 128 * 128 (summed in slab
 // order by k_qtb_sum_gram).  A panel is rows [128 k, m) x columns [128 k, 128 k + w_k) of A.
-template <int VEC>
+// MASKED = false (r6, the row split at P > 1): a rank whose rows all lie BELOW the panels' top blocks -- every panel is the
+// rank's whole row range (rows [0, m) of A, columns of panel k), nothing to mask.
+template <int VEC, bool MASKED = true>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_gram_batch(const double *__restrict__ A, int64_t lda, int64_t m,
                                                                int64_t n, int64_t rps, const int *__restrict__ unit_first,
                                                                int np, double *__restrict__ out, const int *__restrict__ skip) {
@@ -275,11 +279,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_gram_batch(const double *__r
   const int k = kk_s;
   const int64_t c0 = (int64_t)k * DHQR_NBV;
   const int64_t w = (n - c0 < DHQR_NBV) ? n - c0 : DHQR_NBV;
-  const double *P = A + c0 + c0 * lda;
+  const double *P = MASKED ? A + c0 + c0 * lda : A + c0 * lda;
   const unsigned y = blockIdx.x - (unsigned)unit_first[k];
-  gemm_tn_body<VEC, 1, DHQR_NBV, true>(P, lda, P, lda, 1, (int64_t)0, m - c0, w, rps,
-                                       out + (int64_t)blockIdx.x * (DHQR_NBV * DHQR_NBV) - (int64_t)y * (DHQR_NBV * DHQR_NBV),
-                                       (int64_t)DHQR_NBV, (int64_t)(DHQR_NBV * DHQR_NBV), 0u, y, 0u);
+  gemm_tn_body<VEC, 1, DHQR_NBV, (MASKED ? 1 : 2)>(P, lda, P, lda, 1, (int64_t)0, MASKED ? m - c0 : m, w, rps,
+                                         out + (int64_t)blockIdx.x * (DHQR_NBV * DHQR_NBV) - (int64_t)y * (DHQR_NBV * DHQR_NBV),
+                                         (int64_t)DHQR_NBV, (int64_t)(DHQR_NBV * DHQR_NBV), 0u, y, 0u);
 }
 
 // -------------------------------------------------------------------------------------------

@@ -161,10 +161,12 @@ __device__ __forceinline__ void qtb_stage_t(const double *__restrict__ Tt, qtb_l
 // (a) k >= 1: b -= V_{k-1} w_{k-1} (w in L.w_s), (b) k < np: this slab's partial dots of panel k -> yrow[0..128).
 // 256 threads: wave g takes the panel's columns 32 g .. 32 g + 31, lane l the rows r0 + VEC l .. of every 64 VEC-row
 // sub-slab.  VEC = 2: 16-byte loads (lda, m even, 16-byte aligned A, b).
+// goff (r6, the row split at P > 1): the GLOBAL row of local row 0 -- A, b and every row index here are local to a rank that
+// holds rows [goff, goff + m); a panel's first row (and the triangle of R above its diagonal) are global quantities.
 template <int VEC>
 __device__ __forceinline__ void qtb_slab_phase(const double *__restrict__ A, int64_t lda, int64_t m, int64_t n, int k, int np,
                                                int64_t r_lo, int64_t r_hi, double *__restrict__ b, qtb_lds<VEC> &L,
-                                               double *__restrict__ yrow, int &par) {
+                                               double *__restrict__ yrow, int &par, int64_t goff = 0) {
   constexpr int SS = 64 * VEC;
   double (&w_s)[QTB_NB] = L.w_s;
   double (&red)[2][4][SS] = L.red;
@@ -172,6 +174,7 @@ __device__ __forceinline__ void qtb_slab_phase(const double *__restrict__ A, int
   const bool upd = k >= 1, dot = k < np;
   const int64_t cu = (int64_t)(k - 1) * QTB_NB;  // first column (= first row) of the panel that updates
   const int64_t cd = (int64_t)k * QTB_NB;        // ... of the panel whose dot products are formed
+  const int64_t ru = cu - goff, rd = cd - goff;  // the same as LOCAL row numbers (negative: the panel starts above this rank's rows)
   const int wu = upd ? (int)((n - cu < QTB_NB) ? n - cu : QTB_NB) : 0;
   const int wd = dot ? (int)((n - cd < QTB_NB) ? n - cd : QTB_NB) : 0;
   double yacc[32];
@@ -197,7 +200,7 @@ __device__ __forceinline__ void qtb_slab_phase(const double *__restrict__ A, int
       for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
       const int jn = (wu - g * 32 < 32) ? wu - g * 32 : 32;  // this wave's columns inside the panel (wave-uniform)
       const double *Ac = A + ra + (cu + (jn > 0 ? g * 32 : 0)) * lda;  // (a wave beyond a partial panel reads column cu, masked)
-      if (!tail && r0 >= cu + QTB_NB && jn == 32) {          // below the top block: no masks
+      if (!tail && r0 >= ru + QTB_NB && jn == 32) {          // below the top block: no masks
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           double v[16][VEC];
@@ -235,7 +238,7 @@ __device__ __forceinline__ void qtb_slab_phase(const double *__restrict__ A, int
             const double wj = w_s[j];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-              const bool ok = (h * 16 + q < jn) && (r + e < m) && (r + e >= cu + j);
+              const bool ok = (h * 16 + q < jn) && (r + e < m) && (r + e >= ru + j);
               acc[e] = fma(ok ? v[q][e] : 0.0, wj, acc[e]);
             }
           }
@@ -256,10 +259,10 @@ __device__ __forceinline__ void qtb_slab_phase(const double *__restrict__ A, int
           if (r + e < m) b[r + e] = bv[e];
       }
     }
-    if (dot && r0 + SS > cd) {
+    if (dot && r0 + SS > rd) {
       const int jn = (wd - g * 32 < 32) ? wd - g * 32 : 32;
       const double *Ac = A + ra + (cd + (jn > 0 ? g * 32 : 0)) * lda;
-      if (!tail && r0 >= cd + QTB_NB && jn == 32) {
+      if (!tail && r0 >= rd + QTB_NB && jn == 32) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           double v[16][VEC];
@@ -292,7 +295,7 @@ __device__ __forceinline__ void qtb_slab_phase(const double *__restrict__ A, int
             const int j = g * 32 + h * 16 + q;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-              const bool ok = (h * 16 + q < jn) && (r + e < m) && (r + e >= cd + j);
+              const bool ok = (h * 16 + q < jn) && (r + e < m) && (r + e >= rd + j);
               yacc[h * 16 + q] = fma(ok ? v[q][e] : 0.0, bv[e], yacc[h * 16 + q]);
             }
           }
@@ -309,7 +312,7 @@ __device__ __forceinline__ void qtb_slab_phase(const double *__restrict__ A, int
 // halves, then the halves), w_k = T_k' y_k out of L.Tp -> wk[0..128).  All 256 threads; ypart rows are 128 doubles.
 template <int VEC>
 __device__ __forceinline__ void qtb_reduce_phase(const double *__restrict__ ypart, int ns, qtb_lds<VEC> &L,
-                                                 double *__restrict__ wk) {
+                                                 double *__restrict__ wk, bool sum_only = false) {
   const int t = threadIdx.x, i = t & 127, h = t >> 7;
   {
     double s = 0.0;
@@ -324,6 +327,10 @@ __device__ __forceinline__ void qtb_reduce_phase(const double *__restrict__ ypar
   }
   __syncthreads();
   if (t < QTB_NB) L.y_s[0][t] += L.y_s[1][t];
+  if (sum_only) {  // (uniform) the dots leave for an all-reduce: no T product here
+    if (t < QTB_NB) wk[t] = L.y_s[0][t];
+    return;
+  }
   __syncthreads();
   // thread (i, h): columns j = h, h + 2, ... <= i of row i (src:218-221 for the panel's 128 reflectors at once)
   double a0 = 0.0;
@@ -347,20 +354,25 @@ __global__ __launch_bounds__(256) void k_qtb_step(const double *__restrict__ A, 
                                                   const double *__restrict__ Tt_new, const double *__restrict__ Tt_kept,
                                                   const int *__restrict__ use_kept, double *__restrict__ wbuf,
                                                   double *__restrict__ ypart, int *__restrict__ counter,
-                                                  int *__restrict__ err) {
+                                                  int *__restrict__ err, int64_t goff = 0, double *__restrict__ ydist = nullptr) {
+  // goff / ydist (r6, the row split at P > 1, rs_solve): this rank holds rows [goff, goff + m) of the matrix; the reducer
+  // leaves the sum of the LOCAL slabs' partial dots in ydist[k] -- the ranks all-reduce it and k_qtb_tw forms w_k -- instead
+  // of applying T_k' itself.  wbuf / ypart / counter as below.
   __shared__ qtb_lds<VEC> L;
   const int t = threadIdx.x;
+  const bool dist = ydist != nullptr;
   const double *Tt_all = *use_kept ? Tt_kept : Tt_new;
   const bool dot = k < np, reducer = dot && blockIdx.x == gridDim.x - 1;
-  const int64_t rfirst = qtb_rfirst(k);
+  const int64_t rglob = qtb_rfirst(k);
+  const int64_t rfirst = rglob > goff ? rglob - goff : 0;  // first active LOCAL row
   const int64_t slab = rfirst / sl + blockIdx.x;
   const int64_t r_lo = (slab * sl > rfirst) ? slab * sl : rfirst;
   const int64_t r_hi = ((slab + 1) * sl < m) ? (slab + 1) * sl : m;
-  if (reducer) qtb_stage_t<VEC>(Tt_all + (int64_t)k * QTB_NB2, L);
+  if (reducer && !dist) qtb_stage_t<VEC>(Tt_all + (int64_t)k * QTB_NB2, L);
   if (k >= 1 && t < QTB_NB) L.w_s[t] = wbuf[(int64_t)(k - 1) * QTB_NB + t];
   __syncthreads();
   int par = 0;
-  qtb_slab_phase<VEC>(A, lda, m, n, k, np, r_lo, r_hi, b, L, ypart + (int64_t)blockIdx.x * QTB_NB, par);
+  qtb_slab_phase<VEC>(A, lda, m, n, k, np, r_lo, r_hi, b, L, ypart + (int64_t)blockIdx.x * QTB_NB, par, goff);
   if (!dot) return;
   __syncthreads();  // every wave's partial dots are stored (the barrier waits for the stores)
   if (!reducer) {
@@ -369,7 +381,28 @@ __global__ __launch_bounds__(256) void k_qtb_step(const double *__restrict__ A, 
   }
   if (t == 0) qtb_wait_ge(counter + k, (int)gridDim.x - 1, err);
   __syncthreads();
-  qtb_reduce_phase<VEC>(ypart, (int)gridDim.x, L, wbuf + (int64_t)k * QTB_NB);
+  qtb_reduce_phase<VEC>(ypart, (int)gridDim.x, L, dist ? ydist + (int64_t)k * QTB_NB : wbuf + (int64_t)k * QTB_NB, dist);
+}
+
+// w = T' y for one panel (T' dense, column-major, lower triangular): what the reducer of k_qtb_step does when the dots
+// need no all-reduce in between.  One workgroup of 256 threads: thread (i, h) takes the columns j = h, h + 2, ... <= i of row i.
+__global__ __launch_bounds__(256) void k_qtb_tw(const double *__restrict__ Tt, const double *__restrict__ y,
+                                                double *__restrict__ w) {
+  __shared__ double ys[QTB_NB], half[QTB_NB];
+  const int t = threadIdx.x, i = t & 127, h = t >> 7;
+  if (t < QTB_NB) ys[t] = y[t];
+  __syncthreads();
+  double a0 = 0.0, a1 = 0.0;
+  int j = h;
+  for (; j + 2 <= i; j += 4) {
+    a0 = fma(Tt[i + j * QTB_NB], ys[j], a0);
+    a1 = fma(Tt[i + (j + 2) * QTB_NB], ys[j + 2], a1);
+  }
+  for (; j <= i; j += 2) a0 = fma(Tt[i + j * QTB_NB], ys[j], a0);
+  a0 += a1;
+  if (h == 1) half[i] = a0;
+  __syncthreads();
+  if (h == 0) w[i] = a0 + half[i];
 }
 
 // ---- the same panel steps in ONE launch ----------------------------------------------------------------------------------

@@ -784,6 +784,113 @@ static int32_t rs_residual(const RsProblem &pr, uint64_t seed, double *dB, doubl
   return DHQR_OK;
 }
 
+// r6: b <- Q'b (src:215-242) of the row split at P > 1 on the kernels of dhqr_qtb.h.  The per-panel form below re-packs V,
+// all-reduces a 128 x 128 Gram matrix, builds T and pushes ONE right-hand side through the 128-column MFMA tiles: two
+// collectives and ~8 launches per panel.  Here:
+//   pre-pass (independent of b)  every rank's batched Gram products of ALL panels on its own rows, V read in place -- the
+//     panels whose top block it holds with the triangle of R masked (rows addressed globally through a shifted base
+//     pointer), the panels that start above its rows unmasked over its whole row range -- then ONE all-reduce of the np
+//     Gram matrices and the batched T' = (I + striu(S))^{-T};
+//   per panel step               k_qtb_step on the local rows (update by panel k - 1, partial dots of panel k; `goff` = the
+//     rank's first global row), ONE all-reduce of the 128 dots -- the north star's "all-reduce of the cross-partition
+//     partial dots" -- and w_k = T_k' y_k by k_qtb_tw on every rank.
+static int32_t rs_qtb_pipelined(const RsProblem &pr, double *db) {
+  dhqr_ctx *c = pr.c;
+  dhqr_comm *cm = pr.cm;
+  const int64_t NB = DHQR_NBV, n = pr.n, R0 = pr.row0, ml = pr.mloc, lda = pr.lda;
+  const int np = (int)((n + NB - 1) / NB);
+  // panels: k < kA start above this rank's rows (unmasked, all local rows); kA <= k < kB have their top block here; the rest
+  // lie below
+  const int kA = (int)std::min<int64_t>(np, (R0 + NB - 1) / NB), kB = (int)std::min<int64_t>(np, (R0 + ml + NB - 1) / NB);
+  int64_t total = 0;
+  for (int k = 0; k < kB; ++k) total += (k < kA) ? ml : R0 + ml - (int64_t)k * NB;
+  int64_t rps = ((total / 1024 + 15) / 16) * 16;
+  rps = std::min<int64_t>(std::max<int64_t>(rps, 256), 4096);
+  std::vector<int> tab((size_t)3 * (np + 1), 0);  // merged | unmasked launch | masked launch
+  int *merged = tab.data(), *t1 = merged + (np + 1), *t2 = t1 + (np + 1);
+  for (int k = 0; k < np; ++k) {
+    const int64_t rows = (ml <= 0 || k >= kB) ? 0 : ((k < kA) ? ml : R0 + ml - (int64_t)k * NB);
+    merged[k + 1] = merged[k] + (int)((rows + rps - 1) / rps);
+  }
+  const int U2 = merged[kA], U = merged[np];  // units of the unmasked launch (they come first), of both
+  for (int k = 0; k <= np; ++k) {
+    t1[k] = std::min(merged[k], U2);
+    t2[k] = std::max(merged[k] - U2, 0);
+  }
+  const bool vecA = (lda % 2 == 0) && (ml % 2 == 0) && (R0 % 2 == 0) && aligned16(pr.A);
+  const int VEC = (c->qtb_vec == 1 || !(vecA && aligned16(db))) ? 1 : (c->qtb_vec == 2 ? 2 : (ml >= 16384 ? 2 : 1));
+  const int64_t SS = 64 * VEC, maxsl = std::max<int64_t>(8, std::min<int64_t>(c->ncu, 256));
+  const int64_t sl = SS * std::max<int64_t>(1, (ml + SS * maxsl - 1) / (SS * maxsl)), nsl = (ml + sl - 1) / sl;
+  CHECK(ensure(c, c->sv_T, (size_t)np * QTB_NB2));
+  CHECK(ensure(c, c->sv_S, (size_t)np * QTB_NB2));
+  CHECK(ensure(c, c->sv_part, (size_t)std::max(U, 1) * QTB_NB2));
+  const size_t n_ypart = (size_t)std::max<int64_t>(nsl + 2, 8) * QTB_NB, n_w = (size_t)(np + 1) * QTB_NB, n_y = (size_t)np * QTB_NB;
+  const size_t n_ints = tab.size() + (size_t)(np + 1) + 4;
+  CHECK(ensure(c, c->sv_small, n_ypart + n_w + n_y + (n_ints + 1) / 2 + 16));
+  double *ypart = c->sv_small.p, *wbuf = ypart + n_ypart, *ydist = wbuf + n_w;
+  int *ints = reinterpret_cast<int *>(ydist + n_y);
+  int *tab_dev = ints, *counters = tab_dev + tab.size(), *zero = counters + (np + 1);
+  HIPCHECK(hipMemsetAsync(ydist, 0, (n_y + (n_ints + 1) / 2 + 8) * sizeof(double), c->stream));  // the dots of absent ranks, counters, flags
+  HIPCHECK(hipMemcpyAsync(tab_dev, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));  // (the table is a host vector)
+  const int *dm = tab_dev, *d1 = tab_dev + (np + 1), *d2 = d1 + (np + 1);
+  int *err = c->zflags + DHQR_PIPE_ERR_OFFSET;
+  auto sync_local = [&]() -> int32_t {
+    if (cm->kind == COMM_LOCAL) {
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      CHECK(comm_host_barrier(cm));
+    }
+    return DHQR_OK;
+  };
+  // ---- pre-pass
+  if (U2 > 0) {  // panels that start above this rank's rows
+    if (vecA)
+      hipLaunchKernelGGL((k_gemm_tn_gram_batch<2, false>), dim3((unsigned)U2), dim3(256), 0, c->stream, (const double *)pr.A, lda, ml, n,
+                         rps, d1, np, c->sv_part.p, (const int *)zero);
+    else
+      hipLaunchKernelGGL((k_gemm_tn_gram_batch<1, false>), dim3((unsigned)U2), dim3(256), 0, c->stream, (const double *)pr.A, lda, ml, n,
+                         rps, d1, np, c->sv_part.p, (const int *)zero);
+  }
+  if (U - U2 > 0) {  // panels whose top block lives here: global row numbers through the shifted base
+    const double *Ag = pr.A - R0;
+    if (vecA)
+      hipLaunchKernelGGL((k_gemm_tn_gram_batch<2, true>), dim3((unsigned)(U - U2)), dim3(256), 0, c->stream, Ag, lda, R0 + ml, n, rps,
+                         d2, np, c->sv_part.p + (size_t)U2 * QTB_NB2, (const int *)zero);
+    else
+      hipLaunchKernelGGL((k_gemm_tn_gram_batch<1, true>), dim3((unsigned)(U - U2)), dim3(256), 0, c->stream, Ag, lda, R0 + ml, n, rps,
+                         d2, np, c->sv_part.p + (size_t)U2 * QTB_NB2, (const int *)zero);
+  }
+  hipLaunchKernelGGL(k_qtb_sum_gram, dim3((unsigned)np, 16), dim3(256), 0, c->stream, (const double *)c->sv_part.p, dm, n, c->sv_S.p,
+                     (const int *)zero);
+  LAUNCHCHECK();
+  CHECK(comm_allreduce_sum(cm, c->sv_S.p, (int64_t)np * QTB_NB2, c->stream));
+  CHECK(sync_local());
+  hipLaunchKernelGGL(k_build_t_batch, dim3((unsigned)np), dim3(1024), 0, c->stream, (const double *)c->sv_S.p, n, c->sv_T.p,
+                     (const int *)zero);
+  // ---- panel steps
+  for (int k = 0; k <= np; ++k) {
+    const int64_t rglob = (int64_t)(k >= 1 ? k - 1 : 0) * NB, rfl = std::max<int64_t>(0, rglob - R0);
+    if (ml > 0 && rfl < ml) {
+      const unsigned grid = (unsigned)(nsl - rfl / sl);
+      if (VEC == 2)
+        hipLaunchKernelGGL((k_qtb_step<2>), dim3(grid), dim3(256), 0, c->stream, (const double *)pr.A, lda, ml, n, k, np, sl, db,
+                           (const double *)c->sv_T.p, (const double *)c->sv_T.p, (const int *)zero, wbuf, ypart, counters, err, R0, ydist);
+      else
+        hipLaunchKernelGGL((k_qtb_step<1>), dim3(grid), dim3(256), 0, c->stream, (const double *)pr.A, lda, ml, n, k, np, sl, db,
+                           (const double *)c->sv_T.p, (const double *)c->sv_T.p, (const int *)zero, wbuf, ypart, counters, err, R0, ydist);
+      LAUNCHCHECK();
+    }
+    if (k < np) {
+      CHECK(comm_allreduce_sum(cm, ydist + (size_t)k * QTB_NB, QTB_NB, c->stream));
+      CHECK(sync_local());
+      hipLaunchKernelGGL(k_qtb_tw, dim3(1), dim3(256), 0, c->stream, (const double *)(c->sv_T.p + (size_t)k * QTB_NB2),
+                         (const double *)(ydist + (size_t)k * QTB_NB), wbuf + (size_t)k * QTB_NB);
+      LAUNCHCHECK();
+    }
+  }
+  return DHQR_OK;
+}
+
 // `H \ b` (src:317-321) for the row split: db = this rank's rows of b (mloc, overwritten); dx (n) <- x on every rank.
 // Q'b (src:215-242): per panel the partial dots V_r' b_r are all-reduced (a 128-vector), then b_r -= V_r (T' w)
 // locally.  The back substitution (src:244-254) needs R = the top n rows: each 128-row block is solved by the rank
@@ -819,6 +926,9 @@ static int32_t rs_solve(const RsProblem &pr, double *db, double *dx) {
     return DHQR_OK;
   };
   auto body = [&]() -> int32_t {
+    if (cm && c->solve_pipe) {
+      CHECK(rs_qtb_pipelined(pr, db));  // r6: Q'b on the kernels of dhqr_qtb.h
+    } else {
     for (int64_t k = 0; k < K; ++k) {
       const int64_t c0 = k * NB, wcols = std::min<int64_t>(NB, n - c0);
       int64_t off, rows;
@@ -829,6 +939,7 @@ static int32_t rs_solve(const RsProblem &pr, double *db, double *dx) {
       launch_build_t(c, w.S, (int)wcols, w.T, w.Tt);
       CHECK(rs_vtc_allreduce(pr, pr.cm, w.Vw, w.ldv, db + off, ldb, rows, 1));
       CHECK(rs_apply_w(pr, w.Vw, w.ldv, w.T, db + off, ldb, rows, 1, false));
+    }
     }
     // back substitution, block by block from the bottom of R: x_blk solved by the owner of rows [c0, c0 + w)
     HIPCHECK(hipMemsetAsync(dx, 0, (size_t)n * sizeof(double), c->stream));
