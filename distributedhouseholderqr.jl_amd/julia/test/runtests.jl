@@ -1,6 +1,7 @@
 # Acceptance checks of the MI355X drop-in, restated from what the reference's tests ASSERT
 # (/root/reference/test/runtests.jl:42-63,71-82 and test/partialdot.jl:12-20) without its benchmarking,
-# profiling and thread-pinning dependencies.  Usage (one GPU per worker for the DArray part):
+# profiling and thread-pinning dependencies.  Usage (the DArray part binds worker i to GPU i-1 over RCCL when every worker has a GPU
+# of its own, and lets the workers share the GPUs through the callback transport otherwise, e.g. 2 workers on a one-GPU box):
 #   cd distributedhouseholderqr.jl_amd/julia && julia --project=@. test/runtests.jl [nworkers]
 # NOT executed in the build image (no Julia); the same checks run through the C ABI in tests/test_gpu_parity.py
 # (test_reference_acceptance_*) and tests/test_gpu_complex.py (test_reference_distributed_acceptance).
