@@ -1400,7 +1400,14 @@ int32_t dhqr_trim(dhqr_ctx *c) {
   ENTER(c);
   HIPCHECK(hipStreamSynchronize(c->stream));
   HIPCHECK(hipDeviceSynchronize());  // the lane, side, comm and copy streams of this context
-  Buf *bs[] = {&c->host_mat, &c->sv_T, &c->sv_S, &c->sv_part, &c->sv_small, &c->tc_T, &c->tc_alpha, &c->vts, &c->tsq, &c->zsolve_lo};
+  Buf *bs[] = {&c->host_mat, &c->sv_T, &c->sv_S, &c->sv_part, &c->sv_small, &c->tc_T, &c->tc_alpha, &c->vts, &c->tsq, &c->zsolve_lo,
+               &c->small_dev, &c->sv_bkp};
+  c->retry.valid = false;
+  if (c->small_pin) {
+    (void)hipHostFree(c->small_pin);
+    c->small_pin = nullptr;
+    c->small_pin_cap = 0;
+  }
   for (Buf *b : bs)
     if (b->p) {
       (void)hipFree(b->p);
