@@ -1103,13 +1103,14 @@ static int32_t small_qr_launch(dhqr_ctx *c, int fit, const double *Asrc, int64_t
 }
 static int32_t small_ldiv_launch(dhqr_ctx *c, const double *A, int64_t lda, int64_t m, int64_t n, const double *alpha,
                                  const double *bin, double *bout, double *xout, double *Awork) {
-#define DHQR_SML(RPL_)                                                                                                     \
-  hipLaunchKernelGGL((k_small_ldiv<RPL_>), dim3(1), dim3(SML_THREADS), 0, c->stream, A, lda, (int)m, (int)n, alpha, bin, bout, \
-                     xout, Awork)
-  if (m <= 64) DHQR_SML(1);
-  else if (m <= 128) DHQR_SML(2);
-  else if (m <= 192) DHQR_SML(3);
-  else DHQR_SML(4);
+#define DHQR_SML(RPL_, CH_, AW_)                                                                                            \
+  hipLaunchKernelGGL((k_small_ldiv<RPL_, CH_>), dim3(1), dim3(SML_THREADS), 0, c->stream, A, lda, (int)m, (int)n, alpha, bin, \
+                     bout, xout, AW_)
+  // (<= 128 rows: 64-column chunks straight from the caller's memory, no device copy of the factor)
+  if (m <= 64) DHQR_SML(1, 64, (double *)nullptr);
+  else if (m <= 128) DHQR_SML(2, 64, (double *)nullptr);
+  else if (m <= 192) DHQR_SML(3, 16, Awork);
+  else DHQR_SML(4, 16, Awork);
 #undef DHQR_SML
   LAUNCHCHECK();
   return DHQR_OK;

@@ -42,36 +42,31 @@ __device__ __forceinline__ double row16_sum(double v) {
   v += dpp_f64<0x128, 0xf>(v);  // row_ror:8
   return v;
 }
-// Cascaded (unnormalised) double-double sums: hi carries the running sum, lo collects the exact rounding errors of every
-// addition (TwoSum) and whatever low parts come in; hi + lo is the sum as if accumulated in twice the working precision
-// (Ogita, Rump, Oishi: Sum2).  Unlike dd_add there is no renormalisation, so the DEPENDENT chain of a reduction step is one
-// DPP move and one addition; the error terms are side chains the FP64 pipe fills its idle slots with.  Both partners of a
-// symmetric exchange compute identical values (s and its exact error are symmetric in the operands).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ dhqr_dd dd_cascade_step(const dhqr_dd v) {
-  const double ohi = dpp_f64<CTRL, ROW_MASK>(v.hi), olo = dpp_f64<CTRL, ROW_MASK>(v.lo);
-  dhqr_dd r;
-  double e;
-  dd_two_sum(v.hi, ohi, r.hi, e);
-  r.lo = (v.lo + olo) + e;
-  return r;
-}
-__device__ __forceinline__ dhqr_dd row16_sum_dd(dhqr_dd v) {  // every lane of a 16-lane row ends with the row's total
-  v = dd_cascade_step<0xB1, 0xf>(v);
-  v = dd_cascade_step<0x4E, 0xf>(v);
-  v = dd_cascade_step<0x124, 0xf>(v);
-  v = dd_cascade_step<0x128, 0xf>(v);
-  return v;
-}
 __device__ __forceinline__ double smq_readlane(double v, int lane) {  // lane: wave-uniform
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
-// wave sum of a double-double (lane 63's total, broadcast): the DPP pattern of wave_sum_dpp (dhqr_common.h)
-__device__ __forceinline__ dhqr_dd wave_sum_dd(dhqr_dd v) {
-  v = row16_sum_dd(v);
-  v = dd_cascade_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3 (lanes without a source add zero)
-  v = dd_cascade_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+// Wave sum of a double-double (lane 63's total, broadcast; the DPP pattern of wave_sum_dpp, dhqr_common.h) with the TREE in
+// plain double, separately for the high and the low parts.  What is lost is the rounding of six additions of the high parts
+// (<= 3 eps of the sum) -- the products and the per-lane sums stay exact to twice the working precision.  Used for the dot
+// products of the solve (rounded to double anyway) and for the reflector norms: a cascaded tree (TwoSum per step, 14
+// instead of 6 instructions) was measured and bought nothing -- the acceptance statistic over 16-24 draws at 110 x 100:
+// median 0.6-0.9 x LAPACK's either way (the restated reference: 1.4-1.7 x, up to 11.6 x) -- while both kernels are bound by
+// instruction issue.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ dhqr_dd dd_plain_step(const dhqr_dd v) {
+  dhqr_dd r;
+  r.hi = v.hi + dpp_f64<CTRL, ROW_MASK>(v.hi);
+  r.lo = v.lo + dpp_f64<CTRL, ROW_MASK>(v.lo);
+  return r;
+}
+__device__ __forceinline__ dhqr_dd wave_sum_dd_plain(dhqr_dd v) {
+  v = dd_plain_step<0xB1, 0xf>(v);
+  v = dd_plain_step<0x4E, 0xf>(v);
+  v = dd_plain_step<0x124, 0xf>(v);
+  v = dd_plain_step<0x128, 0xf>(v);
+  v = dd_plain_step<0x142, 0xa>(v);
+  v = dd_plain_step<0x143, 0xc>(v);
   dhqr_dd r;
   r.hi = smq_readlane(v.hi, 63);
   r.lo = smq_readlane(v.lo, 63);
@@ -83,7 +78,9 @@ __device__ __forceinline__ dhqr_dd wave_sum_dd(dhqr_dd v) {
 // independent dot products of a block keep the FP64 pipe busy while a DPP reduction's dependent steps are in flight --
 // and ONE uniform branch per block skips the blocks that are finished.
 // qskip: a group this wave has already updated (the look-ahead column's), masked out through its coefficient.
-#define SMQ_GB 4
+#ifndef SMQ_GB
+#define SMQ_GB 1  // (2 and 4 measured: with two waves per SIMD hiding each other's latencies the finer skipping wins)
+#endif
 template <int NR, int NQ, int R0>
 __device__ __forceinline__ void smq_pass(double (&a)[NQ][NR], const double (&vr)[NR], int j, int cbase, int qskip) {
 #pragma unroll
@@ -166,7 +163,10 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
       dd_add_sq(acc, l + 64 * r >= jn ? x[r] : 0.0);  // rows >= m hold zeros
     }
     const double h = xcol[jn];
-    const dhqr_dd ss = wave_sum_dd(acc);
+    // (the squares and the per-lane sums in double-double, the tree across the lanes in plain double: the cascaded tree was
+    // 40 % of this chain and buys nothing measurable -- 24 draws at 110 x 100: acceptance statistic median 0.57 / max 7.9 x
+    // LAPACK's against 0.66 / 7.3 with it, the restated reference 1.4 / 11.6)
+    const dhqr_dd ss = wave_sum_dd_plain(acc);
     const double s2 = ss.hi + ss.lo;
     double sn, f;
     if (s2 > 0.0 && s2 < 1e300) {
@@ -266,17 +266,19 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
 // Awork != nullptr: the factor is first copied there (m x n, leading dimension m; device memory) with every load in
 // flight at once -- A is then pinned HOST memory, and the chunk pipeline below would pay a PCIe round trip per chunk.
 // The solving wave is bound by instruction issue (~150 double-double instructions per reflector at four rows per lane, one
-// wave on its SIMD: 6.3 cycles each): RPL = ceil(m / 64) rows per lane, not always four.
-#define SML_CH 16    // columns per LDS chunk
-#define SML_LDR 256  // rows of a staged column
-template <int RPL>  // rows of b per lane of the solving wave: m <= 64 RPL
+// wave on its SIMD: 6.3 cycles each): RPL = ceil(m / 64) rows per lane, not always four.  Up to 128 rows the chunks are 64
+// columns wide (the same LDS) and come straight from the caller's memory: two or three chunk hand-overs per pass instead of
+// seven to sixteen, and no copy of the factor first.
+#define SML_LDR 256  // most rows of a matrix the solve takes
+template <int RPL, int CH>  // RPL: rows of b per lane of the solving wave, m <= 64 RPL; CH: columns per LDS chunk (2 x CH x 64 RPL doubles of LDS)
 __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__restrict__ A, int64_t lda, int m, int n,
                                                             const double *__restrict__ alpha, const double *bin, double *bout,
                                                             double *xout, double *__restrict__ Awork) {
-  __shared__ double buf[2][SML_CH][SML_LDR];
-  __shared__ double als[2][SML_CH];
+  constexpr int LDR = 64 * RPL;  // rows of a staged column
+  __shared__ double buf[2][CH][LDR];
+  __shared__ double als[2][CH];
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
-  const int nch = (n + SML_CH - 1) / SML_CH;
+  const int nch = (n + CH - 1) / CH;
   if (Awork) {
     const int total = m * n;
     for (int base = 0; base < total; base += 8 * SML_THREADS) {
@@ -301,16 +303,16 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
   // waves 1..3: columns [16 c, 16 c + 16) rows [0, rtop) -> buf[c & 1] (zeros beyond the matrix); every load of a thread is
   // issued before its first LDS store
   auto stage = [&](int c, int rtop) {
-    double(*B)[SML_LDR] = buf[c & 1];
-    constexpr int PER = (SML_CH * (SML_LDR / 2) + SML_THREADS - 64 - 1) / (SML_THREADS - 64);
+    double(*B)[LDR] = buf[c & 1];
+    constexpr int PER = (CH * (LDR / 2) + SML_THREADS - 64 - 1) / (SML_THREADS - 64);
     double x0[PER], x1[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int e = t - 64 + u * (SML_THREADS - 64);
-      const int jj = e / (SML_LDR / 2), row = 2 * (e % (SML_LDR / 2)), col = SML_CH * c + jj;
+      const int jj = e / (LDR / 2), row = 2 * (e % (LDR / 2)), col = CH * c + jj;
       x0[u] = 0.0;
       x1[u] = 0.0;
-      if (jj < SML_CH && col < n && row < rtop) {
+      if (jj < CH && col < n && row < rtop) {
         if (row < m) x0[u] = A[(int64_t)row + (int64_t)col * lda];
         if (row + 1 < m) x1[u] = A[(int64_t)row + 1 + (int64_t)col * lda];
       }
@@ -318,13 +320,13 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int e = t - 64 + u * (SML_THREADS - 64);
-      const int jj = e / (SML_LDR / 2), row = 2 * (e % (SML_LDR / 2));
-      if (jj < SML_CH) {
+      const int jj = e / (LDR / 2), row = 2 * (e % (LDR / 2));
+      if (jj < CH) {
         B[jj][row] = x0[u];
         B[jj][row + 1] = x1[u];
       }
     }
-    if (t >= 64 && t < 64 + SML_CH) als[c & 1][t - 64] = (SML_CH * c + t - 64 < n) ? alpha[SML_CH * c + t - 64] : 1.0;
+    if (t >= 64 && t < 64 + CH) als[c & 1][t - 64] = (CH * c + t - 64 < n) ? alpha[CH * c + t - 64] : 1.0;
   };
   dhqr_dd b[RPL];
   if (w == 0) {
@@ -340,10 +342,10 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
   // ---- b <- Q'b: reflectors left to right (src:215-224)
   for (int c = 0; c < nch; ++c) {
     if (w == 0) {
-      const double(*B)[SML_LDR] = buf[c & 1];
+      const double(*B)[LDR] = buf[c & 1];
 #pragma unroll 4
-      for (int jj = 0; jj < SML_CH; ++jj) {
-        const int j = SML_CH * c + jj;  // (columns >= n are staged as zeros: no-ops)
+      for (int jj = 0; jj < CH; ++jj) {
+        const int j = CH * c + jj;  // (columns >= n are staged as zeros: no-ops)
         double v[RPL];
         dhqr_dd p = {0.0, 0.0};
 #pragma unroll
@@ -353,14 +355,13 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
           dd_add_prod(p, v[r], b[r].hi);       // src:217: sum v_i b_i, b_i = hi + lo
           p.lo = fma(v[r], b[r].lo, p.lo);
         }
-        const dhqr_dd sd = wave_sum_dd(p);
+        const dhqr_dd sd = wave_sum_dd_plain(p);
         const double s = sd.hi + sd.lo;
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) {  // src:218-220: b_i -= v_i s
-          dd_add_prod(b[r], -s, v[r]);
-          dd_renorm(b[r]);
-        }
+        for (int r = 0; r < RPL; ++r) dd_add_prod(b[r], -s, v[r]);  // src:218-220: b_i -= v_i s
       }
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) dd_renorm(b[r]);  // once per chunk: the low parts stay small against the high ones
     } else if (c + 1 < nch) {
       stage(c + 1, m);
     }
@@ -372,11 +373,11 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
   __syncthreads();
   for (int c = nch - 1; c >= 0; --c) {
     if (w == 0) {
-      const double(*B)[SML_LDR] = buf[c & 1];
-      const double rinv = dhqr_rcp(als[c & 1][l & (SML_CH - 1)]);  // lane jj: 1 / alpha of the chunk's column jj
+      const double(*B)[LDR] = buf[c & 1];
+      const double rinv = dhqr_rcp(als[c & 1][l & (CH - 1)]);  // lane jj: 1 / alpha of the chunk's column jj
 #pragma unroll 4
-      for (int jj = SML_CH - 1; jj >= 0; --jj) {
-        const int j = SML_CH * c + jj;
+      for (int jj = CH - 1; jj >= 0; --jj) {
+        const int j = CH * c + jj;
         if (j < n) {  // wave-uniform
           const int rj = j >> 6;
           double bj = 0.0;
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
         }
       }
     } else if (c > 0) {
-      stage(c - 1, SML_CH * c);  // only rows above the chunk's last column are needed
+      stage(c - 1, CH * c);  // only rows above the chunk's last column are needed
     }
     __syncthreads();
   }

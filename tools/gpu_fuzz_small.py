@@ -44,6 +44,9 @@ for case in range(ncases):
         ne, ne1 = np.linalg.norm(A0.T @ (A0 @ x - b)), np.linalg.norm(A0.T @ (A0 @ x1 - b))
         if ne1 > 0:
             ratios.append(ne / ne1)
+            if ne / ne1 >= 6.0:
+                xo_ne = np.linalg.norm(A0.T @ (A0 @ xo - b))
+                print(f"note: m={m} n={n} seed={seed}: statistic {ne:.3e} = {ne / ne1:.2f} x LAPACK's {ne1:.3e}; the oracle's x: {xo_ne / ne1:.2f} x", flush=True)
     if not ok:
         fail += 1
         print(f"FAIL m={m} n={n} seed={seed} dH={eH:.2e} da={ea:.2e} dx={ex:.2e}", flush=True)
