@@ -175,6 +175,7 @@ BENCH_SIGNATURES = {
     "dhqr_bench_mma_probe_f64": (_i32, [_p, _i32, _i32, _pd]),
     "dhqr_bench_lane_probe_f64": (_i32, [_p, _i64, _i32, _i32, _i32, _pd]),
     "dhqr_debug_hold_cus": (_i32, [_p, _i32, _i32, _i32]),
+    "dhqr_debug_smq_phases": (_i32, [_p, _pd]),
 }
 
 _lib = None

@@ -1078,7 +1078,7 @@ static CsProblem cs_single(dhqr_ctx *c, double *dA, int64_t m, int64_t n, int64_
 }
 
 // ---- the single-workgroup route for small matrices (dhqr_small.h) -------------------------------------------------
-// instantiations of k_small_qr_b<NR, NQ, EXTRA>: rows <= 16 NR, columns <= 32 NQ, NR * NQ doubles of matrix per lane
+// instantiations of k_small_qr_d<NR, NQ, EXTRA>: rows <= 16 NR, columns <= 32 NQ, NR * NQ doubles of matrix per lane
 static inline int small_qr_fit(const dhqr_ctx *c, int64_t m, int64_t n) {
   if (!c->small_route || m < n || n < 1) return -1;
   if (m <= 128 && n <= 128) return 0;
@@ -1091,13 +1091,13 @@ static inline bool small_ldiv_fit(const dhqr_ctx *c, int64_t m, int64_t n) {
 }
 static int32_t small_qr_launch(dhqr_ctx *c, int fit, const double *Asrc, int64_t lds, double *Adst, int64_t ldd, int64_t m,
                                int64_t n, double *alpha) {
-  // (k_small_qr_b: the reflectors are built by a ninth wave / by another wave than the column's owner, dhqr_small.h)
+  // (k_small_qr_d: the reflectors are built by a ninth wave / by another wave than the column's owner, dhqr_small.h)
   if (fit == 0)
-    hipLaunchKernelGGL((k_small_qr_b<8, 4, true>), dim3(1), dim3(SMB_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+    hipLaunchKernelGGL((k_small_qr_d<8, 4, true>), dim3(1), dim3(SMB_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
   else if (fit == 1)
-    hipLaunchKernelGGL((k_small_qr_b<14, 7, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+    hipLaunchKernelGGL((k_small_qr_d<14, 7, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
   else
-    hipLaunchKernelGGL((k_small_qr_b<16, 6, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+    hipLaunchKernelGGL((k_small_qr_d<16, 6, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
   LAUNCHCHECK();
   return DHQR_OK;
 }

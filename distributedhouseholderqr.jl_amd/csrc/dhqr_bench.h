@@ -624,5 +624,17 @@ int32_t dhqr_debug_hold_cus(dhqr_ctx *c, int32_t nwg, int32_t max_ms, int32_t re
   LAUNCHCHECK();
   return DHQR_OK;
 }
+// phase clock of the last k_small_qr_d launches since the previous call (dhqr_small.h: g_smq_phase); out: 9 x 6 values
+int32_t dhqr_debug_smq_phases(dhqr_ctx *c, double *out54) {
+  ENTER(c);
+  unsigned long long h[9][6];
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  HIPCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_smq_phase), sizeof(h)));
+  for (int w = 0; w < 9; ++w)
+    for (int q = 0; q < 6; ++q) out54[w * 6 + q] = (double)h[w][q];
+  memset(h, 0, sizeof(h));
+  HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_smq_phase), h, sizeof(h)));
+  return DHQR_OK;
+}
 
 }  // extern "C"

@@ -7,16 +7,16 @@
 // (src:122-148, 198-213) runs here exactly as written -- one reflector after the other, every trailing column updated by
 // every reflector -- with the whole matrix resident in VGPRs and ONE workgroup barrier per column:
 //
-//   k_small_qr_b<NR, NQ> 512 threads = 8 waves (two per SIMD, 256 registers per lane; + a ninth for m <= 128).  Lane (rg, cs) of
+//   k_small_qr_d<NR, NQ> 512 threads = 8 waves (two per SIMD, 256 registers per lane; + a ninth for m <= 128).  Lane (rg, cs) of
 //                        wave w holds rows rg + 16 r (r < NR) of the columns 32 q + 4 w + cs (q < NQ): a 16-lane DPP row spans
 //                        16 consecutive matrix rows of one column, the four rows of a wave are four adjacent columns.  The dot
 //                        product v_j' a_c (partialdot, src:42-49) is NR fma per lane + a 4-step DPP reduction inside the
 //                        16-lane row (VALU only, four columns per instruction); the update (hotloop!, src:156-160) NR fma.
-//                        The wave that owns column j + 1 updates it FIRST and hands it to a builder wave, which forms
-//                        reflector j + 1 (norm in double-double like every other path, src:129-135) while the others are
-//                        still applying reflector j; v travels through 2 x 16 NR doubles of LDS (double buffered by column
-//                        parity).  The kernels are bound by instruction issue (one or two waves per SIMD, 6.3 cycles per
-//                        FP64 instruction), not by latency or memory.
+//                        Reflector j + 1 is built by a BUILDER wave from a copy of column j + 1 handed over through LDS
+//                        (norm in double-double like every other path, src:129-135) while the matrix waves apply reflector
+//                        j; v travels through 2 x 16 NR doubles of LDS (double buffered by column parity).  The kernels are
+//                        bound by instruction issue (one or two waves per SIMD, 6.3 cycles per FP64 instruction), not by
+//                        latency or memory.
 //   k_small_ldiv<RPL>    b <- Q'b (src:215-224) and the back substitution (src:244-254) in one launch: wave 0 keeps b in
 //                        registers and walks the columns, waves 1-3 stream the factor in 16-column chunks into a
 //                        double-buffered LDS stage ahead of it (once left to right for Q'b, once right to left -- upper
@@ -73,61 +73,85 @@ __device__ __forceinline__ dhqr_dd wave_sum_dd_plain(dhqr_dd v) {
   return r;
 }
 
-// One pass of reflector j (vr: its rows rg + 16 r, zeros above row j) over the column groups of this wave, rows r >= R0
-// only (the caller knows that every row below 16 R0 lies above j).  Straight-line code per block of SMQ_GB groups -- the
-// independent dot products of a block keep the FP64 pipe busy while a DPP reduction's dependent steps are in flight --
-// and ONE uniform branch per block skips the blocks that are finished.
-// qskip: a group this wave has already updated (the look-ahead column's), masked out through its coefficient.
-#ifndef SMQ_GB
-#define SMQ_GB 1  // (2 and 4 measured: with two waves per SIMD hiding each other's latencies the finer skipping wins)
+#define SMB_THREADS (SMQ_THREADS + 64)
+#ifdef DHQR_BENCH_BUILD
+// phase clock of k_small_qr_d (libdhqr_bench.so only; dhqr_debug_smq_phases): shader cycles summed over the steps of the last
+// launches, per wave: [0] reflector read + trailing update (take-back and hand-over inside), [1] reflector construction
+// (builder), [2] wait at the barrier, [5] steps
+__device__ unsigned long long g_smq_phase[9][6];
+#define SMQ_CLK(var) const long long var = clock64()
+#else
+#define SMQ_CLK(var) do { } while (0)
 #endif
+// householder!(A, alpha) (src:113, 122-148, 198-213) for m <= 16 NR, n <= 32 NQ, m >= n.  Asrc / Adst may alias.
+// ONE barrier per column.  History of the step, because each version's measurement is why the next looks as it does
+// (110 x 100 / 220 x 200, one launch):
+//   1. the owner of column j + 1 updates it, builds reflector j + 1 (norm, square roots, scaling), then does its share of the
+//      trailing update: ~1000 instructions at 6.3 cycles each where the other seven waves had 350 and waited: 169 / 602 us;
+//   2. the construction moves to a BUILDER wave (m <= 128: a ninth wave that holds no part of the matrix; otherwise the wave
+//      four places from the owner, after its own share of the update); the owner only brings its column up to date and hands
+//      it over through LDS; two barriers per column ("column in xcol", "reflector in vb"); the matrix copy of a finished
+//      column is scaled at the very end: 125 / 560, then 100 / 495 us with the refinement chains shortened.  Its phase clock
+//      (tools/smq_phases.py, cycles per column: owner's update + hand-over 500 / 1300 in front of the first barrier, then the
+//      construction 1713 / 380 beside a trailing update of 700-1050 / 1770-2070) shows two things on the critical chain that
+//      need not be there: the owner's special update of the look-ahead column, and the barrier behind it;
+//   3. (this kernel) the BUILDER applies reflector j to column j + 1 itself: the owner hands the column over one step
+//      EARLIER -- updated through reflector j - 1, inside its ordinary update of step j - 1 -- and the builder (64 lanes x RBL
+//      rows) forms v_j' x, updates its copy, and goes on to norm / alpha / f / the scaled reflector j + 1.  The eight matrix
+//      waves apply reflector j to every column meanwhile -- column j + 1 included, no special case -- and the owner of column
+//      j + 2 hands that one over as it updates it.  One barrier.
+// The builder's copy of a column and the owner's differ in the rounding of one dot product (16-lane rows against 64 lanes),
+// so the owner TAKES THE REFLECTOR BACK: at step j + 1 it reads reflector j + 1 from LDS like every wave, in exactly the
+// layout of its matrix registers, and the lanes of column j + 1 overwrite rows >= j + 1 with it.  What is stored is therefore
+// bit for bit what was applied, and there is no deferred scaling and no LDS image of the reflectors.
+// (A builder in the 16-lane layout of the matrix waves -- bitwise the owner's arithmetic, no take-back -- was measured too:
+//  135 / 647 us against 115 / 440: four times the per-lane work on the one chain that matters, and 100 more spilled registers.)
+// One pass of reflector j (vr: its rows rg + 16 r, zeros above row j) over the column groups of this wave, rows r >= R0
+// only (the caller knows that every row below 16 R0 lies above j).  Straight-line code per group -- and ONE uniform branch
+// per group skips the groups that are finished (blocks of 2 and 4 groups per branch were measured: with two waves per SIMD
+// hiding each other's latencies the finer skipping wins).
+//   qt / tlane: the group / lanes of column j itself when this wave holds it: its rows >= j become reflector j (the take-back);
+//   qh / hlane: the group / lanes of column j + 2 when this wave holds it: handed to the builder (xo) as it is updated.
+// Both happen INSIDE the group's update: as separate passes over the registers the compiler kept a shadow copy of the group
+// in scratch memory.
 template <int NR, int NQ, int R0>
-__device__ __forceinline__ void smq_pass(double (&a)[NQ][NR], const double (&vr)[NR], int j, int cbase, int qskip) {
+__device__ __forceinline__ void smq_pass_d(double (&a)[NQ][NR], const double (&vr)[NR], int j, int cbase, double *xo, int qh,
+                                           bool hlane, int qt, bool tlane) {
+  const int rg = threadIdx.x & 15;
 #pragma unroll
-  for (int qb = 0; qb < NQ; qb += SMQ_GB) {
-    if (SMQ_GW * (qb + SMQ_GB) - 1 > j) {
+  for (int q = 0; q < NQ; ++q) {
+    if (SMQ_GW * (q + 1) - 1 >= j) {  // (>=: the group of column j itself still takes its reflector back)
+      if (q == qt) {                  // this wave holds column j: rows >= j of it become reflector j (src:133-140)
 #pragma unroll
-      for (int q = qb; q < qb + SMQ_GB; ++q) {
-        if (q < NQ) {  // (compile time)
-          double p0 = 0.0, p1 = 0.0;
+        for (int r = R0; r < NR; ++r) a[q][r] = (tlane && rg + 16 * r >= j) ? vr[r] : a[q][r];
+      }
+      double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-          for (int r = R0; r < NR; r += 2) {
-            p0 = fma(vr[r], a[q][r], p0);  // src:42-49
-            if (r + 1 < NR) p1 = fma(vr[r + 1], a[q][r + 1], p1);
-          }
-          const double p = row16_sum(p0 + p1);
-          const double d = (SMQ_GW * q + cbase > j && q != qskip) ? p : 0.0;  // columns <= j are finished, columns >= n hold zeros
+      for (int r = R0; r < NR; r += 2) {
+        p0 = fma(vr[r], a[q][r], p0);  // src:42-49
+        if (r + 1 < NR) p1 = fma(vr[r + 1], a[q][r + 1], p1);
+      }
+      const double p = row16_sum(p0 + p1);
+      const double d = (SMQ_GW * q + cbase > j) ? p : 0.0;  // columns <= j are finished, columns >= n hold zeros
 #pragma unroll
-          for (int r = R0; r < NR; ++r) a[q][r] = fma(-vr[r], d, a[q][r]);  // src:156-160, src:209
-        }
+      for (int r = R0; r < NR; ++r) a[q][r] = fma(-vr[r], d, a[q][r]);  // src:156-160, src:209
+      if (q == qh) {  // column j + 2 leaves for the builder as it is updated
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+          if (hlane) xo[rg + 16 * r] = a[q][r];
       }
     }
   }
 }
-
-// householder!(A, alpha) (src:113, 122-148, 198-213) for m <= 16 NR, n <= 32 NQ, m >= n.  Asrc / Adst may alias.
-// The reflector construction is taken OFF the owner of the look-ahead column (the first version built it there: first the
-// owner's update of the column, then norm / square roots / scaling, then its share of the trailing update -- ~1000
-// instructions at 6.3 cycles each where the other seven waves had 350 and waited at the barrier: 169 us at 110 x 100, 602 us
-// at 220 x 200; now 125 / 560).  The owner only brings its column up to date and hands it over through LDS (xcol); a BUILDER
-// wave turns it into reflector j + 1 (double-double norm, the refinement chains of dhqr_common.h):
-//   EXTRA = true   (m <= 128: registers to spare) a ninth wave that holds no part of the matrix builds WHILE all eight
-//                  matrix waves apply reflector j;
-//   EXTRA = false  the wave four places from the owner (another SIMD) builds after its own share of the update: the
-//                  longest wave of a step has update + build (~600 instructions) instead of update + build + update.
-// The owner never sees the scaled column again during the factorisation -- a finished column is only ever stored -- so the
-// scaling of the matrix copy is deferred to the end: f_j and the new pivot entry of every column wait in LDS.
-// Two barriers per column: "column j + 1 is in xcol" and "reflector j + 1 is in vb / reflector j is applied".
-#define SMB_THREADS (SMQ_THREADS + 64)
 template <int NR, int NQ, bool EXTRA>
-__global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_b(const double *Asrc, int64_t lds, double *Adst,
+__global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_d(const double *Asrc, int64_t lds, double *Adst,
                                                                                    int64_t ldd, int m, int n,
                                                                                    double *__restrict__ alpha) {
-  constexpr int RBL = (16 * NR + 63) / 64;  // rows of the handed-over column per lane of the builder
+  constexpr int RBL = (16 * NR + 63) / 64;  // rows of a column per lane of the builder
   constexpr int NT = EXTRA ? SMB_THREADS : SMQ_THREADS;
-  __shared__ double vb[2][16 * NR];
-  __shared__ double xcol[64 * RBL];
-  __shared__ double als[SMQ_GW * NQ], fcol[SMQ_GW * NQ], pcol[SMQ_GW * NQ];
+  __shared__ double vb[2][64 * RBL];
+  __shared__ double xcol[2][64 * RBL];
+  __shared__ double als[SMQ_GW * NQ];
   const int t = threadIdx.x, w = t >> 6, l = t & 63, rg = l & 15, cs = l >> 4;
   const bool xwave = EXTRA && w == 8;  // holds no part of the matrix
   const int cbase = 4 * w + cs;        // this lane's column of group q: 32 q + cbase (matrix waves)
@@ -140,116 +164,117 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
       a[q][r] = 0.0;
       if (!xwave && row < m && col < n) a[q][r] = Asrc[(int64_t)row + (int64_t)col * lds];
     }
-  for (int i = 16 * NR + t; i < 64 * RBL; i += NT) xcol[i] = 0.0;  // rows beyond the matrix registers: never handed over
-  // owner of column jn: its (up to date) column -> xcol (the prologue's; a step hands over inside its update of the group:
-  // as a separate pass over the registers the compiler kept a shadow copy of the group in scratch memory)
-  auto hand_over = [&](int jn) __attribute__((always_inline)) {
-    const int q1 = jn / SMQ_GW, cs1 = jn & 3;
+  if (xwave) __builtin_amdgcn_s_setprio(3);  // the builder's dependent chain IS the step: its instructions go first
+  for (int i = 16 * NR + t; i < 64 * RBL; i += NT)  // rows beyond the matrix registers: never written again
+    xcol[0][i] = xcol[1][i] = vb[0][i] = vb[1][i] = 0.0;
+  // the prologue's hand-over (a step hands over inside its update of the group: see smq_pass_d)
+  auto hand_over = [&](int jc) __attribute__((always_inline)) {
+    const int q1 = jc / SMQ_GW, cs1 = jc & 3;
+    double *xo = xcol[jc & 1];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       if (q == q1) {
 #pragma unroll
         for (int r = 0; r < NR; ++r)
-          if (cs == cs1) xcol[rg + 16 * r] = a[q][r];
+          if (cs == cs1) xo[rg + 16 * r] = a[q][r];
       }
   };
-  // builder wave: reflector jn from xcol (src:129-135) -> vb[jn & 1], alpha, and what the deferred scaling needs
+  // builder: column jn (in xcol, updated through reflector jn - 2) -> apply reflector jn - 1 (in vb) -> reflector jn
+  // (src:129-135) -> the other vb buffer, alpha
   auto build = [&](int jn) __attribute__((always_inline)) {
+    const double *xi = xcol[jn & 1], *vi = vb[(jn & 1) ^ 1];
     double x[RBL];
+#pragma unroll
+    for (int r = 0; r < RBL; ++r) x[r] = xi[l + 64 * r];
+    if (jn > 0) {  // src:198-213 for this one column (vi holds zeros above row jn - 1)
+      double vp[RBL], p = 0.0;
+#pragma unroll
+      for (int r = 0; r < RBL; ++r) {
+        vp[r] = vi[l + 64 * r];
+        p = fma(vp[r], x[r], p);
+      }
+      const double d = wave_sum_dpp(p);
+#pragma unroll
+      for (int r = 0; r < RBL; ++r) x[r] = fma(-vp[r], d, x[r]);
+    }
+    double hc = 0.0;
     dhqr_dd acc = {0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < RBL; ++r) {
-      x[r] = xcol[l + 64 * r];
+      if (r == (jn >> 6)) hc = x[r];
       dd_add_sq(acc, l + 64 * r >= jn ? x[r] : 0.0);  // rows >= m hold zeros
     }
-    const double h = xcol[jn];
-    // (the squares and the per-lane sums in double-double, the tree across the lanes in plain double: the cascaded tree was
-    // 40 % of this chain and buys nothing measurable -- 24 draws at 110 x 100: acceptance statistic median 0.57 / max 7.9 x
-    // LAPACK's against 0.66 / 7.3 with it, the restated reference 1.4 / 11.6)
+    const double h = smq_readlane(hc, jn & 63);
+    // (the squares and the per-lane sums in double-double, the tree across the lanes in plain double: see wave_sum_dd_plain)
     const dhqr_dd ss = wave_sum_dd_plain(acc);
     const double s2 = ss.hi + ss.lo;
     double sn, f;
     if (s2 > 0.0 && s2 < 1e300) {
       double rinv, sq;
-      dhqr_sqrt_rsqrt(s2, sn, rinv);                // src:129
-      dhqr_sqrt_rsqrt(sn * (sn + fabs(h)), sq, f);  // src:131
+      dhqr_sqrt_rsqrt(s2, sn, rinv);                 // src:129
+      dhqr_sqrt_rsqrt(fma(sn, fabs(h), s2), sq, f);  // src:131: s (s + |h|) = s^2 + s |h|
     } else {
       sn = sqrt(s2);
       f = 1.0 / sqrt(sn * (sn + fabs(h)));
     }
-    const double al = sn * dhqr_alphafactor(h);     // src:130
-    const double piv = (h - al) * f;                // src:132
+    const double al = sn * dhqr_alphafactor(h);      // src:130
+    const double piv = (h - al) * f;                 // src:132
     double *vo = vb[jn & 1];
 #pragma unroll
     for (int r = 0; r < RBL; ++r) {
       const int row = l + 64 * r;
       if (row < 16 * NR) vo[row] = row > jn ? x[r] * f : (row == jn ? piv : 0.0);  // src:133-140
     }
-    if (l == 0) {
-      als[jn] = al;
-      fcol[jn] = f;
-      pcol[jn] = piv;
-    }
+    if (l == 0) als[jn] = al;
   };
   auto step = [&](auto r0c, int j) __attribute__((always_inline)) {
     constexpr int R0 = decltype(r0c)::value;
-    const int jn = j + 1, qn = jn / SMQ_GW, wn = (jn & (SMQ_GW - 1)) >> 2;  // wn: the wave that holds column j + 1
-    double vr[NR];
-    int qskip = -1;
+    const int jn = j + 1, wn = (jn & (SMQ_GW - 1)) >> 2;  // wn: the wave that holds column j + 1
+    SMQ_CLK(tq0);
     if (!xwave) {
+      double vr[NR];
 #pragma unroll
       for (int r = 0; r < NR; ++r) vr[r] = (r >= R0) ? vb[j & 1][rg + 16 * r] : 0.0;
-      if (w == wn) {  // the owner of column j + 1: that column's group first, handed over as it is updated
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          if (q == qn) {
-            double p0 = 0.0, p1 = 0.0;
-#pragma unroll
-            for (int r = R0; r < NR; r += 2) {
-              p0 = fma(vr[r], a[q][r], p0);
-              if (r + 1 < NR) p1 = fma(vr[r + 1], a[q][r + 1], p1);
-            }
-            const double p = row16_sum(p0 + p1);
-            const double d = (SMQ_GW * q + cbase > j) ? p : 0.0;
-#pragma unroll
-            for (int r = R0; r < NR; ++r) a[q][r] = fma(-vr[r], d, a[q][r]);
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-              if (cs == (jn & 3)) xcol[rg + 16 * r] = a[q][r];
-          }
-        qskip = qn;
-      }
+      const int jc = j + 2;
+      const bool mine = jc < n && w == ((jc & (SMQ_GW - 1)) >> 2), back = w == ((j & (SMQ_GW - 1)) >> 2);
+      smq_pass_d<NR, NQ, R0>(a, vr, j, cbase, xcol[jc & 1], mine ? jc / SMQ_GW : -1, cs == (jc & 3), back ? j / SMQ_GW : -1,
+                             cs == (j & 3));
     }
-    __syncthreads();  // column j + 1 is in xcol
-    if (!xwave) smq_pass<NR, NQ, R0>(a, vr, j, cbase, qskip);
-    if (w == (EXTRA ? 8 : ((wn + 4) & 7))) build(jn);
-    __syncthreads();  // reflector j + 1 is in vb; reflector j is applied everywhere
+    SMQ_CLK(tq1);
+    if (jn < n && w == (EXTRA ? 8 : ((wn + 4) & 7))) build(jn);
+    SMQ_CLK(tq2);
+    __syncthreads();  // reflector j + 1 is in vb, column j + 2 in xcol, reflector j applied everywhere
+#ifdef DHQR_BENCH_BUILD
+    if (l == 0) {
+      const long long tq3 = clock64();
+      g_smq_phase[w][0] += (unsigned long long)(tq1 - tq0);
+      g_smq_phase[w][1] += (unsigned long long)(tq2 - tq1);
+      g_smq_phase[w][2] += (unsigned long long)(tq3 - tq2);
+      g_smq_phase[w][5] += 1ull;
+    }
+#endif
   };
   if (w == 0) hand_over(0);
   __syncthreads();
   if (w == (EXTRA ? 8 : 4)) build(0);
+  if (n > 1 && w == 0) hand_over(1);  // (as it came: the builder applies reflector 0 to it)
   __syncthreads();
   {
     constexpr int RA = NR / 4, RB = NR / 2, RC = (3 * NR) / 4;
-    int j = 0;
-    for (; j + 1 < n && j < 16 * RA; ++j) step(std::integral_constant<int, 0>{}, j);
-    for (; j + 1 < n && j < 16 * RB; ++j) step(std::integral_constant<int, RA>{}, j);
-    for (; j + 1 < n && j < 16 * RC; ++j) step(std::integral_constant<int, RB>{}, j);
-    for (; j + 1 < n; ++j) step(std::integral_constant<int, RC>{}, j);
+    int j = 0;  // (the last step, j = n - 1, only takes reflector n - 1 back -- and updates nothing: no column beyond it)
+    for (; j < n && j < 16 * RA; ++j) step(std::integral_constant<int, 0>{}, j);
+    for (; j < n && j < 16 * RB; ++j) step(std::integral_constant<int, RA>{}, j);
+    for (; j < n && j < 16 * RC; ++j) step(std::integral_constant<int, RB>{}, j);
+    for (; j < n; ++j) step(std::integral_constant<int, RC>{}, j);
   }
   if (!xwave) {
-    // the deferred scaling (src:132-135): below the diagonal times f_col, the pivot entry replaced; R above it untouched
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int col = SMQ_GW * q + cbase;
-      const double f = (col < n) ? fcol[col] : 0.0, piv = (col < n) ? pcol[col] : 0.0;
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const int row = rg + 16 * r;
-        if (row < m && col < n) {
-          const double x = a[q][r];
-          Adst[(int64_t)row + (int64_t)col * ldd] = row > col ? x * f : (row == col ? piv : x);
-        }
+        if (row < m && col < n) Adst[(int64_t)row + (int64_t)col * ldd] = a[q][r];
       }
     }
   }

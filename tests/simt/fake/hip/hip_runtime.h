@@ -286,6 +286,7 @@ inline long long wall_clock64() {
   return t += 1000;  // every poll advances the fake constant-rate counter: bounded spins terminate
 }
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
 // inter-workgroup flags (k_zpanel_pipe): workgroups run one after the other here, the atomics are plain host atomics
 #define __HIP_MEMORY_SCOPE_AGENT 4

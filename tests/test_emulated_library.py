@@ -365,7 +365,7 @@ SMALL_SHAPES = [(1, 1), (5, 3), (33, 33), (64, 64), (111, 100), (128, 128), (130
 
 @pytest.mark.parametrize("m,n", SMALL_SHAPES)
 def test_small_route_single_workgroup_kernels(emu, orc, m, n):
-    """csrc/dhqr_small.h: qr! and `\\` of a matrix that fits one compute unit's registers in ONE launch each (k_small_qr_b: the
+    """csrc/dhqr_small.h: qr! and `\\` of a matrix that fits one compute unit's registers in ONE launch each (k_small_qr_d: the
     reference's column-by-column algorithm with the matrix in registers; k_small_ldiv: Q'b + back substitution with the
     factor streamed through LDS) -- device pointers and the host-array entry points on the pinned staging buffer, every
     instantiation and its edges, against the oracle; nb is ignored on this route"""

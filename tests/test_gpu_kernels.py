@@ -310,7 +310,7 @@ def small_route(pkg):
 
 @pytest.mark.parametrize("m,n", SMALL_SHAPES)
 def test_small_route_vs_oracle(pkg, orc, torch_cuda, small_route, m, n):
-    """qr! and `\\` of a matrix that fits one compute unit's registers: ONE single-workgroup launch each (k_small_qr_b,
+    """qr! and `\\` of a matrix that fits one compute unit's registers: ONE single-workgroup launch each (k_small_qr_d,
     k_small_ldiv), on device tensors and on host arrays (the kernels then work on the pinned staging buffer across PCIe),
     every instantiation and its edges, against the oracle (src:122-148,198-213,215-294)"""
     torch = torch_cuda
