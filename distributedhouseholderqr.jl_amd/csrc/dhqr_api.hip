@@ -855,23 +855,40 @@ static int32_t pair_vtc(dhqr_ctx *c, const double *Vp, int64_t ldv, int64_t rows
     // stream-K (k_gemm_tn2<.., true>): 128-row fine units numbered tile-major, a contiguous range per workgroup
     const int64_t FU = 128, S = (rows + FU - 1) / FU, U = ntiles * S;
     const int64_t G = std::min<int64_t>(U, slots), q = (U + G - 1) / G, Gq = (U + q - 1) / q;
+    // row groups (dhqr_gemm.h: tn2_sk_group_of): XCD x works inside row range x % R, so that its slice of [V_a V_b] stays in
+    // its L2.  DHQR_TUNE tn2_rgroups = 1 / 2 / 4 / 8, 0 = by height.
+    int R = c->tn2_rgroups;
+    if (R == 0) R = rows >= c->tn2_rg8_rows ? 8 : rows >= c->tn2_rg4_rows ? 4 : rows >= c->tn2_rg2_rows ? 2 : 1;
+    if (G < 64 || S < 4 * R) R = 1;
+    if (R > 1) {
+      int P = 0;
+      for (int g = 0; g < R; ++g) P = std::max(P, tn2_sk_pieces(tn2_sk_group_of(g, R, G, S, ntiles, q)));
+      CHECK(ensure(c, ws.w1, (size_t)R * (size_t)P * (size_t)wstride));
+      if (vec)
+        hipLaunchKernelGGL((k_gemm_tn2<2, true>), dim3((unsigned)G), dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, FU, ws.w1.p, wstride, q, R, P);
+      else
+        hipLaunchKernelGGL((k_gemm_tn2<1, true>), dim3((unsigned)G), dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, FU, ws.w1.p, wstride, q, R, P);
+      hipLaunchKernelGGL(k_reduce_pieces, dim3((unsigned)((wstride + 255) / 256)), dim3(256), 0, c->stream, (const double *)ws.w1.p, S, q,
+                         wstride, wstride, Y, R, P, G, ntiles);
+      return DHQR_OK;
+    }
     const int64_t pieces = (q >= S) ? 2 : (S + q - 1) / q + 1;
     CHECK(ensure(c, ws.w1, (size_t)pieces * (size_t)wstride));
     if (vec)
-      hipLaunchKernelGGL((k_gemm_tn2<2, true>), dim3((unsigned)Gq), dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, FU, ws.w1.p, wstride, q);
+      hipLaunchKernelGGL((k_gemm_tn2<2, true>), dim3((unsigned)Gq), dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, FU, ws.w1.p, wstride, q, 1, 0);
     else
-      hipLaunchKernelGGL((k_gemm_tn2<1, true>), dim3((unsigned)Gq), dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, FU, ws.w1.p, wstride, q);
+      hipLaunchKernelGGL((k_gemm_tn2<1, true>), dim3((unsigned)Gq), dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, FU, ws.w1.p, wstride, q, 1, 0);
     hipLaunchKernelGGL(k_reduce_pieces, dim3((unsigned)((wstride + 255) / 256)), dim3(256), 0, c->stream, (const double *)ws.w1.p, S, q,
-                       wstride, wstride, Y);
+                       wstride, wstride, Y, 1, 0, Gq, ntiles);
     return DHQR_OK;
   }
   CHECK(ensure(c, ws.w1, (size_t)nsplit * (size_t)wstride));
   // k_gemm_tn2 is persistent: its workgroups loop over the (column tile, row slab) units
   const dim3 gtn((unsigned)std::min<int64_t>(ntiles * nsplit, slots)), gred((unsigned)((wstride + 63) / 64));
   if (vec)
-    hipLaunchKernelGGL((k_gemm_tn2<2>), gtn, dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, rps, ws.w1.p, wstride, (int64_t)0);
+    hipLaunchKernelGGL((k_gemm_tn2<2>), gtn, dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, rps, ws.w1.p, wstride, (int64_t)0, 1, 0);
   else
-    hipLaunchKernelGGL((k_gemm_tn2<1>), gtn, dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, rps, ws.w1.p, wstride, (int64_t)0);
+    hipLaunchKernelGGL((k_gemm_tn2<1>), gtn, dim3(512), 0, c->stream, Vp, ldv, C, ldc, rows, ncols, rps, ws.w1.p, wstride, (int64_t)0, 1, 0);
   hipLaunchKernelGGL(k_reduce_splits, gred, dim3(256), 0, c->stream, (const double *)ws.w1.p, (int)nsplit, wstride, wstride, Y);
   return DHQR_OK;
 }
@@ -1265,6 +1282,10 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_NN_SPLIT")) c->nn_split = std::min(16, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_RANKK_PIPE")) c->rankk_pipe = std::min(2, std::max(0, atoi(e)));
     { long long v; if (tune_get("tn_min_tiles", &v)) c->tn_model_min_tiles = (int)v; }
+    { long long v; if (tune_get("tn2_rgroups", &v)) c->tn2_rgroups = (int)v; }
+    { long long v; if (tune_get("tn2_rg8_rows", &v)) c->tn2_rg8_rows = v; }
+    { long long v; if (tune_get("tn2_rg4_rows", &v)) c->tn2_rg4_rows = v; }
+    { long long v; if (tune_get("tn2_rg2_rows", &v)) c->tn2_rg2_rows = v; }
     { long long v; if (tune_get("tn_spare", &v)) c->tn_spare = std::max(0, std::min((c->ncu - 8) / 2, (int)v)); }
     { long long v; if (tune_get("tn_spare_cols", &v)) c->tn_spare_cols = v; }
     if (const char *e = getenv("DHQR_PAIR")) c->pair = atoi(e) != 0;

@@ -545,7 +545,9 @@ static int32_t cs_prepare(const CsProblem &pr) {
   CHECK(ensure(c, c->vts, (size_t)panel_elems(m)));
   const size_t ncmax = (size_t)std::max<int64_t>(pr.ncl, 2 * NB);
   const size_t ntmax = (ncmax + 127) / 128;
-  const size_t w1cap = NN * (6144 + 2 * ntmax + 128);  // split-K partials of k_gemm_tn (128 rows) / k_gemm_tn2 (256 rows)
+  // split-K partials of k_gemm_tn (128 rows) / k_gemm_tn2 (256 rows; stream-K with R row groups: R x P pieces of 2 ntiles
+  // matrices, P ntiles <= G / R + 2 ntiles)
+  const size_t w1cap = NN * std::max<size_t>(6144 + 2 * ntmax + 128, 640 + 32 * ntmax);
   for (int s = 0; s < 3; ++s) {
     CHECK(ensure(c, c->ws[s].w1, s == 0 ? w1cap : NN * 2200));
     CHECK(ensure(c, c->ws[s].w1r, s == 2 ? (size_t)4 * NB * 2 * NB : (size_t)4 * NB * ncmax));  // Y_1, Y_2 / [W_1; W_2] of a quad step

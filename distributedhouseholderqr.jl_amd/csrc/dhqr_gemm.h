@@ -308,17 +308,63 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_gram_batch(const double *__r
 // s ^ ((c >> 1) & 7)), no staging registers / ds_write / masking.  A slab whose last K-tile is partial stages that one tile
 // through registers (zeros below the slab) into the same image.  Same unit decomposition, same sums in the same order:
 // bit-identical to the register-staged program, which stays as the VEC = 1 instantiation.
+// ROW GROUPS of a stream-K launch (r6; R = 1: the map above, unchanged).  The counters say k_gemm_tn2 fetches 2.6 x its
+// algorithmic bytes: per column tile a workgroup streams 2 KiB of [V_a V_b] for every KiB of C, and with the units
+// numbered tile-major over ALL rows the 32 workgroups of an XCD sit at 32 different heights of V -- a slice of V (67 MB at
+// 32768 rows) is gone from the XCD's 4 MB L2 long before a second workgroup of that XCD asks for it.  With R row groups
+// the rows are cut into R ranges and XCD x (workgroup b runs on XCD b % 8: round-robin dispatch) only ever works inside
+// range x % R: its slice of V is rows / R x 2 KiB (8 MB at 32768 rows, R = 8; 2-4 MB for most of a factorisation), its
+// workgroups sweep that one range tile after tile, and what one of them fetched the others find in the L2.  Each group
+// is a stream-K problem of its own: fine units (column tile, slab of the group) numbered tile-major, the group's Gl
+// workgroups take contiguous ranges of q_g = ceil(units / Gl).  Price: a column tile's partial sums are R x (1-3) pieces
+// instead of 1-3 (slot g * P + piece; k_reduce_pieces walks the groups in order).
+struct tn2_sk_group {
+  int64_t Gl, nsl, slab0, q;  // workgroups of the group, its slabs, its first slab, units per workgroup
+};
+__host__ __device__ __forceinline__ tn2_sk_group tn2_sk_group_of(int g, int R, int64_t G, int64_t S, int64_t ntiles, int64_t skq) {
+  tn2_sk_group r;
+  if (R <= 1) {
+    r.Gl = G, r.nsl = S, r.slab0 = 0, r.q = skq;
+    return r;
+  }
+  const int64_t full = G >> 3, rem = G & 7;
+  r.Gl = full * (8 / R) + (rem > g ? (rem - g - 1) / R + 1 : 0);
+  const int64_t Sg = (S + R - 1) / R;
+  r.slab0 = (int64_t)g * Sg;
+  r.nsl = (r.slab0 >= S) ? 0 : ((S - r.slab0 < Sg) ? S - r.slab0 : Sg);
+  r.q = r.Gl > 0 ? (ntiles * r.nsl + r.Gl - 1) / r.Gl : 1;
+  if (r.q < 1) r.q = 1;
+  return r;
+}
+__host__ __device__ __forceinline__ int tn2_sk_pieces(const tn2_sk_group &gr) {  // most pieces a column tile gets from this group
+  if (gr.nsl <= 0) return 0;
+  return (gr.q >= gr.nsl) ? 2 : (int)((gr.nsl + gr.q - 1) / gr.q) + 1;
+}
 template <bool SK, int OPT = 0>
 __device__ __forceinline__ void gemm_tn2_direct(const double *__restrict__ V, int64_t ldv, const double *__restrict__ C,
                                                 int64_t ldc, int64_t rows, int64_t ncols, int64_t rps,
-                                                double *__restrict__ out, int64_t osplit_stride, int64_t skq) {
+                                                double *__restrict__ out, int64_t osplit_stride, int64_t skq,
+                                                int rgroups = 1, int pstride = 0) {
   constexpr int NP = 256, STG = (NP + 128) * G_KT;  // doubles per stage: V image (256 columns) then C image (128)
   __shared__ __attribute__((aligned(1024))) double ring[3 * STG];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int i16 = lane & 15, k4 = lane >> 4;
   const int wc = w >> 2, wp = w & 3;
-  const int64_t ntiles = (ncols + 127) / 128, nslab = (rows + rps - 1) / rps;
-  const int64_t ufirst = SK ? (int64_t)blockIdx.x * skq : (int64_t)blockIdx.x;
+  const int64_t ntiles = (ncols + 127) / 128, nslab_all = (rows + rps - 1) / rps;
+  // SK: this workgroup's row group (rgroups == 1: one group, the whole launch), its index in the group
+  int64_t nslab = nslab_all, slab0 = 0, wgi = (int64_t)blockIdx.x, pbase = 0;
+  if constexpr (SK) {
+    if (rgroups > 1) {
+      const int x = (int)(blockIdx.x & 7u), g = x % rgroups;
+      const tn2_sk_group gr = tn2_sk_group_of(g, rgroups, (int64_t)gridDim.x, nslab_all, ntiles, skq);
+      nslab = gr.nsl;
+      slab0 = gr.slab0;
+      skq = gr.q;
+      wgi = (int64_t)(blockIdx.x >> 3) * (8 / rgroups) + x / rgroups;
+      pbase = (int64_t)g * pstride;
+    }
+  }
+  const int64_t ufirst = SK ? wgi * skq : (int64_t)blockIdx.x;
   const int64_t ulast = SK ? (ufirst + skq < ntiles * nslab ? ufirst + skq : ntiles * nslab) : ntiles * nslab;
   // fragment addresses (doubles from the stage base): k-step kk, column i16 (+16 x) of the wave's 64
   int af[4];
@@ -338,9 +384,9 @@ __device__ __forceinline__ void gemm_tn2_direct(const double *__restrict__ V, in
       ux = u / nslab;
       const int64_t s0 = u - ux * nslab;
       const int64_t s1 = (s0 + (ulast - u) < nslab) ? s0 + (ulast - u) : nslab;
-      rbeg = s0 * rps;
-      rend = (s1 * rps < rows) ? s1 * rps : rows;
-      uy = (int64_t)blockIdx.x - (ux * nslab) / skq;  // this workgroup's piece of tile ux
+      rbeg = (slab0 + s0) * rps;
+      rend = ((slab0 + s1) * rps < rows) ? (slab0 + s1) * rps : rows;
+      uy = pbase + wgi - (ux * nslab) / skq;  // this workgroup's piece of tile ux
       u += s1 - s0;
     } else {
       ux = u % ntiles;
@@ -453,9 +499,9 @@ template <int VEC, bool SK = false>
 __global__ __launch_bounds__(512) void k_gemm_tn2(const double *__restrict__ V, int64_t ldv,
                                                   const double *__restrict__ C, int64_t ldc, int64_t rows,
                                                   int64_t ncols, int64_t rps, double *__restrict__ out,
-                                                  int64_t osplit_stride, int64_t skq) {
+                                                  int64_t osplit_stride, int64_t skq, int rgroups, int pstride) {
   if constexpr (VEC == 2) {
-    gemm_tn2_direct<SK>(V, ldv, C, ldc, rows, ncols, rps, out, osplit_stride, skq);
+    gemm_tn2_direct<SK>(V, ldv, C, ldc, rows, ncols, rps, out, osplit_stride, skq, rgroups, pstride);
     return;
   }
   constexpr int NP = 256;
@@ -466,8 +512,20 @@ __global__ __launch_bounds__(512) void k_gemm_tn2(const double *__restrict__ V, 
   const int wc = w >> 2, wp = w & 3;
   // PERSISTENT: gridDim.x workgroups (one per CU, the host leaves CUs free for the look-ahead lane / RCCL by launching
   // fewer) loop over the units u = (column tile, row slab), column tile fastest -- the order of the former 2-D grid.
-  const int64_t ntiles = (ncols + 127) / 128, nslab = (rows + rps - 1) / rps;
-  const int64_t ufirst = SK ? (int64_t)blockIdx.x * skq : (int64_t)blockIdx.x;
+  const int64_t ntiles = (ncols + 127) / 128, nslab_all = (rows + rps - 1) / rps;
+  int64_t nslab = nslab_all, slab0 = 0, wgi = (int64_t)blockIdx.x, pbase = 0;  // (row groups: see tn2_sk_group_of)
+  if constexpr (SK) {
+    if (rgroups > 1) {
+      const int x = (int)(blockIdx.x & 7u), g = x % rgroups;
+      const tn2_sk_group gr = tn2_sk_group_of(g, rgroups, (int64_t)gridDim.x, nslab_all, ntiles, skq);
+      nslab = gr.nsl;
+      slab0 = gr.slab0;
+      skq = gr.q;
+      wgi = (int64_t)(blockIdx.x >> 3) * (8 / rgroups) + x / rgroups;
+      pbase = (int64_t)g * pstride;
+    }
+  }
+  const int64_t ufirst = SK ? wgi * skq : (int64_t)blockIdx.x;
   const int64_t ulast = SK ? (ufirst + skq < ntiles * nslab ? ufirst + skq : ntiles * nslab) : ntiles * nslab;
   for (int64_t u = ufirst; u < ulast;) {
   int64_t ux, uy, rbeg, rend;
@@ -475,9 +533,9 @@ __global__ __launch_bounds__(512) void k_gemm_tn2(const double *__restrict__ V, 
     ux = u / nslab;
     const int64_t s0 = u - ux * nslab;
     const int64_t s1 = (s0 + (ulast - u) < nslab) ? s0 + (ulast - u) : nslab;
-    rbeg = s0 * rps;
-    rend = (s1 * rps < rows) ? s1 * rps : rows;
-    uy = (int64_t)blockIdx.x - (ux * nslab) / skq;  // this workgroup's piece of tile ux
+    rbeg = (slab0 + s0) * rps;
+    rend = ((slab0 + s1) * rps < rows) ? (slab0 + s1) * rps : rows;
+    uy = pbase + wgi - (ux * nslab) / skq;  // this workgroup's piece of tile ux
     u += s1 - s0;
   } else {
     ux = u % ntiles;
@@ -1053,14 +1111,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_quad(const double *__restric
 // 128 x 128 Gram matrix with 256 partials is reduced by 256 blocks instead of 64.
 // The reduction of a stream-K k_gemm_tn2 launch: element e of Y (256 x ncols, ld 256) belongs to column tile
 // t = e / (256 * 128) and is the sum of that tile's pieces (slots 0 .. npieces(t) - 1, see k_gemm_tn2).
+// rgroups > 1: the pieces of row group g sit in slots g * pstride ..; G = workgroups of the k_gemm_tn2 launch.
 __global__ __launch_bounds__(256) void k_reduce_pieces(const double *__restrict__ in, int64_t nslab, int64_t skq,
-                                                       int64_t stride, int64_t count, double *__restrict__ out) {
+                                                       int64_t stride, int64_t count, double *__restrict__ out,
+                                                       int rgroups, int pstride, int64_t G, int64_t ntiles) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= count) return;
   const int64_t tile = e / (256 * 128);
-  const int np = (int)((((tile + 1) * nslab - 1) / skq) - ((tile * nslab) / skq) + 1);
-  double s = in[e];
-  for (int q = 1; q < np; ++q) s += in[(int64_t)q * stride + e];
+  double s = 0.0;
+  for (int g = 0; g < (rgroups > 1 ? rgroups : 1); ++g) {
+    const tn2_sk_group gr = tn2_sk_group_of(g, rgroups, G, nslab, ntiles, skq);
+    if (gr.nsl <= 0) continue;
+    const int np = (int)((((tile + 1) * gr.nsl - 1) / gr.q) - ((tile * gr.nsl) / gr.q) + 1);
+    const double *ing = in + (int64_t)g * pstride * stride;
+    double sg = ing[e];
+    for (int q = 1; q < np; ++q) sg += ing[(int64_t)q * stride + e];
+    s = (g == 0) ? sg : s + sg;
+  }
   out[e] = s;
 }
 

@@ -196,7 +196,7 @@ static int32_t rs_prepare(const RsProblem &pr, RsWork *w) {
   // split-K partials / reduced Y / W of the two streams (nothing is reallocated while they run): [0] wide, [1] lane
   const size_t ncmax = (size_t)std::max<int64_t>(pr.n, 2 * NB), ntmax = (ncmax + 127) / 128;
   for (int s = 0; s < 2; ++s) {
-    CHECK(ensure(c, c->ws[s].w1, s == 0 ? NN * (6144 + 2 * ntmax + 128) : NN * 2200));
+    CHECK(ensure(c, c->ws[s].w1, s == 0 ? NN * std::max<size_t>(6144 + 2 * ntmax + 128, 640 + 32 * ntmax) : NN * 2200));
     CHECK(ensure(c, c->ws[s].w1r, 2 * NB * ncmax));
     CHECK(ensure(c, c->ws[s].w2, 2 * NB * ncmax));
   }

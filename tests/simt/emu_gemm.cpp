@@ -62,9 +62,25 @@ int main(int argc, char **argv) {
     std::vector<double> out((size_t)nsplit * ostride, -7.0);
     // persistent: fewer workgroups than units, so every workgroup loops (3 is coprime to most unit counts)
     const int wgs = std::max(1, std::min(3, ntiles * nsplit - 1));
-    if (vec == 2) grid2(wgs, 1, 512, [&] { k_gemm_tn2<2>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride, (int64_t)0); });
-    else grid2(wgs, 1, 512, [&] { k_gemm_tn2<1>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride, (int64_t)0); });
+    if (vec == 2) grid2(wgs, 1, 512, [&] { k_gemm_tn2<2>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride, (int64_t)0, 1, 0); });
+    else grid2(wgs, 1, 512, [&] { k_gemm_tn2<1>(V.data(), ldv, C.data(), ldc, rows, ncols, rps, out.data(), ostride, (int64_t)0, 1, 0); });
     wr(argv[11], out);
+  } else if (op == "tn2sk") {  // stream-K k_gemm_tn2 + k_reduce_pieces: kparam = row groups R, argv[8] = workgroups G; fine units of 32 rows
+    const int R = kparam;
+    const int64_t G = atoll(argv[8]), FU = 32;
+    auto V = rd(argv[9], (size_t)ldv * 256);
+    auto C = rd(argv[10], (size_t)ldc * ncols);
+    const int64_t ntiles = (ncols + 127) / 128, S = (rows + FU - 1) / FU, U = ntiles * S, wstride = 256 * ncols;
+    const int64_t q = (U + G - 1) / G, Gq = (U + q - 1) / q;
+    int P = 0;
+    if (R > 1) for (int g = 0; g < R; ++g) P = std::max(P, tn2_sk_pieces(tn2_sk_group_of(g, R, G, S, ntiles, q)));
+    else P = (int)((q >= S) ? 2 : (S + q - 1) / q + 1);
+    std::vector<double> part((size_t)std::max(R, 1) * P * wstride, -7.0), Y((size_t)wstride, -9.0);
+    const int wgs = (int)(R > 1 ? G : Gq);
+    if (vec == 2) grid2(wgs, 1, 512, [&] { k_gemm_tn2<2, true>(V.data(), ldv, C.data(), ldc, rows, ncols, FU, part.data(), wstride, q, R, P); });
+    else grid2(wgs, 1, 512, [&] { k_gemm_tn2<1, true>(V.data(), ldv, C.data(), ldc, rows, ncols, FU, part.data(), wstride, q, R, P); });
+    grid2((int)((wstride + 255) / 256), 1, 256, [&] { k_reduce_pieces(part.data(), S, q, wstride, wstride, Y.data(), R, P, (int64_t)wgs, ntiles); });
+    wr(argv[11], Y);
   } else if (op == "quad") {  // four-panel C -= [V1 | V2] W (k_gemm_nn_quad): V2 starts `skip` rows below V1 (same ldv); swz 2 = 64-row tiles
     const int swz = atoi(argv[8]);
     auto V1 = rd(argv[9], (size_t)ldv * 256);

@@ -269,6 +269,27 @@ def test_gemm_tn_two_panels(emu_gemm, tmp_path, vec, rows, ncols, rps):
     assert np.abs(W - V[:rows].T @ C[:rows]).max() < 1e-12
 
 
+@pytest.mark.parametrize("vec,rows,ncols,groups,wgs", [(2, 420, 300, 1, 7), (2, 420, 300, 8, 19), (2, 610, 150, 4, 13),
+                                                        (1, 333, 260, 2, 9), (2, 200, 140, 8, 24), (2, 96, 130, 8, 11)])
+def test_gemm_tn_two_panels_stream_k_row_groups(emu_gemm, tmp_path, vec, rows, ncols, groups, wgs):
+    """stream-K k_gemm_tn2 + k_reduce_pieces with ROW GROUPS (tn2_sk_group_of: workgroup b belongs to group (b % 8) % R and
+    works inside that group's row range): every (tile, slab) unit exactly once whatever the number of workgroups -- grids
+    that are not multiples of 8, groups with different numbers of workgroups, a last group with fewer slabs, groups with
+    no slab at all (96 rows = 3 slabs, 8 groups)"""
+    rng = np.random.default_rng(5)
+    ldv, ldc = rows + rows % 2 + 2, rows + rows % 2 + 4
+    V = np.full((ldv, 256), 7.0)
+    V[:rows] = rng.standard_normal((rows, 256))
+    C = np.full((ldc, ncols), 9.0)
+    C[:rows] = rng.standard_normal((rows, ncols))
+    f = {k: str(tmp_path / f"{k}.bin") for k in ("V", "C", "o")}
+    _put(f["V"], V)
+    _put(f["C"], C)
+    _run(emu_gemm, "tn2sk", vec, groups, rows, ncols, ldv, ldc, wgs, f["V"], f["C"], f["o"])
+    Y = np.fromfile(f["o"]).reshape(ncols, 256).T
+    assert np.abs(Y - V[:rows].T @ C[:rows]).max() < 1e-11
+
+
 @pytest.mark.parametrize("vec,kw,rows,ncols,swz", [(2, 128, 200, 150, 0), (1, 128, 131, 129, 0),
                                                    (2, 256, 256, 128, 0), (2, 128, 300, 260, 1),
                                                    (2, 128, 200, 150, 2), (2, 256, 192, 256, 2)])  # swz 2: 64-row tiles

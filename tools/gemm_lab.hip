@@ -504,9 +504,9 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&o2, (size_t)pieces * wstride * 8));
     CK(hipMemset(o1, 0, (size_t)pieces * wstride * 8));
     CK(hipMemset(o2, 0, (size_t)pieces * wstride * 8));
-    auto l1 = [&]() { hipLaunchKernelGGL((k_gemm_tn2<1, true>), dim3((unsigned)Gq), dim3(512), 0, 0, (const double *)V, ldv, (const double *)C0, ldc, rows, ncols, FU, o1, wstride, q); };
-    auto l2 = [&]() { hipLaunchKernelGGL((k_gemm_tn2<2, true>), dim3((unsigned)Gq), dim3(512), 0, 0, (const double *)V, ldv, (const double *)C0, ldc, rows, ncols, FU, o2, wstride, q); };
-    auto l3 = [&]() { hipLaunchKernelGGL((lab_tn2<1>), dim3((unsigned)Gq), dim3(512), 0, 0, (const double *)V, ldv, (const double *)C0, ldc, rows, ncols, FU, o2, wstride, q); };
+    auto l1 = [&]() { hipLaunchKernelGGL((k_gemm_tn2<1, true>), dim3((unsigned)Gq), dim3(512), 0, 0, (const double *)V, ldv, (const double *)C0, ldc, rows, ncols, FU, o1, wstride, q, 1, 0); };
+    auto l2 = [&]() { hipLaunchKernelGGL((k_gemm_tn2<2, true>), dim3((unsigned)Gq), dim3(512), 0, 0, (const double *)V, ldv, (const double *)C0, ldc, rows, ncols, FU, o2, wstride, q, 1, 0); };
+    auto l3 = [&]() { hipLaunchKernelGGL((lab_tn2<1>), dim3((unsigned)Gq), dim3(512), 0, 0, (const double *)V, ldv, (const double *)C0, ldc, rows, ncols, FU, o2, wstride, q, 1, 0); };
     for (int rep = 0; rep < 2; ++rep) {
       time_it(l1, "tn2_staged", 256);
       printf("\n");
