@@ -1111,8 +1111,12 @@ static int32_t small_qr_launch(dhqr_ctx *c, int fit, const double *Asrc, int64_t
   // (k_small_qr_d: the reflectors are built by a ninth wave / by another wave than the column's owner, dhqr_small.h)
   if (fit == 0)
     hipLaunchKernelGGL((k_small_qr_d<8, 4, true>), dim3(1), dim3(SMB_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+  else if (fit == 1 && c->small_flags)  // (above 128 rows: no barrier in the column loop, LDS flags instead; DHQR_TUNE small_flags=0)
+    hipLaunchKernelGGL((k_small_qr_d<14, 7, false, true>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
   else if (fit == 1)
     hipLaunchKernelGGL((k_small_qr_d<14, 7, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+  else if (c->small_flags)
+    hipLaunchKernelGGL((k_small_qr_d<16, 6, false, true>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
   else
     hipLaunchKernelGGL((k_small_qr_d<16, 6, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
   LAUNCHCHECK();
@@ -1282,6 +1286,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_NN_SPLIT")) c->nn_split = std::min(16, std::max(1, atoi(e)));
     if (const char *e = getenv("DHQR_RANKK_PIPE")) c->rankk_pipe = std::min(2, std::max(0, atoi(e)));
     { long long v; if (tune_get("tn_min_tiles", &v)) c->tn_model_min_tiles = (int)v; }
+    { long long v; if (tune_get("small_flags", &v)) c->small_flags = v != 0; }
     { long long v; if (tune_get("tn2_rgroups", &v)) c->tn2_rgroups = (int)v; }
     { long long v; if (tune_get("tn2_rg8_rows", &v)) c->tn2_rg8_rows = v; }
     { long long v; if (tune_get("tn2_rg4_rows", &v)) c->tn2_rg4_rows = v; }

@@ -143,15 +143,70 @@ __device__ __forceinline__ void smq_pass_d(double (&a)[NQ][NR], const double (&v
     }
   }
 }
-template <int NR, int NQ, bool EXTRA>
+// FLAGS (the instantiations above 128 rows, where a matrix wave builds): NO barrier in the column loop.  With a barrier the
+// step is (update + the builder's chain): the seven other waves wait while the builder, after its own share of the update,
+// runs the chain (~4100 cycles every eighth step for each wave against ~2000 of update).  Here the waves run free: v_j is
+// awaited through an LDS word (vready), a handed-over column through another (xready), four buffers of each instead of two,
+// and a builder may not overwrite reflector j - 4's buffer before every wave has finished with it (prog[w]): a wave that
+// has just built is one chain behind and catches up over the next seven steps, so a column costs update + chain / 8.
+// A writer publishes with a workgroup release fence (s_waitcnt lgkmcnt(0)) and a plain LDS store by lane 0; a reader polls.
+// The waits are BOUNDED (a single-workgroup kernel that never ends would take the device with it): after SMQ_SPIN_LIMIT polls
+// -- tens of milliseconds; a hand-over takes a microsecond -- the waiter sets `broken` and goes on, and the kernel returns
+// NaN in alpha instead of a factorisation.
+#define SMQ_SPIN_LIMIT (1 << 20)
+// (relaxed workgroup-scope atomics, not `volatile`: a volatile access through a pointer loses the LDS address space and
+// becomes a FLAT load with system-coherence bits -- measurably slower polls on the chain)
+__device__ __forceinline__ void smq_wait_ge(int *p, int target, int *broken) {
+  int spins = 0;
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    __builtin_amdgcn_s_sleep(0);  // (no pause on the device: the poll is on the chain; the CPU emulator yields here)
+    if (++spins > SMQ_SPIN_LIMIT) {
+      __hip_atomic_store(broken, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// every wave's progress in ONE 64-bit word (byte w = 1 + the last reflector wave w is done with): one LDS round trip per poll
+__device__ __forceinline__ void smq_wait_all_ge(unsigned long long *p, int target, int *broken) {
+  for (int spins = 0;; ++spins) {
+    const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ok = ok && (int)((v >> (8 * q)) & 0xffull) >= target + 1;
+    if (ok) break;
+    __builtin_amdgcn_s_sleep(0);
+    if (spins > SMQ_SPIN_LIMIT) {
+      __hip_atomic_store(broken, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <typename T>
+__device__ __forceinline__ void smq_post(T *p, T value, bool leader) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();  // (a wave runs in lockstep; on the CPU emulator its lanes do not: they meet here)
+  if (leader) __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int NR, int NQ, bool EXTRA, bool FLAGS = false>
 __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_d(const double *Asrc, int64_t lds, double *Adst,
                                                                                    int64_t ldd, int m, int n,
                                                                                    double *__restrict__ alpha) {
   constexpr int RBL = (16 * NR + 63) / 64;  // rows of a column per lane of the builder
   constexpr int NT = EXTRA ? SMB_THREADS : SMQ_THREADS;
-  __shared__ double vb[2][64 * RBL];
-  __shared__ double xcol[2][64 * RBL];
+  constexpr int NBUF = FLAGS ? 8 : 2, BM = NBUF - 1;  // reflector / column buffers (by column index)
+  static_assert(!(FLAGS && EXTRA), "the flag form is for the instantiations whose builder is a matrix wave");
+  __shared__ double vb[NBUF][64 * RBL];
+  __shared__ double xcol[NBUF][64 * RBL];
   __shared__ double als[SMQ_GW * NQ];
+  constexpr int NPARK = 1;  // FLAGS: column groups of the builder's registers parked in LDS while it builds
+  __shared__ double park[FLAGS ? 8 : 1][FLAGS ? NPARK * NR * 64 : 1];  // (one area per wave)
+  __shared__ unsigned long long sync_words[3];  // FLAGS: [0] = {vready, xready} (two ints), [1] = the eight waves' progress bytes, [2] = broken
+  int *const vready = reinterpret_cast<int *>(sync_words), *const xready = vready + 1;
+  unsigned char *const prog = reinterpret_cast<unsigned char *>(sync_words + 1);
+  unsigned long long *const progall = sync_words + 1;
+  int *const broken = reinterpret_cast<int *>(sync_words + 2);
   const int t = threadIdx.x, w = t >> 6, l = t & 63, rg = l & 15, cs = l >> 4;
   const bool xwave = EXTRA && w == 8;  // holds no part of the matrix
   const int cbase = 4 * w + cs;        // this lane's column of group q: 32 q + cbase (matrix waves)
@@ -166,11 +221,18 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
     }
   if (xwave) __builtin_amdgcn_s_setprio(3);  // the builder's dependent chain IS the step: its instructions go first
   for (int i = 16 * NR + t; i < 64 * RBL; i += NT)  // rows beyond the matrix registers: never written again
-    xcol[0][i] = xcol[1][i] = vb[0][i] = vb[1][i] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NBUF; ++q) xcol[q][i] = vb[q][i] = 0.0;
+  if (FLAGS && t == 0) {
+    *vready = -1;
+    *xready = -1;
+    sync_words[1] = 0ull;
+    sync_words[2] = 0ull;
+  }
   // the prologue's hand-over (a step hands over inside its update of the group: see smq_pass_d)
   auto hand_over = [&](int jc) __attribute__((always_inline)) {
     const int q1 = jc / SMQ_GW, cs1 = jc & 3;
-    double *xo = xcol[jc & 1];
+    double *xo = xcol[jc & BM];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       if (q == q1) {
@@ -182,7 +244,7 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
   // builder: column jn (in xcol, updated through reflector jn - 2) -> apply reflector jn - 1 (in vb) -> reflector jn
   // (src:129-135) -> the other vb buffer, alpha
   auto build = [&](int jn) __attribute__((always_inline)) {
-    const double *xi = xcol[jn & 1], *vi = vb[(jn & 1) ^ 1];
+    const double *xi = xcol[jn & BM], *vi = vb[(jn - 1) & BM];
     double x[RBL];
 #pragma unroll
     for (int r = 0; r < RBL; ++r) x[r] = xi[l + 64 * r];
@@ -219,7 +281,7 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
     }
     const double al = sn * dhqr_alphafactor(h);      // src:130
     const double piv = (h - al) * f;                 // src:132
-    double *vo = vb[jn & 1];
+    double *vo = vb[jn & BM];
 #pragma unroll
     for (int r = 0; r < RBL; ++r) {
       const int row = l + 64 * r;
@@ -231,19 +293,62 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
     constexpr int R0 = decltype(r0c)::value;
     const int jn = j + 1, wn = (jn & (SMQ_GW - 1)) >> 2;  // wn: the wave that holds column j + 1
     SMQ_CLK(tq0);
+    SMQ_CLK(tf0);
+    SMQ_CLK(tf1);
+    if constexpr (FLAGS) {
+      smq_wait_ge(vready, j, broken);
+#ifdef DHQR_BENCH_BUILD
+      const long long tf1b = clock64();
+#endif
+      // the builder of reflector j + 1 builds FIRST (the chain of the whole factorisation runs through the builds) and owes
+      // its share of reflector j's update afterwards.  Two column groups of its matrix registers wait in LDS meanwhile: the
+      // chain needs ~40 registers and the allocator otherwise spills three times as many to scratch memory around it.
+      // (the builder changes with EVERY column here -- wn + 2, + 4, + 6, + 8 inside a block of four columns, the odd ones in the
+      // next block: eight different waves in eight steps, never the wave that is about to hand a column over -- so that a
+      // builder's own update is not what the next build waits for)
+      if (jn < n && w == ((wn + 2 + 2 * (jn & 3)) & 7)) {
+        smq_wait_ge(xready, jn, broken);
+        if (jn >= NBUF) smq_wait_all_ge(progall, jn - NBUF, broken);  // the buffer reflector jn goes to still holds reflector jn - 4
+        __builtin_amdgcn_s_setprio(3);  // the chain goes first on its SIMD (the other wave there is in its update)
+        double *pk = park[w];
+#pragma unroll
+        for (int q = NQ - NPARK; q < NQ; ++q)
+#pragma unroll
+          for (int r = 0; r < NR; ++r) pk[((q - (NQ - NPARK)) * NR + r) * 64 + l] = a[q][r];
+        build(jn);
+        smq_post(vready, jn, l == 0);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int q = NQ - NPARK; q < NQ; ++q)
+#pragma unroll
+          for (int r = 0; r < NR; ++r) a[q][r] = pk[((q - (NQ - NPARK)) * NR + r) * 64 + l];
+      }
+#ifdef DHQR_BENCH_BUILD
+      if (l == 0) {  // FLAGS: [3] wait for reflector j, [4] the build block (waits, parking, chain, publication)
+        g_smq_phase[w][3] += (unsigned long long)(tf1b - tf0);
+        g_smq_phase[w][4] += (unsigned long long)(clock64() - tf1b);
+      }
+#endif
+    }
     if (!xwave) {
       double vr[NR];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) vr[r] = (r >= R0) ? vb[j & 1][rg + 16 * r] : 0.0;
+      for (int r = 0; r < NR; ++r) vr[r] = (r >= R0) ? vb[j & BM][rg + 16 * r] : 0.0;
       const int jc = j + 2;
       const bool mine = jc < n && w == ((jc & (SMQ_GW - 1)) >> 2), back = w == ((j & (SMQ_GW - 1)) >> 2);
-      smq_pass_d<NR, NQ, R0>(a, vr, j, cbase, xcol[jc & 1], mine ? jc / SMQ_GW : -1, cs == (jc & 3), back ? j / SMQ_GW : -1,
+      smq_pass_d<NR, NQ, R0>(a, vr, j, cbase, xcol[jc & BM], mine ? jc / SMQ_GW : -1, cs == (jc & 3), back ? j / SMQ_GW : -1,
                              cs == (j & 3));
+      if constexpr (FLAGS) {
+        if (mine) smq_post(xready, jc, l == 0);  // column j + 2 is in its buffer
+        smq_post(prog + w, (unsigned char)(j + 1), l == 0);  // this wave is done with reflector j's buffer
+      }
     }
     SMQ_CLK(tq1);
-    if (jn < n && w == (EXTRA ? 8 : ((wn + 4) & 7))) build(jn);
+    if constexpr (!FLAGS) {
+      if (jn < n && w == (EXTRA ? 8 : ((wn + 4) & 7))) build(jn);
+    }
     SMQ_CLK(tq2);
-    __syncthreads();  // reflector j + 1 is in vb, column j + 2 in xcol, reflector j applied everywhere
+    if constexpr (!FLAGS) __syncthreads();  // reflector j + 1 is in vb, column j + 2 in xcol, reflector j applied everywhere
 #ifdef DHQR_BENCH_BUILD
     if (l == 0) {
       const long long tq3 = clock64();
@@ -259,6 +364,11 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
   if (w == (EXTRA ? 8 : 4)) build(0);
   if (n > 1 && w == 0) hand_over(1);  // (as it came: the builder applies reflector 0 to it)
   __syncthreads();
+  if (FLAGS && t == 0) {
+    *vready = 0;
+    *xready = 1;
+  }
+  __syncthreads();
   {
     constexpr int RA = NR / 4, RB = NR / 2, RC = (3 * NR) / 4;
     int j = 0;  // (the last step, j = n - 1, only takes reflector n - 1 back -- and updates nothing: no column beyond it)
@@ -267,6 +377,7 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
     for (; j < n && j < 16 * RC; ++j) step(std::integral_constant<int, RB>{}, j);
     for (; j < n; ++j) step(std::integral_constant<int, RC>{}, j);
   }
+  if constexpr (FLAGS) __syncthreads();  // alpha of the last columns
   if (!xwave) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -278,7 +389,7 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
       }
     }
   }
-  for (int i = t; i < n; i += NT) alpha[i] = als[i];
+  for (int i = t; i < n; i += NT) alpha[i] = (FLAGS && *broken != 0) ? __builtin_nan("") : als[i];
 }
 
 // solve_householder!(b, H, alpha) (src:284-294) for m <= 256: b (m) <- [x; tail of Q'b], xout (n, may be nullptr) <- x.

@@ -285,11 +285,18 @@ inline long long wall_clock64() {
   static std::atomic<long long> t{0};
   return t += 1000;  // every poll advances the fake constant-rate counter: bounded spins terminate
 }
-#define __builtin_amdgcn_s_sleep(x) ((void)0)
+// s_sleep sits in polling loops (inter-workgroup flags: never taken here, workgroups run one after the other; LDS flags
+// between the waves of one workgroup: dhqr_small.h): give the other fibers / threads of the workgroup the processor
+#ifdef SIMT_FIBERS
+#define __builtin_amdgcn_s_sleep(x) ((void)simt::yield_to_next())
+#else
+#define __builtin_amdgcn_s_sleep(x) (std::this_thread::yield())
+#endif
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
 // inter-workgroup flags (k_zpanel_pipe): workgroups run one after the other here, the atomics are plain host atomics
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
 #define __hip_atomic_fetch_max(p, v, order, scope) __atomic_fetch_max((p), (v), (order))

@@ -12,7 +12,7 @@ import __graft_entry__ as g  # noqa: E402
 pkg = g.import_package()
 BL, h = pkg.bench_context(0)
 P = ctypes.c_void_p
-names = ["read+update", "build", "wait", "-", "-"]
+names = ["all before tq1", "build (barrier form)", "barrier wait", "FLAGS: wait v_j", "FLAGS: build block"]
 for m, n in ((110, 100), (220, 200)):
     A = pkg.rand_colmajor(m, n, 3, "cuda:0")
     import torch
@@ -26,4 +26,4 @@ for m, n in ((110, 100), (220, 200)):
     print(f"== {m} x {n}: cycles per step")
     for w in range(9):
         if v[w, 5] > 0:
-            print(f"  wave {w}: " + "  ".join(f"{names[q]} {v[w, q] / v[w, 5]:7.0f}" for q in range(3)) + f"   total {v[w, :5].sum() / v[w, 5]:7.0f}")
+            print(f"  wave {w}: " + "  ".join(f"{names[q]} {v[w, q] / v[w, 5]:7.0f}" for q in range(5)) + f"   total {v[w, :3].sum() / v[w, 5]:7.0f}")
