@@ -146,10 +146,16 @@ __device__ __forceinline__ void smq_pass_d(double (&a)[NQ][NR], const double (&v
 // FLAGS (the instantiations above 128 rows, where a matrix wave builds): NO barrier in the column loop.  With a barrier the
 // step is (update + the builder's chain): the seven other waves wait while the builder, after its own share of the update,
 // runs the chain (~4100 cycles every eighth step for each wave against ~2000 of update).  Here the waves run free: v_j is
-// awaited through an LDS word (vready), a handed-over column through another (xready), four buffers of each instead of two,
-// and a builder may not overwrite reflector j - 4's buffer before every wave has finished with it (prog[w]): a wave that
-// has just built is one chain behind and catches up over the next seven steps, so a column costs update + chain / 8.
-// A writer publishes with a workgroup release fence (s_waitcnt lgkmcnt(0)) and a plain LDS store by lane 0; a reader polls.
+// awaited through an LDS word (vready), a handed-over column through another (xready), eight buffers of each instead of two,
+// and a builder may not overwrite reflector j - 8's buffer before every wave has finished with it (one progress byte per
+// wave, polled as one 64-bit word): a wave that has just built is one chain behind and catches up over the next seven
+// steps, so a column costs max(chain, update + chain / 8).  The builder is a different wave for every column and builds
+// BEFORE its own share of the update (otherwise that update sits between two builds of the chain); one column
+// group of its matrix registers waits in LDS meanwhile (the chain needs ~40 registers; left to the allocator they went to
+// scratch memory).  A writer publishes with a workgroup release fence (s_waitcnt lgkmcnt(0)) and an LDS store by lane 0.
+// Measured at 220 x 200 (us per qr! call): barrier 440 | flags, builder after its update, same builder for four columns 724
+// | builder first 544 | one poll for all progress bytes, no s_sleep 475 | a new builder every column 410 | eight buffers 383
+// | s_setprio 3 while building 375 | polls as LDS atomics instead of volatile (= flat, system-coherent) loads 334.
 // The waits are BOUNDED (a single-workgroup kernel that never ends would take the device with it): after SMQ_SPIN_LIMIT polls
 // -- tens of milliseconds; a hand-over takes a microsecond -- the waiter sets `broken` and goes on, and the kernel returns
 // NaN in alpha instead of a factorisation.
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
       // builder's own update is not what the next build waits for)
       if (jn < n && w == ((wn + 2 + 2 * (jn & 3)) & 7)) {
         smq_wait_ge(xready, jn, broken);
-        if (jn >= NBUF) smq_wait_all_ge(progall, jn - NBUF, broken);  // the buffer reflector jn goes to still holds reflector jn - 4
+        if (jn >= NBUF) smq_wait_all_ge(progall, jn - NBUF, broken);  // the buffer reflector jn goes to still holds reflector jn - 8
         __builtin_amdgcn_s_setprio(3);  // the chain goes first on its SIMD (the other wave there is in its update)
         double *pk = park[w];
 #pragma unroll
