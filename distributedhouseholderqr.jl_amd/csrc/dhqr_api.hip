@@ -1110,15 +1110,15 @@ static int32_t small_qr_launch(dhqr_ctx *c, int fit, const double *Asrc, int64_t
                                int64_t n, double *alpha) {
   // (k_small_qr_d: the reflectors are built by a ninth wave / by another wave than the column's owner, dhqr_small.h)
   if (fit == 0)
-    hipLaunchKernelGGL((k_small_qr_d<8, 4, true>), dim3(1), dim3(SMB_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+    hipLaunchKernelGGL((k_small_qr_d<8, 4, true>), dim3(1), dim3(SMB_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit);
   else if (fit == 1 && c->small_flags)  // (above 128 rows: no barrier in the column loop, LDS flags instead; DHQR_TUNE small_flags=0)
-    hipLaunchKernelGGL((k_small_qr_d<14, 7, false, true>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+    hipLaunchKernelGGL((k_small_qr_d<14, 7, false, true>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit);
   else if (fit == 1)
-    hipLaunchKernelGGL((k_small_qr_d<14, 7, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+    hipLaunchKernelGGL((k_small_qr_d<14, 7, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit);
   else if (c->small_flags)
-    hipLaunchKernelGGL((k_small_qr_d<16, 6, false, true>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+    hipLaunchKernelGGL((k_small_qr_d<16, 6, false, true>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit);
   else
-    hipLaunchKernelGGL((k_small_qr_d<16, 6, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha);
+    hipLaunchKernelGGL((k_small_qr_d<16, 6, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit);
   LAUNCHCHECK();
   return DHQR_OK;
 }
@@ -1287,6 +1287,7 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     if (const char *e = getenv("DHQR_RANKK_PIPE")) c->rankk_pipe = std::min(2, std::max(0, atoi(e)));
     { long long v; if (tune_get("tn_min_tiles", &v)) c->tn_model_min_tiles = (int)v; }
     { long long v; if (tune_get("small_flags", &v)) c->small_flags = v != 0; }
+    { long long v; if (tune_get("small_spin_limit", &v)) c->small_spin_limit = (int)v; }
     { long long v; if (tune_get("tn2_rgroups", &v)) c->tn2_rgroups = (int)v; }
     { long long v; if (tune_get("tn2_rg8_rows", &v)) c->tn2_rg8_rows = v; }
     { long long v; if (tune_get("tn2_rg4_rows", &v)) c->tn2_rg4_rows = v; }
@@ -1605,6 +1606,16 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
     copy_cols(pA, m, hA, lda, m, n);
     CHECK(small_qr_launch(c, fit, pA, m, pA, m, m, n, pal));
     HIPCHECK(hipStreamSynchronize(c->stream));
+    if (fit >= 1 && c->small_flags && std::isnan(pal[0])) {
+      // the flag form's waits are bounded and it answers NaN when one expires (dhqr_small.h): once more, with a barrier
+      // per column (a NaN in the caller's first column gives the same answer twice)
+      copy_cols(pA, m, hA, lda, m, n);
+      c->small_flags = 0;
+      const int32_t rc = small_qr_launch(c, fit, pA, m, pA, m, m, n, pal);
+      c->small_flags = 1;
+      CHECK(rc);
+      HIPCHECK(hipStreamSynchronize(c->stream));
+    }
     copy_cols(hA, lda, pA, m, m, n);
     memcpy(halpha, pal, (size_t)n * sizeof(double));
     return DHQR_OK;

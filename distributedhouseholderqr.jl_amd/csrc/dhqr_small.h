@@ -156,17 +156,18 @@ __device__ __forceinline__ void smq_pass_d(double (&a)[NQ][NR], const double (&v
 // Measured at 220 x 200 (us per qr! call): barrier 440 | flags, builder after its update, same builder for four columns 724
 // | builder first 544 | one poll for all progress bytes, no s_sleep 475 | a new builder every column 410 | eight buffers 383
 // | s_setprio 3 while building 375 | polls as LDS atomics instead of volatile (= flat, system-coherent) loads 334.
-// The waits are BOUNDED (a single-workgroup kernel that never ends would take the device with it): after SMQ_SPIN_LIMIT polls
-// -- tens of milliseconds; a hand-over takes a microsecond -- the waiter sets `broken` and goes on, and the kernel returns
-// NaN in alpha instead of a factorisation.
+// The waits are BOUNDED (a single-workgroup kernel that never ends would take the device with it): after `limit` polls
+// (SMQ_SPIN_LIMIT: tens of milliseconds; a hand-over takes a microsecond; DHQR_TUNE small_spin_limit, which the tests set to 0
+// to see the answer) the waiter sets `broken` and goes on, and the kernel returns NaN in alpha instead of a factorisation;
+// the host-array entry point then factors once more with the barrier form (dhqr_qr_f64).
 #define SMQ_SPIN_LIMIT (1 << 20)
 // (relaxed workgroup-scope atomics, not `volatile`: a volatile access through a pointer loses the LDS address space and
 // becomes a FLAT load with system-coherence bits -- measurably slower polls on the chain)
-__device__ __forceinline__ void smq_wait_ge(int *p, int target, int *broken) {
+__device__ __forceinline__ void smq_wait_ge(int *p, int target, int *broken, int limit) {
   int spins = 0;
   while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
     __builtin_amdgcn_s_sleep(0);  // (no pause on the device: the poll is on the chain; the CPU emulator yields here)
-    if (++spins > SMQ_SPIN_LIMIT) {
+    if (++spins > limit) {
       __hip_atomic_store(broken, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       break;
     }
@@ -174,7 +175,7 @@ __device__ __forceinline__ void smq_wait_ge(int *p, int target, int *broken) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 // every wave's progress in ONE 64-bit word (byte w = 1 + the last reflector wave w is done with): one LDS round trip per poll
-__device__ __forceinline__ void smq_wait_all_ge(unsigned long long *p, int target, int *broken) {
+__device__ __forceinline__ void smq_wait_all_ge(unsigned long long *p, int target, int *broken, int limit) {
   for (int spins = 0;; ++spins) {
     const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     bool ok = true;
@@ -182,7 +183,7 @@ __device__ __forceinline__ void smq_wait_all_ge(unsigned long long *p, int targe
     for (int q = 0; q < 8; ++q) ok = ok && (int)((v >> (8 * q)) & 0xffull) >= target + 1;
     if (ok) break;
     __builtin_amdgcn_s_sleep(0);
-    if (spins > SMQ_SPIN_LIMIT) {
+    if (spins >= limit) {
       __hip_atomic_store(broken, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       break;
     }
@@ -198,7 +199,7 @@ __device__ __forceinline__ void smq_post(T *p, T value, bool leader) {
 template <int NR, int NQ, bool EXTRA, bool FLAGS = false>
 __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_d(const double *Asrc, int64_t lds, double *Adst,
                                                                                    int64_t ldd, int m, int n,
-                                                                                   double *__restrict__ alpha) {
+                                                                                   double *__restrict__ alpha, int spin_limit) {
   constexpr int RBL = (16 * NR + 63) / 64;  // rows of a column per lane of the builder
   constexpr int NT = EXTRA ? SMB_THREADS : SMQ_THREADS;
   constexpr int NBUF = FLAGS ? 8 : 2, BM = NBUF - 1;  // reflector / column buffers (by column index)
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
     SMQ_CLK(tf0);
     SMQ_CLK(tf1);
     if constexpr (FLAGS) {
-      smq_wait_ge(vready, j, broken);
+      smq_wait_ge(vready, j, broken, spin_limit);
 #ifdef DHQR_BENCH_BUILD
       const long long tf1b = clock64();
 #endif
@@ -313,8 +314,8 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
       // next block: eight different waves in eight steps, never the wave that is about to hand a column over -- so that a
       // builder's own update is not what the next build waits for)
       if (jn < n && w == ((wn + 2 + 2 * (jn & 3)) & 7)) {
-        smq_wait_ge(xready, jn, broken);
-        if (jn >= NBUF) smq_wait_all_ge(progall, jn - NBUF, broken);  // the buffer reflector jn goes to still holds reflector jn - 8
+        smq_wait_ge(xready, jn, broken, spin_limit);
+        if (jn >= NBUF) smq_wait_all_ge(progall, jn - NBUF, broken, spin_limit);  // the buffer reflector jn goes to still holds reflector jn - 8
         __builtin_amdgcn_s_setprio(3);  // the chain goes first on its SIMD (the other wave there is in its update)
         double *pk = park[w];
 #pragma unroll

@@ -433,6 +433,27 @@ def test_small_route_off_and_out_of_range(emu, orc):
     emu.dhqr_destroy(h)
 
 
+def test_small_route_flag_form_gives_up_instead_of_hanging(emu, orc):
+    """above 128 rows the small route's column loop runs on LDS flags with BOUNDED waits (dhqr_small.h): with no poll
+    allowed (DHQR_TUNE small_spin_limit=0) every wait that is not already satisfied gives up, the kernel answers NaN in
+    alpha -- and the host-array entry point factors once more with the barrier form, so the caller still gets the
+    factorisation; the device-resident entry point reports what the kernel said"""
+    A0 = orc.rand_matrix(150, 40, 12)
+    h = _ctx(emu, DHQR_SMALL=1, DHQR_TUNE="small_spin_limit=0")
+    A, al = A0.copy(order="F"), np.zeros(40)
+    assert emu.dhqr_factor_f64(h, _ptr(A), 150, 40, 150, _ptr(al), 0) == 0, emu.dhqr_last_error()
+    assert np.isnan(al).all()                      # every lane of the emulator is a fiber of its own: some wait always has to poll
+    A2, al2 = A0.copy(order="F"), np.zeros(40)
+    assert emu.dhqr_qr_f64(h, _ptr(A2), 150, 40, 150, _ptr(al2), 0) == 0, emu.dhqr_last_error()
+    _check(orc, A0, A2, al2)
+    emu.dhqr_destroy(h)
+    h = _ctx(emu, DHQR_SMALL=1, DHQR_TUNE="small_flags=0")   # the barrier form by request
+    A3, al3 = A0.copy(order="F"), np.zeros(40)
+    assert emu.dhqr_factor_f64(h, _ptr(A3), 150, 40, 150, _ptr(al3), 0) == 0, emu.dhqr_last_error()
+    _check(orc, A0, A3, al3)
+    emu.dhqr_destroy(h)
+
+
 def test_complex_entry_points(emu, orc):
     h = _ctx(emu)
     m, n = 150, 90

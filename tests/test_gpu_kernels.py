@@ -308,6 +308,33 @@ def small_route(pkg):
     ctx.set_small_route(False)
 
 
+@pytest.mark.parametrize("m,n", [(220, 200), (224, 224), (256, 192), (129, 7), (200, 129)])
+def test_small_route_flag_form_equals_barrier_form(pkg, orc, torch_cuda, monkeypatch, m, n):
+    """above 128 rows the column loop of the small route runs on LDS flags (k_small_qr_d<.., FLAGS>: no barrier, eight
+    buffers, a different builder wave per column); DHQR_TUNE small_flags=0 restores the barrier per column.  The same
+    arithmetic in another order of EVENTS: bit-identical factors -- and with small_spin_limit=0 on the device the kernel
+    either gets through (a wave seldom has to wait twice) or answers NaN, and the host-array entry point then returns the
+    barrier form's bits"""
+    torch = torch_cuda
+    L = pkg._lib.lib()
+    A0 = orc.rand_matrix(m, n, 77)
+    out = {}
+    for tune in ("small_flags=1", "small_flags=0", "small_spin_limit=0"):
+        monkeypatch.setenv("DHQR_TUNE", tune)
+        monkeypatch.setenv("DHQR_SMALL", "1")
+        ctx = pkg.Context(0)
+        A = np.asfortranarray(A0.copy())
+        al = np.zeros(n)
+        pkg._lib.check(L.dhqr_qr_f64(ctx.handle, A.ctypes.data_as(ctypes.c_void_p), m, n, m, al.ctypes.data_as(ctypes.c_void_p), 0))
+        out[tune] = (A, al)
+        ctx.close()
+    Ho, ao = orc.householder(A0)
+    tol = 8.0 * max(n, 8) * np.finfo(np.float64).eps * np.abs(Ho).max()
+    assert np.abs(out["small_flags=1"][0] - Ho).max() <= tol and np.abs(out["small_flags=1"][1] - ao).max() <= tol
+    for tune in ("small_flags=0", "small_spin_limit=0"):
+        assert np.array_equal(out[tune][0], out["small_flags=1"][0]) and np.array_equal(out[tune][1], out["small_flags=1"][1]), tune
+
+
 @pytest.mark.parametrize("m,n", SMALL_SHAPES)
 def test_small_route_vs_oracle(pkg, orc, torch_cuda, small_route, m, n):
     """qr! and `\\` of a matrix that fits one compute unit's registers: ONE single-workgroup launch each (k_small_qr_d,
