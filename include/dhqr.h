@@ -122,7 +122,11 @@ int32_t dhqr_get_tsqr_count(dhqr_ctx *ctx, int64_t *n_tsqr);
  * launch per qr! (m <= 128 and n <= 128, m <= 224 and n <= 224, or m <= 256 and n <= 192: the matrix lives in the
  * registers of one compute unit, the reference's column-by-column algorithm src:122-148,198-213 as written) and per `\`
  * (m <= 256), whatever `nb` says; the host-array entry points dhqr_qr_f64 / dhqr_ldiv_f64 then run the kernel directly
- * on a pinned staging buffer (csrc/dhqr_small.h).  on = 0: the general drivers for every shape (also DHQR_SMALL=0). */
+ * on a pinned staging buffer (csrc/dhqr_small.h).  on = 0: the general drivers for every shape (also DHQR_SMALL=0).
+ * Above 128 rows the kernel's waves hand columns and reflectors to each other through LDS flags instead of a barrier per
+ * column; those waits are bounded, and a kernel that gave up on one answers NaN in every alpha (never a hung device):
+ * dhqr_qr_f64 then factors once more with the barrier form by itself; a caller of the device-resident, asynchronous
+ * dhqr_factor_f64 sees the NaN (DHQR_TUNE small_flags=0 selects the barrier form from the start). */
 int32_t dhqr_set_small_route(dhqr_ctx *ctx, int32_t on);
 /* Solves this context REPEATED with one launch per panel step because a wait of the persistent Q'b kernel (all of whose
  * workgroups must be resident at once) expired -- another process or stream held compute units.  The repetition happens
