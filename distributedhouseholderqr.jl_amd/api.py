@@ -144,8 +144,13 @@ def _host_ld(F) -> int:
     return F.strides[1] // F.itemsize if n > 1 else max(m, 1)
 
 
+DEFAULT_UNBLOCKED_MAX_ROWS = 560  # Float64: at most this many rows -> nb = 0 by default (tools/mid_bench.py)
+
+
 def _resolve_nb(A, nb):
-    """nb=None: the default of the element type (128 blocked for Float64; ComplexF64: 64 blocked -- the trailing
+    """nb=None: the default of the element type (Float64: 128 blocked, but the reference's unblocked order up to 560 rows,
+    where the K-reflector passes finish before the blocked driver's panel chains do: 440 x 400 1.45 ms against 2.04,
+    520 x 512 1.86 against 2.11, 600 x 300 even, profiles/r06_mid_sizes.txt; ComplexF64: 64 blocked -- the trailing
     update runs on the FP64 MFMA kernels through the real embedding -- for n >= 256, unblocked below)"""
     if _is_complex(A):
         if nb not in (None, 0, _lib.ZNB):
@@ -153,7 +158,9 @@ def _resolve_nb(A, nb):
         if nb is None:
             return _lib.ZNB if A.shape[1] >= 256 else 0
         return nb
-    return NB if nb is None else nb
+    if nb is None:
+        return 0 if A.shape[0] <= DEFAULT_UNBLOCKED_MAX_ROWS else NB
+    return nb
 
 
 def _dev_matrix(A, dtype=None):

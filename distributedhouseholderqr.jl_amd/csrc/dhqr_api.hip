@@ -1107,26 +1107,27 @@ static inline bool small_ldiv_fit(const dhqr_ctx *c, int64_t m, int64_t n) {
   return c->small_route && m <= SML_LDR && n >= 1 && n <= m;
 }
 static int32_t small_qr_launch(dhqr_ctx *c, int fit, const double *Asrc, int64_t lds, double *Adst, int64_t ldd, int64_t m,
-                               int64_t n, double *alpha) {
+                               int64_t n, double *alpha, unsigned long long *done = nullptr, unsigned long long epoch = 0) {
   // (k_small_qr_d: the reflectors are built by a ninth wave / by another wave than the column's owner, dhqr_small.h)
   if (fit == 0)
-    hipLaunchKernelGGL((k_small_qr_d<8, 4, true>), dim3(1), dim3(SMB_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit);
+    hipLaunchKernelGGL((k_small_qr_d<8, 4, true>), dim3(1), dim3(SMB_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit, done, epoch);
   else if (fit == 1 && c->small_flags)  // (above 128 rows: no barrier in the column loop, LDS flags instead; DHQR_TUNE small_flags=0)
-    hipLaunchKernelGGL((k_small_qr_d<14, 7, false, true>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit);
+    hipLaunchKernelGGL((k_small_qr_d<14, 7, false, true>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit, done, epoch);
   else if (fit == 1)
-    hipLaunchKernelGGL((k_small_qr_d<14, 7, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit);
+    hipLaunchKernelGGL((k_small_qr_d<14, 7, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit, done, epoch);
   else if (c->small_flags)
-    hipLaunchKernelGGL((k_small_qr_d<16, 6, false, true>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit);
+    hipLaunchKernelGGL((k_small_qr_d<16, 6, false, true>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit, done, epoch);
   else
-    hipLaunchKernelGGL((k_small_qr_d<16, 6, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit);
+    hipLaunchKernelGGL((k_small_qr_d<16, 6, false>), dim3(1), dim3(SMQ_THREADS), 0, c->stream, Asrc, lds, Adst, ldd, (int)m, (int)n, alpha, c->small_spin_limit, done, epoch);
   LAUNCHCHECK();
   return DHQR_OK;
 }
 static int32_t small_ldiv_launch(dhqr_ctx *c, const double *A, int64_t lda, int64_t m, int64_t n, const double *alpha,
-                                 const double *bin, double *bout, double *xout, double *Awork) {
+                                 const double *bin, double *bout, double *xout, double *Awork, unsigned long long *done = nullptr,
+                                 unsigned long long epoch = 0) {
 #define DHQR_SML(RPL_, CH_, AW_)                                                                                            \
   hipLaunchKernelGGL((k_small_ldiv<RPL_, CH_>), dim3(1), dim3(SML_THREADS), 0, c->stream, A, lda, (int)m, (int)n, alpha, bin, \
-                     bout, xout, AW_)
+                     bout, xout, AW_, done, epoch)
   // (<= 128 rows: 64-column chunks straight from the caller's memory, no device copy of the factor)
   if (m <= 64) DHQR_SML(1, 64, (double *)nullptr);
   else if (m <= 128) DHQR_SML(2, 64, (double *)nullptr);
@@ -1134,6 +1135,18 @@ static int32_t small_ldiv_launch(dhqr_ctx *c, const double *A, int64_t lda, int6
   else DHQR_SML(4, 16, Awork);
 #undef DHQR_SML
   LAUNCHCHECK();
+  return DHQR_OK;
+}
+// The host side of small_signal_done (dhqr_small.h): poll the pinned word, for at most ~2 ms; then (or when the kernel
+// died) the stream's own synchronisation, which also reports an execution error.
+static int32_t small_wait_done(dhqr_ctx *c, unsigned long long *done, unsigned long long epoch) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned i = 1;; ++i) {
+    if (__atomic_load_n(done, __ATOMIC_ACQUIRE) == epoch) return DHQR_OK;
+    __builtin_ia32_pause();
+    if ((i & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+  }
+  HIPCHECK(hipStreamSynchronize(c->stream));
   return DHQR_OK;
 }
 static int32_t small_pin_ensure(dhqr_ctx *c, size_t need) {
@@ -1145,8 +1158,9 @@ static int32_t small_pin_ensure(dhqr_ctx *c, size_t need) {
     HIPCHECK(hipHostFree(q));
   }
   need = (need + 4095) & ~(size_t)4095;
-  HIPCHECK(hipHostMalloc((void **)&c->small_pin, need * sizeof(double), hipHostMallocDefault));
+  HIPCHECK(hipHostMalloc((void **)&c->small_pin, (need + 8) * sizeof(double), hipHostMallocDefault));  // (+ the completion word)
   c->small_pin_cap = need;
+  memset(c->small_pin + need, 0, 8 * sizeof(double));
   return DHQR_OK;
 }
 static inline void copy_cols(double *dst, int64_t ldd, const double *src, int64_t lds, int64_t m, int64_t n) {
@@ -1603,9 +1617,10 @@ int32_t dhqr_qr_f64(dhqr_ctx *c, double *hA, int64_t m, int64_t n, int64_t lda, 
     const size_t na = (size_t)m * (size_t)n;
     CHECK(small_pin_ensure(c, na + (size_t)n));
     double *pA = c->small_pin, *pal = pA + na;
+    unsigned long long *done = reinterpret_cast<unsigned long long *>(c->small_pin + c->small_pin_cap);
     copy_cols(pA, m, hA, lda, m, n);
-    CHECK(small_qr_launch(c, fit, pA, m, pA, m, m, n, pal));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    CHECK(small_qr_launch(c, fit, pA, m, pA, m, m, n, pal, done, ++c->small_epoch));
+    CHECK(small_wait_done(c, done, c->small_epoch));
     if (fit >= 1 && c->small_flags && std::isnan(pal[0])) {
       // the flag form's waits are bounded and it answers NaN when one expires (dhqr_small.h): once more, with a barrier
       // per column (a NaN in the caller's first column gives the same answer twice)
@@ -1881,8 +1896,9 @@ int32_t dhqr_ldiv_f64(dhqr_ctx *c, const double *hA, int64_t m, int64_t n, int64
     // the kernel first brings the factor from the pinned buffer into device memory (its chunk pipeline would otherwise pay
     // a PCIe round trip per chunk)
     CHECK(ensure(c, c->small_dev, (size_t)SML_LDR * SML_LDR));
-    CHECK(small_ldiv_launch(c, pA, m, m, n, pal, pb, pb, px, c->small_dev.p));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    unsigned long long *done = reinterpret_cast<unsigned long long *>(c->small_pin + c->small_pin_cap);
+    CHECK(small_ldiv_launch(c, pA, m, m, n, pal, pb, pb, px, c->small_dev.p, done, ++c->small_epoch));
+    CHECK(small_wait_done(c, done, c->small_epoch));
     memcpy(hx, px, (size_t)n * sizeof(double));  // src:320
     return DHQR_OK;
   }

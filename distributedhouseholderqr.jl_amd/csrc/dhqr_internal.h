@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <climits>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -132,6 +133,7 @@ struct dhqr_ctx {
   double *small_pin = nullptr;  // pinned host staging of the host-array entry points on that route: the kernels read and
   size_t small_pin_cap = 0;     // write it across PCIe themselves (no hipMemcpy on the path); doubles
   Buf small_dev;                // device copy of a host factor inside k_small_ldiv (256 x 256)
+  unsigned long long small_epoch = 0;  // launches that signalled their end through the pinned word behind small_pin
   bool coop = false;     // the device runs cooperative (all-resident) launches: false on the CPU emulator
   Buf host_mat;          // device copy of the caller's HOST matrix (+ alpha) of dhqr_qr_f64, kept between calls
   int pair = 1;                  // 1: wide updates apply two panels per pass (DHQR_PAIR=0 disables)

@@ -30,6 +30,17 @@
 #include <type_traits>
 #include "dhqr_common.h"
 
+// End of a small-route kernel launched by a host-array entry point: `done` (pinned host memory, may be nullptr) <- epoch
+// once every store of the workgroup is visible to the host.  The host polls that word instead of waiting in
+// hipStreamSynchronize, whose wake-up (an interrupt and a thread switch) costs more than the copy of a 110 x 100 matrix.
+// EVERY thread of the workgroup calls it.
+__device__ __forceinline__ void small_signal_done(unsigned long long *done, unsigned long long epoch) {
+  if (done == nullptr) return;  // (uniform)
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 #define SMQ_THREADS 512  // k_small_qr: 8 waves, two per SIMD, 256 registers per lane
 #define SMQ_GW 32        // columns per group: 8 waves x 4 DPP rows
 #define SML_THREADS 256  // k_small_ldiv
@@ -199,7 +210,9 @@ __device__ __forceinline__ void smq_post(T *p, T value, bool leader) {
 template <int NR, int NQ, bool EXTRA, bool FLAGS = false>
 __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_d(const double *Asrc, int64_t lds, double *Adst,
                                                                                    int64_t ldd, int m, int n,
-                                                                                   double *__restrict__ alpha, int spin_limit) {
+                                                                                   double *__restrict__ alpha, int spin_limit,
+                                                                                   unsigned long long *done,
+                                                                                   unsigned long long epoch) {
   constexpr int RBL = (16 * NR + 63) / 64;  // rows of a column per lane of the builder
   constexpr int NT = EXTRA ? SMB_THREADS : SMQ_THREADS;
   constexpr int NBUF = FLAGS ? 8 : 2, BM = NBUF - 1;  // reflector / column buffers (by column index)
@@ -397,6 +410,7 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
     }
   }
   for (int i = t; i < n; i += NT) alpha[i] = (FLAGS && *broken != 0) ? __builtin_nan("") : als[i];
+  small_signal_done(done, epoch);
 }
 
 // solve_householder!(b, H, alpha) (src:284-294) for m <= 256: b (m) <- [x; tail of Q'b], xout (n, may be nullptr) <- x.
@@ -416,7 +430,8 @@ __global__ __launch_bounds__(EXTRA ? SMB_THREADS : SMQ_THREADS) void k_small_qr_
 template <int RPL, int CH>  // RPL: rows of b per lane of the solving wave, m <= 64 RPL; CH: columns per LDS chunk (2 x CH x 64 RPL doubles of LDS)
 __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__restrict__ A, int64_t lda, int m, int n,
                                                             const double *__restrict__ alpha, const double *bin, double *bout,
-                                                            double *xout, double *__restrict__ Awork) {
+                                                            double *xout, double *__restrict__ Awork, unsigned long long *done,
+                                                            unsigned long long epoch) {
   constexpr int LDR = 64 * RPL;  // rows of a staged column
   __shared__ double buf[2][CH][LDR];
   __shared__ double als[2][CH];
@@ -559,4 +574,5 @@ __global__ __launch_bounds__(SML_THREADS) void k_small_ldiv(const double *__rest
       if (xout && row < n) xout[row] = val;
     }
   }
+  small_signal_done(done, epoch);
 }

@@ -17,9 +17,9 @@
 # top level (no definition hidden behind a hook nobody calls) and that every function has a caller or is API.
 #
 #   reference                                 this module
-#   qr!(A)                      src:311-315   qr!(A; nb=128)                -> dhqr_qr_f64
+#   qr!(A)                      src:311-315   qr!(A; nb=default_nb(A))      -> dhqr_qr_f64
 #   H \ b                       src:317-321   \(H, b)                       -> dhqr_ldiv_f64
-#   householder!(A, α)          src:113       householder!(A, α; nb=128)    -> dhqr_qr_f64
+#   householder!(A, α)          src:113       householder!(A, α; nb=...)    -> dhqr_qr_f64
 #   solve_householder!(b, H, α) src:284-294   solve_householder!(b, H, α)   -> dhqr_ldiv_f64
 #   partialdot(a, b, is, T)     src:42-49     partialdot(a, b, is, Float64) -> dhqr_partialdot_host_f64 (KAT hook)
 #   DistributedHouseholderQRStruct src:296-309  same fields A, α
@@ -77,8 +77,9 @@ DistributedHouseholderQRStruct(A) = DistributedHouseholderQRStruct(A, zeros(elty
 DistributedHouseholderQRStruct(A::DArray) = DistributedHouseholderQRStruct(A, SharedArray(zeros(eltype(A), size(A, 2))))
 
 # householder!(A, α) -- src:113.  In place on A (column-major Matrix{Float64}), fills α.
-# nb = 0 runs the reference's unblocked algorithm verbatim on the GPU; nb = 128 the blocked path.
-function householder!(A::StridedMatrix{Float64}, α::Vector{Float64}; nb::Integer=DHQR_NB)
+# nb = 0 runs the reference's unblocked algorithm verbatim on the GPU; nb = 128 the blocked path (the default above 560 rows).
+default_nb(A::StridedMatrix{Float64}) = size(A, 1) <= 560 ? 0 : DHQR_NB   # (short matrices: the unblocked passes finish first)
+function householder!(A::StridedMatrix{Float64}, α::Vector{Float64}; nb::Integer=default_nb(A))
   m, n = size(A)
   stride(A, 1) == 1 || throw(ArgumentError("column-major storage required"))
   check(ccall((:dhqr_qr_f64, libdhqr), Int32,
@@ -87,7 +88,7 @@ function householder!(A::StridedMatrix{Float64}, α::Vector{Float64}; nb::Intege
   return (A, α)
 end
 
-function qr!(A::StridedMatrix{Float64}; nb::Integer=DHQR_NB)   # src:311-315
+function qr!(A::StridedMatrix{Float64}; nb::Integer=default_nb(A))   # src:311-315
   H = DistributedHouseholderQRStruct(A)
   householder!(H.A, H.α; nb=nb)
   return H

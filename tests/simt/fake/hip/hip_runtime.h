@@ -297,12 +297,14 @@ inline long long wall_clock64() {
 // inter-workgroup flags (k_zpanel_pipe): workgroups run one after the other here, the atomics are plain host atomics
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
 #define __hip_atomic_fetch_max(p, v, order, scope) __atomic_fetch_max((p), (v), (order))
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
   return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
