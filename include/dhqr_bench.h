@@ -55,9 +55,10 @@ int32_t dhqr_bench_lane_probe_f64(dhqr_ctx *ctx, int64_t rows, int32_t nsplit, i
  * tests/test_gpu_kernels.py holds all but a few CUs this way while a solve's persistent kernel needs every workgroup
  * resident: its bounded waits expire and the solve must be repeated with the per-step kernels. */
 int32_t dhqr_debug_hold_cus(dhqr_ctx *ctx, int32_t nwg, int32_t max_ms, int32_t release);
-/* Phase clock of k_small_qr_b (csrc/dhqr_small.h; instrumented in libdhqr_bench.so only): shader cycles summed over the
- * column steps of the launches since the previous call, per wave w < 9: out54[6 w + q], q = reflector read + owner's update,
- * wait for the hand-over, trailing update, reflector construction, wait for the reflector, number of steps. */
+/* Phase clock of k_small_qr_d (csrc/dhqr_small.h; instrumented in libdhqr_bench.so only): shader cycles summed over the
+ * column steps of the launches since the previous call, per wave w < 9: out54[6 w + q], q = 0 everything up to the end of
+ * the update, 1 reflector construction (barrier form), 2 wait at the barrier, 3 / 4 flag form: wait for reflector j / the
+ * build block, 5 number of steps (tools/smq_phases.py prints them). */
 int32_t dhqr_debug_smq_phases(dhqr_ctx *ctx, double *out54);
 
 #ifdef __cplusplus
