@@ -144,14 +144,15 @@ def _host_ld(F) -> int:
     return F.strides[1] // F.itemsize if n > 1 else max(m, 1)
 
 
-DEFAULT_UNBLOCKED_MAX_ROWS = 560  # Float64: at most this many rows -> nb = 0 by default (tools/mid_bench.py)
+DEFAULT_UNBLOCKED_MAX_ROWS = 480  # Float64: at most this many rows -> nb = 0 by default (tools/mid_bench.py)
 
 
 def _resolve_nb(A, nb):
-    """nb=None: the default of the element type (Float64: 128 blocked, but the reference's unblocked order up to 560 rows,
-    where the K-reflector passes finish before the blocked driver's panel chains do: 440 x 400 1.45 ms against 2.04,
-    520 x 512 1.86 against 2.11, 600 x 300 even, profiles/r06_mid_sizes.txt; ComplexF64: 64 blocked -- the trailing
-    update runs on the FP64 MFMA kernels through the real embedding -- for n >= 256, unblocked below)"""
+    """nb=None: the default of the element type (Float64: 128 blocked, but the reference's unblocked order up to 480 rows,
+    where the K-reflector passes finish before the blocked driver's panel chains do: 440 x 400 1.46 ms against 1.53,
+    300 x 260 0.97 against 1.00, 520 x 512 1.86 against 1.49 the other way, profiles/r06_mid_sizes.txt; ComplexF64: 64
+    blocked -- the trailing update runs on the FP64 MFMA kernels through the real embedding -- for n >= 256, unblocked
+    below)"""
     if _is_complex(A):
         if nb not in (None, 0, _lib.ZNB):
             raise ValueError(f"ComplexF64: nb must be None, 0 (unblocked) or {_lib.ZNB} (blocked)")

@@ -77,8 +77,8 @@ DistributedHouseholderQRStruct(A) = DistributedHouseholderQRStruct(A, zeros(elty
 DistributedHouseholderQRStruct(A::DArray) = DistributedHouseholderQRStruct(A, SharedArray(zeros(eltype(A), size(A, 2))))
 
 # householder!(A, α) -- src:113.  In place on A (column-major Matrix{Float64}), fills α.
-# nb = 0 runs the reference's unblocked algorithm verbatim on the GPU; nb = 128 the blocked path (the default above 560 rows).
-default_nb(A::StridedMatrix{Float64}) = size(A, 1) <= 560 ? 0 : DHQR_NB   # (short matrices: the unblocked passes finish first)
+# nb = 0 runs the reference's unblocked algorithm verbatim on the GPU; nb = 128 the blocked path (the default above 480 rows).
+default_nb(A::StridedMatrix{Float64}) = size(A, 1) <= 480 ? 0 : DHQR_NB   # (short matrices: the unblocked passes finish first)
 function householder!(A::StridedMatrix{Float64}, α::Vector{Float64}; nb::Integer=default_nb(A))
   m, n = size(A)
   stride(A, 1) == 1 || throw(ArgumentError("column-major storage required"))

@@ -15,7 +15,11 @@ def test_struct_alpha_follows_eltype(pkg):
 
 def test_default_path_per_element_type(pkg):
     api = pkg.api
-    assert api._resolve_nb(np.zeros((4, 4)), None) == pkg.NB        # Float64: blocked MFMA path
+    assert api._resolve_nb(np.zeros((4000, 40)), None) == pkg.NB    # Float64: blocked MFMA path ...
+    assert api._resolve_nb(np.zeros((api.DEFAULT_UNBLOCKED_MAX_ROWS + 1, 4)), None) == pkg.NB
+    assert api._resolve_nb(np.zeros((api.DEFAULT_UNBLOCKED_MAX_ROWS, 4)), None) == 0   # ... the reference's order for short matrices
+    assert api._resolve_nb(np.zeros((4, 4)), None) == 0
+    assert api._resolve_nb(np.zeros((4, 4)), pkg.NB) == pkg.NB      # explicit blocked
     assert api._resolve_nb(np.zeros((4, 4)), 0) == 0                # explicit unblocked
     assert api._resolve_nb(np.zeros((4, 4), dtype=complex), None) == 0   # ComplexF64: unblocked
     assert api._resolve_nb(np.zeros((4, 4), dtype=complex), 0) == 0
