@@ -778,7 +778,11 @@ static int32_t factor_panel_sync(dhqr_ctx *c, double *P, int64_t rows, int64_t w
     CHECK(status_reset(c));
     c->n_fallback++;
   }
-  if (c->panel_impl >= 2) return factor_panel_v2(c, P, rows, w, ldp, alpha, pb);
+  // (r6: a panel the R-first path does not take -- fewer than 128 columns -- of 257 .. 4608 rows goes through the K-reflector
+  // passes of the unblocked path, ~w / 6 launches, instead of one launch per column: 2200 x 2000 5.34 -> 5.00 ms, 3000 x 300
+  // 1.04 -> 0.97; above that height the per-column kernels win again, 8192 x 1000 3.24 against 3.42: profiles/r06_mid_sizes.txt)
+  if (c->panel_impl >= 2 && !(c->partial_unblocked && rows > 256 && rows <= c->partial_unblocked_max_rows))
+    return factor_panel_v2(c, P, rows, w, ldp, alpha, pb);
   CHECK(factor_unblocked_cols(c, P, rows, w, ldp, alpha, CAT_PANEL));
   return panel_pack_and_t(c, P, rows, w, ldp, alpha, pb);
 }
@@ -1322,6 +1326,8 @@ int32_t dhqr_create(dhqr_ctx **out, int32_t device) {
     { long long v; if (tune_get("tn_min_tiles", &v)) c->tn_model_min_tiles = (int)v; }
     { long long v; if (tune_get("small_flags", &v)) c->small_flags = v != 0; }
     { long long v; if (tune_get("short_panel_small", &v)) c->short_panel_small = v != 0; }
+    { long long v; if (tune_get("partial_unblocked", &v)) c->partial_unblocked = v != 0; }
+    { long long v; if (tune_get("partial_unblocked_max_rows", &v)) c->partial_unblocked_max_rows = v; }
     { long long v; if (tune_get("small_spin_limit", &v)) c->small_spin_limit = (int)v; }
     { long long v; if (tune_get("tn2_rgroups", &v)) c->tn2_rgroups = (int)v; }
     { long long v; if (tune_get("tn2_rg8_rows", &v)) c->tn2_rg8_rows = v; }

@@ -117,6 +117,8 @@ struct dhqr_ctx {
   int64_t n_solve_retry = 0;  // solves repeated that way (dhqr_get_solve_retries)
   int gram_strips = 1;   // the panel chain's Gram products as four 32-row strips (gram128; DHQR_TUNE gram_strips=0: one tile)
   int small_spin_limit = 1 << 20;  // polls before a wait of the flag form gives up (dhqr_small.h: SMQ_SPIN_LIMIT)
+  int partial_unblocked = 1;  // a panel that is not R-first eligible, of 257 .. partial_unblocked_max_rows rows: the K-reflector passes (1) or one launch per column (0)
+  int64_t partial_unblocked_max_rows = 4608;
   int short_panel_small = 1;  // blocked drivers: a panel of at most 256 rows in ONE launch of the small route's kernel (factor_panel_v2)
   int small_flags = 1;   // small route above 128 rows: LDS flags instead of a barrier per column (dhqr_small.h)
   int tn2_rgroups = 1;   // row groups of a stream-K k_gemm_tn2 launch (dhqr_gemm.h: tn2_sk_group_of): 1 / 2 / 4 / 8, 0 = by height
