@@ -1167,7 +1167,9 @@ static int32_t small_wait_done(dhqr_ctx *c, unsigned long long *done, unsigned l
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned i = 1;; ++i) {
     if (__atomic_load_n(done, __ATOMIC_ACQUIRE) == epoch) return DHQR_OK;
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#endif
     if ((i & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
   }
   HIPCHECK(hipStreamSynchronize(c->stream));
