@@ -359,7 +359,8 @@ def test_pipelined_solve_kernels(emu, orc, m, n, env):
     assert np.abs(xs[0] - xs[1]).max() <= 1e-11 * np.abs(xo).max()
 
 
-# (every instantiation and its edges; the remaining shapes -- minutes on the emulator -- with DHQR_SLOW=1; the GPU suite runs all)
+# (every instantiation and its edges; the remaining shapes with DHQR_SLOW=1 -- ~15 s each on the emulator, so this is about
+# redundancy, not suite time: profiles/r06_pytest_cpu.txt has the durations; the GPU suite runs all of them)
 SMALL_SHAPES = [(1, 1), (5, 3), (111, 100), (128, 128), (130, 20), (224, 224), (256, 192)] + [
     pytest.param(m, n, marks=_SLOW) for m, n in ((33, 33), (64, 64), (220, 200), (224, 208), (256, 17), (129, 129))]
 
